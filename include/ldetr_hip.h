@@ -1,0 +1,157 @@
+/* layoutdetr_amd C ABI — hand-written HIP kernels for gfx950 (MI355X) behind plain pointers + sizes.
+ *
+ * All pointers are device pointers (HBM) unless noted; `stream` is a hipStream_t passed as void*.
+ * Every function returns 0 on success or a non-zero LDETR_ERR_* code; `ldetr_last_error()` returns
+ * the message (the Python host raises RuntimeError with it, mirroring TORCH_CHECK in the reference).
+ * Activations are fp32.  "NHWC" means pixels are rows and channels are contiguous.
+ *
+ * Which reference interface each entry point replaces (paths relative to salesforce/LayoutDETR):
+ *   ldetr_bias_act_f32            torch_utils/ops/bias_act.cpp:33-92  (bias_act_plugin.bias_act)
+ *   ldetr_upfirdn2d_f32           torch_utils/ops/upfirdn2d.cpp:17-99 (upfirdn2d_plugin.upfirdn2d)
+ *   ldetr_gemm_f32                ATen addmm/matmul behind nn.Linear: training/detr_transformer.py:187-189,
+ *                                 training/networks_detr.py:50-62, training/networks_stylegan2.py:117-123
+ *   ldetr_conv2d_*_f32            ATen conv2d + its autograd: training/detr_backbone.py:98-114 (torchvision
+ *                                 ResNet-50), networks_detr.py:82 (input_proj), ops/conv2d_resample.py:133-135
+ *   ldetr_conv_transpose2d_*_f32  ATen conv_transpose2d: torch_utils/ops/conv2d_resample.py:113-130
+ *   ldetr_attention_*_f32         nn.MultiheadAttention core: training/detr_transformer.py:208-209,273-274,277-280
+ *   ldetr_layernorm_*_f32         nn.LayerNorm + residual/dropout chain: training/detr_transformer.py:210-214,275-285
+ *   ldetr_act_bwd_reduce_f32      bias_act backward + dx.sum(): torch_utils/ops/bias_act.py:160-173
+ *   ldetr_mul_reduce_f32          `x * styles` / `x * dcoefs` backward: training/networks_stylegan2.py:66-72
+ *   ldetr_torgb_bwd_f32           ToRGBLayer backward: training/networks_stylegan2.py:349-353
+ *   ldetr_maxpool3x3s2_*_f32      torchvision ResNet stem max-pool (called via detr_backbone.py:105)
+ *   ldetr_grad_sanitize_f32, ldetr_adam_step_f32, ldetr_ema_lerp_f32
+ *                                 training/training_loop.py:303-313, 320-328
+ *   ldetr_lsap_f64                scipy.optimize.linear_sum_assignment as used at metrics/metric_layoutnet.py:111,125,240
+ */
+#ifndef LDETR_HIP_H
+#define LDETR_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Human-readable message of the last failing call on this thread. */
+const char* ldetr_last_error(void);
+/* ABI version; bumped whenever a signature changes. */
+int ldetr_abi_version(void);
+
+/* Strided 4-D activation view (sizes + element strides); sc == 1 selects the NHWC fast path. */
+typedef struct ldetr_tensor4 {
+    int N, C, H, W;
+    int64_t sn, sc, sh, sw;
+} ldetr_tensor4;
+
+/* Epilogue applied to every GEMM / conv output element (row m, column n), in this order:
+ *   v = acc * alpha
+ *   v *= col_scale[n]                      (FrozenBatchNorm scale)
+ *   v *= samp_scale[sample(m)][n]          (StyleGAN2 demodulation / style scale)
+ *   v += col_bias[n]
+ *   v += residual[m][n]
+ *   v = act(v)                             (1: relu, 2: leaky-relu(act_alpha) * act_gain)
+ *   v *= dact(mask_src[m][n])              (backward masks: 1 relu, 2 leaky-relu * act_gain)
+ *   v *= dropout_keep(seed, m*ldc + n)/(1-p_drop)
+ *   v *= out_scale
+ *   C[m][n] = v   (or += when accumulate != 0)
+ * NULL pointers / zero modes disable a step. */
+typedef struct ldetr_epilogue {
+    float alpha;
+    const float* col_scale;
+    const float* col_bias;
+    const float* samp_scale;
+    int64_t samp_ld;
+    const float* residual;
+    int64_t ldr;
+    int act;
+    float act_alpha;
+    float act_gain;
+    const float* mask_src;
+    int64_t ldm;
+    int mask_mode;
+    float out_scale;
+    float p_drop;
+    uint64_t seed;
+    int accumulate;
+} ldetr_epilogue;
+
+int ldetr_bias_act_f32(const float* x, const float* b, const float* xref, const float* yref, const float* dy, float* y,
+                       int64_t sizeX, int sizeB, int64_t stepB, int grad, int act, float alpha, float gain, float clamp,
+                       void* stream);
+
+int ldetr_upfirdn2d_f32(const float* x, const float* f, float* y, int N, int C, int inH, int inW,
+                        const int64_t* x_strides_nchw, int fh, int fw, int64_t f_stride_h, int64_t f_stride_w,
+                        int upx, int upy, int downx, int downy, int padx0, int padx1, int pady0, int pady1, int flip,
+                        float gain, int outH, int outW, const int64_t* y_strides_nchw,
+                        const float* act_bias, int has_act, float act_alpha, float act_gain, void* stream);
+
+int ldetr_gemm_f32(const float* A, int64_t lda, int ta, const float* B, int64_t ldb, int tb, float* C, int64_t ldc,
+                   int M, int N, int K, int splitk, const ldetr_epilogue* ep, int pix_per_sample, void* stream);
+
+int ldetr_conv2d_fwd_f32(const float* x, const ldetr_tensor4* xt, const float* w, int Cout, int KH, int KW, int stride,
+                         int pad, float* y, int64_t ldy, int OH, int OW, const float* in_scale, int64_t in_scale_ld,
+                         const ldetr_epilogue* ep, void* stream);
+int ldetr_conv2d_bwd_data_f32(const float* dy, const ldetr_tensor4* dyt, const float* w, int Cin, int KH, int KW,
+                              int stride, int pad, float* dx, int64_t lddx, int IH, int IW, const float* dy_scale,
+                              int64_t dy_scale_ld, const ldetr_epilogue* ep, void* stream);
+int ldetr_conv2d_bwd_weight_f32(const float* x, const ldetr_tensor4* xt, const float* dy, const ldetr_tensor4* dyt,
+                                float* dw, int KH, int KW, int stride, int pad, int splitk, const float* x_scale,
+                                int64_t x_scale_ld, const float* dy_scale, int64_t dy_scale_ld, void* stream);
+
+int ldetr_conv_transpose2d_fwd_f32(const float* x, const ldetr_tensor4* xt, const float* w, int Cout, int KH, int KW,
+                                   int stride, int pad, float* y, int64_t ldy, int OH, int OW, const float* in_scale,
+                                   int64_t in_scale_ld, const ldetr_epilogue* ep, void* stream);
+int ldetr_conv_transpose2d_bwd_data_f32(const float* dy, const ldetr_tensor4* dyt, const float* w, int Cin, int KH,
+                                        int KW, int stride, int pad, float* dx, int64_t lddx, int IH, int IW,
+                                        const float* dy_scale, int64_t dy_scale_ld, const ldetr_epilogue* ep,
+                                        void* stream);
+int ldetr_conv_transpose2d_bwd_weight_f32(const float* x, const ldetr_tensor4* xt, const float* dy,
+                                          const ldetr_tensor4* dyt, float* dw, int KH, int KW, int stride, int pad,
+                                          int splitk, const float* x_scale, int64_t x_scale_ld, const float* dy_scale,
+                                          int64_t dy_scale_ld, void* stream);
+
+int ldetr_attention_fwd_f32(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v, int64_t ldv,
+                            const unsigned char* key_padding_mask, float* out, int64_t ldo, float* lse, int B, int H,
+                            int Lq, int Lk, int head_dim, float scale, float p_drop, uint64_t seed, void* stream);
+int ldetr_attention_bwd_f32(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v, int64_t ldv,
+                            const unsigned char* key_padding_mask, const float* out, int64_t ldo, const float* lse,
+                            const float* dout, int64_t lddo, float* dq, int64_t lddq, float* dk, int64_t lddk,
+                            float* dv, int64_t lddv, int B, int H, int Lq, int Lk, int head_dim, float scale,
+                            float p_drop, uint64_t seed, void* stream);
+
+int ldetr_layernorm_fwd_f32(const float* x, const float* residual, const float* gamma, const float* beta, float* y,
+                            float* z, float* mean, float* rstd, int64_t rows, int D, float eps, float p_drop,
+                            uint64_t seed, void* stream);
+int ldetr_layernorm_bwd_f32(const float* dy, const float* z, const float* mean, const float* rstd, const float* gamma,
+                            float* dx, float* dresidual, float* dgamma, float* dbeta, int64_t rows, int D,
+                            float p_drop, uint64_t seed, void* stream);
+
+int ldetr_colsum_f32(const float* a, float* red, int B, int64_t P, int C, void* stream);
+int ldetr_act_bwd_reduce_f32(const float* dy, const float* y, float* dv, const float* bias, const float* demod,
+                             float* dbias, float* ddemod, int B, int64_t P, int C, int act, float alpha, float gain,
+                             void* stream);
+int ldetr_mul_reduce_f32(const float* a, const float* x, const float* scale, float* out, float* red, int B, int64_t P,
+                         int C, void* stream);
+int ldetr_torgb_bwd_f32(const float* x, const float* dy, const float* w, const float* styles, float* dx, float* dws,
+                        float* dbias, int B, int64_t P, int C, void* stream);
+
+int ldetr_maxpool3x3s2_fwd_f32(const float* x, float* y, unsigned char* idx, int N, int H, int W, int C, void* stream);
+int ldetr_maxpool3x3s2_bwd_f32(const float* dy, const unsigned char* idx, float* dx, int N, int H, int W, int C,
+                               void* stream);
+
+int ldetr_grad_sanitize_f32(float* g, int64_t n, float scale, float nan_value, float posinf, float neginf,
+                            void* stream);
+int ldetr_adam_step_f32(float* p, const float* g, float* m, float* v, int64_t n, int64_t step, float lr, float beta1,
+                        float beta2, float eps, int fuse_sanitize, float gscale, float nan_value, float posinf,
+                        float neginf, void* stream);
+int ldetr_ema_lerp_f32(float* p_ema, const float* p, int64_t n, float beta, void* stream);
+
+/* Batched linear-sum-assignment (Hungarian / shortest augmenting path) on device.
+ * cost: [batch][n][n] float64 row-major; maximize != 0 negates the costs first;
+ * row_ind / col_ind: [batch][n] int32 outputs with scipy's ordering (row_ind sorted ascending). n <= 16. */
+int ldetr_lsap_f64(const double* cost, int batch, int n, int maximize, int* row_ind, int* col_ind, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LDETR_HIP_H */

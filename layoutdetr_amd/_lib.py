@@ -1,0 +1,94 @@
+"""ctypes binding of the C-ABI kernel library (include/ldetr_hip.h).
+
+The product path has no CPU fallback: if `libldetr_hip.so` is missing or a symbol is absent the
+import of any op raises.  (The reference silently falls back to its `_ref` path only for non-CUDA
+tensors, torch_utils/ops/bias_act.py:85-87; here a non-GPU tensor is an error.)
+"""
+import ctypes
+import os
+from ctypes import (POINTER, Structure, c_char_p, c_double, c_float, c_int, c_int64, c_ubyte, c_uint64, c_void_p)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'lib', 'libldetr_hip.so')
+
+
+class Tensor4(Structure):
+    _fields_ = [('N', c_int), ('C', c_int), ('H', c_int), ('W', c_int),
+                ('sn', c_int64), ('sc', c_int64), ('sh', c_int64), ('sw', c_int64)]
+
+
+class Epilogue(Structure):
+    _fields_ = [('alpha', c_float), ('col_scale', c_void_p), ('col_bias', c_void_p), ('samp_scale', c_void_p),
+                ('samp_ld', c_int64), ('residual', c_void_p), ('ldr', c_int64), ('act', c_int),
+                ('act_alpha', c_float), ('act_gain', c_float), ('mask_src', c_void_p), ('ldm', c_int64),
+                ('mask_mode', c_int), ('out_scale', c_float), ('p_drop', c_float), ('seed', c_uint64),
+                ('accumulate', c_int)]
+
+
+_P = c_void_p
+_I = c_int
+_L = c_int64
+_F = c_float
+_T4 = POINTER(Tensor4)
+_EP = POINTER(Epilogue)
+
+# name -> argtypes; the list doubles as the "every declared symbol is exported" check in tests.
+SIGNATURES = {
+    'ldetr_bias_act_f32': [_P, _P, _P, _P, _P, _P, _L, _I, _L, _I, _I, _F, _F, _F, _P],
+    'ldetr_upfirdn2d_f32': [_P, _P, _P, _I, _I, _I, _I, POINTER(c_int64), _I, _I, _L, _L, _I, _I, _I, _I, _I, _I, _I, _I,
+                            _I, _F, _I, _I, POINTER(c_int64), _P, _I, _F, _F, _P],
+    'ldetr_gemm_f32': [_P, _L, _I, _P, _L, _I, _P, _L, _I, _I, _I, _I, _EP, _I, _P],
+    'ldetr_conv2d_fwd_f32': [_P, _T4, _P, _I, _I, _I, _I, _I, _P, _L, _I, _I, _P, _L, _EP, _P],
+    'ldetr_conv2d_bwd_data_f32': [_P, _T4, _P, _I, _I, _I, _I, _I, _P, _L, _I, _I, _P, _L, _EP, _P],
+    'ldetr_conv2d_bwd_weight_f32': [_P, _T4, _P, _T4, _P, _I, _I, _I, _I, _I, _P, _L, _P, _L, _P],
+    'ldetr_conv_transpose2d_fwd_f32': [_P, _T4, _P, _I, _I, _I, _I, _I, _P, _L, _I, _I, _P, _L, _EP, _P],
+    'ldetr_conv_transpose2d_bwd_data_f32': [_P, _T4, _P, _I, _I, _I, _I, _I, _P, _L, _I, _I, _P, _L, _EP, _P],
+    'ldetr_conv_transpose2d_bwd_weight_f32': [_P, _T4, _P, _T4, _P, _I, _I, _I, _I, _I, _P, _L, _P, _L, _P],
+    'ldetr_attention_fwd_f32': [_P, _L, _P, _L, _P, _L, _P, _P, _L, _P, _I, _I, _I, _I, _I, _F, _F, c_uint64, _P],
+    'ldetr_attention_bwd_f32': [_P, _L, _P, _L, _P, _L, _P, _P, _L, _P, _P, _L, _P, _L, _P, _L, _P, _L,
+                                _I, _I, _I, _I, _I, _F, _F, c_uint64, _P],
+    'ldetr_layernorm_fwd_f32': [_P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _F, _F, c_uint64, _P],
+    'ldetr_layernorm_bwd_f32': [_P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _F, c_uint64, _P],
+    'ldetr_colsum_f32': [_P, _P, _I, _L, _I, _P],
+    'ldetr_act_bwd_reduce_f32': [_P, _P, _P, _P, _P, _P, _P, _I, _L, _I, _I, _F, _F, _P],
+    'ldetr_mul_reduce_f32': [_P, _P, _P, _P, _P, _I, _L, _I, _P],
+    'ldetr_torgb_bwd_f32': [_P, _P, _P, _P, _P, _P, _P, _I, _L, _I, _P],
+    'ldetr_maxpool3x3s2_fwd_f32': [_P, _P, _P, _I, _I, _I, _I, _P],
+    'ldetr_maxpool3x3s2_bwd_f32': [_P, _P, _P, _I, _I, _I, _I, _P],
+    'ldetr_grad_sanitize_f32': [_P, _L, _F, _F, _F, _F, _P],
+    'ldetr_adam_step_f32': [_P, _P, _P, _P, _L, _L, _F, _F, _F, _F, _I, _F, _F, _F, _F, _P],
+    'ldetr_ema_lerp_f32': [_P, _P, _L, _F, _P],
+    'ldetr_lsap_f64': [_P, _I, _I, _I, _P, _P, _P],
+}
+
+_lib = None
+
+
+def load():
+    """Load the library (once).  Raises if it is missing: there is no fallback path."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f'{LIB_PATH} not found: build the gfx950 kernels first (python -m layoutdetr_amd.build or '
+            f'__graft_entry__.build()).  layoutdetr_amd has no CPU/PyTorch fallback path.')
+    lib = ctypes.CDLL(LIB_PATH)
+    lib.ldetr_last_error.restype = c_char_p
+    lib.ldetr_last_error.argtypes = []
+    lib.ldetr_abi_version.restype = c_int
+    lib.ldetr_abi_version.argtypes = []
+    for name, argtypes in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+        fn.restype = c_int
+        fn.argtypes = argtypes
+    if lib.ldetr_abi_version() != 1:
+        raise RuntimeError('libldetr_hip.so ABI version mismatch; rebuild it')
+    _lib = lib
+    return lib
+
+
+def check(rc, what=''):
+    if rc != 0:
+        msg = load().ldetr_last_error().decode('utf-8', 'replace')
+        raise RuntimeError(f'{what}: {msg}' if what else msg)

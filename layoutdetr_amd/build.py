@@ -1,0 +1,91 @@
+"""Ahead-of-time build of the gfx950 kernel library (no torch cpp_extension, no hipify pass).
+
+`python -m layoutdetr_amd.build` compiles every source under csrc/ with hipcc for gfx950 and links
+`layoutdetr_amd/lib/libldetr_hip.so`, a C-ABI shared library (see include/ldetr_hip.h).
+The reference builds its plugins lazily at first use (torch_utils/custom_ops.py:62-158); here the
+library is built in-tree so that it travels with the source tree and is visibly loaded.
+"""
+import hashlib
+import os
+import shutil
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, 'csrc')
+LIBDIR = os.path.join(HERE, 'lib')
+OBJDIR = os.path.join(LIBDIR, 'obj')
+LIBNAME = 'libldetr_hip.so'
+ARCH = 'gfx950'
+
+SOURCES = ['ldetr_core.cpp', 'bias_act.hip', 'upfirdn2d.hip', 'gemm_conv.hip', 'attention.hip', 'layernorm.hip',
+           'misc_ops.hip', 'optim.hip', 'lsap.hip']
+HEADERS = ['ldetr_common.hpp', os.path.join('..', '..', 'include', 'ldetr_hip.h')]
+
+FLAGS = ['-O3', '-std=c++17', '-fPIC', f'--offload-arch={ARCH}', '-munsafe-fp-atomics', '-fno-gpu-rdc',
+         '-Wno-unused-result']
+
+
+def _hipcc():
+    for cand in (os.environ.get('HIPCC'), shutil.which('hipcc'), '/opt/rocm/bin/hipcc'):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError('hipcc not found: the gfx950 kernel library cannot be built')
+
+
+def _digest(paths):
+    h = hashlib.sha256()
+    for p in paths:
+        with open(p, 'rb') as f:
+            h.update(f.read())
+    h.update(' '.join(FLAGS).encode())
+    return h.hexdigest()
+
+
+def lib_path():
+    return os.path.join(LIBDIR, LIBNAME)
+
+
+def build(force=False, verbose=True):
+    os.makedirs(OBJDIR, exist_ok=True)
+    hipcc = _hipcc()
+    hdrs = [os.path.normpath(os.path.join(CSRC, h)) for h in HEADERS]
+    objs, jobs = [], []
+    for src in SOURCES:
+        sp = os.path.join(CSRC, src)
+        obj = os.path.join(OBJDIR, src + '.o')
+        stamp = obj + '.sha'
+        dig = _digest([sp] + hdrs)
+        objs.append(obj)
+        if not force and os.path.exists(obj) and os.path.exists(stamp) and open(stamp).read() == dig:
+            continue
+        jobs.append((sp, obj, stamp, dig))
+
+    def compile_one(job):
+        sp, obj, stamp, dig = job
+        cmd = [hipcc] + FLAGS + ['-x', 'hip', '-c', sp, '-o', obj]
+        if verbose:
+            print('[ldetr build]', os.path.basename(sp), flush=True)
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f'hipcc failed for {sp}:\n{r.stdout}\n{r.stderr}')
+        with open(stamp, 'w') as f:
+            f.write(dig)
+
+    if jobs:
+        with ThreadPoolExecutor(max_workers=min(8, len(jobs))) as ex:
+            list(ex.map(compile_one, jobs))
+    out = lib_path()
+    if jobs or not os.path.exists(out):
+        cmd = [hipcc, '-shared', '-fPIC', f'--offload-arch={ARCH}', '-fno-gpu-rdc', '-o', out] + objs
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f'link failed:\n{r.stdout}\n{r.stderr}')
+        if verbose:
+            print('[ldetr build] linked', out, flush=True)
+    return out
+
+
+if __name__ == '__main__':
+    build(force='--force' in sys.argv)

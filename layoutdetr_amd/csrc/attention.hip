@@ -1,0 +1,323 @@
+// Fused multi-head attention (scaled QK^T + key-padding mask + softmax + dropout + PV), forward
+// and backward, for the DETR shapes of LayoutDETR: head_dim 32, Lq <= 256, Lk <= 256.
+// Replaces the attention core of nn.MultiheadAttention as called at
+// training/detr_transformer.py:208-209 (encoder self), :273-274 (decoder self), :277-280 (decoder cross)
+// and by nn.TransformerEncoderLayer in training/util.py:21-26 / networks_detr.py:242-243.
+//
+// Design: one 64-lane wave per (batch, head, 16-row tile).  Scores are produced *transposed*
+// (S^T = K Q^T) with v_mfma_f32_16x16x4_f32, so a lane holds 4 keys x 1 query per key tile and the
+// whole score row lives in registers.  Because the reduction order over keys is free, the C-layout
+// registers of S^T feed the P.V product directly as the MFMA B operand (lane group g, register t
+// <-> key 16j + 4g + t): no LDS round trip, no transposes, no score matrix in HBM.
+// The backward pass recomputes probabilities from the saved log-sum-exp.
+#include "ldetr_common.hpp"
+#include "../../include/ldetr_hip.h"
+
+namespace ldetr {
+
+struct AttnParams {
+    const float* q; const float* k; const float* v;
+    long ldq, ldk, ldv;
+    const unsigned char* kpm;  // [B][Lk], nonzero = masked key
+    float* o; long ldo;
+    float* lse;  // [B][H][Lq]
+    const float* dout; long lddo;
+    float* dq; long lddq;
+    float* dk; long lddk;
+    float* dv; long lddv;
+    int B, H, Lq, Lk;
+    float scale, p_drop;
+    unsigned long long seed;
+};
+
+#define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+
+__device__ __forceinline__ float ldz(const float* p, bool ok) { return ok ? *p : 0.f; }
+
+// Dropout element index: ((b*H + h)*Lq + q)*Lk + key.
+__device__ __forceinline__ float attn_drop(const AttnParams& p, int bh, int q, int key, float inv_keep) {
+    return drop_scale(p.seed, ((uint64_t)bh * p.Lq + q) * p.Lk + key, p.p_drop, inv_keep);
+}
+
+template <int NKT>
+__global__ __launch_bounds__(64) void attn_fwd_kernel(AttnParams p) {
+    const int nqt = (p.Lq + 15) >> 4;
+    const int qt = blockIdx.x % nqt;
+    const int bh = blockIdx.x / nqt;
+    const int b = bh / p.H, h = bh - b * p.H;
+    const int lane = threadIdx.x, li = lane & 15, g = lane >> 4;
+    const int q0 = qt << 4;
+    const int qrow = q0 + li;
+    const bool qok = qrow < p.Lq;
+    const float* qp = p.q + ((long)b * p.Lq + qrow) * p.ldq + h * 32;
+    const float* kb = p.k + (long)b * p.Lk * p.ldk + h * 32;
+    const float* vb = p.v + (long)b * p.Lk * p.ldv + h * 32;
+    const unsigned char* kpm = p.kpm ? p.kpm + (long)b * p.Lk : nullptr;
+
+    float qf[8];
+#pragma unroll
+    for (int kk = 0; kk < 8; kk++) qf[kk] = ldz(qp + 4 * kk + g, qok) * p.scale;
+
+    f32x4 s[NKT];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < NKT; j++) {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        const int krow = 16 * j + li;
+        const bool kok = krow < p.Lk;
+        const float* kp = kb + (long)krow * p.ldk;
+#pragma unroll
+        for (int kk = 0; kk < 8; kk++) acc = MFMA16(ldz(kp + 4 * kk + g, kok), qf[kk], acc);
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            int key = 16 * j + 4 * g + r;
+            bool masked = (key >= p.Lk) || (kpm && kpm[key]);
+            acc[r] = masked ? -INFINITY : acc[r];
+            mx = fmaxf(mx, acc[r]);
+        }
+        s[j] = acc;
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    float sum = 0.f;
+#pragma unroll
+    for (int j = 0; j < NKT; j++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) { float e = expf(s[j][r] - mx); s[j][r] = e; sum += e; }
+    sum += __shfl_xor(sum, 16, 64);
+    sum += __shfl_xor(sum, 32, 64);
+    const float inv = 1.f / sum;
+    if (p.lse && g == 0 && qok) p.lse[(long)bh * p.Lq + qrow] = mx + logf(sum);
+    const float inv_keep = p.p_drop > 0.f ? 1.f / (1.f - p.p_drop) : 1.f;
+
+    f32x4 o0 = {0.f, 0.f, 0.f, 0.f}, o1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < NKT; j++) {
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+            const int key = 16 * j + 4 * g + t;
+            const bool kok = key < p.Lk;
+            float pv = s[j][t] * inv;
+            if (p.p_drop > 0.f) pv *= attn_drop(p, bh, qrow, key, inv_keep);
+            const float* vp = vb + (long)key * p.ldv;
+            o0 = MFMA16(ldz(vp + li, kok), pv, o0);
+            o1 = MFMA16(ldz(vp + 16 + li, kok), pv, o1);
+        }
+    }
+    if (qok) {
+        float* op = p.o + ((long)b * p.Lq + qrow) * p.ldo + h * 32 + 4 * g;
+        *reinterpret_cast<float4*>(op) = make_float4(o0[0], o0[1], o0[2], o0[3]);
+        *reinterpret_cast<float4*>(op + 16) = make_float4(o1[0], o1[1], o1[2], o1[3]);
+    }
+}
+
+// Backward, query-major half: dQ for one 16-query tile.
+template <int NKT>
+__device__ __forceinline__ void attn_bwd_dq(const AttnParams& p, int bh, int qt) {
+    const int b = bh / p.H, h = bh - b * p.H;
+    const int lane = threadIdx.x, li = lane & 15, g = lane >> 4;
+    const int qrow = (qt << 4) + li;
+    const bool qok = qrow < p.Lq;
+    const float* qp = p.q + ((long)b * p.Lq + qrow) * p.ldq + h * 32;
+    const float* dop = p.dout + ((long)b * p.Lq + qrow) * p.lddo + h * 32;
+    const float* op = p.o + ((long)b * p.Lq + qrow) * p.ldo + h * 32;
+    const float* kb = p.k + (long)b * p.Lk * p.ldk + h * 32;
+    const float* vb = p.v + (long)b * p.Lk * p.ldv + h * 32;
+    const unsigned char* kpm = p.kpm ? p.kpm + (long)b * p.Lk : nullptr;
+    const float inv_keep = p.p_drop > 0.f ? 1.f / (1.f - p.p_drop) : 1.f;
+
+    float qf[8], dof[8];
+    float delta = 0.f;
+#pragma unroll
+    for (int kk = 0; kk < 8; kk++) {
+        qf[kk] = ldz(qp + 4 * kk + g, qok) * p.scale;
+        dof[kk] = ldz(dop + 4 * kk + g, qok);
+        delta += dof[kk] * ldz(op + 4 * kk + g, qok);
+    }
+    delta += __shfl_xor(delta, 16, 64);
+    delta += __shfl_xor(delta, 32, 64);
+    const float lse = qok ? p.lse[(long)bh * p.Lq + qrow] : 0.f;
+
+    f32x4 dq0 = {0.f, 0.f, 0.f, 0.f}, dq1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < NKT; j++) {
+        f32x4 sacc = {0.f, 0.f, 0.f, 0.f}, dpacc = {0.f, 0.f, 0.f, 0.f};
+        const int krow = 16 * j + li;
+        const bool kok = krow < p.Lk;
+        const float* kp = kb + (long)krow * p.ldk;
+        const float* vp = vb + (long)krow * p.ldv;
+#pragma unroll
+        for (int kk = 0; kk < 8; kk++) {
+            sacc = MFMA16(ldz(kp + 4 * kk + g, kok), qf[kk], sacc);
+            dpacc = MFMA16(ldz(vp + 4 * kk + g, kok), dof[kk], dpacc);
+        }
+        f32x4 ds;
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            int key = 16 * j + 4 * g + r;
+            bool masked = (key >= p.Lk) || (kpm && kpm[key]);
+            float pr = masked ? 0.f : expf(sacc[r] - lse);
+            float dpv = dpacc[r];
+            if (p.p_drop > 0.f) dpv *= attn_drop(p, bh, qrow, key, inv_keep);
+            ds[r] = pr * (dpv - delta) * p.scale;
+        }
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+            const int key = 16 * j + 4 * g + t;
+            const bool k2 = key < p.Lk;
+            const float* kp2 = kb + (long)key * p.ldk;
+            dq0 = MFMA16(ldz(kp2 + li, k2), ds[t], dq0);
+            dq1 = MFMA16(ldz(kp2 + 16 + li, k2), ds[t], dq1);
+        }
+    }
+    if (qok) {
+        float* dqp = p.dq + ((long)b * p.Lq + qrow) * p.lddq + h * 32 + 4 * g;
+        *reinterpret_cast<float4*>(dqp) = make_float4(dq0[0], dq0[1], dq0[2], dq0[3]);
+        *reinterpret_cast<float4*>(dqp + 16) = make_float4(dq1[0], dq1[1], dq1[2], dq1[3]);
+    }
+}
+
+// Backward, key-major half: dK and dV for one 16-key tile; loops over query tiles.
+__device__ __forceinline__ void attn_bwd_dkv(const AttnParams& p, int bh, int kt) {
+    const int b = bh / p.H, h = bh - b * p.H;
+    const int lane = threadIdx.x, li = lane & 15, g = lane >> 4;
+    const int krow = (kt << 4) + li;
+    const bool kok = krow < p.Lk;
+    const float* kp = p.k + ((long)b * p.Lk + krow) * p.ldk + h * 32;
+    const float* vp = p.v + ((long)b * p.Lk + krow) * p.ldv + h * 32;
+    const unsigned char* kpm = p.kpm ? p.kpm + (long)b * p.Lk : nullptr;
+    const bool kmasked = !kok || (kpm && kpm[krow]);
+    const float inv_keep = p.p_drop > 0.f ? 1.f / (1.f - p.p_drop) : 1.f;
+    // B operands (k = d, j = key): K^T and V^T fragments, loaded once.
+    float kf[8], vf[8];
+#pragma unroll
+    for (int kk = 0; kk < 8; kk++) { kf[kk] = ldz(kp + 4 * kk + g, kok); vf[kk] = ldz(vp + 4 * kk + g, kok); }
+
+    f32x4 dk0 = {0.f, 0.f, 0.f, 0.f}, dk1 = dk0, dv0 = dk0, dv1 = dk0;
+    const int nqt = (p.Lq + 15) >> 4;
+    for (int jq = 0; jq < nqt; jq++) {
+        // A operands (i = query, k = d)
+        const int qa = 16 * jq + li;
+        const bool qaok = qa < p.Lq;
+        const float* qp = p.q + ((long)b * p.Lq + qa) * p.ldq + h * 32;
+        const float* dop = p.dout + ((long)b * p.Lq + qa) * p.lddo + h * 32;
+        f32x4 sacc = {0.f, 0.f, 0.f, 0.f}, dpacc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kk = 0; kk < 8; kk++) {
+            sacc = MFMA16(ldz(qp + 4 * kk + g, qaok) * p.scale, kf[kk], sacc);
+            dpacc = MFMA16(ldz(dop + 4 * kk + g, qaok), vf[kk], dpacc);
+        }
+        // C layout: row = query 16jq + 4g + r, col = key li.
+        float pd[4], ds[4];
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int qr = 16 * jq + 4 * g + r;
+            const bool qok = qr < p.Lq;
+            // delta[qr] = sum_d O*dO over 32 dims: 16 lanes of the group each take 2 dims.
+            const float* o_r = p.o + ((long)b * p.Lq + qr) * p.ldo + h * 32;
+            const float* do_r = p.dout + ((long)b * p.Lq + qr) * p.lddo + h * 32;
+            float part = ldz(o_r + li, qok) * ldz(do_r + li, qok) + ldz(o_r + 16 + li, qok) * ldz(do_r + 16 + li, qok);
+            part += __shfl_xor(part, 1, 64); part += __shfl_xor(part, 2, 64);
+            part += __shfl_xor(part, 4, 64); part += __shfl_xor(part, 8, 64);
+            const float lse = qok ? p.lse[(long)bh * p.Lq + qr] : 0.f;
+            float pr = (kmasked || !qok) ? 0.f : expf(sacc[r] - lse);
+            float dm = 1.f;
+            if (p.p_drop > 0.f) dm = attn_drop(p, bh, qr, krow, inv_keep);
+            pd[r] = pr * dm;
+            ds[r] = pr * (dpacc[r] * dm - part) * p.scale;
+        }
+        // dV^T[d][key] += sum_q dO^T[d][q] * Pdrop[q][key];  dK^T[d][key] += sum_q Q^T[d][q] * dS[q][key]
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+            const int qr = 16 * jq + 4 * g + t;
+            const bool qok = qr < p.Lq;
+            const float* q_r = p.q + ((long)b * p.Lq + qr) * p.ldq + h * 32;
+            const float* do_r = p.dout + ((long)b * p.Lq + qr) * p.lddo + h * 32;
+            dv0 = MFMA16(ldz(do_r + li, qok), pd[t], dv0);
+            dv1 = MFMA16(ldz(do_r + 16 + li, qok), pd[t], dv1);
+            dk0 = MFMA16(ldz(q_r + li, qok), ds[t], dk0);
+            dk1 = MFMA16(ldz(q_r + 16 + li, qok), ds[t], dk1);
+        }
+    }
+    if (kok) {
+        float* dkp = p.dk + ((long)b * p.Lk + krow) * p.lddk + h * 32 + 4 * g;
+        float* dvp = p.dv + ((long)b * p.Lk + krow) * p.lddv + h * 32 + 4 * g;
+        *reinterpret_cast<float4*>(dkp) = make_float4(dk0[0], dk0[1], dk0[2], dk0[3]);
+        *reinterpret_cast<float4*>(dkp + 16) = make_float4(dk1[0], dk1[1], dk1[2], dk1[3]);
+        *reinterpret_cast<float4*>(dvp) = make_float4(dv0[0], dv0[1], dv0[2], dv0[3]);
+        *reinterpret_cast<float4*>(dvp + 16) = make_float4(dv1[0], dv1[1], dv1[2], dv1[3]);
+    }
+}
+
+template <int NKT>
+__global__ __launch_bounds__(64) void attn_bwd_kernel(AttnParams p) {
+    const int nqt = (p.Lq + 15) >> 4, nkt = (p.Lk + 15) >> 4;
+    const int per = nqt + nkt;
+    const int bh = blockIdx.x / per;
+    const int w = blockIdx.x - bh * per;
+    if (w < nqt) attn_bwd_dq<NKT>(p, bh, w);
+    else attn_bwd_dkv(p, bh, w - nqt);
+}
+
+static int check_attn(const AttnParams& p, const char* what) {
+    LDETR_CHECK(p.q && p.k && p.v && p.o, "%s: null pointer", what);
+    LDETR_CHECK(p.B > 0 && p.H > 0 && p.Lq > 0 && p.Lk > 0, "%s: empty problem", what);
+    LDETR_CHECK(p.Lk <= 256, "%s: Lk > 256 is unsupported", what);
+    LDETR_CHECK(p.p_drop >= 0.f && p.p_drop < 1.f, "%s: dropout must be in [0,1)", what);
+    LDETR_CHECK((p.ldo % 4) == 0 && ((uintptr_t)p.o & 15) == 0, "%s: output must be 16-byte aligned", what);
+    return LDETR_OK;
+}
+
+}  // namespace ldetr
+
+using namespace ldetr;
+
+extern "C" int ldetr_attention_fwd_f32(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v, int64_t ldv,
+                                       const unsigned char* key_padding_mask, float* out, int64_t ldo, float* lse,
+                                       int B, int H, int Lq, int Lk, int head_dim, float scale,
+                                       float p_drop, uint64_t seed, void* stream) {
+    LDETR_CHECK(head_dim == 32, "attention: head_dim must be 32 (got %d)", head_dim);
+    AttnParams p; memset(&p, 0, sizeof(p));
+    p.q = q; p.k = k; p.v = v; p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.kpm = key_padding_mask;
+    p.o = out; p.ldo = ldo; p.lse = lse; p.B = B; p.H = H; p.Lq = Lq; p.Lk = Lk;
+    p.scale = scale; p.p_drop = p_drop; p.seed = seed;
+    int rc = check_attn(p, "attention_fwd");
+    if (rc) return rc;
+    const int nqt = (Lq + 15) / 16, nkt = (Lk + 15) / 16;
+    const int grid = B * H * nqt;
+    hipStream_t st = (hipStream_t)stream;
+    if (nkt <= 1) hipLaunchKernelGGL(attn_fwd_kernel<1>, grid, 64, 0, st, p);
+    else if (nkt <= 2) hipLaunchKernelGGL(attn_fwd_kernel<2>, grid, 64, 0, st, p);
+    else if (nkt <= 4) hipLaunchKernelGGL(attn_fwd_kernel<4>, grid, 64, 0, st, p);
+    else if (nkt <= 8) hipLaunchKernelGGL(attn_fwd_kernel<8>, grid, 64, 0, st, p);
+    else hipLaunchKernelGGL(attn_fwd_kernel<16>, grid, 64, 0, st, p);
+    return check_launch("attention_fwd");
+}
+
+extern "C" int ldetr_attention_bwd_f32(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v, int64_t ldv,
+                                       const unsigned char* key_padding_mask, const float* out, int64_t ldo, const float* lse,
+                                       const float* dout, int64_t lddo,
+                                       float* dq, int64_t lddq, float* dk, int64_t lddk, float* dv, int64_t lddv,
+                                       int B, int H, int Lq, int Lk, int head_dim, float scale,
+                                       float p_drop, uint64_t seed, void* stream) {
+    LDETR_CHECK(head_dim == 32, "attention: head_dim must be 32 (got %d)", head_dim);
+    LDETR_CHECK(lse && dout && dq && dk && dv, "attention_bwd: null pointer");
+    AttnParams p; memset(&p, 0, sizeof(p));
+    p.q = q; p.k = k; p.v = v; p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.kpm = key_padding_mask;
+    p.o = const_cast<float*>(out); p.ldo = ldo; p.lse = const_cast<float*>(lse);
+    p.dout = dout; p.lddo = lddo; p.dq = dq; p.lddq = lddq; p.dk = dk; p.lddk = lddk; p.dv = dv; p.lddv = lddv;
+    p.B = B; p.H = H; p.Lq = Lq; p.Lk = Lk; p.scale = scale; p.p_drop = p_drop; p.seed = seed;
+    int rc = check_attn(p, "attention_bwd");
+    if (rc) return rc;
+    LDETR_CHECK((lddq % 4) == 0 && (lddk % 4) == 0 && (lddv % 4) == 0 &&
+                (((uintptr_t)dq | (uintptr_t)dk | (uintptr_t)dv) & 15) == 0, "attention_bwd: gradients must be 16-byte aligned");
+    const int nqt = (Lq + 15) / 16, nkt = (Lk + 15) / 16;
+    const int grid = B * H * (nqt + nkt);
+    hipStream_t st = (hipStream_t)stream;
+    if (nkt <= 1) hipLaunchKernelGGL(attn_bwd_kernel<1>, grid, 64, 0, st, p);
+    else if (nkt <= 2) hipLaunchKernelGGL(attn_bwd_kernel<2>, grid, 64, 0, st, p);
+    else if (nkt <= 4) hipLaunchKernelGGL(attn_bwd_kernel<4>, grid, 64, 0, st, p);
+    else if (nkt <= 8) hipLaunchKernelGGL(attn_bwd_kernel<8>, grid, 64, 0, st, p);
+    else hipLaunchKernelGGL(attn_bwd_kernel<16>, grid, 64, 0, st, p);
+    return check_launch("attention_bwd");
+}

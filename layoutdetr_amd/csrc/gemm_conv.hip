@@ -1,0 +1,715 @@
+// Exact-f32 MFMA contraction engine for gfx950: dense GEMMs and implicit-GEMM convolutions.
+//
+// One kernel template covers every dense contraction on the hot path:
+//   * nn.Linear fwd / dX / dW                      (training/detr_transformer.py:187-189, networks_detr.py:50-62)
+//   * ResNet-50 conv fwd / bwd-data / bwd-weight    (training/detr_backbone.py:98-114; ATen conv2d in the reference)
+//   * StyleGAN2 modulated conv, transposed conv     (training/networks_stylegan2.py:30-75, ops/conv2d_resample.py:113-135)
+// C[m, n] = sum_k A(m, k) * B(k, n), where A and B are *operand views*: dense row-major / col-major
+// matrices, or NHWC gathers (im2col is never materialised).  All activations are NHWC
+// (channels_last) so the reduction index (tap, channel) is contiguous along channels.
+//
+// Arithmetic: v_mfma_f32_32x32x2_f32 — exact fp32 products and accumulation (the reference step is
+// fp32 end-to-end with TF32 disabled, training/training_loop.py:104-105).  Peak 157 TFLOP/s.
+// Tiling: 256 threads = 4 waves (2x2); block tile BMxBN in {128x128, 64x64}, BK = 16; LDS tiles are
+// k-major ([k][row], row stride R+2 -> conflict-free MFMA operand reads and transposing writes),
+// double-buffered with register staging (global loads for tile t+1 are in flight during the
+// MFMAs of tile t; one barrier per k-tile).
+#include "ldetr_common.hpp"
+#include "../../include/ldetr_hip.h"
+
+namespace ldetr {
+
+enum {
+    OP_KC_DENSE = 0,  // (row r, k): src[r*ld + k]
+    OP_KC_CONV = 1,   // row = dst pixel, k = (tap, c): src pixel = dst*stride - pad + tap
+    OP_KC_CONVT = 2,  // row = dst pixel of a parity class, k = (tap', c): src pixel = (dst + pad - tap)/stride
+    OP_KC_WTAP = 3,   // row = out channel, k = (tap', c) with tap remap: src[r*ld + tap*C + c]
+    OP_RC_DENSE = 4,  // (k, row r): src[k*ld + r]
+    OP_RC_PIX = 5,    // k = pixel gathered with one fixed tap, r = channel
+    OP_RC_WT = 6,     // k = (tap', co): src[co*ld + tap*Cr + r]
+    OP_RC_CONVK = 7,  // k = dst pixel, r = (tap, c) scalar gather (3-channel stem weight gradient)
+};
+
+struct Operand {
+    const float* p;
+    long ld;
+    int vec;  // 1: float4 loads are legal (alignment + divisibility checked on the host)
+    // gather geometry
+    int SH, SW;              // source spatial dims
+    long sn, sh, sw, sc;     // source strides (elements) for sample / y / x / channel
+    int DH, DW;              // destination pixel grid (full grid; parity classes subdivide it)
+    int C;                   // channels enumerated by k (KC modes) or the k-channel count (RC_WT)
+    int Cr;                  // RC_WT: inner channel count (tap stride in the weight row)
+    int stride, pad;
+    int KH, KW;
+    const float* scale;      // optional per-sample per-channel scale [nsamp][scale_ld]
+    long scale_ld;
+    int tapped;              // RC_PIX: 1 if this operand takes the per-z tap offset, else centre (dense)
+};
+
+struct GemmEpilogue {
+    float alpha;
+    const float* col_scale;
+    const float* col_bias;
+    const float* samp_scale;
+    long samp_ld;
+    const float* residual;
+    long ldr;
+    int act;  // 0 none, 1 relu, 2 lrelu
+    float act_alpha, act_gain;
+    const float* mask_src;  // backward: multiply by d(act)/d(pre) reconstructed from the saved output
+    long ldm;
+    int mask_mode;  // 0 none, 1 relu (src > 0), 2 lrelu (src > 0 ? gain : gain*alpha)
+    float out_scale;
+    float p_drop;
+    unsigned long long seed;
+    int accumulate;
+};
+
+struct GemmParams {
+    Operand A, B;
+    int M, N, K;  // for zmode 1 these are recomputed per parity class
+    float* C;
+    long ldc;
+    int zmode;   // 0: z = split-K slice; 1: z = parity class; 2: z = tap + ntaps * split-K slice
+    int splitk;  // number of K slices (atomicAdd output when > 1)
+    int pstep;   // parity step (= conv stride) for zmode 1
+    int nsamp;
+    int pix_per_sample;  // rows per sample in the *full* destination grid (epilogue + scale lookups)
+    int ntaps;           // zmode 2
+    long c_tap_stride;   // zmode 2: column offset per tap in C
+    GemmEpilogue ep;
+};
+
+#define BK 16
+
+struct TapMap {
+    int kh0, kw0, tstep, nty, ntx;
+};
+
+struct ZCtx {
+    int M, K, kbeg, kend;
+    int py, px, DH2, DW2;
+    TapMap tm;
+    int fkh, fkw;
+    long c_off;
+};
+
+__device__ __forceinline__ void decode_tap(const TapMap& tm, int t, int& kh, int& kw) {
+    int ty = t / tm.ntx;
+    int tx = t - ty * tm.ntx;
+    kh = tm.kh0 + tm.tstep * ty;
+    kw = tm.kw0 + tm.tstep * tx;
+}
+
+struct RowCtx {  // per-thread cached decode of a KC gather row (a destination pixel)
+    long base;
+    int y, x, samp, valid;
+};
+
+template <int MODE>
+__device__ __forceinline__ RowCtx make_row(const Operand& o, const GemmParams& p, const ZCtx& z, int r, int R) {
+    RowCtx rc;
+    rc.valid = r < R;
+    rc.base = 0; rc.y = 0; rc.x = 0; rc.samp = 0;
+    if (MODE == OP_KC_CONV) {
+        int per = o.DH * o.DW;
+        int n = r / per; int rem = r - n * per;
+        int y = rem / o.DW; int x = rem - y * o.DW;
+        rc.samp = n; rc.base = (long)n * o.sn;
+        rc.y = y * o.stride - o.pad; rc.x = x * o.stride - o.pad;
+    } else if (MODE == OP_KC_CONVT) {
+        int per = z.DH2 * z.DW2;
+        int n = per > 0 ? r / per : 0; int rem = r - n * per;
+        int y2 = z.DW2 > 0 ? rem / z.DW2 : 0; int x2 = rem - y2 * z.DW2;
+        rc.samp = n; rc.base = (long)n * o.sn;
+        rc.y = y2 * p.pstep + z.py + o.pad; rc.x = x2 * p.pstep + z.px + o.pad;
+    } else {
+        rc.base = (long)r * o.ld;
+    }
+    return rc;
+}
+
+// Load 4 consecutive k values (k .. k+3) of one row for a k-contiguous operand.
+template <int MODE>
+__device__ __forceinline__ float4 load_kc(const Operand& o, const ZCtx& z, const RowCtx& rc, int k) {
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (!rc.valid || k >= z.kend) return v;
+    if (MODE == OP_KC_DENSE) {
+        const float* s = o.p + rc.base + k;
+        if (o.vec) return *reinterpret_cast<const float4*>(s);
+        v.x = s[0];
+        if (k + 1 < z.kend) v.y = s[1];
+        if (k + 2 < z.kend) v.z = s[2];
+        if (k + 3 < z.kend) v.w = s[3];
+        return v;
+    }
+    if (MODE == OP_KC_WTAP) {
+        int t = k / o.C; int c = k - t * o.C;
+        int kh, kw; decode_tap(z.tm, t, kh, kw);
+        return *reinterpret_cast<const float4*>(o.p + rc.base + (long)(kh * o.KW + kw) * o.C + c);
+    }
+    // gather modes
+    if (o.vec) {
+        int t = k / o.C; int c = k - t * o.C;
+        int kh, kw; decode_tap(z.tm, t, kh, kw);
+        int sy, sx; bool ok;
+        if (MODE == OP_KC_CONV) {
+            sy = rc.y + kh; sx = rc.x + kw;
+            ok = (sy >= 0) & (sy < o.SH) & (sx >= 0) & (sx < o.SW);
+        } else {
+            int ny = rc.y - kh, nx = rc.x - kw;
+            sy = ny / o.stride; sx = nx / o.stride;
+            ok = (ny >= 0) & (nx >= 0) & (sy < o.SH) & (sx < o.SW);
+        }
+        if (!ok) return v;
+        v = *reinterpret_cast<const float4*>(o.p + rc.base + (long)sy * o.sh + (long)sx * o.sw + c);
+        if (o.scale) {
+            float4 s = *reinterpret_cast<const float4*>(o.scale + (long)rc.samp * o.scale_ld + c);
+            v.x *= s.x; v.y *= s.y; v.z *= s.z; v.w *= s.w;
+        }
+        return v;
+    }
+    float e[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        int kk = k + j;
+        if (kk >= z.kend) break;
+        int t = kk / o.C; int c = kk - t * o.C;
+        int kh, kw; decode_tap(z.tm, t, kh, kw);
+        int sy, sx; bool ok;
+        if (MODE == OP_KC_CONV) {
+            sy = rc.y + kh; sx = rc.x + kw;
+            ok = (sy >= 0) & (sy < o.SH) & (sx >= 0) & (sx < o.SW);
+        } else {
+            int ny = rc.y - kh, nx = rc.x - kw;
+            sy = ny / o.stride; sx = nx / o.stride;
+            ok = (ny >= 0) & (nx >= 0) & (sy < o.SH) & (sx < o.SW);
+        }
+        if (ok) {
+            float val = o.p[rc.base + (long)sy * o.sh + (long)sx * o.sw + (long)c * o.sc];
+            if (o.scale) val *= o.scale[(long)rc.samp * o.scale_ld + c];
+            e[j] = val;
+        }
+    }
+    return make_float4(e[0], e[1], e[2], e[3]);
+}
+
+// Load 4 consecutive row values (r .. r+3) at reduction index k for a row-contiguous operand.
+template <int MODE>
+__device__ __forceinline__ float4 load_rc(const Operand& o, const GemmParams& p, const ZCtx& z, int k, int r, int R) {
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (k >= z.kend || r >= R) return v;
+    if (MODE == OP_RC_DENSE) {
+        const float* s = o.p + (long)k * o.ld + r;
+        if (o.vec) return *reinterpret_cast<const float4*>(s);
+        v.x = s[0];
+        if (r + 1 < R) v.y = s[1];
+        if (r + 2 < R) v.z = s[2];
+        if (r + 3 < R) v.w = s[3];
+        return v;
+    }
+    if (MODE == OP_RC_WT) {
+        int t = k / o.C; int co = k - t * o.C;
+        int kh, kw; decode_tap(z.tm, t, kh, kw);
+        const float* s = o.p + (long)co * o.ld + (long)(kh * o.KW + kw) * o.Cr + r;
+        if (o.vec) return *reinterpret_cast<const float4*>(s);
+        v.x = s[0];
+        if (r + 1 < R) v.y = s[1];
+        if (r + 2 < R) v.z = s[2];
+        if (r + 3 < R) v.w = s[3];
+        return v;
+    }
+    if (MODE == OP_RC_PIX) {
+        int per = o.DH * o.DW;
+        int n = k / per; int rem = k - n * per;
+        int y = rem / o.DW; int x = rem - y * o.DW;
+        int sy = y * o.stride - o.pad + (o.tapped ? z.fkh : o.pad);
+        int sx = x * o.stride - o.pad + (o.tapped ? z.fkw : o.pad);
+        if (!o.tapped) { sy = y; sx = x; }
+        if ((sy < 0) | (sy >= o.SH) | (sx < 0) | (sx >= o.SW)) return v;
+        const float* s = o.p + (long)n * o.sn + (long)sy * o.sh + (long)sx * o.sw + r;
+        if (o.vec) {
+            v = *reinterpret_cast<const float4*>(s);
+        } else {
+            v.x = s[0];
+            if (r + 1 < R) v.y = s[1];
+            if (r + 2 < R) v.z = s[2];
+            if (r + 3 < R) v.w = s[3];
+        }
+        if (o.scale) {
+            const float* sc = o.scale + (long)n * o.scale_ld + r;
+            v.x *= sc[0];
+            if (r + 1 < R) v.y *= sc[1];
+            if (r + 2 < R) v.z *= sc[2];
+            if (r + 3 < R) v.w *= sc[3];
+        }
+        return v;
+    }
+    // OP_RC_CONVK: k = destination pixel, r = (tap, c) natural order, scalar gather
+    {
+        int per = o.DH * o.DW;
+        int n = k / per; int rem = k - n * per;
+        int y = rem / o.DW; int x = rem - y * o.DW;
+        float e[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            int rr = r + j;
+            if (rr >= R) break;
+            int t = rr / o.C; int c = rr - t * o.C;
+            int kh = t / o.KW; int kw = t - kh * o.KW;
+            int sy = y * o.stride - o.pad + kh, sx = x * o.stride - o.pad + kw;
+            if ((sy >= 0) & (sy < o.SH) & (sx >= 0) & (sx < o.SW))
+                e[j] = o.p[(long)n * o.sn + (long)sy * o.sh + (long)sx * o.sw + (long)c * o.sc];
+        }
+        return make_float4(e[0], e[1], e[2], e[3]);
+    }
+}
+
+__device__ __forceinline__ ZCtx make_zctx(const GemmParams& p) {
+    ZCtx z;
+    z.M = p.M; z.K = p.K; z.py = 0; z.px = 0; z.DH2 = p.A.DH; z.DW2 = p.A.DW;
+    z.tm.kh0 = 0; z.tm.kw0 = 0; z.tm.tstep = 1; z.tm.nty = p.A.KH; z.tm.ntx = p.A.KW > 0 ? p.A.KW : 1;
+    z.fkh = 0; z.fkw = 0; z.c_off = 0;
+    int ks = blockIdx.z;
+    if (p.zmode == 1) {
+        ks = 0;
+        int s = p.pstep;
+        z.py = blockIdx.z / s; z.px = blockIdx.z - z.py * s;
+        z.DH2 = (p.A.DH - z.py + s - 1) / s; z.DW2 = (p.A.DW - z.px + s - 1) / s;
+        if (z.DH2 < 0) z.DH2 = 0;
+        if (z.DW2 < 0) z.DW2 = 0;
+        z.M = p.nsamp * z.DH2 * z.DW2;
+        z.tm.tstep = s;
+        z.tm.kh0 = (z.py + p.A.pad) % s; z.tm.kw0 = (z.px + p.A.pad) % s;
+        z.tm.nty = z.tm.kh0 < p.A.KH ? (p.A.KH - z.tm.kh0 + s - 1) / s : 0;
+        z.tm.ntx = z.tm.kw0 < p.A.KW ? (p.A.KW - z.tm.kw0 + s - 1) / s : 0;
+        z.K = z.tm.nty * z.tm.ntx * p.A.C;
+        if (z.tm.ntx == 0) z.tm.ntx = 1;
+    } else if (p.zmode == 2) {
+        int tap = blockIdx.z % p.ntaps;
+        ks = blockIdx.z / p.ntaps;
+        int KWt = p.A.tapped ? p.A.KW : p.B.KW;
+        z.fkh = tap / KWt; z.fkw = tap - z.fkh * KWt;
+        z.c_off = (long)tap * p.c_tap_stride;
+    }
+    if (p.splitk > 1) {
+        int ktiles = (z.K + BK - 1) / BK;
+        int per = (ktiles + p.splitk - 1) / p.splitk;
+        z.kbeg = ks * per * BK;
+        z.kend = min(z.K, (ks + 1) * per * BK);
+    } else {
+        z.kbeg = 0; z.kend = z.K;
+    }
+    return z;
+}
+
+template <int BM, int BN, int AMODE, int BMODE>
+__global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
+    constexpr bool A_KC = AMODE <= OP_KC_WTAP;
+    constexpr bool B_KC = BMODE <= OP_KC_WTAP;
+    constexpr int LDA = BM + 2, LDB = BN + 2;
+    constexpr int NUA = BM / 64, NUB = BN / 64;  // float4 units per thread per k-tile
+    constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
+    __shared__ float As[2][BK][LDA];
+    __shared__ float Bs[2][BK][LDB];
+
+    const ZCtx z = make_zctx(p);
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    if (m0 >= z.M) return;  // uniform per block (parity classes may be smaller than the launch grid)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+
+    // Per-thread unit assignment.
+    int a_r[NUA], a_k[NUA], b_r[NUB], b_k[NUB];
+    RowCtx a_rc[NUA], b_rc[NUB];
+#pragma unroll
+    for (int i = 0; i < NUA; i++) {
+        int u = tid + i * 256;
+        if constexpr (A_KC) { a_r[i] = u >> 2; a_k[i] = (u & 3) << 2; a_rc[i] = make_row<AMODE>(p.A, p, z, m0 + a_r[i], z.M); }
+        else { a_k[i] = u / (BM / 4); a_r[i] = (u - a_k[i] * (BM / 4)) << 2; }
+    }
+#pragma unroll
+    for (int i = 0; i < NUB; i++) {
+        int u = tid + i * 256;
+        if constexpr (B_KC) { b_r[i] = u >> 2; b_k[i] = (u & 3) << 2; b_rc[i] = make_row<BMODE>(p.B, p, z, n0 + b_r[i], p.N); }
+        else { b_k[i] = u / (BN / 4); b_r[i] = (u - b_k[i] * (BN / 4)) << 2; }
+    }
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; i++)
+#pragma unroll
+        for (int j = 0; j < TN; j++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+
+    float4 ra[NUA], rb[NUB];
+    auto gload = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < NUA; i++) {
+            if constexpr (A_KC) ra[i] = load_kc<AMODE>(p.A, z, a_rc[i], k0 + a_k[i]);
+            else ra[i] = load_rc<AMODE>(p.A, p, z, k0 + a_k[i], m0 + a_r[i], z.M);
+        }
+#pragma unroll
+        for (int i = 0; i < NUB; i++) {
+            if constexpr (B_KC) rb[i] = load_kc<BMODE>(p.B, z, b_rc[i], k0 + b_k[i]);
+            else rb[i] = load_rc<BMODE>(p.B, p, z, k0 + b_k[i], n0 + b_r[i], p.N);
+        }
+    };
+    auto lstore = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < NUA; i++) {
+            if constexpr (A_KC) {
+                As[buf][a_k[i] + 0][a_r[i]] = ra[i].x; As[buf][a_k[i] + 1][a_r[i]] = ra[i].y;
+                As[buf][a_k[i] + 2][a_r[i]] = ra[i].z; As[buf][a_k[i] + 3][a_r[i]] = ra[i].w;
+            } else {
+                As[buf][a_k[i]][a_r[i] + 0] = ra[i].x; As[buf][a_k[i]][a_r[i] + 1] = ra[i].y;
+                As[buf][a_k[i]][a_r[i] + 2] = ra[i].z; As[buf][a_k[i]][a_r[i] + 3] = ra[i].w;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NUB; i++) {
+            if constexpr (B_KC) {
+                Bs[buf][b_k[i] + 0][b_r[i]] = rb[i].x; Bs[buf][b_k[i] + 1][b_r[i]] = rb[i].y;
+                Bs[buf][b_k[i] + 2][b_r[i]] = rb[i].z; Bs[buf][b_k[i] + 3][b_r[i]] = rb[i].w;
+            } else {
+                Bs[buf][b_k[i]][b_r[i] + 0] = rb[i].x; Bs[buf][b_k[i]][b_r[i] + 1] = rb[i].y;
+                Bs[buf][b_k[i]][b_r[i] + 2] = rb[i].z; Bs[buf][b_k[i]][b_r[i] + 3] = rb[i].w;
+            }
+        }
+    };
+
+    const int nk = (z.kend > z.kbeg) ? (z.kend - z.kbeg + BK - 1) / BK : 0;
+    if (nk > 0) {
+        gload(z.kbeg);
+        lstore(0);
+    }
+    __syncthreads();
+    const int kl = lane >> 5, cl = lane & 31;
+    for (int kt = 0; kt < nk; kt++) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) gload(z.kbeg + (kt + 1) * BK);
+#pragma unroll
+        for (int kk = 0; kk < BK / 2; kk++) {
+            float a[TM], b[TN];
+#pragma unroll
+            for (int i = 0; i < TM; i++) a[i] = As[buf][kk * 2 + kl][wm * WM + i * 32 + cl];
+#pragma unroll
+            for (int j = 0; j < TN; j++) b[j] = Bs[buf][kk * 2 + kl][wn * WN + j * 32 + cl];
+#pragma unroll
+            for (int i = 0; i < TM; i++)
+#pragma unroll
+                for (int j = 0; j < TN; j++)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        if (kt + 1 < nk) lstore(buf ^ 1);
+        __syncthreads();
+    }
+
+    // Epilogue.  acc[i][j][r]: row = (r&3) + 8*(r>>2) + 4*(lane>>5), col = lane&31 of the 32x32 tile.
+    const GemmEpilogue& ep = p.ep;
+    const float inv_keep = ep.p_drop > 0.f ? 1.f / (1.f - ep.p_drop) : 1.f;
+#pragma unroll
+    for (int i = 0; i < TM; i++) {
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            int m = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kl;
+            if (m >= z.M) continue;
+            long orow = m;
+            if (p.zmode == 1 && p.pstep > 1) {
+                int per = z.DH2 * z.DW2;
+                int n = m / per; int rem = m - n * per;
+                int y2 = rem / z.DW2; int x2 = rem - y2 * z.DW2;
+                orow = ((long)n * p.A.DH + (y2 * p.pstep + z.py)) * p.A.DW + (x2 * p.pstep + z.px);
+            }
+            int samp = p.pix_per_sample > 0 ? (int)(orow / p.pix_per_sample) : 0;
+#pragma unroll
+            for (int j = 0; j < TN; j++) {
+                int n = n0 + wn * WN + j * 32 + cl;
+                if (n >= p.N) continue;
+                float v = acc[i][j][r] * ep.alpha;
+                if (ep.col_scale) v *= ep.col_scale[n];
+                if (ep.samp_scale) v *= ep.samp_scale[(long)samp * ep.samp_ld + n];
+                if (ep.col_bias) v += ep.col_bias[n];
+                if (ep.residual) v += ep.residual[orow * ep.ldr + n];
+                if (ep.act == 1) v = fmaxf(v, 0.f);
+                else if (ep.act == 2) v = (v > 0.f ? v : v * ep.act_alpha) * ep.act_gain;
+                if (ep.mask_mode) {
+                    float s = ep.mask_src[orow * ep.ldm + n];
+                    if (ep.mask_mode == 1) v = s > 0.f ? v : 0.f;
+                    else v *= (s > 0.f ? ep.act_gain : ep.act_gain * ep.act_alpha);
+                }
+                if (ep.p_drop > 0.f) v *= drop_scale(ep.seed, (uint64_t)(orow * p.ldc + n), ep.p_drop, inv_keep);
+                v *= ep.out_scale;
+                float* dst = p.C + z.c_off + orow * p.ldc + n;
+                if (p.splitk > 1) atomicAdd(dst, v);
+                else if (ep.accumulate) *dst += v;
+                else *dst = v;
+            }
+        }
+    }
+}
+
+template <int AMODE, int BMODE>
+static int launch_gemm(const GemmParams& p, int Mmax, int zdim, int tile, hipStream_t st) {
+    if (tile == 128) {
+        dim3 grid(cdiv(p.N, 128), cdiv(Mmax, 128), zdim);
+        hipLaunchKernelGGL((gemm_f32_kernel<128, 128, AMODE, BMODE>), grid, 256, 0, st, p);
+    } else {
+        dim3 grid(cdiv(p.N, 64), cdiv(Mmax, 64), zdim);
+        hipLaunchKernelGGL((gemm_f32_kernel<64, 64, AMODE, BMODE>), grid, 256, 0, st, p);
+    }
+    return check_launch("gemm_f32");
+}
+
+static inline bool al16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
+
+static void init_operand(Operand& o) { memset(&o, 0, sizeof(o)); o.KW = 1; o.KH = 1; o.stride = 1; o.C = 1; o.Cr = 1; }
+
+static int pick_tile(long M, long N, int zdim) {
+    long t128 = (long)cdiv(M, 128) * cdiv(N, 128) * zdim;
+    return (t128 >= 192 && M >= 128 && N >= 128) ? 128 : 64;
+}
+
+static void fill_epilogue(GemmEpilogue& ep, const ldetr_epilogue* e) {
+    memset(&ep, 0, sizeof(ep));
+    ep.out_scale = 1.f; ep.act_gain = 1.f; ep.alpha = 1.f;
+    if (!e) return;
+    ep.alpha = e->alpha;
+    ep.col_scale = e->col_scale; ep.col_bias = e->col_bias;
+    ep.samp_scale = e->samp_scale; ep.samp_ld = e->samp_ld;
+    ep.residual = e->residual; ep.ldr = e->ldr;
+    ep.act = e->act; ep.act_alpha = e->act_alpha; ep.act_gain = e->act_gain;
+    ep.mask_src = e->mask_src; ep.ldm = e->ldm; ep.mask_mode = e->mask_mode;
+    ep.out_scale = e->out_scale; ep.p_drop = e->p_drop; ep.seed = e->seed; ep.accumulate = e->accumulate;
+}
+
+}  // namespace ldetr
+
+using namespace ldetr;
+
+// ---------------------------------------------------------------------------------------------
+// Dense GEMM.  C[M,N] = op(A) * op(B), row-major C with leading dimension ldc.
+//   ta == 0: A is [M,K] row-major (lda);  ta == 1: A is stored [K,M] (lda)
+//   tb == 0: B is stored [N,K] row-major (ldb)  — i.e. nn.Linear weight layout [out,in];
+//   tb == 1: B is stored [K,N] (ldb)
+extern "C" int ldetr_gemm_f32(const float* A, int64_t lda, int ta, const float* B, int64_t ldb, int tb,
+                              float* C, int64_t ldc, int M, int N, int K, int splitk,
+                              const ldetr_epilogue* ep, int pix_per_sample, void* stream) {
+    LDETR_CHECK(A && B && C, "gemm: null pointer");
+    LDETR_CHECK(M >= 0 && N >= 0 && K >= 0, "gemm: negative dimension");
+    if (M == 0 || N == 0) return LDETR_OK;
+    GemmParams p; memset(&p, 0, sizeof(p));
+    init_operand(p.A); init_operand(p.B);
+    p.A.p = A; p.A.ld = lda; p.B.p = B; p.B.ld = ldb;
+    p.A.vec = al16(A) && (lda % 4 == 0) && (ta ? (M % 4 == 0) : (K % 4 == 0));
+    p.B.vec = al16(B) && (ldb % 4 == 0) && (tb ? (N % 4 == 0) : (K % 4 == 0));
+    p.M = M; p.N = N; p.K = K; p.C = C; p.ldc = ldc;
+    p.zmode = 0; p.splitk = splitk < 1 ? 1 : splitk; p.pstep = 1; p.nsamp = 1;
+    p.pix_per_sample = pix_per_sample;
+    fill_epilogue(p.ep, ep);
+    LDETR_CHECK(p.splitk == 1 || (!p.ep.act && !p.ep.col_bias && !p.ep.residual && !p.ep.mask_mode && p.ep.p_drop == 0.f),
+                "gemm: split-K supports only linear epilogues");
+    hipStream_t st = (hipStream_t)stream;
+    int tile = pick_tile(M, N, p.splitk);
+    if (!ta && !tb) return launch_gemm<OP_KC_DENSE, OP_KC_DENSE>(p, M, p.splitk, tile, st);
+    if (!ta && tb) return launch_gemm<OP_KC_DENSE, OP_RC_DENSE>(p, M, p.splitk, tile, st);
+    if (ta && tb) return launch_gemm<OP_RC_DENSE, OP_RC_DENSE>(p, M, p.splitk, tile, st);
+    set_error("gemm: (ta=1, tb=0) is not instantiated");
+    return LDETR_ERR_UNSUPPORTED;
+}
+
+static void set_conv_src(Operand& o, const float* x, const ldetr_tensor4* t) {
+    o.p = x; o.SH = t->H; o.SW = t->W; o.sn = t->sn; o.sh = t->sh; o.sw = t->sw; o.sc = t->sc;
+}
+
+// ---------------------------------------------------------------------------------------------
+// conv2d forward (correlation, as F.conv2d):  y[n,oh,ow,co] = sum x[n, oh*s-p+kh, ow*s-p+kw, ci] * w[co,kh,kw,ci]
+// x: any strides (NHWC fast path when sc == 1 and C % 4 == 0); w: OHWI contiguous; y: NHWC rows of ldy.
+extern "C" int ldetr_conv2d_fwd_f32(const float* x, const ldetr_tensor4* xt, const float* w, int Cout, int KH, int KW,
+                                    int stride, int pad, float* y, int64_t ldy, int OH, int OW,
+                                    const float* in_scale, int64_t in_scale_ld,
+                                    const ldetr_epilogue* ep, void* stream) {
+    LDETR_CHECK(x && w && y && xt, "conv2d_fwd: null pointer");
+    int eOH = (xt->H + 2 * pad - KH) / stride + 1, eOW = (xt->W + 2 * pad - KW) / stride + 1;
+    LDETR_CHECK(eOH == OH && eOW == OW, "conv2d_fwd: output size mismatch (expected %dx%d)", eOH, eOW);
+    GemmParams p; memset(&p, 0, sizeof(p));
+    init_operand(p.A); init_operand(p.B);
+    set_conv_src(p.A, x, xt);
+    p.A.DH = OH; p.A.DW = OW; p.A.C = xt->C; p.A.stride = stride; p.A.pad = pad; p.A.KH = KH; p.A.KW = KW;
+    p.A.scale = in_scale; p.A.scale_ld = in_scale_ld;
+    p.A.vec = (xt->sc == 1) && (xt->C % 4 == 0) && al16(x) && (xt->sn % 4 == 0) && (xt->sh % 4 == 0) && (xt->sw % 4 == 0) &&
+              (!in_scale || (al16(in_scale) && in_scale_ld % 4 == 0));
+    long K = (long)KH * KW * xt->C;
+    p.B.p = w; p.B.ld = K; p.B.vec = al16(w) && (K % 4 == 0);
+    p.M = xt->N * OH * OW; p.N = Cout; p.K = (int)K; p.C = y; p.ldc = ldy;
+    p.zmode = 0; p.splitk = 1; p.pstep = 1; p.nsamp = xt->N; p.pix_per_sample = OH * OW;
+    fill_epilogue(p.ep, ep);
+    hipStream_t st = (hipStream_t)stream;
+    int tile = pick_tile(p.M, p.N, 1);
+    if (KH == 1 && KW == 1 && stride == 1 && pad == 0 && p.A.vec && !in_scale && xt->sw == xt->C && xt->sh == (long)xt->W * xt->C &&
+        xt->sn == (long)xt->H * xt->W * xt->C) {
+        p.A.ld = xt->C;  // pure GEMM view of a packed NHWC tensor
+        return launch_gemm<OP_KC_DENSE, OP_KC_DENSE>(p, p.M, 1, tile, st);
+    }
+    return launch_gemm<OP_KC_CONV, OP_KC_DENSE>(p, p.M, 1, tile, st);
+}
+
+// conv2d backward-data: dx[n,ih,iw,ci] = sum_{co,kh,kw} dy[n,oh,ow,co] * w[co,kh,kw,ci],  ih = oh*s - p + kh.
+// Stride-s problems are decomposed into s*s output-parity classes so no multiply-by-zero work is issued.
+extern "C" int ldetr_conv2d_bwd_data_f32(const float* dy, const ldetr_tensor4* dyt, const float* w, int Cin, int KH, int KW,
+                                         int stride, int pad, float* dx, int64_t lddx, int IH, int IW,
+                                         const float* dy_scale, int64_t dy_scale_ld,
+                                         const ldetr_epilogue* ep, void* stream) {
+    LDETR_CHECK(dy && w && dx && dyt, "conv2d_bwd_data: null pointer");
+    LDETR_CHECK(dyt->sc == 1 && dyt->C % 4 == 0 && Cin % 4 == 0, "conv2d_bwd_data: channels must be NHWC-contiguous multiples of 4");
+    GemmParams p; memset(&p, 0, sizeof(p));
+    init_operand(p.A); init_operand(p.B);
+    set_conv_src(p.A, dy, dyt);
+    p.A.DH = IH; p.A.DW = IW; p.A.C = dyt->C; p.A.stride = stride; p.A.pad = pad; p.A.KH = KH; p.A.KW = KW;
+    p.A.scale = dy_scale; p.A.scale_ld = dy_scale_ld;
+    p.A.vec = al16(dy) && (dyt->sn % 4 == 0) && (dyt->sh % 4 == 0) && (dyt->sw % 4 == 0) &&
+              (!dy_scale || (al16(dy_scale) && dy_scale_ld % 4 == 0));
+    LDETR_CHECK(p.A.vec, "conv2d_bwd_data: dy must be 16-byte aligned NHWC");
+    p.B.p = w; p.B.ld = (long)KH * KW * Cin; p.B.C = dyt->C; p.B.Cr = Cin; p.B.KH = KH; p.B.KW = KW;
+    p.B.vec = al16(w);
+    p.N = Cin; p.C = dx; p.ldc = lddx;
+    p.zmode = 1; p.splitk = 1; p.pstep = stride; p.nsamp = dyt->N; p.pix_per_sample = IH * IW;
+    p.M = dyt->N * IH * IW; p.K = KH * KW * dyt->C;
+    fill_epilogue(p.ep, ep);
+    int Mmax = dyt->N * cdiv(IH, stride) * cdiv(IW, stride);
+    int tile = pick_tile(Mmax, p.N, stride * stride);
+    return launch_gemm<OP_KC_CONVT, OP_RC_WT>(p, Mmax, stride * stride, tile, (hipStream_t)stream);
+}
+
+// conv2d backward-weight: dw[co,kh,kw,ci] = sum_{n,oh,ow} dy[n,oh,ow,co] * x[n, oh*s-p+kh, ow*s-p+kw, ci].
+// One GEMM per tap (grid.z = taps x split-K), fp32 atomic accumulation into a zeroed dw.
+extern "C" int ldetr_conv2d_bwd_weight_f32(const float* x, const ldetr_tensor4* xt, const float* dy, const ldetr_tensor4* dyt,
+                                           float* dw, int KH, int KW, int stride, int pad, int splitk,
+                                           const float* x_scale, int64_t x_scale_ld,
+                                           const float* dy_scale, int64_t dy_scale_ld, void* stream) {
+    LDETR_CHECK(x && dy && dw && xt && dyt, "conv2d_bwd_weight: null pointer");
+    LDETR_CHECK(dyt->sc == 1, "conv2d_bwd_weight: dy must be NHWC");
+    int Cin = xt->C, Cout = dyt->C, OH = dyt->H, OW = dyt->W;
+    hipStream_t st = (hipStream_t)stream;
+    GemmParams p; memset(&p, 0, sizeof(p));
+    init_operand(p.A); init_operand(p.B);
+    if (splitk < 1) splitk = 1;
+    fill_epilogue(p.ep, nullptr);
+    p.splitk = splitk; p.pstep = 1; p.nsamp = xt->N; p.pix_per_sample = 0;
+    long wsz = (long)Cout * KH * KW * Cin;
+    if (hipMemsetAsync(dw, 0, wsz * sizeof(float), st) != hipSuccess) { set_error("conv2d_bwd_weight: memset failed"); return LDETR_ERR_LAUNCH; }
+    int Kpix = dyt->N * OH * OW;
+    if (xt->sc != 1 || Cin % 4 != 0) {
+        // 3-channel (or strided-channel) input, e.g. the ResNet stem on an NCHW image: a single GEMM with
+        // A = dy viewed [k = pixel][m = co] and B = scalar im2col gather [k = pixel][n = (tap, c)].
+        LDETR_CHECK(dyt->sw == Cout && dyt->sh == (long)OW * Cout && dyt->sn == (long)OH * OW * Cout, "conv2d_bwd_weight: dy must be packed NHWC");
+        LDETR_CHECK(!x_scale && !dy_scale, "conv2d_bwd_weight: scales unsupported on the scalar-gather path");
+        p.A.p = dy; p.A.ld = Cout; p.A.vec = al16(dy) && (Cout % 4 == 0);
+        set_conv_src(p.B, x, xt);
+        p.B.DH = OH; p.B.DW = OW; p.B.C = Cin; p.B.stride = stride; p.B.pad = pad; p.B.KH = KH; p.B.KW = KW;
+        p.M = Cout; p.N = KH * KW * Cin; p.K = Kpix; p.C = dw; p.ldc = (long)KH * KW * Cin; p.zmode = 0;
+        return launch_gemm<OP_RC_DENSE, OP_RC_CONVK>(p, p.M, splitk, 64, st);
+    }
+    // A = dy viewed as [k = pixel][m = co]; B = x gathered per tap [k = pixel][n = ci]
+    set_conv_src(p.A, dy, dyt);
+    p.A.DH = OH; p.A.DW = OW; p.A.stride = 1; p.A.pad = 0; p.A.tapped = 0;
+    p.A.scale = dy_scale; p.A.scale_ld = dy_scale_ld;
+    p.A.vec = al16(dy) && (Cout % 4 == 0) && (dyt->sn % 4 == 0) && (dyt->sh % 4 == 0) && (dyt->sw % 4 == 0) &&
+              (!dy_scale || (al16(dy_scale) && dy_scale_ld % 4 == 0));
+    set_conv_src(p.B, x, xt);
+    p.B.DH = OH; p.B.DW = OW; p.B.stride = stride; p.B.pad = pad; p.B.KH = KH; p.B.KW = KW; p.B.tapped = 1;
+    p.B.scale = x_scale; p.B.scale_ld = x_scale_ld;
+    p.B.vec = al16(x) && (xt->sn % 4 == 0) && (xt->sh % 4 == 0) && (xt->sw % 4 == 0) &&
+              (!x_scale || (al16(x_scale) && x_scale_ld % 4 == 0));
+    p.M = Cout; p.N = Cin; p.K = Kpix; p.C = dw; p.ldc = (long)KH * KW * Cin;
+    p.zmode = 2; p.ntaps = KH * KW; p.c_tap_stride = Cin;
+    int tile = pick_tile(p.M, p.N, p.ntaps * splitk);
+    return launch_gemm<OP_RC_PIX, OP_RC_PIX>(p, p.M, p.ntaps * splitk, tile, st);
+}
+
+// conv_transpose2d forward (as F.conv_transpose2d with weight given as the *un-transposed* OHWI tensor
+// w[co,kh,kw,ci]):  y[n,oh,ow,co] = sum_{ci,kh,kw} x[n,ih,iw,ci] * w[co,kh,kw,ci],  oh = ih*s + kh - p.
+extern "C" int ldetr_conv_transpose2d_fwd_f32(const float* x, const ldetr_tensor4* xt, const float* w, int Cout, int KH, int KW,
+                                              int stride, int pad, float* y, int64_t ldy, int OH, int OW,
+                                              const float* in_scale, int64_t in_scale_ld,
+                                              const ldetr_epilogue* ep, void* stream) {
+    LDETR_CHECK(x && w && y && xt, "conv_transpose2d_fwd: null pointer");
+    LDETR_CHECK(xt->sc == 1 && xt->C % 4 == 0, "conv_transpose2d_fwd: x must be NHWC with C % 4 == 0");
+    int eOH = (xt->H - 1) * stride - 2 * pad + KH, eOW = (xt->W - 1) * stride - 2 * pad + KW;
+    LDETR_CHECK(eOH == OH && eOW == OW, "conv_transpose2d_fwd: output size mismatch (expected %dx%d)", eOH, eOW);
+    GemmParams p; memset(&p, 0, sizeof(p));
+    init_operand(p.A); init_operand(p.B);
+    set_conv_src(p.A, x, xt);
+    p.A.DH = OH; p.A.DW = OW; p.A.C = xt->C; p.A.stride = stride; p.A.pad = pad; p.A.KH = KH; p.A.KW = KW;
+    p.A.scale = in_scale; p.A.scale_ld = in_scale_ld;
+    p.A.vec = al16(x) && (xt->sn % 4 == 0) && (xt->sh % 4 == 0) && (xt->sw % 4 == 0) &&
+              (!in_scale || (al16(in_scale) && in_scale_ld % 4 == 0));
+    LDETR_CHECK(p.A.vec, "conv_transpose2d_fwd: x must be 16-byte aligned NHWC");
+    p.B.p = w; p.B.ld = (long)KH * KW * xt->C; p.B.C = xt->C; p.B.KH = KH; p.B.KW = KW; p.B.vec = al16(w);
+    LDETR_CHECK(p.B.vec, "conv_transpose2d_fwd: w must be 16-byte aligned");
+    p.N = Cout; p.C = y; p.ldc = ldy;
+    p.zmode = 1; p.splitk = 1; p.pstep = stride; p.nsamp = xt->N; p.pix_per_sample = OH * OW;
+    p.M = xt->N * OH * OW; p.K = KH * KW * xt->C;
+    fill_epilogue(p.ep, ep);
+    int Mmax = xt->N * cdiv(OH, stride) * cdiv(OW, stride);
+    int tile = pick_tile(Mmax, p.N, stride * stride);
+    return launch_gemm<OP_KC_CONVT, OP_KC_WTAP>(p, Mmax, stride * stride, tile, (hipStream_t)stream);
+}
+
+// conv_transpose2d backward-data: dx[n,ih,iw,ci] = sum_{co,kh,kw} dy[n, ih*s+kh-p, iw*s+kw-p, co] * w[co,kh,kw,ci]
+extern "C" int ldetr_conv_transpose2d_bwd_data_f32(const float* dy, const ldetr_tensor4* dyt, const float* w, int Cin, int KH, int KW,
+                                                   int stride, int pad, float* dx, int64_t lddx, int IH, int IW,
+                                                   const float* dy_scale, int64_t dy_scale_ld,
+                                                   const ldetr_epilogue* ep, void* stream) {
+    LDETR_CHECK(dy && w && dx && dyt, "conv_transpose2d_bwd_data: null pointer");
+    LDETR_CHECK(dyt->sc == 1 && dyt->C % 4 == 0 && Cin % 4 == 0, "conv_transpose2d_bwd_data: channels must be NHWC multiples of 4");
+    GemmParams p; memset(&p, 0, sizeof(p));
+    init_operand(p.A); init_operand(p.B);
+    set_conv_src(p.A, dy, dyt);
+    p.A.DH = IH; p.A.DW = IW; p.A.C = dyt->C; p.A.stride = stride; p.A.pad = pad; p.A.KH = KH; p.A.KW = KW;
+    p.A.scale = dy_scale; p.A.scale_ld = dy_scale_ld;
+    p.A.vec = al16(dy) && (dyt->sn % 4 == 0) && (dyt->sh % 4 == 0) && (dyt->sw % 4 == 0) &&
+              (!dy_scale || (al16(dy_scale) && dy_scale_ld % 4 == 0));
+    LDETR_CHECK(p.A.vec, "conv_transpose2d_bwd_data: dy must be 16-byte aligned NHWC");
+    p.B.p = w; p.B.ld = (long)KH * KW * Cin; p.B.C = dyt->C; p.B.Cr = Cin; p.B.KH = KH; p.B.KW = KW; p.B.vec = al16(w);
+    p.M = dyt->N * IH * IW; p.N = Cin; p.K = KH * KW * dyt->C; p.C = dx; p.ldc = lddx;
+    p.zmode = 0; p.splitk = 1; p.pstep = 1; p.nsamp = dyt->N; p.pix_per_sample = IH * IW;
+    fill_epilogue(p.ep, ep);
+    int tile = pick_tile(p.M, p.N, 1);
+    return launch_gemm<OP_KC_CONV, OP_RC_WT>(p, p.M, 1, tile, (hipStream_t)stream);
+}
+
+// conv_transpose2d backward-weight: dw[co,kh,kw,ci] = sum_{n,ih,iw} dy[n, ih*s+kh-p, iw*s+kw-p, co] * x[n,ih,iw,ci]
+extern "C" int ldetr_conv_transpose2d_bwd_weight_f32(const float* x, const ldetr_tensor4* xt, const float* dy, const ldetr_tensor4* dyt,
+                                                     float* dw, int KH, int KW, int stride, int pad, int splitk,
+                                                     const float* x_scale, int64_t x_scale_ld,
+                                                     const float* dy_scale, int64_t dy_scale_ld, void* stream) {
+    LDETR_CHECK(x && dy && dw && xt && dyt, "conv_transpose2d_bwd_weight: null pointer");
+    LDETR_CHECK(dyt->sc == 1 && xt->sc == 1 && xt->C % 4 == 0 && dyt->C % 4 == 0, "conv_transpose2d_bwd_weight: NHWC, C % 4 == 0 required");
+    int Cin = xt->C, Cout = dyt->C;
+    hipStream_t st = (hipStream_t)stream;
+    GemmParams p; memset(&p, 0, sizeof(p));
+    init_operand(p.A); init_operand(p.B);
+    if (splitk < 1) splitk = 1;
+    fill_epilogue(p.ep, nullptr);
+    p.splitk = splitk; p.pstep = 1; p.nsamp = xt->N; p.pix_per_sample = 0;
+    long wsz = (long)Cout * KH * KW * Cin;
+    if (hipMemsetAsync(dw, 0, wsz * sizeof(float), st) != hipSuccess) { set_error("conv_transpose2d_bwd_weight: memset failed"); return LDETR_ERR_LAUNCH; }
+    // k enumerates *input* pixels (n, ih, iw); A = dy gathered at (ih*s + kh - p, iw*s + kw - p), B = x dense.
+    set_conv_src(p.A, dy, dyt);
+    p.A.DH = xt->H; p.A.DW = xt->W; p.A.stride = stride; p.A.pad = pad; p.A.KH = KH; p.A.KW = KW; p.A.tapped = 1;
+    p.A.scale = dy_scale; p.A.scale_ld = dy_scale_ld;
+    p.A.vec = al16(dy) && (dyt->sn % 4 == 0) && (dyt->sh % 4 == 0) && (dyt->sw % 4 == 0) &&
+              (!dy_scale || (al16(dy_scale) && dy_scale_ld % 4 == 0));
+    set_conv_src(p.B, x, xt);
+    p.B.DH = xt->H; p.B.DW = xt->W; p.B.stride = 1; p.B.pad = 0; p.B.tapped = 0;
+    p.B.scale = x_scale; p.B.scale_ld = x_scale_ld;
+    p.B.vec = al16(x) && (xt->sn % 4 == 0) && (xt->sh % 4 == 0) && (xt->sw % 4 == 0) &&
+              (!x_scale || (al16(x_scale) && x_scale_ld % 4 == 0));
+    p.M = Cout; p.N = Cin; p.K = xt->N * xt->H * xt->W; p.C = dw; p.ldc = (long)KH * KW * Cin;
+    p.zmode = 2; p.ntaps = KH * KW; p.c_tap_stride = Cin;
+    int tile = pick_tile(p.M, p.N, p.ntaps * splitk);
+    return launch_gemm<OP_RC_PIX, OP_RC_PIX>(p, p.M, p.ntaps * splitk, tile, st);
+}

@@ -1,0 +1,191 @@
+// Fused residual-add + dropout + LayerNorm, forward and backward.
+// Replaces the `x = norm(x + dropout(sublayer(x)))` chains of the post-norm DETR layers
+// (training/detr_transformer.py:210-214, 275-285; nn.LayerNorm(256), eps 1e-5) which the reference
+// executes as 3-4 separate elementwise/reduction kernels.
+// HBM-bound: forward reads x, r and writes z (pre-norm sum, kept for backward) and y: 16 B/element;
+// one 64-lane wave per row, float4 per lane, row statistics by wave shuffles only.
+#include "ldetr_common.hpp"
+#include "../../include/ldetr_hip.h"
+
+namespace ldetr {
+
+struct LnParams {
+    const float* x; const float* r; const float* gamma; const float* beta;
+    float* y; float* z; float* mean; float* rstd;
+    const float* dy; float* dx; float* dr; float* dgamma; float* dbeta;
+    long rows; int D; float eps, p_drop; unsigned long long seed;
+};
+
+// NV = float4 vectors per lane (D = 256*NV at most; lanes past D/4 idle)
+template <int NV>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(LnParams p) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long row = (long)blockIdx.x * 4 + wave;
+    if (row >= p.rows) return;
+    const int D4 = p.D >> 2;
+    const float inv_keep = p.p_drop > 0.f ? 1.f / (1.f - p.p_drop) : 1.f;
+    float4 v[NV];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; i++) {
+        int c4 = lane + i * 64;
+        v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (c4 < D4) {
+            v[i] = reinterpret_cast<const float4*>(p.x + row * p.D)[c4];
+            if (p.r) {
+                float4 rr = reinterpret_cast<const float4*>(p.r + row * p.D)[c4];
+                if (p.p_drop > 0.f) {
+                    uint64_t e = (uint64_t)row * p.D + (c4 << 2);
+                    rr.x *= drop_scale(p.seed, e, p.p_drop, inv_keep);
+                    rr.y *= drop_scale(p.seed, e + 1, p.p_drop, inv_keep);
+                    rr.z *= drop_scale(p.seed, e + 2, p.p_drop, inv_keep);
+                    rr.w *= drop_scale(p.seed, e + 3, p.p_drop, inv_keep);
+                }
+                v[i].x += rr.x; v[i].y += rr.y; v[i].z += rr.z; v[i].w += rr.w;
+            }
+            if (p.z) reinterpret_cast<float4*>(p.z + row * p.D)[c4] = v[i];
+            s += v[i].x + v[i].y + v[i].z + v[i].w;
+        }
+    }
+    const float mean = wave_sum(s) / p.D;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; i++) {
+        int c4 = lane + i * 64;
+        if (c4 < D4) {
+            float a = v[i].x - mean, b = v[i].y - mean, c = v[i].z - mean, d = v[i].w - mean;
+            q += a * a + b * b + c * c + d * d;
+        }
+    }
+    const float rstd = rsqrtf(wave_sum(q) / p.D + p.eps);
+    if (lane == 0) { if (p.mean) p.mean[row] = mean; if (p.rstd) p.rstd[row] = rstd; }
+#pragma unroll
+    for (int i = 0; i < NV; i++) {
+        int c4 = lane + i * 64;
+        if (c4 < D4) {
+            float4 g = reinterpret_cast<const float4*>(p.gamma)[c4];
+            float4 b = reinterpret_cast<const float4*>(p.beta)[c4];
+            float4 o;
+            o.x = (v[i].x - mean) * rstd * g.x + b.x; o.y = (v[i].y - mean) * rstd * g.y + b.y;
+            o.z = (v[i].z - mean) * rstd * g.z + b.z; o.w = (v[i].w - mean) * rstd * g.w + b.w;
+            reinterpret_cast<float4*>(p.y + row * p.D)[c4] = o;
+        }
+    }
+}
+
+// Backward: dz = rstd * (g - mean(g) - xhat * mean(g*xhat)), g = dy*gamma.
+// dx = dz; dr = dz * dropmask (regenerated).  dgamma/dbeta: per-wave register partials over a
+// grid-stride row loop, LDS combine across the 4 waves, one atomicAdd per block per column.
+template <int NV>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(LnParams p) {
+    __shared__ float red[2][4][256 * NV];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int D4 = p.D >> 2;
+    const float inv_keep = p.p_drop > 0.f ? 1.f / (1.f - p.p_drop) : 1.f;
+    float4 ag[NV], ab[NV];
+#pragma unroll
+    for (int i = 0; i < NV; i++) { ag[i] = make_float4(0.f, 0.f, 0.f, 0.f); ab[i] = ag[i]; }
+    for (long row = (long)blockIdx.x * 4 + wave; row < p.rows; row += (long)gridDim.x * 4) {
+        const float mean = p.mean[row], rstd = p.rstd[row];
+        float4 xh[NV], g[NV];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; i++) {
+            int c4 = lane + i * 64;
+            xh[i] = make_float4(0.f, 0.f, 0.f, 0.f); g[i] = xh[i];
+            if (c4 < D4) {
+                float4 zz = reinterpret_cast<const float4*>(p.z + row * p.D)[c4];
+                float4 dy = reinterpret_cast<const float4*>(p.dy + row * p.D)[c4];
+                float4 gm = reinterpret_cast<const float4*>(p.gamma)[c4];
+                xh[i].x = (zz.x - mean) * rstd; xh[i].y = (zz.y - mean) * rstd;
+                xh[i].z = (zz.z - mean) * rstd; xh[i].w = (zz.w - mean) * rstd;
+                g[i].x = dy.x * gm.x; g[i].y = dy.y * gm.y; g[i].z = dy.z * gm.z; g[i].w = dy.w * gm.w;
+                s1 += g[i].x + g[i].y + g[i].z + g[i].w;
+                s2 += g[i].x * xh[i].x + g[i].y * xh[i].y + g[i].z * xh[i].z + g[i].w * xh[i].w;
+                ag[i].x += dy.x * xh[i].x; ag[i].y += dy.y * xh[i].y; ag[i].z += dy.z * xh[i].z; ag[i].w += dy.w * xh[i].w;
+                ab[i].x += dy.x; ab[i].y += dy.y; ab[i].z += dy.z; ab[i].w += dy.w;
+            }
+        }
+        const float c1 = wave_sum(s1) / p.D, c2 = wave_sum(s2) / p.D;
+#pragma unroll
+        for (int i = 0; i < NV; i++) {
+            int c4 = lane + i * 64;
+            if (c4 < D4) {
+                float4 dz;
+                dz.x = rstd * (g[i].x - c1 - xh[i].x * c2); dz.y = rstd * (g[i].y - c1 - xh[i].y * c2);
+                dz.z = rstd * (g[i].z - c1 - xh[i].z * c2); dz.w = rstd * (g[i].w - c1 - xh[i].w * c2);
+                if (p.dx) reinterpret_cast<float4*>(p.dx + row * p.D)[c4] = dz;
+                if (p.dr) {
+                    if (p.p_drop > 0.f) {
+                        uint64_t e = (uint64_t)row * p.D + (c4 << 2);
+                        dz.x *= drop_scale(p.seed, e, p.p_drop, inv_keep);
+                        dz.y *= drop_scale(p.seed, e + 1, p.p_drop, inv_keep);
+                        dz.z *= drop_scale(p.seed, e + 2, p.p_drop, inv_keep);
+                        dz.w *= drop_scale(p.seed, e + 3, p.p_drop, inv_keep);
+                    }
+                    reinterpret_cast<float4*>(p.dr + row * p.D)[c4] = dz;
+                }
+            }
+        }
+    }
+    if (!p.dgamma) return;
+#pragma unroll
+    for (int i = 0; i < NV; i++) {
+        int c = (lane + i * 64) << 2;
+        red[0][wave][c + 0] = ag[i].x; red[0][wave][c + 1] = ag[i].y; red[0][wave][c + 2] = ag[i].z; red[0][wave][c + 3] = ag[i].w;
+        red[1][wave][c + 0] = ab[i].x; red[1][wave][c + 1] = ab[i].y; red[1][wave][c + 2] = ab[i].z; red[1][wave][c + 3] = ab[i].w;
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < p.D; c += 256) {
+        float g = red[0][0][c] + red[0][1][c] + red[0][2][c] + red[0][3][c];
+        float b = red[1][0][c] + red[1][1][c] + red[1][2][c] + red[1][3][c];
+        atomicAdd(p.dgamma + c, g);
+        atomicAdd(p.dbeta + c, b);
+    }
+}
+
+}  // namespace ldetr
+
+using namespace ldetr;
+
+extern "C" int ldetr_layernorm_fwd_f32(const float* x, const float* residual, const float* gamma, const float* beta,
+                                       float* y, float* z, float* mean, float* rstd, int64_t rows, int D, float eps,
+                                       float p_drop, uint64_t seed, void* stream) {
+    LDETR_CHECK(x && gamma && beta && y, "layernorm_fwd: null pointer");
+    LDETR_CHECK(D % 4 == 0 && D >= 4 && D <= 1024, "layernorm_fwd: D must be a multiple of 4 in [4, 1024]");
+    if (rows == 0) return LDETR_OK;
+    LnParams p; memset(&p, 0, sizeof(p));
+    p.x = x; p.r = residual; p.gamma = gamma; p.beta = beta; p.y = y; p.z = z; p.mean = mean; p.rstd = rstd;
+    p.rows = rows; p.D = D; p.eps = eps; p.p_drop = p_drop; p.seed = seed;
+    int grid = (int)((rows + 3) / 4);
+    hipStream_t st = (hipStream_t)stream;
+    int nv = (D + 255) / 256;
+    if (nv == 1) hipLaunchKernelGGL(ln_fwd_kernel<1>, grid, 256, 0, st, p);
+    else if (nv == 2) hipLaunchKernelGGL(ln_fwd_kernel<2>, grid, 256, 0, st, p);
+    else if (nv == 3) hipLaunchKernelGGL(ln_fwd_kernel<3>, grid, 256, 0, st, p);
+    else hipLaunchKernelGGL(ln_fwd_kernel<4>, grid, 256, 0, st, p);
+    return check_launch("layernorm_fwd");
+}
+
+// dgamma/dbeta are accumulated with atomics: the caller zeroes them (or passes running gradients).
+extern "C" int ldetr_layernorm_bwd_f32(const float* dy, const float* z, const float* mean, const float* rstd, const float* gamma,
+                                       float* dx, float* dresidual, float* dgamma, float* dbeta, int64_t rows, int D,
+                                       float p_drop, uint64_t seed, void* stream) {
+    LDETR_CHECK(dy && z && mean && rstd && gamma, "layernorm_bwd: null pointer");
+    LDETR_CHECK(D % 4 == 0 && D >= 4 && D <= 1024, "layernorm_bwd: D must be a multiple of 4 in [4, 1024]");
+    LDETR_CHECK((dgamma == nullptr) == (dbeta == nullptr), "layernorm_bwd: dgamma and dbeta go together");
+    if (rows == 0) return LDETR_OK;
+    LnParams p; memset(&p, 0, sizeof(p));
+    p.dy = dy; p.z = const_cast<float*>(z); p.mean = const_cast<float*>(mean); p.rstd = const_cast<float*>(rstd);
+    p.gamma = gamma; p.dx = dx; p.dr = dresidual; p.dgamma = dgamma; p.dbeta = dbeta;
+    p.rows = rows; p.D = D; p.p_drop = p_drop; p.seed = seed;
+    int grid = (int)((rows + 3) / 4);
+    if (grid > 512) grid = 512;
+    hipStream_t st = (hipStream_t)stream;
+    int nv = (D + 255) / 256;
+    if (nv == 1) hipLaunchKernelGGL(ln_bwd_kernel<1>, grid, 256, 0, st, p);
+    else if (nv == 2) hipLaunchKernelGGL(ln_bwd_kernel<2>, grid, 256, 0, st, p);
+    else if (nv == 3) hipLaunchKernelGGL(ln_bwd_kernel<3>, grid, 256, 0, st, p);
+    else hipLaunchKernelGGL(ln_bwd_kernel<4>, grid, 256, 0, st, p);
+    return check_launch("layernorm_bwd");
+}

@@ -1,0 +1,68 @@
+// Shared helpers for the layoutdetr_amd gfx950 kernels.
+// CDNA4 only: 64-lane wavefronts, f32 MFMA, no portability layer.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#define LDETR_OK 0
+#define LDETR_ERR_ARG 1
+#define LDETR_ERR_LAUNCH 2
+#define LDETR_ERR_UNSUPPORTED 3
+
+namespace ldetr {
+
+void set_error(const char* fmt, ...);
+
+inline int check_launch(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        set_error("%s: %s", what, hipGetErrorString(e));
+        return LDETR_ERR_LAUNCH;
+    }
+    return LDETR_OK;
+}
+
+#define LDETR_CHECK(cond, ...)                    \
+    do {                                          \
+        if (!(cond)) {                            \
+            ldetr::set_error(__VA_ARGS__);        \
+            return LDETR_ERR_ARG;                 \
+        }                                         \
+    } while (0)
+
+static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+// Counter-based RNG: splitmix64 finaliser over (seed, element index).
+// The same (seed, idx) pair is evaluated in forward and backward, so dropout
+// masks are regenerated rather than stored.
+__device__ __forceinline__ uint32_t rng_bits(uint64_t seed, uint64_t idx) {
+    uint64_t z = seed + idx * 0x9E3779B97F4A7C15ull + 0x632BE59BD9B4E019ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z = z ^ (z >> 31);
+    return (uint32_t)(z >> 32);
+}
+// keep-scale for dropout: 0 if dropped else 1/(1-p). p_drop in [0,1).
+__device__ __forceinline__ float drop_scale(uint64_t seed, uint64_t idx, float p_drop, float inv_keep) {
+    // 24-bit uniform in [0,1)
+    float u = (float)(rng_bits(seed, idx) >> 8) * (1.0f / 16777216.0f);
+    return (u >= p_drop) ? inv_keep : 0.0f;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+}  // namespace ldetr

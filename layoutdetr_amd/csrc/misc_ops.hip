@@ -1,0 +1,324 @@
+// HBM-bound helper kernels around the contraction engine: fused elementwise + per-(sample, channel)
+// reductions for the modulated-conv / bias_act backward, NHWC max-pool, toRGB backward.
+// All tensors are row-major [rows][C] with C contiguous (NHWC pixels are rows).
+#include "ldetr_common.hpp"
+#include "../../include/ldetr_hip.h"
+
+namespace ldetr {
+
+enum { RR_COLSUM = 0, RR_ACTGRAD = 1, RR_MULRED = 2 };
+
+struct RRParams {
+    const float* a; const float* b; float* out;
+    const float* colv;   // [C]
+    const float* sampv;  // [B][C]
+    float* red1; long red1_bs;
+    float* red2; long red2_bs;
+    long P; int B, C, mode, act, rows_pb;
+    float alpha, gain;
+};
+
+// Block = 256 threads = TQ channel-quads x RL row lanes.  grid = (row chunks, B, channel chunks).
+template <int MODE>
+__global__ __launch_bounds__(256) void rowreduce_kernel(RRParams p) {
+    __shared__ float4 sh1[256];
+    __shared__ float4 sh2[256];
+    const int C4 = p.C >> 2;
+    const int TQ = C4 < 256 ? C4 : 256;
+    const int RL = 256 / TQ;
+    const int tx = threadIdx.x % TQ, ty = threadIdx.x / TQ;
+    const int cq = blockIdx.z * TQ + tx;
+    const int b = blockIdx.y;
+    const bool active = (ty < RL) && (cq < C4);
+    float4 r1 = make_float4(0.f, 0.f, 0.f, 0.f), r2 = r1;
+    if (active) {
+        const int c = cq << 2;
+        float4 cv = make_float4(0.f, 0.f, 0.f, 0.f), sv = make_float4(1.f, 1.f, 1.f, 1.f);
+        if (p.colv) cv = *reinterpret_cast<const float4*>(p.colv + c);
+        if (p.sampv) sv = *reinterpret_cast<const float4*>(p.sampv + (long)b * p.C + c);
+        const long r0 = (long)blockIdx.x * p.rows_pb;
+        const long r1e = min(p.P, r0 + p.rows_pb);
+        for (long r = r0 + ty; r < r1e; r += RL) {
+            const long off = ((long)b * p.P + r) * p.C + c;
+            float4 a = *reinterpret_cast<const float4*>(p.a + off);
+            if (MODE == RR_COLSUM) {
+                r1.x += a.x; r1.y += a.y; r1.z += a.z; r1.w += a.w;
+            } else if (MODE == RR_ACTGRAD) {
+                // a = dy, b = y (saved output).  dv = dy * gain * (y > 0 ? 1 : alpha)   [act 2: lrelu, 1: relu, 0: linear]
+                float4 y = *reinterpret_cast<const float4*>(p.b + off);
+                float4 dv;
+                float gp = p.gain, gn = (p.act == 2) ? p.gain * p.alpha : (p.act == 1 ? 0.f : p.gain);
+                dv.x = a.x * (y.x > 0.f ? gp : gn); dv.y = a.y * (y.y > 0.f ? gp : gn);
+                dv.z = a.z * (y.z > 0.f ? gp : gn); dv.w = a.w * (y.w > 0.f ? gp : gn);
+                if (p.out) *reinterpret_cast<float4*>(p.out + off) = dv;
+                r1.x += dv.x; r1.y += dv.y; r1.z += dv.z; r1.w += dv.w;
+                if (p.red2) {
+                    // pre-activation v = y/gain (y > 0) or y/(gain*alpha); u*d = v - bias; red2 += dv * (v - bias) / d
+                    float ip = 1.f / gp, in = (gn != 0.f) ? 1.f / gn : 0.f;
+                    float vx = y.x * (y.x > 0.f ? ip : in) - cv.x, vy = y.y * (y.y > 0.f ? ip : in) - cv.y;
+                    float vz = y.z * (y.z > 0.f ? ip : in) - cv.z, vw = y.w * (y.w > 0.f ? ip : in) - cv.w;
+                    r2.x += dv.x * vx / sv.x; r2.y += dv.y * vy / sv.y; r2.z += dv.z * vz / sv.z; r2.w += dv.w * vw / sv.w;
+                }
+            } else {  // RR_MULRED: out = a * sampv (optional), red1 += a * b  (optionally / colv-less divisor in red2 slot)
+                float4 x2 = *reinterpret_cast<const float4*>(p.b + off);
+                if (p.out) {
+                    float4 o = make_float4(a.x * sv.x, a.y * sv.y, a.z * sv.z, a.w * sv.w);
+                    *reinterpret_cast<float4*>(p.out + off) = o;
+                }
+                r1.x += a.x * x2.x; r1.y += a.y * x2.y; r1.z += a.z * x2.z; r1.w += a.w * x2.w;
+            }
+        }
+    }
+    sh1[threadIdx.x] = r1; sh2[threadIdx.x] = r2;
+    __syncthreads();
+    if (active && ty == 0) {
+        for (int j = 1; j < RL; j++) {
+            float4 t = sh1[j * TQ + tx]; r1.x += t.x; r1.y += t.y; r1.z += t.z; r1.w += t.w;
+            float4 u = sh2[j * TQ + tx]; r2.x += u.x; r2.y += u.y; r2.z += u.z; r2.w += u.w;
+        }
+        const int c = cq << 2;
+        if (p.red1) {
+            float* d = p.red1 + (long)b * p.red1_bs + c;
+            atomicAdd(d, r1.x); atomicAdd(d + 1, r1.y); atomicAdd(d + 2, r1.z); atomicAdd(d + 3, r1.w);
+        }
+        if (p.red2) {
+            float* d = p.red2 + (long)b * p.red2_bs + c;
+            atomicAdd(d, r2.x); atomicAdd(d + 1, r2.y); atomicAdd(d + 2, r2.z); atomicAdd(d + 3, r2.w);
+        }
+    }
+}
+
+static int launch_rr(RRParams& p, hipStream_t st) {
+    const int C4 = p.C / 4;
+    const int TQ = C4 < 256 ? C4 : 256;
+    const int RL = 256 / TQ;
+    long rows_pb = (long)RL * 16;
+    // keep the grid between ~1k and ~8k blocks
+    long nb = ((p.P + rows_pb - 1) / rows_pb) * p.B * cdiv(C4, TQ);
+    while (nb > 8192) { rows_pb *= 2; nb = ((p.P + rows_pb - 1) / rows_pb) * p.B * cdiv(C4, TQ); }
+    p.rows_pb = (int)rows_pb;
+    dim3 grid((unsigned)((p.P + rows_pb - 1) / rows_pb), p.B, cdiv(C4, TQ));
+    if (p.mode == RR_COLSUM) hipLaunchKernelGGL(rowreduce_kernel<RR_COLSUM>, grid, 256, 0, st, p);
+    else if (p.mode == RR_ACTGRAD) hipLaunchKernelGGL(rowreduce_kernel<RR_ACTGRAD>, grid, 256, 0, st, p);
+    else hipLaunchKernelGGL(rowreduce_kernel<RR_MULRED>, grid, 256, 0, st, p);
+    return check_launch("rowreduce");
+}
+
+// ---------------------------------------------------------------------------------------------
+// 3x3 / stride 2 / pad 1 max-pool on NHWC (torchvision ResNet stem; reference: detr_backbone.py:105).
+struct PoolParams {
+    const float* x; float* y; unsigned char* idx; const float* dy; float* dx;
+    int N, H, W, C, OH, OW;
+};
+
+__global__ __launch_bounds__(256) void maxpool_fwd_kernel(PoolParams p) {
+    const int C4 = p.C >> 2;
+    const long total = (long)p.N * p.OH * p.OW * C4;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        int c = (int)(i % C4) << 2; long t = i / C4;
+        int ox = (int)(t % p.OW); t /= p.OW;
+        int oy = (int)(t % p.OH); int n = (int)(t / p.OH);
+        float4 m = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+        uchar4 mi = make_uchar4(0, 0, 0, 0);
+#pragma unroll
+        for (int kh = 0; kh < 3; kh++) {
+            int y = oy * 2 - 1 + kh;
+            if (y < 0 || y >= p.H) continue;
+#pragma unroll
+            for (int kw = 0; kw < 3; kw++) {
+                int x = ox * 2 - 1 + kw;
+                if (x < 0 || x >= p.W) continue;
+                float4 v = *reinterpret_cast<const float4*>(p.x + (((long)n * p.H + y) * p.W + x) * p.C + c);
+                unsigned char k = (unsigned char)(kh * 3 + kw);
+                if (v.x > m.x || v.x != v.x) { m.x = v.x; mi.x = k; }
+                if (v.y > m.y || v.y != v.y) { m.y = v.y; mi.y = k; }
+                if (v.z > m.z || v.z != v.z) { m.z = v.z; mi.z = k; }
+                if (v.w > m.w || v.w != v.w) { m.w = v.w; mi.w = k; }
+            }
+        }
+        long o = (((long)n * p.OH + oy) * p.OW + ox) * p.C + c;
+        *reinterpret_cast<float4*>(p.y + o) = m;
+        if (p.idx) *reinterpret_cast<uchar4*>(p.idx + o) = mi;
+    }
+}
+
+__global__ __launch_bounds__(256) void maxpool_bwd_kernel(PoolParams p) {
+    const int C4 = p.C >> 2;
+    const long total = (long)p.N * p.H * p.W * C4;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        int c = (int)(i % C4) << 2; long t = i / C4;
+        int x = (int)(t % p.W); t /= p.W;
+        int y = (int)(t % p.H); int n = (int)(t / p.H);
+        float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+        int oy0 = y >> 1, oy1 = (y + 1) >> 1;  // windows with oy*2-1 <= y <= oy*2+1
+        int ox0 = x >> 1, ox1 = (x + 1) >> 1;
+        for (int oy = oy0; oy <= oy1; oy++) {
+            if (oy >= p.OH) continue;
+            for (int ox = ox0; ox <= ox1; ox++) {
+                if (ox >= p.OW) continue;
+                unsigned char k = (unsigned char)((y - (oy * 2 - 1)) * 3 + (x - (ox * 2 - 1)));
+                long o = (((long)n * p.OH + oy) * p.OW + ox) * p.C + c;
+                uchar4 mi = *reinterpret_cast<const uchar4*>(p.idx + o);
+                float4 d = *reinterpret_cast<const float4*>(p.dy + o);
+                if (mi.x == k) g.x += d.x;
+                if (mi.y == k) g.y += d.y;
+                if (mi.z == k) g.z += d.z;
+                if (mi.w == k) g.w += d.w;
+            }
+        }
+        *reinterpret_cast<float4*>(p.dx + (((long)n * p.H + y) * p.W + x) * p.C + c) = g;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// toRGB (1x1 modulated conv to 3 channels, no demodulation) backward:
+//   dx[b,p,c]     = s[b,c] * sum_co dy[b,p,co] * w[co,c]
+//   dws[b,co,c]  += sum_p dy[b,p,co] * x[b,p,c]          (per-sample; host folds in styles / weights)
+//   dbias[co]    += sum_{b,p} dy[b,p,co]
+struct RgbParams {
+    const float* x; const float* dy; const float* w; const float* s;
+    float* dx; float* dws; float* dbias;
+    long P; int B, C, rows_pb;
+};
+
+__global__ __launch_bounds__(256) void torgb_bwd_kernel(RgbParams p) {
+    __shared__ float4 sh[3][256];
+    const int C4 = p.C >> 2;
+    const int TQ = C4 < 256 ? C4 : 256;
+    const int RL = 256 / TQ;
+    const int tx = threadIdx.x % TQ, ty = threadIdx.x / TQ;
+    const int cq = blockIdx.z * TQ + tx;
+    const int b = blockIdx.y;
+    const bool active = (ty < RL) && (cq < C4);
+    float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0, a2 = a0;
+    float db0 = 0.f, db1 = 0.f, db2 = 0.f;
+    if (active) {
+        const int c = cq << 2;
+        const float4 w0 = *reinterpret_cast<const float4*>(p.w + c);
+        const float4 w1 = *reinterpret_cast<const float4*>(p.w + p.C + c);
+        const float4 w2 = *reinterpret_cast<const float4*>(p.w + 2 * p.C + c);
+        const float4 sv = *reinterpret_cast<const float4*>(p.s + (long)b * p.C + c);
+        const long r0 = (long)blockIdx.x * p.rows_pb;
+        const long r1e = min(p.P, r0 + p.rows_pb);
+        for (long r = r0 + ty; r < r1e; r += RL) {
+            const long row = (long)b * p.P + r;
+            const float d0 = p.dy[row * 3], d1 = p.dy[row * 3 + 1], d2 = p.dy[row * 3 + 2];
+            const float4 xv = *reinterpret_cast<const float4*>(p.x + row * p.C + c);
+            float4 o;
+            o.x = sv.x * (d0 * w0.x + d1 * w1.x + d2 * w2.x); o.y = sv.y * (d0 * w0.y + d1 * w1.y + d2 * w2.y);
+            o.z = sv.z * (d0 * w0.z + d1 * w1.z + d2 * w2.z); o.w = sv.w * (d0 * w0.w + d1 * w1.w + d2 * w2.w);
+            *reinterpret_cast<float4*>(p.dx + row * p.C + c) = o;
+            a0.x += d0 * xv.x; a0.y += d0 * xv.y; a0.z += d0 * xv.z; a0.w += d0 * xv.w;
+            a1.x += d1 * xv.x; a1.y += d1 * xv.y; a1.z += d1 * xv.z; a1.w += d1 * xv.w;
+            a2.x += d2 * xv.x; a2.y += d2 * xv.y; a2.z += d2 * xv.z; a2.w += d2 * xv.w;
+            if (cq == 0) { db0 += d0; db1 += d1; db2 += d2; }
+        }
+    }
+    sh[0][threadIdx.x] = a0; sh[1][threadIdx.x] = a1; sh[2][threadIdx.x] = a2;
+    __syncthreads();
+    if (active && ty == 0) {
+        for (int j = 1; j < RL; j++) {
+            float4 t0 = sh[0][j * TQ + tx], t1 = sh[1][j * TQ + tx], t2 = sh[2][j * TQ + tx];
+            a0.x += t0.x; a0.y += t0.y; a0.z += t0.z; a0.w += t0.w;
+            a1.x += t1.x; a1.y += t1.y; a1.z += t1.z; a1.w += t1.w;
+            a2.x += t2.x; a2.y += t2.y; a2.z += t2.z; a2.w += t2.w;
+        }
+        const int c = cq << 2;
+        float* d = p.dws + (long)b * 3 * p.C + c;
+        atomicAdd(d, a0.x); atomicAdd(d + 1, a0.y); atomicAdd(d + 2, a0.z); atomicAdd(d + 3, a0.w);
+        d += p.C;
+        atomicAdd(d, a1.x); atomicAdd(d + 1, a1.y); atomicAdd(d + 2, a1.z); atomicAdd(d + 3, a1.w);
+        d += p.C;
+        atomicAdd(d, a2.x); atomicAdd(d + 1, a2.y); atomicAdd(d + 2, a2.z); atomicAdd(d + 3, a2.w);
+    }
+    if (active && cq == 0 && p.dbias) { atomicAdd(p.dbias, db0); atomicAdd(p.dbias + 1, db1); atomicAdd(p.dbias + 2, db2); }
+}
+
+}  // namespace ldetr
+
+using namespace ldetr;
+
+static int rr_common(RRParams& p, const char* what) {
+    LDETR_CHECK(p.a, "%s: null pointer", what);
+    LDETR_CHECK(p.C % 4 == 0 && p.C > 0, "%s: C must be a positive multiple of 4", what);
+    LDETR_CHECK(p.B > 0 && p.P >= 0, "%s: bad shape", what);
+    return LDETR_OK;
+}
+
+// red[b][c] += sum_p a[b,p,c]   (B = 1 gives a plain column sum).  red must be pre-zeroed by the caller.
+extern "C" int ldetr_colsum_f32(const float* a, float* red, int B, int64_t P, int C, void* stream) {
+    RRParams p; memset(&p, 0, sizeof(p));
+    p.a = a; p.red1 = red; p.red1_bs = C; p.B = B; p.P = P; p.C = C; p.mode = RR_COLSUM;
+    int rc = rr_common(p, "colsum"); if (rc) return rc;
+    if (P == 0) return LDETR_OK;
+    return launch_rr(p, (hipStream_t)stream);
+}
+
+// bias_act first-derivative fused with its reductions (reference: bias_act.py:166-171 does dx then dx.sum()):
+//   dv = dy * gain * (y > 0 ? 1 : alpha)      act: 0 linear, 1 relu, 2 lrelu
+//   dbias[c]     += sum_{b,p} dv
+//   ddemod[b][c] += sum_p dv * (pre(y) - bias[c]) / demod[b][c]      (only when ddemod != NULL)
+extern "C" int ldetr_act_bwd_reduce_f32(const float* dy, const float* y, float* dv, const float* bias, const float* demod,
+                                        float* dbias, float* ddemod, int B, int64_t P, int C, int act, float alpha, float gain,
+                                        void* stream) {
+    RRParams p; memset(&p, 0, sizeof(p));
+    p.a = dy; p.b = y; p.out = dv; p.colv = bias; p.sampv = demod; p.red1 = dbias; p.red1_bs = 0;
+    p.red2 = ddemod; p.red2_bs = C; p.B = B; p.P = P; p.C = C; p.mode = RR_ACTGRAD; p.act = act; p.alpha = alpha; p.gain = gain;
+    int rc = rr_common(p, "act_bwd_reduce"); if (rc) return rc;
+    LDETR_CHECK(y, "act_bwd_reduce: y is required");
+    LDETR_CHECK(!ddemod || demod, "act_bwd_reduce: ddemod needs demod");
+    if (P == 0) return LDETR_OK;
+    return launch_rr(p, (hipStream_t)stream);
+}
+
+//   out[b,p,c] = a[b,p,c] * scale[b][c]   (skipped when out == NULL)
+//   red[b][c] += sum_p a[b,p,c] * x[b,p,c]
+extern "C" int ldetr_mul_reduce_f32(const float* a, const float* x, const float* scale, float* out, float* red,
+                                    int B, int64_t P, int C, void* stream) {
+    RRParams p; memset(&p, 0, sizeof(p));
+    p.a = a; p.b = x; p.out = out; p.sampv = scale; p.red1 = red; p.red1_bs = C; p.B = B; p.P = P; p.C = C; p.mode = RR_MULRED;
+    int rc = rr_common(p, "mul_reduce"); if (rc) return rc;
+    LDETR_CHECK(x, "mul_reduce: x is required");
+    if (P == 0) return LDETR_OK;
+    return launch_rr(p, (hipStream_t)stream);
+}
+
+extern "C" int ldetr_maxpool3x3s2_fwd_f32(const float* x, float* y, unsigned char* idx, int N, int H, int W, int C, void* stream) {
+    LDETR_CHECK(x && y, "maxpool_fwd: null pointer");
+    LDETR_CHECK(C % 4 == 0, "maxpool_fwd: C must be a multiple of 4");
+    PoolParams p; memset(&p, 0, sizeof(p));
+    p.x = x; p.y = y; p.idx = idx; p.N = N; p.H = H; p.W = W; p.C = C; p.OH = (H + 2 - 3) / 2 + 1; p.OW = (W + 2 - 3) / 2 + 1;
+    long total = (long)N * p.OH * p.OW * (C / 4);
+    int grid = (int)((total + 255) / 256); if (grid > 8192) grid = 8192; if (grid < 1) grid = 1;
+    hipLaunchKernelGGL(maxpool_fwd_kernel, grid, 256, 0, (hipStream_t)stream, p);
+    return check_launch("maxpool_fwd");
+}
+
+extern "C" int ldetr_maxpool3x3s2_bwd_f32(const float* dy, const unsigned char* idx, float* dx, int N, int H, int W, int C, void* stream) {
+    LDETR_CHECK(dy && idx && dx, "maxpool_bwd: null pointer");
+    LDETR_CHECK(C % 4 == 0, "maxpool_bwd: C must be a multiple of 4");
+    PoolParams p; memset(&p, 0, sizeof(p));
+    p.dy = dy; p.idx = const_cast<unsigned char*>(idx); p.dx = dx; p.N = N; p.H = H; p.W = W; p.C = C;
+    p.OH = (H + 2 - 3) / 2 + 1; p.OW = (W + 2 - 3) / 2 + 1;
+    long total = (long)N * H * W * (C / 4);
+    int grid = (int)((total + 255) / 256); if (grid > 8192) grid = 8192; if (grid < 1) grid = 1;
+    hipLaunchKernelGGL(maxpool_bwd_kernel, grid, 256, 0, (hipStream_t)stream, p);
+    return check_launch("maxpool_bwd");
+}
+
+// dws [B][3][C] and dbias [3] must be zeroed by the caller.
+extern "C" int ldetr_torgb_bwd_f32(const float* x, const float* dy, const float* w, const float* styles,
+                                   float* dx, float* dws, float* dbias, int B, int64_t P, int C, void* stream) {
+    LDETR_CHECK(x && dy && w && styles && dx && dws, "torgb_bwd: null pointer");
+    LDETR_CHECK(C % 4 == 0, "torgb_bwd: C must be a multiple of 4");
+    RgbParams p; memset(&p, 0, sizeof(p));
+    p.x = x; p.dy = dy; p.w = w; p.s = styles; p.dx = dx; p.dws = dws; p.dbias = dbias; p.B = B; p.P = P; p.C = C;
+    const int C4 = C / 4; const int TQ = C4 < 256 ? C4 : 256; const int RL = 256 / TQ;
+    long rows_pb = (long)RL * 16;
+    long nb = ((P + rows_pb - 1) / rows_pb) * B * cdiv(C4, TQ);
+    while (nb > 8192) { rows_pb *= 2; nb = ((P + rows_pb - 1) / rows_pb) * B * cdiv(C4, TQ); }
+    p.rows_pb = (int)rows_pb;
+    dim3 grid((unsigned)((P + rows_pb - 1) / rows_pb), B, cdiv(C4, TQ));
+    hipLaunchKernelGGL(torgb_bwd_kernel, grid, 256, 0, (hipStream_t)stream, p);
+    return check_launch("torgb_bwd");
+}

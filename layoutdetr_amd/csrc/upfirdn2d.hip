@@ -1,0 +1,183 @@
+// upfirdn2d: zero-insert upsample -> pad/crop -> 2-D FIR -> decimate, per (n, c) plane.
+// Replaces the reference plugin entry `upfirdn2d_plugin.upfirdn2d`
+// (torch_utils/ops/upfirdn2d.cpp:17-99, kernels torch_utils/ops/upfirdn2d.cu:30-201).
+// Stride-aware in x and y (contiguous NCHW and channels_last both run without a copy).
+// HBM-bound: every input element is read once from HBM (neighbour re-reads hit L1/LDS) and
+// every output element written once.
+#include "ldetr_common.hpp"
+#include "../../include/ldetr_hip.h"
+
+namespace ldetr {
+
+struct UpfirdnParams {
+    const float* x;
+    const float* f;
+    float* y;
+    // optional fused epilogue (used by the StyleGAN2 up-layers): y = lrelu(v + bias[c]) * gain2
+    const float* bias;
+    float act_alpha, act_gain;
+    int has_act;
+    int upx, upy, downx, downy, padx0, pady0, flip;
+    float gain;
+    int inW, inH, C, N;
+    long xs_w, xs_h, xs_c, xs_n;
+    int fw, fh;
+    long fs_w, fs_h;
+    int outW, outH;
+    long ys_w, ys_h, ys_c, ys_n;
+};
+
+// floor(a / b) for b > 0 (C division truncates toward zero).
+__device__ __forceinline__ int floor_div(int a, int b) {
+    int q = a / b;
+    return q - ((a - q * b) < 0 ? 1 : 0);
+}
+
+#define LDETR_MAX_TAPS 1024
+
+// Filter staged to LDS with flip resolved: fl[ky*fw + kx] is the tap applied to the input
+// sample that sits ky rows / kx columns *in filter index order of the reference inner loop*.
+__device__ __forceinline__ void stage_filter(const UpfirdnParams& p, float* fl) {
+    for (int i = threadIdx.x; i < p.fw * p.fh; i += blockDim.x) {
+        int ky = i / p.fw, kx = i - ky * p.fw;
+        fl[i] = p.f[kx * p.fs_w + ky * p.fs_h];
+    }
+    __syncthreads();
+}
+
+__device__ __forceinline__ float epilogue(const UpfirdnParams& p, float v, int c) {
+    v *= p.gain;
+    if (p.has_act) {
+        if (p.bias) v += p.bias[c];
+        v = (v > 0.f ? v : v * p.act_alpha) * p.act_gain;
+    }
+    return v;
+}
+
+// One output element per thread; threads run along outX (contiguous for NCHW outputs).
+__global__ __launch_bounds__(256) void upfirdn2d_planar_kernel(UpfirdnParams p) {
+    __shared__ float fl[LDETR_MAX_TAPS];
+    stage_filter(p, fl);
+    const long total = (long)p.N * p.C * p.outH * p.outW;
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += stride) {
+        int outX = (int)(idx % p.outW);
+        long t = idx / p.outW;
+        int outY = (int)(t % p.outH);
+        t /= p.outH;
+        int c = (int)(t % p.C);
+        int n = (int)(t / p.C);
+
+        int midY = outY * p.downy + p.upy - 1 - p.pady0;
+        int inY = min(max(floor_div(midY, p.upy), 0), p.inH);
+        int h = min(max(floor_div(midY + p.fh, p.upy), 0), p.inH) - inY;
+        int filterY = midY + p.fh - (inY + 1) * p.upy;
+        if (p.flip) filterY = p.fh - 1 - filterY;
+        int midX = outX * p.downx + p.upx - 1 - p.padx0;
+        int inX = min(max(floor_div(midX, p.upx), 0), p.inW);
+        int w = min(max(floor_div(midX + p.fw, p.upx), 0), p.inW) - inX;
+        int filterX = midX + p.fw - (inX + 1) * p.upx;
+        if (p.flip) filterX = p.fw - 1 - filterX;
+        int stepX = p.flip ? p.upx : -p.upx;
+        int stepY = p.flip ? p.upy : -p.upy;
+
+        const float* xp = p.x + inX * p.xs_w + inY * p.xs_h + c * p.xs_c + n * p.xs_n;
+        float v = 0.f;
+        for (int yy = 0; yy < h; yy++) {
+            int fy = filterY + yy * stepY;
+            for (int xx = 0; xx < w; xx++) {
+                int fx = filterX + xx * stepX;
+                v += xp[xx * p.xs_w + yy * p.xs_h] * fl[fy * p.fw + fx];
+            }
+        }
+        p.y[outX * p.ys_w + outY * p.ys_h + c * p.ys_c + n * p.ys_n] = epilogue(p, v, c);
+    }
+}
+
+// channels_last: one float4 of channels per thread; threads run along C then outX.
+__global__ __launch_bounds__(256) void upfirdn2d_nhwc4_kernel(UpfirdnParams p) {
+    __shared__ float fl[LDETR_MAX_TAPS];
+    stage_filter(p, fl);
+    const int C4 = p.C >> 2;
+    const long total = (long)p.N * p.outH * p.outW * C4;
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += stride) {
+        int c = (int)(idx % C4) << 2;
+        long t = idx / C4;
+        int outX = (int)(t % p.outW);
+        t /= p.outW;
+        int outY = (int)(t % p.outH);
+        int n = (int)(t / p.outH);
+
+        int midY = outY * p.downy + p.upy - 1 - p.pady0;
+        int inY = min(max(floor_div(midY, p.upy), 0), p.inH);
+        int h = min(max(floor_div(midY + p.fh, p.upy), 0), p.inH) - inY;
+        int filterY = midY + p.fh - (inY + 1) * p.upy;
+        if (p.flip) filterY = p.fh - 1 - filterY;
+        int midX = outX * p.downx + p.upx - 1 - p.padx0;
+        int inX = min(max(floor_div(midX, p.upx), 0), p.inW);
+        int w = min(max(floor_div(midX + p.fw, p.upx), 0), p.inW) - inX;
+        int filterX = midX + p.fw - (inX + 1) * p.upx;
+        if (p.flip) filterX = p.fw - 1 - filterX;
+        int stepX = p.flip ? p.upx : -p.upx;
+        int stepY = p.flip ? p.upy : -p.upy;
+
+        const float* xp = p.x + inX * p.xs_w + inY * p.xs_h + c + n * p.xs_n;
+        float4 v = make_float4(0, 0, 0, 0);
+        for (int yy = 0; yy < h; yy++) {
+            int fy = filterY + yy * stepY;
+            for (int xx = 0; xx < w; xx++) {
+                float fv = fl[fy * p.fw + filterX + xx * stepX];
+                float4 xv = *reinterpret_cast<const float4*>(xp + xx * p.xs_w + yy * p.xs_h);
+                v.x += xv.x * fv; v.y += xv.y * fv; v.z += xv.z * fv; v.w += xv.w * fv;
+            }
+        }
+        float4 o;
+        o.x = epilogue(p, v.x, c); o.y = epilogue(p, v.y, c + 1);
+        o.z = epilogue(p, v.z, c + 2); o.w = epilogue(p, v.w, c + 3);
+        *reinterpret_cast<float4*>(p.y + outX * p.ys_w + outY * p.ys_h + c + n * p.ys_n) = o;
+    }
+}
+
+}  // namespace ldetr
+
+extern "C" int ldetr_upfirdn2d_f32(const float* x, const float* f, float* y,
+                                   int N, int C, int inH, int inW, const int64_t* x_strides_nchw,
+                                   int fh, int fw, int64_t f_stride_h, int64_t f_stride_w,
+                                   int upx, int upy, int downx, int downy,
+                                   int padx0, int padx1, int pady0, int pady1, int flip, float gain,
+                                   int outH, int outW, const int64_t* y_strides_nchw,
+                                   const float* act_bias, int has_act, float act_alpha, float act_gain,
+                                   void* stream) {
+    using namespace ldetr;
+    LDETR_CHECK(x && f && y, "upfirdn2d: null pointer");
+    LDETR_CHECK(N > 0 && C > 0 && inH > 0 && inW > 0, "upfirdn2d: x has zero size");
+    LDETR_CHECK(fh >= 1 && fw >= 1, "upfirdn2d: f must be at least 1x1");
+    LDETR_CHECK(fh * fw <= LDETR_MAX_TAPS, "upfirdn2d: filter larger than %d taps is unsupported", LDETR_MAX_TAPS);
+    LDETR_CHECK(upx >= 1 && upy >= 1, "upfirdn2d: upsampling factor must be at least 1");
+    LDETR_CHECK(downx >= 1 && downy >= 1, "upfirdn2d: downsampling factor must be at least 1");
+    int eW = (inW * upx + padx0 + padx1 - fw + downx) / downx;
+    int eH = (inH * upy + pady0 + pady1 - fh + downy) / downy;
+    LDETR_CHECK(eW >= 1 && eH >= 1, "upfirdn2d: output must be at least 1x1");
+    LDETR_CHECK(eW == outW && eH == outH, "upfirdn2d: output size mismatch (expected %dx%d)", eH, eW);
+    UpfirdnParams p;
+    p.x = x; p.f = f; p.y = y;
+    p.bias = act_bias; p.has_act = has_act; p.act_alpha = act_alpha; p.act_gain = act_gain;
+    p.upx = upx; p.upy = upy; p.downx = downx; p.downy = downy; p.padx0 = padx0; p.pady0 = pady0;
+    p.flip = flip ? 1 : 0; p.gain = gain;
+    p.inW = inW; p.inH = inH; p.C = C; p.N = N;
+    p.xs_n = x_strides_nchw[0]; p.xs_c = x_strides_nchw[1]; p.xs_h = x_strides_nchw[2]; p.xs_w = x_strides_nchw[3];
+    p.fw = fw; p.fh = fh; p.fs_w = f_stride_w; p.fs_h = f_stride_h;
+    p.outW = outW; p.outH = outH;
+    p.ys_n = y_strides_nchw[0]; p.ys_c = y_strides_nchw[1]; p.ys_h = y_strides_nchw[2]; p.ys_w = y_strides_nchw[3];
+    hipStream_t st = (hipStream_t)stream;
+    bool nhwc4 = (p.xs_c == 1 && p.ys_c == 1 && (C % 4 == 0) && (((uintptr_t)x | (uintptr_t)y) & 15) == 0 &&
+                  p.xs_w % 4 == 0 && p.xs_h % 4 == 0 && p.xs_n % 4 == 0 && p.ys_w % 4 == 0 && p.ys_h % 4 == 0 &&
+                  p.ys_n % 4 == 0);
+    long total = nhwc4 ? (long)N * outH * outW * (C / 4) : (long)N * C * outH * outW;
+    int grid = (int)((total + 255) / 256);
+    if (grid > 256 * 32) grid = 256 * 32;
+    if (nhwc4) hipLaunchKernelGGL(upfirdn2d_nhwc4_kernel, grid, 256, 0, st, p);
+    else hipLaunchKernelGGL(upfirdn2d_planar_kernel, grid, 256, 0, st, p);
+    return check_launch("upfirdn2d");
+}

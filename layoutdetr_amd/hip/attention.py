@@ -1,0 +1,81 @@
+"""Fused attention core + multi-head-attention block on the HIP kernels.
+
+`mha_forward` reproduces nn.MultiheadAttention(d, h, dropout) as the reference calls it
+(training/detr_transformer.py:208-209, 273-274, 277-280): packed in_proj_weight [3d, d], scale
+1/sqrt(dh) on q, boolean key_padding_mask -> -inf, dropout on the probabilities, out_proj; the
+head-averaged attention weights the reference discards (`[0]`) are never formed.
+Layout is batch-first: activations are [B*L, d] row-major (row = b*L + position).
+"""
+import math
+
+import torch
+
+from . import core
+from .linear import linear
+
+
+class _AttnFn(torch.autograd.Function):
+    """q: [B*Lq, >=d] view, k/v: [B*Lk, >=d] views (unit inner stride, arbitrary row stride)."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, kpm, B, H, Lq, Lk, p_drop):
+        core.require_gpu(q, k, v, kpm)
+        dh = q.shape[1] // H
+        assert q.stride(1) == 1 and k.stride(1) == 1 and v.stride(1) == 1
+        d = H * dh
+        out = torch.empty((B * Lq, d), device=q.device, dtype=torch.float32)
+        lse = torch.empty((B * H * Lq,), device=q.device, dtype=torch.float32)
+        seed = core.next_seed() if p_drop > 0 else 0
+        scale = 1.0 / math.sqrt(dh)
+        core.check(core.lib().ldetr_attention_fwd_f32(
+            core.ptr(q), q.stride(0), core.ptr(k), k.stride(0), core.ptr(v), v.stride(0), core.ptr(kpm),
+            core.ptr(out), d, core.ptr(lse), B, H, Lq, Lk, dh, scale, p_drop, seed, core.stream()), 'attention_fwd')
+        ctx.save_for_backward(q, k, v, kpm, out, lse)
+        ctx.cfg = (B, H, Lq, Lk, dh, scale, p_drop, seed)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        q, k, v, kpm, out, lse = ctx.saved_tensors
+        B, H, Lq, Lk, dh, scale, p_drop, seed = ctx.cfg
+        d = H * dh
+        dout = core.f32c(dout)
+        dq = torch.empty((B * Lq, d), device=q.device, dtype=torch.float32)
+        dk = torch.empty((B * Lk, d), device=q.device, dtype=torch.float32)
+        dv = torch.empty((B * Lk, d), device=q.device, dtype=torch.float32)
+        core.check(core.lib().ldetr_attention_bwd_f32(
+            core.ptr(q), q.stride(0), core.ptr(k), k.stride(0), core.ptr(v), v.stride(0), core.ptr(kpm),
+            core.ptr(out), d, core.ptr(lse), core.ptr(dout), d, core.ptr(dq), d, core.ptr(dk), d, core.ptr(dv), d,
+            B, H, Lq, Lk, dh, scale, p_drop, seed, core.stream()), 'attention_bwd')
+        return dq, dk, dv, None, None, None, None, None, None
+
+
+def attention(q, k, v, key_padding_mask, B, H, Lq, Lk, p_drop=0.0):
+    kpm = None
+    if key_padding_mask is not None:
+        kpm = key_padding_mask.to(torch.uint8).contiguous()
+    return _AttnFn.apply(q, k, v, kpm, B, H, Lq, Lk, p_drop)
+
+
+def mha_forward(query, key, value, in_proj_weight, in_proj_bias, out_w, out_b, nhead, B, Lq, Lk,
+                key_padding_mask=None, p_drop=0.0, same_qk=False, same_qkv=False):
+    """query: [B*Lq, d]; key/value: [B*Lk, d].  Returns [B*Lq, d] (before the caller's residual/dropout/LN).
+
+    same_qkv: query, key and value are one tensor  -> one packed [3d] projection (decoder self-attention).
+    same_qk:  query and key are one tensor          -> one [2d] projection + one [d] projection (encoder self).
+    """
+    d = query.shape[1]
+    W, bvec = in_proj_weight, in_proj_bias
+    if same_qkv:
+        qkv = linear(query, W, bvec)
+        q, k, v = qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:]
+    elif same_qk:
+        qk = linear(query, W[:2 * d], bvec[:2 * d])
+        q, k = qk[:, :d], qk[:, d:]
+        v = linear(value, W[2 * d:], bvec[2 * d:])
+    else:
+        q = linear(query, W[:d], bvec[:d])
+        k = linear(key, W[d:2 * d], bvec[d:2 * d])
+        v = linear(value, W[2 * d:], bvec[2 * d:])
+    o = attention(q, k, v, key_padding_mask, B, nhead, Lq, Lk, p_drop)
+    return linear(o, out_w, out_b)

@@ -1,0 +1,135 @@
+"""NHWC implicit-GEMM convolutions for the ResNet-50 trunk and input_proj.
+
+y = act( conv(x, w) * scale[c] + shift[c] (+ residual) ):  FrozenBatchNorm2d (a fixed affine,
+training/detr_backbone.py:55-65), the bottleneck residual add and the ReLU are the conv epilogue, so
+each conv block is one launch (the reference runs conv + 3-4 elementwise kernels).
+Activations are [N, H, W, C] contiguous tensors; weights are the usual [O, I, KH, KW] parameters held
+in channels_last memory (= OHWI contiguous) so state_dict keys/shapes stay torchvision-compatible.
+"""
+import ctypes
+
+import torch
+
+from . import core
+from .core import ACT_NONE, ACT_RELU
+from .linear import act_backward
+
+
+def weight_ohwi(w):
+    """[O, I, KH, KW] parameter -> contiguous [O, KH, KW, I] view (copy only if not channels_last)."""
+    v = w.permute(0, 2, 3, 1)
+    return v if v.is_contiguous() else v.contiguous()
+
+
+def _grad_to_oihw(dw_ohwi):
+    return dw_ohwi.permute(0, 3, 1, 2)  # logical OIHW, channels_last strides (matches the parameter layout)
+
+
+class _ConvFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, scale, shift, residual, stride, pad, relu, x_is_nchw):
+        core.require_gpu(x, weight, scale, shift, residual)
+        w = core.f32c(weight_ohwi(weight))
+        O, KH, KW, I = w.shape
+        if x_is_nchw:
+            xt = core.tensor4_nchw(x)
+            N, H, W = x.shape[0], x.shape[2], x.shape[3]
+        else:
+            x = core.f32c(x)
+            xt = core.tensor4_nhwc(x)
+            N, H, W = x.shape[0], x.shape[1], x.shape[2]
+        OH = (H + 2 * pad - KH) // stride + 1
+        OW = (W + 2 * pad - KW) // stride + 1
+        y = torch.empty((N, OH, OW, O), device=x.device, dtype=torch.float32)
+        res = core.f32c(residual) if residual is not None else None
+        sc = core.f32c(scale) if scale is not None else None
+        sh = core.f32c(shift) if shift is not None else None
+        ep = core.epilogue(col_scale=sc, col_bias=sh, residual=res, act=ACT_RELU if relu else ACT_NONE)
+        core.check(core.lib().ldetr_conv2d_fwd_f32(
+            core.ptr(x), ctypes.byref(xt), core.ptr(w), O, KH, KW, stride, pad, core.ptr(y), O, OH, OW, None, 0,
+            ctypes.byref(ep), core.stream()), 'conv2d_fwd')
+        ctx.save_for_backward(x, w, sc, y if relu else None)
+        ctx.cfg = (stride, pad, relu, x_is_nchw, residual is not None, shift is not None, (N, H, W, I))
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, sc, y = ctx.saved_tensors
+        stride, pad, relu, x_is_nchw, has_res, has_shift, (N, H, W, I) = ctx.cfg
+        O, KH, KW, _ = w.shape
+        dy = core.f32c(dy)
+        _, OH, OW, _ = dy.shape
+        need_x, need_w = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        need_shift = has_shift and ctx.needs_input_grad[3]
+        need_res = has_res and ctx.needs_input_grad[4]
+        dy2 = dy.reshape(-1, O)
+        if relu:
+            dpre2, dshift, _ = act_backward(dy2, y.reshape(-1, O), ACT_RELU, 0.0, 1.0, need_shift)
+        else:
+            dpre2 = dy2
+            dshift = core.colsum(dpre2).reshape(-1) if need_shift else None
+        dpre = dpre2.reshape(N, OH, OW, O)
+        dyt = core.tensor4_nhwc(dpre)
+        dx = dw = None
+        if need_x:
+            if x_is_nchw:
+                raise RuntimeError('conv2d: gradient w.r.t. an NCHW image input is not implemented (never needed on the hot path)')
+            dx = torch.empty((N, H, W, I), device=dy.device, dtype=torch.float32)
+            core.check(core.lib().ldetr_conv2d_bwd_data_f32(
+                core.ptr(dpre), ctypes.byref(dyt), core.ptr(w), I, KH, KW, stride, pad, core.ptr(dx), I, H, W,
+                core.ptr(sc), 0, None, core.stream()), 'conv2d_bwd_data')
+        if need_w:
+            dw_ohwi = torch.empty((O, KH, KW, I), device=dy.device, dtype=torch.float32)
+            xt = core.tensor4_nchw(x) if x_is_nchw else core.tensor4_nhwc(x)
+            Kpix = N * OH * OW
+            vec = (not x_is_nchw) and I % 4 == 0
+            tiles = (KH * KW if vec else 1) * ((O + 63) // 64) * (((I if vec else KH * KW * I) + 63) // 64)
+            sk = core.pick_splitk(tiles, Kpix, target=512, min_k=512)
+            if sc is not None and not vec:
+                # scalar-gather path has no operand scale: fold the BN scale into dy first
+                dpre_s = dpre * sc
+                dyt_s = core.tensor4_nhwc(dpre_s)
+                core.check(core.lib().ldetr_conv2d_bwd_weight_f32(
+                    core.ptr(x), ctypes.byref(xt), core.ptr(dpre_s), ctypes.byref(dyt_s), core.ptr(dw_ohwi), KH, KW,
+                    stride, pad, sk, None, 0, None, 0, core.stream()), 'conv2d_bwd_weight')
+            else:
+                core.check(core.lib().ldetr_conv2d_bwd_weight_f32(
+                    core.ptr(x), ctypes.byref(xt), core.ptr(dpre), ctypes.byref(dyt), core.ptr(dw_ohwi), KH, KW, stride,
+                    pad, sk, None, 0, core.ptr(sc), 0, core.stream()), 'conv2d_bwd_weight')
+            dw = _grad_to_oihw(dw_ohwi)
+        dres = dpre if need_res else None
+        return dx, dw, None, dshift, dres, None, None, None, None
+
+
+def conv2d_nhwc(x, weight, scale=None, shift=None, residual=None, stride=1, pad=0, relu=False, x_is_nchw=False):
+    return _ConvFn.apply(x, weight, scale, shift, residual, stride, pad, relu, x_is_nchw)
+
+
+class _MaxPoolFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        core.require_gpu(x)
+        x = core.f32c(x)
+        N, H, W, C = x.shape
+        OH, OW = (H + 2 - 3) // 2 + 1, (W + 2 - 3) // 2 + 1
+        y = torch.empty((N, OH, OW, C), device=x.device, dtype=torch.float32)
+        idx = torch.empty((N, OH, OW, C), device=x.device, dtype=torch.uint8)
+        core.check(core.lib().ldetr_maxpool3x3s2_fwd_f32(core.ptr(x), core.ptr(y), core.ptr(idx), N, H, W, C,
+                                                          core.stream()), 'maxpool_fwd')
+        ctx.save_for_backward(idx)
+        ctx.shape = (N, H, W, C)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        idx, = ctx.saved_tensors
+        N, H, W, C = ctx.shape
+        dy = core.f32c(dy)
+        dx = torch.empty((N, H, W, C), device=dy.device, dtype=torch.float32)
+        core.check(core.lib().ldetr_maxpool3x3s2_bwd_f32(core.ptr(dy), core.ptr(idx), core.ptr(dx), N, H, W, C,
+                                                          core.stream()), 'maxpool_bwd')
+        return dx
+
+
+def maxpool3x3s2_nhwc(x):
+    return _MaxPoolFn.apply(x)

@@ -1,0 +1,126 @@
+"""Thin host-side plumbing between torch tensors (device memory + streams only) and the C ABI."""
+import ctypes
+
+import torch
+
+from .. import _lib
+from .._lib import Epilogue, Tensor4
+
+ACT_NONE, ACT_RELU, ACT_LRELU = 0, 1, 2
+
+_seed_counter = [0x5EED]
+
+
+def lib():
+    return _lib.load()
+
+
+def check(rc, what=''):
+    _lib.check(rc, what)
+
+
+def require_gpu(*tensors):
+    for t in tensors:
+        if t is not None and t.device.type != 'cuda':
+            raise RuntimeError('layoutdetr_amd ops require tensors in GPU memory (no CPU fallback); got device '
+                               f'{t.device}')
+
+
+def stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t):
+    if t is None:
+        return None
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def f32c(t):
+    """fp32 + contiguous (no copy when already so)."""
+    if t is None:
+        return None
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t.contiguous()
+
+
+def next_seed():
+    """Per-launch dropout seed derived from torch's CPU generator (so torch.manual_seed controls it)."""
+    _seed_counter[0] += 1
+    base = int(torch.initial_seed()) & 0xFFFFFFFF
+    return ((base << 32) ^ (_seed_counter[0] * 0x9E3779B1)) & 0xFFFFFFFFFFFFFFFF
+
+
+def tensor4_nhwc(x):
+    """x: [N, H, W, C] tensor (any strides) -> ldetr_tensor4 describing it."""
+    N, H, W, C = x.shape
+    sn, sh, sw, sc = x.stride()
+    return Tensor4(N, C, H, W, sn, sc, sh, sw)
+
+
+def tensor4_nchw(x):
+    """x: [N, C, H, W] tensor (any strides)."""
+    N, C, H, W = x.shape
+    sn, sc, sh, sw = x.stride()
+    return Tensor4(N, C, H, W, sn, sc, sh, sw)
+
+
+def epilogue(alpha=1.0, col_scale=None, col_bias=None, samp_scale=None, residual=None, act=ACT_NONE, act_alpha=0.0,
+             act_gain=1.0, mask_src=None, mask_mode=0, out_scale=1.0, p_drop=0.0, seed=0, accumulate=False):
+    ep = Epilogue()
+    ep.alpha = alpha
+    ep.col_scale = col_scale.data_ptr() if col_scale is not None else None
+    ep.col_bias = col_bias.data_ptr() if col_bias is not None else None
+    if samp_scale is not None:
+        ep.samp_scale = samp_scale.data_ptr()
+        ep.samp_ld = samp_scale.stride(0)
+    if residual is not None:
+        ep.residual = residual.data_ptr()
+        ep.ldr = residual.shape[-1]
+    ep.act = act
+    ep.act_alpha = act_alpha
+    ep.act_gain = act_gain
+    if mask_src is not None:
+        ep.mask_src = mask_src.data_ptr()
+        ep.ldm = mask_src.shape[-1]
+    ep.mask_mode = mask_mode
+    ep.out_scale = out_scale
+    ep.p_drop = p_drop
+    ep.seed = seed
+    ep.accumulate = 1 if accumulate else 0
+    return ep
+
+
+def gemm(A, B, ta, tb, M, N, K, out=None, ep=None, splitk=1, pix_per_sample=0, lda=None, ldb=None):
+    """C[M,N] = op(A) @ op(B); see ldetr_gemm_f32.  A/B are 2-D fp32 device tensors (row-major, unit inner stride)."""
+    require_gpu(A, B)
+    if out is None:
+        out = (torch.zeros if splitk > 1 else torch.empty)((M, N), device=A.device, dtype=torch.float32)
+    elif splitk > 1 and not (ep is not None and ep.accumulate):
+        out.zero_()
+    lda = A.stride(0) if lda is None else lda
+    ldb = B.stride(0) if ldb is None else ldb
+    check(lib().ldetr_gemm_f32(ptr(A), lda, int(ta), ptr(B), ldb, int(tb), ptr(out), out.stride(0), M, N, K, splitk,
+                               ctypes.byref(ep) if ep is not None else None, pix_per_sample, stream()), 'gemm')
+    return out
+
+
+def colsum(a2d, B=1):
+    """a2d: [B*P, C] -> [B, C] column sums per group of P rows."""
+    require_gpu(a2d)
+    R, C = a2d.shape
+    red = torch.zeros((B, C), device=a2d.device, dtype=torch.float32)
+    if C % 4 != 0:
+        # tiny ragged widths (e.g. 3 RGB channels): host reduction of a [R, C] view
+        return a2d.reshape(B, R // B, C).sum(1)
+    check(lib().ldetr_colsum_f32(ptr(a2d), ptr(red), B, R // B, C, stream()), 'colsum')
+    return red
+
+
+def pick_splitk(tiles, K, target=512, min_k=256):
+    """Choose a split-K factor so a reduction-heavy GEMM fills the 256 CUs."""
+    s = 1
+    while tiles * s < target and K // (s * 2) >= min_k and s < 256:
+        s *= 2
+    return s

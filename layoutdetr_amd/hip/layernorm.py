@@ -1,0 +1,53 @@
+"""y = LayerNorm(x + dropout(residual)) fused into one forward and one backward launch.
+Reference chain: training/detr_transformer.py:210-214 / 275-285 (post-norm blocks, eps 1e-5)."""
+import torch
+
+from . import core
+
+
+class _AddLnFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, r, gamma, beta, eps, p_drop):
+        core.require_gpu(x, r, gamma, beta)
+        D = x.shape[-1]
+        x2 = core.f32c(x.reshape(-1, D))
+        r2 = core.f32c(r.reshape(-1, D)) if r is not None else None
+        g, b = core.f32c(gamma), core.f32c(beta)
+        rows = x2.shape[0]
+        y = torch.empty_like(x2)
+        z = torch.empty_like(x2) if r2 is not None else x2
+        mean = torch.empty(rows, device=x.device, dtype=torch.float32)
+        rstd = torch.empty(rows, device=x.device, dtype=torch.float32)
+        seed = core.next_seed() if (p_drop > 0 and r2 is not None) else 0
+        core.check(core.lib().ldetr_layernorm_fwd_f32(
+            core.ptr(x2), core.ptr(r2), core.ptr(g), core.ptr(b), core.ptr(y), core.ptr(z) if r2 is not None else None,
+            core.ptr(mean), core.ptr(rstd), rows, D, eps, p_drop if r2 is not None else 0.0, seed, core.stream()),
+            'layernorm_fwd')
+        ctx.save_for_backward(z, mean, rstd, g)
+        ctx.cfg = (x.shape, r is not None, p_drop if r2 is not None else 0.0, seed, D)
+        return y.reshape(x.shape)
+
+    @staticmethod
+    def backward(ctx, dy):
+        z, mean, rstd, g = ctx.saved_tensors
+        xshape, has_r, p_drop, seed, D = ctx.cfg
+        dy2 = core.f32c(dy.reshape(-1, D))
+        rows = dy2.shape[0]
+        need_x, need_r = ctx.needs_input_grad[0], has_r and ctx.needs_input_grad[1]
+        need_g = ctx.needs_input_grad[2] or ctx.needs_input_grad[3]
+        dx = torch.empty_like(dy2)
+        dr = None
+        if need_r:
+            dr = torch.empty_like(dy2) if p_drop > 0 else dx
+        dgamma = torch.zeros(D, device=dy2.device, dtype=torch.float32) if need_g else None
+        dbeta = torch.zeros(D, device=dy2.device, dtype=torch.float32) if need_g else None
+        core.check(core.lib().ldetr_layernorm_bwd_f32(
+            core.ptr(dy2), core.ptr(z), core.ptr(mean), core.ptr(rstd), core.ptr(g), core.ptr(dx),
+            core.ptr(dr) if (need_r and p_drop > 0) else None, core.ptr(dgamma), core.ptr(dbeta), rows, D, p_drop, seed,
+            core.stream()), 'layernorm_bwd')
+        return (dx.reshape(xshape) if need_x else None, dr.reshape(xshape) if need_r else None, dgamma, dbeta, None, None)
+
+
+def add_layernorm(x, residual, gamma, beta, eps=1e-5, p_drop=0.0):
+    """LayerNorm(x + dropout(residual)); residual may be None (plain LayerNorm)."""
+    return _AddLnFn.apply(x, residual, gamma, beta, eps, p_drop)

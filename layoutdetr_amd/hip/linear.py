@@ -1,0 +1,79 @@
+"""nn.Linear-shaped contractions on the f32 MFMA GEMM engine (forward, dX, dW, fused bias/act/dropout).
+
+Replaces ATen addmm/matmul behind every nn.Linear on the hot path: FFN 256<->2048
+(training/detr_transformer.py:187-189,212), MLP heads (training/networks_detr.py:50-62) and
+FullyConnectedLayer (training/networks_stylegan2.py:117-123).
+"""
+import ctypes
+
+import torch
+
+from . import core
+from .core import ACT_LRELU, ACT_NONE, ACT_RELU
+
+
+def act_backward(dy2, y2, act, act_alpha, act_gain, want_dbias, bias=None, demod=None, want_ddemod=False, B=1):
+    """dv = dy * gain * dact(y); optional fused reductions.  2-D [rows, C] tensors."""
+    R, C = dy2.shape
+    if C % 4 != 0:
+        if act == ACT_NONE:
+            dv = dy2 * act_gain if act_gain != 1.0 else dy2
+        else:
+            neg = 0.0 if act == ACT_RELU else act_alpha
+            dv = dy2 * torch.where(y2 > 0, act_gain, act_gain * neg)
+        return dv, (dv.sum(0) if want_dbias else None), None
+    dv = torch.empty_like(dy2)
+    dbias = torch.zeros(C, device=dy2.device, dtype=torch.float32) if want_dbias else None
+    ddemod = torch.zeros((B, C), device=dy2.device, dtype=torch.float32) if want_ddemod else None
+    core.check(core.lib().ldetr_act_bwd_reduce_f32(
+        core.ptr(dy2), core.ptr(y2), core.ptr(dv), core.ptr(bias), core.ptr(demod), core.ptr(dbias), core.ptr(ddemod),
+        B, R // B, C, act, act_alpha, act_gain, core.stream()), 'act_bwd_reduce')
+    return dv, dbias, ddemod
+
+
+class _LinearFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, act, act_alpha, act_gain, p_drop, wscale):
+        core.require_gpu(x, weight, bias)
+        N, K = weight.shape
+        x2 = core.f32c(x.reshape(-1, K))
+        w = core.f32c(weight)
+        b = core.f32c(bias) if bias is not None else None
+        M = x2.shape[0]
+        seed = core.next_seed() if p_drop > 0 else 0
+        ep = core.epilogue(alpha=wscale, col_bias=b, act=act, act_alpha=act_alpha, act_gain=act_gain, p_drop=p_drop,
+                           seed=seed)
+        y = core.gemm(x2, w, 0, 0, M, N, K, ep=ep)
+        ctx.save_for_backward(x2, w, y if act != ACT_NONE else None)
+        ctx.cfg = (act, act_alpha, act_gain, p_drop, wscale, bias is not None, x.shape)
+        if p_drop > 0 and act != ACT_RELU:
+            raise RuntimeError('linear: fused dropout is only defined after relu (FFN hidden layer)')
+        return y.reshape(*x.shape[:-1], N)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, w, y = ctx.saved_tensors
+        act, act_alpha, act_gain, p_drop, wscale, has_bias, xshape = ctx.cfg
+        N, K = w.shape
+        M = x2.shape[0]
+        dy2 = core.f32c(dy.reshape(-1, N))
+        need_x, need_w, need_b = ctx.needs_input_grad[0], ctx.needs_input_grad[1], has_bias and ctx.needs_input_grad[2]
+        if act != ACT_NONE:
+            gain = act_gain / (1.0 - p_drop) if p_drop > 0 else act_gain
+            dpre, db, _ = act_backward(dy2, y, act, act_alpha, gain, need_b)
+        else:
+            dpre = dy2
+            db = core.colsum(dpre).reshape(-1) if need_b else None
+        dx = dw = None
+        if need_x:
+            dx = core.gemm(dpre, w, 0, 1, M, K, N, ep=core.epilogue(alpha=wscale)).reshape(xshape)
+        if need_w:
+            tiles = ((N + 63) // 64) * ((K + 63) // 64)
+            sk = core.pick_splitk(tiles, M)
+            dw = core.gemm(dpre, x2, 1, 1, N, K, M, ep=core.epilogue(alpha=wscale), splitk=sk)
+        return dx, dw, db, None, None, None, None, None
+
+
+def linear(x, weight, bias=None, act=ACT_NONE, act_alpha=0.0, act_gain=1.0, p_drop=0.0, wscale=1.0):
+    """y = dropout(act((x @ (wscale*weight).T) + bias) * act_gain)."""
+    return _LinearFn.apply(x, weight, bias, act, act_alpha, act_gain, p_drop, wscale)

@@ -1,0 +1,242 @@
+"""Generates tests/golden/*.npz by importing the REFERENCE (salesforce/LayoutDETR at /root/reference).
+
+Run in the build container only:  python oracle/gen_golden.py
+Nothing here is imported at test time; the fixtures are plain data (inputs, weights, expected
+outputs and gradients) that pin the CPU oracle (oracle/*.py) to the reference's arithmetic.
+Modules the reference cannot import here (torchvision, pytorch_fid, skimage are absent) are stubbed in
+sys.modules with the minimum surface the import needs; none of the stubs takes part in a computation
+that is captured.
+"""
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+REF = '/root/reference'
+OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tests', 'golden')
+
+
+def _stub_modules():
+    tv = types.ModuleType('torchvision'); tv.__version__ = '0.13.1'; tv._is_tracing = lambda: False
+    ops = types.ModuleType('torchvision.ops'); boxes = types.ModuleType('torchvision.ops.boxes')
+    boxes.box_area = lambda b: (b[:, 2] - b[:, 0]) * (b[:, 3] - b[:, 1])
+    models = types.ModuleType('torchvision.models'); mu = types.ModuleType('torchvision.models._utils')
+    mu.IntermediateLayerGetter = object
+    tvu = types.ModuleType('torchvision.utils'); tvt = types.ModuleType('torchvision.transforms')
+    tv.ops = ops; ops.boxes = boxes; tv.models = models; models._utils = mu; tv.utils = tvu; tv.transforms = tvt
+    tv.__path__ = []
+    for name, mod in [('torchvision', tv), ('torchvision.ops', ops), ('torchvision.ops.boxes', boxes),
+                      ('torchvision.models', models), ('torchvision.models._utils', mu),
+                      ('torchvision.utils', tvu), ('torchvision.transforms', tvt)]:
+        sys.modules[name] = mod
+    pf = types.ModuleType('pytorch_fid'); fs = types.ModuleType('pytorch_fid.fid_score')
+    fs.calculate_frechet_distance = lambda *a, **k: 0.0
+    pf.fid_score = fs
+    sys.modules['pytorch_fid'] = pf; sys.modules['pytorch_fid.fid_score'] = fs
+    sk = types.ModuleType('skimage'); skt = types.ModuleType('skimage.transform'); skt.resize = None
+    sk.transform = skt
+    sys.modules['skimage'] = sk; sys.modules['skimage.transform'] = skt
+
+
+def npy(t):
+    return t.detach().cpu().numpy()
+
+
+def save(name, d):
+    os.makedirs(OUT, exist_ok=True)
+    path = os.path.join(OUT, name + '.npz')
+    np.savez_compressed(path, **{k: (npy(v) if isinstance(v, torch.Tensor) else np.asarray(v)) for k, v in d.items()})
+    print('wrote', path, f'{os.path.getsize(path) / 1024:.0f} KiB')
+
+
+def gen_ops():
+    from torch_utils.ops import bias_act, conv2d_resample, upfirdn2d
+    from training.networks_stylegan2 import modulated_conv2d
+    d = {}
+    torch.manual_seed(100)
+    x = torch.randn(2, 6, 5, 4) * 2; b = torch.randn(6)
+    d['ba_x'] = x; d['ba_b'] = b
+    for act in bias_act.activation_funcs.keys():
+        xr = x.clone().requires_grad_(True); br = b.clone().requires_grad_(True)
+        y = bias_act.bias_act(xr, br, act=act, impl='ref')
+        g = torch.ones_like(y) * 0.5 + y.detach() * 0.1
+        y.backward(g)
+        d[f'ba_{act}_y'] = y; d[f'ba_{act}_dx'] = xr.grad; d[f'ba_{act}_db'] = br.grad
+        d[f'ba_{act}_yc'] = bias_act.bias_act(x, b, act=act, alpha=0.1, gain=0.7, clamp=0.9, impl='ref')
+    f = upfirdn2d.setup_filter([1, 3, 3, 1])
+    d['f'] = f
+    xu = torch.randn(2, 4, 7, 6); d['up_x'] = xu
+    cases = [dict(up=1, down=1, padding=[1, 1, 1, 1], gain=4), dict(up=2, down=1, padding=[2, 1, 2, 1], gain=4),
+             dict(up=1, down=2, padding=[1, 1, 1, 1], gain=1), dict(up=[2, 1], down=[1, 3], padding=[0, 2, -1, 3], gain=0.5),
+             dict(up=3, down=2, padding=[-1, 4, 2, 0], gain=1.5, flip_filter=True)]
+    fa = f + 0.01 * torch.arange(16.).reshape(4, 4)
+    d['fa'] = fa
+    for i, c in enumerate(cases):
+        xr = xu.clone().requires_grad_(True)
+        y = upfirdn2d.upfirdn2d(xr, fa, impl='ref', **c)
+        y.backward(torch.ones_like(y) + 0.1 * y.detach())
+        d[f'up{i}_y'] = y; d[f'up{i}_dx'] = xr.grad
+    d['up2d_y'] = upfirdn2d.upsample2d(xu, f, impl='ref')
+    xc = torch.randn(2, 8, 6, 6); w3 = torch.randn(12, 8, 3, 3) * 0.2; w1 = torch.randn(3, 8, 1, 1) * 0.3
+    d['cr_x'] = xc; d['cr_w3'] = w3; d['cr_w1'] = w1
+    d['cr_up2'] = conv2d_resample.conv2d_resample(xc, w3, f=f, up=2, padding=1, flip_weight=False)
+    d['cr_up1'] = conv2d_resample.conv2d_resample(xc, w3, f=f, up=1, padding=1, flip_weight=True)
+    d['cr_1x1'] = conv2d_resample.conv2d_resample(xc, w1, f=None, up=1, padding=0, flip_weight=True)
+    d['cr_down2'] = conv2d_resample.conv2d_resample(xc, w3, f=f, down=2, padding=1)
+    s = torch.randn(2, 8) + 1.0; d['mc_s'] = s
+    for nm, kw in [('up2', dict(up=2, padding=1, resample_filter=f, flip_weight=False)), ('up1', dict(up=1, padding=1, flip_weight=True))]:
+        xr = xc.clone().requires_grad_(True); wr = w3.clone().requires_grad_(True); sr = s.clone().requires_grad_(True)
+        y = modulated_conv2d(x=xr, weight=wr, styles=sr, fused_modconv=False, **kw)
+        y.backward(torch.ones_like(y) + 0.1 * y.detach())
+        d[f'mc_{nm}_y'] = y; d[f'mc_{nm}_dx'] = xr.grad; d[f'mc_{nm}_dw'] = wr.grad; d[f'mc_{nm}_ds'] = sr.grad
+    d['mc_rgb_y'] = modulated_conv2d(x=xc, weight=w1, styles=s, demodulate=False, fused_modconv=False)
+    save('ops', d)
+
+
+def gen_transformer():
+    from training.detr_transformer import Transformer, TransformerWithToken
+    from training.detr_position_encoding import PositionEmbeddingSine
+    from detr_util.misc import NestedTensor
+    from training.util import TransformerWithToken_layoutganpp
+    B, d_model, nhead, h, w, Lq = 2, 64, 2, 3, 4, 5
+    for name, cls in [('transformer', Transformer), ('transformer_token', TransformerWithToken)]:
+        torch.manual_seed(200)
+        m = cls(d_model=d_model, nhead=nhead, num_encoder_layers=2, num_decoder_layers=2, dim_feedforward=128, dropout=0.1).eval()
+        src = torch.randn(B, d_model, h, w, requires_grad=True)
+        mask = torch.zeros(B, h, w, dtype=torch.bool); mask[1, :, 3] = True
+        pe = PositionEmbeddingSine(d_model // 2, normalize=True)
+        pos = pe(NestedTensor(src, mask))
+        tgt = torch.randn(Lq, B, d_model, requires_grad=True)
+        kpm = torch.zeros(B, Lq, dtype=torch.bool); kpm[0, 3:] = True
+        hs, mem = m(src, mask, pos, tgt, kpm)
+        g_hs = torch.randn_like(hs); g_mem = torch.randn_like(mem) * 0.1
+        (hs * g_hs).sum().add((mem * g_mem).sum()).backward()
+        d = {'src': src, 'mask': mask, 'pos': pos, 'tgt': tgt, 'kpm': kpm, 'hs': hs, 'mem': mem, 'g_hs': g_hs, 'g_mem': g_mem,
+             'd_src': src.grad, 'd_tgt': tgt.grad}
+        for k, v in m.state_dict().items():
+            d['sd/' + k] = v
+        for k, p in m.named_parameters():
+            if p.grad is not None:
+                d['grad/' + k] = p.grad
+        save(name, d)
+    # nn.TransformerEncoder-based unconditional branch (training/util.py:13-43)
+    torch.manual_seed(201)
+    m = TransformerWithToken_layoutganpp(d_model=d_model, nhead=nhead, dim_feedforward=128, num_layers=2).eval()
+    x = torch.randn(Lq, B, d_model, requires_grad=True)
+    kpm = torch.zeros(B, Lq, dtype=torch.bool); kpm[1, 2:] = True
+    y = m(x, src_key_padding_mask=kpm)
+    g = torch.randn_like(y); (y * g).sum().backward()
+    d = {'x': x, 'kpm': kpm, 'y': y, 'g': g, 'd_x': x.grad}
+    for k, v in m.state_dict().items():
+        d['sd/' + k] = v
+    for k, p in m.named_parameters():
+        d['grad/' + k] = p.grad
+    save('transformer_layoutganpp', d)
+    # position encoding at the real width (128 feats/axis) on a ragged mask
+    pe = PositionEmbeddingSine(128, normalize=True)
+    mask = torch.zeros(2, 4, 5, dtype=torch.bool); mask[0, 3:, :] = True; mask[1, :, 4:] = True
+    save('pos_encoding', {'mask': mask, 'pos': pe(NestedTensor(torch.zeros(2, 1, 4, 5), mask))})
+
+
+def gen_losses():
+    from metrics.metric_layoutnet import compute_alignment, compute_overlap, generalized_iou_loss
+    torch.manual_seed(300)
+    B, N = 4, 9
+    bbox = torch.cat([torch.rand(B, N, 2) * 0.6 + 0.2, torch.rand(B, N, 2) * 0.35 + 0.05], -1)
+    bbox[0, 1] = bbox[0, 0]  # an exactly aligned / fully overlapping pair
+    mask = torch.ones(B, N, dtype=torch.bool); mask[1, 5:] = False; mask[2, 1:] = False
+    real = torch.cat([torch.rand(B, N, 2) * 0.6 + 0.2, torch.rand(B, N, 2) * 0.35 + 0.05], -1)
+    d = {'bbox': bbox, 'mask': mask, 'real': real}
+    for nm, fn in [('overlap', lambda b: compute_overlap(b, mask)), ('alignment', lambda b: compute_alignment(b, mask))]:
+        br = bbox.clone().requires_grad_(True)
+        v = fn(br); v.sum().backward()
+        d[nm] = v; d['d_' + nm] = br.grad
+    br = bbox.clone().requires_grad_(True)
+    v = generalized_iou_loss(br[mask], real[mask]); v.backward()
+    d['giou'] = v; d['d_giou'] = br.grad
+    save('losses', d)
+
+
+def gen_decoder():
+    from training.networks_stylegan2 import Decoder
+    torch.manual_seed(400)
+    m = Decoder(z_dim=32, w_dim=32, img_resolution=16, img_channels=3, use_noise=False, channel_base=256, channel_max=32,
+                num_fp16_res=0, conv_clamp=None, fused_modconv_default=False).train()
+    z = torch.randn(2, 32, requires_grad=True)
+    img = m(z)
+    g = torch.randn_like(img); (img * g).sum().backward()
+    d = {'z': z, 'img': img, 'g': g, 'd_z': z.grad}
+    for k, v in m.state_dict().items():
+        d['sd/' + k] = v
+    for k, p in m.named_parameters():
+        d['grad/' + k] = p.grad
+    save('decoder', d)
+
+
+def gen_frozen_bn():
+    from training.detr_backbone import FrozenBatchNorm2d
+    torch.manual_seed(500)
+    bn = FrozenBatchNorm2d(6)
+    bn.weight.copy_(torch.rand(6) + 0.5); bn.bias.copy_(torch.randn(6)); bn.running_mean.copy_(torch.randn(6)); bn.running_var.copy_(torch.rand(6) + 0.2)
+    x = torch.randn(2, 6, 3, 3)
+    save('frozen_bn', {'x': x, 'y': bn(x), 'weight': bn.weight, 'bias': bn.bias, 'running_mean': bn.running_mean, 'running_var': bn.running_var})
+
+
+def gen_lsap():
+    """Cost matrices built as metrics/metric_layoutnet.py:100-113 builds them (pairwise IoU of same-label boxes),
+    solved by scipy.optimize.linear_sum_assignment(maximize=True) — the only Hungarian arithmetic in the reference."""
+    import scipy
+    from scipy.optimize import linear_sum_assignment
+    from metrics.metric_layoutnet import compute_iou
+    rng = np.random.RandomState(7)
+    d = {'scipy_version': scipy.__version__}
+    idx = 0
+    for n in [1, 2, 3, 4, 5, 7, 9]:
+        for rep in range(6):
+            bi = np.concatenate([rng.rand(n, 2) * 0.6 + 0.2, rng.rand(n, 2) * 0.3 + 0.05], 1)
+            bj = np.concatenate([rng.rand(n, 2) * 0.6 + 0.2, rng.rand(n, 2) * 0.3 + 0.05], 1)
+            if rep == 1:
+                bj = bi.copy()            # identical layouts: diagonal ones, ties elsewhere
+            if rep == 2:
+                bj = bi[::-1].copy()
+            if rep == 3:
+                bi[:] = bi[0]; bj[:] = bj[0]   # constant matrix -> identity assignment
+            ii, jj = np.meshgrid(range(n), range(n)); ii, jj = ii.flatten(), jj.flatten()
+            iou = compute_iou(bi[ii], bj[jj]).reshape(n, n)
+            if rep == 4:
+                iou = np.round(iou * 4) / 4   # quantised -> many ties
+            if rep == 5:
+                iou = np.zeros((n, n))
+            r, c = linear_sum_assignment(iou, maximize=True)
+            d[f'cost{idx}'] = iou; d[f'row{idx}'] = r; d[f'col{idx}'] = c
+            idx += 1
+    d['count'] = idx
+    save('lsap', d)
+
+
+def gen_dp_step():
+    from torch_utils import misc
+    torch.manual_seed(600)
+    grads = [torch.randn(7), torch.randn(3, 4), torch.randn(2, 2, 2)]
+    grads[0][1] = float('nan'); grads[1][0, 0] = float('inf'); grads[2][1, 1, 1] = -float('inf')
+    d = {}
+    for W in (1, 2, 8):
+        flat = torch.cat([g.flatten() for g in grads]) * W   # what an all_reduce SUM of W identical ranks yields
+        if W > 1:
+            flat /= W
+        misc.nan_to_num(flat, nan=0, posinf=1e5, neginf=-1e5, out=flat)
+        d[f'out_w{W}'] = flat
+    for i, g in enumerate(grads):
+        d[f'g{i}'] = g
+    save('dp_step', d)
+
+
+if __name__ == '__main__':
+    sys.path.insert(0, REF)
+    _stub_modules()
+    torch.set_num_threads(8)
+    if '--skip-done' not in sys.argv:
+        gen_ops(); gen_transformer()
+    gen_losses(); gen_decoder(); gen_frozen_bn(); gen_lsap(); gen_dp_step()
