@@ -1,0 +1,169 @@
+"""CPU tests: pin the oracle (oracle/*.py) to golden vectors captured from the reference itself
+(tests/golden/*.npz, produced by oracle/gen_golden.py importing /root/reference).  fp32, tolerance 2e-5
+relative unless stated (summation-order differences only); index outputs bit-exact."""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import detr_ref, losses_ref, ops_ref, stylegan2_ref
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def load(name):
+    d = np.load(os.path.join(G, name + '.npz'), allow_pickle=False)
+    return {k: torch.from_numpy(d[k]) if d[k].dtype.kind in 'fbiu' and d[k].ndim > 0 else d[k] for k in d.files}
+
+
+def sd_of(d, prefix='sd/'):
+    return {k[len(prefix):]: v for k, v in d.items() if k.startswith(prefix)}
+
+
+def close(a, b, tol=2e-5):
+    a, b = torch.as_tensor(a).double(), torch.as_tensor(b).double()
+    err = (a - b).abs().max().item() / (b.abs().max().item() + 1e-12)
+    assert err <= tol, f'rel err {err:.3e}'
+
+
+def test_ops_bias_act():
+    d = load('ops')
+    for act in ops_ref.ACT_DEFAULTS:
+        x = d['ba_x'].clone().requires_grad_(True); b = d['ba_b'].clone().requires_grad_(True)
+        y = ops_ref.bias_act(x, b, act=act)
+        y.backward(torch.ones_like(y) * 0.5 + y.detach() * 0.1)
+        close(y, d[f'ba_{act}_y']); close(x.grad, d[f'ba_{act}_dx']); close(b.grad, d[f'ba_{act}_db'])
+        close(ops_ref.bias_act(d['ba_x'], d['ba_b'], act=act, alpha=0.1, gain=0.7, clamp=0.9), d[f'ba_{act}_yc'])
+
+
+def test_ops_upfirdn2d_and_resample():
+    d = load('ops')
+    cases = [dict(up=1, down=1, padding=[1, 1, 1, 1], gain=4), dict(up=2, down=1, padding=[2, 1, 2, 1], gain=4),
+             dict(up=1, down=2, padding=[1, 1, 1, 1], gain=1), dict(up=[2, 1], down=[1, 3], padding=[0, 2, -1, 3], gain=0.5),
+             dict(up=3, down=2, padding=[-1, 4, 2, 0], gain=1.5, flip_filter=True)]
+    close(ops_ref.setup_filter([1, 3, 3, 1]), d['f'], 1e-7)
+    for i, c in enumerate(cases):
+        x = d['up_x'].clone().requires_grad_(True)
+        y = ops_ref.upfirdn2d(x, d['fa'], **c)
+        y.backward(torch.ones_like(y) + 0.1 * y.detach())
+        close(y, d[f'up{i}_y']); close(x.grad, d[f'up{i}_dx'])
+    close(ops_ref.upsample2d(d['up_x'], d['f']), d['up2d_y'])
+    f = d['f']
+    close(ops_ref.conv2d_resample(d['cr_x'], d['cr_w3'], f=f, up=2, padding=1, flip_weight=False), d['cr_up2'])
+    close(ops_ref.conv2d_resample(d['cr_x'], d['cr_w3'], f=f, up=1, padding=1, flip_weight=True), d['cr_up1'])
+    close(ops_ref.conv2d_resample(d['cr_x'], d['cr_w1'], f=None, up=1, padding=0), d['cr_1x1'])
+    close(ops_ref.conv2d_resample(d['cr_x'], d['cr_w3'], f=f, down=2, padding=1), d['cr_down2'])
+
+
+def test_ops_modulated_conv():
+    d = load('ops')
+    for nm, kw in [('up2', dict(up=2, padding=1, resample_filter=d['f'], flip_weight=False)), ('up1', dict(up=1, padding=1, flip_weight=True))]:
+        x = d['cr_x'].clone().requires_grad_(True); w = d['cr_w3'].clone().requires_grad_(True); s = d['mc_s'].clone().requires_grad_(True)
+        y = ops_ref.modulated_conv2d(x, w, s, **kw)
+        y.backward(torch.ones_like(y) + 0.1 * y.detach())
+        close(y, d[f'mc_{nm}_y']); close(x.grad, d[f'mc_{nm}_dx']); close(w.grad, d[f'mc_{nm}_dw']); close(s.grad, d[f'mc_{nm}_ds'])
+    close(ops_ref.modulated_conv2d(d['cr_x'], d['cr_w1'], d['mc_s'], demodulate=False), d['mc_rgb_y'])
+
+
+@pytest.mark.parametrize('name,with_token', [('transformer', False), ('transformer_token', True)])
+def test_detr_transformer(name, with_token):
+    d = load(name)
+    sd = {k: v.clone().requires_grad_(v.dtype.is_floating_point) for k, v in sd_of(d).items()}
+    src = d['src'].clone().requires_grad_(True); tgt = d['tgt'].clone().requires_grad_(True)
+    hs, mem = detr_ref.transformer(sd, src, d['mask'], d['pos'], tgt, d['kpm'], nhead=2, with_token=with_token)
+    close(hs, d['hs']); close(mem, d['mem'])
+    ((hs * d['g_hs']).sum() + (mem * d['g_mem']).sum()).backward()
+    close(src.grad, d['d_src'], 5e-5); close(tgt.grad, d['d_tgt'], 5e-5)
+    for k, g in sd_of(d, 'grad/').items():
+        close(sd[k].grad, g, 1e-4)
+
+
+def test_torch_encoder_branch():
+    d = load('transformer_layoutganpp')
+    sd = {k: v.clone().requires_grad_(v.dtype.is_floating_point) for k, v in sd_of(d).items()}
+    x = d['x'].clone().requires_grad_(True)
+    y = detr_ref.token_encoder_layoutganpp(sd, '', x, d['kpm'], nhead=2)
+    close(y, d['y'])
+    (y * d['g']).sum().backward()
+    close(x.grad, d['d_x'], 5e-5)
+    for k, g in sd_of(d, 'grad/').items():
+        close(sd[k].grad, g, 1e-4)
+
+
+def test_position_encoding_and_frozen_bn():
+    d = load('pos_encoding')
+    close(detr_ref.position_embedding_sine(d['mask']), d['pos'], 1e-6)
+    d = load('frozen_bn')
+    close(detr_ref.frozen_bn(d, '', d['x']), d['y'], 1e-6)
+
+
+def test_layout_losses():
+    d = load('losses')
+    for nm, fn in [('overlap', losses_ref.compute_overlap), ('alignment', losses_ref.compute_alignment)]:
+        b = d['bbox'].clone().requires_grad_(True)
+        v = fn(b, d['mask']); v.sum().backward()
+        close(v, d[nm]); close(b.grad, d['d_' + nm], 5e-5)
+    b = d['bbox'].clone().requires_grad_(True)
+    v = losses_ref.generalized_iou_loss(b[d['mask']], d['real'][d['mask']]); v.backward()
+    close(v, d['giou']); close(b.grad, d['d_giou'], 5e-5)
+
+
+def test_stylegan2_decoder():
+    d = load('decoder')
+    sd = {k: v.clone().requires_grad_(v.dtype.is_floating_point) for k, v in sd_of(d).items()}
+    z = d['z'].clone().requires_grad_(True)
+    img = stylegan2_ref.decoder(sd, '', z, 16)
+    close(img, d['img'])
+    (img * d['g']).sum().backward()
+    close(z.grad, d['d_z'], 1e-4)
+    for k, g in sd_of(d, 'grad/').items():
+        close(sd[k].grad, g, 2e-4)
+
+
+def test_dp_postprocess():
+    d = load('dp_step')
+    flat = torch.cat([d[f'g{i}'].flatten() for i in range(3)])
+    for W in (1, 2, 8):
+        out = losses_ref.dp_postprocess(flat * W, W)
+        assert torch.equal(out, d[f'out_w{W}'])
+
+
+def _lsap_lib():
+    so = os.path.join(ROOT, 'oracle', '_build', 'liblsap_oracle.so')
+    if not os.path.exists(so):
+        os.makedirs(os.path.dirname(so), exist_ok=True)
+        subprocess.check_call(['gcc', '-O2', '-shared', '-fPIC', '-o', so, os.path.join(ROOT, 'oracle', 'lsap.c'), '-lm'])
+    return ctypes.CDLL(so)
+
+
+def _lsap(lib, c, maximize):
+    n = c.shape[0]
+    c = np.ascontiguousarray(c, dtype=np.float64)
+    r = np.zeros(n, np.int32); cc = np.zeros(n, np.int32)
+    rc = lib.lsap_oracle(c.ctypes.data_as(ctypes.c_void_p), n, int(maximize), r.ctypes.data_as(ctypes.c_void_p), cc.ctypes.data_as(ctypes.c_void_p))
+    assert rc == 0
+    return r, cc
+
+
+def test_lsap_oracle_bit_exact():
+    """C restatement vs (a) fixtures solved by scipy on reference-built IoU matrices, (b) live scipy incl. ties."""
+    lib = _lsap_lib()
+    d = np.load(os.path.join(G, 'lsap.npz'))
+    for i in range(int(d['count'])):
+        r, c = _lsap(lib, d[f'cost{i}'], True)
+        assert r.tolist() == d[f'row{i}'].tolist() and c.tolist() == d[f'col{i}'].tolist()
+    from scipy.optimize import linear_sum_assignment
+    rng = np.random.RandomState(1)
+    for n in (1, 2, 4, 9, 13):
+        for t in range(50):
+            cost = rng.rand(n, n)
+            if t % 2:
+                cost = np.round(cost * 3) / 3
+            for mx in (False, True):
+                r, c = _lsap(lib, cost, mx)
+                rs, cs = linear_sum_assignment(cost, maximize=mx)
+                assert c.tolist() == cs.tolist()
