@@ -1,0 +1,197 @@
+#!/usr/bin/env python
+"""bench.py — LayoutDETR G+D adversarial step on MI355X (BASELINE.json metric).
+
+A "step" is one full training iteration of the hot path: phase Gmain + phase Dmain
+(G fwd x2, G bwd x1, D fwd x3, D bwd x3; training/loss.py:84-116,146-218 with gamma=0, pl_weight=0),
+gradient exchange + /world + nan_to_num, Adam, G_ema lerp — in train mode (dropout 0.1), fp32.
+Workload (BASELINE.json configs[2]/[3]): global batch 16, 256x256 synthetic backgrounds, 9 elements per layout,
+hot-path-only (BASELINE.md variant A): the frozen BERT text encoder's CLS features are an input tensor and the
+LM-decoder loss is excluded (SURVEY §8a rows a16/a17 are boundary inputs).
+N > 1: one process per GPU (torchrun), the global batch of 16 is sharded across ranks ("strong" scaling, as
+configs[3] states) and gradients are exchanged with RCCL all-reduce over xGMI.
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import copy
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+F32_MFMA_PEAK_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense, 256 CUs @ 2.4 GHz
+
+
+def make_batch(b, bg, device, seed):
+    g = torch.Generator().manual_seed(seed)
+    xy = torch.rand(b, 9, 2, generator=g) * 0.6 + 0.2
+    wh = torch.rand(b, 9, 2, generator=g) * 0.35 + 0.05
+    bt = dict(bbox_real=torch.cat([xy, wh], -1), bbox_class=torch.randint(0, 8, (b, 9), generator=g),
+              text_feat=torch.randn(b, 9, 768, generator=g), text_len=torch.randint(1, 40, (b, 9), generator=g),
+              padding_mask=torch.zeros(b, 9, dtype=torch.bool), background=torch.randn(b, 3, bg, bg, generator=g))
+    return bt
+
+
+def to_device_batch(bt, device):
+    from layoutdetr_amd.training.networks_detr import TextFeatures
+    b = bt['bbox_real'].shape[0]
+    return dict(bbox_real=bt['bbox_real'].to(device), bbox_class=bt['bbox_class'].to(device),
+                bbox_text=TextFeatures(bt['text_feat'].to(device), bt['text_len'].to(device)),
+                bbox_patch=torch.zeros(b, 9, 1, 1, 1, device=device).expand(b, 9, 3, 256, 256),  # shape only (0-stride view)
+                padding_mask=bt['padding_mask'].to(device), background=bt['background'].to(device),
+                real_c=torch.zeros(b, 0, device=device), gen_c=torch.zeros(b, 0, device=device))
+
+
+def cpu_baseline(G_sd, D_sd, G_names, D_names, bg, budget_s=25.0):
+    """The oracle (a CPU port of the same step) on the host cores, bounded sample: batch 2."""
+    from oracle import step_ref
+    B = 2
+    ncores = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    ncores = min(ncores, 16)   # measured on the GPU box: 16 threads 1.1 s/iteration, 64 threads 3.3 s, 256 threads > 400 s (oversubscribed tiny ops)
+    torch.set_num_threads(ncores)
+    bt = make_batch(B, bg, 'cpu', 123)
+    zg, zd = torch.randn(B, 9, 4), torch.randn(B, 9, 4)
+    kw = dict(bg_size=bg, G_param_names=G_names, D_param_names=D_names)
+    t0 = time.time()
+    step_ref.training_iteration(G_sd, D_sd, bt, zg, zd, **kw)   # warm-up (allocator, oneDNN primitive caches)
+    warm = time.time() - t0
+    n, t0 = 0, time.time()
+    while True:
+        step_ref.training_iteration(G_sd, D_sd, bt, zg, zd, **kw)
+        n += 1
+        el = time.time() - t0
+        if el + warm > budget_s or n >= 3:
+            break
+    return dict(value=round(B * n / el, 4), unit='images/s', cores=ncores, kind='port',
+                sample=f'{n} timed iteration(s) of the same Gmain+Dmain step at batch {B}, {bg}x{bg} (oracle/step_ref.py, torch CPU fp32, dropout off) after 1 warm-up')
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--batch', type=int, default=16, help='global batch')
+    ap.add_argument('--bg', type=int, default=256)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-roofline', action='store_true')
+    args = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    assert torch.cuda.is_available(), 'bench.py needs a GPU'
+    torch.cuda.set_device(local_rank)
+    device = torch.device('cuda', local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', device_id=device)
+    assert args.gpus == world, f'--gpus {args.gpus} but WORLD_SIZE={world} (launch with torch.distributed.run)'
+    assert args.batch % world == 0
+
+    from layoutdetr_amd import _lib
+    _lib.load()   # fails loudly if the HIP library is missing: there is no fallback path
+    from layoutdetr_amd.hip import core
+    from layoutdetr_amd.training import training_loop as tl
+    from layoutdetr_amd.training.loss import StyleGAN2Loss
+    from layoutdetr_amd.training.networks_detr import Discriminator, Generator
+
+    bg, b_local = args.bg, args.batch // world
+    torch.manual_seed(0)   # identical initial parameters on every rank (stands in for the rank-0 broadcast, training_loop.py:176-179)
+    kw = dict(num_bbox_labels=8, img_channels=3, img_height=bg, img_width=bg, c_dim=0, background_size=bg, bert_f_dim=768,
+              bert_num_heads=4, bert_num_encoder_layers=12, bert_num_decoder_layers=2, im_f_dim=512)
+    G = Generator(z_dim=4, f_dim=256, num_heads=4, num_layers=8, **kw).train().requires_grad_(False)
+    D = Discriminator(f_dim=256, num_heads=4, num_layers=8, **kw).train().requires_grad_(False)
+    G_sd_cpu = D_sd_cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        G_sd_cpu = {k: v.clone() for k, v in G.state_dict().items()}
+        D_sd_cpu = {k: v.clone() for k, v in D.state_dict().items()}
+    G_names = {n for n, _ in G.named_parameters()}
+    D_names = {n for n, _ in D.named_parameters()}
+    G.to(device); D.to(device)
+    G_ema = copy.deepcopy(G).eval()
+    pG = tl.Phase('Gmain', G, lr=1e-5, betas=(0.0, 0.99), eps=1e-8, reg_interval=4)     # train.py:204,281; training_loop.py:191-194
+    pD = tl.Phase('Dmain', D, lr=1e-5, betas=(0.0, 0.99), eps=1e-8, reg_interval=16)
+    ema = tl.EmaTracker(pG, G_ema)
+    loss = StyleGAN2Loss(device, G, D)
+    dp = tl.DataParallelStep(world_size=world)
+
+    torch.manual_seed(0 * world + rank)   # training_loop.py:101-102 seed rule
+    batch = to_device_batch(make_batch(b_local, bg, device, 1000 + rank), device)
+    n_params = (pG.fm.total, pD.fm.total)
+    cur_nimg = [0]
+
+    def step():
+        gen_z = [torch.randn(b_local, 9, 4, device=device) for _ in range(2)]
+        tl.training_iteration(loss, [pG, pD], dp, batch, b_local, gen_z, ema=ema, batch_size=args.batch,
+                              ema_kimg=args.batch * 10 / 32, cur_nimg=cur_nimg[0])
+        cur_nimg[0] += args.batch
+
+    def barrier():
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        import torch.distributed as dist
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = t.item()
+    ms_per_step = elapsed / args.steps * 1e3
+    value = args.batch * args.steps / elapsed
+
+    roofline = None
+    if not args.no_roofline:
+        # Dominant kernel = the f32-MFMA contraction engine (ldetr::gemm_f32_kernel<...>, every dense GEMM and implicit conv).
+        # HIP events on the launch stream around each engine launch, algorithmic FLOPs = 2*M*N*K (GEMM) /
+        # 2*pixels*Cout*KH*KW*Cin (conv fwd, bwd-data, bwd-weight alike), over 2 extra iterations.
+        core.PROF.enabled = True
+        core.PROF.reset()
+        for _ in range(2):
+            step()
+        torch.cuda.synchronize()
+        fl, sec, launches = core.PROF.summary()
+        core.PROF.enabled = False
+        ach = fl / sec / 1e12 if sec > 0 else 0.0
+        roofline = dict(bound='mfma', kernel='ldetr::gemm_f32_kernel<*> (f32 MFMA GEMM / implicit-conv engine, all instantiations)',
+                        achieved=round(ach, 3), peak=F32_MFMA_PEAK_TFLOPS, unit='TFLOP/s', frac=round(ach / F32_MFMA_PEAK_TFLOPS, 4),
+                        traffic=None, launches_per_step=launches // 2, algorithmic_gflop_per_step=round(fl / 2 / 1e9, 2),
+                        engine_ms_per_step=round(sec / 2 * 1e3, 3))
+
+    if rank == 0:
+        cpu = None
+        if G_sd_cpu is not None:
+            cpu = cpu_baseline(G_sd_cpu, D_sd_cpu, G_names, D_names, bg)
+        out = dict(metric='images/sec G+D fwd-bwd, 256x256 bg x9 elems', value=round(value, 3), unit='images/s', n_gpus=world,
+                   steps=args.steps, warmup=args.warmup, ms_per_step=round(ms_per_step, 3), higher_is_better=True,
+                   scaling='strong', vs_baseline=None, dtype='f32', data='synthetic',
+                   config=dict(workload=f'BASELINE configs[2]: global batch {args.batch}, {bg}x{bg} backgrounds x 9 elements, full G+D adversarial '
+                                        'step (Gmain+Dmain fwd/bwd, grad exchange + nan_to_num, Adam, EMA), train mode (dropout 0.1); '
+                                        'hot-path-only: frozen-BERT text features are an input, LM-decoder loss excluded',
+                               global_batch=args.batch, per_gpu_batch=b_local, background=bg, elements=9,
+                               parallelism=f'dp{world}', params_G=n_params[0], params_D=n_params[1]),
+                   roofline=roofline, cpu_baseline=cpu)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -45,9 +45,9 @@ class _ConvFn(torch.autograd.Function):
         sc = core.f32c(scale) if scale is not None else None
         sh = core.f32c(shift) if shift is not None else None
         ep = core.epilogue(col_scale=sc, col_bias=sh, residual=res, act=ACT_RELU if relu else ACT_NONE)
-        core.check(core.lib().ldetr_conv2d_fwd_f32(
+        core.engine_call('ldetr_conv2d_fwd_f32', 2.0 * N * OH * OW * O * KH * KW * I, lambda: core.check(core.lib().ldetr_conv2d_fwd_f32(
             core.ptr(x), ctypes.byref(xt), core.ptr(w), O, KH, KW, stride, pad, core.ptr(y), O, OH, OW, None, 0,
-            ctypes.byref(ep), core.stream()), 'conv2d_fwd')
+            ctypes.byref(ep), core.stream()), 'conv2d_fwd'))
         ctx.save_for_backward(x, w, sc, y if relu else None)
         ctx.cfg = (stride, pad, relu, x_is_nchw, residual is not None, shift is not None, (N, H, W, I))
         return y
@@ -75,9 +75,9 @@ class _ConvFn(torch.autograd.Function):
             if x_is_nchw:
                 raise RuntimeError('conv2d: gradient w.r.t. an NCHW image input is not implemented (never needed on the hot path)')
             dx = torch.empty((N, H, W, I), device=dy.device, dtype=torch.float32)
-            core.check(core.lib().ldetr_conv2d_bwd_data_f32(
+            core.engine_call('ldetr_conv2d_bwd_data_f32', 2.0 * N * OH * OW * O * KH * KW * I, lambda: core.check(core.lib().ldetr_conv2d_bwd_data_f32(
                 core.ptr(dpre), ctypes.byref(dyt), core.ptr(w), I, KH, KW, stride, pad, core.ptr(dx), I, H, W,
-                core.ptr(sc), 0, None, core.stream()), 'conv2d_bwd_data')
+                core.ptr(sc), 0, None, core.stream()), 'conv2d_bwd_data'))
         if need_w:
             dw_ohwi = torch.empty((O, KH, KW, I), device=dy.device, dtype=torch.float32)
             xt = core.tensor4_nchw(x) if x_is_nchw else core.tensor4_nhwc(x)
@@ -89,13 +89,13 @@ class _ConvFn(torch.autograd.Function):
                 # scalar-gather path has no operand scale: fold the BN scale into dy first
                 dpre_s = dpre * sc
                 dyt_s = core.tensor4_nhwc(dpre_s)
-                core.check(core.lib().ldetr_conv2d_bwd_weight_f32(
+                core.engine_call('ldetr_conv2d_bwd_weight_f32', 2.0 * N * OH * OW * O * KH * KW * I, lambda: core.check(core.lib().ldetr_conv2d_bwd_weight_f32(
                     core.ptr(x), ctypes.byref(xt), core.ptr(dpre_s), ctypes.byref(dyt_s), core.ptr(dw_ohwi), KH, KW,
-                    stride, pad, sk, None, 0, None, 0, core.stream()), 'conv2d_bwd_weight')
+                    stride, pad, sk, None, 0, None, 0, core.stream()), 'conv2d_bwd_weight'))
             else:
-                core.check(core.lib().ldetr_conv2d_bwd_weight_f32(
+                core.engine_call('ldetr_conv2d_bwd_weight_f32', 2.0 * N * OH * OW * O * KH * KW * I, lambda: core.check(core.lib().ldetr_conv2d_bwd_weight_f32(
                     core.ptr(x), ctypes.byref(xt), core.ptr(dpre), ctypes.byref(dyt), core.ptr(dw_ohwi), KH, KW, stride,
-                    pad, sk, None, 0, core.ptr(sc), 0, core.stream()), 'conv2d_bwd_weight')
+                    pad, sk, None, 0, core.ptr(sc), 0, core.stream()), 'conv2d_bwd_weight'))
             dw = _grad_to_oihw(dw_ohwi)
         dres = dpre if need_res else None
         return dx, dw, None, dshift, dres, None, None, None, None

@@ -11,6 +11,39 @@ ACT_NONE, ACT_RELU, ACT_LRELU = 0, 1, 2
 _seed_counter = [0x5EED]
 
 
+class _EngineProfile(object):
+    """Optional per-launch accounting of the f32-MFMA contraction engine (bench.py roofline leg): HIP events are
+    recorded on the launch stream around every engine launch together with its algorithmic FLOP count."""
+
+    def __init__(self):
+        self.enabled = False
+        self.records = []
+
+    def reset(self):
+        self.records = []
+
+    def summary(self):
+        """(total algorithmic flops, total seconds, launches) — call after torch.cuda.synchronize()."""
+        fl = sum(r[1] for r in self.records)
+        ms = sum(r[2].elapsed_time(r[3]) for r in self.records)
+        return fl, ms * 1e-3, len(self.records)
+
+
+PROF = _EngineProfile()
+
+
+def engine_call(tag, flops, thunk):
+    if not PROF.enabled:
+        return thunk()
+    s = torch.cuda.Event(enable_timing=True)
+    e = torch.cuda.Event(enable_timing=True)
+    s.record()
+    r = thunk()
+    e.record()
+    PROF.records.append((tag, float(flops), s, e))
+    return r
+
+
 def lib():
     return _lib.load()
 
@@ -101,8 +134,9 @@ def gemm(A, B, ta, tb, M, N, K, out=None, ep=None, splitk=1, pix_per_sample=0, l
         out.zero_()
     lda = A.stride(0) if lda is None else lda
     ldb = B.stride(0) if ldb is None else ldb
-    check(lib().ldetr_gemm_f32(ptr(A), lda, int(ta), ptr(B), ldb, int(tb), ptr(out), out.stride(0), M, N, K, splitk,
-                               ctypes.byref(ep) if ep is not None else None, pix_per_sample, stream()), 'gemm')
+    engine_call('gemm', 2.0 * M * N * K, lambda: check(lib().ldetr_gemm_f32(
+        ptr(A), lda, int(ta), ptr(B), ldb, int(tb), ptr(out), out.stride(0), M, N, K, splitk,
+        ctypes.byref(ep) if ep is not None else None, pix_per_sample, stream()), 'gemm'))
     return out
 
 

@@ -1,0 +1,195 @@
+"""StyleGAN2 modulated convolution layers as fused gfx950 launches (forward + hand-written backward).
+
+Reference chain (non-fused branch, training/networks_stylegan2.py:57-75 + SynthesisLayer :307-326):
+    x*styles -> conv2d_resample (conv | transposed conv + 4x4 FIR) -> *dcoefs -> bias_act(lrelu, sqrt2)
+i.e. one conv plus 4-5 full-tensor elementwise passes per layer.  Here:
+    3x3 layer : ONE implicit-GEMM launch (style scale in the A-operand loader; dcoefs, bias, lrelu in the epilogue)
+    up layer  : transposed-conv launch (style scale in loader, dcoefs in epilogue) + ONE FIR launch with
+                bias + lrelu fused (demodulation commutes with the per-channel FIR)
+    toRGB     : one launch (style scale in loader, bias in epilogue)
+Activations are NHWC [B, H, W, C]; weights are [O, I, k, k] parameters in channels_last memory (OHWI).
+"""
+import ctypes
+import math
+
+import torch
+
+from . import core
+from .conv import weight_ohwi, _grad_to_oihw
+from .core import ACT_LRELU, ACT_NONE
+from .linear import act_backward
+from ..torch_utils.ops import upfirdn2d as _up
+
+
+def _mul_reduce(a, x, scale, B, P, C, want_out=True):
+    out = torch.empty_like(a) if want_out else None
+    red = torch.zeros((B, C), device=a.device, dtype=torch.float32)
+    core.check(core.lib().ldetr_mul_reduce_f32(core.ptr(a), core.ptr(x), core.ptr(scale), core.ptr(out), core.ptr(red),
+                                               B, P, C, core.stream()), 'mul_reduce')
+    return out, red
+
+
+class _ModConvFn(torch.autograd.Function):
+    """y = lrelu(conv3x3(x * s) * d + bias) * gain      (up == 1)"""
+
+    @staticmethod
+    def forward(ctx, x, weight, styles, dcoefs, bias, pad, act_alpha, act_gain):
+        core.require_gpu(x, weight, styles, dcoefs, bias)
+        x = core.f32c(x); w = core.f32c(weight_ohwi(weight)); s = core.f32c(styles); d = core.f32c(dcoefs); b = core.f32c(bias)
+        B, H, W, I = x.shape
+        O, KH, KW, _ = w.shape
+        OH, OW = H + 2 * pad - KH + 1, W + 2 * pad - KW + 1
+        y = torch.empty((B, OH, OW, O), device=x.device, dtype=torch.float32)
+        xt = core.tensor4_nhwc(x)
+        ep = core.epilogue(samp_scale=d, col_bias=b, act=ACT_LRELU, act_alpha=act_alpha, act_gain=act_gain)
+        core.engine_call('ldetr_conv2d_fwd_f32', 2.0 * B * OH * OW * O * KH * KW * I, lambda: core.check(core.lib().ldetr_conv2d_fwd_f32(core.ptr(x), ctypes.byref(xt), core.ptr(w), O, KH, KW, 1, pad, core.ptr(y), O,
+                                                   OH, OW, core.ptr(s), s.stride(0), ctypes.byref(ep), core.stream()), 'modconv_fwd'))
+        ctx.save_for_backward(x, w, s, d, b, y)
+        ctx.cfg = (pad, act_alpha, act_gain)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, s, d, b, y = ctx.saved_tensors
+        pad, act_alpha, act_gain = ctx.cfg
+        B, H, W, I = x.shape
+        O, KH, KW, _ = w.shape
+        _, OH, OW, _ = y.shape
+        dy = core.f32c(dy)
+        dv2, dbias, ddemod = act_backward(dy.reshape(-1, O), y.reshape(-1, O), ACT_LRELU, act_alpha, act_gain, True,
+                                          bias=b, demod=d, want_ddemod=True, B=B)
+        dv = dv2.reshape(B, OH, OW, O)
+        dvt = core.tensor4_nhwc(dv)
+        dx = dw = ds = None
+        if ctx.needs_input_grad[0] or ctx.needs_input_grad[2]:
+            dxs = torch.empty((B, H, W, I), device=dy.device, dtype=torch.float32)
+            core.engine_call('ldetr_conv2d_bwd_data_f32', 2.0 * B * OH * OW * O * KH * KW * I, lambda: core.check(core.lib().ldetr_conv2d_bwd_data_f32(core.ptr(dv), ctypes.byref(dvt), core.ptr(w), I, KH, KW, 1, pad,
+                                                            core.ptr(dxs), I, H, W, core.ptr(d), d.stride(0), None, core.stream()),
+                       'modconv_bwd_data'))
+            dx, ds = _mul_reduce(dxs, x, s, B, H * W, I)
+        if ctx.needs_input_grad[1]:
+            dw_ohwi = torch.empty((O, KH, KW, I), device=dy.device, dtype=torch.float32)
+            xt = core.tensor4_nhwc(x)
+            tiles = KH * KW * ((O + 63) // 64) * ((I + 63) // 64)
+            sk = core.pick_splitk(tiles, B * OH * OW, target=512, min_k=512)
+            core.engine_call('ldetr_conv2d_bwd_weight_f32', 2.0 * B * OH * OW * O * KH * KW * I, lambda: core.check(core.lib().ldetr_conv2d_bwd_weight_f32(core.ptr(x), ctypes.byref(xt), core.ptr(dv), ctypes.byref(dvt),
+                                                              core.ptr(dw_ohwi), KH, KW, 1, pad, sk, core.ptr(s), s.stride(0),
+                                                              core.ptr(d), d.stride(0), core.stream()), 'modconv_bwd_weight'))
+            dw = _grad_to_oihw(dw_ohwi)
+        return dx, dw, ds, ddemod, dbias, None, None, None
+
+
+class _ModConvUpFn(torch.autograd.Function):
+    """y = lrelu(FIR4x4(conv_transpose3x3_s2(x * s) * d) * 4 + bias) * gain      (up == 2)"""
+
+    @staticmethod
+    def forward(ctx, x, weight, styles, dcoefs, bias, f, act_alpha, act_gain):
+        core.require_gpu(x, weight, styles, dcoefs, bias, f)
+        x = core.f32c(x); w = core.f32c(weight_ohwi(weight)); s = core.f32c(styles); d = core.f32c(dcoefs); b = core.f32c(bias)
+        B, H, W, I = x.shape
+        O, KH, KW, _ = w.shape
+        UH, UW = (H - 1) * 2 + KH, (W - 1) * 2 + KW
+        ud = torch.empty((B, UH, UW, O), device=x.device, dtype=torch.float32)
+        xt = core.tensor4_nhwc(x)
+        ep = core.epilogue(samp_scale=d)
+        core.engine_call('ldetr_conv_transpose2d_fwd_f32', 2.0 * B * H * W * O * KH * KW * I, lambda: core.check(core.lib().ldetr_conv_transpose2d_fwd_f32(core.ptr(x), ctypes.byref(xt), core.ptr(w), O, KH, KW, 2, 0, core.ptr(ud),
+                                                             O, UH, UW, core.ptr(s), s.stride(0), ctypes.byref(ep), core.stream()),
+                   'modconv_up_fwd'))
+        # conv2d_resample.py:113-130 with padding=1, 4-tap filter, up=2 -> transposed-conv pad 0, FIR pad [1,1,1,1], gain 4
+        y = _up._kernel_call(ud.permute(0, 3, 1, 2), f, 1, 1, 1, 1, 1, 1, 1, 1, False, 4.0, act_bias=b,
+                             act=(act_alpha, act_gain)).permute(0, 2, 3, 1)
+        ctx.save_for_backward(x, w, s, d, b, f, ud, y)
+        ctx.cfg = (act_alpha, act_gain)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, s, d, b, f, ud, y = ctx.saved_tensors
+        act_alpha, act_gain = ctx.cfg
+        B, H, W, I = x.shape
+        O, KH, KW, _ = w.shape
+        _, UH, UW, _ = ud.shape
+        dy = core.f32c(dy)
+        dv2, dbias, _ = act_backward(dy.reshape(-1, O), y.reshape(-1, O), ACT_LRELU, act_alpha, act_gain, True)
+        dv = dv2.reshape(y.shape)
+        # adjoint of the FIR (upfirdn2d.py:252-270): flipped taps, pad [fw-px0-1, iw-ow+px0, ...] = [2,2,2,2]
+        dud = _up._kernel_call(dv.permute(0, 3, 1, 2), f, 1, 1, 1, 1, 2, 2, 2, 2, True, 4.0).permute(0, 2, 3, 1)
+        _, dd_num = _mul_reduce(dud, ud, None, B, UH * UW, O, want_out=False)
+        ddemod = dd_num / d
+        dudt = core.tensor4_nhwc(dud)
+        dx = dw = ds = None
+        if ctx.needs_input_grad[0] or ctx.needs_input_grad[2]:
+            dxs = torch.empty((B, H, W, I), device=dy.device, dtype=torch.float32)
+            core.engine_call('ldetr_conv_transpose2d_bwd_data_f32', 2.0 * B * H * W * O * KH * KW * I, lambda: core.check(core.lib().ldetr_conv_transpose2d_bwd_data_f32(core.ptr(dud), ctypes.byref(dudt), core.ptr(w), I, KH, KW, 2, 0,
+                                                                      core.ptr(dxs), I, H, W, core.ptr(d), d.stride(0), None,
+                                                                      core.stream()), 'modconv_up_bwd_data'))
+            dx, ds = _mul_reduce(dxs, x, s, B, H * W, I)
+        if ctx.needs_input_grad[1]:
+            dw_ohwi = torch.empty((O, KH, KW, I), device=dy.device, dtype=torch.float32)
+            xt = core.tensor4_nhwc(x)
+            tiles = KH * KW * ((O + 63) // 64) * ((I + 63) // 64)
+            sk = core.pick_splitk(tiles, B * H * W, target=512, min_k=512)
+            core.engine_call('ldetr_conv_transpose2d_bwd_weight_f32', 2.0 * B * H * W * O * KH * KW * I, lambda: core.check(core.lib().ldetr_conv_transpose2d_bwd_weight_f32(core.ptr(x), ctypes.byref(xt), core.ptr(dud), ctypes.byref(dudt),
+                                                                        core.ptr(dw_ohwi), KH, KW, 2, 0, sk, core.ptr(s), s.stride(0),
+                                                                        core.ptr(d), d.stride(0), core.stream()), 'modconv_up_bwd_weight'))
+            dw = _grad_to_oihw(dw_ohwi)
+        return dx, dw, ds, ddemod, dbias, None, None, None
+
+
+class _ToRGBFn(torch.autograd.Function):
+    """y = conv1x1(x * s) + bias   (no demodulation, linear activation; 3 output channels)"""
+
+    @staticmethod
+    def forward(ctx, x, weight, styles, bias):
+        core.require_gpu(x, weight, styles, bias)
+        x = core.f32c(x); s = core.f32c(styles); b = core.f32c(bias)
+        w = core.f32c(weight.reshape(weight.shape[0], -1))  # [3, C]
+        B, H, W, C = x.shape
+        O = w.shape[0]
+        y = torch.empty((B, H, W, O), device=x.device, dtype=torch.float32)
+        xt = core.tensor4_nhwc(x)
+        ep = core.epilogue(col_bias=b)
+        core.engine_call('ldetr_conv2d_fwd_f32', 2.0 * B * H * W * O * C, lambda: core.check(core.lib().ldetr_conv2d_fwd_f32(core.ptr(x), ctypes.byref(xt), core.ptr(w), O, 1, 1, 1, 0, core.ptr(y), O, H, W,
+                                                   core.ptr(s), s.stride(0), ctypes.byref(ep), core.stream()), 'torgb_fwd'))
+        ctx.save_for_backward(x, w, s)
+        ctx.wshape = weight.shape
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, s = ctx.saved_tensors
+        B, H, W, C = x.shape
+        O = w.shape[0]
+        if O != 3:
+            raise NotImplementedError('toRGB backward kernel is specialised for 3 colour channels')
+        dy = core.f32c(dy)
+        dx = torch.empty_like(x)
+        dws = torch.zeros((B, O, C), device=x.device, dtype=torch.float32)
+        dbias = torch.zeros(O, device=x.device, dtype=torch.float32)
+        core.check(core.lib().ldetr_torgb_bwd_f32(core.ptr(x), core.ptr(dy), core.ptr(w), core.ptr(s), core.ptr(dx), core.ptr(dws),
+                                                  core.ptr(dbias), B, H * W, C, core.stream()), 'torgb_bwd')
+        dw = (dws * s.unsqueeze(1)).sum(0).reshape(ctx.wshape)
+        ds = (dws * w.unsqueeze(0)).sum(1)
+        return dx, dw, ds, dbias
+
+
+def demod_coefs(weight, styles):
+    """dcoefs[b,o] = rsqrt(sum_{i,kh,kw} (w[o,i,kh,kw] * s[b,i])^2 + 1e-8)  (networks_stylegan2.py:57-61), evaluated as
+    a [B,I]x[I,O] GEMM over squared operands instead of materialising the [B,O,I,k,k] tensor."""
+    from .linear import linear
+    w2 = weight.square().sum(dim=[2, 3])          # [O, I]
+    return (linear(styles.square(), w2) + 1e-8).rsqrt()
+
+
+def modconv3x3(x, weight, styles, bias, act_alpha=0.2, act_gain=math.sqrt(2)):
+    d = demod_coefs(weight, styles)
+    return _ModConvFn.apply(x, weight, styles, d, bias, weight.shape[2] // 2, act_alpha, act_gain)
+
+
+def modconv3x3_up2(x, weight, styles, bias, f, act_alpha=0.2, act_gain=math.sqrt(2)):
+    d = demod_coefs(weight, styles)
+    return _ModConvUpFn.apply(x, weight, styles, d, bias, f, act_alpha, act_gain)
+
+
+def torgb(x, weight, styles, bias):
+    return _ToRGBFn.apply(x, weight, styles, bias)

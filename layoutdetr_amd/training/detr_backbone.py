@@ -1,0 +1,166 @@
+"""ResNet-50 trunk with frozen BatchNorm on the gfx950 implicit-GEMM conv kernels.
+
+Interface of the reference `training/detr_backbone.py` (FrozenBatchNorm2d :29-65, BackboneBase :68-95,
+Backbone :98-114, Joiner :117-134) with torchvision-0.13.1 ResNet-50 v1.5 parameter names
+(`body.conv1.weight`, `body.layer2.0.downsample.0.weight`, ...), so UP-DETR / SwAV state dicts load.
+Differences by design: activations are NHWC, each conv+BN(+residual)+ReLU is ONE kernel launch
+(BN affine folded into the conv epilogue), and construction never touches the network (the
+reference downloads SwAV weights at detr_backbone.py:110; load a local state_dict instead).
+"""
+import math
+from collections import OrderedDict
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from ..detr_util.misc import NestedTensor
+from ..hip import conv as hconv
+
+
+class FrozenBatchNorm2d(nn.Module):
+    """Fixed affine y = x * w*rsqrt(rv+eps) + (b - rm * w*rsqrt(rv+eps)); consumed as a conv epilogue."""
+
+    def __init__(self, n):
+        super().__init__()
+        self.register_buffer('weight', torch.ones(n))
+        self.register_buffer('bias', torch.zeros(n))
+        self.register_buffer('running_mean', torch.zeros(n))
+        self.register_buffer('running_var', torch.ones(n))
+        self._folded = None
+
+    def _load_from_state_dict(self, state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys, error_msgs):
+        state_dict.pop(prefix + 'num_batches_tracked', None)
+        super()._load_from_state_dict(state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys, error_msgs)
+
+    def folded(self):
+        ver = (self.weight._version, self.bias._version, self.running_mean._version, self.running_var._version,
+               self.weight.data_ptr())
+        if self._folded is None or self._folded[0] != ver:
+            scale = self.weight * (self.running_var + 1e-5).rsqrt()
+            shift = self.bias - self.running_mean * scale
+            self._folded = (ver, scale.contiguous(), shift.contiguous())
+        return self._folded[1], self._folded[2]
+
+    def forward(self, x):  # standalone use (NCHW), e.g. tests
+        s, b = self.folded()
+        return x * s.view(1, -1, 1, 1) + b.view(1, -1, 1, 1)
+
+    def __deepcopy__(self, memo):
+        new = FrozenBatchNorm2d(self.weight.numel())
+        for k in ('weight', 'bias', 'running_mean', 'running_var'):
+            getattr(new, k).data = getattr(self, k).data.clone()
+        return new
+
+    def __getstate__(self):
+        d = dict(self.__dict__)
+        d['_folded'] = None
+        return d
+
+
+class _Conv(nn.Module):
+    """Conv2d parameters (OIHW shape, channels_last memory = OHWI contiguous), torchvision's kaiming fan_out init."""
+
+    def __init__(self, cin, cout, k, stride=1, pad=0):
+        super().__init__()
+        w = torch.empty(cout, cin, k, k)
+        nn.init.kaiming_normal_(w, mode='fan_out', nonlinearity='relu')
+        self.weight = nn.Parameter(w.to(memory_format=torch.channels_last))
+        self.stride, self.pad = stride, pad
+
+
+class Bottleneck(nn.Module):
+    expansion = 4
+
+    def __init__(self, inplanes, planes, stride=1, downsample=False):
+        super().__init__()
+        self.conv1 = _Conv(inplanes, planes, 1)
+        self.bn1 = FrozenBatchNorm2d(planes)
+        self.conv2 = _Conv(planes, planes, 3, stride, 1)
+        self.bn2 = FrozenBatchNorm2d(planes)
+        self.conv3 = _Conv(planes, planes * 4, 1)
+        self.bn3 = FrozenBatchNorm2d(planes * 4)
+        self.downsample = None
+        if downsample:
+            self.downsample = nn.Sequential(_Conv(inplanes, planes * 4, 1, stride, 0), FrozenBatchNorm2d(planes * 4))
+
+    def forward(self, x):  # x: [N, H, W, C]
+        s1, b1 = self.bn1.folded(); s2, b2 = self.bn2.folded(); s3, b3 = self.bn3.folded()
+        out = hconv.conv2d_nhwc(x, self.conv1.weight, s1, b1, None, 1, 0, relu=True)
+        out = hconv.conv2d_nhwc(out, self.conv2.weight, s2, b2, None, self.conv2.stride, 1, relu=True)
+        idt = x
+        if self.downsample is not None:
+            sd, bd = self.downsample[1].folded()
+            idt = hconv.conv2d_nhwc(x, self.downsample[0].weight, sd, bd, None, self.downsample[0].stride, 0, relu=False)
+        return hconv.conv2d_nhwc(out, self.conv3.weight, s3, b3, idt, 1, 0, relu=True)
+
+
+class ResNet50Body(nn.Module):
+    """conv1/bn1/maxpool/layer1..4 of torchvision resnet50 (what IntermediateLayerGetter keeps, detr_backbone.py:78-79)."""
+
+    def __init__(self):
+        super().__init__()
+        self.conv1 = _Conv(3, 64, 7, 2, 3)
+        self.bn1 = FrozenBatchNorm2d(64)
+        inplanes = 64
+        for li, (planes, blocks) in enumerate(zip((64, 128, 256, 512), (3, 4, 6, 3)), start=1):
+            stride = 1 if li == 1 else 2
+            layers = [Bottleneck(inplanes, planes, stride, downsample=True)]
+            inplanes = planes * 4
+            layers += [Bottleneck(inplanes, planes) for _ in range(1, blocks)]
+            setattr(self, f'layer{li}', nn.Sequential(*layers))
+
+    def forward(self, x_nchw):
+        s, b = self.bn1.folded()
+        x = hconv.conv2d_nhwc(x_nchw, self.conv1.weight, s, b, None, 2, 3, relu=True, x_is_nchw=True)
+        x = hconv.maxpool3x3s2_nhwc(x)
+        x = self.layer1(x); x = self.layer2(x); x = self.layer3(x); x = self.layer4(x)
+        return x  # [N, H/32, W/32, 2048]
+
+
+class BackboneBase(nn.Module):
+    def __init__(self, backbone: nn.Module, train_backbone: bool, num_channels: int, return_interm_layers: bool):
+        super().__init__()
+        for name, parameter in backbone.named_parameters():
+            if not train_backbone or 'layer2' not in name and 'layer3' not in name and 'layer4' not in name:
+                parameter.requires_grad_(False)
+        if return_interm_layers:
+            raise NotImplementedError('return_interm_layers is not used by LayoutDETR')
+        self.body = backbone
+        self.num_channels = num_channels
+
+    def forward(self, tensor_list):
+        if isinstance(tensor_list, NestedTensor):
+            x = self.body(tensor_list.tensors).permute(0, 3, 1, 2)  # NCHW-shaped view of NHWC memory
+            m = tensor_list.mask
+            assert m is not None
+            if getattr(tensor_list, 'uniform', False):
+                mask = torch.zeros((x.shape[0], x.shape[2], x.shape[3]), dtype=torch.bool, device=x.device)
+            else:
+                mask = F.interpolate(m[None].float(), size=x.shape[-2:]).to(torch.bool)[0]
+            return OrderedDict([('0', NestedTensor(x, mask, getattr(tensor_list, 'uniform', False)))])
+        return OrderedDict([('0', self.body(tensor_list).permute(0, 3, 1, 2))])
+
+
+class Backbone(BackboneBase):
+    """ResNet-50 backbone with frozen BatchNorm.  `name` must be 'resnet50'."""
+
+    def __init__(self, name: str = 'resnet50', train_backbone: bool = True, return_interm_layers: bool = False, dilation: bool = False):
+        if name != 'resnet50' or dilation:
+            raise NotImplementedError('only the resnet50 / no-dilation configuration of LayoutDETR is implemented')
+        super().__init__(ResNet50Body(), train_backbone, 2048, return_interm_layers)
+
+
+class Joiner(nn.Sequential):
+    def __init__(self, backbone, position_embedding):
+        super().__init__(backbone, position_embedding)
+
+    def forward(self, tensor_list):
+        if isinstance(tensor_list, NestedTensor):
+            xs = self[0](tensor_list)
+            out, pos = [], []
+            for _, x in xs.items():
+                out.append(x)
+                pos.append(self[1](x).to(x.tensors.dtype))
+            return out, pos
+        return list(self[0](tensor_list).values())

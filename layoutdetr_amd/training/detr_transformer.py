@@ -1,0 +1,191 @@
+"""DETR encoder-decoder on the gfx950 kernels, interface-compatible with the reference
+`training/detr_transformer.py` (Transformer :73-112, TransformerWithToken :22-70, encoder/decoder layers
+:180-322; post-norm only, relu FFN).  Same constructor signatures, same parameter names (so UP-DETR
+checkpoints and `state_dict`s load unchanged), same forward signature and return values.
+
+Internals differ by design: activations are batch-first row-major [B*L, d] matrices (row = b*L + l),
+every projection / FFN is one f32-MFMA GEMM with fused bias/relu/dropout, attention is one fused
+kernel per call, and each `x = norm(x + dropout(sub(x)))` is one kernel.
+"""
+import copy
+from typing import Optional
+
+import torch
+from torch import Tensor, nn
+
+from ..hip import core
+from ..hip.attention import mha_forward
+from ..hip.layernorm import add_layernorm
+from ..hip.linear import linear
+
+
+class _MHAParams(nn.MultiheadAttention):
+    """Parameter container with nn.MultiheadAttention's names/initialisation; forward is the HIP path."""
+
+    def forward(self, *a, **k):  # pragma: no cover
+        raise RuntimeError('use layoutdetr_amd.hip.attention.mha_forward')
+
+
+def _mha(m: nn.MultiheadAttention, q2, k2, v2, B, Lq, Lk, kpm, training, same_qk=False, same_qkv=False):
+    p = m.dropout if training else 0.0
+    return mha_forward(q2, k2, v2, m.in_proj_weight, m.in_proj_bias, m.out_proj.weight, m.out_proj.bias, m.num_heads,
+                       B, Lq, Lk, key_padding_mask=kpm, p_drop=p, same_qk=same_qk, same_qkv=same_qkv)
+
+
+def _ffn(layer, x2):
+    p = layer.dropout.p if layer.training else 0.0
+    h = linear(x2, layer.linear1.weight, layer.linear1.bias, act=core.ACT_RELU, p_drop=p)
+    return linear(h, layer.linear2.weight, layer.linear2.bias)
+
+
+def _add_ln(norm: nn.LayerNorm, x2, r2, drop: nn.Dropout, training):
+    return add_layernorm(x2, r2, norm.weight, norm.bias, norm.eps, drop.p if training else 0.0)
+
+
+class TransformerEncoderLayer(nn.Module):
+    def __init__(self, d_model, nhead, dim_feedforward=2048, dropout=0.1, activation='relu', normalize_before=False):
+        super().__init__()
+        if activation != 'relu' or normalize_before:
+            raise NotImplementedError('only the post-norm relu configuration used by LayoutDETR is implemented')
+        self.self_attn = _MHAParams(d_model, nhead, dropout=dropout)
+        self.linear1 = nn.Linear(d_model, dim_feedforward)
+        self.dropout = nn.Dropout(dropout)
+        self.linear2 = nn.Linear(dim_feedforward, d_model)
+        self.norm1 = nn.LayerNorm(d_model)
+        self.norm2 = nn.LayerNorm(d_model)
+        self.dropout1 = nn.Dropout(dropout)
+        self.dropout2 = nn.Dropout(dropout)
+        self.normalize_before = normalize_before
+
+    def forward2d(self, x2, B, L, kpm, pos2):
+        qk = x2 if pos2 is None else x2 + pos2
+        a = _mha(self.self_attn, qk, qk, x2, B, L, L, kpm, self.training, same_qk=pos2 is not None, same_qkv=pos2 is None)
+        x2 = _add_ln(self.norm1, x2, a, self.dropout1, self.training)
+        return _add_ln(self.norm2, x2, _ffn(self, x2), self.dropout2, self.training)
+
+
+class TransformerDecoderLayer(nn.Module):
+    def __init__(self, d_model, nhead, dim_feedforward=2048, dropout=0.1, activation='relu', normalize_before=False):
+        super().__init__()
+        if activation != 'relu' or normalize_before:
+            raise NotImplementedError('only the post-norm relu configuration used by LayoutDETR is implemented')
+        self.self_attn = _MHAParams(d_model, nhead, dropout=dropout)
+        self.multihead_attn = _MHAParams(d_model, nhead, dropout=dropout)
+        self.linear1 = nn.Linear(d_model, dim_feedforward)
+        self.dropout = nn.Dropout(dropout)
+        self.linear2 = nn.Linear(dim_feedforward, d_model)
+        self.norm1 = nn.LayerNorm(d_model)
+        self.norm2 = nn.LayerNorm(d_model)
+        self.norm3 = nn.LayerNorm(d_model)
+        self.dropout1 = nn.Dropout(dropout)
+        self.dropout2 = nn.Dropout(dropout)
+        self.dropout3 = nn.Dropout(dropout)
+        self.normalize_before = normalize_before
+
+    def forward2d(self, t2, mem2, mem_pos2, B, Lq, S, tgt_kpm, mem_kpm):
+        a = _mha(self.self_attn, t2, t2, t2, B, Lq, Lq, tgt_kpm, self.training, same_qkv=True)
+        t2 = _add_ln(self.norm1, t2, a, self.dropout1, self.training)
+        a = _mha(self.multihead_attn, t2, mem_pos2, mem2, B, Lq, S, mem_kpm, self.training)
+        t2 = _add_ln(self.norm2, t2, a, self.dropout2, self.training)
+        return _add_ln(self.norm3, t2, _ffn(self, t2), self.dropout3, self.training)
+
+
+def _get_clones(module, N):
+    return nn.ModuleList([copy.deepcopy(module) for _ in range(N)])
+
+
+class TransformerEncoder(nn.Module):
+    def __init__(self, encoder_layer, num_layers, norm=None):
+        super().__init__()
+        self.layers = _get_clones(encoder_layer, num_layers)
+        self.num_layers = num_layers
+        self.norm = norm
+
+    def forward2d(self, x2, B, L, kpm, pos2):
+        for layer in self.layers:
+            x2 = layer.forward2d(x2, B, L, kpm, pos2)
+        if self.norm is not None:
+            x2 = add_layernorm(x2, None, self.norm.weight, self.norm.bias, self.norm.eps)
+        return x2
+
+
+class TransformerDecoder(nn.Module):
+    def __init__(self, decoder_layer, num_layers, norm=None, return_intermediate=False):
+        super().__init__()
+        if return_intermediate:
+            raise NotImplementedError('return_intermediate_dec=True is not used by LayoutDETR')
+        self.layers = _get_clones(decoder_layer, num_layers)
+        self.num_layers = num_layers
+        self.norm = norm
+        self.return_intermediate = return_intermediate
+
+    def forward2d(self, t2, mem2, pos2, B, Lq, S, tgt_kpm, mem_kpm):
+        mem_pos2 = mem2 + pos2
+        for layer in self.layers:
+            t2 = layer.forward2d(t2, mem2, mem_pos2, B, Lq, S, tgt_kpm, mem_kpm)
+        if self.norm is not None:
+            t2 = add_layernorm(t2, None, self.norm.weight, self.norm.bias, self.norm.eps)
+        return t2
+
+
+def _rows_from_nchw(x):
+    """[B, C, h, w] (any memory format) -> ([B*h*w, C] row-major, h*w).  Free for channels_last inputs."""
+    B, C, h, w = x.shape
+    return x.permute(0, 2, 3, 1).reshape(B * h * w, C), h * w
+
+
+class Transformer(nn.Module):
+    _with_token = False
+
+    def __init__(self, d_model=512, nhead=8, num_encoder_layers=6, num_decoder_layers=6, dim_feedforward=2048,
+                 dropout=0.1, activation='relu', normalize_before=False, return_intermediate_dec=False):
+        super().__init__()
+        if self._with_token:
+            self.token = nn.Parameter(torch.randn(1, 1, d_model))
+            self.register_buffer('token_mask', torch.zeros(1, 1, dtype=torch.bool))
+        encoder_layer = TransformerEncoderLayer(d_model, nhead, dim_feedforward, dropout, activation, normalize_before)
+        encoder_norm = nn.LayerNorm(d_model) if normalize_before else None
+        self.encoder = TransformerEncoder(encoder_layer, num_encoder_layers, encoder_norm)
+        decoder_layer = TransformerDecoderLayer(d_model, nhead, dim_feedforward, dropout, activation, normalize_before)
+        decoder_norm = nn.LayerNorm(d_model)
+        self.decoder = TransformerDecoder(decoder_layer, num_decoder_layers, decoder_norm,
+                                          return_intermediate=return_intermediate_dec)
+        self._reset_parameters()
+        self.d_model = d_model
+        self.nhead = nhead
+        if d_model // nhead != 32:
+            raise NotImplementedError('the fused attention kernel is specialised for head_dim 32 (d_model 256, 8 heads)')
+
+    def _reset_parameters(self):
+        for p in self.parameters():
+            if p.dim() > 1:
+                nn.init.xavier_uniform_(p)
+
+    def forward(self, src, mask, pos_embed, tgt, tgt_key_padding_mask, decoder_mask=None):
+        if decoder_mask is not None:
+            raise NotImplementedError('decoder_mask (tgt_mask) is never passed on the LayoutDETR path')
+        bs, c, h, w = src.shape
+        x2, S = _rows_from_nchw(src)
+        pos2, _ = _rows_from_nchw(pos_embed)
+        pos2 = pos2.contiguous()
+        mem_kpm = mask.flatten(1)
+        mem2 = self.encoder.forward2d(x2, bs, S, mem_kpm, pos2)
+        if self._with_token:
+            tgt = torch.cat([self.token.expand(-1, bs, -1), tgt], dim=0)
+            tgt_key_padding_mask = torch.cat([self.token_mask.expand(bs, -1), tgt_key_padding_mask], dim=1)
+        Lq = tgt.shape[0]
+        t2 = tgt.permute(1, 0, 2).reshape(bs * Lq, c)
+        hs2 = self.decoder.forward2d(t2, mem2, pos2, bs, Lq, S, tgt_key_padding_mask, mem_kpm)
+        hs = hs2.reshape(bs, Lq, c)
+        memory = mem2.reshape(bs, h, w, c).permute(0, 3, 1, 2)
+        return hs, memory
+
+
+class TransformerWithToken(Transformer):
+    _with_token = True
+
+
+def build_transformer(args):
+    return Transformer(d_model=args.hidden_dim, dropout=args.dropout, nhead=args.nheads,
+                       dim_feedforward=args.dim_feedforward, num_encoder_layers=args.enc_layers,
+                       num_decoder_layers=args.dec_layers, normalize_before=args.pre_norm, return_intermediate_dec=True)

@@ -1,0 +1,116 @@
+"""StyleGAN2Loss for the LayoutDETR G/D step (reference: training/loss.py:28-218) over the gfx950 modules.
+Same class name, constructor arguments, phase names and loss composition; the default `gamma=0,
+pl_weight=0` configuration (train.py:135-136) makes Greg/Dreg no-ops exactly as loss.py:77-80 does.
+R1 / path-length regularisation need double-backward through the fused kernels and are not implemented
+(SURVEY §7 'second-order autograd'); requesting them raises."""
+import torch
+import torch.nn.functional as F
+
+from ..metrics.metric_layoutnet import compute_alignment, compute_overlap, generalized_iou_loss
+
+
+class Loss:
+    def accumulate_gradients(self, phase, bbox_real, bbox_class, bbox_text, bbox_patch, padding_mask, background, real_c, gen_z, gen_c, gain, cur_nimg):
+        raise NotImplementedError()
+
+
+class StyleGAN2Loss(Loss):
+    def __init__(self, device, G, D, augment_pipe=None, r1_gamma=0.0, style_mixing_prob=0, pl_weight=0.0, pl_batch_shrink=2,
+                 pl_decay=0.01, pl_no_weight_grad=False, blur_init_sigma=0, blur_fade_kimg=0,
+                 Dreal_bbox_cls_weight=50.0, Dreal_bbox_rec_weight=500.0, Dreal_text_rec_weight=0.1, Dreal_text_len_rec_weight=2.0,
+                 Dreal_im_rec_weight=0.5, Ggen_bbox_rec_weight=100.0, Ggen_bbox_gIoU_weight=4.0, Ggen_overlapping_weight=7.0,
+                 Ggen_alignment_weight=17.0, Ggen_z_rec_weight=5.0, Ggen_bbox_cls_weight=50.0, Ggen_text_rec_weight=1.0,
+                 Ggen_text_len_rec_weight=1.0, report_fn=None):
+        super().__init__()
+        self.device = device
+        self.G = G
+        self.D = D
+        self.augment_pipe = augment_pipe
+        self.r1_gamma = r1_gamma
+        self.pl_weight = pl_weight
+        if r1_gamma != 0 or pl_weight != 0:
+            raise NotImplementedError('R1 / path-length regularisation (double backward) is not implemented on the fused kernels')
+        self.w = dict(Dreal_bbox_cls=Dreal_bbox_cls_weight, Dreal_bbox_rec=Dreal_bbox_rec_weight, Dreal_text_rec=Dreal_text_rec_weight,
+                      Dreal_text_len_rec=Dreal_text_len_rec_weight, Dreal_im_rec=Dreal_im_rec_weight, Ggen_bbox_rec=Ggen_bbox_rec_weight,
+                      Ggen_bbox_gIoU=Ggen_bbox_gIoU_weight, Ggen_overlapping=Ggen_overlapping_weight, Ggen_alignment=Ggen_alignment_weight,
+                      Ggen_z_rec=Ggen_z_rec_weight, Ggen_bbox_cls=Ggen_bbox_cls_weight, Ggen_text_rec=Ggen_text_rec_weight,
+                      Ggen_text_len_rec=Ggen_text_len_rec_weight)
+        self.report = report_fn if report_fn is not None else (lambda name, value: None)
+        self.last = {}
+
+    def run_G(self, z, bbox_class, bbox_real, bbox_text, bbox_patch, padding_mask, background, c, reconst=False, update_emas=False):
+        if not reconst:
+            return self.G(z, bbox_class, bbox_real, bbox_text, bbox_patch, padding_mask, background, c)
+        return self.G(z, bbox_class, bbox_real, bbox_text, bbox_patch, padding_mask, background, c, reconst)
+
+    def run_D(self, bbox, bbox_class, bbox_text, bbox_patch, padding_mask, background, c, reconst=False, blur_sigma=0, update_emas=False):
+        if not reconst:
+            return self.D(bbox, bbox_class, bbox_text, bbox_patch, padding_mask, background, c)
+        return self.D(bbox, bbox_class, bbox_text, bbox_patch, padding_mask, background, c, reconst)
+
+    def g_main_loss(self, bbox_real, bbox_class, bbox_text, bbox_patch, padding_mask, background, gen_z, gen_c):
+        w = self.w
+        valid = ~padding_mask
+        bbox_fake, loss_z, cls_logits, loss_lm, loss_text_len = self.run_G(gen_z, bbox_class, bbox_real, bbox_text, bbox_patch, padding_mask, background, gen_c, reconst=True)
+        gen_logits, gen_logits_uncond = self.run_D(bbox_fake, bbox_class, bbox_text, bbox_patch, padding_mask, background, gen_c)
+        terms = dict(
+            loss_Ggen=F.softplus(-gen_logits),
+            loss_Ggen_uncond=F.softplus(-gen_logits_uncond),
+            loss_Ggen_bbox_rec=F.mse_loss(bbox_fake[valid], bbox_real[valid]) * w['Ggen_bbox_rec'],
+            loss_Ggen_bbox_gIoU=generalized_iou_loss(bbox_fake[valid], bbox_real[valid]) * w['Ggen_bbox_gIoU'],
+            loss_Ggen_overlapping=compute_overlap(bbox_fake, valid) * w['Ggen_overlapping'],
+            loss_Ggen_alignment=compute_alignment(bbox_fake, valid) * w['Ggen_alignment'],
+            loss_Ggen_z_rec=loss_z * w['Ggen_z_rec'],
+            loss_Ggen_bbox_cls=F.cross_entropy(cls_logits, bbox_class[valid]) * w['Ggen_bbox_cls'],
+            loss_Ggen_text_rec=loss_lm * w['Ggen_text_rec'],
+            loss_Ggen_text_len_rec=loss_text_len * w['Ggen_text_len_rec'],
+        )
+        self.report('Loss/scores/fake', gen_logits)
+        for k, v in terms.items():
+            self.report('Loss/G/' + k, v)
+        total = sum(terms.values())
+        self.last = dict(bbox_fake=bbox_fake.detach(), **{k: v.detach() for k, v in terms.items()})
+        return total.mean()
+
+    def d_gen_loss(self, bbox_real, bbox_class, bbox_text, bbox_patch, padding_mask, background, gen_z, gen_c):
+        bbox_fake = self.run_G(gen_z, bbox_class, bbox_real, bbox_text, bbox_patch, padding_mask, background, gen_c, update_emas=True)
+        gen_logits, gen_logits_uncond = self.run_D(bbox_fake, bbox_class, bbox_text, bbox_patch, padding_mask, background, gen_c, update_emas=True)
+        loss_Dgen = F.softplus(gen_logits)
+        loss_Dgen_uncond = F.softplus(gen_logits_uncond)
+        self.report('Loss/D/loss_Dgen', loss_Dgen)
+        self.report('Loss/D/loss_Dgen_uncond', loss_Dgen_uncond)
+        return (loss_Dgen + loss_Dgen_uncond).mean()
+
+    def d_real_loss(self, bbox_real, bbox_class, bbox_text, bbox_patch, padding_mask, background, real_c):
+        w = self.w
+        valid = ~padding_mask
+        bbox_real_tmp = bbox_real.detach()
+        (real_logits, real_logits_uncond, bbox_rec, cls_logits, loss_lm, loss_text_len, bg_rec, bbox_rec_uncond,
+         cls_logits_uncond) = self.run_D(bbox_real_tmp, bbox_class, bbox_text, bbox_patch, padding_mask, background, real_c, reconst=True)
+        terms = dict(
+            loss_Dreal=F.softplus(-real_logits),
+            loss_Dreal_uncond=F.softplus(-real_logits_uncond),
+            loss_Dreal_bbox_rec=F.mse_loss(bbox_rec, bbox_real_tmp[valid]) * w['Dreal_bbox_rec'],
+            loss_Dreal_bbox_cls=F.cross_entropy(cls_logits, bbox_class[valid]) * w['Dreal_bbox_cls'],
+            loss_Dreal_text_rec=loss_lm * w['Dreal_text_rec'],
+            loss_Dreal_text_len_rec=loss_text_len * w['Dreal_text_len_rec'],
+            loss_Dreal_bg_rec=F.mse_loss(bg_rec, background) * w['Dreal_im_rec'],
+            loss_Dreal_bbox_rec_uncond=F.mse_loss(bbox_rec_uncond, bbox_real_tmp[valid]) * w['Dreal_bbox_rec'],
+            loss_Dreal_bbox_cls_uncond=F.cross_entropy(cls_logits_uncond, bbox_class[valid]) * w['Dreal_bbox_cls'],
+        )
+        self.report('Loss/scores/real', real_logits)
+        for k, v in terms.items():
+            self.report('Loss/D/' + k, v)
+        return sum(terms.values()).mean()
+
+    def accumulate_gradients(self, phase, bbox_real, bbox_class, bbox_text, bbox_patch, padding_mask, background, real_c, gen_z, gen_c, gain, cur_nimg):
+        assert phase in ['Gmain', 'Greg', 'Gboth', 'Dmain', 'Dreg', 'Dboth']
+        if self.pl_weight == 0:
+            phase = {'Greg': 'none', 'Gboth': 'Gmain'}.get(phase, phase)
+        if self.r1_gamma == 0:
+            phase = {'Dreg': 'none', 'Dboth': 'Dmain'}.get(phase, phase)
+        if phase == 'Gmain':
+            self.g_main_loss(bbox_real, bbox_class, bbox_text, bbox_patch, padding_mask, background, gen_z, gen_c).mul(gain).backward()
+        if phase == 'Dmain':
+            self.d_gen_loss(bbox_real, bbox_class, bbox_text, bbox_patch, padding_mask, background, gen_z, gen_c).mul(gain).backward()
+            self.d_real_loss(bbox_real, bbox_class, bbox_text, bbox_patch, padding_mask, background, real_c).mul(gain).backward()

@@ -1,0 +1,279 @@
+"""LayoutDETR Generator / Discriminator on the gfx950 hot path — drop-in for the reference
+`training/networks_detr.py` (Generator :65-187, Discriminator :190-361): same class names, constructor
+keyword arguments, forward signatures, return tuples, parameter names and `text_encoder` attribute, so
+`dnnlib.util.construct_class_by_name(class_name='layoutdetr_amd.training.networks_detr.Generator', ...)`
+works from the reference `train.py` / `training_loop.py` unchanged (SURVEY §8b seam 1).
+
+Text path (SURVEY §8a rows a16/a17 are *boundary inputs*, not kernel rows): `bbox_text` may be
+  * a `TextFeatures` carrying the frozen BERT CLS features [B, N, 768] and character counts [B, N]
+    (hot-path-only mode, BASELINE.md variant A), or
+  * a list of B lists of N strings as in the reference — requires `text_mode='bert'`, which is the
+    round-2 row 8f-1 and raises NotImplementedError for now.
+In features mode the LM-decoder reconstruction loss (`loss_lm`) is returned as a zero tensor.
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from ..detr_util.misc import NestedTensor, nested_tensor_from_tensor_list
+from ..hip import conv as hconv
+from ..hip import core
+from ..hip.linear import linear
+from .detr_backbone import Backbone, Joiner
+from .detr_position_encoding import PositionEmbeddingSine
+from .detr_transformer import Transformer, TransformerEncoder, TransformerEncoderLayer, TransformerWithToken
+from .networks_stylegan2 import Decoder
+from .util import TransformerWithToken_layoutganpp, encode_seq_first
+
+
+def merge_lists(lists):
+    ret = []
+    for l in lists:
+        ret += l
+    return ret
+
+
+def split_list(list_a, chunk_size):
+    return [list_a[i:i + chunk_size] for i in range(0, len(list_a), chunk_size)]
+
+
+def normalize_2nd_moment(x, eps=1e-8):
+    return x * (x.square().mean(dim=1, keepdim=True) + eps).rsqrt()
+
+
+def build_backbone():
+    backbone = Backbone(name='resnet50', train_backbone=True, return_interm_layers=None, dilation=False)
+    position_embedding = PositionEmbeddingSine(num_pos_feats=128, normalize=True)
+    model = Joiner(backbone, position_embedding)
+    model.num_channels = backbone.num_channels
+    return model
+
+
+class TextFeatures(object):
+    """Precomputed output of the frozen text encoder for one batch (boundary input of the hot path)."""
+
+    def __init__(self, text_feat, text_len, input_ids=None, attention_mask=None):
+        self.text_feat = text_feat      # [B, N, bert_f_dim] fp32
+        self.text_len = text_len        # [B, N] int64 (character counts, < max_text_length)
+        self.input_ids = input_ids
+        self.attention_mask = attention_mask
+
+    def __len__(self):
+        return self.text_feat.shape[0]
+
+    def __getitem__(self, idx):  # supports the `bbox_text[:batch_size]` slicing of loss.py:125
+        return TextFeatures(self.text_feat[idx], self.text_len[idx],
+                            None if self.input_ids is None else self.input_ids[idx],
+                            None if self.attention_mask is None else self.attention_mask[idx])
+
+
+class _NoTextEncoder(nn.Module):
+    """Placeholder so `module.text_encoder.requires_grad_(False)` (training_loop.py:283) keeps working."""
+
+    def forward(self, *a, **k):
+        raise NotImplementedError("text_mode='features': pass TextFeatures instead of strings (BERT text path is SURVEY §8f-1)")
+
+
+class Linear(nn.Linear):
+    """nn.Linear parameters, f32-MFMA forward/backward."""
+
+    def forward(self, x, relu=False):
+        return linear(x, self.weight, self.bias, act=core.ACT_RELU if relu else core.ACT_NONE)
+
+
+class Conv1x1(nn.Conv2d):
+    """nn.Conv2d(cin, cout, kernel_size=1) parameters; NHWC implicit-GEMM forward/backward."""
+
+    def forward(self, x_nchw_view):
+        x = x_nchw_view.permute(0, 2, 3, 1)
+        y = hconv.conv2d_nhwc(x, self.weight, None, self.bias, None, 1, 0, relu=False)
+        return y.permute(0, 3, 1, 2)
+
+
+class MLP(nn.Module):
+    """Very simple multi-layer perceptron (reference: networks_detr.py:50-62); ReLU fused in the GEMM epilogue."""
+
+    def __init__(self, input_dim, hidden_dim, output_dim, num_layers):
+        super().__init__()
+        self.num_layers = num_layers
+        h = [hidden_dim] * (num_layers - 1)
+        self.layers = nn.ModuleList(Linear(n, k) for n, k in zip([input_dim] + h, h + [output_dim]))
+
+    def forward(self, x, final_relu=False):
+        for i, layer in enumerate(self.layers):
+            x = layer(x, relu=(i < self.num_layers - 1) or final_relu)
+        return x
+
+
+def _text_inputs(module, bbox_text, B, N, device):
+    if isinstance(bbox_text, TextFeatures):
+        return bbox_text.text_feat.to(device=device, dtype=torch.float32), bbox_text.text_len.to(device=device, dtype=torch.int64)
+    raise NotImplementedError('string inputs need the BERT text encoder (SURVEY §8f-1, next round); pass TextFeatures')
+
+
+def _zero_like_loss(ref):
+    return ref.new_zeros(())
+
+
+class Generator(nn.Module):
+    def __init__(self, z_dim, num_bbox_labels, img_channels, img_height, img_width, c_dim,
+                 f_dim=256, num_heads=4, num_layers=8, hidden_dim=256,
+                 med_config='configs/med_config.json', bert_f_dim=768, bert_num_encoder_layers=12, bert_num_decoder_layers=12,
+                 bert_num_heads=12, background_size=1024, im_f_dim=512, max_text_length=256, text_mode='features'):
+        super().__init__()
+        self.z_dim = z_dim
+        self.num_bbox_labels = num_bbox_labels
+        self.c_dim = c_dim
+        self.max_text_length = max_text_length
+        self.text_mode = text_mode
+        if text_mode != 'features':
+            raise NotImplementedError("text_mode='bert' is the next hot-path row (SURVEY §8f-1)")
+
+        self.backbone = build_backbone()
+        self.input_proj = Conv1x1(self.backbone.num_channels, hidden_dim, kernel_size=1)
+        self.fc_z = Linear(z_dim * 9, bert_f_dim)
+        self.emb_label = nn.Embedding(num_bbox_labels, bert_f_dim)
+        self.text_encoder = _NoTextEncoder()
+        self.enc_text_len = nn.Embedding(max_text_length, bert_f_dim)
+        self.fc_in = MLP(input_dim=4 * bert_f_dim, hidden_dim=bert_f_dim, output_dim=hidden_dim, num_layers=3)
+        self.transformer = Transformer(d_model=hidden_dim, dropout=0.1, nhead=8, dim_feedforward=2048, num_encoder_layers=6,
+                                       num_decoder_layers=6, normalize_before=False, return_intermediate_dec=False)
+        self.bbox_embed = MLP(input_dim=hidden_dim, hidden_dim=hidden_dim, output_dim=4, num_layers=3)
+        # reconstructor heads
+        self.fc_z_rec = Linear(hidden_dim, z_dim * 9)
+        self.fc_out_cls = Linear(hidden_dim, num_bbox_labels)
+        self.fc_text_len_rec = Linear(hidden_dim, max_text_length)
+
+    def forward(self, z, bbox_class, bbox_real, bbox_text, bbox_patch, padding_mask, background, c, reconst=False):
+        if isinstance(background, (list, torch.Tensor)):
+            background = nested_tensor_from_tensor_list(background)
+        bg_feat, pos = self.backbone(background)
+        bg_feat, mask = bg_feat[-1].decompose()
+        assert mask is not None
+
+        B, N = bbox_patch.shape[0], bbox_patch.shape[1]
+        z0 = normalize_2nd_moment(z.view(B, -1))
+        zf = self.fc_z(z0).unsqueeze(1).expand(-1, N, -1)
+        l = self.emb_label(bbox_class)
+        text_feat, text_len = _text_inputs(self, bbox_text, B, N, bbox_class.device)
+        text_len_feat = self.enc_text_len(text_len)
+        x = torch.cat([zf, l, text_feat, text_len_feat], dim=-1)
+        x = self.fc_in(x, final_relu=True).permute(1, 0, 2)
+
+        x = self.transformer(src=self.input_proj(bg_feat), mask=mask, pos_embed=pos[-1], tgt=x, tgt_key_padding_mask=padding_mask)[0]
+        bbox_fake = self.bbox_embed(x).sigmoid()
+        if not reconst:
+            return bbox_fake
+
+        valid = ~padding_mask
+        xv = x[valid]
+        z_rec = self.fc_z_rec(xv)
+        loss_z = F.mse_loss(z_rec, z0.unsqueeze(1).expand(-1, N, -1)[valid])
+        logit_cls = self.fc_out_cls(xv)
+        loss_lm = _zero_like_loss(loss_z)
+        text_len_rec = self.fc_text_len_rec(xv)
+        loss_text_len = F.cross_entropy(text_len_rec, text_len[valid])
+        return bbox_fake, loss_z, logit_cls, loss_lm, loss_text_len
+
+
+class Discriminator(nn.Module):
+    def __init__(self, num_bbox_labels, img_channels, img_height, img_width, c_dim,
+                 f_dim=256, num_heads=4, num_layers=8, max_bbox=50, hidden_dim=256,
+                 med_config='configs/med_config.json', bert_f_dim=768, bert_num_encoder_layers=12, bert_num_decoder_layers=12,
+                 bert_num_heads=12, background_size=1024, im_f_dim=512, max_text_length=256, text_mode='features'):
+        super().__init__()
+        self.num_bbox_labels = num_bbox_labels
+        self.c_dim = c_dim
+        self.max_text_length = max_text_length
+        self.text_mode = text_mode
+        if text_mode != 'features':
+            raise NotImplementedError("text_mode='bert' is the next hot-path row (SURVEY §8f-1)")
+
+        # encoder
+        self.backbone = build_backbone()
+        self.input_proj = Conv1x1(self.backbone.num_channels, hidden_dim, kernel_size=1)
+        self.fc_bbox = Linear(4, bert_f_dim)
+        self.emb_label = nn.Embedding(num_bbox_labels, bert_f_dim)
+        self.text_encoder = _NoTextEncoder()
+        self.enc_text_len = nn.Embedding(max_text_length, bert_f_dim)
+        self.enc_fc_in = MLP(input_dim=4 * bert_f_dim, hidden_dim=bert_f_dim, output_dim=hidden_dim, num_layers=3)
+        self.enc_transformer = TransformerWithToken(d_model=hidden_dim, dropout=0.1, nhead=8, dim_feedforward=2048,
+                                                    num_encoder_layers=6, num_decoder_layers=6, normalize_before=False,
+                                                    return_intermediate_dec=False)
+        self.fc_out_disc = Linear(hidden_dim, 1)
+
+        # decoder
+        self.pos_token = nn.Parameter(torch.rand(max_bbox, 1, hidden_dim))
+        self.dec_fc_in = Linear(hidden_dim + hidden_dim, hidden_dim)
+        self.dec_transformer = TransformerEncoder(TransformerEncoderLayer(d_model=hidden_dim, nhead=8, dim_feedforward=2048), num_layers=6)
+        self.bbox_embed = Linear(hidden_dim, 4)
+        self.fc_out_cls = Linear(hidden_dim, num_bbox_labels)
+        self.fc_text_len_rec = Linear(hidden_dim, max_text_length)
+        self.bg_decoder = Decoder(z_dim=hidden_dim, w_dim=im_f_dim, channel_max=im_f_dim, channel_base=8192, img_channels=img_channels,
+                                  img_resolution=background_size, use_noise=False, num_fp16_res=0, conv_clamp=None,
+                                  fused_modconv_default=False)
+
+        # unconditional discriminator
+        self.fc_bbox_uncond = Linear(4, bert_f_dim)
+        self.emb_label_uncond = nn.Embedding(num_bbox_labels, bert_f_dim)
+        self.enc_fc_in_uncond = MLP(input_dim=2 * bert_f_dim, hidden_dim=bert_f_dim, output_dim=hidden_dim, num_layers=3)
+        self.enc_transformer_uncond = TransformerWithToken_layoutganpp(d_model=hidden_dim, dim_feedforward=2048, nhead=8, num_layers=6)
+        self.fc_out_disc_uncond = Linear(hidden_dim, 1)
+        self.pos_token_uncond = nn.Parameter(torch.rand(max_bbox, 1, hidden_dim))
+        self.dec_fc_in_uncond = Linear(hidden_dim + hidden_dim, hidden_dim)
+        self.dec_transformer_uncond = TransformerEncoder(TransformerEncoderLayer(d_model=hidden_dim, nhead=8, dim_feedforward=2048), num_layers=6)
+        self.bbox_embed_uncond = Linear(hidden_dim, 4)
+        self.fc_out_cls_uncond = Linear(hidden_dim, num_bbox_labels)
+
+    def forward(self, bbox, bbox_class, bbox_text, bbox_patch, padding_mask, background, c, reconst=False):
+        if isinstance(background, (list, torch.Tensor)):
+            background = nested_tensor_from_tensor_list(background)
+        bg_feat, pos = self.backbone(background)
+        bg_feat, mask = bg_feat[-1].decompose()
+        assert mask is not None
+
+        B, N = bbox_patch.shape[0], bbox_patch.shape[1]
+        b = self.fc_bbox(bbox)
+        l = self.emb_label(bbox_class)
+        text_feat, text_len = _text_inputs(self, bbox_text, B, N, bbox_class.device)
+        text_len_feat = self.enc_text_len(text_len)
+        x = torch.cat([b, l, text_feat, text_len_feat], dim=-1)
+        x = self.enc_fc_in(x, final_relu=True).permute(1, 0, 2)
+
+        x = self.enc_transformer(src=self.input_proj(bg_feat), mask=mask, pos_embed=pos[-1], tgt=x,
+                                 tgt_key_padding_mask=padding_mask)[0].transpose(0, 1)
+        x0 = x[0]
+        logit_disc = self.fc_out_disc(x0).squeeze(-1)
+
+        b_uncond = self.fc_bbox_uncond(bbox)
+        l_uncond = self.emb_label_uncond(bbox_class)
+        x_uncond = torch.cat([b_uncond, l_uncond], dim=-1)
+        x_uncond = self.enc_fc_in_uncond(x_uncond, final_relu=True).permute(1, 0, 2)
+        x_uncond = self.enc_transformer_uncond(x_uncond, src_key_padding_mask=padding_mask)
+        x0_uncond = x_uncond[0]
+        logit_disc_uncond = self.fc_out_disc_uncond(x0_uncond).squeeze(-1)
+        if not reconst:
+            return logit_disc, logit_disc_uncond
+
+        valid = ~padding_mask
+        x = x0.unsqueeze(0).expand(N, -1, -1)
+        t = self.pos_token[:N].expand(-1, B, -1)
+        x = self.dec_fc_in(torch.cat([x, t], dim=-1), relu=True)
+        x = encode_seq_first(self.dec_transformer, x, padding_mask)
+        x = x.permute(1, 0, 2)[valid]
+        bbox_pred = self.bbox_embed(x).sigmoid()
+        logit_cls = self.fc_out_cls(x)
+        text_len_rec = self.fc_text_len_rec(x)
+        loss_text_len = F.cross_entropy(text_len_rec, text_len[valid])
+        loss_lm = _zero_like_loss(loss_text_len)
+        bg_rec = self.bg_decoder(x0)
+
+        x_uncond = x0_uncond.unsqueeze(0).expand(N, -1, -1)
+        t_uncond = self.pos_token_uncond[:N].expand(-1, B, -1)
+        x_uncond = self.dec_fc_in_uncond(torch.cat([x_uncond, t_uncond], dim=-1), relu=True)
+        x_uncond = encode_seq_first(self.dec_transformer_uncond, x_uncond, padding_mask)
+        x_uncond = x_uncond.permute(1, 0, 2)[valid]
+        bbox_pred_uncond = self.bbox_embed_uncond(x_uncond).sigmoid()
+        logit_cls_uncond = self.fc_out_cls_uncond(x_uncond)
+        return (logit_disc, logit_disc_uncond, bbox_pred, logit_cls, loss_lm, loss_text_len, bg_rec, bbox_pred_uncond, logit_cls_uncond)

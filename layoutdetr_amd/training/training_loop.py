@@ -1,0 +1,179 @@
+"""The per-iteration G/D step of the reference training loop, MI355X-first.
+
+Reference (training/training_loop.py:274-328), per phase: zero_grad -> requires_grad_(True) (text encoder
+re-frozen) -> accumulate_gradients over micro-batches -> `flat = torch.cat(all grads)` -> all_reduce ->
+/num_gpus -> nan_to_num(0, 1e5, -1e5) -> split back -> Adam.step(); then G_ema lerp.
+
+Here every module's parameters (and their gradients) live in ONE contiguous fp32 buffer each
+(`FlatModule`), so that:
+  * zero_grad is one memset, the gradient exchange is an in-place RCCL all-reduce of the flat gradient
+    buffer in large buckets on a side HIP stream (no cat / split copies: the reference moves 2x the
+    gradient volume through HBM just to pack and unpack),
+  * `/world`, nan_to_num and Adam are ONE streaming kernel over (p, g, m, v)  (ldetr_adam_step_f32),
+  * the EMA is one kernel over (p_ema, p)  (ldetr_ema_lerp_f32).
+Semantics kept: SUM all-reduce then divide by world size, nan_to_num constants, Adam(betas, eps) with
+bias correction, EMA beta = 0.5 ** (batch / ema_nimg), buffers of G copied to G_ema.
+
+Everything outside this step (dataset, snapshots, metrics, pickles: training_loop.py:112-171, 341-469)
+is out of scope; `training_iteration` is what `bench.py` times.
+"""
+import copy
+
+import numpy as np
+import torch
+
+from ..hip import core
+from .networks_detr import split_list  # noqa: F401  (training_loop.py:32 imports it from networks_layoutganpp)
+
+
+def _phys_view(flat_slice, like):
+    """View of a flat slice with the same shape *and memory layout* as the dense tensor `like`."""
+    if like.is_contiguous():
+        return flat_slice.view(like.shape)
+    if like.ndim == 4 and like.is_contiguous(memory_format=torch.channels_last):
+        O, I, KH, KW = like.shape
+        return flat_slice.view(O, KH, KW, I).permute(0, 3, 1, 2)
+    raise RuntimeError('FlatModule: parameter is neither contiguous nor channels_last')
+
+
+class FlatModule(object):
+    """Re-homes all parameters of `module` into one flat fp32 buffer and their .grad into another."""
+
+    def __init__(self, module):
+        self.module = module
+        params = list(module.parameters())
+        self.params = params
+        device = params[0].device
+        # keep every segment 16-byte aligned so the float4 kernels and conv loaders stay on the vector path
+        offs, total = [], 0
+        for p in params:
+            offs.append(total)
+            total += (p.numel() + 3) // 4 * 4
+        self.offsets, self.total = offs, total
+        self.flat = torch.zeros(total, device=device, dtype=torch.float32)
+        self.gflat = torch.zeros(total, device=device, dtype=torch.float32)
+        with torch.no_grad():
+            for p, off in zip(params, offs):
+                view = _phys_view(self.flat[off:off + p.numel()], p.data)
+                view.copy_(p.data)
+                p.data = view
+                p.grad = _phys_view(self.gflat[off:off + p.numel()], p.data)
+
+    def zero_grad(self):
+        self.gflat.zero_()
+        for p, off in zip(self.params, self.offsets):  # re-attach in case something set .grad = None
+            if p.grad is None or p.grad.data_ptr() != self.gflat.data_ptr() + 4 * off:
+                p.grad = _phys_view(self.gflat[off:off + p.numel()], p.data)
+
+    def numel(self):
+        return self.total
+
+
+class Phase(object):
+    """One optimiser phase ('Gmain' or 'Dmain'): module + flat Adam state."""
+
+    def __init__(self, name, module, lr, betas=(0.0, 0.99), eps=1e-8, reg_interval=None):
+        self.name = name
+        self.module = module
+        self.fm = FlatModule(module)
+        if reg_interval is not None:  # lazy-regularisation rescaling, training_loop.py:191-194
+            mb_ratio = reg_interval / (reg_interval + 1)
+            lr = lr * mb_ratio
+            betas = [beta ** mb_ratio for beta in betas]
+        self.lr, self.betas, self.eps = lr, tuple(betas), eps
+        self.m = torch.zeros_like(self.fm.flat)
+        self.v = torch.zeros_like(self.fm.flat)
+        self.step = 0
+
+
+class DataParallelStep(object):
+    """Gradient exchange + optimiser for one rank (one process per GPU; RCCL via torch.distributed 'nccl')."""
+
+    def __init__(self, world_size=1, bucket_bytes=256 << 20, fuse_sanitize=True):
+        self.world = world_size
+        self.bucket = bucket_bytes // 4
+        self.fuse = fuse_sanitize
+        self.comm_stream = torch.cuda.Stream() if (world_size > 1 and torch.cuda.is_available()) else None
+
+    def exchange(self, gflat):
+        """In-place SUM all-reduce of the flat gradient in large buckets on a side stream (xGMI is point-to-point:
+        few large transfers beat many small ones).  Division by world and nan_to_num are fused into Adam."""
+        if self.world <= 1:
+            return
+        import torch.distributed as dist
+        n = gflat.numel()
+        if self.comm_stream is not None:
+            self.comm_stream.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(self.comm_stream):
+                for s in range(0, n, self.bucket):
+                    dist.all_reduce(gflat[s:min(n, s + self.bucket)])
+            torch.cuda.current_stream().wait_stream(self.comm_stream)
+        else:  # gloo / CPU tests
+            for s in range(0, n, self.bucket):
+                dist.all_reduce(gflat[s:min(n, s + self.bucket)])
+
+    def apply(self, phase):
+        fm = phase.fm
+        self.exchange(fm.gflat)
+        phase.step += 1
+        scale = 1.0 / self.world
+        if fm.flat.device.type != 'cuda':
+            raise RuntimeError('DataParallelStep.apply: parameters must live in GPU memory (no CPU fallback)')
+        if not self.fuse:
+            core.check(core.lib().ldetr_grad_sanitize_f32(core.ptr(fm.gflat), fm.total, scale, 0.0, 1e5, -1e5, core.stream()), 'grad_sanitize')
+        core.check(core.lib().ldetr_adam_step_f32(core.ptr(fm.flat), core.ptr(fm.gflat), core.ptr(phase.m), core.ptr(phase.v), fm.total,
+                                                  phase.step, phase.lr, phase.betas[0], phase.betas[1], phase.eps,
+                                                  1 if self.fuse else 0, scale, 0.0, 1e5, -1e5, core.stream()), 'adam_step')
+
+
+class EmaTracker(object):
+    """G_ema = lerp(G, G_ema, beta) over flat buffers (training_loop.py:320-328)."""
+
+    def __init__(self, G_phase, G_ema):
+        self.src = G_phase.fm
+        self.G = G_phase.module
+        self.G_ema = G_ema
+        self.fm = FlatModule(G_ema)
+        assert self.fm.total == self.src.total
+        for p in G_ema.parameters():
+            p.grad = None
+        self.fm.gflat = None
+
+    def update(self, batch_size, ema_kimg, cur_nimg, ema_rampup=0.05):
+        ema_nimg = ema_kimg * 1000
+        if ema_rampup is not None:
+            ema_nimg = min(ema_nimg, cur_nimg * ema_rampup)
+        beta = 0.5 ** (batch_size / max(ema_nimg, 1e-8))
+        core.check(core.lib().ldetr_ema_lerp_f32(core.ptr(self.fm.flat), core.ptr(self.src.flat), self.src.total, float(beta), core.stream()), 'ema_lerp')
+        for b_ema, b in zip(self.G_ema.buffers(), self.G.buffers()):
+            b_ema.copy_(b)
+
+
+def broadcast_module(module, src=0):
+    """Initial parameter/buffer broadcast (training_loop.py:176-179) — one collective per flat buffer when available."""
+    import torch.distributed as dist
+    for t in list(module.parameters()) + list(module.buffers()):
+        dist.broadcast(t.data, src=src)
+
+
+def training_iteration(loss, phases, dp, batch, batch_gpu, gen_z_per_phase, ema=None, batch_size=None, ema_kimg=None, cur_nimg=0):
+    """One iteration = all phases (Gmain, Dmain) over the rank-local batch, as training_loop.py:274-328.
+
+    batch: dict with bbox_real [b,9,4], bbox_class [b,9], bbox_text (TextFeatures), bbox_patch, padding_mask [b,9] bool,
+           background [b,3,R,R], real_c, gen_c.  gen_z_per_phase: list of [b,9,z_dim] tensors, one per phase.
+    """
+    b = batch['bbox_real'].shape[0]
+    for phase, gen_z in zip(phases, gen_z_per_phase):
+        phase.fm.zero_grad()
+        phase.module.requires_grad_(True)
+        phase.module.text_encoder.requires_grad_(False)
+        for s in range(0, b, batch_gpu):
+            sl = slice(s, s + batch_gpu)
+            loss.accumulate_gradients(phase=phase.name, bbox_real=batch['bbox_real'][sl], bbox_class=batch['bbox_class'][sl],
+                                      bbox_text=batch['bbox_text'][sl], bbox_patch=batch['bbox_patch'][sl],
+                                      padding_mask=batch['padding_mask'][sl], background=batch['background'][sl],
+                                      real_c=batch['real_c'][sl], gen_z=gen_z[sl], gen_c=batch['gen_c'][sl], gain=1, cur_nimg=cur_nimg)
+        phase.module.requires_grad_(False)
+        dp.apply(phase)
+    if ema is not None:
+        ema.update(batch_size, ema_kimg, cur_nimg)

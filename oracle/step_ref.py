@@ -1,0 +1,109 @@
+"""ORACLE (test infrastructure only — never imported by the product path).
+
+CPU fp32 restatement of one G/D training iteration in hot-path-only mode:
+  StyleGAN2Loss.accumulate_gradients, phases Gmain and Dmain with gamma=0, pl_weight=0
+      training/loss.py:84-116 (Gmain), :146-157 (Dgen), :161-218 (Dreal); weights from train.py:263-275
+  gradient post-processing + Adam(betas=(0,0.99), eps=1e-8)      training/training_loop.py:303-313, train.py:204-205
+Built on the pinned pieces (networks_ref / detr_ref / stylegan2_ref / losses_ref).  Used by the GPU parity
+tests, by __graft_entry__.smoke() and as bench.py's `cpu_baseline` ("port").
+"""
+import torch
+import torch.nn.functional as F
+
+from . import losses_ref, networks_ref
+
+WEIGHTS = dict(Dreal_bbox_cls=50.0, Dreal_bbox_rec=500.0, Dreal_text_rec=0.1, Dreal_text_len_rec=2.0, Dreal_im_rec=0.5,
+               Ggen_bbox_rec=100.0, Ggen_bbox_gIoU=4.0, Ggen_overlapping=7.0, Ggen_alignment=17.0, Ggen_z_rec=5.0,
+               Ggen_bbox_cls=50.0, Ggen_text_rec=1.0, Ggen_text_len_rec=1.0)
+
+
+def g_main_loss(G, D, bt, z, w=WEIGHTS, bg_size=256):
+    pm = bt['padding_mask']; valid = ~pm
+    bbox_fake, loss_z, cls_logits, loss_lm, loss_tl = networks_ref.generator(
+        G, z, bt['bbox_class'], bt['text_feat'], bt['text_len'], pm, bt['background'], reconst=True)
+    logits, logits_u = networks_ref.discriminator(D, bbox_fake, bt['bbox_class'], bt['text_feat'], bt['text_len'], pm, bt['background'])
+    real = bt['bbox_real']
+    total = (F.softplus(-logits) + F.softplus(-logits_u)
+             + F.mse_loss(bbox_fake[valid], real[valid]) * w['Ggen_bbox_rec']
+             + losses_ref.generalized_iou_loss(bbox_fake[valid], real[valid]) * w['Ggen_bbox_gIoU']
+             + losses_ref.compute_overlap(bbox_fake, valid) * w['Ggen_overlapping']
+             + losses_ref.compute_alignment(bbox_fake, valid) * w['Ggen_alignment']
+             + loss_z * w['Ggen_z_rec']
+             + F.cross_entropy(cls_logits, bt['bbox_class'][valid]) * w['Ggen_bbox_cls']
+             + loss_lm * w['Ggen_text_rec'] + loss_tl * w['Ggen_text_len_rec'])
+    return total.mean(), bbox_fake
+
+
+def d_gen_loss(G, D, bt, z):
+    pm = bt['padding_mask']
+    with torch.no_grad():
+        bbox_fake = networks_ref.generator(G, z, bt['bbox_class'], bt['text_feat'], bt['text_len'], pm, bt['background'])
+    logits, logits_u = networks_ref.discriminator(D, bbox_fake, bt['bbox_class'], bt['text_feat'], bt['text_len'], pm, bt['background'])
+    return (F.softplus(logits) + F.softplus(logits_u)).mean()
+
+
+def d_real_loss(D, bt, w=WEIGHTS, bg_size=256):
+    pm = bt['padding_mask']; valid = ~pm
+    real = bt['bbox_real']
+    (logits, logits_u, bbox_rec, cls_logits, loss_lm, loss_tl, bg_rec, bbox_rec_u, cls_logits_u) = networks_ref.discriminator(
+        D, real, bt['bbox_class'], bt['text_feat'], bt['text_len'], pm, bt['background'], reconst=True, bg_size=bg_size)
+    total = (F.softplus(-logits) + F.softplus(-logits_u)
+             + F.mse_loss(bbox_rec, real[valid]) * w['Dreal_bbox_rec']
+             + F.cross_entropy(cls_logits, bt['bbox_class'][valid]) * w['Dreal_bbox_cls']
+             + loss_lm * w['Dreal_text_rec'] + loss_tl * w['Dreal_text_len_rec']
+             + F.mse_loss(bg_rec, bt['background']) * w['Dreal_im_rec']
+             + F.mse_loss(bbox_rec_u, real[valid]) * w['Dreal_bbox_rec']
+             + F.cross_entropy(cls_logits_u, bt['bbox_class'][valid]) * w['Dreal_bbox_cls'])
+    return total.mean()
+
+
+def _params(sd, param_names=None):
+    """state dict -> leaf tensors; `param_names` (names of nn.Parameters) decides what is trainable, buffers
+    (FrozenBatchNorm statistics, FIR taps, token masks, w_avg) never are."""
+    out = {}
+    for k, v in sd.items():
+        if param_names is not None:
+            trainable = k in param_names
+        else:
+            trainable = v.dtype.is_floating_point and not any(s in k for s in (
+                'running_mean', 'running_var', '.bn', 'token_mask', 'downsample.1.', 'w_avg', 'resample_filter'))
+        out[k] = v.detach().clone().requires_grad_(bool(trainable))
+    return out
+
+
+def training_iteration(G_sd, D_sd, bt, z_g, z_d, lr=1e-5, world=1, bg_size=256, apply_adam=True, G_param_names=None, D_param_names=None):
+    """One Gmain + Dmain iteration on CPU.  Returns (losses dict, grads dicts, updated state dicts)."""
+    G = _params(G_sd, G_param_names); D = _params(D_sd, D_param_names)
+    out = {}
+    # Gmain: D is frozen (its parameters get no gradient), gradient flows through D to bbox_fake.
+    Dfrozen = {k: v.detach() for k, v in D.items()}
+    lg, bbox_fake = g_main_loss(G, Dfrozen, bt, z_g, bg_size=bg_size)
+    lg.backward()
+    out['loss_G'] = lg.detach(); out['bbox_fake'] = bbox_fake.detach()
+    gG = {k: v.grad for k, v in G.items() if v.requires_grad and v.grad is not None}
+    G_new = dict(G_sd)
+    if apply_adam:
+        G_new = adam_step(G, gG, lr, world)
+    # Dmain uses the *updated* generator (phases run sequentially within an iteration).
+    Gd = {k: v.detach() for k, v in (G_new if apply_adam else G).items()}
+    ld1 = d_gen_loss(Gd, D, bt, z_d); ld1.backward()
+    ld2 = d_real_loss(D, bt, bg_size=bg_size); ld2.backward()
+    out['loss_Dgen'] = ld1.detach(); out['loss_Dreal'] = ld2.detach()
+    gD = {k: v.grad for k, v in D.items() if v.requires_grad and v.grad is not None}
+    D_new = adam_step(D, gD, lr, world) if apply_adam else dict(D_sd)
+    return out, gG, gD, G_new, D_new
+
+
+def adam_step(params, grads, lr, world=1, step=1, betas=(0.0, 0.99), eps=1e-8):
+    """First Adam step from zero state after the DP post-processing; returns a new state dict."""
+    new = {}
+    for k, p in params.items():
+        if k not in grads:
+            new[k] = p.detach()
+            continue
+        g = losses_ref.dp_postprocess(grads[k] * world, world)
+        m = (1 - betas[0]) * g
+        v = (1 - betas[1]) * g * g
+        bc1 = 1 - betas[0] ** step; bc2 = 1 - betas[1] ** step
+        new[k] = p.detach() - (lr / bc1) * m / (v.sqrt() / (bc2 ** 0.5) + eps)
+    return new

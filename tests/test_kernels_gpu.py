@@ -178,6 +178,14 @@ CONV_CASES = [
     (2, 16, 16, 64, 128, 1, 2, 0),
     (3, 9, 9, 8, 12, 3, 1, 1),
     (1, 8, 8, 256, 64, 3, 1, 1),
+    # ResNet-50 stage transitions at 64x64 / 256x256 inputs
+    (2, 8, 8, 256, 256, 3, 2, 1),
+    (2, 16, 16, 128, 128, 3, 2, 1),
+    (2, 4, 4, 512, 512, 3, 2, 1),
+    (2, 8, 8, 512, 1024, 1, 2, 0),
+    (2, 8, 8, 512, 256, 1, 1, 0),
+    (2, 4, 4, 256, 1024, 1, 1, 0),
+    (2, 32, 32, 256, 128, 1, 1, 0),
 ]
 
 

@@ -1,0 +1,196 @@
+"""GPU parity of the module-level hot path (seam 1) against (a) golden vectors captured from the reference
+and (b) the CPU oracle on seeded inputs.  Tolerance: 1e-3 relative fp32 on outputs / losses / bbox
+(north_star); most checks are far tighter and say so."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+G_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+
+
+def load(name):
+    d = np.load(os.path.join(G_DIR, name + '.npz'), allow_pickle=False)
+    return {k: torch.from_numpy(d[k]) for k in d.files if d[k].ndim > 0 or d[k].dtype.kind in 'fiub'}
+
+
+def sd_of(d, prefix='sd/'):
+    return {k[len(prefix):]: v for k, v in d.items() if k.startswith(prefix)}
+
+
+def rel(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return ((a - b).abs().max() / (b.abs().max() + 1e-12)).item()
+
+
+def check(a, b, tol, what):
+    e = rel(a, b)
+    assert e <= tol, f'{what}: rel err {e:.3e} > {tol:.1e}'
+
+
+@pytest.mark.parametrize('name', ['transformer', 'transformer_token'])
+def test_detr_transformer_matches_reference_golden(dev, name):
+    from layoutdetr_amd.training.detr_transformer import Transformer, TransformerWithToken
+    d = load(name)
+    cls = TransformerWithToken if name.endswith('token') else Transformer
+    m = cls(d_model=64, nhead=2, num_encoder_layers=2, num_decoder_layers=2, dim_feedforward=128, dropout=0.1).eval()
+    m.load_state_dict(sd_of(d))
+    m.to(dev)
+    src = d['src'].to(dev).requires_grad_(True); tgt = d['tgt'].to(dev).requires_grad_(True)
+    hs, mem = m(src, d['mask'].to(dev), d['pos'].to(dev), tgt, d['kpm'].to(dev))
+    check(hs, d['hs'], 2e-5, 'hs'); check(mem, d['mem'], 2e-5, 'memory')
+    ((hs * d['g_hs'].to(dev)).sum() + (mem * d['g_mem'].to(dev)).sum()).backward()
+    check(src.grad, d['d_src'], 1e-4, 'd_src'); check(tgt.grad, d['d_tgt'], 1e-4, 'd_tgt')
+    grads = sd_of(d, 'grad/')
+    for k, p in m.named_parameters():
+        if k in grads:
+            check(p.grad, grads[k], 2e-4, 'grad ' + k)
+
+
+def test_layoutganpp_encoder_matches_reference_golden(dev):
+    from layoutdetr_amd.training.util import TransformerWithToken_layoutganpp
+    d = load('transformer_layoutganpp')
+    m = TransformerWithToken_layoutganpp(d_model=64, nhead=2, dim_feedforward=128, num_layers=2).eval()
+    m.load_state_dict(sd_of(d)); m.to(dev)
+    x = d['x'].to(dev).requires_grad_(True)
+    y = m(x, src_key_padding_mask=d['kpm'].to(dev))
+    valid = torch.cat([torch.ones(2, 1, dtype=torch.bool), ~d['kpm']], 1).t()  # [L+1, B]; padded rows are never compared
+    check(y[valid.to(dev)], d['y'][valid], 2e-5, 'y')
+    g = d['g'].clone(); g[~valid] = 0
+    (y * g.to(dev)).sum().backward()
+
+
+def test_stylegan2_decoder_matches_reference_golden(dev):
+    from layoutdetr_amd.training.networks_stylegan2 import Decoder
+    d = load('decoder')
+    m = Decoder(z_dim=32, w_dim=32, img_resolution=16, img_channels=3, use_noise=False, channel_base=256, channel_max=32,
+                num_fp16_res=0, conv_clamp=None, fused_modconv_default=False).train()
+    m.load_state_dict(sd_of(d)); m.to(dev)
+    z = d['z'].to(dev).requires_grad_(True)
+    img = m(z)
+    assert img.shape == (2, 3, 16, 16)
+    check(img, d['img'], 2e-5, 'img')
+    (img * d['g'].to(dev)).sum().backward()
+    check(z.grad, d['d_z'], 2e-4, 'd_z')
+    grads = sd_of(d, 'grad/')
+    for k, p in m.named_parameters():
+        check(p.grad, grads[k], 5e-4, 'grad ' + k)
+
+
+def test_position_encoding_and_frozen_bn(dev):
+    from layoutdetr_amd.detr_util.misc import NestedTensor
+    from layoutdetr_amd.training.detr_backbone import FrozenBatchNorm2d
+    from layoutdetr_amd.training.detr_position_encoding import PositionEmbeddingSine
+    d = load('pos_encoding')
+    pe = PositionEmbeddingSine(128, normalize=True)
+    pos = pe(NestedTensor(torch.zeros(2, 1, 4, 5, device=dev), d['mask'].to(dev)))
+    check(pos, d['pos'], 1e-6, 'pos')
+    d = load('frozen_bn')
+    bn = FrozenBatchNorm2d(6)
+    bn.load_state_dict({k: d[k] for k in ('weight', 'bias', 'running_mean', 'running_var')})
+    check(bn.to(dev)(d['x'].to(dev)), d['y'], 1e-6, 'frozen bn')
+
+
+def _make(dev, bg=64, seed=0):
+    from layoutdetr_amd.training.networks_detr import Discriminator, Generator
+    torch.manual_seed(seed)
+    kw = dict(num_bbox_labels=8, img_channels=3, img_height=bg, img_width=bg, c_dim=0, background_size=bg, bert_f_dim=768, im_f_dim=512)
+    G = Generator(z_dim=4, **kw)
+    D = Discriminator(**kw)
+    # non-trivial frozen-BN statistics so the folded affine is exercised
+    for m in list(G.modules()) + list(D.modules()):
+        if m.__class__.__name__ == 'FrozenBatchNorm2d':
+            m.weight.uniform_(0.5, 1.5); m.bias.normal_(0, 0.1); m.running_mean.normal_(0, 0.1); m.running_var.uniform_(0.5, 1.5)
+    return G, D
+
+
+def _batch(B, bg, seed=1):
+    g = torch.Generator().manual_seed(seed)
+    bt = dict(bbox_real=torch.cat([torch.rand(B, 9, 2, generator=g) * 0.6 + 0.2, torch.rand(B, 9, 2, generator=g) * 0.35 + 0.05], -1),
+              bbox_class=torch.randint(0, 8, (B, 9), generator=g), text_feat=torch.randn(B, 9, 768, generator=g),
+              text_len=torch.randint(1, 40, (B, 9), generator=g), padding_mask=torch.zeros(B, 9, dtype=torch.bool),
+              background=torch.randn(B, 3, bg, bg, generator=g))
+    bt['padding_mask'][0, 6:] = True
+    return bt, torch.randn(B, 9, 4, generator=g), torch.randn(B, 9, 4, generator=g)
+
+
+def test_generator_discriminator_forward_vs_oracle(dev):
+    from layoutdetr_amd.training.networks_detr import TextFeatures
+    from oracle import networks_ref
+    G, D = _make(dev)
+    bt, z, _ = _batch(2, 64)
+    Gsd = {k: v.clone() for k, v in G.state_dict().items()}; Dsd = {k: v.clone() for k, v in D.state_dict().items()}
+    with torch.no_grad():
+        ref_g = networks_ref.generator(Gsd, z, bt['bbox_class'], bt['text_feat'], bt['text_len'], bt['padding_mask'], bt['background'], reconst=True)
+        ref_d = networks_ref.discriminator(Dsd, bt['bbox_real'], bt['bbox_class'], bt['text_feat'], bt['text_len'], bt['padding_mask'],
+                                           bt['background'], reconst=True, bg_size=64)
+    G.eval().to(dev); D.eval().to(dev)
+    tf = TextFeatures(bt['text_feat'].to(dev), bt['text_len'].to(dev))
+    patch = torch.zeros(2, 9, 1, 1, 1, device=dev)
+    with torch.no_grad():
+        out_g = G(z.to(dev), bt['bbox_class'].to(dev), bt['bbox_real'].to(dev), tf, patch, bt['padding_mask'].to(dev), bt['background'].to(dev), None, reconst=True)
+        out_d = D(bt['bbox_real'].to(dev), bt['bbox_class'].to(dev), tf, patch, bt['padding_mask'].to(dev), bt['background'].to(dev), None, reconst=True)
+    valid = ~bt['padding_mask']
+    check(out_g[0][valid.to(dev)], ref_g[0][valid], 1e-3, 'bbox_fake')
+    for i, nm in [(1, 'loss_z'), (2, 'logit_cls'), (4, 'loss_text_len')]:
+        check(out_g[i], ref_g[i], 1e-3, 'G ' + nm)
+    names = ['logit', 'logit_uncond', 'bbox_pred', 'logit_cls', 'loss_lm', 'loss_text_len', 'bg_rec', 'bbox_pred_uncond', 'logit_cls_uncond']
+    for i, nm in enumerate(names):
+        if nm != 'loss_lm':
+            check(out_d[i], ref_d[i], 1e-3, 'D ' + nm)
+
+
+def test_training_iteration_vs_oracle(dev):
+    """Full Gmain + Dmain iteration (fwd, bwd, DP post-processing, Adam) on the HIP path vs the CPU oracle."""
+    from layoutdetr_amd.training import training_loop as tl
+    from layoutdetr_amd.training.loss import StyleGAN2Loss
+    from layoutdetr_amd.training.networks_detr import TextFeatures
+    from oracle import step_ref
+    G, D = _make(dev, seed=3)
+    bt, zg, zd = _batch(2, 64, seed=4)
+    Gsd = {k: v.clone() for k, v in G.state_dict().items()}; Dsd = {k: v.clone() for k, v in D.state_dict().items()}
+    out, gG, gD, Gn, Dn = step_ref.training_iteration(Gsd, Dsd, bt, zg, zd, lr=1e-5, bg_size=64,
+                                                      G_param_names={n for n, _ in G.named_parameters()},
+                                                      D_param_names={n for n, _ in D.named_parameters()})
+    G.eval().requires_grad_(False).to(dev); D.eval().requires_grad_(False).to(dev)   # eval: dropout off (parity mode)
+    pG = tl.Phase('Gmain', G, lr=1e-5, reg_interval=None); pD = tl.Phase('Dmain', D, lr=1e-5, reg_interval=None)
+    loss = StyleGAN2Loss(dev, G, D)
+    dp = tl.DataParallelStep(world_size=1, fuse_sanitize=True)
+    batch = dict(bbox_real=bt['bbox_real'].to(dev), bbox_class=bt['bbox_class'].to(dev),
+                 bbox_text=TextFeatures(bt['text_feat'].to(dev), bt['text_len'].to(dev)), bbox_patch=torch.zeros(2, 9, 1, 1, 1, device=dev),
+                 padding_mask=bt['padding_mask'].to(dev), background=bt['background'].to(dev), real_c=torch.zeros(2, 0, device=dev),
+                 gen_c=torch.zeros(2, 0, device=dev))
+    # snapshot gradients of each phase before Adam consumes them
+    grads = {}
+    orig_apply = dp.apply
+
+    def spy(phase):
+        grads[phase.name] = {n: p.grad.detach().clone() for n, p in phase.module.named_parameters()}
+        orig_apply(phase)
+    dp.apply = spy
+    tl.training_iteration(loss, [pG, pD], dp, batch, 2, [zg.to(dev), zd.to(dev)])
+    check(loss.last['bbox_fake'][(~bt['padding_mask']).to(dev)], out['bbox_fake'][~bt['padding_mask']], 1e-3, 'bbox_fake')
+    # Gradients: the step is only piecewise differentiable (ReLU / max-pool).  A single ReLU whose pre-activation is
+    # ~1e-5 on one side and 0 on the other flips its mask and moves a few weight-gradient rows by percents while every
+    # value still agrees to 1e-6 (measured: 1 flip in 32768 activations of layer3.0 -> 3e-2 on that conv's dW).  So the
+    # gate is distributional: median and 90th percentile over all parameter tensors tight, maximum bounded.
+    errs = []
+    for name, ref in (('Gmain', gG), ('Dmain', gD)):
+        errs += [rel(grads[name][k], g) for k, g in ref.items()]
+    errs = torch.tensor(errs)
+    worst = errs.max().item()
+    assert errs.median().item() <= 1e-4, f'median grad rel err {errs.median().item():.3e}'
+    assert errs.quantile(0.9).item() <= 5e-3, f'p90 grad rel err {errs.quantile(0.9).item():.3e}'
+    assert worst <= 0.15, f'worst grad rel err {worst:.3e}'
+    # Adam: parameters moved by ~lr in the direction of -sign(g) where |g| is not tiny
+    for k, p in G.named_parameters():
+        if k in gG:
+            mask = gG[k].abs() > 1e-4 * gG[k].abs().max()
+            if mask.any():
+                d_ref = (Gn[k] - Gsd[k])[mask]; d_gpu = (p.detach().cpu() - Gsd[k])[mask]
+                agree = torch.isclose(d_gpu, d_ref, rtol=0.05, atol=2e-7).float().mean().item()
+                assert agree >= 0.98, f'{k}: only {agree:.3f} of the Adam updates agree'
+    print('worst grad rel err', worst)
