@@ -85,6 +85,8 @@ int ldetr_upfirdn2d_f32(const float* x, const float* f, float* y, int N, int C, 
                         float gain, int outH, int outW, const int64_t* y_strides_nchw,
                         const float* act_bias, int has_act, float act_alpha, float act_gain, void* stream);
 
+/* splitk: 0 = launch policy may split the reduction over grid.z (output zeroed + fp32 atomics + epilogue pass),
+ * 1 = never split, > 1 = explicit number of K slices. */
 int ldetr_gemm_f32(const float* A, int64_t lda, int ta, const float* B, int64_t ldb, int tb, float* C, int64_t ldc,
                    int M, int N, int K, int splitk, const ldetr_epilogue* ep, int pix_per_sample, void* stream);
 

@@ -10,7 +10,7 @@
 //
 // Arithmetic: v_mfma_f32_32x32x2_f32 — exact fp32 products and accumulation (the reference step is
 // fp32 end-to-end with TF32 disabled, training/training_loop.py:104-105).  Peak 157 TFLOP/s.
-// Tiling: 256 threads = 4 waves (2x2); block tile BMxBN in {128x128, 64x64}, BK = 16; LDS tiles are
+// Tiling: 256 threads = 4 waves (2x2); block tile 128x128 (BK 16) or 64x64 (BK 32); LDS tiles are
 // k-major ([k][row], row stride R+2 -> conflict-free MFMA operand reads and transposing writes),
 // double-buffered with register staging (global loads for tile t+1 are in flight during the
 // MFMAs of tile t; one barrier per k-tile).
@@ -81,8 +81,6 @@ struct GemmParams {
     GemmEpilogue ep;
 };
 
-#define BK 16
-
 struct TapMap {
     int kh0, kw0, tstep, nty, ntx;
 };
@@ -95,11 +93,30 @@ struct ZCtx {
     long c_off;
 };
 
-__device__ __forceinline__ void decode_tap(const TapMap& tm, int t, int& kh, int& kw) {
-    int ty = t / tm.ntx;
-    int tx = t - ty * tm.ntx;
-    kh = tm.kh0 + tm.tstep * ty;
-    kw = tm.kw0 + tm.tstep * tx;
+// Incremental decode of the reduction index: k = (tap', c) for conv operands, k = pixel (n, y, x) for
+// weight-gradient operands.  Decoded once per thread with integer divisions, then advanced by BK per k-tile
+// with carries only (the old per-tile divisions cost more VALU issue slots than the loads themselves).
+struct KDec {
+    int c, ty, tx;   // KC gathers / RC_WT: channel, tap row/col index (in the tap map)
+    int n, y, x;     // RC_PIX / RC_CONVK: pixel
+};
+
+__device__ __forceinline__ void kdec_init_tap(KDec& d, const TapMap& tm, int k, int C) {
+    int t = k / C; d.c = k - t * C;
+    d.ty = t / tm.ntx; d.tx = t - d.ty * tm.ntx;
+}
+__device__ __forceinline__ void kdec_step_tap(KDec& d, const TapMap& tm, int step, int C) {
+    d.c += step;
+    while (d.c >= C) { d.c -= C; if (++d.tx == tm.ntx) { d.tx = 0; ++d.ty; } }
+}
+__device__ __forceinline__ void kdec_init_pix(KDec& d, int k, int DH, int DW) {
+    int per = DH * DW;
+    d.n = k / per; int rem = k - d.n * per;
+    d.y = rem / DW; d.x = rem - d.y * DW;
+}
+__device__ __forceinline__ void kdec_step_pix(KDec& d, int step, int DH, int DW) {
+    d.x += step;
+    while (d.x >= DW) { d.x -= DW; if (++d.y == DH) { d.y = 0; ++d.n; } }
 }
 
 struct RowCtx {  // per-thread cached decode of a KC gather row (a destination pixel)
@@ -132,7 +149,7 @@ __device__ __forceinline__ RowCtx make_row(const Operand& o, const GemmParams& p
 
 // Load 4 consecutive k values (k .. k+3) of one row for a k-contiguous operand.
 template <int MODE>
-__device__ __forceinline__ float4 load_kc(const Operand& o, const ZCtx& z, const RowCtx& rc, int k) {
+__device__ __forceinline__ float4 load_kc(const Operand& o, const ZCtx& z, const RowCtx& rc, int k, const KDec& d) {
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
     if (!rc.valid || k >= z.kend) return v;
     if (MODE == OP_KC_DENSE) {
@@ -145,14 +162,12 @@ __device__ __forceinline__ float4 load_kc(const Operand& o, const ZCtx& z, const
         return v;
     }
     if (MODE == OP_KC_WTAP) {
-        int t = k / o.C; int c = k - t * o.C;
-        int kh, kw; decode_tap(z.tm, t, kh, kw);
-        return *reinterpret_cast<const float4*>(o.p + rc.base + (long)(kh * o.KW + kw) * o.C + c);
+        int kh = z.tm.kh0 + z.tm.tstep * d.ty, kw = z.tm.kw0 + z.tm.tstep * d.tx;
+        return *reinterpret_cast<const float4*>(o.p + rc.base + (long)(kh * o.KW + kw) * o.C + d.c);
     }
     // gather modes
     if (o.vec) {
-        int t = k / o.C; int c = k - t * o.C;
-        int kh, kw; decode_tap(z.tm, t, kh, kw);
+        int kh = z.tm.kh0 + z.tm.tstep * d.ty, kw = z.tm.kw0 + z.tm.tstep * d.tx;
         int sy, sx; bool ok;
         if (MODE == OP_KC_CONV) {
             sy = rc.y + kh; sx = rc.x + kw;
@@ -163,9 +178,9 @@ __device__ __forceinline__ float4 load_kc(const Operand& o, const ZCtx& z, const
             ok = (ny >= 0) & (nx >= 0) & (sy < o.SH) & (sx < o.SW);
         }
         if (!ok) return v;
-        v = *reinterpret_cast<const float4*>(o.p + rc.base + (long)sy * o.sh + (long)sx * o.sw + c);
+        v = *reinterpret_cast<const float4*>(o.p + rc.base + (long)sy * o.sh + (long)sx * o.sw + d.c);
         if (o.scale) {
-            float4 s = *reinterpret_cast<const float4*>(o.scale + (long)rc.samp * o.scale_ld + c);
+            float4 s = *reinterpret_cast<const float4*>(o.scale + (long)rc.samp * o.scale_ld + d.c);
             v.x *= s.x; v.y *= s.y; v.z *= s.z; v.w *= s.w;
         }
         return v;
@@ -176,7 +191,8 @@ __device__ __forceinline__ float4 load_kc(const Operand& o, const ZCtx& z, const
         int kk = k + j;
         if (kk >= z.kend) break;
         int t = kk / o.C; int c = kk - t * o.C;
-        int kh, kw; decode_tap(z.tm, t, kh, kw);
+        int ty = t / z.tm.ntx, tx = t - ty * z.tm.ntx;
+        int kh = z.tm.kh0 + z.tm.tstep * ty, kw = z.tm.kw0 + z.tm.tstep * tx;
         int sy, sx; bool ok;
         if (MODE == OP_KC_CONV) {
             sy = rc.y + kh; sx = rc.x + kw;
@@ -197,7 +213,7 @@ __device__ __forceinline__ float4 load_kc(const Operand& o, const ZCtx& z, const
 
 // Load 4 consecutive row values (r .. r+3) at reduction index k for a row-contiguous operand.
 template <int MODE>
-__device__ __forceinline__ float4 load_rc(const Operand& o, const GemmParams& p, const ZCtx& z, int k, int r, int R) {
+__device__ __forceinline__ float4 load_rc(const Operand& o, const GemmParams& p, const ZCtx& z, int k, int r, int R, const KDec& d) {
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
     if (k >= z.kend || r >= R) return v;
     if (MODE == OP_RC_DENSE) {
@@ -210,9 +226,8 @@ __device__ __forceinline__ float4 load_rc(const Operand& o, const GemmParams& p,
         return v;
     }
     if (MODE == OP_RC_WT) {
-        int t = k / o.C; int co = k - t * o.C;
-        int kh, kw; decode_tap(z.tm, t, kh, kw);
-        const float* s = o.p + (long)co * o.ld + (long)(kh * o.KW + kw) * o.Cr + r;
+        int kh = z.tm.kh0 + z.tm.tstep * d.ty, kw = z.tm.kw0 + z.tm.tstep * d.tx;
+        const float* s = o.p + (long)d.c * o.ld + (long)(kh * o.KW + kw) * o.Cr + r;
         if (o.vec) return *reinterpret_cast<const float4*>(s);
         v.x = s[0];
         if (r + 1 < R) v.y = s[1];
@@ -221,14 +236,10 @@ __device__ __forceinline__ float4 load_rc(const Operand& o, const GemmParams& p,
         return v;
     }
     if (MODE == OP_RC_PIX) {
-        int per = o.DH * o.DW;
-        int n = k / per; int rem = k - n * per;
-        int y = rem / o.DW; int x = rem - y * o.DW;
-        int sy = y * o.stride - o.pad + (o.tapped ? z.fkh : o.pad);
-        int sx = x * o.stride - o.pad + (o.tapped ? z.fkw : o.pad);
-        if (!o.tapped) { sy = y; sx = x; }
+        int sy = d.y, sx = d.x;
+        if (o.tapped) { sy = d.y * o.stride - o.pad + z.fkh; sx = d.x * o.stride - o.pad + z.fkw; }
         if ((sy < 0) | (sy >= o.SH) | (sx < 0) | (sx >= o.SW)) return v;
-        const float* s = o.p + (long)n * o.sn + (long)sy * o.sh + (long)sx * o.sw + r;
+        const float* s = o.p + (long)d.n * o.sn + (long)sy * o.sh + (long)sx * o.sw + r;
         if (o.vec) {
             v = *reinterpret_cast<const float4*>(s);
         } else {
@@ -238,7 +249,7 @@ __device__ __forceinline__ float4 load_rc(const Operand& o, const GemmParams& p,
             if (r + 3 < R) v.w = s[3];
         }
         if (o.scale) {
-            const float* sc = o.scale + (long)n * o.scale_ld + r;
+            const float* sc = o.scale + (long)d.n * o.scale_ld + r;
             v.x *= sc[0];
             if (r + 1 < R) v.y *= sc[1];
             if (r + 2 < R) v.z *= sc[2];
@@ -248,9 +259,6 @@ __device__ __forceinline__ float4 load_rc(const Operand& o, const GemmParams& p,
     }
     // OP_RC_CONVK: k = destination pixel, r = (tap, c) natural order, scalar gather
     {
-        int per = o.DH * o.DW;
-        int n = k / per; int rem = k - n * per;
-        int y = rem / o.DW; int x = rem - y * o.DW;
         float e[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int j = 0; j < 4; j++) {
@@ -258,14 +266,15 @@ __device__ __forceinline__ float4 load_rc(const Operand& o, const GemmParams& p,
             if (rr >= R) break;
             int t = rr / o.C; int c = rr - t * o.C;
             int kh = t / o.KW; int kw = t - kh * o.KW;
-            int sy = y * o.stride - o.pad + kh, sx = x * o.stride - o.pad + kw;
+            int sy = d.y * o.stride - o.pad + kh, sx = d.x * o.stride - o.pad + kw;
             if ((sy >= 0) & (sy < o.SH) & (sx >= 0) & (sx < o.SW))
-                e[j] = o.p[(long)n * o.sn + (long)sy * o.sh + (long)sx * o.sw + (long)c * o.sc];
+                e[j] = o.p[(long)d.n * o.sn + (long)sy * o.sh + (long)sx * o.sw + (long)c * o.sc];
         }
         return make_float4(e[0], e[1], e[2], e[3]);
     }
 }
 
+template <int BKT>
 __device__ __forceinline__ ZCtx make_zctx(const GemmParams& p) {
     ZCtx z;
     z.M = p.M; z.K = p.K; z.py = 0; z.px = 0; z.DH2 = p.A.DH; z.DW2 = p.A.DW;
@@ -273,9 +282,11 @@ __device__ __forceinline__ ZCtx make_zctx(const GemmParams& p) {
     z.fkh = 0; z.fkw = 0; z.c_off = 0;
     int ks = blockIdx.z;
     if (p.zmode == 1) {
-        ks = 0;
         int s = p.pstep;
-        z.py = blockIdx.z / s; z.px = blockIdx.z - z.py * s;
+        int ncls = s * s;
+        int cls = blockIdx.z % ncls;
+        ks = blockIdx.z / ncls;
+        z.py = cls / s; z.px = cls - z.py * s;
         z.DH2 = (p.A.DH - z.py + s - 1) / s; z.DW2 = (p.A.DW - z.px + s - 1) / s;
         if (z.DH2 < 0) z.DH2 = 0;
         if (z.DW2 < 0) z.DW2 = 0;
@@ -294,46 +305,80 @@ __device__ __forceinline__ ZCtx make_zctx(const GemmParams& p) {
         z.c_off = (long)tap * p.c_tap_stride;
     }
     if (p.splitk > 1) {
-        int ktiles = (z.K + BK - 1) / BK;
+        int ktiles = (z.K + BKT - 1) / BKT;
         int per = (ktiles + p.splitk - 1) / p.splitk;
-        z.kbeg = ks * per * BK;
-        z.kend = min(z.K, (ks + 1) * per * BK);
+        z.kbeg = ks * per * BKT;
+        z.kend = min(z.K, (ks + 1) * per * BKT);
     } else {
         z.kbeg = 0; z.kend = z.K;
     }
     return z;
 }
 
-template <int BM, int BN, int AMODE, int BMODE>
+// One output element through the epilogue chain documented in include/ldetr_hip.h.
+__device__ __forceinline__ float apply_epilogue(const GemmEpilogue& ep, float v, long orow, int n, int samp, long ldc, float inv_keep) {
+    v *= ep.alpha;
+    if (ep.col_scale) v *= ep.col_scale[n];
+    if (ep.samp_scale) v *= ep.samp_scale[(long)samp * ep.samp_ld + n];
+    if (ep.col_bias) v += ep.col_bias[n];
+    if (ep.residual) v += ep.residual[orow * ep.ldr + n];
+    if (ep.act == 1) v = fmaxf(v, 0.f);
+    else if (ep.act == 2) v = (v > 0.f ? v : v * ep.act_alpha) * ep.act_gain;
+    if (ep.mask_mode) {
+        float s = ep.mask_src[orow * ep.ldm + n];
+        if (ep.mask_mode == 1) v = s > 0.f ? v : 0.f;
+        else v *= (s > 0.f ? ep.act_gain : ep.act_gain * ep.act_alpha);
+    }
+    if (ep.p_drop > 0.f) v *= drop_scale(ep.seed, (uint64_t)(orow * ldc + n), ep.p_drop, inv_keep);
+    return v * ep.out_scale;
+}
+
+template <int BM, int BN, int BKT, int AMODE, int BMODE>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
     constexpr bool A_KC = AMODE <= OP_KC_WTAP;
     constexpr bool B_KC = BMODE <= OP_KC_WTAP;
     constexpr int LDA = BM + 2, LDB = BN + 2;
-    constexpr int NUA = BM / 64, NUB = BN / 64;  // float4 units per thread per k-tile
+    constexpr int QK = BKT / 4;                                  // float4 quads along k per row
+    constexpr int NUA = BM * BKT / 4 / 256, NUB = BN * BKT / 4 / 256;  // float4 units per thread per k-tile
     constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
-    __shared__ float As[2][BK][LDA];
-    __shared__ float Bs[2][BK][LDB];
+    __shared__ float As[2][BKT][LDA];
+    __shared__ float Bs[2][BKT][LDB];
 
-    const ZCtx z = make_zctx(p);
+    const ZCtx z = make_zctx<BKT>(p);
     const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
     if (m0 >= z.M) return;  // uniform per block (parity classes may be smaller than the launch grid)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
 
-    // Per-thread unit assignment.
+    // Per-thread unit assignment + incremental k decode state.
     int a_r[NUA], a_k[NUA], b_r[NUB], b_k[NUB];
     RowCtx a_rc[NUA], b_rc[NUB];
+    KDec a_d[NUA], b_d[NUB];
 #pragma unroll
     for (int i = 0; i < NUA; i++) {
         int u = tid + i * 256;
-        if constexpr (A_KC) { a_r[i] = u >> 2; a_k[i] = (u & 3) << 2; a_rc[i] = make_row<AMODE>(p.A, p, z, m0 + a_r[i], z.M); }
-        else { a_k[i] = u / (BM / 4); a_r[i] = (u - a_k[i] * (BM / 4)) << 2; }
+        a_d[i].c = a_d[i].ty = a_d[i].tx = a_d[i].n = a_d[i].y = a_d[i].x = 0;
+        if constexpr (A_KC) {
+            a_r[i] = u / QK; a_k[i] = (u - a_r[i] * QK) << 2; a_rc[i] = make_row<AMODE>(p.A, p, z, m0 + a_r[i], z.M);
+            if constexpr (AMODE != OP_KC_DENSE) kdec_init_tap(a_d[i], z.tm, z.kbeg + a_k[i], p.A.C);
+        } else {
+            a_k[i] = u / (BM / 4); a_r[i] = (u - a_k[i] * (BM / 4)) << 2;
+            if constexpr (AMODE == OP_RC_WT) kdec_init_tap(a_d[i], z.tm, z.kbeg + a_k[i], p.A.C);
+            if constexpr (AMODE == OP_RC_PIX || AMODE == OP_RC_CONVK) kdec_init_pix(a_d[i], z.kbeg + a_k[i], p.A.DH, p.A.DW);
+        }
     }
 #pragma unroll
     for (int i = 0; i < NUB; i++) {
         int u = tid + i * 256;
-        if constexpr (B_KC) { b_r[i] = u >> 2; b_k[i] = (u & 3) << 2; b_rc[i] = make_row<BMODE>(p.B, p, z, n0 + b_r[i], p.N); }
-        else { b_k[i] = u / (BN / 4); b_r[i] = (u - b_k[i] * (BN / 4)) << 2; }
+        b_d[i].c = b_d[i].ty = b_d[i].tx = b_d[i].n = b_d[i].y = b_d[i].x = 0;
+        if constexpr (B_KC) {
+            b_r[i] = u / QK; b_k[i] = (u - b_r[i] * QK) << 2; b_rc[i] = make_row<BMODE>(p.B, p, z, n0 + b_r[i], p.N);
+            if constexpr (BMODE != OP_KC_DENSE) kdec_init_tap(b_d[i], z.tm, z.kbeg + b_k[i], p.B.C);
+        } else {
+            b_k[i] = u / (BN / 4); b_r[i] = (u - b_k[i] * (BN / 4)) << 2;
+            if constexpr (BMODE == OP_RC_WT) kdec_init_tap(b_d[i], z.tm, z.kbeg + b_k[i], p.B.C);
+            if constexpr (BMODE == OP_RC_PIX || BMODE == OP_RC_CONVK) kdec_init_pix(b_d[i], z.kbeg + b_k[i], p.B.DH, p.B.DW);
+        }
     }
 
     f32x16 acc[TM][TN];
@@ -345,16 +390,29 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
             for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
 
     float4 ra[NUA], rb[NUB];
+    // loads the k-tile starting at k0 and advances the decode state to the following tile
     auto gload = [&](int k0) {
 #pragma unroll
         for (int i = 0; i < NUA; i++) {
-            if constexpr (A_KC) ra[i] = load_kc<AMODE>(p.A, z, a_rc[i], k0 + a_k[i]);
-            else ra[i] = load_rc<AMODE>(p.A, p, z, k0 + a_k[i], m0 + a_r[i], z.M);
+            if constexpr (A_KC) {
+                ra[i] = load_kc<AMODE>(p.A, z, a_rc[i], k0 + a_k[i], a_d[i]);
+                if constexpr (AMODE != OP_KC_DENSE) kdec_step_tap(a_d[i], z.tm, BKT, p.A.C);
+            } else {
+                ra[i] = load_rc<AMODE>(p.A, p, z, k0 + a_k[i], m0 + a_r[i], z.M, a_d[i]);
+                if constexpr (AMODE == OP_RC_WT) kdec_step_tap(a_d[i], z.tm, BKT, p.A.C);
+                if constexpr (AMODE == OP_RC_PIX || AMODE == OP_RC_CONVK) kdec_step_pix(a_d[i], BKT, p.A.DH, p.A.DW);
+            }
         }
 #pragma unroll
         for (int i = 0; i < NUB; i++) {
-            if constexpr (B_KC) rb[i] = load_kc<BMODE>(p.B, z, b_rc[i], k0 + b_k[i]);
-            else rb[i] = load_rc<BMODE>(p.B, p, z, k0 + b_k[i], n0 + b_r[i], p.N);
+            if constexpr (B_KC) {
+                rb[i] = load_kc<BMODE>(p.B, z, b_rc[i], k0 + b_k[i], b_d[i]);
+                if constexpr (BMODE != OP_KC_DENSE) kdec_step_tap(b_d[i], z.tm, BKT, p.B.C);
+            } else {
+                rb[i] = load_rc<BMODE>(p.B, p, z, k0 + b_k[i], n0 + b_r[i], p.N, b_d[i]);
+                if constexpr (BMODE == OP_RC_WT) kdec_step_tap(b_d[i], z.tm, BKT, p.B.C);
+                if constexpr (BMODE == OP_RC_PIX || BMODE == OP_RC_CONVK) kdec_step_pix(b_d[i], BKT, p.B.DH, p.B.DW);
+            }
         }
     };
     auto lstore = [&](int buf) {
@@ -380,7 +438,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
         }
     };
 
-    const int nk = (z.kend > z.kbeg) ? (z.kend - z.kbeg + BK - 1) / BK : 0;
+    const int nk = (z.kend > z.kbeg) ? (z.kend - z.kbeg + BKT - 1) / BKT : 0;
     if (nk > 0) {
         gload(z.kbeg);
         lstore(0);
@@ -389,9 +447,9 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
     const int kl = lane >> 5, cl = lane & 31;
     for (int kt = 0; kt < nk; kt++) {
         const int buf = kt & 1;
-        if (kt + 1 < nk) gload(z.kbeg + (kt + 1) * BK);
+        if (kt + 1 < nk) gload(z.kbeg + (kt + 1) * BKT);
 #pragma unroll
-        for (int kk = 0; kk < BK / 2; kk++) {
+        for (int kk = 0; kk < BKT / 2; kk++) {
             float a[TM], b[TN];
 #pragma unroll
             for (int i = 0; i < TM; i++) a[i] = As[buf][kk * 2 + kl][wm * WM + i * 32 + cl];
@@ -428,48 +486,84 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
             for (int j = 0; j < TN; j++) {
                 int n = n0 + wn * WN + j * 32 + cl;
                 if (n >= p.N) continue;
-                float v = acc[i][j][r] * ep.alpha;
-                if (ep.col_scale) v *= ep.col_scale[n];
-                if (ep.samp_scale) v *= ep.samp_scale[(long)samp * ep.samp_ld + n];
-                if (ep.col_bias) v += ep.col_bias[n];
-                if (ep.residual) v += ep.residual[orow * ep.ldr + n];
-                if (ep.act == 1) v = fmaxf(v, 0.f);
-                else if (ep.act == 2) v = (v > 0.f ? v : v * ep.act_alpha) * ep.act_gain;
-                if (ep.mask_mode) {
-                    float s = ep.mask_src[orow * ep.ldm + n];
-                    if (ep.mask_mode == 1) v = s > 0.f ? v : 0.f;
-                    else v *= (s > 0.f ? ep.act_gain : ep.act_gain * ep.act_alpha);
-                }
-                if (ep.p_drop > 0.f) v *= drop_scale(ep.seed, (uint64_t)(orow * p.ldc + n), ep.p_drop, inv_keep);
-                v *= ep.out_scale;
                 float* dst = p.C + z.c_off + orow * p.ldc + n;
-                if (p.splitk > 1) atomicAdd(dst, v);
-                else if (ep.accumulate) *dst += v;
-                else *dst = v;
+                if (p.splitk > 1) {
+                    atomicAdd(dst, acc[i][j][r] * ep.alpha);   // raw partial sums; the rest of the epilogue runs in epilogue_kernel
+                } else {
+                    float v = apply_epilogue(ep, acc[i][j][r], orow, n, samp, p.ldc, inv_keep);
+                    if (ep.accumulate) *dst += v; else *dst = v;
+                }
             }
         }
     }
 }
 
-template <int AMODE, int BMODE>
-static int launch_gemm(const GemmParams& p, int Mmax, int zdim, int tile, hipStream_t st) {
-    if (tile == 128) {
-        dim3 grid(cdiv(p.N, 128), cdiv(Mmax, 128), zdim);
-        hipLaunchKernelGGL((gemm_f32_kernel<128, 128, AMODE, BMODE>), grid, 256, 0, st, p);
-    } else {
-        dim3 grid(cdiv(p.N, 64), cdiv(Mmax, 64), zdim);
-        hipLaunchKernelGGL((gemm_f32_kernel<64, 64, AMODE, BMODE>), grid, 256, 0, st, p);
+// Second phase of a split-K contraction: C holds sum_k (already scaled by alpha); apply the rest of the epilogue in place.
+struct EpiParams { GemmEpilogue ep; float* C; long ldc; long rows; int N; int pix_per_sample; };
+
+__global__ __launch_bounds__(256) void gemm_epilogue_kernel(EpiParams q) {
+    const float inv_keep = q.ep.p_drop > 0.f ? 1.f / (1.f - q.ep.p_drop) : 1.f;
+    const long total = q.rows * q.N;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        long row = i / q.N; int n = (int)(i - row * q.N);
+        int samp = q.pix_per_sample > 0 ? (int)(row / q.pix_per_sample) : 0;
+        float* dst = q.C + row * q.ldc + n;
+        *dst = apply_epilogue(q.ep, *dst, row, n, samp, q.ldc, inv_keep);
     }
-    return check_launch("gemm_f32");
+}
+
+static bool epilogue_is_linear(const GemmEpilogue& ep) {
+    return !ep.col_scale && !ep.samp_scale && !ep.col_bias && !ep.residual && !ep.act && !ep.mask_mode && ep.p_drop == 0.f &&
+           ep.out_scale == 1.f;
 }
 
 static inline bool al16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 
 static void init_operand(Operand& o) { memset(&o, 0, sizeof(o)); o.KW = 1; o.KH = 1; o.stride = 1; o.C = 1; o.Cr = 1; }
 
-static int pick_tile(long M, long N, int zdim) {
-    long t128 = (long)cdiv(M, 128) * cdiv(N, 128) * zdim;
-    return (t128 >= 192 && M >= 128 && N >= 128) ? 128 : 64;
+// Launch policy.  Tile 128x128 (BK 16) when it alone fills the chip; otherwise 64x64 (BK 32), and when even those
+// tiles leave most of the 256 CUs idle the reduction is split across grid.z (fp32 atomics into a zeroed C) with
+// the non-linear part of the epilogue applied by a second streaming pass.
+//   out_rows: rows of C touched (for the memset / epilogue pass); zbase: grid.z multiplicity before split-K;
+//   auto_split: the caller allows the policy to split K (explicit p.splitk > 1 is always honoured);
+//   caller_zeroed: C was already zeroed by the caller (weight-gradient entry points).
+template <int AMODE, int BMODE>
+static int launch_gemm(GemmParams& p, int Mmax, long out_rows, int zbase, bool auto_split, bool caller_zeroed, hipStream_t st) {
+    const int sk0 = p.splitk > 1 ? p.splitk : 1;
+    long t128 = (long)cdiv(Mmax, 128) * cdiv(p.N, 128) * zbase * sk0;
+    bool use128 = (t128 >= 384 && Mmax >= 128 && p.N >= 128);   // measured: the 128-tile only wins with >= ~1.5 blocks per CU
+    long t64 = (long)cdiv(Mmax, 64) * cdiv(p.N, 64) * zbase;
+    if (!use128 && auto_split && p.splitk <= 1 && t64 < 160 && !(p.ep.accumulate && !epilogue_is_linear(p.ep))) {
+        int want = (int)((384 + t64 - 1) / t64);
+        int maxs = p.K / 128;   // keep >= 4 k-tiles of 32 per slice
+        int sk = want < maxs ? want : maxs;
+        if (sk >= 2) p.splitk = sk;
+    }
+    GemmEpilogue full = p.ep;
+    const bool split = p.splitk > 1;
+    if (split) {
+        if (!p.ep.accumulate && !caller_zeroed) {
+            if (hipMemset2DAsync(p.C, (size_t)p.ldc * sizeof(float), 0, (size_t)p.N * sizeof(float), (size_t)out_rows, st) != hipSuccess) {
+                set_error("gemm: memset of the split-K output failed");
+                return LDETR_ERR_LAUNCH;
+            }
+        }
+    }
+    dim3 grid(cdiv(p.N, use128 ? 128 : 64), cdiv(Mmax, use128 ? 128 : 64), zbase * (split ? p.splitk : 1));
+    if (use128) hipLaunchKernelGGL((gemm_f32_kernel<128, 128, 16, AMODE, BMODE>), grid, 256, 0, st, p);
+    else hipLaunchKernelGGL((gemm_f32_kernel<64, 64, 32, AMODE, BMODE>), grid, 256, 0, st, p);
+    int rc = check_launch("gemm_f32");
+    if (rc) return rc;
+    if (split && !epilogue_is_linear(full)) {
+        EpiParams q;
+        q.ep = full; q.ep.alpha = 1.f; q.ep.accumulate = 0;
+        q.C = p.C; q.ldc = p.ldc; q.rows = out_rows; q.N = p.N; q.pix_per_sample = p.pix_per_sample;
+        long total = out_rows * p.N;
+        int g = (int)((total + 255) / 256); if (g > 4096) g = 4096; if (g < 1) g = 1;
+        hipLaunchKernelGGL(gemm_epilogue_kernel, g, 256, 0, st, q);
+        rc = check_launch("gemm_epilogue");
+    }
+    return rc;
 }
 
 static void fill_epilogue(GemmEpilogue& ep, const ldetr_epilogue* e) {
@@ -509,13 +603,12 @@ extern "C" int ldetr_gemm_f32(const float* A, int64_t lda, int ta, const float* 
     p.zmode = 0; p.splitk = splitk < 1 ? 1 : splitk; p.pstep = 1; p.nsamp = 1;
     p.pix_per_sample = pix_per_sample;
     fill_epilogue(p.ep, ep);
-    LDETR_CHECK(p.splitk == 1 || (!p.ep.act && !p.ep.col_bias && !p.ep.residual && !p.ep.mask_mode && p.ep.p_drop == 0.f),
-                "gemm: split-K supports only linear epilogues");
+    LDETR_CHECK(!(p.splitk > 1 && p.ep.accumulate && !epilogue_is_linear(p.ep)), "gemm: split-K + accumulate needs a linear epilogue");
     hipStream_t st = (hipStream_t)stream;
-    int tile = pick_tile(M, N, p.splitk);
-    if (!ta && !tb) return launch_gemm<OP_KC_DENSE, OP_KC_DENSE>(p, M, p.splitk, tile, st);
-    if (!ta && tb) return launch_gemm<OP_KC_DENSE, OP_RC_DENSE>(p, M, p.splitk, tile, st);
-    if (ta && tb) return launch_gemm<OP_RC_DENSE, OP_RC_DENSE>(p, M, p.splitk, tile, st);
+    const bool auto_split = (splitk == 0);   // splitk: 0 = let the launch policy decide, 1 = never split, >1 = explicit
+    if (!ta && !tb) return launch_gemm<OP_KC_DENSE, OP_KC_DENSE>(p, M, M, 1, auto_split, false, st);
+    if (!ta && tb) return launch_gemm<OP_KC_DENSE, OP_RC_DENSE>(p, M, M, 1, auto_split, false, st);
+    if (ta && tb) return launch_gemm<OP_RC_DENSE, OP_RC_DENSE>(p, M, M, 1, auto_split, false, st);
     set_error("gemm: (ta=1, tb=0) is not instantiated");
     return LDETR_ERR_UNSUPPORTED;
 }
@@ -547,13 +640,12 @@ extern "C" int ldetr_conv2d_fwd_f32(const float* x, const ldetr_tensor4* xt, con
     p.zmode = 0; p.splitk = 1; p.pstep = 1; p.nsamp = xt->N; p.pix_per_sample = OH * OW;
     fill_epilogue(p.ep, ep);
     hipStream_t st = (hipStream_t)stream;
-    int tile = pick_tile(p.M, p.N, 1);
     if (KH == 1 && KW == 1 && stride == 1 && pad == 0 && p.A.vec && !in_scale && xt->sw == xt->C && xt->sh == (long)xt->W * xt->C &&
         xt->sn == (long)xt->H * xt->W * xt->C) {
         p.A.ld = xt->C;  // pure GEMM view of a packed NHWC tensor
-        return launch_gemm<OP_KC_DENSE, OP_KC_DENSE>(p, p.M, 1, tile, st);
+        return launch_gemm<OP_KC_DENSE, OP_KC_DENSE>(p, p.M, p.M, 1, true, false, st);
     }
-    return launch_gemm<OP_KC_CONV, OP_KC_DENSE>(p, p.M, 1, tile, st);
+    return launch_gemm<OP_KC_CONV, OP_KC_DENSE>(p, p.M, p.M, 1, true, false, st);
 }
 
 // conv2d backward-data: dx[n,ih,iw,ci] = sum_{co,kh,kw} dy[n,oh,ow,co] * w[co,kh,kw,ci],  ih = oh*s - p + kh.
@@ -579,8 +671,7 @@ extern "C" int ldetr_conv2d_bwd_data_f32(const float* dy, const ldetr_tensor4* d
     p.M = dyt->N * IH * IW; p.K = KH * KW * dyt->C;
     fill_epilogue(p.ep, ep);
     int Mmax = dyt->N * cdiv(IH, stride) * cdiv(IW, stride);
-    int tile = pick_tile(Mmax, p.N, stride * stride);
-    return launch_gemm<OP_KC_CONVT, OP_RC_WT>(p, Mmax, stride * stride, tile, (hipStream_t)stream);
+    return launch_gemm<OP_KC_CONVT, OP_RC_WT>(p, Mmax, (long)p.M, stride * stride, true, false, (hipStream_t)stream);
 }
 
 // conv2d backward-weight: dw[co,kh,kw,ci] = sum_{n,oh,ow} dy[n,oh,ow,co] * x[n, oh*s-p+kh, ow*s-p+kw, ci].
@@ -610,7 +701,7 @@ extern "C" int ldetr_conv2d_bwd_weight_f32(const float* x, const ldetr_tensor4* 
         set_conv_src(p.B, x, xt);
         p.B.DH = OH; p.B.DW = OW; p.B.C = Cin; p.B.stride = stride; p.B.pad = pad; p.B.KH = KH; p.B.KW = KW;
         p.M = Cout; p.N = KH * KW * Cin; p.K = Kpix; p.C = dw; p.ldc = (long)KH * KW * Cin; p.zmode = 0;
-        return launch_gemm<OP_RC_DENSE, OP_RC_CONVK>(p, p.M, splitk, 64, st);
+        return launch_gemm<OP_RC_DENSE, OP_RC_CONVK>(p, p.M, p.M, 1, false, true, st);
     }
     // A = dy viewed as [k = pixel][m = co]; B = x gathered per tap [k = pixel][n = ci]
     set_conv_src(p.A, dy, dyt);
@@ -625,8 +716,7 @@ extern "C" int ldetr_conv2d_bwd_weight_f32(const float* x, const ldetr_tensor4* 
               (!x_scale || (al16(x_scale) && x_scale_ld % 4 == 0));
     p.M = Cout; p.N = Cin; p.K = Kpix; p.C = dw; p.ldc = (long)KH * KW * Cin;
     p.zmode = 2; p.ntaps = KH * KW; p.c_tap_stride = Cin;
-    int tile = pick_tile(p.M, p.N, p.ntaps * splitk);
-    return launch_gemm<OP_RC_PIX, OP_RC_PIX>(p, p.M, p.ntaps * splitk, tile, st);
+    return launch_gemm<OP_RC_PIX, OP_RC_PIX>(p, p.M, p.M, p.ntaps, false, true, st);
 }
 
 // conv_transpose2d forward (as F.conv_transpose2d with weight given as the *un-transposed* OHWI tensor
@@ -654,8 +744,7 @@ extern "C" int ldetr_conv_transpose2d_fwd_f32(const float* x, const ldetr_tensor
     p.M = xt->N * OH * OW; p.K = KH * KW * xt->C;
     fill_epilogue(p.ep, ep);
     int Mmax = xt->N * cdiv(OH, stride) * cdiv(OW, stride);
-    int tile = pick_tile(Mmax, p.N, stride * stride);
-    return launch_gemm<OP_KC_CONVT, OP_KC_WTAP>(p, Mmax, stride * stride, tile, (hipStream_t)stream);
+    return launch_gemm<OP_KC_CONVT, OP_KC_WTAP>(p, Mmax, (long)p.M, stride * stride, false, false, (hipStream_t)stream);
 }
 
 // conv_transpose2d backward-data: dx[n,ih,iw,ci] = sum_{co,kh,kw} dy[n, ih*s+kh-p, iw*s+kw-p, co] * w[co,kh,kw,ci]
@@ -677,8 +766,7 @@ extern "C" int ldetr_conv_transpose2d_bwd_data_f32(const float* dy, const ldetr_
     p.M = dyt->N * IH * IW; p.N = Cin; p.K = KH * KW * dyt->C; p.C = dx; p.ldc = lddx;
     p.zmode = 0; p.splitk = 1; p.pstep = 1; p.nsamp = dyt->N; p.pix_per_sample = IH * IW;
     fill_epilogue(p.ep, ep);
-    int tile = pick_tile(p.M, p.N, 1);
-    return launch_gemm<OP_KC_CONV, OP_RC_WT>(p, p.M, 1, tile, (hipStream_t)stream);
+    return launch_gemm<OP_KC_CONV, OP_RC_WT>(p, p.M, p.M, 1, true, false, (hipStream_t)stream);
 }
 
 // conv_transpose2d backward-weight: dw[co,kh,kw,ci] = sum_{n,ih,iw} dy[n, ih*s+kh-p, iw*s+kw-p, co] * x[n,ih,iw,ci]
@@ -710,6 +798,5 @@ extern "C" int ldetr_conv_transpose2d_bwd_weight_f32(const float* x, const ldetr
               (!x_scale || (al16(x_scale) && x_scale_ld % 4 == 0));
     p.M = Cout; p.N = Cin; p.K = xt->N * xt->H * xt->W; p.C = dw; p.ldc = (long)KH * KW * Cin;
     p.zmode = 2; p.ntaps = KH * KW; p.c_tap_stride = Cin;
-    int tile = pick_tile(p.M, p.N, p.ntaps * splitk);
-    return launch_gemm<OP_RC_PIX, OP_RC_PIX>(p, p.M, p.ntaps * splitk, tile, st);
+    return launch_gemm<OP_RC_PIX, OP_RC_PIX>(p, p.M, p.M, p.ntaps, false, true, st);
 }

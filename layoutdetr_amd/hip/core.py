@@ -125,13 +125,13 @@ def epilogue(alpha=1.0, col_scale=None, col_bias=None, samp_scale=None, residual
     return ep
 
 
-def gemm(A, B, ta, tb, M, N, K, out=None, ep=None, splitk=1, pix_per_sample=0, lda=None, ldb=None):
-    """C[M,N] = op(A) @ op(B); see ldetr_gemm_f32.  A/B are 2-D fp32 device tensors (row-major, unit inner stride)."""
+def gemm(A, B, ta, tb, M, N, K, out=None, ep=None, splitk=0, pix_per_sample=0, lda=None, ldb=None):
+    """C[M,N] = op(A) @ op(B); see ldetr_gemm_f32.  A/B are 2-D fp32 device tensors (row-major, unit inner stride).
+    splitk: 0 = let the launch policy split the reduction when the tile grid would leave CUs idle, 1 = never, >1 = explicit.
+    (The library zeroes the output itself when it splits.)"""
     require_gpu(A, B)
     if out is None:
-        out = (torch.zeros if splitk > 1 else torch.empty)((M, N), device=A.device, dtype=torch.float32)
-    elif splitk > 1 and not (ep is not None and ep.accumulate):
-        out.zero_()
+        out = torch.empty((M, N), device=A.device, dtype=torch.float32)
     lda = A.stride(0) if lda is None else lda
     ldb = B.stride(0) if ldb is None else ldb
     engine_call('gemm', 2.0 * M * N * K, lambda: check(lib().ldetr_gemm_f32(

@@ -68,9 +68,7 @@ class _LinearFn(torch.autograd.Function):
         if need_x:
             dx = core.gemm(dpre, w, 0, 1, M, K, N, ep=core.epilogue(alpha=wscale)).reshape(xshape)
         if need_w:
-            tiles = ((N + 63) // 64) * ((K + 63) // 64)
-            sk = core.pick_splitk(tiles, M)
-            dw = core.gemm(dpre, x2, 1, 1, N, K, M, ep=core.epilogue(alpha=wscale), splitk=sk)
+            dw = core.gemm(dpre, x2, 1, 1, N, K, M, ep=core.epilogue(alpha=wscale))
         return dx, dw, db, None, None, None, None, None
 
 

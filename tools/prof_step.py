@@ -1,5 +1,5 @@
 """Timing breakdown of the G+D step (development aid)."""
-import sys, time, copy; sys.path.insert(0, '.')
+import sys, time, copy; sys.path.insert(0, '.'); sys.path.insert(0, '..')
 import torch
 from bench import make_batch, to_device_batch
 from layoutdetr_amd.training import training_loop as tl
