@@ -7,8 +7,9 @@ gradient exchange + /world + nan_to_num, Adam, G_ema lerp — in train mode (dro
 Workload (BASELINE.json configs[2]/[3]): global batch 16, 256x256 synthetic backgrounds, 9 elements per layout,
 hot-path-only (BASELINE.md variant A): the frozen BERT text encoder's CLS features are an input tensor and the
 LM-decoder loss is excluded (SURVEY §8a rows a16/a17 are boundary inputs).
-N > 1: one process per GPU (torchrun), the global batch of 16 is sharded across ranks ("strong" scaling, as
-configs[3] states) and gradients are exchanged with RCCL all-reduce over xGMI.
+N > 1: one process per GPU (torchrun); by default every GPU keeps 16 samples ("weak" scaling: global batch 16 x N,
+the regime in which the north-star's >= 6.5x at 8 GPUs is meaningful); `--global-batch 16` reproduces configs[3]
+(global batch fixed at 16, "strong").  Gradients are exchanged with RCCL all-reduce over xGMI.
 
 Prints ONE JSON line on rank 0.
 """
@@ -77,7 +78,9 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=10)
     ap.add_argument('--warmup', type=int, default=3)
-    ap.add_argument('--batch', type=int, default=16, help='global batch')
+    ap.add_argument('--per-gpu-batch', type=int, default=16, help='samples per GPU (weak scaling: global batch = 16 x N)')
+    ap.add_argument('--global-batch', type=int, default=0, help='fix the GLOBAL batch instead (strong scaling, BASELINE configs[3] uses 16)')
+    ap.add_argument('--no-graph', action='store_true', help='eager launches instead of hipGraph replay of each phase')
     ap.add_argument('--bg', type=int, default=256)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
@@ -94,7 +97,11 @@ def main():
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         dist.init_process_group('nccl', device_id=device)
     assert args.gpus == world, f'--gpus {args.gpus} but WORLD_SIZE={world} (launch with torch.distributed.run)'
-    assert args.batch % world == 0
+    if args.global_batch:
+        assert args.global_batch % world == 0
+        args.batch, scaling = args.global_batch, 'strong'
+    else:
+        args.batch, scaling = args.per_gpu_batch * world, 'weak'
 
     from layoutdetr_amd import _lib
     _lib.load()   # fails loudly if the HIP library is missing: there is no fallback path
@@ -116,6 +123,7 @@ def main():
     G_names = {n for n, _ in G.named_parameters()}
     D_names = {n for n, _ in D.named_parameters()}
     G.to(device); D.to(device)
+    G.static_shapes = D.static_shapes = True   # sync-free heads/losses (same values; required for graph capture)
     G_ema = copy.deepcopy(G).eval()
     pG = tl.Phase('Gmain', G, lr=1e-5, betas=(0.0, 0.99), eps=1e-8, reg_interval=4)     # train.py:204,281; training_loop.py:191-194
     pD = tl.Phase('Dmain', D, lr=1e-5, betas=(0.0, 0.99), eps=1e-8, reg_interval=16)
@@ -128,11 +136,20 @@ def main():
     n_params = (pG.fm.total, pD.fm.total)
     cur_nimg = [0]
 
-    def step():
+    def eager_step():
         gen_z = [torch.randn(b_local, 9, 4, device=device) for _ in range(2)]
         tl.training_iteration(loss, [pG, pD], dp, batch, b_local, gen_z, ema=ema, batch_size=args.batch,
                               ema_kimg=args.batch * 10 / 32, cur_nimg=cur_nimg[0])
         cur_nimg[0] += args.batch
+
+    step = eager_step
+    if not args.no_graph:
+        for _ in range(2):        # eager warm-up before capture (allocator, folded-BN / position-encoding caches)
+            eager_step()
+        torch.cuda.synchronize()
+        graphed = tl.GraphedIteration(loss, [pG, pD], dp, batch, b_local, 4, ema=ema, batch_size=args.batch, ema_kimg=args.batch * 10 / 32)
+        graphed.cur_nimg = cur_nimg[0]
+        step = graphed.run
 
     def barrier():
         if world > 1:
@@ -164,7 +181,7 @@ def main():
         core.PROF.enabled = True
         core.PROF.reset()
         for _ in range(2):
-            step()
+            eager_step()          # per-launch events need eager launches (same kernels, same shapes as the replayed graphs)
         torch.cuda.synchronize()
         fl, sec, launches = core.PROF.summary()
         core.PROF.enabled = False
@@ -180,12 +197,12 @@ def main():
             cpu = cpu_baseline(G_sd_cpu, D_sd_cpu, G_names, D_names, bg)
         out = dict(metric='images/sec G+D fwd-bwd, 256x256 bg x9 elems', value=round(value, 3), unit='images/s', n_gpus=world,
                    steps=args.steps, warmup=args.warmup, ms_per_step=round(ms_per_step, 3), higher_is_better=True,
-                   scaling='strong', vs_baseline=None, dtype='f32', data='synthetic',
-                   config=dict(workload=f'BASELINE configs[2]: global batch {args.batch}, {bg}x{bg} backgrounds x 9 elements, full G+D adversarial '
+                   scaling=scaling, vs_baseline=None, dtype='f32', data='synthetic',
+                   config=dict(workload=f'BASELINE configs[2] (16 samples per GPU): global batch {args.batch}, {bg}x{bg} backgrounds x 9 elements, full G+D adversarial '
                                         'step (Gmain+Dmain fwd/bwd, grad exchange + nan_to_num, Adam, EMA), train mode (dropout 0.1); '
                                         'hot-path-only: frozen-BERT text features are an input, LM-decoder loss excluded',
                                global_batch=args.batch, per_gpu_batch=b_local, background=bg, elements=9,
-                               parallelism=f'dp{world}', params_G=n_params[0], params_D=n_params[1]),
+                               parallelism=f'dp{world}', hip_graph=not args.no_graph, params_G=n_params[0], params_D=n_params[1]),
                    roofline=roofline, cpu_baseline=cpu)
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -72,6 +72,7 @@ typedef struct ldetr_epilogue {
     float out_scale;
     float p_drop;
     uint64_t seed;
+    const uint64_t* seed_ptr; /* optional device word added to `seed` at run time (keeps dropout fresh under hipGraph replay) */
     int accumulate;
 } ldetr_epilogue;
 
@@ -114,19 +115,20 @@ int ldetr_conv_transpose2d_bwd_weight_f32(const float* x, const ldetr_tensor4* x
 
 int ldetr_attention_fwd_f32(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v, int64_t ldv,
                             const unsigned char* key_padding_mask, float* out, int64_t ldo, float* lse, int B, int H,
-                            int Lq, int Lk, int head_dim, float scale, float p_drop, uint64_t seed, void* stream);
+                            int Lq, int Lk, int head_dim, float scale, float p_drop, uint64_t seed, const uint64_t* seed_ptr,
+                            void* stream);
 int ldetr_attention_bwd_f32(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v, int64_t ldv,
                             const unsigned char* key_padding_mask, const float* out, int64_t ldo, const float* lse,
                             const float* dout, int64_t lddo, float* dq, int64_t lddq, float* dk, int64_t lddk,
                             float* dv, int64_t lddv, int B, int H, int Lq, int Lk, int head_dim, float scale,
-                            float p_drop, uint64_t seed, void* stream);
+                            float p_drop, uint64_t seed, const uint64_t* seed_ptr, void* stream);
 
 int ldetr_layernorm_fwd_f32(const float* x, const float* residual, const float* gamma, const float* beta, float* y,
                             float* z, float* mean, float* rstd, int64_t rows, int D, float eps, float p_drop,
-                            uint64_t seed, void* stream);
+                            uint64_t seed, const uint64_t* seed_ptr, void* stream);
 int ldetr_layernorm_bwd_f32(const float* dy, const float* z, const float* mean, const float* rstd, const float* gamma,
                             float* dx, float* dresidual, float* dgamma, float* dbeta, int64_t rows, int D,
-                            float p_drop, uint64_t seed, void* stream);
+                            float p_drop, uint64_t seed, const uint64_t* seed_ptr, void* stream);
 
 int ldetr_colsum_f32(const float* a, float* red, int B, int64_t P, int C, void* stream);
 int ldetr_act_bwd_reduce_f32(const float* dy, const float* y, float* dv, const float* bias, const float* demod,

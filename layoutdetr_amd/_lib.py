@@ -22,7 +22,7 @@ class Epilogue(Structure):
                 ('samp_ld', c_int64), ('residual', c_void_p), ('ldr', c_int64), ('act', c_int),
                 ('act_alpha', c_float), ('act_gain', c_float), ('mask_src', c_void_p), ('ldm', c_int64),
                 ('mask_mode', c_int), ('out_scale', c_float), ('p_drop', c_float), ('seed', c_uint64),
-                ('accumulate', c_int)]
+                ('seed_ptr', c_void_p), ('accumulate', c_int)]
 
 
 _P = c_void_p
@@ -44,11 +44,11 @@ SIGNATURES = {
     'ldetr_conv_transpose2d_fwd_f32': [_P, _T4, _P, _I, _I, _I, _I, _I, _P, _L, _I, _I, _P, _L, _EP, _P],
     'ldetr_conv_transpose2d_bwd_data_f32': [_P, _T4, _P, _I, _I, _I, _I, _I, _P, _L, _I, _I, _P, _L, _EP, _P],
     'ldetr_conv_transpose2d_bwd_weight_f32': [_P, _T4, _P, _T4, _P, _I, _I, _I, _I, _I, _P, _L, _P, _L, _P],
-    'ldetr_attention_fwd_f32': [_P, _L, _P, _L, _P, _L, _P, _P, _L, _P, _I, _I, _I, _I, _I, _F, _F, c_uint64, _P],
+    'ldetr_attention_fwd_f32': [_P, _L, _P, _L, _P, _L, _P, _P, _L, _P, _I, _I, _I, _I, _I, _F, _F, c_uint64, _P, _P],
     'ldetr_attention_bwd_f32': [_P, _L, _P, _L, _P, _L, _P, _P, _L, _P, _P, _L, _P, _L, _P, _L, _P, _L,
-                                _I, _I, _I, _I, _I, _F, _F, c_uint64, _P],
-    'ldetr_layernorm_fwd_f32': [_P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _F, _F, c_uint64, _P],
-    'ldetr_layernorm_bwd_f32': [_P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _F, c_uint64, _P],
+                                _I, _I, _I, _I, _I, _F, _F, c_uint64, _P, _P],
+    'ldetr_layernorm_fwd_f32': [_P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _F, _F, c_uint64, _P, _P],
+    'ldetr_layernorm_bwd_f32': [_P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _F, c_uint64, _P, _P],
     'ldetr_colsum_f32': [_P, _P, _I, _L, _I, _P],
     'ldetr_act_bwd_reduce_f32': [_P, _P, _P, _P, _P, _P, _P, _I, _L, _I, _I, _F, _F, _P],
     'ldetr_mul_reduce_f32': [_P, _P, _P, _P, _P, _I, _L, _I, _P],
@@ -82,7 +82,7 @@ def load():
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported
         fn.restype = c_int
         fn.argtypes = argtypes
-    if lib.ldetr_abi_version() != 1:
+    if lib.ldetr_abi_version() != 2:
         raise RuntimeError('libldetr_hip.so ABI version mismatch; rebuild it')
     _lib = lib
     return lib

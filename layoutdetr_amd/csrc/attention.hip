@@ -28,6 +28,7 @@ struct AttnParams {
     int B, H, Lq, Lk;
     float scale, p_drop;
     unsigned long long seed;
+    const unsigned long long* seed_ptr;
 };
 
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
@@ -36,7 +37,7 @@ __device__ __forceinline__ float ldz(const float* p, bool ok) { return ok ? *p :
 
 // Dropout element index: ((b*H + h)*Lq + q)*Lk + key.
 __device__ __forceinline__ float attn_drop(const AttnParams& p, int bh, int q, int key, float inv_keep) {
-    return drop_scale(p.seed, ((uint64_t)bh * p.Lq + q) * p.Lk + key, p.p_drop, inv_keep);
+    return drop_scale(p.seed + (p.seed_ptr ? *p.seed_ptr : 0ull), ((uint64_t)bh * p.Lq + q) * p.Lk + key, p.p_drop, inv_keep);
 }
 
 template <int NKT>
@@ -275,12 +276,12 @@ using namespace ldetr;
 extern "C" int ldetr_attention_fwd_f32(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v, int64_t ldv,
                                        const unsigned char* key_padding_mask, float* out, int64_t ldo, float* lse,
                                        int B, int H, int Lq, int Lk, int head_dim, float scale,
-                                       float p_drop, uint64_t seed, void* stream) {
+                                       float p_drop, uint64_t seed, const uint64_t* seed_ptr, void* stream) {
     LDETR_CHECK(head_dim == 32, "attention: head_dim must be 32 (got %d)", head_dim);
     AttnParams p; memset(&p, 0, sizeof(p));
     p.q = q; p.k = k; p.v = v; p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.kpm = key_padding_mask;
     p.o = out; p.ldo = ldo; p.lse = lse; p.B = B; p.H = H; p.Lq = Lq; p.Lk = Lk;
-    p.scale = scale; p.p_drop = p_drop; p.seed = seed;
+    p.scale = scale; p.p_drop = p_drop; p.seed = seed; p.seed_ptr = (const unsigned long long*)seed_ptr;
     int rc = check_attn(p, "attention_fwd");
     if (rc) return rc;
     const int nqt = (Lq + 15) / 16, nkt = (Lk + 15) / 16;
@@ -299,14 +300,14 @@ extern "C" int ldetr_attention_bwd_f32(const float* q, int64_t ldq, const float*
                                        const float* dout, int64_t lddo,
                                        float* dq, int64_t lddq, float* dk, int64_t lddk, float* dv, int64_t lddv,
                                        int B, int H, int Lq, int Lk, int head_dim, float scale,
-                                       float p_drop, uint64_t seed, void* stream) {
+                                       float p_drop, uint64_t seed, const uint64_t* seed_ptr, void* stream) {
     LDETR_CHECK(head_dim == 32, "attention: head_dim must be 32 (got %d)", head_dim);
     LDETR_CHECK(lse && dout && dq && dk && dv, "attention_bwd: null pointer");
     AttnParams p; memset(&p, 0, sizeof(p));
     p.q = q; p.k = k; p.v = v; p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.kpm = key_padding_mask;
     p.o = const_cast<float*>(out); p.ldo = ldo; p.lse = const_cast<float*>(lse);
     p.dout = dout; p.lddo = lddo; p.dq = dq; p.lddq = lddq; p.dk = dk; p.lddk = lddk; p.dv = dv; p.lddv = lddv;
-    p.B = B; p.H = H; p.Lq = Lq; p.Lk = Lk; p.scale = scale; p.p_drop = p_drop; p.seed = seed;
+    p.B = B; p.H = H; p.Lq = Lq; p.Lk = Lk; p.scale = scale; p.p_drop = p_drop; p.seed = seed; p.seed_ptr = (const unsigned long long*)seed_ptr;
     int rc = check_attn(p, "attention_bwd");
     if (rc) return rc;
     LDETR_CHECK((lddq % 4) == 0 && (lddk % 4) == 0 && (lddv % 4) == 0 &&

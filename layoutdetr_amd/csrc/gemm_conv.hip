@@ -63,6 +63,7 @@ struct GemmEpilogue {
     float out_scale;
     float p_drop;
     unsigned long long seed;
+    const unsigned long long* seed_ptr;
     int accumulate;
 };
 
@@ -329,7 +330,7 @@ __device__ __forceinline__ float apply_epilogue(const GemmEpilogue& ep, float v,
         if (ep.mask_mode == 1) v = s > 0.f ? v : 0.f;
         else v *= (s > 0.f ? ep.act_gain : ep.act_gain * ep.act_alpha);
     }
-    if (ep.p_drop > 0.f) v *= drop_scale(ep.seed, (uint64_t)(orow * ldc + n), ep.p_drop, inv_keep);
+    if (ep.p_drop > 0.f) v *= drop_scale(ep.seed + (ep.seed_ptr ? *ep.seed_ptr : 0ull), (uint64_t)(orow * ldc + n), ep.p_drop, inv_keep);
     return v * ep.out_scale;
 }
 
@@ -576,7 +577,7 @@ static void fill_epilogue(GemmEpilogue& ep, const ldetr_epilogue* e) {
     ep.residual = e->residual; ep.ldr = e->ldr;
     ep.act = e->act; ep.act_alpha = e->act_alpha; ep.act_gain = e->act_gain;
     ep.mask_src = e->mask_src; ep.ldm = e->ldm; ep.mask_mode = e->mask_mode;
-    ep.out_scale = e->out_scale; ep.p_drop = e->p_drop; ep.seed = e->seed; ep.accumulate = e->accumulate;
+    ep.out_scale = e->out_scale; ep.p_drop = e->p_drop; ep.seed = e->seed; ep.seed_ptr = (const unsigned long long*)e->seed_ptr; ep.accumulate = e->accumulate;
 }
 
 }  // namespace ldetr

@@ -13,7 +13,7 @@ struct LnParams {
     const float* x; const float* r; const float* gamma; const float* beta;
     float* y; float* z; float* mean; float* rstd;
     const float* dy; float* dx; float* dr; float* dgamma; float* dbeta;
-    long rows; int D; float eps, p_drop; unsigned long long seed;
+    long rows; int D; float eps, p_drop; unsigned long long seed; const unsigned long long* seed_ptr;
 };
 
 // NV = float4 vectors per lane (D = 256*NV at most; lanes past D/4 idle)
@@ -24,6 +24,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(LnParams p) {
     if (row >= p.rows) return;
     const int D4 = p.D >> 2;
     const float inv_keep = p.p_drop > 0.f ? 1.f / (1.f - p.p_drop) : 1.f;
+    const unsigned long long seed = p.seed + (p.seed_ptr ? *p.seed_ptr : 0ull);
     float4 v[NV];
     float s = 0.f;
 #pragma unroll
@@ -36,10 +37,10 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(LnParams p) {
                 float4 rr = reinterpret_cast<const float4*>(p.r + row * p.D)[c4];
                 if (p.p_drop > 0.f) {
                     uint64_t e = (uint64_t)row * p.D + (c4 << 2);
-                    rr.x *= drop_scale(p.seed, e, p.p_drop, inv_keep);
-                    rr.y *= drop_scale(p.seed, e + 1, p.p_drop, inv_keep);
-                    rr.z *= drop_scale(p.seed, e + 2, p.p_drop, inv_keep);
-                    rr.w *= drop_scale(p.seed, e + 3, p.p_drop, inv_keep);
+                    rr.x *= drop_scale(seed, e, p.p_drop, inv_keep);
+                    rr.y *= drop_scale(seed, e + 1, p.p_drop, inv_keep);
+                    rr.z *= drop_scale(seed, e + 2, p.p_drop, inv_keep);
+                    rr.w *= drop_scale(seed, e + 3, p.p_drop, inv_keep);
                 }
                 v[i].x += rr.x; v[i].y += rr.y; v[i].z += rr.z; v[i].w += rr.w;
             }
@@ -82,6 +83,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(LnParams p) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int D4 = p.D >> 2;
     const float inv_keep = p.p_drop > 0.f ? 1.f / (1.f - p.p_drop) : 1.f;
+    const unsigned long long seed = p.seed + (p.seed_ptr ? *p.seed_ptr : 0ull);
     float4 ag[NV], ab[NV];
 #pragma unroll
     for (int i = 0; i < NV; i++) { ag[i] = make_float4(0.f, 0.f, 0.f, 0.f); ab[i] = ag[i]; }
@@ -118,10 +120,10 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(LnParams p) {
                 if (p.dr) {
                     if (p.p_drop > 0.f) {
                         uint64_t e = (uint64_t)row * p.D + (c4 << 2);
-                        dz.x *= drop_scale(p.seed, e, p.p_drop, inv_keep);
-                        dz.y *= drop_scale(p.seed, e + 1, p.p_drop, inv_keep);
-                        dz.z *= drop_scale(p.seed, e + 2, p.p_drop, inv_keep);
-                        dz.w *= drop_scale(p.seed, e + 3, p.p_drop, inv_keep);
+                        dz.x *= drop_scale(seed, e, p.p_drop, inv_keep);
+                        dz.y *= drop_scale(seed, e + 1, p.p_drop, inv_keep);
+                        dz.z *= drop_scale(seed, e + 2, p.p_drop, inv_keep);
+                        dz.w *= drop_scale(seed, e + 3, p.p_drop, inv_keep);
                     }
                     reinterpret_cast<float4*>(p.dr + row * p.D)[c4] = dz;
                 }
@@ -150,13 +152,13 @@ using namespace ldetr;
 
 extern "C" int ldetr_layernorm_fwd_f32(const float* x, const float* residual, const float* gamma, const float* beta,
                                        float* y, float* z, float* mean, float* rstd, int64_t rows, int D, float eps,
-                                       float p_drop, uint64_t seed, void* stream) {
+                                       float p_drop, uint64_t seed, const uint64_t* seed_ptr, void* stream) {
     LDETR_CHECK(x && gamma && beta && y, "layernorm_fwd: null pointer");
     LDETR_CHECK(D % 4 == 0 && D >= 4 && D <= 1024, "layernorm_fwd: D must be a multiple of 4 in [4, 1024]");
     if (rows == 0) return LDETR_OK;
     LnParams p; memset(&p, 0, sizeof(p));
     p.x = x; p.r = residual; p.gamma = gamma; p.beta = beta; p.y = y; p.z = z; p.mean = mean; p.rstd = rstd;
-    p.rows = rows; p.D = D; p.eps = eps; p.p_drop = p_drop; p.seed = seed;
+    p.rows = rows; p.D = D; p.eps = eps; p.p_drop = p_drop; p.seed = seed; p.seed_ptr = (const unsigned long long*)seed_ptr;
     int grid = (int)((rows + 3) / 4);
     hipStream_t st = (hipStream_t)stream;
     int nv = (D + 255) / 256;
@@ -170,7 +172,7 @@ extern "C" int ldetr_layernorm_fwd_f32(const float* x, const float* residual, co
 // dgamma/dbeta are accumulated with atomics: the caller zeroes them (or passes running gradients).
 extern "C" int ldetr_layernorm_bwd_f32(const float* dy, const float* z, const float* mean, const float* rstd, const float* gamma,
                                        float* dx, float* dresidual, float* dgamma, float* dbeta, int64_t rows, int D,
-                                       float p_drop, uint64_t seed, void* stream) {
+                                       float p_drop, uint64_t seed, const uint64_t* seed_ptr, void* stream) {
     LDETR_CHECK(dy && z && mean && rstd && gamma, "layernorm_bwd: null pointer");
     LDETR_CHECK(D % 4 == 0 && D >= 4 && D <= 1024, "layernorm_bwd: D must be a multiple of 4 in [4, 1024]");
     LDETR_CHECK((dgamma == nullptr) == (dbeta == nullptr), "layernorm_bwd: dgamma and dbeta go together");
@@ -178,7 +180,7 @@ extern "C" int ldetr_layernorm_bwd_f32(const float* dy, const float* z, const fl
     LnParams p; memset(&p, 0, sizeof(p));
     p.dy = dy; p.z = const_cast<float*>(z); p.mean = const_cast<float*>(mean); p.rstd = const_cast<float*>(rstd);
     p.gamma = gamma; p.dx = dx; p.dr = dresidual; p.dgamma = dgamma; p.dbeta = dbeta;
-    p.rows = rows; p.D = D; p.p_drop = p_drop; p.seed = seed;
+    p.rows = rows; p.D = D; p.p_drop = p_drop; p.seed = seed; p.seed_ptr = (const unsigned long long*)seed_ptr;
     int grid = (int)((rows + 3) / 4);
     if (grid > 512) grid = 512;
     hipStream_t st = (hipStream_t)stream;

@@ -29,7 +29,8 @@ class _AttnFn(torch.autograd.Function):
         scale = 1.0 / math.sqrt(dh)
         core.check(core.lib().ldetr_attention_fwd_f32(
             core.ptr(q), q.stride(0), core.ptr(k), k.stride(0), core.ptr(v), v.stride(0), core.ptr(kpm),
-            core.ptr(out), d, core.ptr(lse), B, H, Lq, Lk, dh, scale, p_drop, seed, core.stream()), 'attention_fwd')
+            core.ptr(out), d, core.ptr(lse), B, H, Lq, Lk, dh, scale, p_drop, seed, core.seed_ptr() if p_drop > 0 else None,
+            core.stream()), 'attention_fwd')
         ctx.save_for_backward(q, k, v, kpm, out, lse)
         ctx.cfg = (B, H, Lq, Lk, dh, scale, p_drop, seed)
         return out
@@ -46,7 +47,7 @@ class _AttnFn(torch.autograd.Function):
         core.check(core.lib().ldetr_attention_bwd_f32(
             core.ptr(q), q.stride(0), core.ptr(k), k.stride(0), core.ptr(v), v.stride(0), core.ptr(kpm),
             core.ptr(out), d, core.ptr(lse), core.ptr(dout), d, core.ptr(dq), d, core.ptr(dk), d, core.ptr(dv), d,
-            B, H, Lq, Lk, dh, scale, p_drop, seed, core.stream()), 'attention_bwd')
+            B, H, Lq, Lk, dh, scale, p_drop, seed, core.seed_ptr() if p_drop > 0 else None, core.stream()), 'attention_bwd')
         return dq, dk, dv, None, None, None, None, None, None
 
 

@@ -85,6 +85,27 @@ def next_seed():
     return ((base << 32) ^ (_seed_counter[0] * 0x9E3779B1)) & 0xFFFFFFFFFFFFFFFF
 
 
+_iter_seed = {}
+
+
+def iter_seed(device=None):
+    """Device-resident 64-bit word that every dropout kernel adds to its (host, per-launch) seed.  `reseed()` redraws
+    it with torch's graph-safe Philox generator, so a hipGraph replay of the step still sees fresh dropout masks."""
+    device = torch.device('cuda', torch.cuda.current_device()) if device is None else torch.device(device)
+    key = (device.type, device.index)
+    if key not in _iter_seed:
+        _iter_seed[key] = torch.zeros(1, dtype=torch.int64, device=device)
+    return _iter_seed[key]
+
+
+def reseed(device=None):
+    iter_seed(device).random_()
+
+
+def seed_ptr():
+    return ctypes.c_void_p(iter_seed().data_ptr())
+
+
 def tensor4_nhwc(x):
     """x: [N, H, W, C] tensor (any strides) -> ldetr_tensor4 describing it."""
     N, H, W, C = x.shape
@@ -121,6 +142,7 @@ def epilogue(alpha=1.0, col_scale=None, col_bias=None, samp_scale=None, residual
     ep.out_scale = out_scale
     ep.p_drop = p_drop
     ep.seed = seed
+    ep.seed_ptr = iter_seed().data_ptr() if p_drop > 0 else None
     ep.accumulate = 1 if accumulate else 0
     return ep
 

@@ -21,7 +21,8 @@ class _AddLnFn(torch.autograd.Function):
         seed = core.next_seed() if (p_drop > 0 and r2 is not None) else 0
         core.check(core.lib().ldetr_layernorm_fwd_f32(
             core.ptr(x2), core.ptr(r2), core.ptr(g), core.ptr(b), core.ptr(y), core.ptr(z) if r2 is not None else None,
-            core.ptr(mean), core.ptr(rstd), rows, D, eps, p_drop if r2 is not None else 0.0, seed, core.stream()),
+            core.ptr(mean), core.ptr(rstd), rows, D, eps, p_drop if r2 is not None else 0.0, seed,
+            core.seed_ptr() if seed else None, core.stream()),
             'layernorm_fwd')
         ctx.save_for_backward(z, mean, rstd, g)
         ctx.cfg = (x.shape, r is not None, p_drop if r2 is not None else 0.0, seed, D)
@@ -44,7 +45,7 @@ class _AddLnFn(torch.autograd.Function):
         core.check(core.lib().ldetr_layernorm_bwd_f32(
             core.ptr(dy2), core.ptr(z), core.ptr(mean), core.ptr(rstd), core.ptr(g), core.ptr(dx),
             core.ptr(dr) if (need_r and p_drop > 0) else None, core.ptr(dgamma), core.ptr(dbeta), rows, D, p_drop, seed,
-            core.stream()), 'layernorm_bwd')
+            core.seed_ptr() if p_drop > 0 else None, core.stream()), 'layernorm_bwd')
         return (dx.reshape(xshape) if need_x else None, dr.reshape(xshape) if need_r else None, dgamma, dbeta, None, None)
 
 

@@ -9,6 +9,38 @@ import torch.nn.functional as F
 from ..metrics.metric_layoutnet import compute_alignment, compute_overlap, generalized_iou_loss
 
 
+def _masked_mse(a, b, valid):
+    """F.mse_loss(a[valid], b[valid]) without the gather: a, b [B,N,D], valid [B,N] bool."""
+    vf = valid.to(a.dtype)
+    return ((a - b).square().sum(-1) * vf).sum() / (vf.sum().clamp_min(1.0) * a.shape[-1])
+
+
+def _masked_ce(logits, target, valid):
+    """F.cross_entropy(logits[valid], target[valid]) without the gather: logits [B,N,L]."""
+    vf = valid.to(logits.dtype).flatten()
+    ce = F.cross_entropy(logits.flatten(0, 1), target.flatten(), reduction='none')
+    return (ce * vf).sum() / vf.sum().clamp_min(1.0)
+
+
+def _masked_giou(a, b, valid):
+    """generalized_iou_loss(a[valid], b[valid]) without the gather (padded slots are replaced by a unit box first)."""
+    unit = a.new_full((4,), 0.5)
+    unit[2:] = 1.0                      # [0.5, 0.5, 1, 1] built on device (no host copy: stays hipGraph-capturable)
+    v3 = valid.unsqueeze(-1)
+    a2 = torch.where(v3, a, unit).flatten(0, 1)
+    b2 = torch.where(v3, b, unit).flatten(0, 1)
+    l1, t1, r1, b1 = a2[:, 0] - a2[:, 2] / 2, a2[:, 1] - a2[:, 3] / 2, a2[:, 0] + a2[:, 2] / 2, a2[:, 1] + a2[:, 3] / 2
+    l2, t2, r2, bb2 = b2[:, 0] - b2[:, 2] / 2, b2[:, 1] - b2[:, 3] / 2, b2[:, 0] + b2[:, 2] / 2, b2[:, 1] + b2[:, 3] / 2
+    a_1, a_2 = (r1 - l1) * (b1 - t1), (r2 - l2) * (bb2 - t2)
+    lm, rm, tm, bm = torch.maximum(l1, l2), torch.minimum(r1, r2), torch.maximum(t1, t2), torch.minimum(b1, bb2)
+    ai = torch.where((lm < rm) & (tm < bm), (rm - lm) * (bm - tm), torch.zeros_like(a_1))
+    au = a_1 + a_2 - ai
+    ah = (torch.maximum(r1, r2) - torch.minimum(l1, l2)) * (torch.maximum(b1, bb2) - torch.minimum(t1, t2))
+    per = 1.0 - (ai / au - (ah - au) / ah)
+    vf = valid.to(a.dtype).flatten()
+    return (per * vf).sum() / vf.sum().clamp_min(1.0)
+
+
 class Loss:
     def accumulate_gradients(self, phase, bbox_real, bbox_class, bbox_text, bbox_patch, padding_mask, background, real_c, gen_z, gen_c, gain, cur_nimg):
         raise NotImplementedError()
@@ -51,17 +83,18 @@ class StyleGAN2Loss(Loss):
     def g_main_loss(self, bbox_real, bbox_class, bbox_text, bbox_patch, padding_mask, background, gen_z, gen_c):
         w = self.w
         valid = ~padding_mask
+        static = bool(getattr(self.G, 'static_shapes', False))
         bbox_fake, loss_z, cls_logits, loss_lm, loss_text_len = self.run_G(gen_z, bbox_class, bbox_real, bbox_text, bbox_patch, padding_mask, background, gen_c, reconst=True)
         gen_logits, gen_logits_uncond = self.run_D(bbox_fake, bbox_class, bbox_text, bbox_patch, padding_mask, background, gen_c)
         terms = dict(
             loss_Ggen=F.softplus(-gen_logits),
             loss_Ggen_uncond=F.softplus(-gen_logits_uncond),
-            loss_Ggen_bbox_rec=F.mse_loss(bbox_fake[valid], bbox_real[valid]) * w['Ggen_bbox_rec'],
-            loss_Ggen_bbox_gIoU=generalized_iou_loss(bbox_fake[valid], bbox_real[valid]) * w['Ggen_bbox_gIoU'],
+            loss_Ggen_bbox_rec=(_masked_mse(bbox_fake, bbox_real, valid) if static else F.mse_loss(bbox_fake[valid], bbox_real[valid])) * w['Ggen_bbox_rec'],
+            loss_Ggen_bbox_gIoU=(_masked_giou(bbox_fake, bbox_real, valid) if static else generalized_iou_loss(bbox_fake[valid], bbox_real[valid])) * w['Ggen_bbox_gIoU'],
             loss_Ggen_overlapping=compute_overlap(bbox_fake, valid) * w['Ggen_overlapping'],
             loss_Ggen_alignment=compute_alignment(bbox_fake, valid) * w['Ggen_alignment'],
             loss_Ggen_z_rec=loss_z * w['Ggen_z_rec'],
-            loss_Ggen_bbox_cls=F.cross_entropy(cls_logits, bbox_class[valid]) * w['Ggen_bbox_cls'],
+            loss_Ggen_bbox_cls=(_masked_ce(cls_logits, bbox_class, valid) if static else F.cross_entropy(cls_logits, bbox_class[valid])) * w['Ggen_bbox_cls'],
             loss_Ggen_text_rec=loss_lm * w['Ggen_text_rec'],
             loss_Ggen_text_len_rec=loss_text_len * w['Ggen_text_len_rec'],
         )
@@ -84,19 +117,20 @@ class StyleGAN2Loss(Loss):
     def d_real_loss(self, bbox_real, bbox_class, bbox_text, bbox_patch, padding_mask, background, real_c):
         w = self.w
         valid = ~padding_mask
+        static = bool(getattr(self.D, 'static_shapes', False))
         bbox_real_tmp = bbox_real.detach()
         (real_logits, real_logits_uncond, bbox_rec, cls_logits, loss_lm, loss_text_len, bg_rec, bbox_rec_uncond,
          cls_logits_uncond) = self.run_D(bbox_real_tmp, bbox_class, bbox_text, bbox_patch, padding_mask, background, real_c, reconst=True)
         terms = dict(
             loss_Dreal=F.softplus(-real_logits),
             loss_Dreal_uncond=F.softplus(-real_logits_uncond),
-            loss_Dreal_bbox_rec=F.mse_loss(bbox_rec, bbox_real_tmp[valid]) * w['Dreal_bbox_rec'],
-            loss_Dreal_bbox_cls=F.cross_entropy(cls_logits, bbox_class[valid]) * w['Dreal_bbox_cls'],
+            loss_Dreal_bbox_rec=(_masked_mse(bbox_rec, bbox_real_tmp, valid) if static else F.mse_loss(bbox_rec, bbox_real_tmp[valid])) * w['Dreal_bbox_rec'],
+            loss_Dreal_bbox_cls=(_masked_ce(cls_logits, bbox_class, valid) if static else F.cross_entropy(cls_logits, bbox_class[valid])) * w['Dreal_bbox_cls'],
             loss_Dreal_text_rec=loss_lm * w['Dreal_text_rec'],
             loss_Dreal_text_len_rec=loss_text_len * w['Dreal_text_len_rec'],
             loss_Dreal_bg_rec=F.mse_loss(bg_rec, background) * w['Dreal_im_rec'],
-            loss_Dreal_bbox_rec_uncond=F.mse_loss(bbox_rec_uncond, bbox_real_tmp[valid]) * w['Dreal_bbox_rec'],
-            loss_Dreal_bbox_cls_uncond=F.cross_entropy(cls_logits_uncond, bbox_class[valid]) * w['Dreal_bbox_cls'],
+            loss_Dreal_bbox_rec_uncond=(_masked_mse(bbox_rec_uncond, bbox_real_tmp, valid) if static else F.mse_loss(bbox_rec_uncond, bbox_real_tmp[valid])) * w['Dreal_bbox_rec'],
+            loss_Dreal_bbox_cls_uncond=(_masked_ce(cls_logits_uncond, bbox_class, valid) if static else F.cross_entropy(cls_logits_uncond, bbox_class[valid])) * w['Dreal_bbox_cls'],
         )
         self.report('Loss/scores/real', real_logits)
         for k, v in terms.items():

@@ -10,6 +10,12 @@ Text path (SURVEY §8a rows a16/a17 are *boundary inputs*, not kernel rows): `bb
   * a list of B lists of N strings as in the reference — requires `text_mode='bert'`, which is the
     round-2 row 8f-1 and raises NotImplementedError for now.
 In features mode the LM-decoder reconstruction loss (`loss_lm`) is returned as a zero tensor.
+
+`module.static_shapes = True` (opt-in, used by bench.py) switches the reconstruction heads from the reference's
+boolean gathers `x[~padding_mask]` (dynamic shape M -> device-to-host sync, SURVEY §7 "launch-bound regime") to
+full-slot tensors `[B, N, ...]` whose padded slots are masked out inside the losses: identical values up to summation
+order, no host synchronisation, so a whole phase can be captured into a hipGraph.  The default (False) keeps the
+reference's return shapes exactly.
 """
 import numpy as np
 import torch
@@ -127,6 +133,7 @@ class Generator(nn.Module):
         self.c_dim = c_dim
         self.max_text_length = max_text_length
         self.text_mode = text_mode
+        self.static_shapes = False   # see module docstring: True = sync-free full-slot outputs (hipGraph-capturable)
         if text_mode != 'features':
             raise NotImplementedError("text_mode='bert' is the next hot-path row (SURVEY §8f-1)")
 
@@ -167,6 +174,15 @@ class Generator(nn.Module):
             return bbox_fake
 
         valid = ~padding_mask
+        if self.static_shapes:
+            vf = valid.to(torch.float32)
+            cnt = vf.sum().clamp_min(1.0)
+            z_rec = self.fc_z_rec(x)
+            loss_z = ((z_rec - z0.unsqueeze(1)).square().sum(-1) * vf).sum() / (cnt * z_rec.shape[-1])
+            logit_cls = self.fc_out_cls(x)                                   # [B, N, L]: every slot, masked by the caller
+            ce = F.cross_entropy(self.fc_text_len_rec(x).flatten(0, 1), text_len.flatten(), reduction='none')
+            loss_text_len = (ce * vf.flatten()).sum() / cnt
+            return bbox_fake, loss_z, logit_cls, _zero_like_loss(loss_z), loss_text_len
         xv = x[valid]
         z_rec = self.fc_z_rec(xv)
         loss_z = F.mse_loss(z_rec, z0.unsqueeze(1).expand(-1, N, -1)[valid])
@@ -187,6 +203,7 @@ class Discriminator(nn.Module):
         self.c_dim = c_dim
         self.max_text_length = max_text_length
         self.text_mode = text_mode
+        self.static_shapes = False
         if text_mode != 'features':
             raise NotImplementedError("text_mode='bert' is the next hot-path row (SURVEY §8f-1)")
 
@@ -261,11 +278,17 @@ class Discriminator(nn.Module):
         t = self.pos_token[:N].expand(-1, B, -1)
         x = self.dec_fc_in(torch.cat([x, t], dim=-1), relu=True)
         x = encode_seq_first(self.dec_transformer, x, padding_mask)
-        x = x.permute(1, 0, 2)[valid]
+        static = self.static_shapes
+        x = x.permute(1, 0, 2) if static else x.permute(1, 0, 2)[valid]
         bbox_pred = self.bbox_embed(x).sigmoid()
         logit_cls = self.fc_out_cls(x)
         text_len_rec = self.fc_text_len_rec(x)
-        loss_text_len = F.cross_entropy(text_len_rec, text_len[valid])
+        if static:
+            vf = valid.to(torch.float32)
+            ce = F.cross_entropy(text_len_rec.flatten(0, 1), text_len.flatten(), reduction='none')
+            loss_text_len = (ce * vf.flatten()).sum() / vf.sum().clamp_min(1.0)
+        else:
+            loss_text_len = F.cross_entropy(text_len_rec, text_len[valid])
         loss_lm = _zero_like_loss(loss_text_len)
         bg_rec = self.bg_decoder(x0)
 
@@ -273,7 +296,7 @@ class Discriminator(nn.Module):
         t_uncond = self.pos_token_uncond[:N].expand(-1, B, -1)
         x_uncond = self.dec_fc_in_uncond(torch.cat([x_uncond, t_uncond], dim=-1), relu=True)
         x_uncond = encode_seq_first(self.dec_transformer_uncond, x_uncond, padding_mask)
-        x_uncond = x_uncond.permute(1, 0, 2)[valid]
+        x_uncond = x_uncond.permute(1, 0, 2) if static else x_uncond.permute(1, 0, 2)[valid]
         bbox_pred_uncond = self.bbox_embed_uncond(x_uncond).sigmoid()
         logit_cls_uncond = self.fc_out_cls_uncond(x_uncond)
         return (logit_disc, logit_disc_uncond, bbox_pred, logit_cls, loss_lm, loss_text_len, bg_rec, bbox_pred_uncond, logit_cls_uncond)

@@ -138,6 +138,7 @@ class EmaTracker(object):
         for p in G_ema.parameters():
             p.grad = None
         self.fm.gflat = None
+        self._buf_versions = {}
 
     def update(self, batch_size, ema_kimg, cur_nimg, ema_rampup=0.05):
         ema_nimg = ema_kimg * 1000
@@ -145,8 +146,11 @@ class EmaTracker(object):
             ema_nimg = min(ema_nimg, cur_nimg * ema_rampup)
         beta = 0.5 ** (batch_size / max(ema_nimg, 1e-8))
         core.check(core.lib().ldetr_ema_lerp_f32(core.ptr(self.fm.flat), core.ptr(self.src.flat), self.src.total, float(beta), core.stream()), 'ema_lerp')
-        for b_ema, b in zip(self.G_ema.buffers(), self.G.buffers()):
-            b_ema.copy_(b)
+        for i, (b_ema, b) in enumerate(zip(self.G_ema.buffers(), self.G.buffers())):
+            ver = (b._version, b.data_ptr())
+            if self._buf_versions.get(i) != ver:      # buffers are frozen statistics: copy only when they changed
+                b_ema.copy_(b)
+                self._buf_versions[i] = ver
 
 
 def broadcast_module(module, src=0):
@@ -163,6 +167,7 @@ def training_iteration(loss, phases, dp, batch, batch_gpu, gen_z_per_phase, ema=
            background [b,3,R,R], real_c, gen_c.  gen_z_per_phase: list of [b,9,z_dim] tensors, one per phase.
     """
     b = batch['bbox_real'].shape[0]
+    core.reseed(batch['bbox_real'].device)   # fresh device-side dropout seed word for this iteration
     for phase, gen_z in zip(phases, gen_z_per_phase):
         phase.fm.zero_grad()
         phase.module.requires_grad_(True)
@@ -177,3 +182,51 @@ def training_iteration(loss, phases, dp, batch, batch_gpu, gen_z_per_phase, ema=
         dp.apply(phase)
     if ema is not None:
         ema.update(batch_size, ema_kimg, cur_nimg)
+
+
+class GraphedIteration(object):
+    """The same iteration with each phase's forward+backward captured once into a hipGraph and replayed.
+
+    A G+D iteration is ~10^4 kernel launches; at 2 samples per GPU (the reference's recommended --gpus=8 --batch=16) the
+    eager step is bound by host launch cost, not by the GPU (SURVEY §7 "launch-bound regime").  Requirements, all met by
+    the modules here: static shapes (`module.static_shapes = True`: no boolean gathers), no host synchronisation,
+    device-side dropout seed word (hip.core.reseed), static input buffers (`self.batch`; copy new data into them).
+    The gradient exchange, Adam and EMA stay outside the graphs (RCCL collectives and host-side step counters).
+    """
+
+    def __init__(self, loss, phases, dp, batch, batch_gpu, z_dim, ema=None, batch_size=None, ema_kimg=None):
+        self.loss, self.phases, self.dp, self.batch, self.batch_gpu = loss, phases, dp, batch, batch_gpu
+        self.ema, self.batch_size, self.ema_kimg = ema, batch_size, ema_kimg
+        self.cur_nimg = 0
+        self.graphs = []
+        dev = batch['bbox_real'].device
+        b = batch['bbox_real'].shape[0]
+        for phase in phases:
+            for m in (loss.G, loss.D):
+                if not getattr(m, 'static_shapes', False):
+                    raise RuntimeError('GraphedIteration needs module.static_shapes = True on G and D')
+            phase.fm.zero_grad()
+            phase.module.requires_grad_(True)
+            phase.module.text_encoder.requires_grad_(False)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                core.reseed(dev)
+                phase.fm.gflat.zero_()
+                gen_z = torch.randn(b, batch['bbox_class'].shape[1], z_dim, device=dev)
+                for s in range(0, b, batch_gpu):
+                    sl = slice(s, s + batch_gpu)
+                    loss.accumulate_gradients(phase=phase.name, bbox_real=batch['bbox_real'][sl], bbox_class=batch['bbox_class'][sl],
+                                              bbox_text=batch['bbox_text'][sl], bbox_patch=batch['bbox_patch'][sl],
+                                              padding_mask=batch['padding_mask'][sl], background=batch['background'][sl],
+                                              real_c=batch['real_c'][sl], gen_z=gen_z[sl], gen_c=batch['gen_c'][sl], gain=1, cur_nimg=0)
+            phase.module.requires_grad_(False)
+            self.graphs.append(g)
+
+    def run(self):
+        for phase, g in zip(self.phases, self.graphs):
+            g.replay()
+            self.dp.apply(phase)
+        if self.ema is not None:
+            self.ema.update(self.batch_size, self.ema_kimg, self.cur_nimg)
+        if self.batch_size:
+            self.cur_nimg += self.batch_size
