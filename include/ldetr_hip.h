@@ -97,9 +97,10 @@ int ldetr_conv2d_fwd_f32(const float* x, const ldetr_tensor4* xt, const float* w
 int ldetr_conv2d_bwd_data_f32(const float* dy, const ldetr_tensor4* dyt, const float* w, int Cin, int KH, int KW,
                               int stride, int pad, float* dx, int64_t lddx, int IH, int IW, const float* dy_scale,
                               int64_t dy_scale_ld, const ldetr_epilogue* ep, void* stream);
+/* accumulate != 0: dw += gradient (fp32 atomics onto the existing buffer, e.g. a view of the flat .grad buffer) instead of dw = gradient. */
 int ldetr_conv2d_bwd_weight_f32(const float* x, const ldetr_tensor4* xt, const float* dy, const ldetr_tensor4* dyt,
                                 float* dw, int KH, int KW, int stride, int pad, int splitk, const float* x_scale,
-                                int64_t x_scale_ld, const float* dy_scale, int64_t dy_scale_ld, void* stream);
+                                int64_t x_scale_ld, const float* dy_scale, int64_t dy_scale_ld, int accumulate, void* stream);
 
 int ldetr_conv_transpose2d_fwd_f32(const float* x, const ldetr_tensor4* xt, const float* w, int Cout, int KH, int KW,
                                    int stride, int pad, float* y, int64_t ldy, int OH, int OW, const float* in_scale,
@@ -111,7 +112,7 @@ int ldetr_conv_transpose2d_bwd_data_f32(const float* dy, const ldetr_tensor4* dy
 int ldetr_conv_transpose2d_bwd_weight_f32(const float* x, const ldetr_tensor4* xt, const float* dy,
                                           const ldetr_tensor4* dyt, float* dw, int KH, int KW, int stride, int pad,
                                           int splitk, const float* x_scale, int64_t x_scale_ld, const float* dy_scale,
-                                          int64_t dy_scale_ld, void* stream);
+                                          int64_t dy_scale_ld, int accumulate, void* stream);
 
 int ldetr_attention_fwd_f32(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v, int64_t ldv,
                             const unsigned char* key_padding_mask, float* out, int64_t ldo, float* lse, int B, int H,

@@ -40,10 +40,10 @@ SIGNATURES = {
     'ldetr_gemm_f32': [_P, _L, _I, _P, _L, _I, _P, _L, _I, _I, _I, _I, _EP, _I, _P],
     'ldetr_conv2d_fwd_f32': [_P, _T4, _P, _I, _I, _I, _I, _I, _P, _L, _I, _I, _P, _L, _EP, _P],
     'ldetr_conv2d_bwd_data_f32': [_P, _T4, _P, _I, _I, _I, _I, _I, _P, _L, _I, _I, _P, _L, _EP, _P],
-    'ldetr_conv2d_bwd_weight_f32': [_P, _T4, _P, _T4, _P, _I, _I, _I, _I, _I, _P, _L, _P, _L, _P],
+    'ldetr_conv2d_bwd_weight_f32': [_P, _T4, _P, _T4, _P, _I, _I, _I, _I, _I, _P, _L, _P, _L, _I, _P],
     'ldetr_conv_transpose2d_fwd_f32': [_P, _T4, _P, _I, _I, _I, _I, _I, _P, _L, _I, _I, _P, _L, _EP, _P],
     'ldetr_conv_transpose2d_bwd_data_f32': [_P, _T4, _P, _I, _I, _I, _I, _I, _P, _L, _I, _I, _P, _L, _EP, _P],
-    'ldetr_conv_transpose2d_bwd_weight_f32': [_P, _T4, _P, _T4, _P, _I, _I, _I, _I, _I, _P, _L, _P, _L, _P],
+    'ldetr_conv_transpose2d_bwd_weight_f32': [_P, _T4, _P, _T4, _P, _I, _I, _I, _I, _I, _P, _L, _P, _L, _I, _P],
     'ldetr_attention_fwd_f32': [_P, _L, _P, _L, _P, _L, _P, _P, _L, _P, _I, _I, _I, _I, _I, _F, _F, c_uint64, _P, _P],
     'ldetr_attention_bwd_f32': [_P, _L, _P, _L, _P, _L, _P, _P, _L, _P, _P, _L, _P, _L, _P, _L, _P, _L,
                                 _I, _I, _I, _I, _I, _F, _F, c_uint64, _P, _P],
@@ -82,7 +82,7 @@ def load():
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported
         fn.restype = c_int
         fn.argtypes = argtypes
-    if lib.ldetr_abi_version() != 2:
+    if lib.ldetr_abi_version() != 3:
         raise RuntimeError('libldetr_hip.so ABI version mismatch; rebuild it')
     _lib = lib
     return lib

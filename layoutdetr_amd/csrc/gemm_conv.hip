@@ -680,7 +680,7 @@ extern "C" int ldetr_conv2d_bwd_data_f32(const float* dy, const ldetr_tensor4* d
 extern "C" int ldetr_conv2d_bwd_weight_f32(const float* x, const ldetr_tensor4* xt, const float* dy, const ldetr_tensor4* dyt,
                                            float* dw, int KH, int KW, int stride, int pad, int splitk,
                                            const float* x_scale, int64_t x_scale_ld,
-                                           const float* dy_scale, int64_t dy_scale_ld, void* stream) {
+                                           const float* dy_scale, int64_t dy_scale_ld, int accumulate, void* stream) {
     LDETR_CHECK(x && dy && dw && xt && dyt, "conv2d_bwd_weight: null pointer");
     LDETR_CHECK(dyt->sc == 1, "conv2d_bwd_weight: dy must be NHWC");
     int Cin = xt->C, Cout = dyt->C, OH = dyt->H, OW = dyt->W;
@@ -691,7 +691,8 @@ extern "C" int ldetr_conv2d_bwd_weight_f32(const float* x, const ldetr_tensor4* 
     fill_epilogue(p.ep, nullptr);
     p.splitk = splitk; p.pstep = 1; p.nsamp = xt->N; p.pix_per_sample = 0;
     long wsz = (long)Cout * KH * KW * Cin;
-    if (hipMemsetAsync(dw, 0, wsz * sizeof(float), st) != hipSuccess) { set_error("conv2d_bwd_weight: memset failed"); return LDETR_ERR_LAUNCH; }
+    if (!accumulate && hipMemsetAsync(dw, 0, wsz * sizeof(float), st) != hipSuccess) { set_error("conv2d_bwd_weight: memset failed"); return LDETR_ERR_LAUNCH; }
+    if (splitk == 1 && accumulate) p.ep.accumulate = 1;
     int Kpix = dyt->N * OH * OW;
     if (xt->sc != 1 || Cin % 4 != 0) {
         // 3-channel (or strided-channel) input, e.g. the ResNet stem on an NCHW image: a single GEMM with
@@ -774,7 +775,7 @@ extern "C" int ldetr_conv_transpose2d_bwd_data_f32(const float* dy, const ldetr_
 extern "C" int ldetr_conv_transpose2d_bwd_weight_f32(const float* x, const ldetr_tensor4* xt, const float* dy, const ldetr_tensor4* dyt,
                                                      float* dw, int KH, int KW, int stride, int pad, int splitk,
                                                      const float* x_scale, int64_t x_scale_ld,
-                                                     const float* dy_scale, int64_t dy_scale_ld, void* stream) {
+                                                     const float* dy_scale, int64_t dy_scale_ld, int accumulate, void* stream) {
     LDETR_CHECK(x && dy && dw && xt && dyt, "conv_transpose2d_bwd_weight: null pointer");
     LDETR_CHECK(dyt->sc == 1 && xt->sc == 1 && xt->C % 4 == 0 && dyt->C % 4 == 0, "conv_transpose2d_bwd_weight: NHWC, C % 4 == 0 required");
     int Cin = xt->C, Cout = dyt->C;
@@ -785,7 +786,8 @@ extern "C" int ldetr_conv_transpose2d_bwd_weight_f32(const float* x, const ldetr
     fill_epilogue(p.ep, nullptr);
     p.splitk = splitk; p.pstep = 1; p.nsamp = xt->N; p.pix_per_sample = 0;
     long wsz = (long)Cout * KH * KW * Cin;
-    if (hipMemsetAsync(dw, 0, wsz * sizeof(float), st) != hipSuccess) { set_error("conv_transpose2d_bwd_weight: memset failed"); return LDETR_ERR_LAUNCH; }
+    if (!accumulate && hipMemsetAsync(dw, 0, wsz * sizeof(float), st) != hipSuccess) { set_error("conv_transpose2d_bwd_weight: memset failed"); return LDETR_ERR_LAUNCH; }
+    if (splitk == 1 && accumulate) p.ep.accumulate = 1;
     // k enumerates *input* pixels (n, ih, iw); A = dy gathered at (ih*s + kh - p, iw*s + kw - p), B = x dense.
     set_conv_src(p.A, dy, dyt);
     p.A.DH = xt->H; p.A.DW = xt->W; p.A.stride = stride; p.A.pad = pad; p.A.KH = KH; p.A.KW = KW; p.A.tapped = 1;

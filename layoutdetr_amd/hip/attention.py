@@ -71,12 +71,12 @@ def mha_forward(query, key, value, in_proj_weight, in_proj_bias, out_w, out_b, n
         qkv = linear(query, W, bvec)
         q, k, v = qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:]
     elif same_qk:
-        qk = linear(query, W[:2 * d], bvec[:2 * d])
+        qk = linear(query, W, bvec, rows=(0, 2 * d))
         q, k = qk[:, :d], qk[:, d:]
-        v = linear(value, W[2 * d:], bvec[2 * d:])
+        v = linear(value, W, bvec, rows=(2 * d, 3 * d))
     else:
-        q = linear(query, W[:d], bvec[:d])
-        k = linear(key, W[d:2 * d], bvec[d:2 * d])
-        v = linear(value, W[2 * d:], bvec[2 * d:])
+        q = linear(query, W, bvec, rows=(0, d))
+        k = linear(key, W, bvec, rows=(d, 2 * d))
+        v = linear(value, W, bvec, rows=(2 * d, 3 * d))
     o = attention(q, k, v, key_padding_mask, B, nhead, Lq, Lk, p_drop)
     return linear(o, out_w, out_b)

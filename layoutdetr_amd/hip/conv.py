@@ -50,6 +50,7 @@ class _ConvFn(torch.autograd.Function):
             ctypes.byref(ep), core.stream()), 'conv2d_fwd'))
         ctx.save_for_backward(x, w, sc, y if relu else None)
         ctx.cfg = (stride, pad, relu, x_is_nchw, residual is not None, shift is not None, (N, H, W, I))
+        ctx.params = (weight, shift)
         return y
 
     @staticmethod
@@ -63,11 +64,18 @@ class _ConvFn(torch.autograd.Function):
         need_shift = has_shift and ctx.needs_input_grad[3]
         need_res = has_res and ctx.needs_input_grad[4]
         dy2 = dy.reshape(-1, O)
+        wparam, sparam = ctx.params
+        gs = core.flat_grad(sparam) if (need_shift and O % 4 == 0) else None
         if relu:
-            dpre2, dshift, _ = act_backward(dy2, y.reshape(-1, O), ACT_RELU, 0.0, 1.0, need_shift)
+            dpre2, dshift, _ = act_backward(dy2, y.reshape(-1, O), ACT_RELU, 0.0, 1.0, need_shift, dbias_out=gs)
         else:
             dpre2 = dy2
-            dshift = core.colsum(dpre2).reshape(-1) if need_shift else None
+            dshift = None
+            if need_shift:
+                if gs is not None:
+                    core.check(core.lib().ldetr_colsum_f32(core.ptr(dpre2), core.ptr(gs), 1, dpre2.shape[0], O, core.stream()), 'colsum')
+                else:
+                    dshift = core.colsum(dpre2).reshape(-1)
         dpre = dpre2.reshape(N, OH, OW, O)
         dyt = core.tensor4_nhwc(dpre)
         dx = dw = None
@@ -79,7 +87,12 @@ class _ConvFn(torch.autograd.Function):
                 core.ptr(dpre), ctypes.byref(dyt), core.ptr(w), I, KH, KW, stride, pad, core.ptr(dx), I, H, W,
                 core.ptr(sc), 0, None, core.stream()), 'conv2d_bwd_data'))
         if need_w:
-            dw_ohwi = torch.empty((O, KH, KW, I), device=dy.device, dtype=torch.float32)
+            gw = core.flat_grad(wparam)
+            acc = 0
+            if gw is not None and gw.permute(0, 2, 3, 1).is_contiguous():
+                dw_ohwi, acc = gw.permute(0, 2, 3, 1), 1          # accumulate into the flat .grad view (OHWI memory)
+            else:
+                dw_ohwi = torch.empty((O, KH, KW, I), device=dy.device, dtype=torch.float32)
             xt = core.tensor4_nchw(x) if x_is_nchw else core.tensor4_nhwc(x)
             Kpix = N * OH * OW
             vec = (not x_is_nchw) and I % 4 == 0
@@ -91,12 +104,12 @@ class _ConvFn(torch.autograd.Function):
                 dyt_s = core.tensor4_nhwc(dpre_s)
                 core.engine_call('ldetr_conv2d_bwd_weight_f32', 2.0 * N * OH * OW * O * KH * KW * I, lambda: core.check(core.lib().ldetr_conv2d_bwd_weight_f32(
                     core.ptr(x), ctypes.byref(xt), core.ptr(dpre_s), ctypes.byref(dyt_s), core.ptr(dw_ohwi), KH, KW,
-                    stride, pad, sk, None, 0, None, 0, core.stream()), 'conv2d_bwd_weight'))
+                    stride, pad, sk, None, 0, None, 0, acc, core.stream()), 'conv2d_bwd_weight'))
             else:
                 core.engine_call('ldetr_conv2d_bwd_weight_f32', 2.0 * N * OH * OW * O * KH * KW * I, lambda: core.check(core.lib().ldetr_conv2d_bwd_weight_f32(
                     core.ptr(x), ctypes.byref(xt), core.ptr(dpre), ctypes.byref(dyt), core.ptr(dw_ohwi), KH, KW, stride,
-                    pad, sk, None, 0, core.ptr(sc), 0, core.stream()), 'conv2d_bwd_weight'))
-            dw = _grad_to_oihw(dw_ohwi)
+                    pad, sk, None, 0, core.ptr(sc), 0, acc, core.stream()), 'conv2d_bwd_weight'))
+            dw = None if acc else _grad_to_oihw(dw_ohwi)
         dres = dpre if need_res else None
         return dx, dw, None, dshift, dres, None, None, None, None
 

@@ -174,6 +174,15 @@ def colsum(a2d, B=1):
     return red
 
 
+def flat_grad(p):
+    """`p.grad` when p is a Parameter re-homed by training_loop.FlatModule (its .grad is a persistent view of the flat
+    gradient buffer): weight-gradient kernels then accumulate straight into it (fp32 atomics / += epilogue) and the
+    autograd Function returns None for that input — no temporary, no memset, no separate `grad += dw` launch."""
+    if isinstance(p, torch.nn.Parameter) and getattr(p, '_ldetr_flat', False) and p.grad is not None and not torch.is_grad_enabled():
+        return p.grad
+    return None
+
+
 def pick_splitk(tiles, K, target=512, min_k=256):
     """Choose a split-K factor so a reduction-heavy GEMM fills the 256 CUs."""
     s = 1

@@ -26,6 +26,7 @@ class _AddLnFn(torch.autograd.Function):
             'layernorm_fwd')
         ctx.save_for_backward(z, mean, rstd, g)
         ctx.cfg = (x.shape, r is not None, p_drop if r2 is not None else 0.0, seed, D)
+        ctx.params = (gamma, beta)
         return y.reshape(x.shape)
 
     @staticmethod
@@ -40,12 +41,19 @@ class _AddLnFn(torch.autograd.Function):
         dr = None
         if need_r:
             dr = torch.empty_like(dy2) if p_drop > 0 else dx
-        dgamma = torch.zeros(D, device=dy2.device, dtype=torch.float32) if need_g else None
-        dbeta = torch.zeros(D, device=dy2.device, dtype=torch.float32) if need_g else None
+        gg, gbt = core.flat_grad(ctx.params[0]), core.flat_grad(ctx.params[1])
+        fused = need_g and gg is not None and gbt is not None
+        if fused:
+            dgamma, dbeta = gg, gbt          # the kernel's atomics accumulate straight into the flat .grad views
+        else:
+            dgamma = torch.zeros(D, device=dy2.device, dtype=torch.float32) if need_g else None
+            dbeta = torch.zeros(D, device=dy2.device, dtype=torch.float32) if need_g else None
         core.check(core.lib().ldetr_layernorm_bwd_f32(
             core.ptr(dy2), core.ptr(z), core.ptr(mean), core.ptr(rstd), core.ptr(g), core.ptr(dx),
             core.ptr(dr) if (need_r and p_drop > 0) else None, core.ptr(dgamma), core.ptr(dbeta), rows, D, p_drop, seed,
             core.seed_ptr() if p_drop > 0 else None, core.stream()), 'layernorm_bwd')
+        if fused:
+            dgamma = dbeta = None
         return (dx.reshape(xshape) if need_x else None, dr.reshape(xshape) if need_r else None, dgamma, dbeta, None, None)
 
 

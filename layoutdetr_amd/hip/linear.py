@@ -12,8 +12,9 @@ from . import core
 from .core import ACT_LRELU, ACT_NONE, ACT_RELU
 
 
-def act_backward(dy2, y2, act, act_alpha, act_gain, want_dbias, bias=None, demod=None, want_ddemod=False, B=1):
-    """dv = dy * gain * dact(y); optional fused reductions.  2-D [rows, C] tensors."""
+def act_backward(dy2, y2, act, act_alpha, act_gain, want_dbias, bias=None, demod=None, want_ddemod=False, B=1, dbias_out=None):
+    """dv = dy * gain * dact(y); optional fused reductions.  2-D [rows, C] tensors.
+    dbias_out: existing [C] buffer to accumulate the bias gradient into (returned dbias is then None)."""
     R, C = dy2.shape
     if C % 4 != 0:
         if act == ACT_NONE:
@@ -21,24 +22,31 @@ def act_backward(dy2, y2, act, act_alpha, act_gain, want_dbias, bias=None, demod
         else:
             neg = 0.0 if act == ACT_RELU else act_alpha
             dv = dy2 * torch.where(y2 > 0, act_gain, act_gain * neg)
+        if want_dbias and dbias_out is not None:
+            dbias_out += dv.sum(0)
+            return dv, None, None
         return dv, (dv.sum(0) if want_dbias else None), None
     dv = torch.empty_like(dy2)
-    dbias = torch.zeros(C, device=dy2.device, dtype=torch.float32) if want_dbias else None
+    if want_dbias and dbias_out is not None:
+        dbias = dbias_out
+    else:
+        dbias = torch.zeros(C, device=dy2.device, dtype=torch.float32) if want_dbias else None
     ddemod = torch.zeros((B, C), device=dy2.device, dtype=torch.float32) if want_ddemod else None
     core.check(core.lib().ldetr_act_bwd_reduce_f32(
         core.ptr(dy2), core.ptr(y2), core.ptr(dv), core.ptr(bias), core.ptr(demod), core.ptr(dbias), core.ptr(ddemod),
         B, R // B, C, act, act_alpha, act_gain, core.stream()), 'act_bwd_reduce')
-    return dv, dbias, ddemod
+    return dv, (None if dbias_out is not None else dbias), ddemod
 
 
 class _LinearFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, bias, act, act_alpha, act_gain, p_drop, wscale):
+    def forward(ctx, x, weight, bias, act, act_alpha, act_gain, p_drop, wscale, rows):
         core.require_gpu(x, weight, bias)
-        N, K = weight.shape
+        r0, r1 = rows if rows is not None else (0, weight.shape[0])   # row range of a packed weight (MHA in_proj)
+        N, K = r1 - r0, weight.shape[1]
         x2 = core.f32c(x.reshape(-1, K))
-        w = core.f32c(weight)
-        b = core.f32c(bias) if bias is not None else None
+        w = core.f32c(weight.detach()[r0:r1])
+        b = core.f32c(bias.detach()[r0:r1]) if bias is not None else None
         M = x2.shape[0]
         seed = core.next_seed() if p_drop > 0 else 0
         ep = core.epilogue(alpha=wscale, col_bias=b, act=act, act_alpha=act_alpha, act_gain=act_gain, p_drop=p_drop,
@@ -46,6 +54,7 @@ class _LinearFn(torch.autograd.Function):
         y = core.gemm(x2, w, 0, 0, M, N, K, ep=ep)
         ctx.save_for_backward(x2, w, y if act != ACT_NONE else None)
         ctx.cfg = (act, act_alpha, act_gain, p_drop, wscale, bias is not None, x.shape)
+        ctx.params = (weight, bias, r0, r1)
         if p_drop > 0 and act != ACT_RELU:
             raise RuntimeError('linear: fused dropout is only defined after relu (FFN hidden layer)')
         return y.reshape(*x.shape[:-1], N)
@@ -58,20 +67,41 @@ class _LinearFn(torch.autograd.Function):
         M = x2.shape[0]
         dy2 = core.f32c(dy.reshape(-1, N))
         need_x, need_w, need_b = ctx.needs_input_grad[0], ctx.needs_input_grad[1], has_bias and ctx.needs_input_grad[2]
+        wparam, bparam, r0, r1 = ctx.params
+        gw = core.flat_grad(wparam) if need_w else None
+        gb = core.flat_grad(bparam) if need_b else None
+        if gw is not None:
+            gw = gw[r0:r1]
+        if gb is not None:
+            gb = gb[r0:r1] if (N % 4 == 0 and r0 % 4 == 0) else None
         if act != ACT_NONE:
             gain = act_gain / (1.0 - p_drop) if p_drop > 0 else act_gain
-            dpre, db, _ = act_backward(dy2, y, act, act_alpha, gain, need_b)
+            dpre, db, _ = act_backward(dy2, y, act, act_alpha, gain, need_b, dbias_out=gb)
         else:
             dpre = dy2
-            db = core.colsum(dpre).reshape(-1) if need_b else None
+            db = None
+            if need_b:
+                if gb is not None:
+                    core.check(core.lib().ldetr_colsum_f32(core.ptr(dpre), core.ptr(gb), 1, M, N, core.stream()), 'colsum')
+                else:
+                    db = core.colsum(dpre).reshape(-1)
         dx = dw = None
         if need_x:
             dx = core.gemm(dpre, w, 0, 1, M, K, N, ep=core.epilogue(alpha=wscale)).reshape(xshape)
         if need_w:
-            dw = core.gemm(dpre, x2, 1, 1, N, K, M, ep=core.epilogue(alpha=wscale))
-        return dx, dw, db, None, None, None, None, None
+            if gw is not None and gw.is_contiguous():
+                core.gemm(dpre, x2, 1, 1, N, K, M, out=gw, ep=core.epilogue(alpha=wscale, accumulate=True))
+            else:
+                dw = core.gemm(dpre, x2, 1, 1, N, K, M, ep=core.epilogue(alpha=wscale))
+        full = wparam.shape[0]
+        if dw is not None and (r1 - r0) != full:      # fallback path for a packed weight without a flat .grad
+            dwf = torch.zeros((full, K), device=dw.device, dtype=torch.float32); dwf[r0:r1] = dw; dw = dwf
+        if db is not None and (r1 - r0) != full:
+            dbf = torch.zeros(full, device=db.device, dtype=torch.float32); dbf[r0:r1] = db; db = dbf
+        return dx, dw, db, None, None, None, None, None, None
 
 
-def linear(x, weight, bias=None, act=ACT_NONE, act_alpha=0.0, act_gain=1.0, p_drop=0.0, wscale=1.0):
-    """y = dropout(act((x @ (wscale*weight).T) + bias) * act_gain)."""
-    return _LinearFn.apply(x, weight, bias, act, act_alpha, act_gain, p_drop, wscale)
+def linear(x, weight, bias=None, act=ACT_NONE, act_alpha=0.0, act_gain=1.0, p_drop=0.0, wscale=1.0, rows=None):
+    """y = dropout(act((x @ (wscale*weight[rows]).T) + bias[rows]) * act_gain);  rows=(r0, r1) selects a row block of a packed
+    projection weight (nn.MultiheadAttention.in_proj_weight) without creating an autograd slice node."""
+    return _LinearFn.apply(x, weight, bias, act, act_alpha, act_gain, p_drop, wscale, rows)

@@ -46,6 +46,7 @@ class _ModConvFn(torch.autograd.Function):
                                                    OH, OW, core.ptr(s), s.stride(0), ctypes.byref(ep), core.stream()), 'modconv_fwd'))
         ctx.save_for_backward(x, w, s, d, b, y)
         ctx.cfg = (pad, act_alpha, act_gain)
+        ctx.params = (weight, bias)
         return y
 
     @staticmethod
@@ -56,8 +57,9 @@ class _ModConvFn(torch.autograd.Function):
         O, KH, KW, _ = w.shape
         _, OH, OW, _ = y.shape
         dy = core.f32c(dy)
+        wparam, bparam = ctx.params
         dv2, dbias, ddemod = act_backward(dy.reshape(-1, O), y.reshape(-1, O), ACT_LRELU, act_alpha, act_gain, True,
-                                          bias=b, demod=d, want_ddemod=True, B=B)
+                                          bias=b, demod=d, want_ddemod=True, B=B, dbias_out=core.flat_grad(bparam))
         dv = dv2.reshape(B, OH, OW, O)
         dvt = core.tensor4_nhwc(dv)
         dx = dw = ds = None
@@ -68,14 +70,19 @@ class _ModConvFn(torch.autograd.Function):
                        'modconv_bwd_data'))
             dx, ds = _mul_reduce(dxs, x, s, B, H * W, I)
         if ctx.needs_input_grad[1]:
-            dw_ohwi = torch.empty((O, KH, KW, I), device=dy.device, dtype=torch.float32)
+            gw = core.flat_grad(wparam)
+            acc = 0
+            if gw is not None and gw.permute(0, 2, 3, 1).is_contiguous():
+                dw_ohwi, acc = gw.permute(0, 2, 3, 1), 1
+            else:
+                dw_ohwi = torch.empty((O, KH, KW, I), device=dy.device, dtype=torch.float32)
             xt = core.tensor4_nhwc(x)
             tiles = KH * KW * ((O + 63) // 64) * ((I + 63) // 64)
             sk = core.pick_splitk(tiles, B * OH * OW, target=512, min_k=512)
             core.engine_call('ldetr_conv2d_bwd_weight_f32', 2.0 * B * OH * OW * O * KH * KW * I, lambda: core.check(core.lib().ldetr_conv2d_bwd_weight_f32(core.ptr(x), ctypes.byref(xt), core.ptr(dv), ctypes.byref(dvt),
                                                               core.ptr(dw_ohwi), KH, KW, 1, pad, sk, core.ptr(s), s.stride(0),
-                                                              core.ptr(d), d.stride(0), core.stream()), 'modconv_bwd_weight'))
-            dw = _grad_to_oihw(dw_ohwi)
+                                                              core.ptr(d), d.stride(0), acc, core.stream()), 'modconv_bwd_weight'))
+            dw = None if acc else _grad_to_oihw(dw_ohwi)
         return dx, dw, ds, ddemod, dbias, None, None, None
 
 
@@ -100,6 +107,7 @@ class _ModConvUpFn(torch.autograd.Function):
                              act=(act_alpha, act_gain)).permute(0, 2, 3, 1)
         ctx.save_for_backward(x, w, s, d, b, f, ud, y)
         ctx.cfg = (act_alpha, act_gain)
+        ctx.params = (weight, bias)
         return y
 
     @staticmethod
@@ -110,7 +118,9 @@ class _ModConvUpFn(torch.autograd.Function):
         O, KH, KW, _ = w.shape
         _, UH, UW, _ = ud.shape
         dy = core.f32c(dy)
-        dv2, dbias, _ = act_backward(dy.reshape(-1, O), y.reshape(-1, O), ACT_LRELU, act_alpha, act_gain, True)
+        wparam, bparam = ctx.params
+        dv2, dbias, _ = act_backward(dy.reshape(-1, O), y.reshape(-1, O), ACT_LRELU, act_alpha, act_gain, True,
+                                     dbias_out=core.flat_grad(bparam))
         dv = dv2.reshape(y.shape)
         # adjoint of the FIR (upfirdn2d.py:252-270): flipped taps, pad [fw-px0-1, iw-ow+px0, ...] = [2,2,2,2]
         dud = _up._kernel_call(dv.permute(0, 3, 1, 2), f, 1, 1, 1, 1, 2, 2, 2, 2, True, 4.0).permute(0, 2, 3, 1)
@@ -125,14 +135,19 @@ class _ModConvUpFn(torch.autograd.Function):
                                                                       core.stream()), 'modconv_up_bwd_data'))
             dx, ds = _mul_reduce(dxs, x, s, B, H * W, I)
         if ctx.needs_input_grad[1]:
-            dw_ohwi = torch.empty((O, KH, KW, I), device=dy.device, dtype=torch.float32)
+            gw = core.flat_grad(wparam)
+            acc = 0
+            if gw is not None and gw.permute(0, 2, 3, 1).is_contiguous():
+                dw_ohwi, acc = gw.permute(0, 2, 3, 1), 1
+            else:
+                dw_ohwi = torch.empty((O, KH, KW, I), device=dy.device, dtype=torch.float32)
             xt = core.tensor4_nhwc(x)
             tiles = KH * KW * ((O + 63) // 64) * ((I + 63) // 64)
             sk = core.pick_splitk(tiles, B * H * W, target=512, min_k=512)
             core.engine_call('ldetr_conv_transpose2d_bwd_weight_f32', 2.0 * B * H * W * O * KH * KW * I, lambda: core.check(core.lib().ldetr_conv_transpose2d_bwd_weight_f32(core.ptr(x), ctypes.byref(xt), core.ptr(dud), ctypes.byref(dudt),
                                                                         core.ptr(dw_ohwi), KH, KW, 2, 0, sk, core.ptr(s), s.stride(0),
-                                                                        core.ptr(d), d.stride(0), core.stream()), 'modconv_up_bwd_weight'))
-            dw = _grad_to_oihw(dw_ohwi)
+                                                                        core.ptr(d), d.stride(0), acc, core.stream()), 'modconv_up_bwd_weight'))
+            dw = None if acc else _grad_to_oihw(dw_ohwi)
         return dx, dw, ds, ddemod, dbias, None, None, None
 
 

@@ -58,6 +58,7 @@ class FlatModule(object):
                 view.copy_(p.data)
                 p.data = view
                 p.grad = _phys_view(self.gflat[off:off + p.numel()], p.data)
+                p._ldetr_flat = True   # lets the weight-gradient kernels accumulate in place (hip.core.flat_grad)
 
     def zero_grad(self):
         self.gflat.zero_()
@@ -137,6 +138,7 @@ class EmaTracker(object):
         assert self.fm.total == self.src.total
         for p in G_ema.parameters():
             p.grad = None
+            p._ldetr_flat = False
         self.fm.gflat = None
         self._buf_versions = {}
 
