@@ -334,7 +334,7 @@ __device__ __forceinline__ float apply_epilogue(const GemmEpilogue& ep, float v,
     return v * ep.out_scale;
 }
 
-template <int BM, int BN, int BKT, int AMODE, int BMODE>
+template <int BM, int BN, int BKT, int AMODE, int BMODE, int NST>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
     constexpr bool A_KC = AMODE <= OP_KC_WTAP;
     constexpr bool B_KC = BMODE <= OP_KC_WTAP;
@@ -390,9 +390,11 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
 #pragma unroll
             for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
 
-    float4 ra[NUA], rb[NUB];
+    // Two register staging sets (NST == 2, the 64x64 tile): global loads run TWO k-tiles ahead of the MFMAs (PMC on the one-ahead version: waves
+    // spent 33% of their cycles parked on s_waitcnt/barriers with only 2 blocks resident per CU — exposed HBM/L2 latency).
+    float4 ra0[NUA], rb0[NUB], ra1[NUA], rb1[NUB];
     // loads the k-tile starting at k0 and advances the decode state to the following tile
-    auto gload = [&](int k0) {
+    auto gload = [&](int k0, float4 (&ra)[NUA], float4 (&rb)[NUB]) {
 #pragma unroll
         for (int i = 0; i < NUA; i++) {
             if constexpr (A_KC) {
@@ -416,7 +418,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
             }
         }
     };
-    auto lstore = [&](int buf) {
+    auto lstore = [&](int buf, const float4 (&ra)[NUA], const float4 (&rb)[NUB]) {
 #pragma unroll
         for (int i = 0; i < NUA; i++) {
             if constexpr (A_KC) {
@@ -440,15 +442,8 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
     };
 
     const int nk = (z.kend > z.kbeg) ? (z.kend - z.kbeg + BKT - 1) / BKT : 0;
-    if (nk > 0) {
-        gload(z.kbeg);
-        lstore(0);
-    }
-    __syncthreads();
     const int kl = lane >> 5, cl = lane & 31;
-    for (int kt = 0; kt < nk; kt++) {
-        const int buf = kt & 1;
-        if (kt + 1 < nk) gload(z.kbeg + (kt + 1) * BKT);
+    auto compute = [&](int buf) {
 #pragma unroll
         for (int kk = 0; kk < BKT / 2; kk++) {
             float a[TM], b[TN];
@@ -462,8 +457,37 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
                 for (int j = 0; j < TN; j++)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
         }
-        if (kt + 1 < nk) lstore(buf ^ 1);
+    };
+    if (nk > 0) {
+        gload(z.kbeg, ra0, rb0);
+        lstore(0, ra0, rb0);
+    }
+    if constexpr (NST == 2) {
+        if (nk > 1) gload(z.kbeg + BKT, ra1, rb1);
         __syncthreads();
+        for (int kt = 0; kt < nk; kt += 2) {
+            // tile kt is in LDS buffer 0, tile kt+1 is in flight in register set 1, set 0 is free
+            if (kt + 2 < nk) gload(z.kbeg + (kt + 2) * BKT, ra0, rb0);
+            compute(0);
+            if (kt + 1 < nk) lstore(1, ra1, rb1);
+            __syncthreads();
+            if (kt + 1 >= nk) break;
+            // tile kt+1 is in LDS buffer 1, tile kt+2 is in flight in register set 0, set 1 is free
+            if (kt + 3 < nk) gload(z.kbeg + (kt + 3) * BKT, ra1, rb1);
+            compute(1);
+            if (kt + 2 < nk) lstore(0, ra0, rb0);
+            __syncthreads();
+        }
+    } else {
+        // one tile ahead (the 128x128 tile: the second register set costs a wave of occupancy and measured slower)
+        __syncthreads();
+        for (int kt = 0; kt < nk; kt++) {
+            const int buf = kt & 1;
+            if (kt + 1 < nk) gload(z.kbeg + (kt + 1) * BKT, ra0, rb0);
+            compute(buf);
+            if (kt + 1 < nk) lstore(buf ^ 1, ra0, rb0);
+            __syncthreads();
+        }
     }
 
     // Epilogue.  acc[i][j][r]: row = (r&3) + 8*(r>>2) + 4*(lane>>5), col = lane&31 of the 32x32 tile.
@@ -551,8 +575,8 @@ static int launch_gemm(GemmParams& p, int Mmax, long out_rows, int zbase, bool a
         }
     }
     dim3 grid(cdiv(p.N, use128 ? 128 : 64), cdiv(Mmax, use128 ? 128 : 64), zbase * (split ? p.splitk : 1));
-    if (use128) hipLaunchKernelGGL((gemm_f32_kernel<128, 128, 16, AMODE, BMODE>), grid, 256, 0, st, p);
-    else hipLaunchKernelGGL((gemm_f32_kernel<64, 64, 32, AMODE, BMODE>), grid, 256, 0, st, p);
+    if (use128) hipLaunchKernelGGL((gemm_f32_kernel<128, 128, 16, AMODE, BMODE, 1>), grid, 256, 0, st, p);
+    else hipLaunchKernelGGL((gemm_f32_kernel<64, 64, 32, AMODE, BMODE, 1>), grid, 256, 0, st, p);
     int rc = check_launch("gemm_f32");
     if (rc) return rc;
     if (split && !epilogue_is_linear(full)) {
