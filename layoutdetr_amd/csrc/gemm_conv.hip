@@ -342,8 +342,10 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
     constexpr int QK = BKT / 4;                                  // float4 quads along k per row
     constexpr int NUA = BM * BKT / 4 / 256, NUB = BN * BKT / 4 / 256;  // float4 units per thread per k-tile
     constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
-    __shared__ float As[2][BKT][LDA];
-    __shared__ float Bs[2][BKT][LDB];
+    // dynamic LDS (the 128x128xBK32 image is 65 KiB: above the 64 KiB static limit, within the CU's 160 KiB)
+    extern __shared__ __attribute__((aligned(16))) float ldetr_smem[];
+    float (*As)[BKT][LDA] = reinterpret_cast<float (*)[BKT][LDA]>(ldetr_smem);
+    float (*Bs)[BKT][LDB] = reinterpret_cast<float (*)[BKT][LDB]>(ldetr_smem + 2 * BKT * LDA);
 
     const ZCtx z = make_zctx<BKT>(p);
     const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
@@ -552,15 +554,42 @@ static void init_operand(Operand& o) { memset(&o, 0, sizeof(o)); o.KW = 1; o.KH 
 //   out_rows: rows of C touched (for the memset / epilogue pass); zbase: grid.z multiplicity before split-K;
 //   auto_split: the caller allows the policy to split K (explicit p.splitk > 1 is always honoured);
 //   caller_zeroed: C was already zeroed by the caller (weight-gradient entry points).
+#ifndef T128_BK
+#define T128_BK 32
+#endif
+
+template <int BM, int BN, int BKT, int AMODE, int BMODE>
+static int launch_tile(const GemmParams& p, dim3 grid, hipStream_t st) {
+    constexpr size_t lds = (size_t)2 * BKT * ((BM + 2) + (BN + 2)) * sizeof(float);
+    auto kern = gemm_f32_kernel<BM, BN, BKT, AMODE, BMODE, 1>;
+    if (lds > 64 * 1024) {
+        static bool raised = false;   // one-time opt-in to > 64 KiB of dynamic LDS for this instantiation
+        if (!raised) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+                set_error("gemm: cannot raise the dynamic LDS limit to %zu bytes", lds);
+                return LDETR_ERR_LAUNCH;
+            }
+            raised = true;
+        }
+    }
+    hipLaunchKernelGGL(kern, grid, 256, lds, st, p);
+    return check_launch("gemm_f32");
+}
+
 template <int AMODE, int BMODE>
 static int launch_gemm(GemmParams& p, int Mmax, long out_rows, int zbase, bool auto_split, bool caller_zeroed, hipStream_t st) {
     const int sk0 = p.splitk > 1 ? p.splitk : 1;
     long t128 = (long)cdiv(Mmax, 128) * cdiv(p.N, 128) * zbase * sk0;
     bool use128 = (t128 >= 384 && Mmax >= 128 && p.N >= 128);   // measured: the 128-tile only wins with >= ~1.5 blocks per CU
     long t64 = (long)cdiv(Mmax, 64) * cdiv(p.N, 64) * zbase;
-    if (!use128 && auto_split && p.splitk <= 1 && t64 < 160 && !(p.ep.accumulate && !epilogue_is_linear(p.ep))) {
-        int want = (int)((384 + t64 - 1) / t64);
-        int maxs = p.K / 128;   // keep >= 4 k-tiles of 32 per slice
+    // 128x64 tile: every wave owns a 64x32 sub-tile = TWO independent MFMA accumulator chains (the 64x64 tile has one per wave,
+    // so any LDS/barrier hiccup idles its SIMD's matrix pipe) and needs 1.5 instead of 2 LDS operand reads per MFMA.
+    long t12864 = (long)cdiv(Mmax, 128) * cdiv(p.N, 64) * zbase * sk0;
+    const bool use12864 = !use128 && t12864 >= 512 && Mmax >= 128;
+    if (!use128 && !use12864 && auto_split && p.splitk <= 1 && t64 < 768 && !(p.ep.accumulate && !epilogue_is_linear(p.ep))) {
+        // PMC: with <= 2 resident blocks per CU the single-accumulator waves leave the MFMA pipe ~55% idle; more, shorter blocks fill it
+        int want = (int)(((t64 < 160 ? 384 : 1024) + t64 - 1) / t64);
+        int maxs = p.K / (t64 < 160 ? 128 : 256);   // keep >= 4 (8) k-tiles of 32 per slice
         int sk = want < maxs ? want : maxs;
         if (sk >= 2) p.splitk = sk;
     }
@@ -574,10 +603,11 @@ static int launch_gemm(GemmParams& p, int Mmax, long out_rows, int zbase, bool a
             }
         }
     }
-    dim3 grid(cdiv(p.N, use128 ? 128 : 64), cdiv(Mmax, use128 ? 128 : 64), zbase * (split ? p.splitk : 1));
-    if (use128) hipLaunchKernelGGL((gemm_f32_kernel<128, 128, 16, AMODE, BMODE, 1>), grid, 256, 0, st, p);
-    else hipLaunchKernelGGL((gemm_f32_kernel<64, 64, 32, AMODE, BMODE, 1>), grid, 256, 0, st, p);
-    int rc = check_launch("gemm_f32");
+    dim3 grid(cdiv(p.N, use128 ? 128 : 64), cdiv(Mmax, (use128 || use12864) ? 128 : 64), zbase * (split ? p.splitk : 1));
+    int rc;
+    if (use128) rc = launch_tile<128, 128, T128_BK, AMODE, BMODE>(p, grid, st);
+    else if (use12864) rc = launch_tile<128, 64, 16, AMODE, BMODE>(p, grid, st);
+    else rc = launch_tile<64, 64, 32, AMODE, BMODE>(p, grid, st);
     if (rc) return rc;
     if (split && !epilogue_is_linear(full)) {
         EpiParams q;
