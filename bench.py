@@ -185,6 +185,13 @@ def main():
         torch.cuda.synchronize()
         fl, sec, launches = core.PROF.summary()
         core.PROF.enabled = False
+        if os.environ.get('LDETR_ENGINE_SHAPES'):   # development aid: per-(entry point, flop count) table
+            agg = {}
+            for tag, f, s_, e_ in core.PROF.records:
+                a = agg.setdefault((tag, f), [0, 0.0]); a[0] += 1; a[1] += s_.elapsed_time(e_)
+            with open(os.environ['LDETR_ENGINE_SHAPES'], 'w') as fh:
+                for (tag, f), (n, ms) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+                    fh.write(f'{tag:42s} gflop={f / 1e9:9.3f} calls/step={n // 2:4d} ms/step={ms / 2:8.3f} TF={f * n / ms / 1e9 if ms else 0:7.2f}\n')
         ach = fl / sec / 1e12 if sec > 0 else 0.0
         roofline = dict(bound='mfma', kernel='ldetr::gemm_f32_kernel<*> (f32 MFMA GEMM / implicit-conv engine, all instantiations)',
                         achieved=round(ach, 3), peak=F32_MFMA_PEAK_TFLOPS, unit='TFLOP/s', frac=round(ach / F32_MFMA_PEAK_TFLOPS, 4),

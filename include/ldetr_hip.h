@@ -37,6 +37,13 @@ const char* ldetr_last_error(void);
 /* ABI version; bumped whenever a signature changes. */
 int ldetr_abi_version(void);
 
+/* Scratch memory for the contraction engine's in-kernel split-K reduction on the calling thread's current device.
+ * `ptr`: zero-filled, 16-byte aligned device memory the caller keeps alive and uses from one stream at a time
+ * (the first 256 KiB hold per-tile arrival counters, the rest partial tiles); (NULL, 0) unregisters it and the
+ * engine falls back to fp32 atomics into a zero-filled C plus a second epilogue launch.  No reference counterpart:
+ * the reference leaves split-K decisions to cuBLAS/cuDNN workspaces (torch.backends.cudnn.benchmark, train.py:330). */
+int ldetr_set_workspace(void* ptr, int64_t bytes);
+
 /* Strided 4-D activation view (sizes + element strides); sc == 1 selects the NHWC fast path. */
 typedef struct ldetr_tensor4 {
     int N, C, H, W;

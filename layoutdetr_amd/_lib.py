@@ -34,6 +34,7 @@ _EP = POINTER(Epilogue)
 
 # name -> argtypes; the list doubles as the "every declared symbol is exported" check in tests.
 SIGNATURES = {
+    'ldetr_set_workspace': [_P, _L],
     'ldetr_bias_act_f32': [_P, _P, _P, _P, _P, _P, _L, _I, _L, _I, _I, _F, _F, _F, _P],
     'ldetr_upfirdn2d_f32': [_P, _P, _P, _I, _I, _I, _I, POINTER(c_int64), _I, _I, _L, _L, _I, _I, _I, _I, _I, _I, _I, _I,
                             _I, _F, _I, _I, POINTER(c_int64), _P, _I, _F, _F, _P],
@@ -82,7 +83,7 @@ def load():
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported
         fn.restype = c_int
         fn.argtypes = argtypes
-    if lib.ldetr_abi_version() != 3:
+    if lib.ldetr_abi_version() != 4:
         raise RuntimeError('libldetr_hip.so ABI version mismatch; rebuild it')
     _lib = lib
     return lib

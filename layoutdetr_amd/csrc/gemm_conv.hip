@@ -79,6 +79,8 @@ struct GemmParams {
     int pix_per_sample;  // rows per sample in the *full* destination grid (epilogue + scale lookups)
     int ntaps;           // zmode 2
     long c_tap_stride;   // zmode 2: column offset per tap in C
+    float* ws;           // split-K fix-up: per-(tile, slice) partial tiles; null = fp32 atomics into C
+    int* ws_count;       //   per-tile arrival counters (zero between launches)
     GemmEpilogue ep;
 };
 
@@ -492,6 +494,51 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
         }
     }
 
+    // Split-K fix-up: every slice parks its raw tile in the workspace (register order, so all traffic is coalesced), the slice
+    // that arrives last at the tile's counter sums the slices in slice order (deterministic, unlike the atomic path) and
+    // carries on into the ordinary fused epilogue.  No zero-fill of C and no second epilogue launch.
+    bool direct = p.splitk <= 1;
+    if (p.splitk > 1 && p.ws) {
+        const int zb = p.zmode == 1 ? p.pstep * p.pstep : (p.zmode == 2 ? p.ntaps : 1);
+        const int ks = blockIdx.z / zb;
+        const long tile = ((long)(blockIdx.z - ks * zb) * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+        float* slot0 = p.ws + tile * p.splitk * (long)(BM * BN);
+        float* mine = slot0 + (long)ks * (BM * BN);
+#pragma unroll
+        for (int i = 0; i < TM; i++)
+#pragma unroll
+            for (int j = 0; j < TN; j++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) mine[((i * TN + j) * 16 + r) * 256 + tid] = acc[i][j][r];
+        __threadfence();
+        __shared__ int s_last;
+        __syncthreads();
+        if (tid == 0) {
+            int old = atomicAdd(p.ws_count + tile, 1);
+            s_last = (old == p.splitk - 1);
+            if (s_last) p.ws_count[tile] = 0;   // re-armed for the next launch (stream order makes it visible)
+        }
+        __syncthreads();
+        if (!s_last) return;
+        __threadfence();
+#pragma unroll
+        for (int i = 0; i < TM; i++)
+#pragma unroll
+            for (int j = 0; j < TN; j++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+        for (int sl = 0; sl < p.splitk; sl++) {
+            const float* src = slot0 + (long)sl * (BM * BN);
+#pragma unroll
+            for (int i = 0; i < TM; i++)
+#pragma unroll
+                for (int j = 0; j < TN; j++)
+#pragma unroll
+                    for (int r = 0; r < 16; r++) acc[i][j][r] += src[((i * TN + j) * 16 + r) * 256 + tid];
+        }
+        direct = true;
+    }
+
     // Epilogue.  acc[i][j][r]: row = (r&3) + 8*(r>>2) + 4*(lane>>5), col = lane&31 of the 32x32 tile.
     const GemmEpilogue& ep = p.ep;
     const float inv_keep = ep.p_drop > 0.f ? 1.f / (1.f - ep.p_drop) : 1.f;
@@ -514,7 +561,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
                 int n = n0 + wn * WN + j * 32 + cl;
                 if (n >= p.N) continue;
                 float* dst = p.C + z.c_off + orow * p.ldc + n;
-                if (p.splitk > 1) {
+                if (!direct) {
                     atomicAdd(dst, acc[i][j][r] * ep.alpha);   // raw partial sums; the rest of the epilogue runs in epilogue_kernel
                 } else {
                     float v = apply_epilogue(ep, acc[i][j][r], orow, n, samp, p.ldc, inv_keep);
@@ -558,6 +605,17 @@ static void init_operand(Operand& o) { memset(&o, 0, sizeof(o)); o.KW = 1; o.KH 
 #define T128_BK 32
 #endif
 
+// Caller-provided scratch for the split-K fix-up (ldetr_set_workspace): WS_COUNTERS ints of arrival counters, then partial tiles.
+constexpr long WS_COUNTERS = 65536;
+struct Workspace { void* ptr; size_t bytes; };
+static Workspace g_workspace[64];
+static const Workspace& workspace_for_current_device() {
+    static const Workspace none = {nullptr, 0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return none;
+    return g_workspace[dev];
+}
+
 template <int BM, int BN, int BKT, int AMODE, int BMODE>
 static int launch_tile(const GemmParams& p, dim3 grid, hipStream_t st) {
     constexpr size_t lds = (size_t)2 * BKT * ((BM + 2) + (BN + 2)) * sizeof(float);
@@ -595,7 +653,19 @@ static int launch_gemm(GemmParams& p, int Mmax, long out_rows, int zbase, bool a
     }
     GemmEpilogue full = p.ep;
     const bool split = p.splitk > 1;
-    if (split) {
+    bool fixup = false;
+    if (split && !(caller_zeroed && epilogue_is_linear(p.ep)) && !(p.ep.accumulate && epilogue_is_linear(p.ep))) {
+        // in-kernel fix-up when the caller registered a workspace that can hold this launch's partial tiles
+        const Workspace& w = workspace_for_current_device();
+        const int bm = (use128 || use12864) ? 128 : 64, bn = use128 ? 128 : 64;
+        const long tiles = (long)cdiv(p.N, bn) * cdiv(Mmax, bm) * zbase;
+        if (w.ptr && tiles <= WS_COUNTERS && (size_t)tiles * p.splitk * bm * bn * sizeof(float) + WS_COUNTERS * sizeof(int) <= w.bytes) {
+            p.ws_count = reinterpret_cast<int*>(w.ptr);
+            p.ws = reinterpret_cast<float*>(reinterpret_cast<char*>(w.ptr) + WS_COUNTERS * sizeof(int));
+            fixup = true;
+        }
+    }
+    if (split && !fixup) {
         if (!p.ep.accumulate && !caller_zeroed) {
             if (hipMemset2DAsync(p.C, (size_t)p.ldc * sizeof(float), 0, (size_t)p.N * sizeof(float), (size_t)out_rows, st) != hipSuccess) {
                 set_error("gemm: memset of the split-K output failed");
@@ -609,7 +679,7 @@ static int launch_gemm(GemmParams& p, int Mmax, long out_rows, int zbase, bool a
     else if (use12864) rc = launch_tile<128, 64, 16, AMODE, BMODE>(p, grid, st);
     else rc = launch_tile<64, 64, 32, AMODE, BMODE>(p, grid, st);
     if (rc) return rc;
-    if (split && !epilogue_is_linear(full)) {
+    if (split && !fixup && !epilogue_is_linear(full)) {
         EpiParams q;
         q.ep = full; q.ep.alpha = 1.f; q.ep.accumulate = 0;
         q.C = p.C; q.ldc = p.ldc; q.rows = out_rows; q.N = p.N; q.pix_per_sample = p.pix_per_sample;
@@ -637,6 +707,18 @@ static void fill_epilogue(GemmEpilogue& ep, const ldetr_epilogue* e) {
 }  // namespace ldetr
 
 using namespace ldetr;
+
+// Scratch memory for the in-kernel split-K reduction on the calling thread's current device.  `ptr` must be zero-filled
+// device memory that stays alive (and is used by one stream at a time); null/0 unregisters (atomic split-K path).
+extern "C" int ldetr_set_workspace(void* ptr, int64_t bytes) {
+    int dev = 0;
+    LDETR_CHECK(hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64, "set_workspace: no current device");
+    LDETR_CHECK(bytes >= 0, "set_workspace: negative size");
+    LDETR_CHECK(!ptr || (((uintptr_t)ptr) & 15) == 0, "set_workspace: pointer must be 16-byte aligned");
+    LDETR_CHECK(!ptr || bytes > (int64_t)(WS_COUNTERS * sizeof(int)), "set_workspace: too small");
+    g_workspace[dev].ptr = ptr; g_workspace[dev].bytes = ptr ? (size_t)bytes : 0;
+    return LDETR_OK;
+}
 
 // ---------------------------------------------------------------------------------------------
 // Dense GEMM.  C[M,N] = op(A) * op(B), row-major C with leading dimension ldc.

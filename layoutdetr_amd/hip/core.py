@@ -44,8 +44,22 @@ def engine_call(tag, flops, thunk):
     return r
 
 
+_workspace = {}
+WORKSPACE_BYTES = 256 << 20
+
+
 def lib():
-    return _lib.load()
+    l = _lib.load()
+    if torch.cuda.is_available():
+        dev = torch.cuda.current_device()
+        if dev not in _workspace:
+            # split-K scratch (arrival counters + partial tiles), registered once per device and kept alive here
+            ws = torch.zeros(WORKSPACE_BYTES // 4, dtype=torch.float32, device=torch.device('cuda', dev))
+            _workspace[dev] = ws
+            check_rc = l.ldetr_set_workspace(ctypes.c_void_p(ws.data_ptr()), ws.numel() * 4)
+            if check_rc != 0:
+                raise RuntimeError('ldetr_set_workspace failed: ' + l.ldetr_last_error().decode())
+    return l
 
 
 def check(rc, what=''):

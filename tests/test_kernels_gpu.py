@@ -169,6 +169,37 @@ def test_gemm_epilogue(dev):
     assert torch.allclose(d[d != 0], torch.tensor(1 / 0.75))
 
 
+@pytest.mark.parametrize('M,N,K,sk', [(144, 256, 256, 4), (1024, 256, 2048, 3), (70, 36, 520, 5), (300, 200, 1024, 8)])
+def test_gemm_splitk_fixup_and_atomic_paths(dev, M, N, K, sk):
+    """Split-K through the in-kernel fix-up (workspace registered by core.lib()) and through the fp32-atomic fallback
+    (workspace unregistered) with a full non-linear epilogue; the fix-up path must be bit-reproducible across launches
+    and leave its arrival counters re-armed (second launch equals the first)."""
+    import ctypes
+    from layoutdetr_amd.hip import core
+    torch.manual_seed(41)
+    A = torch.randn(M, K); W = torch.randn(N, K); b = torch.randn(N); R = torch.randn(M, N)
+    Ad, Wd, bd, Rd = [t.to(dev) for t in (A, W, b, R)]
+    ref = F.leaky_relu(0.5 * (A.double() @ W.double().t()).float() + b + R, 0.2) * math.sqrt(2)
+    ep = core.epilogue(alpha=0.5, col_bias=bd, residual=Rd, act=core.ACT_LRELU, act_alpha=0.2, act_gain=math.sqrt(2))
+    tol = 4e-6 * max(1.0, math.sqrt(K / 256))
+    c1 = core.gemm(Ad, Wd, 0, 0, M, N, K, splitk=sk, ep=ep)
+    c2 = core.gemm(Ad, Wd, 0, 0, M, N, K, splitk=sk, ep=ep)
+    assert_close(c1, ref, tol, 'fix-up split-K')
+    assert torch.equal(c1, c2), 'fix-up path is not deterministic / counters not re-armed'
+    ws = core._workspace[torch.cuda.current_device()]
+    torch.cuda.synchronize()
+    assert int(ws[:65536].view(torch.int32).abs().sum().item()) == 0, 'arrival counters left non-zero'
+    lib = core.lib()
+    try:
+        core.check(lib.ldetr_set_workspace(None, 0), 'unregister')
+        c3 = core.gemm(Ad, Wd, 0, 0, M, N, K, splitk=sk, ep=ep)
+        assert_close(c3, ref, tol, 'atomic split-K')
+    finally:
+        core.check(lib.ldetr_set_workspace(ctypes.c_void_p(ws.data_ptr()), ws.numel() * 4), 're-register')
+    c4 = core.gemm(Ad, Wd, 0, 0, M, N, K, splitk=sk, ep=ep)
+    assert torch.equal(c1, c4)
+
+
 # ------------------------------------------------------------------------------------------ conv
 CONV_CASES = [
     # N, H, W, Cin, Cout, k, stride, pad
