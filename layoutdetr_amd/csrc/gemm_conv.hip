@@ -575,6 +575,112 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Latency-bound dense GEMMs (the transformer's 256-wide projections on a few hundred tokens: fewer 64x64 tiles than CUs).
+// One block owns a 32x32 tile of C; its NW waves each take a contiguous 1/NW of K and stream their own A/B fragments
+// global -> registers in MFMA operand order (no LDS staging, no barrier in the k-loop, every load of a wave in flight at once),
+// the NW partial tiles are summed through LDS in wave order (deterministic) and the fused epilogue writes float4 rows.
+// Replaces {zero-fill, split-K atomics, epilogue} = 3 graph nodes by one launch.
+//   TA/TB: 0 = operand stored [rows, K] (k-contiguous), 1 = stored [K, rows] (row-contiguous).
+template <int T>
+__device__ __forceinline__ void small_load(const Operand& o, int row, int R, int k0, int kl, int kend, float (&f)[16]) {
+    // f[t] holds reduction index k0 + 16*kl + t of `row` (the two half-waves interleave as the x2 MFMA expects)
+    const int kb = k0 + 16 * kl;
+    if (T == 0) {
+        const float* src = o.p + (long)row * o.ld + kb;
+        if (row < R && o.vec) {
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (kb + 4 * j < kend) v = *reinterpret_cast<const float4*>(src + 4 * j);
+                f[4 * j] = v.x; f[4 * j + 1] = v.y; f[4 * j + 2] = v.z; f[4 * j + 3] = v.w;
+            }
+        } else {
+#pragma unroll
+            for (int t = 0; t < 16; t++) f[t] = (row < R && kb + t < kend) ? src[t] : 0.f;
+        }
+    } else {
+        const float* src = o.p + (long)kb * o.ld + row;
+#pragma unroll
+        for (int t = 0; t < 16; t++) f[t] = (row < R && kb + t < kend) ? src[(long)t * o.ld] : 0.f;
+    }
+}
+
+template <int TA, int TB, int NW>
+__global__ __launch_bounds__(NW * 64) void gemm_small_kernel(GemmParams p) {
+    using f32x16 = __attribute__((__vector_size__(16 * sizeof(float)))) float;
+    __shared__ float red[NW][32][33];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int cl = lane & 31, kl = lane >> 5;
+    const int m0 = blockIdx.y * 32, n0 = blockIdx.x * 32;
+    const int chunks = (p.K + 31) / 32, per = (chunks + NW - 1) / NW;
+    const int kbeg = wave * per * 32, kend = min(p.K, kbeg + per * 32);
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; r++) acc[r] = 0.f;
+    float a0[16], b0[16], a1[16], b1[16];
+    if (kbeg < kend) {
+        small_load<TA>(p.A, m0 + cl, p.M, kbeg, kl, kend, a0);
+        small_load<TB>(p.B, n0 + cl, p.N, kbeg, kl, kend, b0);
+    }
+    for (int k = kbeg; k < kend; k += 64) {
+        if (k + 32 < kend) {
+            small_load<TA>(p.A, m0 + cl, p.M, k + 32, kl, kend, a1);
+            small_load<TB>(p.B, n0 + cl, p.N, k + 32, kl, kend, b1);
+        }
+#pragma unroll
+        for (int t = 0; t < 16; t++) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[t], b0[t], acc, 0, 0, 0);
+        if (k + 32 >= kend) break;
+        if (k + 64 < kend) {
+            small_load<TA>(p.A, m0 + cl, p.M, k + 64, kl, kend, a0);
+            small_load<TB>(p.B, n0 + cl, p.N, k + 64, kl, kend, b0);
+        }
+#pragma unroll
+        for (int t = 0; t < 16; t++) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[t], b1[t], acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; r++) red[wave][(r & 3) + 8 * (r >> 2) + 4 * kl][cl] = acc[r];
+    __syncthreads();
+    const GemmEpilogue& ep = p.ep;
+    const float inv_keep = ep.p_drop > 0.f ? 1.f / (1.f - ep.p_drop) : 1.f;
+    for (int q = tid; q < 256; q += NW * 64) {   // 256 float4 groups: row = q / 8, cols 4*(q % 8) .. +3
+        const int row = q >> 3, c4 = (q & 7) * 4;
+        const int m = m0 + row;
+        if (m >= p.M) continue;
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            float sum = 0.f;
+#pragma unroll
+            for (int w = 0; w < NW; w++) sum += red[w][row][c4 + e];
+            v[e] = sum;
+        }
+        const int samp = p.pix_per_sample > 0 ? m / p.pix_per_sample : 0;
+        float* dst = p.C + (long)m * p.ldc + n0 + c4;
+#pragma unroll
+        for (int e = 0; e < 4; e++)
+            if (n0 + c4 + e < p.N) v[e] = apply_epilogue(ep, v[e], m, n0 + c4 + e, samp, p.ldc, inv_keep);
+        if (n0 + c4 + 3 < p.N && (p.ldc & 3) == 0 && ((((uintptr_t)p.C) & 15) == 0)) {
+            float4 o = make_float4(v[0], v[1], v[2], v[3]);
+            if (ep.accumulate) { float4 c = *reinterpret_cast<float4*>(dst); o.x += c.x; o.y += c.y; o.z += c.z; o.w += c.w; }
+            *reinterpret_cast<float4*>(dst) = o;
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; e++)
+                if (n0 + c4 + e < p.N) { if (ep.accumulate) dst[e] += v[e]; else dst[e] = v[e]; }
+        }
+    }
+}
+
+template <int TA, int TB>
+static int launch_small(const GemmParams& p, hipStream_t st) {
+    dim3 grid(cdiv(p.N, 32), cdiv(p.M, 32), 1);
+    const long blocks = (long)grid.x * grid.y;
+    if (blocks <= 256 && p.K >= 512) hipLaunchKernelGGL((gemm_small_kernel<TA, TB, 8>), grid, 512, 0, st, p);
+    else hipLaunchKernelGGL((gemm_small_kernel<TA, TB, 4>), grid, 256, 0, st, p);
+    return check_launch("gemm_small");
+}
+
 // Second phase of a split-K contraction: C holds sum_k (already scaled by alpha); apply the rest of the epilogue in place.
 struct EpiParams { GemmEpilogue ep; float* C; long ldc; long rows; int N; int pix_per_sample; };
 
@@ -607,6 +713,12 @@ static void init_operand(Operand& o) { memset(&o, 0, sizeof(o)); o.KW = 1; o.KH 
 #ifndef T128_BK
 #define T128_BK 32
 #endif
+
+// Dense GEMMs with fewer 64x64 tiles than this (and at most this much work) take the register-streaming 32x32 kernel.
+#ifndef SMALL_GEMM_TILES
+#define SMALL_GEMM_TILES 256
+#endif
+constexpr long SMALL_GEMM_MNK = 1l << 30;
 
 // Caller-provided scratch for the split-K fix-up (ldetr_set_workspace): WS_COUNTERS ints of arrival counters, then partial tiles.
 constexpr long WS_COUNTERS = 65536;
@@ -746,6 +858,11 @@ extern "C" int ldetr_gemm_f32(const float* A, int64_t lda, int ta, const float* 
     LDETR_CHECK(!(p.splitk > 1 && p.ep.accumulate && !epilogue_is_linear(p.ep)), "gemm: split-K + accumulate needs a linear epilogue");
     hipStream_t st = (hipStream_t)stream;
     const bool auto_split = (splitk == 0);   // splitk: 0 = let the launch policy decide, 1 = never split, >1 = explicit
+    if (auto_split && (long)cdiv(M, 64) * cdiv(N, 64) < SMALL_GEMM_TILES && (long)M * N * K <= SMALL_GEMM_MNK) {
+        if (!ta && !tb) return launch_small<0, 0>(p, st);
+        if (!ta && tb) return launch_small<0, 1>(p, st);
+        if (ta && tb) return launch_small<1, 1>(p, st);
+    }
     if (!ta && !tb) return launch_gemm<OP_KC_DENSE, OP_KC_DENSE>(p, M, M, 1, auto_split, false, st);
     if (!ta && tb) return launch_gemm<OP_KC_DENSE, OP_RC_DENSE>(p, M, M, 1, auto_split, false, st);
     if (ta && tb) return launch_gemm<OP_RC_DENSE, OP_RC_DENSE>(p, M, M, 1, auto_split, false, st);

@@ -1,5 +1,6 @@
 """Thin host-side plumbing between torch tensors (device memory + streams only) and the C ABI."""
 import ctypes
+import os
 
 import torch
 
@@ -52,6 +53,8 @@ def lib():
     l = _lib.load()
     if torch.cuda.is_available():
         dev = torch.cuda.current_device()
+        if dev not in _workspace and os.environ.get('LDETR_NO_WORKSPACE'):
+            _workspace[dev] = None   # development switch: exercise the fp32-atomic split-K path
         if dev not in _workspace:
             # split-K scratch (arrival counters + partial tiles), registered once per device and kept alive here
             ws = torch.zeros(WORKSPACE_BYTES // 4, dtype=torch.float32, device=torch.device('cuda', dev))

@@ -7,13 +7,16 @@ from layoutdetr_amd.hip import core
 dev = torch.device('cuda:0')
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 16
 
-def timeit(fn, n=10):
+def timeit(fn, n=20):
+    """GPU time per call from a hipGraph replay of n back-to-back launches (no CPU launch gaps in the measurement)."""
     fn(); torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for _ in range(n): fn()
+    g.replay(); torch.cuda.synchronize()
     s = torch.cuda.Event(enable_timing=True); e = torch.cuda.Event(enable_timing=True)
-    s.record()
-    for _ in range(n): fn()
-    e.record(); torch.cuda.synchronize()
-    return s.elapsed_time(e) / n * 1e-3
+    s.record(); g.replay(); g.replay(); e.record(); torch.cuda.synchronize()
+    return s.elapsed_time(e) / (2 * n) * 1e-3
 
 def conv_case(name, N, H, Ci, Co, k, s, p):
     OH = (H + 2 * p - k) // s + 1
@@ -21,23 +24,24 @@ def conv_case(name, N, H, Ci, Co, k, s, p):
     y = torch.empty(N, OH, OH, Co, device=dev); dx = torch.empty_like(x); dw = torch.empty_like(w)
     xt = core.tensor4_nhwc(x); dyt = core.tensor4_nhwc(dy)
     fl = 2.0 * N * OH * OH * Co * k * k * Ci
-    L = core.lib(); st = core.stream()
-    tf = timeit(lambda: L.ldetr_conv2d_fwd_f32(core.ptr(x), ctypes.byref(xt), core.ptr(w), Co, k, k, s, p, core.ptr(y), Co, OH, OH, None, 0, None, st))
-    tb = timeit(lambda: L.ldetr_conv2d_bwd_data_f32(core.ptr(dy), ctypes.byref(dyt), core.ptr(w), Ci, k, k, s, p, core.ptr(dx), Ci, H, H, None, 0, None, st))
+    L = core.lib()
+    tf = timeit(lambda: L.ldetr_conv2d_fwd_f32(core.ptr(x), ctypes.byref(xt), core.ptr(w), Co, k, k, s, p, core.ptr(y), Co, OH, OH, None, 0, None, core.stream()))
+    tb = timeit(lambda: L.ldetr_conv2d_bwd_data_f32(core.ptr(dy), ctypes.byref(dyt), core.ptr(w), Ci, k, k, s, p, core.ptr(dx), Ci, H, H, None, 0, None, core.stream()))
     tiles = k * k * ((Co + 63) // 64) * ((Ci + 63) // 64)
     sk = core.pick_splitk(tiles, N * OH * OH, target=512, min_k=512)
-    tw = timeit(lambda: L.ldetr_conv2d_bwd_weight_f32(core.ptr(x), ctypes.byref(xt), core.ptr(dy), ctypes.byref(dyt), core.ptr(dw), k, k, s, p, sk, None, 0, None, 0, 0, st))
+    tw = timeit(lambda: L.ldetr_conv2d_bwd_weight_f32(core.ptr(x), ctypes.byref(xt), core.ptr(dy), ctypes.byref(dyt), core.ptr(dw), k, k, s, p, sk, None, 0, None, 0, 0, core.stream()))
     print(f'{name:28s} M={N*OH*OH:6d} N={Co:4d} K={k*k*Ci:5d}  fwd {tf*1e6:8.1f}us {fl/tf/1e12:6.1f}TF | bwdD {tb*1e6:8.1f}us {fl/tb/1e12:6.1f}TF | bwdW(sk={sk:3d}) {tw*1e6:8.1f}us {fl/tw/1e12:6.1f}TF', flush=True)
     return fl, tf, tb, tw
 
 def gemm_case(name, M, N, K):
-    A = torch.randn(M, K, device=dev); W = torch.randn(N, K, device=dev); dY = torch.randn(M, N, device=dev)
+    A = torch.randn(M, K, device=dev); W = torch.randn(N, K, device=dev); dY = torch.randn(M, N, device=dev); b = torch.randn(N, device=dev)
     fl = 2.0 * M * N * K
-    t1 = timeit(lambda: core.gemm(A, W, 0, 0, M, N, K))
-    t2 = timeit(lambda: core.gemm(dY, W, 0, 1, M, K, N))
-    sk = 0
-    t3 = timeit(lambda: core.gemm(dY, A, 1, 1, N, K, M))
-    print(f'{name:28s} M={M:6d} N={N:4d} K={K:5d}  fwd {t1*1e6:8.1f}us {fl/t1/1e12:6.1f}TF | dX   {t2*1e6:8.1f}us {fl/t2/1e12:6.1f}TF | dW  (sk={sk:3d}) {t3*1e6:8.1f}us {fl/t3/1e12:6.1f}TF', flush=True)
+    ep = core.epilogue(col_bias=b, act=core.ACT_RELU)
+    y = torch.empty(M, N, device=dev); dx = torch.empty(M, K, device=dev); dw = torch.empty(N, K, device=dev)
+    t1 = timeit(lambda: core.gemm(A, W, 0, 0, M, N, K, out=y, ep=ep))
+    t2 = timeit(lambda: core.gemm(dY, W, 0, 1, M, K, N, out=dx))
+    t3 = timeit(lambda: core.gemm(dY, A, 1, 1, N, K, M, out=dw))
+    print(f'{name:28s} M={M:6d} N={N:4d} K={K:5d}  fwd+bias+relu {t1*1e6:8.1f}us {fl/t1/1e12:6.1f}TF | dX   {t2*1e6:8.1f}us {fl/t2/1e12:6.1f}TF | dW   {t3*1e6:8.1f}us {fl/t3/1e12:6.1f}TF', flush=True)
 
 print('batch', B)
 tot = [0, 0, 0, 0]
@@ -51,5 +55,5 @@ cases = [('l1 1x1 64->64', B, R, 64, 64, 1, 1, 0), ('l1 3x3 64->64', B, R, 64, 6
          ('sg 3x3 64->64 @128', B, 128, 64, 64, 3, 1, 1), ('sg 3x3 32->32 @256', B, 256, 32, 32, 3, 1, 1)]
 for c in cases:
     conv_case(*c)
-for g in [('enc qk proj', B * 64, 512, 256), ('enc ffn1', B * 64, 2048, 256), ('enc ffn2', B * 64, 256, 2048), ('dec ffn1', B * 9, 2048, 256), ('fc_in 3072->768', B * 9, 768, 3072), ('mapping 512', B, 512, 512)]:
+for g in [('enc proj 256', B * 64, 256, 256), ('encdec proj 256', B * 80, 256, 256), ('dec proj 256', B * 9, 256, 256), ('dec proj 256 (10)', B * 10, 256, 256), ('enc qk proj', B * 64, 512, 256), ('enc ffn1', B * 64, 2048, 256), ('enc ffn2', B * 64, 256, 2048), ('dec ffn1', B * 9, 2048, 256), ('fc_in 3072->768', B * 9, 768, 3072), ('mapping 512', B, 512, 512)]:
     gemm_case(*g)
