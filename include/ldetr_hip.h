@@ -93,8 +93,9 @@ int ldetr_upfirdn2d_f32(const float* x, const float* f, float* y, int N, int C, 
                         float gain, int outH, int outW, const int64_t* y_strides_nchw,
                         const float* act_bias, int has_act, float act_alpha, float act_gain, void* stream);
 
-/* splitk: 0 = launch policy may split the reduction over grid.z (output zeroed + fp32 atomics + epilogue pass),
- * 1 = never split, > 1 = explicit number of K slices. */
+/* splitk: 0 = the launch policy decides (latency-bound sizes take a register-streaming 32x32 kernel; otherwise the
+ * reduction may be split over grid.z, reduced in-kernel through the ldetr_set_workspace scratch or, without one, by
+ * fp32 atomics into a zero-filled C plus an epilogue pass), 1 = never split, > 1 = explicit number of K slices. */
 int ldetr_gemm_f32(const float* A, int64_t lda, int ta, const float* B, int64_t ldb, int tb, float* C, int64_t ldc,
                    int M, int N, int K, int splitk, const ldetr_epilogue* ep, int pix_per_sample, void* stream);
 
@@ -104,7 +105,8 @@ int ldetr_conv2d_fwd_f32(const float* x, const ldetr_tensor4* xt, const float* w
 int ldetr_conv2d_bwd_data_f32(const float* dy, const ldetr_tensor4* dyt, const float* w, int Cin, int KH, int KW,
                               int stride, int pad, float* dx, int64_t lddx, int IH, int IW, const float* dy_scale,
                               int64_t dy_scale_ld, const ldetr_epilogue* ep, void* stream);
-/* accumulate != 0: dw += gradient (fp32 atomics onto the existing buffer, e.g. a view of the flat .grad buffer) instead of dw = gradient. */
+/* accumulate != 0: dw += gradient (fp32 atomics onto the existing buffer, e.g. a view of the flat .grad buffer) instead of dw = gradient.
+ * splitk: 0 = the library picks the tile shape and the number of pixel slices together; >= 1 explicit. */
 int ldetr_conv2d_bwd_weight_f32(const float* x, const ldetr_tensor4* xt, const float* dy, const ldetr_tensor4* dyt,
                                 float* dw, int KH, int KW, int stride, int pad, int splitk, const float* x_scale,
                                 int64_t x_scale_ld, const float* dy_scale, int64_t dy_scale_ld, int accumulate, void* stream);

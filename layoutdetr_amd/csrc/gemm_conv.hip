@@ -719,6 +719,9 @@ static void init_operand(Operand& o) { memset(&o, 0, sizeof(o)); o.KW = 1; o.KH 
 #define SMALL_GEMM_TILES 256
 #endif
 constexpr long SMALL_GEMM_MNK = 1l << 30;
+#ifndef WGRAD_MIN_K
+#define WGRAD_MIN_K 512
+#endif
 
 // Caller-provided scratch for the split-K fix-up (ldetr_set_workspace): WS_COUNTERS ints of arrival counters, then partial tiles.
 constexpr long WS_COUNTERS = 65536;
@@ -804,6 +807,27 @@ static int launch_gemm(GemmParams& p, int Mmax, long out_rows, int zbase, bool a
         rc = check_launch("gemm_epilogue");
     }
     return rc;
+}
+
+// Weight gradients reduce over pixels (K = N*OH*OW, up to 2^20) into a small [Cout, taps, Cin] output: pick the tile
+// first (128-wide tiles when the channel counts allow them: two accumulator chains per wave, fewer LDS reads per MFMA),
+// then split K until that tile's grid fills the chip.  Mirrors the tile thresholds of launch_gemm.
+static int wgrad_auto_split(int M, int N, int K, int zbase) {
+    auto pick = [&](long tiles, long target, int min_k) {
+        long s = (target + tiles - 1) / tiles, maxs = K / min_k;
+        if (s > maxs) s = maxs;
+        return (int)(s < 1 ? 1 : s);
+    };
+    if (M >= 128 && N >= 128) {
+        long t = (long)cdiv(M, 128) * cdiv(N, 128) * zbase; int s = pick(t, 512, WGRAD_MIN_K);
+        if (t * s >= 384) return s;
+    }
+    if (M >= 128) {
+        long t = (long)cdiv(M, 128) * cdiv(N, 64) * zbase; int s = pick(t, 768, WGRAD_MIN_K);
+        if (t * s >= 512) return s;
+    }
+    long t = (long)cdiv(M, 64) * cdiv(N, 64) * zbase;
+    return pick(t, 768, WGRAD_MIN_K);
 }
 
 static void fill_epilogue(GemmEpilogue& ep, const ldetr_epilogue* e) {
@@ -943,14 +967,16 @@ extern "C" int ldetr_conv2d_bwd_weight_f32(const float* x, const ldetr_tensor4* 
     hipStream_t st = (hipStream_t)stream;
     GemmParams p; memset(&p, 0, sizeof(p));
     init_operand(p.A); init_operand(p.B);
-    if (splitk < 1) splitk = 1;
+    int Kpix = dyt->N * OH * OW;
+    const bool gather = (xt->sc != 1 || Cin % 4 != 0);
+    if (splitk < 1)   // 0 = automatic
+        splitk = gather ? wgrad_auto_split(Cout, KH * KW * Cin, Kpix, 1) : wgrad_auto_split(Cout, Cin, Kpix, KH * KW);
     fill_epilogue(p.ep, nullptr);
     p.splitk = splitk; p.pstep = 1; p.nsamp = xt->N; p.pix_per_sample = 0;
     long wsz = (long)Cout * KH * KW * Cin;
     if (!accumulate && hipMemsetAsync(dw, 0, wsz * sizeof(float), st) != hipSuccess) { set_error("conv2d_bwd_weight: memset failed"); return LDETR_ERR_LAUNCH; }
     if (splitk == 1 && accumulate) p.ep.accumulate = 1;
-    int Kpix = dyt->N * OH * OW;
-    if (xt->sc != 1 || Cin % 4 != 0) {
+    if (gather) {
         // 3-channel (or strided-channel) input, e.g. the ResNet stem on an NCHW image: a single GEMM with
         // A = dy viewed [k = pixel][m = co] and B = scalar im2col gather [k = pixel][n = (tap, c)].
         LDETR_CHECK(dyt->sw == Cout && dyt->sh == (long)OW * Cout && dyt->sn == (long)OH * OW * Cout, "conv2d_bwd_weight: dy must be packed NHWC");
@@ -1038,7 +1064,7 @@ extern "C" int ldetr_conv_transpose2d_bwd_weight_f32(const float* x, const ldetr
     hipStream_t st = (hipStream_t)stream;
     GemmParams p; memset(&p, 0, sizeof(p));
     init_operand(p.A); init_operand(p.B);
-    if (splitk < 1) splitk = 1;
+    if (splitk < 1) splitk = wgrad_auto_split(Cout, Cin, xt->N * xt->H * xt->W, KH * KW);   // 0 = automatic
     fill_epilogue(p.ep, nullptr);
     p.splitk = splitk; p.pstep = 1; p.nsamp = xt->N; p.pix_per_sample = 0;
     long wsz = (long)Cout * KH * KW * Cin;

@@ -96,8 +96,7 @@ class _ConvFn(torch.autograd.Function):
             xt = core.tensor4_nchw(x) if x_is_nchw else core.tensor4_nhwc(x)
             Kpix = N * OH * OW
             vec = (not x_is_nchw) and I % 4 == 0
-            tiles = (KH * KW if vec else 1) * ((O + 63) // 64) * (((I if vec else KH * KW * I) + 63) // 64)
-            sk = core.pick_splitk(tiles, Kpix, target=512, min_k=512)
+            sk = 0   # the library picks tile and split-K factor together
             if sc is not None and not vec:
                 # scalar-gather path has no operand scale: fold the BN scale into dy first
                 dpre_s = dpre * sc

@@ -77,8 +77,7 @@ class _ModConvFn(torch.autograd.Function):
             else:
                 dw_ohwi = torch.empty((O, KH, KW, I), device=dy.device, dtype=torch.float32)
             xt = core.tensor4_nhwc(x)
-            tiles = KH * KW * ((O + 63) // 64) * ((I + 63) // 64)
-            sk = core.pick_splitk(tiles, B * OH * OW, target=512, min_k=512)
+            sk = 0   # the library picks tile and split-K factor together
             core.engine_call('ldetr_conv2d_bwd_weight_f32', 2.0 * B * OH * OW * O * KH * KW * I, lambda: core.check(core.lib().ldetr_conv2d_bwd_weight_f32(core.ptr(x), ctypes.byref(xt), core.ptr(dv), ctypes.byref(dvt),
                                                               core.ptr(dw_ohwi), KH, KW, 1, pad, sk, core.ptr(s), s.stride(0),
                                                               core.ptr(d), d.stride(0), acc, core.stream()), 'modconv_bwd_weight'))
@@ -142,8 +141,7 @@ class _ModConvUpFn(torch.autograd.Function):
             else:
                 dw_ohwi = torch.empty((O, KH, KW, I), device=dy.device, dtype=torch.float32)
             xt = core.tensor4_nhwc(x)
-            tiles = KH * KW * ((O + 63) // 64) * ((I + 63) // 64)
-            sk = core.pick_splitk(tiles, B * H * W, target=512, min_k=512)
+            sk = 0   # the library picks tile and split-K factor together
             core.engine_call('ldetr_conv_transpose2d_bwd_weight_f32', 2.0 * B * H * W * O * KH * KW * I, lambda: core.check(core.lib().ldetr_conv_transpose2d_bwd_weight_f32(core.ptr(x), ctypes.byref(xt), core.ptr(dud), ctypes.byref(dudt),
                                                                         core.ptr(dw_ohwi), KH, KW, 2, 0, sk, core.ptr(s), s.stride(0),
                                                                         core.ptr(d), d.stride(0), acc, core.stream()), 'modconv_up_bwd_weight'))

@@ -27,8 +27,7 @@ def conv_case(name, N, H, Ci, Co, k, s, p):
     L = core.lib()
     tf = timeit(lambda: L.ldetr_conv2d_fwd_f32(core.ptr(x), ctypes.byref(xt), core.ptr(w), Co, k, k, s, p, core.ptr(y), Co, OH, OH, None, 0, None, core.stream()))
     tb = timeit(lambda: L.ldetr_conv2d_bwd_data_f32(core.ptr(dy), ctypes.byref(dyt), core.ptr(w), Ci, k, k, s, p, core.ptr(dx), Ci, H, H, None, 0, None, core.stream()))
-    tiles = k * k * ((Co + 63) // 64) * ((Ci + 63) // 64)
-    sk = core.pick_splitk(tiles, N * OH * OH, target=512, min_k=512)
+    sk = 0
     tw = timeit(lambda: L.ldetr_conv2d_bwd_weight_f32(core.ptr(x), ctypes.byref(xt), core.ptr(dy), ctypes.byref(dyt), core.ptr(dw), k, k, s, p, sk, None, 0, None, 0, 0, core.stream()))
     print(f'{name:28s} M={N*OH*OH:6d} N={Co:4d} K={k*k*Ci:5d}  fwd {tf*1e6:8.1f}us {fl/tf/1e12:6.1f}TF | bwdD {tb*1e6:8.1f}us {fl/tb/1e12:6.1f}TF | bwdW(sk={sk:3d}) {tw*1e6:8.1f}us {fl/tw/1e12:6.1f}TF', flush=True)
     return fl, tf, tb, tw
