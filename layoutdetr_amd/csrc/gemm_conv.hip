@@ -65,6 +65,7 @@ struct GemmEpilogue {
     unsigned long long seed;
     const unsigned long long* seed_ptr;
     int accumulate;
+    const float* row_scale;  // internal (weight gradients): per-output-row factor, linear like alpha (FrozenBN scale of the dy operand)
 };
 
 struct GemmParams {
@@ -321,6 +322,7 @@ __device__ __forceinline__ ZCtx make_zctx(const GemmParams& p) {
 // One output element through the epilogue chain documented in include/ldetr_hip.h.
 __device__ __forceinline__ float apply_epilogue(const GemmEpilogue& ep, float v, long orow, int n, int samp, long ldc, float inv_keep) {
     v *= ep.alpha;
+    if (ep.row_scale) v *= ep.row_scale[orow];
     if (ep.col_scale) v *= ep.col_scale[n];
     if (ep.samp_scale) v *= ep.samp_scale[(long)samp * ep.samp_ld + n];
     if (ep.col_bias) v += ep.col_bias[n];
@@ -565,7 +567,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
                 if (n >= p.N) continue;
                 float* dst = p.C + z.c_off + orow * p.ldc + n;
                 if (!direct) {
-                    atomicAdd(dst, acc[i][j][r] * ep.alpha);   // raw partial sums; the rest of the epilogue runs in epilogue_kernel
+                    atomicAdd(dst, acc[i][j][r] * (ep.row_scale ? ep.alpha * ep.row_scale[orow] : ep.alpha));   // raw partial sums; the rest of the epilogue runs in epilogue_kernel
                 } else {
                     float v = apply_epilogue(ep, acc[i][j][r], orow, n, samp, p.ldc, inv_keep);
                     if (ep.accumulate) *dst += v; else *dst = v;
@@ -799,7 +801,7 @@ static int launch_gemm(GemmParams& p, int Mmax, long out_rows, int zbase, bool a
     if (rc) return rc;
     if (split && !fixup && !epilogue_is_linear(full)) {
         EpiParams q;
-        q.ep = full; q.ep.alpha = 1.f; q.ep.accumulate = 0;
+        q.ep = full; q.ep.alpha = 1.f; q.ep.row_scale = nullptr; q.ep.accumulate = 0;
         q.C = p.C; q.ldc = p.ldc; q.rows = out_rows; q.N = p.N; q.pix_per_sample = p.pix_per_sample;
         long total = out_rows * p.N;
         int g = (int)((total + 255) / 256); if (g > 4096) g = 4096; if (g < 1) g = 1;
@@ -988,6 +990,27 @@ extern "C" int ldetr_conv2d_bwd_weight_f32(const float* x, const ldetr_tensor4* 
         return launch_gemm<OP_RC_DENSE, OP_RC_CONVK>(p, p.M, p.M, 1, false, true, st);
     }
     // A = dy viewed as [k = pixel][m = co]; B = x gathered per tap [k = pixel][n = ci]
+    if (dy_scale && dy_scale_ld == 0) { p.ep.row_scale = dy_scale; dy_scale = nullptr; }   // one scale per co for all samples: out of the k-loop
+    p.M = Cout; p.N = Cin; p.K = Kpix; p.C = dw; p.ldc = (long)KH * KW * Cin;
+    p.zmode = 2; p.ntaps = KH * KW; p.c_tap_stride = Cin;
+    const bool dy_packed = !dy_scale && dyt->sw == Cout && dyt->sh == (long)OW * Cout && dyt->sn == (long)OH * OW * Cout;
+    if (dy_packed) {
+        // packed NHWC dy without per-sample scale is a plain [pixels, Cout] matrix: no pixel decode for that operand;
+        // a 1x1 / stride 1 conv over packed x is a plain transposed GEMM altogether
+        p.A.p = dy; p.A.ld = Cout; p.A.vec = al16(dy) && (Cout % 4 == 0);
+        const bool x_packed = !x_scale && KH == 1 && KW == 1 && stride == 1 && pad == 0 && xt->sw == Cin && xt->sh == (long)xt->W * Cin &&
+                              xt->sn == (long)xt->H * xt->W * Cin;
+        if (x_packed) {
+            p.B.p = x; p.B.ld = Cin; p.B.vec = al16(x);
+            return launch_gemm<OP_RC_DENSE, OP_RC_DENSE>(p, p.M, p.M, 1, false, true, st);
+        }
+        set_conv_src(p.B, x, xt);
+        p.B.DH = OH; p.B.DW = OW; p.B.stride = stride; p.B.pad = pad; p.B.KH = KH; p.B.KW = KW; p.B.tapped = 1;
+        p.B.scale = x_scale; p.B.scale_ld = x_scale_ld;
+        p.B.vec = al16(x) && (xt->sn % 4 == 0) && (xt->sh % 4 == 0) && (xt->sw % 4 == 0) &&
+                  (!x_scale || (al16(x_scale) && x_scale_ld % 4 == 0));
+        return launch_gemm<OP_RC_DENSE, OP_RC_PIX>(p, p.M, p.M, p.ntaps, false, true, st);
+    }
     set_conv_src(p.A, dy, dyt);
     p.A.DH = OH; p.A.DW = OW; p.A.stride = 1; p.A.pad = 0; p.A.tapped = 0;
     p.A.scale = dy_scale; p.A.scale_ld = dy_scale_ld;
