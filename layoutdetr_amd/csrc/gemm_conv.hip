@@ -320,12 +320,14 @@ __device__ __forceinline__ ZCtx make_zctx(const GemmParams& p) {
 }
 
 // One output element through the epilogue chain documented in include/ldetr_hip.h.
-__device__ __forceinline__ float apply_epilogue(const GemmEpilogue& ep, float v, long orow, int n, int samp, long ldc, float inv_keep) {
+// cs / cb: the column's scale and bias, fetched once per column by the caller (not once per element).
+__device__ __forceinline__ float apply_epilogue(const GemmEpilogue& ep, float v, long orow, int n, int samp, long ldc, float inv_keep,
+                                                float cs, float cb) {
     v *= ep.alpha;
     if (ep.row_scale) v *= ep.row_scale[orow];
-    if (ep.col_scale) v *= ep.col_scale[n];
+    v *= cs;
     if (ep.samp_scale) v *= ep.samp_scale[(long)samp * ep.samp_ld + n];
-    if (ep.col_bias) v += ep.col_bias[n];
+    v += cb;
     if (ep.residual) v += ep.residual[orow * ep.ldr + n];
     if (ep.act == 1) v = fmaxf(v, 0.f);
     else if (ep.act == 2) v = (v > 0.f ? v : v * ep.act_alpha) * ep.act_gain;
@@ -547,6 +549,13 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
     // Epilogue.  acc[i][j][r]: row = (r&3) + 8*(r>>2) + 4*(lane>>5), col = lane&31 of the 32x32 tile.
     const GemmEpilogue& ep = p.ep;
     const float inv_keep = ep.p_drop > 0.f ? 1.f / (1.f - ep.p_drop) : 1.f;
+    float cs[TN], cb[TN];
+#pragma unroll
+    for (int j = 0; j < TN; j++) {
+        int n = n0 + wn * WN + j * 32 + cl;
+        cs[j] = (ep.col_scale && n < p.N) ? ep.col_scale[n] : 1.f;
+        cb[j] = (ep.col_bias && n < p.N) ? ep.col_bias[n] : 0.f;
+    }
 #pragma unroll
     for (int i = 0; i < TM; i++) {
 #pragma unroll
@@ -560,7 +569,8 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
                 int y2 = rem / z.DW2; int x2 = rem - y2 * z.DW2;
                 orow = ((long)n * p.A.DH + (y2 * p.pstep + z.py)) * p.A.DW + (x2 * p.pstep + z.px);
             }
-            int samp = p.pix_per_sample > 0 ? (int)(orow / p.pix_per_sample) : 0;
+            // only the per-sample scale needs the sample index; the division was costing more issue slots than a K=64 main loop
+            int samp = (ep.samp_scale && p.pix_per_sample > 0) ? (int)((unsigned)orow / (unsigned)p.pix_per_sample) : 0;
 #pragma unroll
             for (int j = 0; j < TN; j++) {
                 int n = n0 + wn * WN + j * 32 + cl;
@@ -569,7 +579,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
                 if (!direct) {
                     atomicAdd(dst, acc[i][j][r] * (ep.row_scale ? ep.alpha * ep.row_scale[orow] : ep.alpha));   // raw partial sums; the rest of the epilogue runs in epilogue_kernel
                 } else {
-                    float v = apply_epilogue(ep, acc[i][j][r], orow, n, samp, p.ldc, inv_keep);
+                    float v = apply_epilogue(ep, acc[i][j][r], orow, n, samp, p.ldc, inv_keep, cs[j], cb[j]);
                     if (ep.accumulate) *dst += v; else *dst = v;
                 }
             }
@@ -657,11 +667,11 @@ __global__ __launch_bounds__(NW * 64) void gemm_small_kernel(GemmParams p) {
             for (int w = 0; w < NW; w++) sum += red[w][row][c4 + e];
             v[e] = sum;
         }
-        const int samp = p.pix_per_sample > 0 ? m / p.pix_per_sample : 0;
+        const int samp = (ep.samp_scale && p.pix_per_sample > 0) ? m / p.pix_per_sample : 0;
         float* dst = p.C + (long)m * p.ldc + n0 + c4;
 #pragma unroll
         for (int e = 0; e < 4; e++)
-            if (n0 + c4 + e < p.N) v[e] = apply_epilogue(ep, v[e], m, n0 + c4 + e, samp, p.ldc, inv_keep);
+            if (n0 + c4 + e < p.N) v[e] = apply_epilogue(ep, v[e], m, n0 + c4 + e, samp, p.ldc, inv_keep, ep.col_scale ? ep.col_scale[n0 + c4 + e] : 1.f, ep.col_bias ? ep.col_bias[n0 + c4 + e] : 0.f);
         if (n0 + c4 + 3 < p.N && (p.ldc & 3) == 0 && ((((uintptr_t)p.C) & 15) == 0)) {
             float4 o = make_float4(v[0], v[1], v[2], v[3]);
             if (ep.accumulate) { float4 c = *reinterpret_cast<float4*>(dst); o.x += c.x; o.y += c.y; o.z += c.z; o.w += c.w; }
@@ -691,9 +701,9 @@ __global__ __launch_bounds__(256) void gemm_epilogue_kernel(EpiParams q) {
     const long total = q.rows * q.N;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         long row = i / q.N; int n = (int)(i - row * q.N);
-        int samp = q.pix_per_sample > 0 ? (int)(row / q.pix_per_sample) : 0;
+        int samp = (q.ep.samp_scale && q.pix_per_sample > 0) ? (int)(row / q.pix_per_sample) : 0;
         float* dst = q.C + row * q.ldc + n;
-        *dst = apply_epilogue(q.ep, *dst, row, n, samp, q.ldc, inv_keep);
+        *dst = apply_epilogue(q.ep, *dst, row, n, samp, q.ldc, inv_keep, q.ep.col_scale ? q.ep.col_scale[n] : 1.f, q.ep.col_bias ? q.ep.col_bias[n] : 0.f);
     }
 }
 

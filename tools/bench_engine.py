@@ -25,7 +25,9 @@ def conv_case(name, N, H, Ci, Co, k, s, p):
     xt = core.tensor4_nhwc(x); dyt = core.tensor4_nhwc(dy)
     fl = 2.0 * N * OH * OH * Co * k * k * Ci
     L = core.lib()
-    tf = timeit(lambda: L.ldetr_conv2d_fwd_f32(core.ptr(x), ctypes.byref(xt), core.ptr(w), Co, k, k, s, p, core.ptr(y), Co, OH, OH, None, 0, None, core.stream()))
+    sc = torch.rand(Co, device=dev) + 0.5; sh = torch.randn(Co, device=dev); res = torch.randn_like(y)
+    ep = core.epilogue(col_scale=sc, col_bias=sh, residual=res.reshape(-1, Co), act=core.ACT_RELU)   # FrozenBN + residual + ReLU, as the trunk runs it
+    tf = timeit(lambda: L.ldetr_conv2d_fwd_f32(core.ptr(x), ctypes.byref(xt), core.ptr(w), Co, k, k, s, p, core.ptr(y), Co, OH, OH, None, 0, ctypes.byref(ep), core.stream()))
     tb = timeit(lambda: L.ldetr_conv2d_bwd_data_f32(core.ptr(dy), ctypes.byref(dyt), core.ptr(w), Ci, k, k, s, p, core.ptr(dx), Ci, H, H, None, 0, None, core.stream()))
     sk = 0
     tw = timeit(lambda: L.ldetr_conv2d_bwd_weight_f32(core.ptr(x), ctypes.byref(xt), core.ptr(dy), ctypes.byref(dyt), core.ptr(dw), k, k, s, p, sk, None, 0, None, 0, 0, core.stream()))
