@@ -322,13 +322,13 @@ __device__ __forceinline__ ZCtx make_zctx(const GemmParams& p) {
 // One output element through the epilogue chain documented in include/ldetr_hip.h.
 // cs / cb: the column's scale and bias, fetched once per column by the caller (not once per element).
 __device__ __forceinline__ float apply_epilogue(const GemmEpilogue& ep, float v, long orow, int n, int samp, long ldc, float inv_keep,
-                                                float cs, float cb) {
+                                                float cs, float cb, float res) {
     v *= ep.alpha;
     if (ep.row_scale) v *= ep.row_scale[orow];
     v *= cs;
     if (ep.samp_scale) v *= ep.samp_scale[(long)samp * ep.samp_ld + n];
     v += cb;
-    if (ep.residual) v += ep.residual[orow * ep.ldr + n];
+    v += res;
     if (ep.act == 1) v = fmaxf(v, 0.f);
     else if (ep.act == 2) v = (v > 0.f ? v : v * ep.act_alpha) * ep.act_gain;
     if (ep.mask_mode) {
@@ -579,7 +579,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
                 if (!direct) {
                     atomicAdd(dst, acc[i][j][r] * (ep.row_scale ? ep.alpha * ep.row_scale[orow] : ep.alpha));   // raw partial sums; the rest of the epilogue runs in epilogue_kernel
                 } else {
-                    float v = apply_epilogue(ep, acc[i][j][r], orow, n, samp, p.ldc, inv_keep, cs[j], cb[j]);
+                    float v = apply_epilogue(ep, acc[i][j][r], orow, n, samp, p.ldc, inv_keep, cs[j], cb[j], ep.residual ? ep.residual[orow * ep.ldr + n] : 0.f);
                     if (ep.accumulate) *dst += v; else *dst = v;
                 }
             }
@@ -671,7 +671,8 @@ __global__ __launch_bounds__(NW * 64) void gemm_small_kernel(GemmParams p) {
         float* dst = p.C + (long)m * p.ldc + n0 + c4;
 #pragma unroll
         for (int e = 0; e < 4; e++)
-            if (n0 + c4 + e < p.N) v[e] = apply_epilogue(ep, v[e], m, n0 + c4 + e, samp, p.ldc, inv_keep, ep.col_scale ? ep.col_scale[n0 + c4 + e] : 1.f, ep.col_bias ? ep.col_bias[n0 + c4 + e] : 0.f);
+            if (n0 + c4 + e < p.N) v[e] = apply_epilogue(ep, v[e], m, n0 + c4 + e, samp, p.ldc, inv_keep, ep.col_scale ? ep.col_scale[n0 + c4 + e] : 1.f, ep.col_bias ? ep.col_bias[n0 + c4 + e] : 0.f,
+                                                             ep.residual ? ep.residual[(long)m * ep.ldr + n0 + c4 + e] : 0.f);
         if (n0 + c4 + 3 < p.N && (p.ldc & 3) == 0 && ((((uintptr_t)p.C) & 15) == 0)) {
             float4 o = make_float4(v[0], v[1], v[2], v[3]);
             if (ep.accumulate) { float4 c = *reinterpret_cast<float4*>(dst); o.x += c.x; o.y += c.y; o.z += c.z; o.w += c.w; }
@@ -682,6 +683,138 @@ __global__ __launch_bounds__(NW * 64) void gemm_small_kernel(GemmParams p) {
                 if (n0 + c4 + e < p.N) { if (ep.accumulate) dst[e] += v[e]; else dst[e] = v[e]; }
         }
     }
+}
+
+static inline bool al16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
+#ifndef SKINNY_MIN_M
+#define SKINNY_MIN_M 4096
+#endif
+
+// ---------------------------------------------------------------------------------------------
+// Skinny-K dense contractions (the trunk's 1x1 convs and their data gradients with K = channels <= 256 on up to 2^20 pixels):
+// ~100 FLOP per byte of activation traffic at best, i.e. HBM-bound, and the LDS-tiled kernel above keeps too few bytes in
+// flight for that (load -> barrier -> 2 k-tiles -> store per block).  Here every wave keeps its 32 rows of A in registers as
+// MFMA operands for the whole launch (A is read exactly once, all of it in flight at once), B streams through LDS in
+// column chunks shared by the block's 4 waves, and each 32x32 product goes straight through the fused epilogue.
+//   TB: 0 = B stored [N, K] (conv weight OHWI / nn.Linear), 1 = B stored [K, N].   KS = ceil(K / 32) rounded up to 2, 4 or 8.
+template <int TB, int KS>
+__global__ __launch_bounds__(256, 2) void gemm_skinny_kernel(GemmParams p, int cols_per_block, int NC) {
+    using f32x16 = __attribute__((__vector_size__(16 * sizeof(float)))) float;
+    extern __shared__ __attribute__((aligned(16))) float Wsm[];   // [KS*32][NC + 4]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int cl = lane & 31, kl = lane >> 5;
+    const int pitch = NC + 4;
+    const int mrow = blockIdx.x * 128 + wave * 32 + cl;
+    float a[KS][16];
+#pragma unroll
+    for (int s = 0; s < KS; s++) {
+        const int kb = s * 32 + kl * 16;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (mrow < p.M && kb + 4 * j < p.K) {
+                v = *reinterpret_cast<const float4*>(p.A.p + (long)mrow * p.A.ld + kb + 4 * j);
+                if (p.A.scale) {   // one factor per k for all rows (FrozenBN scale of the incoming gradient)
+                    float4 f = *reinterpret_cast<const float4*>(p.A.scale + kb + 4 * j);
+                    v.x *= f.x; v.y *= f.y; v.z *= f.z; v.w *= f.w;
+                }
+            }
+            a[s][4 * j] = v.x; a[s][4 * j + 1] = v.y; a[s][4 * j + 2] = v.z; a[s][4 * j + 3] = v.w;
+        }
+    }
+    const GemmEpilogue& ep = p.ep;
+    const float inv_keep = ep.p_drop > 0.f ? 1.f / (1.f - ep.p_drop) : 1.f;
+    const int nbeg = blockIdx.y * cols_per_block, nend = min(p.N, nbeg + cols_per_block);
+    const int mbase = blockIdx.x * 128 + wave * 32 + 4 * kl;
+    for (int nc0 = nbeg; nc0 < nend; nc0 += NC) {
+        __syncthreads();
+        if (TB == 0) {
+            for (int u = tid; u < NC * KS * 8; u += 256) {   // consecutive threads = consecutive columns: conflict-free transposing store
+                const int n = u % NC, k4 = (u / NC) * 4;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (nc0 + n < nend && k4 < p.K) v = *reinterpret_cast<const float4*>(p.B.p + (long)(nc0 + n) * p.B.ld + k4);
+                Wsm[(k4 + 0) * pitch + n] = v.x; Wsm[(k4 + 1) * pitch + n] = v.y;
+                Wsm[(k4 + 2) * pitch + n] = v.z; Wsm[(k4 + 3) * pitch + n] = v.w;
+            }
+        } else {
+            const int q = NC / 4;
+            for (int u = tid; u < KS * 32 * q; u += 256) {
+                const int n4 = (u % q) * 4, k = u / q;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (k < p.K && nc0 + n4 < nend) v = *reinterpret_cast<const float4*>(p.B.p + (long)k * p.B.ld + nc0 + n4);
+                *reinterpret_cast<float4*>(Wsm + k * pitch + n4) = v;
+            }
+        }
+        __syncthreads();
+        for (int n32 = 0; n32 < NC && nc0 + n32 < nend; n32 += 32) {
+            const int n = nc0 + n32 + cl;
+            const bool nok = n < nend;
+            float res[16];
+            if (ep.residual) {   // issued ahead of the MFMA chain so their latency hides under it
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    const int m = mbase + (r & 3) + 8 * (r >> 2);
+                    res[r] = (nok && m < p.M) ? ep.residual[(long)m * ep.ldr + n] : 0.f;
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; r++) res[r] = 0.f;
+            }
+            const float cs = (ep.col_scale && nok) ? ep.col_scale[n] : 1.f;
+            const float cb = (ep.col_bias && nok) ? ep.col_bias[n] : 0.f;
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[r] = 0.f;
+            const float* wcol = Wsm + (kl * 16) * pitch + n32 + cl;
+#pragma unroll
+            for (int s = 0; s < KS; s++) {
+#pragma unroll
+                for (int t = 0; t < 16; t++)
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s][t], wcol[(s * 32 + t) * pitch], acc, 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);   // keep the LDS operand prefetch to one stage (else the scheduler hoists all K/2 reads and spills)
+            }
+            if (!nok) continue;
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int m = mbase + (r & 3) + 8 * (r >> 2);
+                if (m >= p.M) continue;
+                const int samp = (ep.samp_scale && p.pix_per_sample > 0) ? m / p.pix_per_sample : 0;
+                float v = apply_epilogue(ep, acc[r], m, n, samp, p.ldc, inv_keep, cs, cb, res[r]);
+                float* dst = p.C + (long)m * p.ldc + n;
+                if (ep.accumulate) *dst += v; else *dst = v;
+            }
+        }
+    }
+}
+
+// Eligibility + launch of the skinny-K kernel; returns -1 when the problem does not qualify (caller falls through).
+template <int TB>
+static int try_launch_skinny(const GemmParams& p, hipStream_t st) {
+    if (p.K > 256 || p.M < SKINNY_MIN_M || !p.A.vec || !p.B.vec || (p.K & 3) || p.zmode != 0 || p.splitk > 1) return -1;
+    if (p.A.scale && (p.A.scale_ld != 0 || !al16(p.A.scale))) return -1;
+    if (TB == 1 && (p.N & 3)) return -1;
+    const int KS = p.K <= 64 ? 2 : (p.K <= 128 ? 4 : 8);
+    const int NC = 512 / KS;   // 256 / 128 / 64 columns per LDS chunk (~66 KiB)
+    const int bx = cdiv(p.M, 128), chunks = cdiv(p.N, NC);
+    int ny = cdiv(768, bx); if (ny > chunks) ny = chunks; if (ny < 1) ny = 1;
+    const int cpb = cdiv(chunks, ny) * NC;
+    dim3 grid(bx, cdiv(p.N, cpb), 1);
+    const size_t lds = (size_t)KS * 32 * (NC + 4) * sizeof(float);
+    auto go = [&](auto kern, bool& raised) {
+        if (!raised) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+                set_error("gemm_skinny: cannot raise the dynamic LDS limit to %zu bytes", lds);
+                return (int)LDETR_ERR_LAUNCH;
+            }
+            raised = true;
+        }
+        hipLaunchKernelGGL(kern, grid, 256, lds, st, p, cpb, NC);
+        return check_launch("gemm_skinny");
+    };
+    static bool r2 = false, r4 = false, r8 = false;
+    if (KS == 2) return go(gemm_skinny_kernel<TB, 2>, r2);
+    if (KS == 4) return go(gemm_skinny_kernel<TB, 4>, r4);
+    return go(gemm_skinny_kernel<TB, 8>, r8);
 }
 
 template <int TA, int TB>
@@ -703,7 +836,8 @@ __global__ __launch_bounds__(256) void gemm_epilogue_kernel(EpiParams q) {
         long row = i / q.N; int n = (int)(i - row * q.N);
         int samp = (q.ep.samp_scale && q.pix_per_sample > 0) ? (int)(row / q.pix_per_sample) : 0;
         float* dst = q.C + row * q.ldc + n;
-        *dst = apply_epilogue(q.ep, *dst, row, n, samp, q.ldc, inv_keep, q.ep.col_scale ? q.ep.col_scale[n] : 1.f, q.ep.col_bias ? q.ep.col_bias[n] : 0.f);
+        *dst = apply_epilogue(q.ep, *dst, row, n, samp, q.ldc, inv_keep, q.ep.col_scale ? q.ep.col_scale[n] : 1.f, q.ep.col_bias ? q.ep.col_bias[n] : 0.f,
+                              q.ep.residual ? q.ep.residual[row * q.ep.ldr + n] : 0.f);
     }
 }
 
@@ -712,7 +846,6 @@ static bool epilogue_is_linear(const GemmEpilogue& ep) {
            ep.out_scale == 1.f;
 }
 
-static inline bool al16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 
 static void init_operand(Operand& o) { memset(&o, 0, sizeof(o)); o.KW = 1; o.KH = 1; o.stride = 1; o.C = 1; o.Cr = 1; }
 
@@ -899,6 +1032,10 @@ extern "C" int ldetr_gemm_f32(const float* A, int64_t lda, int ta, const float* 
         if (!ta && tb) return launch_small<0, 1>(p, st);
         if (ta && tb) return launch_small<1, 1>(p, st);
     }
+    if (auto_split && !ta) {
+        int rc = tb ? try_launch_skinny<1>(p, st) : try_launch_skinny<0>(p, st);
+        if (rc >= 0) return rc;
+    }
     if (!ta && !tb) return launch_gemm<OP_KC_DENSE, OP_KC_DENSE>(p, M, M, 1, auto_split, false, st);
     if (!ta && tb) return launch_gemm<OP_KC_DENSE, OP_RC_DENSE>(p, M, M, 1, auto_split, false, st);
     if (ta && tb) return launch_gemm<OP_RC_DENSE, OP_RC_DENSE>(p, M, M, 1, auto_split, false, st);
@@ -936,6 +1073,8 @@ extern "C" int ldetr_conv2d_fwd_f32(const float* x, const ldetr_tensor4* xt, con
     if (KH == 1 && KW == 1 && stride == 1 && pad == 0 && p.A.vec && !in_scale && xt->sw == xt->C && xt->sh == (long)xt->W * xt->C &&
         xt->sn == (long)xt->H * xt->W * xt->C) {
         p.A.ld = xt->C;  // pure GEMM view of a packed NHWC tensor
+        int rc = try_launch_skinny<0>(p, st);
+        if (rc >= 0) return rc;
         return launch_gemm<OP_KC_DENSE, OP_KC_DENSE>(p, p.M, p.M, 1, true, false, st);
     }
     return launch_gemm<OP_KC_CONV, OP_KC_DENSE>(p, p.M, p.M, 1, true, false, st);
@@ -963,6 +1102,14 @@ extern "C" int ldetr_conv2d_bwd_data_f32(const float* dy, const ldetr_tensor4* d
     p.zmode = 1; p.splitk = 1; p.pstep = stride; p.nsamp = dyt->N; p.pix_per_sample = IH * IW;
     p.M = dyt->N * IH * IW; p.K = KH * KW * dyt->C;
     fill_epilogue(p.ep, ep);
+    if (KH == 1 && KW == 1 && stride == 1 && pad == 0 && dyt->sw == dyt->C && dyt->sh == (long)dyt->W * dyt->C &&
+        dyt->sn == (long)dyt->H * dyt->W * dyt->C && (!dy_scale || dy_scale_ld == 0)) {
+        // 1x1 / stride 1: dx[M, Cin] = (dy * scale)[M, Cout] . w[Cout, Cin], a dense contraction over Cout
+        GemmParams g = p;
+        g.zmode = 0; g.A.ld = dyt->C; g.B.ld = Cin; g.B.vec = al16(w) && (Cin % 4 == 0);
+        int rc = try_launch_skinny<1>(g, (hipStream_t)stream);
+        if (rc >= 0) return rc;
+    }
     int Mmax = dyt->N * cdiv(IH, stride) * cdiv(IW, stride);
     return launch_gemm<OP_KC_CONVT, OP_RC_WT>(p, Mmax, (long)p.M, stride * stride, true, false, (hipStream_t)stream);
 }

@@ -139,6 +139,26 @@ def test_gemm_variants(dev, M, N, K):
     assert_close(c, At.t() @ Bt, 2e-6, 'TN split-K')
 
 
+@pytest.mark.parametrize('M,N,K', [(5000, 77, 100), (4096, 256, 64), (4100, 36, 256), (8192, 300, 132)])
+def test_gemm_skinny_k(dev, M, N, K):
+    """Dense GEMMs with M >= 4096 and K <= 256 take the register-stationary kernel: both B layouts, full epilogue."""
+    from layoutdetr_amd.hip import core
+    torch.manual_seed(44)
+    A = torch.randn(M, K); W = torch.randn(N, K); b = torch.randn(N); s = torch.rand(N) + 0.5; R = torch.randn(M, N)
+    Ad, Wd, bd, sd, Rd = [t.to(dev) for t in (A, W, b, s, R)]
+    ep = core.epilogue(alpha=0.5, col_scale=sd, col_bias=bd, residual=Rd, act=core.ACT_RELU)
+    ref = F.relu(0.5 * (A.double() @ W.double().t()).float() * s + b + R)
+    c = core.gemm(Ad, Wd, 0, 0, M, N, K, ep=ep)
+    assert_close(c, ref, 3e-6, 'skinny NT')
+    N4 = (N + 3) // 4 * 4
+    Bt = torch.randn(K, N4); Btd = Bt.to(dev)
+    c = core.gemm(Ad, Btd, 0, 1, M, N4, K)
+    assert_close(c, (A.double() @ Bt.double()).float(), 3e-6, 'skinny NN')
+    base = torch.randn(M, N4); out = base.to(dev).clone()
+    core.gemm(Ad, Btd, 0, 1, M, N4, K, out=out, ep=core.epilogue(accumulate=True))
+    assert_close(out, base + (A.double() @ Bt.double()).float(), 3e-6, 'skinny NN accumulate')
+
+
 def test_gemm_epilogue(dev):
     from layoutdetr_amd.hip import core
     torch.manual_seed(5)
@@ -217,6 +237,14 @@ CONV_CASES = [
     (2, 8, 8, 512, 256, 1, 1, 0),
     (2, 4, 4, 256, 1024, 1, 1, 0),
     (2, 32, 32, 256, 128, 1, 1, 0),
+    # 1x1 / stride 1 with >= 4096 pixels and K <= 256: the register-stationary skinny-K kernel (fwd and data gradient),
+    # incl. ragged pixel counts, channel counts that are not multiples of 32 and every K bucket (<=64, <=128, <=256)
+    (4, 32, 32, 64, 256, 1, 1, 0),
+    (4, 32, 32, 256, 64, 1, 1, 0),
+    (2, 47, 49, 72, 200, 1, 1, 0),
+    (2, 48, 48, 128, 36, 1, 1, 0),
+    (1, 65, 65, 40, 260, 1, 1, 0),
+    (2, 64, 64, 192, 96, 1, 1, 0),
 ]
 
 
