@@ -14,6 +14,7 @@
 // k-major ([k][row], row stride R+2 -> conflict-free MFMA operand reads and transposing writes),
 // double-buffered with register staging (global loads for tile t+1 are in flight during the
 // MFMAs of tile t; one barrier per k-tile).
+#include <cstdlib>
 #include "ldetr_common.hpp"
 #include "../../include/ldetr_hip.h"
 
@@ -698,13 +699,14 @@ static inline bool al16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 // column chunks shared by the block's 4 waves, and each 32x32 product goes straight through the fused epilogue.
 //   TB: 0 = B stored [N, K] (conv weight OHWI / nn.Linear), 1 = B stored [K, N].   KS = ceil(K / 32) rounded up to 2, 4 or 8.
 template <int TB, int KS>
-__global__ __launch_bounds__(256, 2) void gemm_skinny_kernel(GemmParams p, int cols_per_block, int NC) {
+__global__ __launch_bounds__(256, (KS == 2 ? 4 : (KS == 4 ? 3 : 2))) void gemm_skinny_kernel(GemmParams p, int cols_per_block, int NC) {
     using f32x16 = __attribute__((__vector_size__(16 * sizeof(float)))) float;
     extern __shared__ __attribute__((aligned(16))) float Wsm[];   // [KS*32][NC + 4]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int cl = lane & 31, kl = lane >> 5;
     const int pitch = NC + 4;
-    const int mrow = blockIdx.x * 128 + wave * 32 + cl;
+    const int mb = blockIdx.x * 128 + wave * 32;   // first of this wave's 32 rows
+    const int mrow = mb + cl;
     float a[KS][16];
 #pragma unroll
     for (int s = 0; s < KS; s++) {
@@ -723,67 +725,90 @@ __global__ __launch_bounds__(256, 2) void gemm_skinny_kernel(GemmParams p, int c
         }
     }
     const GemmEpilogue& ep = p.ep;
-    const float inv_keep = ep.p_drop > 0.f ? 1.f / (1.f - ep.p_drop) : 1.f;
     const int nbeg = blockIdx.y * cols_per_block, nend = min(p.N, nbeg + cols_per_block);
-    const int mbase = blockIdx.x * 128 + wave * 32 + 4 * kl;
-    for (int nc0 = nbeg; nc0 < nend; nc0 += NC) {
-        __syncthreads();
-        if (TB == 0) {
-            for (int u = tid; u < NC * KS * 8; u += 256) {   // consecutive threads = consecutive columns: conflict-free transposing store
-                const int n = u % NC, k4 = (u / NC) * 4;
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (nc0 + n < nend && k4 < p.K) v = *reinterpret_cast<const float4*>(p.B.p + (long)(nc0 + n) * p.B.ld + k4);
-                Wsm[(k4 + 0) * pitch + n] = v.x; Wsm[(k4 + 1) * pitch + n] = v.y;
-                Wsm[(k4 + 2) * pitch + n] = v.z; Wsm[(k4 + 3) * pitch + n] = v.w;
-            }
-        } else {
-            const int q = NC / 4;
-            for (int u = tid; u < KS * 32 * q; u += 256) {
-                const int n4 = (u % q) * 4, k = u / q;
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (k < p.K && nc0 + n4 < nend) v = *reinterpret_cast<const float4*>(p.B.p + (long)k * p.B.ld + nc0 + n4);
-                *reinterpret_cast<float4*>(Wsm + k * pitch + n4) = v;
-            }
-        }
-        __syncthreads();
-        for (int n32 = 0; n32 < NC && nc0 + n32 < nend; n32 += 32) {
-            const int n = nc0 + n32 + cl;
-            const bool nok = n < nend;
-            float res[16];
-            if (ep.residual) {   // issued ahead of the MFMA chain so their latency hides under it
+    // C and the residual go through buffer descriptors: one VGPR byte offset per lane + a scalar row offset per element
+    // (the host guarantees both extents fit 31 bits), instead of a 64-bit address pair per element.
+    const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc(p.C, 0, (int)((long)p.M * p.ldc * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(ep.residual ? ep.residual : p.C), 0,
+                                                                          ep.residual ? (int)((long)p.M * ep.ldr * 4) : 0, 0x00020000);
+    const int mlane = mb + 4 * kl;                       // row of element r: mlane + (r & 3) + 8 * (r >> 2)
+    const int voc = (mlane * (int)p.ldc + cl) * 4, vor = (mlane * (int)ep.ldr + cl) * 4;
+    const int ldc4 = (int)p.ldc * 4, ldr4 = (int)ep.ldr * 4;
+    const bool full_rows = mb + 32 <= p.M;
+    const int spc = NC / 32;                             // 32-column steps per LDS chunk
+    const int nsteps = (nend - nbeg + 31) / 32;
+    float res[16], resn[16];
+    auto load_res = [&](int step, float (&dstv)[16]) {
+        const int n = nbeg + step * 32 + cl;
 #pragma unroll
-                for (int r = 0; r < 16; r++) {
-                    const int m = mbase + (r & 3) + 8 * (r >> 2);
-                    res[r] = (nok && m < p.M) ? ep.residual[(long)m * ep.ldr + n] : 0.f;
+        for (int r = 0; r < 16; r++) {
+            const int ro = (r & 3) + 8 * (r >> 2);
+            float v = 0.f;
+            if (n < nend && (full_rows || mlane + ro < p.M)) v = __builtin_amdgcn_raw_buffer_load_b32(rr, vor + (nbeg + step * 32) * 4, ro * ldr4, 0);
+            dstv[r] = v;
+        }
+    };
+#pragma unroll
+    for (int r = 0; r < 16; r++) { res[r] = 0.f; resn[r] = 0.f; }
+    if (ep.residual && nsteps > 0) load_res(0, res);
+    for (int step = 0; step < nsteps; step++) {
+        const int nc0 = nbeg + (step / spc) * NC;
+        if (step % spc == 0) {
+            __syncthreads();
+            if (TB == 0) {
+                for (int u = tid; u < NC * KS * 8; u += 256) {   // consecutive threads = consecutive columns: conflict-free transposing store
+                    const int n = u % NC, k4 = (u / NC) * 4;
+                    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (nc0 + n < nend && k4 < p.K) v = *reinterpret_cast<const float4*>(p.B.p + (long)(nc0 + n) * p.B.ld + k4);
+                    Wsm[(k4 + 0) * pitch + n] = v.x; Wsm[(k4 + 1) * pitch + n] = v.y;
+                    Wsm[(k4 + 2) * pitch + n] = v.z; Wsm[(k4 + 3) * pitch + n] = v.w;
                 }
             } else {
-#pragma unroll
-                for (int r = 0; r < 16; r++) res[r] = 0.f;
+                const int q = NC / 4;
+                for (int u = tid; u < KS * 32 * q; u += 256) {
+                    const int n4 = (u % q) * 4, k = u / q;
+                    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (k < p.K && nc0 + n4 < nend) v = *reinterpret_cast<const float4*>(p.B.p + (long)k * p.B.ld + nc0 + n4);
+                    *reinterpret_cast<float4*>(Wsm + k * pitch + n4) = v;
+                }
             }
-            const float cs = (ep.col_scale && nok) ? ep.col_scale[n] : 1.f;
-            const float cb = (ep.col_bias && nok) ? ep.col_bias[n] : 0.f;
-            f32x16 acc;
+            __syncthreads();
+        }
+        if (ep.residual && step + 1 < nsteps) load_res(step + 1, resn);   // one step ahead: its latency hides under this step's MFMA chain
+        const int n32 = (step % spc) * 32;
+        const int n = nc0 + n32 + cl;
+        const bool nok = n < nend;
+        const float cs = (ep.col_scale && nok) ? ep.col_scale[n] : 1.f;
+        const float cb = (ep.col_bias && nok) ? ep.col_bias[n] : 0.f;
+        f32x16 acc;
 #pragma unroll
-            for (int r = 0; r < 16; r++) acc[r] = 0.f;
-            const float* wcol = Wsm + (kl * 16) * pitch + n32 + cl;
+        for (int r = 0; r < 16; r++) acc[r] = 0.f;
+        const float* wcol = Wsm + (kl * 16) * pitch + n32 + cl;
 #pragma unroll
-            for (int s = 0; s < KS; s++) {
+        for (int s = 0; s < KS; s++) {
 #pragma unroll
-                for (int t = 0; t < 16; t++)
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s][t], wcol[(s * 32 + t) * pitch], acc, 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);   // keep the LDS operand prefetch to one stage (else the scheduler hoists all K/2 reads and spills)
-            }
-            if (!nok) continue;
+            for (int t = 0; t < 16; t++)
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s][t], wcol[(s * 32 + t) * pitch], acc, 0, 0, 0);
+        }
+        if (nok) {
+            const int vo = voc + (nc0 + n32) * 4;
 #pragma unroll
             for (int r = 0; r < 16; r++) {
-                const int m = mbase + (r & 3) + 8 * (r >> 2);
-                if (m >= p.M) continue;
-                const int samp = (ep.samp_scale && p.pix_per_sample > 0) ? m / p.pix_per_sample : 0;
-                float v = apply_epilogue(ep, acc[r], m, n, samp, p.ldc, inv_keep, cs, cb, res[r]);
-                float* dst = p.C + (long)m * p.ldc + n;
-                if (ep.accumulate) *dst += v; else *dst = v;
+                const int ro = (r & 3) + 8 * (r >> 2);
+                const int m = mlane + ro;
+                if (!full_rows && m >= p.M) continue;
+                // lean epilogue (the launcher rejects per-sample scales, backward masks and dropout: their per-row index
+                // arithmetic gets hoisted out of the step loop and spills this kernel's A-stationary register budget)
+                float v = acc[r] * ep.alpha * cs + cb + res[r];
+                if (ep.act == 1) v = fmaxf(v, 0.f);
+                else if (ep.act == 2) v = (v > 0.f ? v : v * ep.act_alpha) * ep.act_gain;
+                v *= ep.out_scale;
+                if (ep.accumulate) v += __builtin_amdgcn_raw_buffer_load_b32(rc, vo, ro * ldc4, 0);
+                __builtin_amdgcn_raw_buffer_store_b32(v, rc, vo, ro * ldc4, 0);
             }
         }
+#pragma unroll
+        for (int r = 0; r < 16; r++) res[r] = resn[r];
     }
 }
 
@@ -793,8 +818,11 @@ static int try_launch_skinny(const GemmParams& p, hipStream_t st) {
     if (p.K > 256 || p.M < SKINNY_MIN_M || !p.A.vec || !p.B.vec || (p.K & 3) || p.zmode != 0 || p.splitk > 1) return -1;
     if (p.A.scale && (p.A.scale_ld != 0 || !al16(p.A.scale))) return -1;
     if (TB == 1 && (p.N & 3)) return -1;
+    if (p.ep.samp_scale || p.ep.mask_mode || p.ep.p_drop > 0.f || p.ep.row_scale) return -1;   // lean epilogue only
+    if ((long)p.M * p.ldc * 4 >= (1l << 31) || (p.ep.residual && (long)p.M * p.ep.ldr * 4 >= (1l << 31))) return -1;   // 32-bit buffer offsets
     const int KS = p.K <= 64 ? 2 : (p.K <= 128 ? 4 : 8);
-    const int NC = 512 / KS;   // 256 / 128 / 64 columns per LDS chunk (~66 KiB)
+    int NC = KS == 2 ? 128 : 64;   // columns per LDS chunk: ~34 KiB (K <= 128: 4 resp. 3 blocks per CU) or ~68 KiB (K <= 256: 2 per CU)
+    if (const char* e = getenv("LDETR_SKINNY_NC")) { int v = atoi(e); if (v >= 32 && v % 32 == 0 && v < NC) NC = v; }   // tuning aid
     const int bx = cdiv(p.M, 128), chunks = cdiv(p.N, NC);
     int ny = cdiv(768, bx); if (ny > chunks) ny = chunks; if (ny < 1) ny = 1;
     const int cpb = cdiv(chunks, ny) * NC;
