@@ -744,7 +744,7 @@ __global__ __launch_bounds__(256, (KS == 2 ? 4 : (KS == 4 ? 3 : 2))) void gemm_s
         for (int r = 0; r < 16; r++) {
             const int ro = (r & 3) + 8 * (r >> 2);
             float v = 0.f;
-            if (n < nend && (full_rows || mlane + ro < p.M)) v = __builtin_amdgcn_raw_buffer_load_b32(rr, vor + (nbeg + step * 32) * 4, ro * ldr4, 0);
+            if (n < nend && (full_rows || mlane + ro < p.M)) v = __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(rr, vor + (nbeg + step * 32) * 4, ro * ldr4, 0));   // b32 = raw bits
             dstv[r] = v;
         }
     };
@@ -803,8 +803,8 @@ __global__ __launch_bounds__(256, (KS == 2 ? 4 : (KS == 4 ? 3 : 2))) void gemm_s
                 if (ep.act == 1) v = fmaxf(v, 0.f);
                 else if (ep.act == 2) v = (v > 0.f ? v : v * ep.act_alpha) * ep.act_gain;
                 v *= ep.out_scale;
-                if (ep.accumulate) v += __builtin_amdgcn_raw_buffer_load_b32(rc, vo, ro * ldc4, 0);
-                __builtin_amdgcn_raw_buffer_store_b32(v, rc, vo, ro * ldc4, 0);
+                if (ep.accumulate) v += __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(rc, vo, ro * ldc4, 0));
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_int(v), rc, vo, ro * ldc4, 0);
             }
         }
 #pragma unroll

@@ -139,7 +139,7 @@ def test_gemm_variants(dev, M, N, K):
     assert_close(c, At.t() @ Bt, 2e-6, 'TN split-K')
 
 
-@pytest.mark.parametrize('M,N,K', [(5000, 77, 100), (4096, 256, 64), (4100, 36, 256), (8192, 300, 132)])
+@pytest.mark.parametrize('M,N,K', [(20000, 77, 100), (4096, 256, 64), (33000, 36, 256), (8192, 300, 132), (16384, 512, 128), (4100, 1000, 32)])
 def test_gemm_skinny_k(dev, M, N, K):
     """Dense GEMMs with M >= 4096 and K <= 256 take the register-stationary kernel: both B layouts, full epilogue."""
     from layoutdetr_amd.hip import core
