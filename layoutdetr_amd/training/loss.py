@@ -52,7 +52,7 @@ class StyleGAN2Loss(Loss):
                  Dreal_bbox_cls_weight=50.0, Dreal_bbox_rec_weight=500.0, Dreal_text_rec_weight=0.1, Dreal_text_len_rec_weight=2.0,
                  Dreal_im_rec_weight=0.5, Ggen_bbox_rec_weight=100.0, Ggen_bbox_gIoU_weight=4.0, Ggen_overlapping_weight=7.0,
                  Ggen_alignment_weight=17.0, Ggen_z_rec_weight=5.0, Ggen_bbox_cls_weight=50.0, Ggen_text_rec_weight=1.0,
-                 Ggen_text_len_rec_weight=1.0, report_fn=None):
+                 Ggen_text_len_rec_weight=1.0, report_fn=None, share_D_trunk=True):
         super().__init__()
         self.device = device
         self.G = G
@@ -67,6 +67,11 @@ class StyleGAN2Loss(Loss):
                       Ggen_bbox_gIoU=Ggen_bbox_gIoU_weight, Ggen_overlapping=Ggen_overlapping_weight, Ggen_alignment=Ggen_alignment_weight,
                       Ggen_z_rec=Ggen_z_rec_weight, Ggen_bbox_cls=Ggen_bbox_cls_weight, Ggen_text_rec=Ggen_text_rec_weight,
                       Ggen_text_len_rec=Ggen_text_len_rec_weight)
+        # Dmain evaluates D on the generated and on the real layout of the SAME backgrounds with the SAME weights; D's ResNet
+        # trunk is deterministic, so both passes can read one trunk evaluation and its backward runs once on the summed
+        # gradient (the reference recomputes it, training/loss.py:176-210: two run_D calls, two backward calls).  Same losses and
+        # gradients up to fp32 summation order; share_D_trunk=False restores the reference's call pattern.
+        self.share_D_trunk = share_D_trunk
         self.report = report_fn if report_fn is not None else (lambda name, value: None)
         self.last = {}
 
@@ -75,10 +80,12 @@ class StyleGAN2Loss(Loss):
             return self.G(z, bbox_class, bbox_real, bbox_text, bbox_patch, padding_mask, background, c)
         return self.G(z, bbox_class, bbox_real, bbox_text, bbox_patch, padding_mask, background, c, reconst)
 
-    def run_D(self, bbox, bbox_class, bbox_text, bbox_patch, padding_mask, background, c, reconst=False, blur_sigma=0, update_emas=False):
+    def run_D(self, bbox, bbox_class, bbox_text, bbox_patch, padding_mask, background, c, reconst=False, blur_sigma=0, update_emas=False,
+              trunk_out=None):
+        kw = {} if trunk_out is None else dict(trunk_out=trunk_out)
         if not reconst:
-            return self.D(bbox, bbox_class, bbox_text, bbox_patch, padding_mask, background, c)
-        return self.D(bbox, bbox_class, bbox_text, bbox_patch, padding_mask, background, c, reconst)
+            return self.D(bbox, bbox_class, bbox_text, bbox_patch, padding_mask, background, c, **kw)
+        return self.D(bbox, bbox_class, bbox_text, bbox_patch, padding_mask, background, c, reconst, **kw)
 
     def g_main_loss(self, bbox_real, bbox_class, bbox_text, bbox_patch, padding_mask, background, gen_z, gen_c):
         w = self.w
@@ -105,22 +112,23 @@ class StyleGAN2Loss(Loss):
         self.last = dict(bbox_fake=bbox_fake.detach(), **{k: v.detach() for k, v in terms.items()})
         return total.mean()
 
-    def d_gen_loss(self, bbox_real, bbox_class, bbox_text, bbox_patch, padding_mask, background, gen_z, gen_c):
+    def d_gen_loss(self, bbox_real, bbox_class, bbox_text, bbox_patch, padding_mask, background, gen_z, gen_c, trunk_out=None):
         bbox_fake = self.run_G(gen_z, bbox_class, bbox_real, bbox_text, bbox_patch, padding_mask, background, gen_c, update_emas=True)
-        gen_logits, gen_logits_uncond = self.run_D(bbox_fake, bbox_class, bbox_text, bbox_patch, padding_mask, background, gen_c, update_emas=True)
+        gen_logits, gen_logits_uncond = self.run_D(bbox_fake, bbox_class, bbox_text, bbox_patch, padding_mask, background, gen_c, update_emas=True,
+                                                   trunk_out=trunk_out)
         loss_Dgen = F.softplus(gen_logits)
         loss_Dgen_uncond = F.softplus(gen_logits_uncond)
         self.report('Loss/D/loss_Dgen', loss_Dgen)
         self.report('Loss/D/loss_Dgen_uncond', loss_Dgen_uncond)
         return (loss_Dgen + loss_Dgen_uncond).mean()
 
-    def d_real_loss(self, bbox_real, bbox_class, bbox_text, bbox_patch, padding_mask, background, real_c):
+    def d_real_loss(self, bbox_real, bbox_class, bbox_text, bbox_patch, padding_mask, background, real_c, trunk_out=None):
         w = self.w
         valid = ~padding_mask
         static = bool(getattr(self.D, 'static_shapes', False))
         bbox_real_tmp = bbox_real.detach()
         (real_logits, real_logits_uncond, bbox_rec, cls_logits, loss_lm, loss_text_len, bg_rec, bbox_rec_uncond,
-         cls_logits_uncond) = self.run_D(bbox_real_tmp, bbox_class, bbox_text, bbox_patch, padding_mask, background, real_c, reconst=True)
+         cls_logits_uncond) = self.run_D(bbox_real_tmp, bbox_class, bbox_text, bbox_patch, padding_mask, background, real_c, reconst=True, trunk_out=trunk_out)
         terms = dict(
             loss_Dreal=F.softplus(-real_logits),
             loss_Dreal_uncond=F.softplus(-real_logits_uncond),
@@ -146,5 +154,11 @@ class StyleGAN2Loss(Loss):
         if phase == 'Gmain':
             self.g_main_loss(bbox_real, bbox_class, bbox_text, bbox_patch, padding_mask, background, gen_z, gen_c).mul(gain).backward()
         if phase == 'Dmain':
-            self.d_gen_loss(bbox_real, bbox_class, bbox_text, bbox_patch, padding_mask, background, gen_z, gen_c).mul(gain).backward()
-            self.d_real_loss(bbox_real, bbox_class, bbox_text, bbox_patch, padding_mask, background, real_c).mul(gain).backward()
+            if self.share_D_trunk and hasattr(self.D, 'trunk'):
+                trunk_out = self.D.trunk(background)
+                l_gen = self.d_gen_loss(bbox_real, bbox_class, bbox_text, bbox_patch, padding_mask, background, gen_z, gen_c, trunk_out=trunk_out)
+                l_real = self.d_real_loss(bbox_real, bbox_class, bbox_text, bbox_patch, padding_mask, background, real_c, trunk_out=trunk_out)
+                (l_gen + l_real).mul(gain).backward()   # one backward: the trunk sees the summed gradient of both passes
+            else:
+                self.d_gen_loss(bbox_real, bbox_class, bbox_text, bbox_patch, padding_mask, background, gen_z, gen_c).mul(gain).backward()
+                self.d_real_loss(bbox_real, bbox_class, bbox_text, bbox_patch, padding_mask, background, real_c).mul(gain).backward()

@@ -243,10 +243,16 @@ class Discriminator(nn.Module):
         self.bbox_embed_uncond = Linear(hidden_dim, 4)
         self.fc_out_cls_uncond = Linear(hidden_dim, num_bbox_labels)
 
-    def forward(self, bbox, bbox_class, bbox_text, bbox_patch, padding_mask, background, c, reconst=False):
+    def trunk(self, background):
+        """ResNet trunk + position encoding of the backgrounds (reference: the first statement of D.forward,
+        training/networks_detr.py:382-385).  Deterministic in train mode (FrozenBatchNorm, no dropout), so one
+        evaluation can serve every D pass of a phase that sees the same backgrounds (`trunk_out=`)."""
         if isinstance(background, (list, torch.Tensor)):
             background = nested_tensor_from_tensor_list(background)
-        bg_feat, pos = self.backbone(background)
+        return self.backbone(background)
+
+    def forward(self, bbox, bbox_class, bbox_text, bbox_patch, padding_mask, background, c, reconst=False, trunk_out=None):
+        bg_feat, pos = self.trunk(background) if trunk_out is None else trunk_out
         bg_feat, mask = bg_feat[-1].decompose()
         assert mask is not None
 
