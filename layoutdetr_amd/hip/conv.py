@@ -105,9 +105,14 @@ class _ConvFn(torch.autograd.Function):
                     core.ptr(x), ctypes.byref(xt), core.ptr(dpre_s), ctypes.byref(dyt_s), core.ptr(dw_ohwi), KH, KW,
                     stride, pad, sk, None, 0, None, 0, acc, core.stream()), 'conv2d_bwd_weight'))
             else:
-                core.engine_call('ldetr_conv2d_bwd_weight_f32', 2.0 * N * OH * OW * O * KH * KW * I, lambda: core.check(core.lib().ldetr_conv2d_bwd_weight_f32(
-                    core.ptr(x), ctypes.byref(xt), core.ptr(dpre), ctypes.byref(dyt), core.ptr(dw_ohwi), KH, KW, stride,
-                    pad, sk, None, 0, core.ptr(sc), 0, acc, core.stream()), 'conv2d_bwd_weight'))
+                def wgrad():
+                    core.engine_call('ldetr_conv2d_bwd_weight_f32', 2.0 * N * OH * OW * O * KH * KW * I, lambda: core.check(core.lib().ldetr_conv2d_bwd_weight_f32(
+                        core.ptr(x), ctypes.byref(xt), core.ptr(dpre), ctypes.byref(dyt), core.ptr(dw_ohwi), KH, KW, stride,
+                        pad, sk, None, 0, core.ptr(sc), 0, acc, core.stream()), 'conv2d_bwd_weight'))
+                if acc:
+                    core.run_on_side(wgrad, keep=(x, dpre, sc))
+                else:
+                    wgrad()
             dw = None if acc else _grad_to_oihw(dw_ohwi)
         dres = dpre if need_res else None
         return dx, dw, None, dshift, dres, None, None, None, None

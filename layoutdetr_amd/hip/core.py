@@ -69,6 +69,45 @@ def check(rc, what=''):
     _lib.check(rc, what)
 
 
+# Weight-gradient side stream.  The data-gradient chain (dX of layer n feeds layer n-1) is the critical path of a backward pass;
+# the weight/bias gradients only feed the optimizer.  They are launched on a second HIP stream (forked after their inputs are
+# ready, joined once after backward), so the hundreds of latency-bound dW launches of the transformer blocks overlap the dX
+# chain instead of sitting in it; inside a captured phase the fork/join become parallel branches of the hipGraph.
+SIDE_WGRAD = os.environ.get('LDETR_SIDE_WGRAD', '1') != '0'
+_side_streams = {}
+_side_keep = []
+_side_busy = [False]
+
+
+def run_on_side(fn, keep=()):
+    """Run fn() (kernel launches that only write flat .grad buffers) on the side stream, ordered after everything queued so far
+    on the current stream.  `keep`: tensors fn reads; held until join_side() so the allocator cannot recycle them early."""
+    if not SIDE_WGRAD:
+        return fn()
+    main = torch.cuda.current_stream()
+    key = main.device.index
+    side = _side_streams.get(key)
+    if side is None:
+        side = _side_streams[key] = torch.cuda.Stream(device=main.device)
+    side.wait_stream(main)
+    with torch.cuda.stream(side):
+        fn()
+    _side_keep.append(keep)
+    _side_busy[0] = True
+
+
+def join_side():
+    """Make the current stream wait for the side-stream gradient launches (call after backward, before the gradients are read)."""
+    if not _side_busy[0]:
+        return
+    main = torch.cuda.current_stream()
+    side = _side_streams.get(main.device.index)
+    if side is not None:
+        main.wait_stream(side)
+    del _side_keep[:]
+    _side_busy[0] = False
+
+
 def require_gpu(*tensors):
     for t in tensors:
         if t is not None and t.device.type != 'cuda':

@@ -82,7 +82,8 @@ class _LinearFn(torch.autograd.Function):
             db = None
             if need_b:
                 if gb is not None:
-                    core.check(core.lib().ldetr_colsum_f32(core.ptr(dpre), core.ptr(gb), 1, M, N, core.stream()), 'colsum')
+                    core.run_on_side(lambda: core.check(core.lib().ldetr_colsum_f32(core.ptr(dpre), core.ptr(gb), 1, M, N, core.stream()), 'colsum'),
+                                     keep=(dpre,))
                 else:
                     db = core.colsum(dpre).reshape(-1)
         dx = dw = None
@@ -90,7 +91,8 @@ class _LinearFn(torch.autograd.Function):
             dx = core.gemm(dpre, w, 0, 1, M, K, N, ep=core.epilogue(alpha=wscale)).reshape(xshape)
         if need_w:
             if gw is not None and gw.is_contiguous():
-                core.gemm(dpre, x2, 1, 1, N, K, M, out=gw, ep=core.epilogue(alpha=wscale, accumulate=True))
+                core.run_on_side(lambda: core.gemm(dpre, x2, 1, 1, N, K, M, out=gw, ep=core.epilogue(alpha=wscale, accumulate=True)),
+                                 keep=(dpre, x2))
             else:
                 dw = core.gemm(dpre, x2, 1, 1, N, K, M, ep=core.epilogue(alpha=wscale))
         full = wparam.shape[0]

@@ -6,6 +6,8 @@ R1 / path-length regularisation need double-backward through the fused kernels a
 import torch
 import torch.nn.functional as F
 
+from ..hip import core
+
 from ..metrics.metric_layoutnet import compute_alignment, compute_overlap, generalized_iou_loss
 
 
@@ -153,12 +155,15 @@ class StyleGAN2Loss(Loss):
             phase = {'Dreg': 'none', 'Dboth': 'Dmain'}.get(phase, phase)
         if phase == 'Gmain':
             self.g_main_loss(bbox_real, bbox_class, bbox_text, bbox_patch, padding_mask, background, gen_z, gen_c).mul(gain).backward()
+            core.join_side()
         if phase == 'Dmain':
             if self.share_D_trunk and hasattr(self.D, 'trunk'):
                 trunk_out = self.D.trunk(background)
                 l_gen = self.d_gen_loss(bbox_real, bbox_class, bbox_text, bbox_patch, padding_mask, background, gen_z, gen_c, trunk_out=trunk_out)
                 l_real = self.d_real_loss(bbox_real, bbox_class, bbox_text, bbox_patch, padding_mask, background, real_c, trunk_out=trunk_out)
                 (l_gen + l_real).mul(gain).backward()   # one backward: the trunk sees the summed gradient of both passes
+                core.join_side()
             else:
                 self.d_gen_loss(bbox_real, bbox_class, bbox_text, bbox_patch, padding_mask, background, gen_z, gen_c).mul(gain).backward()
                 self.d_real_loss(bbox_real, bbox_class, bbox_text, bbox_patch, padding_mask, background, real_c).mul(gain).backward()
+                core.join_side()

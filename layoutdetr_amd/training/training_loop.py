@@ -115,6 +115,7 @@ class DataParallelStep(object):
 
     def apply(self, phase):
         fm = phase.fm
+        core.join_side()   # weight-gradient launches of a backward that was not run through Loss.accumulate_gradients
         self.exchange(fm.gflat)
         phase.step += 1
         scale = 1.0 / self.world
