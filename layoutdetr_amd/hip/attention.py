@@ -51,6 +51,55 @@ class _AttnFn(torch.autograd.Function):
         return dq, dk, dv, None, None, None, None, None, None
 
 
+class _AttnPackedFn(torch.autograd.Function):
+    """Self-attention on a packed projection: qkv is [B*L, 3d] (v_sep None) or [B*L, 2d] = (q | k) with v separate.
+    Autograd sees ONE input and gets ONE packed gradient: slicing q/k/v out of the projection as autograd views costs
+    a zero-fill + copy per slice and two adds per attention in backward (SliceBackward), 8 launches of pure overhead."""
+
+    @staticmethod
+    def forward(ctx, qkv, v_sep, kpm, B, H, L, p_drop):
+        core.require_gpu(qkv, v_sep, kpm)
+        assert qkv.stride(1) == 1
+        d = qkv.shape[1] // (3 if v_sep is None else 2)
+        dh = d // H
+        q, k = qkv[:, :d], qkv[:, d:2 * d]
+        v = qkv[:, 2 * d:] if v_sep is None else v_sep
+        assert v.stride(1) == 1
+        out = torch.empty((B * L, d), device=qkv.device, dtype=torch.float32)
+        lse = torch.empty((B * H * L,), device=qkv.device, dtype=torch.float32)
+        seed = core.next_seed() if p_drop > 0 else 0
+        scale = 1.0 / math.sqrt(dh)
+        core.check(core.lib().ldetr_attention_fwd_f32(
+            core.ptr(q), q.stride(0), core.ptr(k), k.stride(0), core.ptr(v), v.stride(0), core.ptr(kpm),
+            core.ptr(out), d, core.ptr(lse), B, H, L, L, dh, scale, p_drop, seed, core.seed_ptr() if p_drop > 0 else None,
+            core.stream()), 'attention_fwd')
+        ctx.save_for_backward(qkv, v_sep, kpm, out, lse)
+        ctx.cfg = (B, H, L, dh, scale, p_drop, seed)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        qkv, v_sep, kpm, out, lse = ctx.saved_tensors
+        B, H, L, dh, scale, p_drop, seed = ctx.cfg
+        d = H * dh
+        q, k = qkv[:, :d], qkv[:, d:2 * d]
+        v = qkv[:, 2 * d:] if v_sep is None else v_sep
+        dout = core.f32c(dout)
+        dqkv = torch.empty_like(qkv)
+        dq, dk = dqkv[:, :d], dqkv[:, d:2 * d]
+        dv = dqkv[:, 2 * d:] if v_sep is None else torch.empty((B * L, d), device=qkv.device, dtype=torch.float32)
+        core.check(core.lib().ldetr_attention_bwd_f32(
+            core.ptr(q), q.stride(0), core.ptr(k), k.stride(0), core.ptr(v), v.stride(0), core.ptr(kpm),
+            core.ptr(out), d, core.ptr(lse), core.ptr(dout), d, core.ptr(dq), dq.stride(0), core.ptr(dk), dk.stride(0),
+            core.ptr(dv), dv.stride(0), B, H, L, L, dh, scale, p_drop, seed, core.seed_ptr() if p_drop > 0 else None,
+            core.stream()), 'attention_bwd')
+        return dqkv, (None if v_sep is None else dv), None, None, None, None, None
+
+
+def _kpm_u8(key_padding_mask):
+    return None if key_padding_mask is None else key_padding_mask.to(torch.uint8).contiguous()
+
+
 def attention(q, k, v, key_padding_mask, B, H, Lq, Lk, p_drop=0.0):
     kpm = None
     if key_padding_mask is not None:
@@ -69,11 +118,13 @@ def mha_forward(query, key, value, in_proj_weight, in_proj_bias, out_w, out_b, n
     W, bvec = in_proj_weight, in_proj_bias
     if same_qkv:
         qkv = linear(query, W, bvec)
-        q, k, v = qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:]
+        o = _AttnPackedFn.apply(qkv, None, _kpm_u8(key_padding_mask), B, nhead, Lq, p_drop)
+        return linear(o, out_w, out_b)
     elif same_qk:
         qk = linear(query, W, bvec, rows=(0, 2 * d))
-        q, k = qk[:, :d], qk[:, d:]
         v = linear(value, W, bvec, rows=(2 * d, 3 * d))
+        o = _AttnPackedFn.apply(qk, v, _kpm_u8(key_padding_mask), B, nhead, Lq, p_drop)
+        return linear(o, out_w, out_b)
     else:
         q = linear(query, W, bvec, rows=(0, d))
         k = linear(key, W, bvec, rows=(d, 2 * d))

@@ -73,17 +73,17 @@ def check(rc, what=''):
 # the weight/bias gradients only feed the optimizer.  They are launched on a second HIP stream (forked after their inputs are
 # ready, joined once after backward), so the hundreds of latency-bound dW launches of the transformer blocks overlap the dX
 # chain instead of sitting in it; inside a captured phase the fork/join become parallel branches of the hipGraph.
-SIDE_WGRAD = os.environ.get('LDETR_SIDE_WGRAD', '1') != '0'
+SIDE_WGRAD = os.environ.get('LDETR_SIDE_WGRAD', '0') != '0'
+SIDE_BATCH = int(os.environ.get('LDETR_SIDE_BATCH', '32'))   # launches queued per fork (every fork is a cross-stream edge in the graph)
 _side_streams = {}
 _side_keep = []
+_side_queue = []
 _side_busy = [False]
 
 
-def run_on_side(fn, keep=()):
-    """Run fn() (kernel launches that only write flat .grad buffers) on the side stream, ordered after everything queued so far
-    on the current stream.  `keep`: tensors fn reads; held until join_side() so the allocator cannot recycle them early."""
-    if not SIDE_WGRAD:
-        return fn()
+def _side_flush():
+    if not _side_queue:
+        return
     main = torch.cuda.current_stream()
     key = main.device.index
     side = _side_streams.get(key)
@@ -91,13 +91,26 @@ def run_on_side(fn, keep=()):
         side = _side_streams[key] = torch.cuda.Stream(device=main.device)
     side.wait_stream(main)
     with torch.cuda.stream(side):
-        fn()
-    _side_keep.append(keep)
+        for fn in _side_queue:
+            fn()
+    del _side_queue[:]
     _side_busy[0] = True
+
+
+def run_on_side(fn, keep=()):
+    """Run fn() (kernel launches that only write flat .grad buffers) on the side stream, ordered after everything queued so far
+    on the current stream.  `keep`: tensors fn reads; held until join_side() so the allocator cannot recycle them early."""
+    if not SIDE_WGRAD:
+        return fn()
+    _side_queue.append(fn)
+    _side_keep.append(keep)
+    if len(_side_queue) >= SIDE_BATCH:
+        _side_flush()
 
 
 def join_side():
     """Make the current stream wait for the side-stream gradient launches (call after backward, before the gradients are read)."""
+    _side_flush()
     if not _side_busy[0]:
         return
     main = torch.cuda.current_stream()
