@@ -3,6 +3,8 @@ Same class name, constructor arguments, phase names and loss composition; the de
 pl_weight=0` configuration (train.py:135-136) makes Greg/Dreg no-ops exactly as loss.py:77-80 does.
 R1 / path-length regularisation need double-backward through the fused kernels and are not implemented
 (SURVEY §7 'second-order autograd'); requesting them raises."""
+import os
+
 import torch
 import torch.nn.functional as F
 
@@ -48,6 +50,32 @@ class Loss:
         raise NotImplementedError()
 
 
+class _TrunkFork(object):
+    """D's ResNet trunk launched on a second HIP stream while the current stream runs G (the trunk only reads the backgrounds,
+    G's many latency-bound transformer launches leave most CUs idle): join() orders the current stream after it."""
+
+    def __init__(self, D, background, enabled):
+        self.out = None
+        self.side = None
+        if enabled and background.is_cuda:
+            main = torch.cuda.current_stream()
+            self.side = _TrunkFork.streams.setdefault(main.device.index, torch.cuda.Stream(device=main.device))
+            self.side.wait_stream(main)
+            with torch.cuda.stream(self.side):
+                self.out = D.trunk(background)
+        else:
+            self.out = D.trunk(background)
+
+    def join(self):
+        if self.side is not None:
+            torch.cuda.current_stream().wait_stream(self.side)
+            self.side = None
+        return self.out
+
+
+_TrunkFork.streams = {}
+
+
 class StyleGAN2Loss(Loss):
     def __init__(self, device, G, D, augment_pipe=None, r1_gamma=0.0, style_mixing_prob=0, pl_weight=0.0, pl_batch_shrink=2,
                  pl_decay=0.01, pl_no_weight_grad=False, blur_init_sigma=0, blur_fade_kimg=0,
@@ -74,6 +102,7 @@ class StyleGAN2Loss(Loss):
         # gradient (the reference recomputes it, training/loss.py:176-210: two run_D calls, two backward calls).  Same losses and
         # gradients up to fp32 summation order; share_D_trunk=False restores the reference's call pattern.
         self.share_D_trunk = share_D_trunk
+        self.fork_D_trunk = os.environ.get('LDETR_FORK_TRUNK', '0') != '0'   # measured: no gain inside hipGraphs (negative results)
         self.report = report_fn if report_fn is not None else (lambda name, value: None)
         self.last = {}
 
@@ -93,8 +122,10 @@ class StyleGAN2Loss(Loss):
         w = self.w
         valid = ~padding_mask
         static = bool(getattr(self.G, 'static_shapes', False))
+        fork = _TrunkFork(self.D, background, self.fork_D_trunk) if hasattr(self.D, 'trunk') else None
         bbox_fake, loss_z, cls_logits, loss_lm, loss_text_len = self.run_G(gen_z, bbox_class, bbox_real, bbox_text, bbox_patch, padding_mask, background, gen_c, reconst=True)
-        gen_logits, gen_logits_uncond = self.run_D(bbox_fake, bbox_class, bbox_text, bbox_patch, padding_mask, background, gen_c)
+        gen_logits, gen_logits_uncond = self.run_D(bbox_fake, bbox_class, bbox_text, bbox_patch, padding_mask, background, gen_c,
+                                                   trunk_out=fork.join() if fork is not None else None)
         terms = dict(
             loss_Ggen=F.softplus(-gen_logits),
             loss_Ggen_uncond=F.softplus(-gen_logits_uncond),
@@ -116,6 +147,8 @@ class StyleGAN2Loss(Loss):
 
     def d_gen_loss(self, bbox_real, bbox_class, bbox_text, bbox_patch, padding_mask, background, gen_z, gen_c, trunk_out=None):
         bbox_fake = self.run_G(gen_z, bbox_class, bbox_real, bbox_text, bbox_patch, padding_mask, background, gen_c, update_emas=True)
+        if isinstance(trunk_out, _TrunkFork):
+            trunk_out = trunk_out.join()
         gen_logits, gen_logits_uncond = self.run_D(bbox_fake, bbox_class, bbox_text, bbox_patch, padding_mask, background, gen_c, update_emas=True,
                                                    trunk_out=trunk_out)
         loss_Dgen = F.softplus(gen_logits)
@@ -158,9 +191,9 @@ class StyleGAN2Loss(Loss):
             core.join_side()
         if phase == 'Dmain':
             if self.share_D_trunk and hasattr(self.D, 'trunk'):
-                trunk_out = self.D.trunk(background)
-                l_gen = self.d_gen_loss(bbox_real, bbox_class, bbox_text, bbox_patch, padding_mask, background, gen_z, gen_c, trunk_out=trunk_out)
-                l_real = self.d_real_loss(bbox_real, bbox_class, bbox_text, bbox_patch, padding_mask, background, real_c, trunk_out=trunk_out)
+                fork = _TrunkFork(self.D, background, self.fork_D_trunk)   # overlaps G's no-grad forward inside d_gen_loss
+                l_gen = self.d_gen_loss(bbox_real, bbox_class, bbox_text, bbox_patch, padding_mask, background, gen_z, gen_c, trunk_out=fork)
+                l_real = self.d_real_loss(bbox_real, bbox_class, bbox_text, bbox_patch, padding_mask, background, real_c, trunk_out=fork.join())
                 (l_gen + l_real).mul(gain).backward()   # one backward: the trunk sees the summed gradient of both passes
                 core.join_side()
             else:

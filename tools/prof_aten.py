@@ -21,11 +21,22 @@ it(); torch.cuda.synchronize()
 with profile(activities=[ProfilerActivity.CPU], with_stack=True, record_shapes=False) as prof:
     it(); torch.cuda.synchronize()
 agg = collections.Counter()
-want = ('aten::copy_', 'aten::add', 'aten::add_', 'aten::fill_', 'aten::zero_', 'aten::mul', 'aten::cat', 'aten::sum', 'aten::div', 'aten::neg', 'aten::where', 'aten::sub', 'aten::pow', 'aten::rsqrt', 'aten::index_select', 'aten::gather', 'aten::masked_fill_', 'aten::clamp')
+want = ('aten::copy_', 'aten::add', 'aten::add_', 'aten::zero_', 'aten::mul', 'aten::sum', 'aten::div', 'aten::fill_')
+def top_parent(ev):
+    names = []
+    p = ev.cpu_parent
+    while p is not None:
+        names.append(p.name)
+        p = p.cpu_parent
+    for n in names:
+        if 'Backward' in n or 'AccumulateGrad' in n:
+            return n
+    return names[-1] if names else 'top'
 for ev in prof.events():
     if ev.name in want:
-        st = [f for f in (ev.stack or []) if 'layoutdetr_amd' in f or 'bench.py' in f]
-        key = (ev.name, st[0].split('layoutdetr_amd/')[-1] if st else 'autograd/none')
-        agg[key] += 1
-for (name, where), n in agg.most_common(70):
-    print(f'{n:5d}  {name:22s} {where}')
+        par = ev.cpu_parent.name if ev.cpu_parent is not None else 'top'
+        if ev.name == 'aten::fill_' and par == 'aten::zero_':
+            continue
+        agg[(ev.name, top_parent(ev))] += 1
+for (name, where), n in agg.most_common(60):
+    print(f'{n:5d}  {name:14s} {where}')
