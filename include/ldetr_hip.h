@@ -81,6 +81,10 @@ typedef struct ldetr_epilogue {
     uint64_t seed;
     const uint64_t* seed_ptr; /* optional device word added to `seed` at run time (keeps dropout fresh under hipGraph replay) */
     int accumulate;
+    /* ldetr_gemm_f32 with ta == 1 only: a_rowsum[m] += sum_k op(A)[m, k] (no alpha) as a by-product of the contraction — the
+     * bias gradient of a linear layer falls out of its weight-gradient GEMM dW = dY^T X (A = dY stored [K, M], lda == M).
+     * The latency-bound kernel sums it from the A fragments it streams anyway; other sizes run the column-sum kernel. */
+    float* a_rowsum;
 } ldetr_epilogue;
 
 int ldetr_bias_act_f32(const float* x, const float* b, const float* xref, const float* yref, const float* dy, float* y,

@@ -22,7 +22,7 @@ class Epilogue(Structure):
                 ('samp_ld', c_int64), ('residual', c_void_p), ('ldr', c_int64), ('act', c_int),
                 ('act_alpha', c_float), ('act_gain', c_float), ('mask_src', c_void_p), ('ldm', c_int64),
                 ('mask_mode', c_int), ('out_scale', c_float), ('p_drop', c_float), ('seed', c_uint64),
-                ('seed_ptr', c_void_p), ('accumulate', c_int)]
+                ('seed_ptr', c_void_p), ('accumulate', c_int), ('a_rowsum', c_void_p)]
 
 
 _P = c_void_p
@@ -83,7 +83,7 @@ def load():
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported
         fn.restype = c_int
         fn.argtypes = argtypes
-    if lib.ldetr_abi_version() != 4:
+    if lib.ldetr_abi_version() != 5:
         raise RuntimeError('libldetr_hip.so ABI version mismatch; rebuild it')
     _lib = lib
     return lib

@@ -67,6 +67,7 @@ struct GemmEpilogue {
     const unsigned long long* seed_ptr;
     int accumulate;
     const float* row_scale;  // internal (weight gradients): per-output-row factor, linear like alpha (FrozenBN scale of the dy operand)
+    float* a_rowsum;         // ta == 1 dense GEMM: a_rowsum[m] += sum_k A[k][m]
 };
 
 struct GemmParams {
@@ -632,6 +633,8 @@ __global__ __launch_bounds__(NW * 64) void gemm_small_kernel(GemmParams p) {
 #pragma unroll
     for (int r = 0; r < 16; r++) acc[r] = 0.f;
     float a0[16], b0[16], a1[16], b1[16];
+    const bool want_rs = TA == 1 && p.ep.a_rowsum != nullptr && blockIdx.x == 0;   // the A panel is the same for every column block
+    float rs = 0.f;
     if (kbeg < kend) {
         small_load<TA>(p.A, m0 + cl, p.M, kbeg, kl, kend, a0);
         small_load<TB>(p.B, n0 + cl, p.N, kbeg, kl, kend, b0);
@@ -643,6 +646,10 @@ __global__ __launch_bounds__(NW * 64) void gemm_small_kernel(GemmParams p) {
         }
 #pragma unroll
         for (int t = 0; t < 16; t++) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[t], b0[t], acc, 0, 0, 0);
+        if (want_rs) {
+#pragma unroll
+            for (int t = 0; t < 16; t++) rs += a0[t];
+        }
         if (k + 32 >= kend) break;
         if (k + 64 < kend) {
             small_load<TA>(p.A, m0 + cl, p.M, k + 64, kl, kend, a0);
@@ -650,10 +657,25 @@ __global__ __launch_bounds__(NW * 64) void gemm_small_kernel(GemmParams p) {
         }
 #pragma unroll
         for (int t = 0; t < 16; t++) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[t], b1[t], acc, 0, 0, 0);
+        if (want_rs) {
+#pragma unroll
+            for (int t = 0; t < 16; t++) rs += a1[t];
+        }
+    }
+    __shared__ float rsum[NW][32];
+    if (want_rs) {
+        rs += __shfl_xor(rs, 32);
+        if (kl == 0) rsum[wave][cl] = rs;
     }
 #pragma unroll
     for (int r = 0; r < 16; r++) red[wave][(r & 3) + 8 * (r >> 2) + 4 * kl][cl] = acc[r];
     __syncthreads();
+    if (want_rs && tid < 32 && m0 + tid < p.M) {
+        float tot = 0.f;
+#pragma unroll
+        for (int w = 0; w < NW; w++) tot += rsum[w][tid];
+        p.ep.a_rowsum[m0 + tid] += tot;   // unique writer per m (column block 0), launches on one stream are ordered
+    }
     const GemmEpilogue& ep = p.ep;
     const float inv_keep = ep.p_drop > 0.f ? 1.f / (1.f - ep.p_drop) : 1.f;
     for (int q = tid; q < 256; q += NW * 64) {   // 256 float4 groups: row = q / 8, cols 4*(q % 8) .. +3
@@ -1014,6 +1036,7 @@ static void fill_epilogue(GemmEpilogue& ep, const ldetr_epilogue* e) {
     ep.act = e->act; ep.act_alpha = e->act_alpha; ep.act_gain = e->act_gain;
     ep.mask_src = e->mask_src; ep.ldm = e->ldm; ep.mask_mode = e->mask_mode;
     ep.out_scale = e->out_scale; ep.p_drop = e->p_drop; ep.seed = e->seed; ep.seed_ptr = (const unsigned long long*)e->seed_ptr; ep.accumulate = e->accumulate;
+    ep.a_rowsum = e->a_rowsum;
 }
 
 }  // namespace ldetr
@@ -1055,6 +1078,15 @@ extern "C" int ldetr_gemm_f32(const float* A, int64_t lda, int ta, const float* 
     LDETR_CHECK(!(p.splitk > 1 && p.ep.accumulate && !epilogue_is_linear(p.ep)), "gemm: split-K + accumulate needs a linear epilogue");
     hipStream_t st = (hipStream_t)stream;
     const bool auto_split = (splitk == 0);   // splitk: 0 = let the launch policy decide, 1 = never split, >1 = explicit
+    if (p.ep.a_rowsum) {
+        LDETR_CHECK(ta == 1 && lda == M, "gemm: a_rowsum needs ta == 1 and a packed A (lda == M)");
+        const bool small = auto_split && (long)cdiv(M, 64) * cdiv(N, 64) < SMALL_GEMM_TILES && (long)M * N * K <= SMALL_GEMM_MNK && tb;
+        if (!small) {   // not the kernel that folds the row sums in: one column-sum pass over A = [K, M]
+            int rc = ldetr_colsum_f32(A, p.ep.a_rowsum, 1, K, M, stream);
+            if (rc) return rc;
+            p.ep.a_rowsum = nullptr;
+        }
+    }
     if (auto_split && (long)cdiv(M, 64) * cdiv(N, 64) < SMALL_GEMM_TILES && (long)M * N * K <= SMALL_GEMM_MNK) {
         if (!ta && !tb) return launch_small<0, 0>(p, st);
         if (!ta && tb) return launch_small<0, 1>(p, st);

@@ -190,7 +190,7 @@ def tensor4_nchw(x):
 
 
 def epilogue(alpha=1.0, col_scale=None, col_bias=None, samp_scale=None, residual=None, act=ACT_NONE, act_alpha=0.0,
-             act_gain=1.0, mask_src=None, mask_mode=0, out_scale=1.0, p_drop=0.0, seed=0, accumulate=False):
+             act_gain=1.0, mask_src=None, mask_mode=0, out_scale=1.0, p_drop=0.0, seed=0, accumulate=False, a_rowsum=None):
     ep = Epilogue()
     ep.alpha = alpha
     ep.col_scale = col_scale.data_ptr() if col_scale is not None else None
@@ -213,6 +213,7 @@ def epilogue(alpha=1.0, col_scale=None, col_bias=None, samp_scale=None, residual
     ep.seed = seed
     ep.seed_ptr = iter_seed().data_ptr() if p_drop > 0 else None
     ep.accumulate = 1 if accumulate else 0
+    ep.a_rowsum = a_rowsum.data_ptr() if a_rowsum is not None else None
     return ep
 
 

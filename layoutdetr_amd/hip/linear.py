@@ -80,7 +80,8 @@ class _LinearFn(torch.autograd.Function):
         else:
             dpre = dy2
             db = None
-            if need_b:
+            fold_db = need_b and gb is not None and need_w and gw is not None and gw.is_contiguous() and dpre.is_contiguous()
+            if need_b and not fold_db:
                 if gb is not None:
                     core.run_on_side(lambda: core.check(core.lib().ldetr_colsum_f32(core.ptr(dpre), core.ptr(gb), 1, M, N, core.stream()), 'colsum'),
                                      keep=(dpre,))
@@ -91,8 +92,10 @@ class _LinearFn(torch.autograd.Function):
             dx = core.gemm(dpre, w, 0, 1, M, K, N, ep=core.epilogue(alpha=wscale)).reshape(xshape)
         if need_w:
             if gw is not None and gw.is_contiguous():
-                core.run_on_side(lambda: core.gemm(dpre, x2, 1, 1, N, K, M, out=gw, ep=core.epilogue(alpha=wscale, accumulate=True)),
-                                 keep=(dpre, x2))
+                # dW = dY^T X accumulated into the flat .grad; the bias gradient (column sums of dY) rides along (a_rowsum)
+                rsum = gb if (act == ACT_NONE and fold_db) else None
+                core.run_on_side(lambda: core.gemm(dpre, x2, 1, 1, N, K, M, out=gw,
+                                                   ep=core.epilogue(alpha=wscale, accumulate=True, a_rowsum=rsum)), keep=(dpre, x2))
             else:
                 dw = core.gemm(dpre, x2, 1, 1, N, K, M, ep=core.epilogue(alpha=wscale))
         full = wparam.shape[0]

@@ -32,6 +32,11 @@ def _mha(m: nn.MultiheadAttention, q2, k2, v2, B, Lq, Lk, kpm, training, same_qk
                        B, Lq, Lk, key_padding_mask=kpm, p_drop=p, same_qk=same_qk, same_qkv=same_qkv)
 
 
+def _mask_u8(kpm):
+    """bool key-padding mask -> the uint8 form the attention kernels read (no-op when already converted)."""
+    return None if kpm is None else kpm.to(torch.uint8).contiguous()
+
+
 def _ffn(layer, x2):
     p = layer.dropout.p if layer.training else 0.0
     h = linear(x2, layer.linear1.weight, layer.linear1.bias, act=core.ACT_RELU, p_drop=p)
@@ -102,6 +107,7 @@ class TransformerEncoder(nn.Module):
         self.norm = norm
 
     def forward2d(self, x2, B, L, kpm, pos2):
+        kpm = _mask_u8(kpm)   # one conversion per stack, not one per attention launch
         for layer in self.layers:
             x2 = layer.forward2d(x2, B, L, kpm, pos2)
         if self.norm is not None:
@@ -120,6 +126,7 @@ class TransformerDecoder(nn.Module):
         self.return_intermediate = return_intermediate
 
     def forward2d(self, t2, mem2, pos2, B, Lq, S, tgt_kpm, mem_kpm):
+        tgt_kpm, mem_kpm = _mask_u8(tgt_kpm), _mask_u8(mem_kpm)
         mem_pos2 = mem2 + pos2
         for layer in self.layers:
             t2 = layer.forward2d(t2, mem2, mem_pos2, B, Lq, S, tgt_kpm, mem_kpm)

@@ -159,6 +159,19 @@ def test_gemm_skinny_k(dev, M, N, K):
     assert_close(out, base + (A.double() @ Bt.double()).float(), 3e-6, 'skinny NN accumulate')
 
 
+@pytest.mark.parametrize('tokens,N,K', [(144, 256, 256), (1024, 256, 2048), (1000, 2048, 256), (4096, 1024, 512)])
+def test_gemm_dw_with_bias_rowsum(dev, tokens, N, K):
+    """dW = dY^T X accumulated onto an existing buffer with the bias gradient (column sums of dY) as a by-product:
+    folded into the latency-bound kernel, a separate column-sum pass on the tiled path."""
+    from layoutdetr_amd.hip import core
+    torch.manual_seed(45)
+    dY = torch.randn(tokens, N); X = torch.randn(tokens, K); gw0 = torch.randn(N, K); gb0 = torch.randn(N)
+    gw = gw0.to(dev).clone(); gb = gb0.to(dev).clone(); dYd, Xd = dY.to(dev), X.to(dev)
+    core.gemm(dYd, Xd, 1, 1, N, K, tokens, out=gw, ep=core.epilogue(alpha=0.5, accumulate=True, a_rowsum=gb))
+    assert_close(gw, gw0 + 0.5 * (dY.double().t() @ X.double()).float(), 4e-6 * max(1.0, math.sqrt(tokens / 256)), 'dW')
+    assert_close(gb, gb0 + dY.double().sum(0).float(), 1e-5, 'db')
+
+
 def test_gemm_epilogue(dev):
     from layoutdetr_amd.hip import core
     torch.manual_seed(5)
