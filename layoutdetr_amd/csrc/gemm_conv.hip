@@ -751,11 +751,15 @@ __global__ __launch_bounds__(256, (KS == 2 ? 4 : (KS == 4 ? 3 : 2))) void gemm_s
     // C and the residual go through buffer descriptors: one VGPR byte offset per lane + a scalar row offset per element
     // (the host guarantees both extents fit 31 bits), instead of a 64-bit address pair per element.
     const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc(p.C, 0, (int)((long)p.M * p.ldc * 4), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(ep.residual ? ep.residual : p.C), 0,
-                                                                          ep.residual ? (int)((long)p.M * ep.ldr * 4) : 0, 0x00020000);
+    // one prefetched side operand per output element: the residual (forward) or the ReLU-mask source (data gradient)
+    const bool is_mask = !ep.residual && ep.mask_mode == 1;
+    const float* auxp = ep.residual ? ep.residual : (is_mask ? ep.mask_src : nullptr);
+    const long auxld = ep.residual ? ep.ldr : ep.ldm;
+    const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(auxp ? auxp : p.C), 0,
+                                                                          auxp ? (int)((long)p.M * auxld * 4) : 0, 0x00020000);
     const int mlane = mb + 4 * kl;                       // row of element r: mlane + (r & 3) + 8 * (r >> 2)
-    const int voc = (mlane * (int)p.ldc + cl) * 4, vor = (mlane * (int)ep.ldr + cl) * 4;
-    const int ldc4 = (int)p.ldc * 4, ldr4 = (int)ep.ldr * 4;
+    const int voc = (mlane * (int)p.ldc + cl) * 4, vor = (mlane * (int)auxld + cl) * 4;
+    const int ldc4 = (int)p.ldc * 4, ldr4 = (int)auxld * 4;
     const bool full_rows = mb + 32 <= p.M;
     const int spc = NC / 32;                             // 32-column steps per LDS chunk
     const int nsteps = (nend - nbeg + 31) / 32;
@@ -772,7 +776,7 @@ __global__ __launch_bounds__(256, (KS == 2 ? 4 : (KS == 4 ? 3 : 2))) void gemm_s
     };
 #pragma unroll
     for (int r = 0; r < 16; r++) { res[r] = 0.f; resn[r] = 0.f; }
-    if (ep.residual && nsteps > 0) load_res(0, res);
+    if (auxp && nsteps > 0) load_res(0, res);
     for (int step = 0; step < nsteps; step++) {
         const int nc0 = nbeg + (step / spc) * NC;
         if (step % spc == 0) {
@@ -796,7 +800,7 @@ __global__ __launch_bounds__(256, (KS == 2 ? 4 : (KS == 4 ? 3 : 2))) void gemm_s
             }
             __syncthreads();
         }
-        if (ep.residual && step + 1 < nsteps) load_res(step + 1, resn);   // one step ahead: its latency hides under this step's MFMA chain
+        if (auxp && step + 1 < nsteps) load_res(step + 1, resn);   // one step ahead: its latency hides under this step's MFMA chain
         const int n32 = (step % spc) * 32;
         const int n = nc0 + n32 + cl;
         const bool nok = n < nend;
@@ -821,9 +825,10 @@ __global__ __launch_bounds__(256, (KS == 2 ? 4 : (KS == 4 ? 3 : 2))) void gemm_s
                 if (!full_rows && m >= p.M) continue;
                 // lean epilogue (the launcher rejects per-sample scales, backward masks and dropout: their per-row index
                 // arithmetic gets hoisted out of the step loop and spills this kernel's A-stationary register budget)
-                float v = acc[r] * ep.alpha * cs + cb + res[r];
+                float v = acc[r] * ep.alpha * cs + cb + (is_mask ? 0.f : res[r]);
                 if (ep.act == 1) v = fmaxf(v, 0.f);
                 else if (ep.act == 2) v = (v > 0.f ? v : v * ep.act_alpha) * ep.act_gain;
+                if (is_mask) v = res[r] > 0.f ? v : 0.f;
                 v *= ep.out_scale;
                 if (ep.accumulate) v += __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(rc, vo, ro * ldc4, 0));
                 __builtin_amdgcn_raw_buffer_store_b32(__float_as_int(v), rc, vo, ro * ldc4, 0);
@@ -840,8 +845,10 @@ static int try_launch_skinny(const GemmParams& p, hipStream_t st) {
     if (p.K > 256 || p.M < SKINNY_MIN_M || !p.A.vec || !p.B.vec || (p.K & 3) || p.zmode != 0 || p.splitk > 1) return -1;
     if (p.A.scale && (p.A.scale_ld != 0 || !al16(p.A.scale))) return -1;
     if (TB == 1 && (p.N & 3)) return -1;
-    if (p.ep.samp_scale || p.ep.mask_mode || p.ep.p_drop > 0.f || p.ep.row_scale) return -1;   // lean epilogue only
-    if ((long)p.M * p.ldc * 4 >= (1l << 31) || (p.ep.residual && (long)p.M * p.ep.ldr * 4 >= (1l << 31))) return -1;   // 32-bit buffer offsets
+    if (p.ep.samp_scale || p.ep.p_drop > 0.f || p.ep.row_scale) return -1;   // lean epilogue only
+    if (p.ep.mask_mode && (p.ep.mask_mode != 1 || p.ep.residual)) return -1;
+    if ((long)p.M * p.ldc * 4 >= (1l << 31) || (p.ep.residual && (long)p.M * p.ep.ldr * 4 >= (1l << 31)) ||
+        (p.ep.mask_mode && (long)p.M * p.ep.ldm * 4 >= (1l << 31))) return -1;   // 32-bit buffer offsets
     const int KS = p.K <= 64 ? 2 : (p.K <= 128 ? 4 : 8);
     int NC = KS == 2 ? 128 : 64;   // columns per LDS chunk: ~34 KiB (K <= 128: 4 resp. 3 blocks per CU) or ~68 KiB (K <= 256: 2 per CU)
     if (const char* e = getenv("LDETR_SKINNY_NC")) { int v = atoi(e); if (v >= 32 && v % 32 == 0 && v < NC) NC = v; }   // tuning aid

@@ -27,7 +27,7 @@ def _grad_to_oihw(dw_ohwi):
 
 class _ConvFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, scale, shift, residual, stride, pad, relu, x_is_nchw):
+    def forward(ctx, x, weight, scale, shift, residual, stride, pad, relu, x_is_nchw, premasked=False, mask_input=False):
         core.require_gpu(x, weight, scale, shift, residual)
         w = core.f32c(weight_ohwi(weight))
         O, KH, KW, I = w.shape
@@ -49,14 +49,14 @@ class _ConvFn(torch.autograd.Function):
             core.ptr(x), ctypes.byref(xt), core.ptr(w), O, KH, KW, stride, pad, core.ptr(y), O, OH, OW, None, 0,
             ctypes.byref(ep), core.stream()), 'conv2d_fwd'))
         ctx.save_for_backward(x, w, sc, y if relu else None)
-        ctx.cfg = (stride, pad, relu, x_is_nchw, residual is not None, shift is not None, (N, H, W, I))
+        ctx.cfg = (stride, pad, relu, x_is_nchw, residual is not None, shift is not None, (N, H, W, I), premasked, mask_input)
         ctx.params = (weight, shift)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         x, w, sc, y = ctx.saved_tensors
-        stride, pad, relu, x_is_nchw, has_res, has_shift, (N, H, W, I) = ctx.cfg
+        stride, pad, relu, x_is_nchw, has_res, has_shift, (N, H, W, I), premasked, mask_input = ctx.cfg
         O, KH, KW, _ = w.shape
         dy = core.f32c(dy)
         _, OH, OW, _ = dy.shape
@@ -66,7 +66,9 @@ class _ConvFn(torch.autograd.Function):
         dy2 = dy.reshape(-1, O)
         wparam, sparam = ctx.params
         gs = core.flat_grad(sparam) if (need_shift and O % 4 == 0) else None
-        if relu:
+        if relu and premasked and not need_shift:
+            dpre2, dshift = dy2, None   # every consumer of this output already applied (y > 0) in its data-gradient epilogue
+        elif relu:
             dpre2, dshift, _ = act_backward(dy2, y.reshape(-1, O), ACT_RELU, 0.0, 1.0, need_shift, dbias_out=gs)
         else:
             dpre2 = dy2
@@ -83,9 +85,12 @@ class _ConvFn(torch.autograd.Function):
             if x_is_nchw:
                 raise RuntimeError('conv2d: gradient w.r.t. an NCHW image input is not implemented (never needed on the hot path)')
             dx = torch.empty((N, H, W, I), device=dy.device, dtype=torch.float32)
+            # mask_input: x is the ReLU output of a producer whose only consumer is this conv -> its (x > 0) mask is applied here,
+            # in the epilogue, and the producer skips its own activation-gradient pass (premasked)
+            epb = core.epilogue(mask_src=x.reshape(-1, I), mask_mode=1) if mask_input else None
             core.engine_call('ldetr_conv2d_bwd_data_f32', 2.0 * N * OH * OW * O * KH * KW * I, lambda: core.check(core.lib().ldetr_conv2d_bwd_data_f32(
                 core.ptr(dpre), ctypes.byref(dyt), core.ptr(w), I, KH, KW, stride, pad, core.ptr(dx), I, H, W,
-                core.ptr(sc), 0, None, core.stream()), 'conv2d_bwd_data'))
+                core.ptr(sc), 0, ctypes.byref(epb) if epb is not None else None, core.stream()), 'conv2d_bwd_data'))
         if need_w:
             gw = core.flat_grad(wparam)
             acc = 0
@@ -115,11 +120,14 @@ class _ConvFn(torch.autograd.Function):
                     wgrad()
             dw = None if acc else _grad_to_oihw(dw_ohwi)
         dres = dpre if need_res else None
-        return dx, dw, None, dshift, dres, None, None, None, None
+        return dx, dw, None, dshift, dres, None, None, None, None, None, None
 
 
-def conv2d_nhwc(x, weight, scale=None, shift=None, residual=None, stride=1, pad=0, relu=False, x_is_nchw=False):
-    return _ConvFn.apply(x, weight, scale, shift, residual, stride, pad, relu, x_is_nchw)
+def conv2d_nhwc(x, weight, scale=None, shift=None, residual=None, stride=1, pad=0, relu=False, x_is_nchw=False,
+                premasked=False, mask_input=False):
+    """premasked / mask_input: ReLU-gradient hand-off between a producer and its ONLY consumer (see _ConvFn.backward);
+    set both ends together or neither."""
+    return _ConvFn.apply(x, weight, scale, shift, residual, stride, pad, relu, x_is_nchw, premasked, mask_input)
 
 
 class _MaxPoolFn(torch.autograd.Function):

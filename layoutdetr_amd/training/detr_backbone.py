@@ -86,13 +86,15 @@ class Bottleneck(nn.Module):
 
     def forward(self, x):  # x: [N, H, W, C]
         s1, b1 = self.bn1.folded(); s2, b2 = self.bn2.folded(); s3, b3 = self.bn3.folded()
-        out = hconv.conv2d_nhwc(x, self.conv1.weight, s1, b1, None, 1, 0, relu=True)
-        out = hconv.conv2d_nhwc(out, self.conv2.weight, s2, b2, None, self.conv2.stride, 1, relu=True)
+        # conv1 -> conv2 -> conv3 is a chain of single-consumer ReLU outputs: each consumer masks its data gradient with
+        # (input > 0) in the GEMM epilogue, so conv1 and conv2 need no separate activation-gradient pass in backward
+        out = hconv.conv2d_nhwc(x, self.conv1.weight, s1, b1, None, 1, 0, relu=True, premasked=True)
+        out = hconv.conv2d_nhwc(out, self.conv2.weight, s2, b2, None, self.conv2.stride, 1, relu=True, premasked=True, mask_input=True)
         idt = x
         if self.downsample is not None:
             sd, bd = self.downsample[1].folded()
             idt = hconv.conv2d_nhwc(x, self.downsample[0].weight, sd, bd, None, self.downsample[0].stride, 0, relu=False)
-        return hconv.conv2d_nhwc(out, self.conv3.weight, s3, b3, idt, 1, 0, relu=True)
+        return hconv.conv2d_nhwc(out, self.conv3.weight, s3, b3, idt, 1, 0, relu=True, mask_input=True)
 
 
 class ResNet50Body(nn.Module):

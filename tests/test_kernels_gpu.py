@@ -284,6 +284,31 @@ def test_conv2d_fwd_bwd(dev, case):
     assert_close(rg.grad.permute(0, 3, 1, 2), rr.grad, 3e-6, 'dres')
 
 
+@pytest.mark.parametrize('case', [(2, 16, 16, 64, 32, 3, 1), (2, 17, 15, 32, 64, 3, 2), (4, 32, 32, 64, 128, 1, 1), (2, 8, 8, 256, 512, 1, 1)])
+def test_conv_relu_gradient_handoff(dev, case):
+    """conv_a -> ReLU -> conv_b where conv_b applies the (input > 0) mask in its data-gradient epilogue and conv_a skips its
+    activation-gradient pass (Bottleneck conv1->conv2->conv3): gradients equal the ordinary chain's."""
+    from layoutdetr_amd.hip import conv
+    N, H, W, Ca, Cb, k, s = case
+    torch.manual_seed(61)
+    x = torch.randn(N, 24, H, W); wa = torch.randn(Ca, 24, 1, 1) / math.sqrt(24); wb = torch.randn(Cb, Ca, k, k) / math.sqrt(Ca * k * k)
+    sa = torch.rand(Ca) + 0.5; ba = torch.randn(Ca) * 0.3; sb = torch.rand(Cb) + 0.5; bb = torch.randn(Cb) * 0.3
+    xr = x.clone().requires_grad_(True); war = wa.clone().requires_grad_(True); wbr = wb.clone().requires_grad_(True)
+    ya = F.relu(F.conv2d(xr, war) * sa.view(1, -1, 1, 1) + ba.view(1, -1, 1, 1))
+    yb = F.relu(F.conv2d(ya, wbr, stride=s, padding=k // 2) * sb.view(1, -1, 1, 1) + bb.view(1, -1, 1, 1))
+    g = torch.randn_like(yb); yb.backward(g)
+    xg = x.permute(0, 2, 3, 1).contiguous().to(dev).requires_grad_(True)
+    wag = wa.to(dev).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    wbg = wb.to(dev).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    a = conv.conv2d_nhwc(xg, wag, sa.to(dev), ba.to(dev), None, 1, 0, relu=True, premasked=True)
+    b = conv.conv2d_nhwc(a, wbg, sb.to(dev), bb.to(dev), None, s, k // 2, relu=True, mask_input=True)
+    b.backward(g.permute(0, 2, 3, 1).contiguous().to(dev))
+    assert_close(b.permute(0, 3, 1, 2), yb, 3e-6, 'y')
+    assert_close(wbg.grad, wbr.grad, 1e-5, 'dw_b')
+    assert_close(wag.grad, war.grad, 1e-5, 'dw_a')
+    assert_close(xg.grad.permute(0, 3, 1, 2), xr.grad, 5e-6, 'dx')
+
+
 def test_conv2d_stem_nchw(dev):
     from layoutdetr_amd.hip import conv
     torch.manual_seed(7)
