@@ -108,26 +108,34 @@ def attention(q, k, v, key_padding_mask, B, H, Lq, Lk, p_drop=0.0):
 
 
 def mha_forward(query, key, value, in_proj_weight, in_proj_bias, out_w, out_b, nhead, B, Lq, Lk,
-                key_padding_mask=None, p_drop=0.0, same_qk=False, same_qkv=False):
+                key_padding_mask=None, p_drop=0.0, same_qk=False, same_qkv=False, qk_pos=None, passthru=False):
     """query: [B*Lq, d]; key/value: [B*Lk, d].  Returns [B*Lq, d] (before the caller's residual/dropout/LN).
 
     same_qkv: query, key and value are one tensor  -> one packed [3d] projection (decoder self-attention).
-    same_qk:  query and key are one tensor          -> one [2d] projection + one [d] projection (encoder self).
+    same_qk:  query and key are `query (+ qk_pos)`, value is `value` (= query without the position term: encoder self-attention)
+              -> one [2d] projection + one [d] projection; qk_pos is added inside the projection node.
+    passthru: also return an alias of `query` that already went through the projection nodes; feeding the residual branch
+              from it keeps autograd from summing the gradients of `query` with separate add launches (hip/linear.py).
     """
     d = query.shape[1]
     W, bvec = in_proj_weight, in_proj_bias
+    alias = query
     if same_qkv:
-        qkv = linear(query, W, bvec)
+        r = linear(query, W, bvec, passthru=passthru)
+        qkv, alias = r if passthru else (r, query)
         o = _AttnPackedFn.apply(qkv, None, _kpm_u8(key_padding_mask), B, nhead, Lq, p_drop)
-        return linear(o, out_w, out_b)
     elif same_qk:
-        qk = linear(query, W, bvec, rows=(0, 2 * d))
-        v = linear(value, W, bvec, rows=(2 * d, 3 * d))
+        r = linear(query, W, bvec, rows=(0, 2 * d), add_input=qk_pos, passthru=passthru)
+        qk, alias = r if passthru else (r, query)
+        vin = alias if value is query else value
+        r = linear(vin, W, bvec, rows=(2 * d, 3 * d), passthru=passthru and value is query)
+        v, alias = r if (passthru and value is query) else (r, alias)
         o = _AttnPackedFn.apply(qk, v, _kpm_u8(key_padding_mask), B, nhead, Lq, p_drop)
-        return linear(o, out_w, out_b)
     else:
-        q = linear(query, W, bvec, rows=(0, d))
+        r = linear(query, W, bvec, rows=(0, d), passthru=passthru)
+        q, alias = r if passthru else (r, query)
         k = linear(key, W, bvec, rows=(d, 2 * d))
         v = linear(value, W, bvec, rows=(2 * d, 3 * d))
-    o = attention(q, k, v, key_padding_mask, B, nhead, Lq, Lk, p_drop)
-    return linear(o, out_w, out_b)
+        o = attention(q, k, v, key_padding_mask, B, nhead, Lq, Lk, p_drop)
+    out = linear(o, out_w, out_b)
+    return (out, alias) if passthru else out

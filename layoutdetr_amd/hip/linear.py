@@ -40,11 +40,14 @@ def act_backward(dy2, y2, act, act_alpha, act_gain, want_dbias, bias=None, demod
 
 class _LinearFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, bias, act, act_alpha, act_gain, p_drop, wscale, rows):
+    def forward(ctx, x, weight, bias, act, act_alpha, act_gain, p_drop, wscale, rows, add_input, passthru):
         core.require_gpu(x, weight, bias)
+        ctx.set_materialize_grads(False)
         r0, r1 = rows if rows is not None else (0, weight.shape[0])   # row range of a packed weight (MHA in_proj)
         N, K = r1 - r0, weight.shape[1]
         x2 = core.f32c(x.reshape(-1, K))
+        if add_input is not None:          # y = f((x + add_input) W^T): the position embedding of q/k (no gradient for it)
+            x2 = x2 + add_input.reshape(-1, K)
         w = core.f32c(weight.detach()[r0:r1])
         b = core.f32c(bias.detach()[r0:r1]) if bias is not None else None
         M = x2.shape[0]
@@ -57,14 +60,21 @@ class _LinearFn(torch.autograd.Function):
         ctx.params = (weight, bias, r0, r1)
         if p_drop > 0 and act != ACT_RELU:
             raise RuntimeError('linear: fused dropout is only defined after relu (FFN hidden layer)')
+        if passthru:
+            # second output = x itself (autograd aliases it).  A residual connection that reads x through THIS alias makes the
+            # node the only consumer of x: its backward receives the residual-path gradient and adds it in the dX GEMM's
+            # epilogue, instead of autograd launching an add kernel to sum two gradients of x.
+            return y.reshape(*x.shape[:-1], N), x
         return y.reshape(*x.shape[:-1], N)
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, dx_pass=None):
         x2, w, y = ctx.saved_tensors
         act, act_alpha, act_gain, p_drop, wscale, has_bias, xshape = ctx.cfg
         N, K = w.shape
         M = x2.shape[0]
+        if dy is None:                      # only the pass-through output was used
+            return (dx_pass,) + (None,) * 10
         dy2 = core.f32c(dy.reshape(-1, N))
         need_x, need_w, need_b = ctx.needs_input_grad[0], ctx.needs_input_grad[1], has_bias and ctx.needs_input_grad[2]
         wparam, bparam, r0, r1 = ctx.params
@@ -89,7 +99,8 @@ class _LinearFn(torch.autograd.Function):
                     db = core.colsum(dpre).reshape(-1)
         dx = dw = None
         if need_x:
-            dx = core.gemm(dpre, w, 0, 1, M, K, N, ep=core.epilogue(alpha=wscale)).reshape(xshape)
+            res = core.f32c(dx_pass.reshape(-1, K)) if dx_pass is not None else None
+            dx = core.gemm(dpre, w, 0, 1, M, K, N, ep=core.epilogue(alpha=wscale, residual=res)).reshape(xshape)
         if need_w:
             if gw is not None and gw.is_contiguous():
                 # dW = dY^T X accumulated into the flat .grad; the bias gradient (column sums of dY) rides along (a_rowsum)
@@ -103,10 +114,12 @@ class _LinearFn(torch.autograd.Function):
             dwf = torch.zeros((full, K), device=dw.device, dtype=torch.float32); dwf[r0:r1] = dw; dw = dwf
         if db is not None and (r1 - r0) != full:
             dbf = torch.zeros(full, device=db.device, dtype=torch.float32); dbf[r0:r1] = db; db = dbf
-        return dx, dw, db, None, None, None, None, None, None
+        return dx, dw, db, None, None, None, None, None, None, None, None
 
 
-def linear(x, weight, bias=None, act=ACT_NONE, act_alpha=0.0, act_gain=1.0, p_drop=0.0, wscale=1.0, rows=None):
-    """y = dropout(act((x @ (wscale*weight[rows]).T) + bias[rows]) * act_gain);  rows=(r0, r1) selects a row block of a packed
-    projection weight (nn.MultiheadAttention.in_proj_weight) without creating an autograd slice node."""
-    return _LinearFn.apply(x, weight, bias, act, act_alpha, act_gain, p_drop, wscale, rows)
+def linear(x, weight, bias=None, act=ACT_NONE, act_alpha=0.0, act_gain=1.0, p_drop=0.0, wscale=1.0, rows=None, add_input=None,
+           passthru=False):
+    """y = dropout(act(((x [+ add_input]) @ (wscale*weight[rows]).T) + bias[rows]) * act_gain);  rows=(r0, r1) selects a row block
+    of a packed projection weight (nn.MultiheadAttention.in_proj_weight) without creating an autograd slice node.
+    passthru=True returns (y, x_alias): route the residual branch through x_alias (see _LinearFn.forward)."""
+    return _LinearFn.apply(x, weight, bias, act, act_alpha, act_gain, p_drop, wscale, rows, add_input, passthru)

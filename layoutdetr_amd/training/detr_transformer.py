@@ -26,10 +26,11 @@ class _MHAParams(nn.MultiheadAttention):
         raise RuntimeError('use layoutdetr_amd.hip.attention.mha_forward')
 
 
-def _mha(m: nn.MultiheadAttention, q2, k2, v2, B, Lq, Lk, kpm, training, same_qk=False, same_qkv=False):
+def _mha(m: nn.MultiheadAttention, q2, k2, v2, B, Lq, Lk, kpm, training, same_qk=False, same_qkv=False, qk_pos=None):
+    """-> (attention block output, alias of q2 to feed the residual branch from)."""
     p = m.dropout if training else 0.0
     return mha_forward(q2, k2, v2, m.in_proj_weight, m.in_proj_bias, m.out_proj.weight, m.out_proj.bias, m.num_heads,
-                       B, Lq, Lk, key_padding_mask=kpm, p_drop=p, same_qk=same_qk, same_qkv=same_qkv)
+                       B, Lq, Lk, key_padding_mask=kpm, p_drop=p, same_qk=same_qk, same_qkv=same_qkv, qk_pos=qk_pos, passthru=True)
 
 
 def _mask_u8(kpm):
@@ -38,9 +39,10 @@ def _mask_u8(kpm):
 
 
 def _ffn(layer, x2):
+    """-> (FFN output, alias of x2 for the residual branch)."""
     p = layer.dropout.p if layer.training else 0.0
-    h = linear(x2, layer.linear1.weight, layer.linear1.bias, act=core.ACT_RELU, p_drop=p)
-    return linear(h, layer.linear2.weight, layer.linear2.bias)
+    h, x2 = linear(x2, layer.linear1.weight, layer.linear1.bias, act=core.ACT_RELU, p_drop=p, passthru=True)
+    return linear(h, layer.linear2.weight, layer.linear2.bias), x2
 
 
 def _add_ln(norm: nn.LayerNorm, x2, r2, drop: nn.Dropout, training):
@@ -63,10 +65,10 @@ class TransformerEncoderLayer(nn.Module):
         self.normalize_before = normalize_before
 
     def forward2d(self, x2, B, L, kpm, pos2):
-        qk = x2 if pos2 is None else x2 + pos2
-        a = _mha(self.self_attn, qk, qk, x2, B, L, L, kpm, self.training, same_qk=pos2 is not None, same_qkv=pos2 is None)
+        a, x2 = _mha(self.self_attn, x2, x2, x2, B, L, L, kpm, self.training, same_qk=pos2 is not None, same_qkv=pos2 is None, qk_pos=pos2)
         x2 = _add_ln(self.norm1, x2, a, self.dropout1, self.training)
-        return _add_ln(self.norm2, x2, _ffn(self, x2), self.dropout2, self.training)
+        f, x2 = _ffn(self, x2)
+        return _add_ln(self.norm2, x2, f, self.dropout2, self.training)
 
 
 class TransformerDecoderLayer(nn.Module):
@@ -88,11 +90,12 @@ class TransformerDecoderLayer(nn.Module):
         self.normalize_before = normalize_before
 
     def forward2d(self, t2, mem2, mem_pos2, B, Lq, S, tgt_kpm, mem_kpm):
-        a = _mha(self.self_attn, t2, t2, t2, B, Lq, Lq, tgt_kpm, self.training, same_qkv=True)
+        a, t2 = _mha(self.self_attn, t2, t2, t2, B, Lq, Lq, tgt_kpm, self.training, same_qkv=True)
         t2 = _add_ln(self.norm1, t2, a, self.dropout1, self.training)
-        a = _mha(self.multihead_attn, t2, mem_pos2, mem2, B, Lq, S, mem_kpm, self.training)
+        a, t2 = _mha(self.multihead_attn, t2, mem_pos2, mem2, B, Lq, S, mem_kpm, self.training)
         t2 = _add_ln(self.norm2, t2, a, self.dropout2, self.training)
-        return _add_ln(self.norm3, t2, _ffn(self, t2), self.dropout3, self.training)
+        f, t2 = _ffn(self, t2)
+        return _add_ln(self.norm3, t2, f, self.dropout3, self.training)
 
 
 def _get_clones(module, N):
