@@ -202,10 +202,16 @@ def main():
                 for (tag, f), (n, ms) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
                     fh.write(f'{tag:42s} gflop={f / 1e9:9.3f} calls/step={n // 2:4d} ms/step={ms / 2:8.3f} TF={f * n / ms / 1e9 if ms else 0:7.2f}\n')
         ach = fl / sec / 1e12 if sec > 0 else 0.0
-        roofline = dict(bound='mfma', kernel='ldetr::gemm_f32_kernel<*> (f32 MFMA GEMM / implicit-conv engine, all instantiations)',
+        by = {}
+        for tag, f, s_, e_ in core.PROF.records:   # the same records, split by C-ABI entry point
+            key = 'dense_gemm' if tag == 'gemm' else tag.replace('ldetr_', '').replace('_f32', '')
+            a = by.setdefault(key, [0.0, 0.0, 0]); a[0] += f; a[1] += s_.elapsed_time(e_); a[2] += 1
+        by_entry = {k: dict(gflop_per_step=round(v[0] / 2 / 1e9, 1), ms_per_step=round(v[1] / 2, 2), launches_per_step=v[2] // 2,
+                            tflops=round(v[0] / v[1] / 1e9, 2) if v[1] > 0 else 0.0) for k, v in sorted(by.items())}
+        roofline = dict(bound='mfma', kernel='f32 MFMA contraction engine: ldetr::gemm_f32_kernel<*> (LDS-tiled GEMM / implicit conv) + gemm_skinny_kernel<*> + gemm_small_kernel<*>, every launch',
                         achieved=round(ach, 3), peak=F32_MFMA_PEAK_TFLOPS, unit='TFLOP/s', frac=round(ach / F32_MFMA_PEAK_TFLOPS, 4),
                         traffic=None, launches_per_step=launches // 2, algorithmic_gflop_per_step=round(fl / 2 / 1e9, 2),
-                        engine_ms_per_step=round(sec / 2 * 1e3, 3))
+                        engine_ms_per_step=round(sec / 2 * 1e3, 3), by_entry=by_entry)
 
     if rank == 0:
         cpu = None

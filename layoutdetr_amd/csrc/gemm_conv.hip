@@ -82,6 +82,11 @@ struct GemmParams {
     int pix_per_sample;  // rows per sample in the *full* destination grid (epilogue + scale lookups)
     int ntaps;           // zmode 2
     long c_tap_stride;   // zmode 2: column offset per tap in C
+    // weight gradients with per-sample operand scales (modulated convs): K slices aligned to samples, so the two scales
+    // leave the k-loop and become one factor per partial tile:  C += acc * srow[samp][m] * scol[samp][n]
+    int samp_pix, samp_q;             // pixels (k indices) per sample, slices per sample; samp_pix == 0: ordinary split-K
+    const float* srow; long srow_ld;  // per-sample factor of output row m
+    const float* scol; long scol_ld;  // per-sample factor of output column n
     float* ws;           // split-K fix-up: per-(tile, slice) partial tiles; null = fp32 atomics into C
     int* ws_count;       //   per-tile arrival counters (zero between launches)
     GemmEpilogue ep;
@@ -97,6 +102,7 @@ struct ZCtx {
     TapMap tm;
     int fkh, fkw;
     long c_off;
+    int samp;   // sample a sample-aligned K slice belongs to
 };
 
 // Incremental decode of the reduction index: k = (tap', c) for conv operands, k = pixel (n, y, x) for
@@ -310,7 +316,15 @@ __device__ __forceinline__ ZCtx make_zctx(const GemmParams& p) {
         z.fkh = tap / KWt; z.fkw = tap - z.fkh * KWt;
         z.c_off = (long)tap * p.c_tap_stride;
     }
-    if (p.splitk > 1) {
+    z.samp = 0;
+    if (p.samp_pix > 0) {
+        const int n = ks / p.samp_q, j = ks - n * p.samp_q;
+        const int len = ((p.samp_pix + p.samp_q - 1) / p.samp_q + BKT - 1) / BKT * BKT;
+        z.samp = n;
+        z.kbeg = n * p.samp_pix + j * len;
+        z.kend = min(n * p.samp_pix + (j + 1) * len, (n + 1) * p.samp_pix);
+        if (z.kend < z.kbeg) z.kend = z.kbeg;
+    } else if (p.splitk > 1) {
         int ktiles = (z.K + BKT - 1) / BKT;
         int per = (ktiles + p.splitk - 1) / p.splitk;
         z.kbeg = ks * per * BKT;
@@ -551,12 +565,13 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
     // Epilogue.  acc[i][j][r]: row = (r&3) + 8*(r>>2) + 4*(lane>>5), col = lane&31 of the 32x32 tile.
     const GemmEpilogue& ep = p.ep;
     const float inv_keep = ep.p_drop > 0.f ? 1.f / (1.f - ep.p_drop) : 1.f;
-    float cs[TN], cb[TN];
+    float cs[TN], cb[TN], sfc[TN];
 #pragma unroll
     for (int j = 0; j < TN; j++) {
         int n = n0 + wn * WN + j * 32 + cl;
         cs[j] = (ep.col_scale && n < p.N) ? ep.col_scale[n] : 1.f;
         cb[j] = (ep.col_bias && n < p.N) ? ep.col_bias[n] : 0.f;
+        sfc[j] = (p.scol && n < p.N) ? p.scol[(long)z.samp * p.scol_ld + n] : 1.f;
     }
 #pragma unroll
     for (int i = 0; i < TM; i++) {
@@ -573,15 +588,17 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
             }
             // only the per-sample scale needs the sample index; the division was costing more issue slots than a K=64 main loop
             int samp = (ep.samp_scale && p.pix_per_sample > 0) ? (int)((unsigned)orow / (unsigned)p.pix_per_sample) : 0;
+            const float sfr = p.srow ? p.srow[(long)z.samp * p.srow_ld + m] : 1.f;
 #pragma unroll
             for (int j = 0; j < TN; j++) {
                 int n = n0 + wn * WN + j * 32 + cl;
                 if (n >= p.N) continue;
                 float* dst = p.C + z.c_off + orow * p.ldc + n;
+                const float a = acc[i][j][r] * sfr * sfc[j];
                 if (!direct) {
-                    atomicAdd(dst, acc[i][j][r] * (ep.row_scale ? ep.alpha * ep.row_scale[orow] : ep.alpha));   // raw partial sums; the rest of the epilogue runs in epilogue_kernel
+                    atomicAdd(dst, a * (ep.row_scale ? ep.alpha * ep.row_scale[orow] : ep.alpha));   // raw partial sums; the rest of the epilogue runs in epilogue_kernel
                 } else {
-                    float v = apply_epilogue(ep, acc[i][j][r], orow, n, samp, p.ldc, inv_keep, cs[j], cb[j], ep.residual ? ep.residual[orow * ep.ldr + n] : 0.f);
+                    float v = apply_epilogue(ep, a, orow, n, samp, p.ldc, inv_keep, cs[j], cb[j], ep.residual ? ep.residual[orow * ep.ldr + n] : 0.f);
                     if (ep.accumulate) *dst += v; else *dst = v;
                 }
             }
@@ -1032,6 +1049,19 @@ static int wgrad_auto_split(int M, int N, int K, int zbase) {
     return pick(t, 768, WGRAD_MIN_K);
 }
 
+// Per-sample operand scales of a weight gradient -> sample-aligned K slices (see GemmParams::samp_pix).  `want` = split the
+// policy asked for; the slice count becomes nsamp * q with q slices per sample.
+static void set_sample_slices(GemmParams& p, int nsamp, int pix_per_samp, int want, const float* srow, long srow_ld,
+                              const float* scol, long scol_ld) {
+    int q = (want + nsamp / 2) / nsamp;
+    if (q < 1) q = 1;
+    while (q > 1 && pix_per_samp / q < 64) q--;
+    p.samp_pix = pix_per_samp; p.samp_q = q;
+    p.srow = srow; p.srow_ld = srow_ld; p.scol = scol; p.scol_ld = scol_ld;
+    p.splitk = nsamp * q;
+    if (p.splitk > 1) p.ep.accumulate = 0;   // atomics onto the (zeroed or existing) buffer
+}
+
 static void fill_epilogue(GemmEpilogue& ep, const ldetr_epilogue* e) {
     memset(&ep, 0, sizeof(ep));
     ep.out_scale = 1.f; ep.act_gain = 1.f; ep.alpha = 1.f;
@@ -1217,6 +1247,12 @@ extern "C" int ldetr_conv2d_bwd_weight_f32(const float* x, const ldetr_tensor4* 
     if (dy_scale && dy_scale_ld == 0) { p.ep.row_scale = dy_scale; dy_scale = nullptr; }   // one scale per co for all samples: out of the k-loop
     p.M = Cout; p.N = Cin; p.K = Kpix; p.C = dw; p.ldc = (long)KH * KW * Cin;
     p.zmode = 2; p.ntaps = KH * KW; p.c_tap_stride = Cin;
+    if ((dy_scale || x_scale) && (!dy_scale || dy_scale_ld != 0) && (!x_scale || x_scale_ld != 0) && OH * OW >= 64) {
+        // per-sample scales (style modulation of x, demodulation of dy): factor them out of the k-loop
+        set_sample_slices(p, dyt->N, OH * OW, splitk, dy_scale, dy_scale_ld, x_scale, x_scale_ld);
+        if (p.splitk == 1 && accumulate) p.ep.accumulate = 1;
+        dy_scale = nullptr; x_scale = nullptr;
+    }
     const bool dy_packed = !dy_scale && dyt->sw == Cout && dyt->sh == (long)OW * Cout && dyt->sn == (long)OH * OW * Cout;
     if (dy_packed) {
         // packed NHWC dy without per-sample scale is a plain [pixels, Cout] matrix: no pixel decode for that operand;
@@ -1317,6 +1353,11 @@ extern "C" int ldetr_conv_transpose2d_bwd_weight_f32(const float* x, const ldetr
     long wsz = (long)Cout * KH * KW * Cin;
     if (!accumulate && hipMemsetAsync(dw, 0, wsz * sizeof(float), st) != hipSuccess) { set_error("conv_transpose2d_bwd_weight: memset failed"); return LDETR_ERR_LAUNCH; }
     if (splitk == 1 && accumulate) p.ep.accumulate = 1;
+    if ((dy_scale || x_scale) && (!dy_scale || dy_scale_ld != 0) && (!x_scale || x_scale_ld != 0) && xt->H * xt->W >= 64) {
+        set_sample_slices(p, xt->N, xt->H * xt->W, splitk, dy_scale, dy_scale_ld, x_scale, x_scale_ld);   // scales out of the k-loop
+        if (p.splitk == 1 && accumulate) p.ep.accumulate = 1;
+        dy_scale = nullptr; x_scale = nullptr;
+    }
     // k enumerates *input* pixels (n, ih, iw); A = dy gathered at (ih*s + kh - p, iw*s + kw - p), B = x dense.
     set_conv_src(p.A, dy, dyt);
     p.A.DH = xt->H; p.A.DW = xt->W; p.A.stride = stride; p.A.pad = pad; p.A.KH = KH; p.A.KW = KW; p.A.tapped = 1;
@@ -1330,5 +1371,9 @@ extern "C" int ldetr_conv_transpose2d_bwd_weight_f32(const float* x, const ldetr
               (!x_scale || (al16(x_scale) && x_scale_ld % 4 == 0));
     p.M = Cout; p.N = Cin; p.K = xt->N * xt->H * xt->W; p.C = dw; p.ldc = (long)KH * KW * Cin;
     p.zmode = 2; p.ntaps = KH * KW; p.c_tap_stride = Cin;
+    if (!x_scale && xt->sw == Cin && xt->sh == (long)xt->W * Cin && xt->sn == (long)xt->H * xt->W * Cin) {
+        p.B.p = x; p.B.ld = Cin; p.B.vec = al16(x);   // packed x: a plain [pixels, Cin] matrix
+        return launch_gemm<OP_RC_PIX, OP_RC_DENSE>(p, p.M, p.M, p.ntaps, false, true, st);
+    }
     return launch_gemm<OP_RC_PIX, OP_RC_PIX>(p, p.M, p.M, p.ntaps, false, true, st);
 }

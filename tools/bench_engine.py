@@ -31,6 +31,9 @@ def conv_case(name, N, H, Ci, Co, k, s, p):
     tb = timeit(lambda: L.ldetr_conv2d_bwd_data_f32(core.ptr(dy), ctypes.byref(dyt), core.ptr(w), Ci, k, k, s, p, core.ptr(dx), Ci, H, H, None, 0, None, core.stream()))
     sk = 0
     tw = timeit(lambda: L.ldetr_conv2d_bwd_weight_f32(core.ptr(x), ctypes.byref(xt), core.ptr(dy), ctypes.byref(dyt), core.ptr(dw), k, k, s, p, sk, None, 0, None, 0, 0, core.stream()))
+    xs = torch.rand(N, Ci, device=dev) + 0.5; ds = torch.rand(N, Co, device=dev) + 0.5
+    tws = timeit(lambda: L.ldetr_conv2d_bwd_weight_f32(core.ptr(x), ctypes.byref(xt), core.ptr(dy), ctypes.byref(dyt), core.ptr(dw), k, k, s, p, sk, core.ptr(xs), Ci, core.ptr(ds), Co, 0, core.stream())) if name.startswith('sg') else 0
+    if tws: name = name + f' [wgrad+scales {tws*1e6:.0f}us {fl/tws/1e12:.1f}TF]'
     print(f'{name:28s} M={N*OH*OH:6d} N={Co:4d} K={k*k*Ci:5d}  fwd {tf*1e6:8.1f}us {fl/tf/1e12:6.1f}TF | bwdD {tb*1e6:8.1f}us {fl/tb/1e12:6.1f}TF | bwdW(sk={sk:3d}) {tw*1e6:8.1f}us {fl/tw/1e12:6.1f}TF', flush=True)
     return fl, tf, tb, tw
 
