@@ -467,19 +467,31 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
 
     const int nk = (z.kend > z.kbeg) ? (z.kend - z.kbeg + BKT - 1) / BKT : 0;
     const int kl = lane >> 5, cl = lane & 31;
+    // Operand fetch from LDS runs one k-pair ahead of the MFMAs in a second register set: without it hipcc emits
+    // {ds_read, s_waitcnt lgkmcnt(0), 4 MFMA} per k-pair into ONE register set and the matrix pipe idles for the LDS latency
+    // every 256 cycles.
     auto compute = [&](int buf) {
+        float a[2][TM], b[2][TN];
+#pragma unroll
+        for (int i = 0; i < TM; i++) a[0][i] = As[buf][kl][wm * WM + i * 32 + cl];
+#pragma unroll
+        for (int j = 0; j < TN; j++) b[0][j] = Bs[buf][kl][wn * WN + j * 32 + cl];
 #pragma unroll
         for (int kk = 0; kk < BKT / 2; kk++) {
-            float a[TM], b[TN];
+            const int c = kk & 1, nx = c ^ 1;
+            if (kk + 1 < BKT / 2) {
 #pragma unroll
-            for (int i = 0; i < TM; i++) a[i] = As[buf][kk * 2 + kl][wm * WM + i * 32 + cl];
+                for (int i = 0; i < TM; i++) a[nx][i] = As[buf][(kk + 1) * 2 + kl][wm * WM + i * 32 + cl];
 #pragma unroll
-            for (int j = 0; j < TN; j++) b[j] = Bs[buf][kk * 2 + kl][wn * WN + j * 32 + cl];
+                for (int j = 0; j < TN; j++) b[nx][j] = Bs[buf][(kk + 1) * 2 + kl][wn * WN + j * 32 + cl];
+            }
+            __builtin_amdgcn_sched_barrier(0);   // keep the prefetch ahead of the MFMAs (the scheduler otherwise sinks it below them)
 #pragma unroll
             for (int i = 0; i < TM; i++)
 #pragma unroll
                 for (int j = 0; j < TN; j++)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[c][i], b[c][j], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
     };
     if (nk > 0) {
@@ -509,8 +521,8 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
             const int buf = kt & 1;
             if (kt + 1 < nk) gload(z.kbeg + (kt + 1) * BKT, ra0, rb0);
             compute(buf);
-            if (kt + 1 < nk) lstore(buf ^ 1, ra0, rb0);
-            __syncthreads();
+            if (kt + 1 < nk) lstore(buf ^ 1, ra0, rb0);   // (writing these between the MFMAs of the last k-pairs measured slower:
+            __syncthreads();                               //  the vmcnt wait then sits in the middle of the MFMA stream)
         }
     }
 

@@ -47,17 +47,22 @@ def gemm_case(name, M, N, K):
     t3 = timeit(lambda: core.gemm(dY, A, 1, 1, N, K, M, out=dw))
     print(f'{name:28s} M={M:6d} N={N:4d} K={K:5d}  fwd+bias+relu {t1*1e6:8.1f}us {fl/t1/1e12:6.1f}TF | dX   {t2*1e6:8.1f}us {fl/t2/1e12:6.1f}TF | dW   {t3*1e6:8.1f}us {fl/t3/1e12:6.1f}TF', flush=True)
 
-print('batch', B)
-tot = [0, 0, 0, 0]
-R = 64  # spatial after stem+pool at 256x256
-cases = [('l1 1x1 64->64', B, R, 64, 64, 1, 1, 0), ('l1 3x3 64->64', B, R, 64, 64, 3, 1, 1), ('l1 1x1 64->256', B, R, 64, 256, 1, 1, 0), ('l1 1x1 256->64', B, R, 256, 64, 1, 1, 0),
-         ('l2 1x1 256->128', B, R, 256, 128, 1, 1, 0), ('l2 3x3 128->128 s2', B, R, 128, 128, 3, 2, 1), ('l2 1x1 128->512', B, 32, 128, 512, 1, 1, 0), ('l2 1x1 256->512 s2', B, R, 256, 512, 1, 2, 0),
-         ('l2 1x1 512->128', B, 32, 512, 128, 1, 1, 0), ('l2 3x3 128->128', B, 32, 128, 128, 3, 1, 1),
-         ('l3 3x3 256->256 s2', B, 32, 256, 256, 3, 2, 1), ('l3 1x1 256->1024', B, 16, 256, 1024, 1, 1, 0), ('l3 1x1 1024->256', B, 16, 1024, 256, 1, 1, 0), ('l3 3x3 256->256', B, 16, 256, 256, 3, 1, 1),
-         ('l4 3x3 512->512 s2', B, 16, 512, 512, 3, 2, 1), ('l4 1x1 512->2048', B, 8, 512, 2048, 1, 1, 0), ('l4 1x1 2048->512', B, 8, 2048, 512, 1, 1, 0), ('l4 3x3 512->512', B, 8, 512, 512, 3, 1, 1),
-         ('sg 3x3 512->512 @16', B, 16, 512, 512, 3, 1, 1), ('sg 3x3 256->256 @32', B, 32, 256, 256, 3, 1, 1), ('sg 3x3 128->128 @64', B, 64, 128, 128, 3, 1, 1),
-         ('sg 3x3 64->64 @128', B, 128, 64, 64, 3, 1, 1), ('sg 3x3 32->32 @256', B, 256, 32, 32, 3, 1, 1)]
-for c in cases:
-    conv_case(*c)
-for g in [('enc proj 256', B * 64, 256, 256), ('encdec proj 256', B * 80, 256, 256), ('dec proj 256', B * 9, 256, 256), ('dec proj 256 (10)', B * 10, 256, 256), ('enc qk proj', B * 64, 512, 256), ('enc ffn1', B * 64, 2048, 256), ('enc ffn2', B * 64, 256, 2048), ('dec ffn1', B * 9, 2048, 256), ('fc_in 3072->768', B * 9, 768, 3072), ('mapping 512', B, 512, 512)]:
-    gemm_case(*g)
+def main():
+    print("batch", B)
+    tot = [0, 0, 0, 0]
+    R = 64  # spatial after stem+pool at 256x256
+    cases = [('l1 1x1 64->64', B, R, 64, 64, 1, 1, 0), ('l1 3x3 64->64', B, R, 64, 64, 3, 1, 1), ('l1 1x1 64->256', B, R, 64, 256, 1, 1, 0), ('l1 1x1 256->64', B, R, 256, 64, 1, 1, 0),
+             ('l2 1x1 256->128', B, R, 256, 128, 1, 1, 0), ('l2 3x3 128->128 s2', B, R, 128, 128, 3, 2, 1), ('l2 1x1 128->512', B, 32, 128, 512, 1, 1, 0), ('l2 1x1 256->512 s2', B, R, 256, 512, 1, 2, 0),
+             ('l2 1x1 512->128', B, 32, 512, 128, 1, 1, 0), ('l2 3x3 128->128', B, 32, 128, 128, 3, 1, 1),
+             ('l3 3x3 256->256 s2', B, 32, 256, 256, 3, 2, 1), ('l3 1x1 256->1024', B, 16, 256, 1024, 1, 1, 0), ('l3 1x1 1024->256', B, 16, 1024, 256, 1, 1, 0), ('l3 3x3 256->256', B, 16, 256, 256, 3, 1, 1),
+             ('l4 3x3 512->512 s2', B, 16, 512, 512, 3, 2, 1), ('l4 1x1 512->2048', B, 8, 512, 2048, 1, 1, 0), ('l4 1x1 2048->512', B, 8, 2048, 512, 1, 1, 0), ('l4 3x3 512->512', B, 8, 512, 512, 3, 1, 1),
+             ('sg 3x3 512->512 @16', B, 16, 512, 512, 3, 1, 1), ('sg 3x3 256->256 @32', B, 32, 256, 256, 3, 1, 1), ('sg 3x3 128->128 @64', B, 64, 128, 128, 3, 1, 1),
+             ('sg 3x3 64->64 @128', B, 128, 64, 64, 3, 1, 1), ('sg 3x3 32->32 @256', B, 256, 32, 32, 3, 1, 1)]
+    for c in cases:
+        conv_case(*c)
+    for g in [('enc proj 256', B * 64, 256, 256), ('encdec proj 256', B * 80, 256, 256), ('dec proj 256', B * 9, 256, 256), ('dec proj 256 (10)', B * 10, 256, 256), ('enc qk proj', B * 64, 512, 256), ('enc ffn1', B * 64, 2048, 256), ('enc ffn2', B * 64, 256, 2048), ('dec ffn1', B * 9, 2048, 256), ('fc_in 3072->768', B * 9, 768, 3072), ('mapping 512', B, 512, 512)]:
+        gemm_case(*g)
+
+
+if __name__ == '__main__':
+    main()
