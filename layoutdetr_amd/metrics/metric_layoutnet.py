@@ -69,3 +69,122 @@ def linear_sum_assignment_batched(cost, maximize=False):
     ci = torch.empty_like(ri)
     core.check(core.lib().ldetr_lsap_f64(core.ptr(c), batch, n, 1 if maximize else 0, core.ptr(ri), core.ptr(ci), core.stream()), 'lsap')
     return ri, ci
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+# Evaluation metrics (reference metrics/metric_layoutnet.py:66-150, 204-242).  Same names and arguments as the
+# reference.  The reference scores one pair of layouts at a time on the host (numpy + scipy, a process pool over conditions);
+# here every same-condition pair of a corpus is scored in ONE batched device pass: pairwise IoU / DocSim weights as [P, n, n]
+# tensors, cross-label entries excluded by a large cost, one device Hungarian solve per pair (csrc/lsap.hip, n <= 16).
+# Since both layouts of a pair carry the same multiset of labels, the optimum of the single n x n problem is the sum of the
+# reference's per-label optima.  Only the final N x M matching per condition (rectangular, N and M unbounded) stays on scipy.
+_CROSS_LABEL = -1.0e6
+
+
+def compute_iou(box_1, box_2):
+    """IoU of corresponding xywh boxes: [N, 4] x [N, 4] -> [N] (reference :66-92); torch tensors on any device or numpy."""
+    import numpy as np
+    if isinstance(box_1, np.ndarray):
+        return compute_iou(torch.from_numpy(box_1), torch.from_numpy(box_2)).numpy()
+    l1, t1, r1, b1 = convert_xywh_to_ltrb(box_1.T)
+    l2, t2, r2, b2 = convert_xywh_to_ltrb(box_2.T)
+    a1, a2 = (r1 - l1) * (b1 - t1), (r2 - l2) * (b2 - t2)
+    l_max, r_min = torch.maximum(l1, l2), torch.minimum(r1, r2)
+    t_max, b_min = torch.maximum(t1, t2), torch.minimum(b1, b2)
+    cond = (l_max < r_min) & (t_max < b_min)
+    ai = torch.where(cond, (r_min - l_max) * (b_min - t_max), torch.zeros_like(a1))
+    return torch.nan_to_num(ai / (a1 + a2 - ai))
+
+
+def compute_docsim_weight(box_1, box_2):
+    """DocSim weight of corresponding boxes (reference :204-221)."""
+    import numpy as np
+    if isinstance(box_1, np.ndarray):
+        return compute_docsim_weight(torch.from_numpy(box_1), torch.from_numpy(box_2)).numpy()
+    xc1, yc1, w1, h1 = box_1.T
+    xc2, yc2, w2, h2 = box_2.T
+    location_difference = ((xc1 - xc2) ** 2 + (yc1 - yc2) ** 2) ** 0.5
+    shape_difference = (w1 - w2).abs() + (h1 - h2).abs()
+    area_factor = torch.minimum(w1 * h1, w2 * h2) ** 0.5
+    return area_factor * 2 ** (-location_difference - 2.0 * shape_difference)
+
+
+def compute_iou_for_layout(layout_1, layout_2):
+    (bi, li), (bj, lj) = layout_1, layout_2
+    return compute_iou(bi, bj).mean().item()
+
+
+def compute_docsim_for_layout(layout_1, layout_2):
+    (bi, li), (bj, lj) = layout_1, layout_2
+    return compute_docsim_weight(bi, bj).mean().item()
+
+
+def maximum_scores_batched(b1, l1, b2, l2, kind='iou'):
+    """Scores of P layout pairs at once.  b1, b2: [P, n, 4] float32 device tensors (xywh); l1, l2: [P, n] integer labels with
+    equal label multisets per pair; n <= 16.  -> [P] float64: per pair, the maximum over label-preserving matchings of the
+    summed IoU (kind='iou', reference :100-113) or DocSim weight (kind='docsim', :229-242), divided by n."""
+    P, n, _ = b1.shape
+    fn = compute_iou if kind == 'iou' else compute_docsim_weight
+    # rows = boxes of layout 2, columns = boxes of layout 1 (the reference's meshgrid order)
+    bi = b1[:, None, :, :].expand(P, n, n, 4).reshape(-1, 4)
+    bj = b2[:, :, None, :].expand(P, n, n, 4).reshape(-1, 4)
+    w = fn(bi, bj).reshape(P, n, n).to(torch.float64)
+    same = l2[:, :, None] == l1[:, None, :]
+    cost = torch.where(same, w, torch.full_like(w, _CROSS_LABEL))
+    ri, ci = linear_sum_assignment_batched(cost, maximize=True)
+    picked = torch.gather(cost, 2, ci.long().unsqueeze(-1)).squeeze(-1)        # row_ind is 0..n-1 in order
+    if bool((picked <= _CROSS_LABEL / 2).any()):
+        raise ValueError('maximum_scores_batched: a pair of layouts does not share one multiset of labels')
+    return picked.sum(-1) / n
+
+
+def _pair_on_device(layout_1, layout_2, kind):
+    import numpy as np
+    (bi, li), (bj, lj) = layout_1, layout_2
+    dev = torch.device('cuda', torch.cuda.current_device())
+    t = lambda a, dt: torch.as_tensor(np.asarray(a), dtype=dt, device=dev).unsqueeze(0)
+    return maximum_scores_batched(t(bi, torch.float32), t(li, torch.int64), t(bj, torch.float32), t(lj, torch.int64), kind).item()
+
+
+def compute_maximum_iou_for_layout(layout_1, layout_2):
+    """layout = (bbox [N, 4] array, label [N] array), as in the reference (:100-113)."""
+    return _pair_on_device(layout_1, layout_2, 'iou')
+
+
+def compute_maximum_docsim_for_layout(layout_1, layout_2):
+    return _pair_on_device(layout_1, layout_2, 'docsim')
+
+
+def compute_maximum_iou(layouts_1, layouts_2, n_jobs=None):
+    """Corpus-level maximum IoU (reference :116-150).  Layouts are grouped by their sorted label list; every same-condition
+    pair is scored in one batched device pass per condition; the N x M matching per condition runs on scipy as in the
+    reference.  n_jobs is accepted for signature compatibility (there is no process pool: the device pass replaces it).
+    Like the reference (:118-124) the pair scores are enumerated layouts_2-major and re-wrapped to (N, M)."""
+    import numpy as np
+    from scipy.optimize import linear_sum_assignment
+    dev = torch.device('cuda', torch.cuda.current_device())
+
+    def group(layout_list):
+        out = {}
+        for bs, ls in layout_list:
+            out.setdefault(str(sorted(np.asarray(ls).tolist())), []).append((np.asarray(bs), np.asarray(ls)))
+        return out
+
+    c1, c2 = group(layouts_1), group(layouts_2)
+    scores = []
+    for key in c1:
+        if key not in c2:
+            continue
+        A, B = c1[key], c2[key]
+        N, M = len(A), len(B)
+        b1 = torch.as_tensor(np.stack([a[0] for a in A]), dtype=torch.float32, device=dev)
+        l1 = torch.as_tensor(np.stack([a[1] for a in A]), dtype=torch.int64, device=dev)
+        b2 = torch.as_tensor(np.stack([b[0] for b in B]), dtype=torch.float32, device=dev)
+        l2 = torch.as_tensor(np.stack([b[1] for b in B]), dtype=torch.int64, device=dev)
+        jj, ii = torch.meshgrid(torch.arange(M, device=dev), torch.arange(N, device=dev), indexing='ij')   # j outer, i inner
+        ii, jj = ii.reshape(-1), jj.reshape(-1)
+        flat = maximum_scores_batched(b1[ii], l1[ii], b2[jj], l2[jj], 'iou')
+        s = flat.cpu().numpy().reshape(N, M)
+        r, c = linear_sum_assignment(s, maximize=True)
+        scores.extend(s[r, c].tolist())
+    return float(np.mean(scores))

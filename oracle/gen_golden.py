@@ -216,6 +216,52 @@ def gen_lsap():
     save('lsap', d)
 
 
+def gen_metrics():
+    """Layout metrics of the evaluation path: pairwise IoU / DocSim weights, per-pair maximum scores with the
+    per-label Hungarian matching, and the corpus-level compute_maximum_iou (metrics/metric_layoutnet.py:66-150, 204-242)."""
+    import numpy as np
+    from metrics import metric_layoutnet as M
+    rng = np.random.RandomState(77)
+
+    def layout(labels):
+        n = len(labels)
+        b = np.concatenate([rng.rand(n, 2) * 0.6 + 0.2, rng.rand(n, 2) * 0.35 + 0.05], -1).astype(np.float32)
+        return b, np.asarray(labels, dtype=np.int64)
+
+    conds = [[0, 0, 1, 2, 2, 2, 3], [1, 1, 1, 1], [0, 1, 2, 3, 4, 5, 6, 7, 0], [2], [3, 3, 0]]
+    L1, L2 = [], []
+    for c in conds:
+        for _ in range(3):
+            L1.append(layout(list(rng.permutation(c))))
+        for _ in range(4):
+            L2.append(layout(list(rng.permutation(c))))
+    L2.append(layout([4, 4]))                     # a condition with no counterpart
+    L1[1] = (L1[0][0].copy(), L1[0][1].copy())    # exact duplicate layout -> tied assignments
+    d = {}
+    for i, (b, l) in enumerate(L1):
+        d[f'l1_b{i}'] = b; d[f'l1_l{i}'] = l
+    for i, (b, l) in enumerate(L2):
+        d[f'l2_b{i}'] = b; d[f'l2_l{i}'] = l
+    d['n1'] = np.asarray(len(L1)); d['n2'] = np.asarray(len(L2))
+    b1 = np.concatenate([b for b, _ in L1[:6]]); b2 = np.concatenate([b for b, _ in L2[:8]])[:len(b1)]
+    d['iou_in1'] = b1; d['iou_in2'] = b2
+    d['iou'] = M.compute_iou(b1, b2); d['docsim_w'] = M.compute_docsim_weight(b1, b2)
+    # per-pair maximum scores for every same-condition pair, in (i, j) order of the lists above
+    pairs, miou, mdoc, piou, pdoc = [], [], [], [], []
+    for i, (bi, li) in enumerate(L1):
+        for j, (bj, lj) in enumerate(L2):
+            if sorted(li.tolist()) == sorted(lj.tolist()):
+                pairs.append((i, j))
+                miou.append(M.compute_maximum_iou_for_layout((bi, li), (bj, lj)))
+                mdoc.append(M.compute_maximum_docsim_for_layout((bi, li), (bj, lj)))
+                if (li == lj).all():
+                    piou.append(M.compute_iou_for_layout((bi, li), (bj, lj))); pdoc.append(M.compute_docsim_for_layout((bi, li), (bj, lj)))
+    d['pairs'] = np.asarray(pairs); d['max_iou_pair'] = np.asarray(miou); d['max_docsim_pair'] = np.asarray(mdoc)
+    d['iou_layout'] = np.asarray(piou); d['docsim_layout'] = np.asarray(pdoc)
+    d['max_iou_corpus'] = np.asarray(M.compute_maximum_iou(L1, L2, n_jobs=1))
+    save('metrics', d)
+
+
 def gen_dp_step():
     from torch_utils import misc
     torch.manual_seed(600)
@@ -237,6 +283,8 @@ if __name__ == '__main__':
     sys.path.insert(0, REF)
     _stub_modules()
     torch.set_num_threads(8)
+    if '--only-metrics' in sys.argv:
+        gen_metrics(); sys.exit(0)
     if '--skip-done' not in sys.argv:
         gen_ops(); gen_transformer()
-    gen_losses(); gen_decoder(); gen_frozen_bn(); gen_lsap(); gen_dp_step()
+    gen_losses(); gen_decoder(); gen_frozen_bn(); gen_lsap(); gen_dp_step(); gen_metrics()

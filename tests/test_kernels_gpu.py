@@ -3,6 +3,7 @@ native ops, plain torch fp32 for the ATen-replacing contractions).  Tolerances a
 index outputs (max-pool argmax routing, LSAP) are bit-exact."""
 import ctypes
 import math
+import os
 
 import numpy as np
 import pytest
@@ -441,3 +442,46 @@ def test_lsap_matches_scipy_bit_exact(dev):
             for b in range(batch):
                 r, cc = linear_sum_assignment(cost[b], maximize=bool(maximize))
                 assert ri[b].cpu().tolist() == r.tolist() and ci[b].cpu().tolist() == cc.tolist()
+
+
+# ------------------------------------------------------------------------------------------ layout metrics
+def _metric_layouts():
+    d = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'metrics.npz'))
+    L1 = [(d[f'l1_b{i}'], d[f'l1_l{i}']) for i in range(int(d['n1']))]
+    L2 = [(d[f'l2_b{i}'], d[f'l2_l{i}']) for i in range(int(d['n2']))]
+    return d, L1, L2
+
+
+def test_layout_metrics_device_vs_reference_golden(dev):
+    """Batched device scoring (pairwise IoU / DocSim + one device Hungarian solve per pair) against the values the reference's
+    host functions produced, incl. a duplicated layout (tied assignments) and conditions present on one side only."""
+    from layoutdetr_amd.metrics import metric_layoutnet as M
+    d, L1, L2 = _metric_layouts()
+    mi = np.asarray([M.compute_maximum_iou_for_layout(L1[i], L2[j]) for i, j in d['pairs']])
+    md = np.asarray([M.compute_maximum_docsim_for_layout(L1[i], L2[j]) for i, j in d['pairs']])
+    assert np.abs(mi - d['max_iou_pair']).max() <= 1e-6, np.abs(mi - d['max_iou_pair']).max()
+    assert np.abs(md - d['max_docsim_pair']).max() <= 1e-6
+    assert abs(M.compute_maximum_iou(L1, L2) - float(d['max_iou_corpus'])) <= 1e-6
+    with pytest.raises(ValueError):
+        M.compute_maximum_iou_for_layout(L1[0], (L2[0][0], L2[0][1] + 7))
+
+
+def test_layout_metrics_device_vs_oracle_random(dev):
+    """Larger random corpus: device pass vs oracle/metrics_ref.py (numpy + scipy)."""
+    from layoutdetr_amd.metrics import metric_layoutnet as M
+    from oracle import metrics_ref as R
+    rng = np.random.RandomState(5)
+    def layout(labels):
+        n = len(labels)
+        return (np.concatenate([rng.rand(n, 2) * 0.6 + 0.2, rng.rand(n, 2) * 0.35 + 0.05], -1).astype(np.float32), np.asarray(labels, dtype=np.int64))
+    conds = [[0, 1, 1, 2, 2, 2, 3, 3, 3], [5, 5, 5], [0, 0, 0, 0, 0, 0], [1, 2]]
+    L1 = [layout(list(rng.permutation(c))) for c in conds for _ in range(7)]
+    L2 = [layout(list(rng.permutation(c))) for c in conds for _ in range(5)]
+    assert abs(M.compute_maximum_iou(L1, L2) - R.compute_maximum_iou(L1, L2)) <= 1e-6
+    b1 = torch.as_tensor(np.stack([l[0] for l in L1[:7]]), device=dev); l1 = torch.as_tensor(np.stack([l[1] for l in L1[:7]]), device=dev)
+    b2 = torch.as_tensor(np.stack([l[0] for l in L2[:5]] + [L2[0][0], L2[1][0]]), device=dev)
+    l2 = torch.as_tensor(np.stack([l[1] for l in L2[:5]] + [L2[0][1], L2[1][1]]), device=dev)
+    got = M.maximum_scores_batched(b1, l1, b2, l2, 'docsim').cpu().numpy()
+    L2x = L2[:5] + [L2[0], L2[1]]
+    ref = np.asarray([R.compute_maximum_docsim_for_layout(L1[k], L2x[k]) for k in range(7)])
+    assert np.abs(got - ref).max() <= 1e-6

@@ -167,3 +167,33 @@ def test_lsap_oracle_bit_exact():
                 r, c = _lsap(lib, cost, mx)
                 rs, cs = linear_sum_assignment(cost, maximize=mx)
                 assert c.tolist() == cs.tolist()
+
+
+def _metric_layouts():
+    d = np.load(os.path.join(G, 'metrics.npz'))
+    L1 = [(d[f'l1_b{i}'], d[f'l1_l{i}']) for i in range(int(d['n1']))]
+    L2 = [(d[f'l2_b{i}'], d[f'l2_l{i}']) for i in range(int(d['n2']))]
+    return d, L1, L2
+
+
+def test_layout_metrics_oracle():
+    """oracle/metrics_ref.py against the reference's own metric functions (golden from metrics/metric_layoutnet.py:66-150,204-242)."""
+    from oracle import metrics_ref as R
+    d, L1, L2 = _metric_layouts()
+    assert np.abs(R.compute_iou(d['iou_in1'], d['iou_in2']) - d['iou']).max() <= 1e-7
+    assert np.abs(R.compute_docsim_weight(d['iou_in1'], d['iou_in2']) - d['docsim_w']).max() <= 1e-7
+    mi = np.asarray([R.compute_maximum_iou_for_layout(L1[i], L2[j]) for i, j in d['pairs']])
+    md = np.asarray([R.compute_maximum_docsim_for_layout(L1[i], L2[j]) for i, j in d['pairs']])
+    assert np.abs(mi - d['max_iou_pair']).max() <= 1e-7 and np.abs(md - d['max_docsim_pair']).max() <= 1e-7
+    same = [(i, j) for i, j in d['pairs'] if (L1[i][1] == L2[j][1]).all()]
+    pi = np.asarray([R.compute_iou_for_layout(L1[i], L2[j]) for i, j in same])
+    assert np.abs(pi - d['iou_layout']).max() <= 1e-7
+    assert abs(R.compute_maximum_iou(L1, L2) - float(d['max_iou_corpus'])) <= 1e-9
+
+
+def test_layout_metric_formulas_product():
+    """The product module's elementwise IoU / DocSim formulas (torch glue, device-agnostic) against the same golden."""
+    from layoutdetr_amd.metrics import metric_layoutnet as M
+    d, _, _ = _metric_layouts()
+    assert np.abs(M.compute_iou(d['iou_in1'], d['iou_in2']) - d['iou']).max() <= 1e-7
+    assert np.abs(M.compute_docsim_weight(d['iou_in1'], d['iou_in2']) - d['docsim_w']).max() <= 1e-7
