@@ -40,8 +40,10 @@ __device__ __forceinline__ float attn_drop(const AttnParams& p, int bh, int q, i
     return drop_scale(p.seed + (p.seed_ptr ? *p.seed_ptr : 0ull), ((uint64_t)bh * p.Lq + q) * p.Lk + key, p.p_drop, inv_keep);
 }
 
-template <int NKT>
+// DHC = head_dim / 32 (1 for the DETR blocks; 2..6 for the BERT text encoder's 64..192-wide heads, forward only).
+template <int NKT, int DHC>
 __global__ __launch_bounds__(64) void attn_fwd_kernel(AttnParams p) {
+    constexpr int DH = 32 * DHC;
     const int nqt = (p.Lq + 15) >> 4;
     const int qt = blockIdx.x % nqt;
     const int bh = blockIdx.x / nqt;
@@ -50,14 +52,14 @@ __global__ __launch_bounds__(64) void attn_fwd_kernel(AttnParams p) {
     const int q0 = qt << 4;
     const int qrow = q0 + li;
     const bool qok = qrow < p.Lq;
-    const float* qp = p.q + ((long)b * p.Lq + qrow) * p.ldq + h * 32;
-    const float* kb = p.k + (long)b * p.Lk * p.ldk + h * 32;
-    const float* vb = p.v + (long)b * p.Lk * p.ldv + h * 32;
+    const float* qp = p.q + ((long)b * p.Lq + qrow) * p.ldq + h * DH;
+    const float* kb = p.k + (long)b * p.Lk * p.ldk + h * DH;
+    const float* vb = p.v + (long)b * p.Lk * p.ldv + h * DH;
     const unsigned char* kpm = p.kpm ? p.kpm + (long)b * p.Lk : nullptr;
 
-    float qf[8];
+    float qf[8 * DHC];
 #pragma unroll
-    for (int kk = 0; kk < 8; kk++) qf[kk] = ldz(qp + 4 * kk + g, qok) * p.scale;
+    for (int kk = 0; kk < 8 * DHC; kk++) qf[kk] = ldz(qp + 4 * kk + g, qok) * p.scale;
 
     f32x4 s[NKT];
     float mx = -INFINITY;
@@ -68,7 +70,7 @@ __global__ __launch_bounds__(64) void attn_fwd_kernel(AttnParams p) {
         const bool kok = krow < p.Lk;
         const float* kp = kb + (long)krow * p.ldk;
 #pragma unroll
-        for (int kk = 0; kk < 8; kk++) acc = MFMA16(ldz(kp + 4 * kk + g, kok), qf[kk], acc);
+        for (int kk = 0; kk < 8 * DHC; kk++) acc = MFMA16(ldz(kp + 4 * kk + g, kok), qf[kk], acc);
 #pragma unroll
         for (int r = 0; r < 4; r++) {
             int key = 16 * j + 4 * g + r;
@@ -91,7 +93,9 @@ __global__ __launch_bounds__(64) void attn_fwd_kernel(AttnParams p) {
     if (p.lse && g == 0 && qok) p.lse[(long)bh * p.Lq + qrow] = mx + logf(sum);
     const float inv_keep = p.p_drop > 0.f ? 1.f / (1.f - p.p_drop) : 1.f;
 
-    f32x4 o0 = {0.f, 0.f, 0.f, 0.f}, o1 = {0.f, 0.f, 0.f, 0.f};
+    f32x4 o[2 * DHC];
+#pragma unroll
+    for (int c = 0; c < 2 * DHC; c++) o[c] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int j = 0; j < NKT; j++) {
 #pragma unroll
@@ -101,14 +105,14 @@ __global__ __launch_bounds__(64) void attn_fwd_kernel(AttnParams p) {
             float pv = s[j][t] * inv;
             if (p.p_drop > 0.f) pv *= attn_drop(p, bh, qrow, key, inv_keep);
             const float* vp = vb + (long)key * p.ldv;
-            o0 = MFMA16(ldz(vp + li, kok), pv, o0);
-            o1 = MFMA16(ldz(vp + 16 + li, kok), pv, o1);
+#pragma unroll
+            for (int c = 0; c < 2 * DHC; c++) o[c] = MFMA16(ldz(vp + 16 * c + li, kok), pv, o[c]);
         }
     }
     if (qok) {
-        float* op = p.o + ((long)b * p.Lq + qrow) * p.ldo + h * 32 + 4 * g;
-        *reinterpret_cast<float4*>(op) = make_float4(o0[0], o0[1], o0[2], o0[3]);
-        *reinterpret_cast<float4*>(op + 16) = make_float4(o1[0], o1[1], o1[2], o1[3]);
+        float* op = p.o + ((long)b * p.Lq + qrow) * p.ldo + h * DH + 4 * g;
+#pragma unroll
+        for (int c = 0; c < 2 * DHC; c++) *reinterpret_cast<float4*>(op + 16 * c) = make_float4(o[c][0], o[c][1], o[c][2], o[c][3]);
     }
 }
 
@@ -277,7 +281,7 @@ extern "C" int ldetr_attention_fwd_f32(const float* q, int64_t ldq, const float*
                                        const unsigned char* key_padding_mask, float* out, int64_t ldo, float* lse,
                                        int B, int H, int Lq, int Lk, int head_dim, float scale,
                                        float p_drop, uint64_t seed, const uint64_t* seed_ptr, void* stream) {
-    LDETR_CHECK(head_dim == 32, "attention: head_dim must be 32 (got %d)", head_dim);
+    LDETR_CHECK(head_dim >= 32 && head_dim <= 192 && head_dim % 32 == 0, "attention_fwd: head_dim must be a multiple of 32 up to 192 (got %d)", head_dim);
     AttnParams p; memset(&p, 0, sizeof(p));
     p.q = q; p.k = k; p.v = v; p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.kpm = key_padding_mask;
     p.o = out; p.ldo = ldo; p.lse = lse; p.B = B; p.H = H; p.Lq = Lq; p.Lk = Lk;
@@ -287,11 +291,23 @@ extern "C" int ldetr_attention_fwd_f32(const float* q, int64_t ldq, const float*
     const int nqt = (Lq + 15) / 16, nkt = (Lk + 15) / 16;
     const int grid = B * H * nqt;
     hipStream_t st = (hipStream_t)stream;
-    if (nkt <= 1) hipLaunchKernelGGL(attn_fwd_kernel<1>, grid, 64, 0, st, p);
-    else if (nkt <= 2) hipLaunchKernelGGL(attn_fwd_kernel<2>, grid, 64, 0, st, p);
-    else if (nkt <= 4) hipLaunchKernelGGL(attn_fwd_kernel<4>, grid, 64, 0, st, p);
-    else if (nkt <= 8) hipLaunchKernelGGL(attn_fwd_kernel<8>, grid, 64, 0, st, p);
-    else hipLaunchKernelGGL(attn_fwd_kernel<16>, grid, 64, 0, st, p);
+#define LDETR_ATTN_FWD(DHC)                                                                     \
+    do {                                                                                         \
+        if (nkt <= 1) hipLaunchKernelGGL((attn_fwd_kernel<1, DHC>), grid, 64, 0, st, p);         \
+        else if (nkt <= 2) hipLaunchKernelGGL((attn_fwd_kernel<2, DHC>), grid, 64, 0, st, p);    \
+        else if (nkt <= 4) hipLaunchKernelGGL((attn_fwd_kernel<4, DHC>), grid, 64, 0, st, p);    \
+        else if (nkt <= 8) hipLaunchKernelGGL((attn_fwd_kernel<8, DHC>), grid, 64, 0, st, p);    \
+        else hipLaunchKernelGGL((attn_fwd_kernel<16, DHC>), grid, 64, 0, st, p);                 \
+    } while (0)
+    switch (head_dim / 32) {
+        case 1: LDETR_ATTN_FWD(1); break;
+        case 2: LDETR_ATTN_FWD(2); break;
+        case 3: LDETR_ATTN_FWD(3); break;
+        case 4: LDETR_ATTN_FWD(4); break;
+        case 5: LDETR_ATTN_FWD(5); break;
+        default: LDETR_ATTN_FWD(6); break;
+    }
+#undef LDETR_ATTN_FWD
     return check_launch("attention_fwd");
 }
 

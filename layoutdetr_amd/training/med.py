@@ -1,0 +1,184 @@
+"""BERT text encoder of the LayoutDETR hot path, forward only, on the gfx950 kernels (first half).
+
+Drop-in for the frozen `text_encoder` the reference builds at training/networks_detr.py:88-93 / :213-218
+(`BertModel(config, add_pooling_layer=False)` from training/med.py) as it is CALLED on the hot path
+(networks_detr.py:146,290):  `text_encoder(input_ids, attention_mask=..., return_dict=True, mode='text')`
+followed by `.last_hidden_state[:, 0, :]`.  Same sub-module and parameter names as training/med.py
+(BertEmbeddings :55-97, BertSelfAttention :100-228, BertSelfOutput :231-241, BertIntermediate :296-307, BertOutput
+:310-320, BertLayer :323-386 in mode='text', BertEncoder :389-486), so a reference / HF `bert-base-uncased`
+state_dict loads with strict=True (the cross-attention parameters of an `add_cross_attention` config exist and are never
+touched in text mode, exactly as in the reference).
+
+The module is frozen in the reference (`requires_grad_(False)`, training_loop.py:283): there is no backward path here,
+and calling it with gradients enabled on its parameters raises.  Per layer: one packed q|k|v GEMM (the three weight
+matrices are concatenated once and cached), fused attention for head widths 32..192 (`csrc/attention.hip`), output
+projection, residual + dropout + LayerNorm in one kernel, GELU fused into the intermediate GEMM's epilogue.
+Tokenisation (strings -> ids) stays on the host and outside this package: pass token ids.
+"""
+import math
+from types import SimpleNamespace
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from ..hip import core
+from ..hip.layernorm import add_layernorm
+
+
+class BertConfig(SimpleNamespace):
+    """The fields of configs/med_config.json that the text-mode forward reads (defaults = that file)."""
+
+    def __init__(self, vocab_size=30522, hidden_size=768, num_hidden_layers=12, num_attention_heads=12, intermediate_size=3072,
+                 max_position_embeddings=512, layer_norm_eps=1e-12, hidden_dropout_prob=0.1, attention_probs_dropout_prob=0.1,
+                 pad_token_id=0, add_cross_attention=True, encoder_width=768, **unused):
+        super().__init__(vocab_size=vocab_size, hidden_size=hidden_size, num_hidden_layers=num_hidden_layers,
+                         num_attention_heads=num_attention_heads, intermediate_size=intermediate_size,
+                         max_position_embeddings=max_position_embeddings, layer_norm_eps=layer_norm_eps,
+                         hidden_dropout_prob=hidden_dropout_prob, attention_probs_dropout_prob=attention_probs_dropout_prob,
+                         pad_token_id=pad_token_id, add_cross_attention=add_cross_attention, encoder_width=encoder_width)
+
+    @classmethod
+    def from_json_file(cls, path):
+        import json
+        with open(path) as f:
+            return cls(**json.load(f))
+
+
+class BertEmbeddings(nn.Module):
+    def __init__(self, config):
+        super().__init__()
+        self.word_embeddings = nn.Embedding(config.vocab_size, config.hidden_size, padding_idx=config.pad_token_id)
+        self.position_embeddings = nn.Embedding(config.max_position_embeddings, config.hidden_size)
+        self.LayerNorm = nn.LayerNorm(config.hidden_size, eps=config.layer_norm_eps)
+        self.dropout = nn.Dropout(config.hidden_dropout_prob)
+        self.register_buffer('position_ids', torch.arange(config.max_position_embeddings).expand((1, -1)))
+
+    def forward(self, input_ids):
+        T = input_ids.shape[1]
+        x = self.word_embeddings(input_ids) + self.position_embeddings(self.position_ids[:, :T])
+        x = add_layernorm(x.reshape(-1, x.shape[-1]), None, self.LayerNorm.weight, self.LayerNorm.bias, self.LayerNorm.eps)
+        return self.dropout(x)   # [B*T, hidden]
+
+
+class _SelfAttentionParams(nn.Module):
+    def __init__(self, hidden, kv_width=None):
+        super().__init__()
+        self.query = nn.Linear(hidden, hidden)
+        self.key = nn.Linear(kv_width or hidden, hidden)
+        self.value = nn.Linear(kv_width or hidden, hidden)
+
+
+class _SelfOutput(nn.Module):
+    def __init__(self, config):
+        super().__init__()
+        self.dense = nn.Linear(config.hidden_size, config.hidden_size)
+        self.LayerNorm = nn.LayerNorm(config.hidden_size, eps=config.layer_norm_eps)
+
+
+class BertAttention(nn.Module):
+    def __init__(self, config, is_cross_attention=False):
+        super().__init__()
+        self.self = _SelfAttentionParams(config.hidden_size, config.encoder_width if is_cross_attention else None)
+        self.output = _SelfOutput(config)
+
+
+class _Intermediate(nn.Module):
+    def __init__(self, config):
+        super().__init__()
+        self.dense = nn.Linear(config.hidden_size, config.intermediate_size)
+
+
+class _Output(nn.Module):
+    def __init__(self, config):
+        super().__init__()
+        self.dense = nn.Linear(config.intermediate_size, config.hidden_size)
+        self.LayerNorm = nn.LayerNorm(config.hidden_size, eps=config.layer_norm_eps)
+
+
+class BertLayer(nn.Module):
+    def __init__(self, config, layer_num):
+        super().__init__()
+        self.config = config
+        self.layer_num = layer_num
+        self.attention = BertAttention(config)
+        if config.add_cross_attention:
+            self.crossattention = BertAttention(config, is_cross_attention=True)   # mode='multimodal' only: unused here
+        self.intermediate = _Intermediate(config)
+        self.output = _Output(config)
+        self._packed = None
+
+    def _qkv(self):
+        """q|k|v weights concatenated to one [3*hidden, hidden] matrix (+ bias), rebuilt only when a weight was modified."""
+        a = self.attention.self
+        ver = (a.query.weight._version, a.key.weight._version, a.value.weight._version, a.query.bias._version,
+               a.key.bias._version, a.value.bias._version, a.query.weight.data_ptr())
+        if self._packed is None or self._packed[0] != ver:
+            w = torch.cat([a.query.weight, a.key.weight, a.value.weight], 0).detach().contiguous()
+            b = torch.cat([a.query.bias, a.key.bias, a.value.bias], 0).detach().contiguous()
+            self._packed = (ver, w, b)
+        return self._packed[1], self._packed[2]
+
+    def forward2d(self, x2, B, T, kpm):
+        cfg = self.config
+        d, H = cfg.hidden_size, cfg.num_attention_heads
+        dh = d // H
+        M = x2.shape[0]
+        p_attn = cfg.attention_probs_dropout_prob if self.training else 0.0
+        p_hid = cfg.hidden_dropout_prob if self.training else 0.0
+        w, b = self._qkv()
+        qkv = core.gemm(x2, w, 0, 0, M, 3 * d, d, ep=core.epilogue(col_bias=b))
+        ctx = torch.empty((M, d), device=x2.device, dtype=torch.float32)
+        seed = core.next_seed() if p_attn > 0 else 0
+        q, k, v = qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:]
+        core.check(core.lib().ldetr_attention_fwd_f32(
+            core.ptr(q), qkv.stride(0), core.ptr(k), qkv.stride(0), core.ptr(v), qkv.stride(0), core.ptr(kpm),
+            core.ptr(ctx), d, None, B, H, T, T, dh, 1.0 / math.sqrt(dh), p_attn, seed,
+            core.seed_ptr() if p_attn > 0 else None, core.stream()), 'bert attention')
+        so = self.attention.output
+        a = core.gemm(ctx, so.dense.weight.detach(), 0, 0, M, d, d, ep=core.epilogue(col_bias=so.dense.bias.detach()))
+        x2 = add_layernorm(x2, a, so.LayerNorm.weight, so.LayerNorm.bias, so.LayerNorm.eps, p_hid)
+        it, out = self.intermediate.dense, self.output
+        h = core.gemm(x2, it.weight.detach(), 0, 0, M, cfg.intermediate_size, d,
+                      ep=core.epilogue(col_bias=it.bias.detach(), act=core.ACT_GELU))
+        f = core.gemm(h, out.dense.weight.detach(), 0, 0, M, d, cfg.intermediate_size, ep=core.epilogue(col_bias=out.dense.bias.detach()))
+        return add_layernorm(x2, f, out.LayerNorm.weight, out.LayerNorm.bias, out.LayerNorm.eps, p_hid)
+
+
+class BertEncoder(nn.Module):
+    def __init__(self, config):
+        super().__init__()
+        self.config = config
+        self.layer = nn.ModuleList([BertLayer(config, i) for i in range(config.num_hidden_layers)])
+
+
+class BertModel(nn.Module):
+    """Text-mode forward of the reference's BertModel(add_pooling_layer=False)."""
+
+    def __init__(self, config, add_pooling_layer=False):
+        super().__init__()
+        if add_pooling_layer:
+            raise NotImplementedError('the hot path builds the text encoder with add_pooling_layer=False (networks_detr.py:92)')
+        self.config = config
+        self.embeddings = BertEmbeddings(config)
+        self.encoder = BertEncoder(config)
+
+    def forward(self, input_ids, attention_mask=None, return_dict=True, mode='text'):
+        if mode != 'text':
+            raise NotImplementedError("only mode='text' (self-attention only) is on the hot path (training/med.py:361)")
+        core.require_gpu(input_ids)
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            raise RuntimeError('the text encoder is forward-only (frozen in the reference, training_loop.py:283): '
+                               'call text_encoder.requires_grad_(False) or run it under torch.no_grad()')
+        B, T = input_ids.shape
+        if T > 256:
+            raise NotImplementedError('sequence length > 256 is not supported by the fused attention kernel')
+        with torch.no_grad():
+            # reference: additive mask (1 - attention_mask) * -10000 (get_extended_attention_mask); a masked key's probability
+            # underflows to exactly 0 in fp32 either way, so the kernel's -inf key-padding mask gives the same numbers
+            kpm = None if attention_mask is None else (attention_mask == 0).to(torch.uint8).contiguous()
+            x2 = self.embeddings(input_ids)
+            for layer in self.encoder.layer:
+                x2 = layer.forward2d(x2, B, T, kpm)
+            hs = x2.reshape(B, T, -1)
+        return SimpleNamespace(last_hidden_state=hs) if return_dict else (hs,)

@@ -262,6 +262,46 @@ def gen_metrics():
     save('metrics', d)
 
 
+def gen_bert():
+    """Text-mode BERT encoder: outputs of the reference's own BertEmbeddings + BertEncoder (training/med.py).
+    BertModel itself cannot be constructed under the installed transformers (5.x changed PreTrainedModel's init protocol), and
+    med.py imports three helpers that moved since 4.19.2; they are aliased to their current homes (real functions of the same
+    dependency) or, for the head-pruning helper that the forward never calls, to a stub that raises.  The mask preparation
+    of BertModel.forward (:709-748) is the one-liner below."""
+    hidden = {k: sys.modules.pop(k) for k in list(sys.modules) if k.split('.')[0] == 'torchvision'}   # transformers probes the real package
+    import transformers.modeling_utils as mu
+    import transformers.pytorch_utils as pu
+    mu.apply_chunking_to_forward = pu.apply_chunking_to_forward
+    mu.prune_linear_layer = pu.prune_linear_layer
+
+    def _unused(*a, **k):
+        raise NotImplementedError
+    mu.find_pruneable_heads_and_indices = _unused
+    from training.med import BertConfig, BertEmbeddings, BertEncoder
+    sys.modules.update(hidden)
+    for tag, (hid, heads, layers, inter, T, B) in {'': (64, 2, 2, 128, 12, 3), '_dh64': (128, 2, 2, 256, 21, 4)}.items():
+        torch.manual_seed(410 + hid)
+        cfg = BertConfig(vocab_size=60, hidden_size=hid, num_hidden_layers=layers, num_attention_heads=heads, intermediate_size=inter,
+                         max_position_embeddings=40, add_cross_attention=True, encoder_width=hid)
+        emb, enc = BertEmbeddings(cfg).eval(), BertEncoder(cfg).eval()
+        for nm, prm in list(emb.named_parameters()) + list(enc.named_parameters()):
+            prm.data.normal_(0, 0.08)
+            if 'LayerNorm.weight' in nm:
+                prm.data.add_(1.0)
+        ids = torch.randint(1, 60, (B, T)); am = torch.ones(B, T, dtype=torch.long)
+        am[1, T // 2:] = 0; am[B - 1, 1:] = 0; ids[am == 0] = 0
+        ext = (1.0 - am[:, None, None, :].float()) * -10000.0
+        with torch.no_grad():
+            out = enc(emb(input_ids=ids), attention_mask=ext, return_dict=True, mode='text').last_hidden_state
+        d = {'input_ids': ids, 'attention_mask': am, 'last_hidden_state': out, 'num_heads': np.asarray(heads)}
+        for k, v in emb.state_dict().items():
+            d['sd/embeddings.' + k] = v
+        for k, v in enc.state_dict().items():
+            if 'crossattention' not in k:      # never read in text mode; left out of the fixture
+                d['sd/encoder.' + k] = v
+        save('bert_text' + tag, d)
+
+
 def gen_dp_step():
     from torch_utils import misc
     torch.manual_seed(600)
@@ -285,6 +325,8 @@ if __name__ == '__main__':
     torch.set_num_threads(8)
     if '--only-metrics' in sys.argv:
         gen_metrics(); sys.exit(0)
+    if '--only-bert' in sys.argv:
+        gen_bert(); sys.exit(0)
     if '--skip-done' not in sys.argv:
         gen_ops(); gen_transformer()
-    gen_losses(); gen_decoder(); gen_frozen_bn(); gen_lsap(); gen_dp_step(); gen_metrics()
+    gen_losses(); gen_decoder(); gen_frozen_bn(); gen_lsap(); gen_dp_step(); gen_metrics(); gen_bert()

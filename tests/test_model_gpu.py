@@ -239,3 +239,56 @@ def test_static_shapes_and_graph_replay_match_eager(dev):
         a, b = grads[name][-2], grads[name][-1]
         assert torch.isfinite(a).all() and a.abs().sum() > 0
         assert ((a - b).norm() / b.norm()).item() < 5e-3, name
+
+
+# ------------------------------------------------------------------------------------------ BERT text encoder
+@pytest.mark.gpu
+@pytest.mark.parametrize('tag', ['', '_dh64'])
+def test_bert_text_encoder_vs_reference_golden(dev, tag):
+    """HIP text encoder (packed qkv GEMM, fused attention, GELU epilogue, fused add+LN) against the reference modules' output."""
+    from layoutdetr_amd.training import med
+    d = np.load(os.path.join(G_DIR, f"bert_text{tag}.npz"))
+    sd = {k[3:]: torch.from_numpy(d[k]) for k in d.files if k.startswith('sd/')}
+    hid = sd['embeddings.word_embeddings.weight'].shape[1]
+    cfg = med.BertConfig(vocab_size=sd['embeddings.word_embeddings.weight'].shape[0], hidden_size=hid, num_hidden_layers=2,
+                         num_attention_heads=int(d['num_heads']), intermediate_size=sd['encoder.layer.0.intermediate.dense.weight'].shape[0],
+                         max_position_embeddings=sd['embeddings.position_embeddings.weight'].shape[0], add_cross_attention=False)
+    m = med.BertModel(cfg).eval().requires_grad_(False)
+    missing, unexpected = m.load_state_dict(sd, strict=False)
+    assert not unexpected and not [k for k in missing if 'crossattention' not in k]
+    m.to(dev)
+    out = m(torch.from_numpy(d['input_ids']).to(dev), attention_mask=torch.from_numpy(d['attention_mask']).to(dev), return_dict=True, mode='text')
+    ref = torch.from_numpy(d['last_hidden_state'])
+    err = (out.last_hidden_state.cpu() - ref).abs().max().item() / ref.abs().max().item()
+    assert err <= 1e-5, err
+    with pytest.raises(RuntimeError):
+        med.BertModel(cfg).to(dev)(torch.from_numpy(d['input_ids']).to(dev))     # parameters still require grad: forward-only module
+
+
+@pytest.mark.gpu
+def test_bert_text_encoder_hot_path_shape_vs_oracle(dev):
+    """The hot path's configuration class (hidden 768, 4 heads x 192, GELU 3072) at 2 layers, 40 tokens, ragged masks."""
+    from layoutdetr_amd.training import med
+    from oracle import bert_ref
+    torch.manual_seed(91)
+    cfg = med.BertConfig(vocab_size=300, hidden_size=768, num_hidden_layers=2, num_attention_heads=4, intermediate_size=3072,
+                         max_position_embeddings=64, add_cross_attention=True)
+    m = med.BertModel(cfg).eval().requires_grad_(False)
+    for n, p in m.named_parameters():
+        p.data.normal_(0, 0.03)
+        if 'LayerNorm.weight' in n:
+            p.data.add_(1.0)
+    B, T = 6, 40
+    ids = torch.randint(1, 300, (B, T)); am = torch.ones(B, T, dtype=torch.long)
+    am[0, 17:] = 0; am[3, 1:] = 0; am[5, 33:] = 0
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    ref = bert_ref.bert_text_forward(sd, 4, ids, am)
+    m.to(dev)
+    out = m(ids.to(dev), attention_mask=am.to(dev)).last_hidden_state.cpu()
+    keep = am.bool()
+    err = (out - ref)[keep].abs().max().item() / ref.abs().max().item()
+    assert err <= 2e-5, err
+    # train mode draws dropout masks (attention probabilities + hidden states): finite, different from eval, same CLS scale
+    m.train()
+    out_t = m(ids.to(dev), attention_mask=am.to(dev)).last_hidden_state.cpu()
+    assert torch.isfinite(out_t).all() and (out_t - out).abs().max().item() > 1e-3

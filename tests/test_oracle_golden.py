@@ -197,3 +197,13 @@ def test_layout_metric_formulas_product():
     d, _, _ = _metric_layouts()
     assert np.abs(M.compute_iou(d['iou_in1'], d['iou_in2']) - d['iou']).max() <= 1e-7
     assert np.abs(M.compute_docsim_weight(d['iou_in1'], d['iou_in2']) - d['docsim_w']).max() <= 1e-7
+
+
+@pytest.mark.parametrize('tag', ['', '_dh64'])
+def test_bert_text_encoder_oracle(tag):
+    """oracle/bert_ref.py against the outputs of the reference's BertEmbeddings + BertEncoder in text mode (training/med.py)."""
+    from oracle import bert_ref
+    d = np.load(os.path.join(G, f'bert_text{tag}.npz'))
+    sd = {k[3:]: torch.from_numpy(d[k]) for k in d.files if k.startswith('sd/')}
+    out = bert_ref.bert_text_forward(sd, int(d['num_heads']), torch.from_numpy(d['input_ids']), torch.from_numpy(d['attention_mask']))
+    close(out, d['last_hidden_state'], 2e-6)
