@@ -7,9 +7,11 @@ works from the reference `train.py` / `training_loop.py` unchanged (SURVEY §8b 
 Text path (SURVEY §8a rows a16/a17 are *boundary inputs*, not kernel rows): `bbox_text` may be
   * a `TextFeatures` carrying the frozen BERT CLS features [B, N, 768] and character counts [B, N]
     (hot-path-only mode, BASELINE.md variant A), or
-  * a list of B lists of N strings as in the reference — requires `text_mode='bert'`, which is the
-    round-2 row 8f-1 and raises NotImplementedError for now.
-In features mode the LM-decoder reconstruction loss (`loss_lm`) is returned as a zero tensor.
+  * a `TextTokens` carrying the tokenizer's output (`input_ids`, `attention_mask` [B, N, T]) and the character counts —
+    requires `text_mode='encoder'`: the frozen BERT text encoder (training/med.py) then runs on the HIP
+    kernels inside forward(), exactly where the reference calls it (networks_detr.py:145-147, 289-291).
+Strings are not accepted: tokenisation is host-side work outside this package (the reference's `init_tokenizer` needs the
+`bert-base-uncased` vocabulary).  The LM-decoder reconstruction loss (`loss_lm`, §8f-1 second half) is a zero tensor.
 
 `module.static_shapes = True` (opt-in, used by bench.py) switches the reconstruction heads from the reference's
 boolean gathers `x[~padding_mask]` (dynamic shape M -> device-to-host sync, SURVEY §7 "launch-bound regime") to
@@ -74,6 +76,32 @@ class TextFeatures(object):
                             None if self.attention_mask is None else self.attention_mask[idx])
 
 
+class TextTokens(object):
+    """Tokenizer output for one batch: input_ids / attention_mask [B, N, T] int64, text_len [B, N] (character counts)."""
+
+    def __init__(self, input_ids, attention_mask, text_len):
+        self.input_ids, self.attention_mask, self.text_len = input_ids, attention_mask, text_len
+
+    def __len__(self):
+        return self.input_ids.shape[0]
+
+    def __getitem__(self, idx):
+        return TextTokens(self.input_ids[idx], self.attention_mask[idx], self.text_len[idx])
+
+
+def _build_text_encoder(text_mode, med_config, num_layers, num_heads):
+    """reference: networks_detr.py:88-93 (encoder_config from med_config.json with layers / heads overridden)."""
+    if text_mode == 'features':
+        return _NoTextEncoder()
+    if text_mode != 'encoder':
+        raise ValueError("text_mode must be 'features' (TextFeatures in) or 'encoder' (TextTokens in)")
+    import os
+    from . import med
+    cfg = med.BertConfig.from_json_file(med_config) if (med_config and os.path.exists(med_config)) else med.BertConfig()
+    cfg.num_hidden_layers, cfg.num_attention_heads = num_layers, num_heads
+    return med.BertModel(cfg, add_pooling_layer=False)
+
+
 class _NoTextEncoder(nn.Module):
     """Placeholder so `module.text_encoder.requires_grad_(False)` (training_loop.py:283) keeps working."""
 
@@ -115,7 +143,12 @@ class MLP(nn.Module):
 def _text_inputs(module, bbox_text, B, N, device):
     if isinstance(bbox_text, TextFeatures):
         return bbox_text.text_feat.to(device=device, dtype=torch.float32), bbox_text.text_len.to(device=device, dtype=torch.int64)
-    raise NotImplementedError('string inputs need the BERT text encoder (SURVEY §8f-1, next round); pass TextFeatures')
+    if isinstance(bbox_text, TextTokens):
+        T = bbox_text.input_ids.shape[-1]
+        out = module.text_encoder(bbox_text.input_ids.reshape(B * N, T).to(device), attention_mask=bbox_text.attention_mask.reshape(B * N, T).to(device),
+                                  return_dict=True, mode='text')
+        return out.last_hidden_state[:, 0, :].reshape(B, N, -1), bbox_text.text_len.to(device=device, dtype=torch.int64)
+    raise NotImplementedError('pass TextFeatures (precomputed CLS features) or TextTokens (tokenizer output); strings need the host tokenizer')
 
 
 def _zero_like_loss(ref):
@@ -134,14 +167,12 @@ class Generator(nn.Module):
         self.max_text_length = max_text_length
         self.text_mode = text_mode
         self.static_shapes = False   # see module docstring: True = sync-free full-slot outputs (hipGraph-capturable)
-        if text_mode != 'features':
-            raise NotImplementedError("text_mode='bert' is the next hot-path row (SURVEY §8f-1)")
 
         self.backbone = build_backbone()
         self.input_proj = Conv1x1(self.backbone.num_channels, hidden_dim, kernel_size=1)
         self.fc_z = Linear(z_dim * 9, bert_f_dim)
         self.emb_label = nn.Embedding(num_bbox_labels, bert_f_dim)
-        self.text_encoder = _NoTextEncoder()
+        self.text_encoder = _build_text_encoder(text_mode, med_config, bert_num_encoder_layers, bert_num_heads)
         self.enc_text_len = nn.Embedding(max_text_length, bert_f_dim)
         self.fc_in = MLP(input_dim=4 * bert_f_dim, hidden_dim=bert_f_dim, output_dim=hidden_dim, num_layers=3)
         self.transformer = Transformer(d_model=hidden_dim, dropout=0.1, nhead=8, dim_feedforward=2048, num_encoder_layers=6,
@@ -204,15 +235,13 @@ class Discriminator(nn.Module):
         self.max_text_length = max_text_length
         self.text_mode = text_mode
         self.static_shapes = False
-        if text_mode != 'features':
-            raise NotImplementedError("text_mode='bert' is the next hot-path row (SURVEY §8f-1)")
 
         # encoder
         self.backbone = build_backbone()
         self.input_proj = Conv1x1(self.backbone.num_channels, hidden_dim, kernel_size=1)
         self.fc_bbox = Linear(4, bert_f_dim)
         self.emb_label = nn.Embedding(num_bbox_labels, bert_f_dim)
-        self.text_encoder = _NoTextEncoder()
+        self.text_encoder = _build_text_encoder(text_mode, med_config, bert_num_encoder_layers, bert_num_heads)
         self.enc_text_len = nn.Embedding(max_text_length, bert_f_dim)
         self.enc_fc_in = MLP(input_dim=4 * bert_f_dim, hidden_dim=bert_f_dim, output_dim=hidden_dim, num_layers=3)
         self.enc_transformer = TransformerWithToken(d_model=hidden_dim, dropout=0.1, nhead=8, dim_feedforward=2048,

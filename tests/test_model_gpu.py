@@ -292,3 +292,41 @@ def test_bert_text_encoder_hot_path_shape_vs_oracle(dev):
     m.train()
     out_t = m(ids.to(dev), attention_mask=am.to(dev)).last_hidden_state.cpu()
     assert torch.isfinite(out_t).all() and (out_t - out).abs().max().item() > 1e-3
+
+
+@pytest.mark.gpu
+def test_generator_text_mode_encoder_equals_features_mode(dev):
+    """G with the in-module text encoder (TextTokens in) == G fed the same encoder's CLS features (TextFeatures in),
+    and a full G+D iteration runs with tokens (text encoder frozen inside the flat-parameter step)."""
+    from layoutdetr_amd.training.networks_detr import Discriminator, Generator, TextFeatures, TextTokens
+    from layoutdetr_amd.training import training_loop as tl
+    from layoutdetr_amd.training.loss import StyleGAN2Loss
+    torch.manual_seed(12)
+    bg, B, N, T = 64, 2, 9, 24
+    kw = dict(num_bbox_labels=8, img_channels=3, img_height=bg, img_width=bg, c_dim=0, background_size=bg, bert_f_dim=768, im_f_dim=512,
+              bert_num_encoder_layers=2, bert_num_heads=4)
+    G = Generator(z_dim=4, text_mode='encoder', **kw).eval().requires_grad_(False).to(dev)
+    D = Discriminator(text_mode='encoder', **kw).eval().requires_grad_(False).to(dev)
+    ids = torch.randint(1, 30000, (B, N, T), device=dev); am = torch.ones(B, N, T, dtype=torch.long, device=dev)
+    am[0, 2, 9:] = 0; am[1, :, 15:] = 0
+    text_len = torch.randint(1, 40, (B, N), device=dev)
+    toks = TextTokens(ids, am, text_len)
+    xy = torch.rand(B, N, 2, device=dev) * 0.6 + 0.2; wh = torch.rand(B, N, 2, device=dev) * 0.35 + 0.05
+    bbox = torch.cat([xy, wh], -1); cls = torch.randint(0, 8, (B, N), device=dev)
+    patch = torch.zeros(B, N, 1, 1, 1, device=dev).expand(B, N, 3, 8, 8)
+    pm = torch.zeros(B, N, dtype=torch.bool, device=dev); back = torch.randn(B, 3, bg, bg, device=dev)
+    z = torch.randn(B, N, 4, device=dev)
+    with torch.no_grad():
+        out_tok = G(z, cls, bbox, toks, patch, pm, back, None)
+        feat = G.text_encoder(ids.reshape(B * N, T), attention_mask=am.reshape(B * N, T)).last_hidden_state[:, 0].reshape(B, N, -1)
+        out_feat = G(z, cls, bbox, TextFeatures(feat, text_len), patch, pm, back, None)
+    assert torch.equal(out_tok, out_feat)
+    G.train(); D.train(); G.static_shapes = D.static_shapes = True
+    pG = tl.Phase('Gmain', G, lr=1e-5); pD = tl.Phase('Dmain', D, lr=1e-5)
+    batch = dict(bbox_real=bbox, bbox_class=cls, bbox_text=toks, bbox_patch=patch, padding_mask=pm, background=back,
+                 real_c=torch.zeros(B, 0, device=dev), gen_c=torch.zeros(B, 0, device=dev))
+    w0 = G.text_encoder.encoder.layer[0].intermediate.dense.weight.clone()
+    tl.training_iteration(StyleGAN2Loss(dev, G, D), [pG, pD], tl.DataParallelStep(1), batch, B, [z, z])
+    torch.cuda.synchronize()
+    assert torch.equal(G.text_encoder.encoder.layer[0].intermediate.dense.weight, w0), 'frozen text encoder moved'
+    assert all(torch.isfinite(p).all() for p in G.parameters())
