@@ -56,8 +56,7 @@ typedef struct ldetr_tensor4 {
  *   v *= samp_scale[sample(m)][n]          (StyleGAN2 demodulation / style scale)
  *   v += col_bias[n]
  *   v += residual[m][n]
- *   v = act(v)                             (1: relu, 2: leaky-relu(act_alpha) * act_gain, 3: erf-GELU, forward only:
- *                                           BERT's intermediate activation, training/med.py:296-307)
+ *   v = act(v)                             (1: relu, 2: leaky-relu(act_alpha) * act_gain)
  *   v *= dact(mask_src[m][n])              (backward masks: 1 relu, 2 leaky-relu * act_gain)
  *   v *= dropout_keep(seed, m*ldc + n)/(1-p_drop)
  *   v *= out_scale

@@ -24,7 +24,10 @@ SOURCES = ['ldetr_core.cpp', 'bias_act.hip', 'upfirdn2d.hip', 'gemm_conv.hip', '
 HEADERS = ['ldetr_common.hpp', os.path.join('..', '..', 'include', 'ldetr_hip.h')]
 
 FLAGS = ['-O3', '-std=c++17', '-fPIC', f'--offload-arch={ARCH}', '-munsafe-fp-atomics', '-fno-gpu-rdc',
-         '-Wno-unused-result']
+         '-Wno-unused-result', '-Rpass-analysis=kernel-resource-usage']
+# kernels whose register budget is the design: any scratch (spill / stack object) is a build error, not a silent 10x slowdown
+# (an erf in the engine's epilogue once cost 320 bytes of scratch per lane and every 128x128 GEMM ran 14x slower)
+NO_SCRATCH = ('gemm_f32_kernel', 'gemm_skinny_kernel', 'gemm_small_kernel', 'attn_fwd_kernel', 'attn_bwd_kernel')
 
 
 def _hipcc():
@@ -41,6 +44,22 @@ def _digest(paths):
             h.update(f.read())
     h.update(' '.join(FLAGS).encode())
     return h.hexdigest()
+
+
+def _kernel_resources(remarks):
+    """Parse clang's -Rpass-analysis=kernel-resource-usage remarks -> {mangled kernel name: {field: value}}."""
+    out, cur = {}, None
+    for line in remarks.splitlines():
+        if 'remark:' not in line:
+            continue
+        body = line.split('remark:', 1)[1].split('[-Rpass-analysis', 1)[0].strip()
+        if body.startswith('Function Name:'):
+            cur = body.split(':', 1)[1].strip()
+            out[cur] = {}
+        elif cur is not None and ':' in body:
+            k, v = body.rsplit(':', 1)
+            out[cur][k.strip()] = v.strip()
+    return out
 
 
 def lib_path():
@@ -70,6 +89,14 @@ def build(force=False, verbose=True):
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f'hipcc failed for {sp}:\n{r.stdout}\n{r.stderr}')
+        res = _kernel_resources(r.stderr)
+        with open(obj + '.resources.txt', 'w') as f:
+            for name, d in res.items():
+                f.write(f"{name} vgprs={d.get('VGPRs', '?')} agprs={d.get('AGPRs', '?')} scratch={d.get('ScratchSize [bytes/lane]', '?')} "
+                        f"occupancy={d.get('Occupancy [waves/SIMD]', '?')} lds={d.get('LDS Size [bytes/block]', '?')}\n")
+        bad = [n for n, d in res.items() if any(k in n for k in NO_SCRATCH) and d.get('ScratchSize [bytes/lane]', '0') != '0']
+        if bad:
+            raise RuntimeError(f'{os.path.basename(sp)}: scratch memory in register-budgeted kernels: ' + ', '.join(bad[:4]))
         with open(stamp, 'w') as f:
             f.write(dig)
 

@@ -347,7 +347,6 @@ __device__ __forceinline__ float apply_epilogue(const GemmEpilogue& ep, float v,
     v += res;
     if (ep.act == 1) v = fmaxf(v, 0.f);
     else if (ep.act == 2) v = (v > 0.f ? v : v * ep.act_alpha) * ep.act_gain;
-    else if (ep.act == 3) v = 0.5f * v * (1.f + erff(v * 0.70710678118654752f));   // exact (erf) GELU: BERT's "gelu" (forward only)
     if (ep.mask_mode) {
         float s = ep.mask_src[orow * ep.ldm + n];
         if (ep.mask_mode == 1) v = s > 0.f ? v : 0.f;
@@ -858,7 +857,6 @@ __global__ __launch_bounds__(256, (KS == 2 ? 4 : (KS == 4 ? 3 : 2))) void gemm_s
                 float v = acc[r] * ep.alpha * cs + cb + (is_mask ? 0.f : res[r]);
                 if (ep.act == 1) v = fmaxf(v, 0.f);
                 else if (ep.act == 2) v = (v > 0.f ? v : v * ep.act_alpha) * ep.act_gain;
-                else if (ep.act == 3) v = 0.5f * v * (1.f + erff(v * 0.70710678118654752f));
                 if (is_mask) v = res[r] > 0.f ? v : 0.f;
                 v *= ep.out_scale;
                 if (ep.accumulate) v += __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(rc, vo, ro * ldc4, 0));

@@ -7,7 +7,7 @@ import torch
 from .. import _lib
 from .._lib import Epilogue, Tensor4
 
-ACT_NONE, ACT_RELU, ACT_LRELU, ACT_GELU = 0, 1, 2, 3
+ACT_NONE, ACT_RELU, ACT_LRELU = 0, 1, 2
 
 _seed_counter = [0x5EED]
 

@@ -12,7 +12,7 @@ touched in text mode, exactly as in the reference).
 The module is frozen in the reference (`requires_grad_(False)`, training_loop.py:283): there is no backward path here,
 and calling it with gradients enabled on its parameters raises.  Per layer: one packed q|k|v GEMM (the three weight
 matrices are concatenated once and cached), fused attention for head widths 32..192 (`csrc/attention.hip`), output
-projection, residual + dropout + LayerNorm in one kernel, GELU fused into the intermediate GEMM's epilogue.
+projection, residual + dropout + LayerNorm in one kernel, bias + erf-GELU as one in-place streaming pass.
 Tokenisation (strings -> ids) stays on the host and outside this package: pass token ids.
 """
 import math
@@ -139,8 +139,11 @@ class BertLayer(nn.Module):
         a = core.gemm(ctx, so.dense.weight.detach(), 0, 0, M, d, d, ep=core.epilogue(col_bias=so.dense.bias.detach()))
         x2 = add_layernorm(x2, a, so.LayerNorm.weight, so.LayerNorm.bias, so.LayerNorm.eps, p_hid)
         it, out = self.intermediate.dense, self.output
-        h = core.gemm(x2, it.weight.detach(), 0, 0, M, cfg.intermediate_size, d,
-                      ep=core.epilogue(col_bias=it.bias.detach(), act=core.ACT_GELU))
+        h = core.gemm(x2, it.weight.detach(), 0, 0, M, cfg.intermediate_size, d)
+        # bias + erf-GELU in place, one streaming pass (inside the contraction kernel's epilogue the erf cost 320 bytes of
+        # scratch per lane and sent the accumulator tile through it: 14x slower GEMMs)
+        core.check(core.lib().ldetr_bias_act_f32(core.ptr(h), core.ptr(it.bias.detach()), None, None, None, core.ptr(h), h.numel(),
+                                                 cfg.intermediate_size, 1, 0, 10, 0.0, 1.0, -1.0, core.stream()), 'bias_act gelu')
         f = core.gemm(h, out.dense.weight.detach(), 0, 0, M, d, cfg.intermediate_size, ep=core.epilogue(col_bias=out.dense.bias.detach()))
         return add_layernorm(x2, f, out.LayerNorm.weight, out.LayerNorm.bias, out.LayerNorm.eps, p_hid)
 

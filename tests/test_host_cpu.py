@@ -180,3 +180,21 @@ def test_bench_batch_helpers():
     assert bt['bbox_real'].shape == (3, 9, 4) and bt['background'].shape == (3, 3, 32, 32)
     assert (bt['bbox_real'][..., :2] >= 0.2).all() and (bt['bbox_real'][..., 2:] <= 0.4).all()
     assert not bt['padding_mask'].any()
+
+
+def test_register_budgeted_kernels_use_no_scratch():
+    """The contraction-engine / attention kernels are designed around their register budget; the build records clang's
+    per-kernel resource usage and refuses scratch in them (guards against silent 10x regressions from an innocent edit)."""
+    from layoutdetr_amd import build
+    build.build(verbose=False)
+    import glob
+    files = glob.glob(os.path.join(build.OBJDIR, '*.resources.txt'))
+    assert files, 'no resource reports next to the objects'
+    n = 0
+    for f in files:
+        for line in open(f):
+            name = line.split()[0]
+            if any(k in name for k in build.NO_SCRATCH):
+                n += 1
+                assert ' scratch=0 ' in line, line
+    assert n > 50
