@@ -15,6 +15,6 @@ for _ in range(reps):
     elif mode == 'bwdd':
         L.ldetr_conv2d_bwd_data_f32(core.ptr(dy), ctypes.byref(dyt), core.ptr(w), Ci, k, k, s, p, core.ptr(dx), Ci, H, H, None, 0, None, st)
     else:
-        tiles = k * k * ((Co + 63) // 64) * ((Ci + 63) // 64); sk = core.pick_splitk(tiles, N * OH * OH, target=512, min_k=512)
+        sk = 0
         L.ldetr_conv2d_bwd_weight_f32(core.ptr(x), ctypes.byref(xt), core.ptr(dy), ctypes.byref(dyt), core.ptr(dw), k, k, s, p, sk, None, 0, None, 0, 0, st)
 torch.cuda.synchronize()
