@@ -356,14 +356,19 @@ __device__ __forceinline__ float apply_epilogue(const GemmEpilogue& ep, float v,
     return v * ep.out_scale;
 }
 
-template <int BM, int BN, int BKT, int AMODE, int BMODE, int NST>
-__global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
+// NWV waves per block: 4 (2x2 wave grid) or 8 (2x4: same tile, half the accumulators per wave, twice the waves per SIMD to
+// cover each other's barrier / staging phases).
+template <int BM, int BN, int BKT, int AMODE, int BMODE, int NWV>
+__global__ __launch_bounds__(NWV * 64) void gemm_f32_kernel(GemmParams p) {
+    constexpr int NT = NWV * 64;
+    constexpr int WGN = (NWV == 8 && BN >= 128) ? 4 : 2, WGM = NWV / WGN;
     constexpr bool A_KC = AMODE <= OP_KC_WTAP;
     constexpr bool B_KC = BMODE <= OP_KC_WTAP;
     constexpr int LDA = BM + 2, LDB = BN + 2;
     constexpr int QK = BKT / 4;                                  // float4 quads along k per row
-    constexpr int NUA = BM * BKT / 4 / 256, NUB = BN * BKT / 4 / 256;  // float4 units per thread per k-tile
-    constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
+    constexpr int NUA = BM * BKT / 4 / NT, NUB = BN * BKT / 4 / NT;  // float4 units per thread per k-tile
+    constexpr int WM = BM / WGM, WN = BN / WGN, TM = WM / 32, TN = WN / 32;
+    static_assert(NUA >= 1 && NUB >= 1 && TM >= 1 && TN >= 1, "tile too small for this many waves");
     // dynamic LDS (the 128x128xBK32 image is 65 KiB: above the 64 KiB static limit, within the CU's 160 KiB)
     extern __shared__ __attribute__((aligned(16))) float ldetr_smem[];
     float (*As)[BKT][LDA] = reinterpret_cast<float (*)[BKT][LDA]>(ldetr_smem);
@@ -373,7 +378,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
     const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
     if (m0 >= z.M) return;  // uniform per block (parity classes may be smaller than the launch grid)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WGN, wn = wave % WGN;
 
     // Per-thread unit assignment + incremental k decode state.
     int a_r[NUA], a_k[NUA], b_r[NUB], b_k[NUB];
@@ -381,7 +386,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
     KDec a_d[NUA], b_d[NUB];
 #pragma unroll
     for (int i = 0; i < NUA; i++) {
-        int u = tid + i * 256;
+        int u = tid + i * NT;
         a_d[i].c = a_d[i].ty = a_d[i].tx = a_d[i].n = a_d[i].y = a_d[i].x = 0;
         if constexpr (A_KC) {
             a_r[i] = u / QK; a_k[i] = (u - a_r[i] * QK) << 2; a_rc[i] = make_row<AMODE>(p.A, p, z, m0 + a_r[i], z.M);
@@ -394,7 +399,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
     }
 #pragma unroll
     for (int i = 0; i < NUB; i++) {
-        int u = tid + i * 256;
+        int u = tid + i * NT;
         b_d[i].c = b_d[i].ty = b_d[i].tx = b_d[i].n = b_d[i].y = b_d[i].x = 0;
         if constexpr (B_KC) {
             b_r[i] = u / QK; b_k[i] = (u - b_r[i] * QK) << 2; b_rc[i] = make_row<BMODE>(p.B, p, z, n0 + b_r[i], p.N);
@@ -414,9 +419,8 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
 #pragma unroll
             for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
 
-    // Two register staging sets (NST == 2, the 64x64 tile): global loads run TWO k-tiles ahead of the MFMAs (PMC on the one-ahead version: waves
-    // spent 33% of their cycles parked on s_waitcnt/barriers with only 2 blocks resident per CU — exposed HBM/L2 latency).
-    float4 ra0[NUA], rb0[NUB], ra1[NUA], rb1[NUB];
+    // register staging of the next k-tile (global loads run one k-tile ahead of the MFMAs; two ahead measured slower)
+    float4 ra0[NUA], rb0[NUB];
     // loads the k-tile starting at k0 and advances the decode state to the following tile
     auto gload = [&](int k0, float4 (&ra)[NUA], float4 (&rb)[NUB]) {
 #pragma unroll
@@ -498,24 +502,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
         gload(z.kbeg, ra0, rb0);
         lstore(0, ra0, rb0);
     }
-    if constexpr (NST == 2) {
-        if (nk > 1) gload(z.kbeg + BKT, ra1, rb1);
-        __syncthreads();
-        for (int kt = 0; kt < nk; kt += 2) {
-            // tile kt is in LDS buffer 0, tile kt+1 is in flight in register set 1, set 0 is free
-            if (kt + 2 < nk) gload(z.kbeg + (kt + 2) * BKT, ra0, rb0);
-            compute(0);
-            if (kt + 1 < nk) lstore(1, ra1, rb1);
-            __syncthreads();
-            if (kt + 1 >= nk) break;
-            // tile kt+1 is in LDS buffer 1, tile kt+2 is in flight in register set 0, set 1 is free
-            if (kt + 3 < nk) gload(z.kbeg + (kt + 3) * BKT, ra1, rb1);
-            compute(1);
-            if (kt + 2 < nk) lstore(0, ra0, rb0);
-            __syncthreads();
-        }
-    } else {
-        // one tile ahead (the 128x128 tile: the second register set costs a wave of occupancy and measured slower)
+    {
         __syncthreads();
         for (int kt = 0; kt < nk; kt++) {
             const int buf = kt & 1;
@@ -542,7 +529,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
             for (int j = 0; j < TN; j++)
 #pragma unroll
                 for (int r = 0; r < 16; r++)
-                    __hip_atomic_store(mine + ((i * TN + j) * 16 + r) * 256 + tid, acc[i][j][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(mine + ((i * TN + j) * 16 + r) * NT + tid, acc[i][j][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         // Agent-scope (sc1) stores/loads go past the per-XCD L2s, so draining this wave's stores is all the ordering the counter
         // needs; a full __threadfence() here writes back + invalidates the whole 4 MiB L2 and measured 100-150 us per launch.
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -569,7 +556,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
                 for (int j = 0; j < TN; j++)
 #pragma unroll
                     for (int r = 0; r < 16; r++)
-                        acc[i][j][r] += __hip_atomic_load(src + ((i * TN + j) * 16 + r) * 256 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        acc[i][j][r] += __hip_atomic_load(src + ((i * TN + j) * 16 + r) * NT + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         direct = true;
     }
@@ -944,6 +931,16 @@ static void init_operand(Operand& o) { memset(&o, 0, sizeof(o)); o.KW = 1; o.KH 
 #ifndef T128_BK
 #define T128_BK 32
 #endif
+#ifndef T128_WAVES
+#define T128_WAVES 8
+#endif
+#ifndef T12864_SPLIT_MIN_TILES
+#define T12864_SPLIT_MIN_TILES 64
+#endif
+#ifndef T12864_WAVES
+#define T12864_WAVES 8
+#define T12864_BK 32
+#endif
 
 // Dense GEMMs with fewer 64x64 tiles than this (and at most this much work) take the register-streaming 32x32 kernel.
 #ifndef SMALL_GEMM_TILES
@@ -965,10 +962,10 @@ static const Workspace& workspace_for_current_device() {
     return g_workspace[dev];
 }
 
-template <int BM, int BN, int BKT, int AMODE, int BMODE>
+template <int BM, int BN, int BKT, int AMODE, int BMODE, int NWV = 4>
 static int launch_tile(const GemmParams& p, dim3 grid, hipStream_t st) {
     constexpr size_t lds = (size_t)2 * BKT * ((BM + 2) + (BN + 2)) * sizeof(float);
-    auto kern = gemm_f32_kernel<BM, BN, BKT, AMODE, BMODE, 1>;
+    auto kern = gemm_f32_kernel<BM, BN, BKT, AMODE, BMODE, NWV>;
     if (lds > 64 * 1024) {
         static bool raised = false;   // one-time opt-in to > 64 KiB of dynamic LDS for this instantiation
         if (!raised) {
@@ -979,7 +976,7 @@ static int launch_tile(const GemmParams& p, dim3 grid, hipStream_t st) {
             raised = true;
         }
     }
-    hipLaunchKernelGGL(kern, grid, 256, lds, st, p);
+    hipLaunchKernelGGL(kern, grid, NWV * 64, lds, st, p);
     return check_launch("gemm_f32");
 }
 
@@ -992,7 +989,14 @@ static int launch_gemm(GemmParams& p, int Mmax, long out_rows, int zbase, bool a
     // 128x64 tile: every wave owns a 64x32 sub-tile = TWO independent MFMA accumulator chains (the 64x64 tile has one per wave,
     // so any LDS/barrier hiccup idles its SIMD's matrix pipe) and needs 1.5 instead of 2 LDS operand reads per MFMA.
     long t12864 = (long)cdiv(Mmax, 128) * cdiv(p.N, 64) * zbase * sk0;
-    const bool use12864 = !use128 && t12864 >= 512 && Mmax >= 128;
+    bool use12864 = !use128 && t12864 >= 512 && Mmax >= 128;
+    if (!use128 && !use12864 && auto_split && p.splitk <= 1 && zbase == 1 && Mmax >= 128 && t12864 >= T12864_SPLIT_MIN_TILES &&
+        !(p.ep.accumulate && !epilogue_is_linear(p.ep))) {
+        // mid-size problems (ResNet layer2-4 at batch 16): the 8-wave 128x64 tile with the reduction split until its grid fills the
+        // chip beats the 4-wave 64x64 tile, as long as every slice keeps >= 512 of K
+        const int sk = (int)((512 + t12864 - 1) / t12864);
+        if (sk >= 2 && sk <= 8 && p.K / sk >= 512) { use12864 = true; p.splitk = sk; }
+    }
     if (!use128 && !use12864 && auto_split && p.splitk <= 1 && t64 < 768 && !(p.ep.accumulate && !epilogue_is_linear(p.ep))) {
         // PMC: with <= 2 resident blocks per CU the single-accumulator waves leave the MFMA pipe ~55% idle; more, shorter blocks fill it
         int want = (int)(((t64 < 160 ? 384 : 1024) + t64 - 1) / t64);
@@ -1024,8 +1028,8 @@ static int launch_gemm(GemmParams& p, int Mmax, long out_rows, int zbase, bool a
     }
     dim3 grid(cdiv(p.N, use128 ? 128 : 64), cdiv(Mmax, (use128 || use12864) ? 128 : 64), zbase * (split ? p.splitk : 1));
     int rc;
-    if (use128) rc = launch_tile<128, 128, T128_BK, AMODE, BMODE>(p, grid, st);
-    else if (use12864) rc = launch_tile<128, 64, 16, AMODE, BMODE>(p, grid, st);
+    if (use128) rc = launch_tile<128, 128, T128_BK, AMODE, BMODE, T128_WAVES>(p, grid, st);
+    else if (use12864) rc = launch_tile<128, 64, T12864_BK, AMODE, BMODE, T12864_WAVES>(p, grid, st);
     else rc = launch_tile<64, 64, 32, AMODE, BMODE>(p, grid, st);
     if (rc) return rc;
     if (split && !fixup && !epilogue_is_linear(full)) {
