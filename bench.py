@@ -85,6 +85,7 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--no-share-trunk', action='store_true', help="evaluate D's ResNet trunk separately for the fake and the real pass of Dmain, as the reference does")
+    ap.add_argument('--share-trunk', default='phase', choices=['phase', 'iteration'], help="'iteration': one D-trunk evaluation also serves Gmain's D(fake) (D's weights do not change between the two phases)")
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -129,7 +130,7 @@ def main():
     pG = tl.Phase('Gmain', G, lr=1e-5, betas=(0.0, 0.99), eps=1e-8, reg_interval=4)     # train.py:204,281; training_loop.py:191-194
     pD = tl.Phase('Dmain', D, lr=1e-5, betas=(0.0, 0.99), eps=1e-8, reg_interval=16)
     ema = tl.EmaTracker(pG, G_ema)
-    loss = StyleGAN2Loss(device, G, D, share_D_trunk=not args.no_share_trunk)
+    loss = StyleGAN2Loss(device, G, D, share_D_trunk=False if args.no_share_trunk else (True if args.share_trunk == 'phase' else 'iteration'))
     dp = tl.DataParallelStep(world_size=world)
 
     torch.manual_seed(0 * world + rank)   # training_loop.py:101-102 seed rule
@@ -224,7 +225,7 @@ def main():
                                         'step (Gmain+Dmain fwd/bwd, grad exchange + nan_to_num, Adam, EMA), train mode (dropout 0.1); '
                                         'hot-path-only: frozen-BERT text features are an input, LM-decoder loss excluded',
                                global_batch=args.batch, per_gpu_batch=b_local, background=bg, elements=9,
-                               parallelism=f'dp{world}', hip_graph=not args.no_graph, d_trunk_shared=not args.no_share_trunk, params_G=n_params[0], params_D=n_params[1]),
+                               parallelism=f'dp{world}', hip_graph=not args.no_graph, d_trunk_shared=False if args.no_share_trunk else args.share_trunk, params_G=n_params[0], params_D=n_params[1]),
                    roofline=roofline, cpu_baseline=cpu)
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -102,9 +102,42 @@ class StyleGAN2Loss(Loss):
         # gradient (the reference recomputes it, training/loss.py:176-210: two run_D calls, two backward calls).  Same losses and
         # gradients up to fp32 summation order; share_D_trunk=False restores the reference's call pattern.
         self.share_D_trunk = share_D_trunk
+        # share_D_trunk='iteration' goes one step further: D's weights do not change between the Gmain and the Dmain phase of one
+        # iteration (Gmain updates G only, training_loop.py:281-313), so ONE trunk evaluation per iteration serves D(fake) in Gmain
+        # (values only: D is frozen there) and both D passes of Dmain (with its autograd graph).  The iteration driver calls
+        # precompute_D_trunk() before the phases; without that call the per-phase behaviour above applies.
+        self._trunk_cache = {}
         self.fork_D_trunk = os.environ.get('LDETR_FORK_TRUNK', '0') != '0'   # measured: no gain inside hipGraphs (negative results)
         self.report = report_fn if report_fn is not None else (lambda name, value: None)
         self.last = {}
+
+    @staticmethod
+    def _bg_key(background):
+        return (background.data_ptr(), tuple(background.shape)) if isinstance(background, torch.Tensor) else id(background)
+
+    def precompute_D_trunk(self, background):
+        """Evaluate D's trunk on `background` with gradient tracking and park it for this iteration's phases."""
+        if self.share_D_trunk != 'iteration' or not hasattr(self.D, 'trunk'):
+            return
+        trunk_params = list(self.D.backbone.parameters())
+        was = [p.requires_grad for p in trunk_params]
+        for p in trunk_params:
+            p.requires_grad_(True)     # the autograd graph is built now, used by Dmain's backward (training_loop.py:282 sets it there)
+        try:
+            with torch.enable_grad():
+                self._trunk_cache[self._bg_key(background)] = self.D.trunk(background)
+        finally:
+            for p, w in zip(trunk_params, was):
+                p.requires_grad_(w)
+
+    def _cached_trunk(self, background, detach, pop):
+        key = self._bg_key(background)
+        out = self._trunk_cache.pop(key, None) if pop else self._trunk_cache.get(key)
+        if out is None or not detach:
+            return out
+        from ..detr_util.misc import NestedTensor
+        feats, pos = out
+        return [NestedTensor(f.tensors.detach(), f.mask, getattr(f, 'uniform', False)) for f in feats], [p.detach() for p in pos]
 
     def run_G(self, z, bbox_class, bbox_real, bbox_text, bbox_patch, padding_mask, background, c, reconst=False, update_emas=False):
         if not reconst:
@@ -122,10 +155,11 @@ class StyleGAN2Loss(Loss):
         w = self.w
         valid = ~padding_mask
         static = bool(getattr(self.G, 'static_shapes', False))
-        fork = _TrunkFork(self.D, background, self.fork_D_trunk) if hasattr(self.D, 'trunk') else None
+        cached = self._cached_trunk(background, detach=True, pop=False)
+        fork = _TrunkFork(self.D, background, self.fork_D_trunk) if (cached is None and hasattr(self.D, 'trunk')) else None
         bbox_fake, loss_z, cls_logits, loss_lm, loss_text_len = self.run_G(gen_z, bbox_class, bbox_real, bbox_text, bbox_patch, padding_mask, background, gen_c, reconst=True)
         gen_logits, gen_logits_uncond = self.run_D(bbox_fake, bbox_class, bbox_text, bbox_patch, padding_mask, background, gen_c,
-                                                   trunk_out=fork.join() if fork is not None else None)
+                                                   trunk_out=cached if cached is not None else (fork.join() if fork is not None else None))
         terms = dict(
             loss_Ggen=F.softplus(-gen_logits),
             loss_Ggen_uncond=F.softplus(-gen_logits_uncond),
@@ -190,10 +224,15 @@ class StyleGAN2Loss(Loss):
             self.g_main_loss(bbox_real, bbox_class, bbox_text, bbox_patch, padding_mask, background, gen_z, gen_c).mul(gain).backward()
             core.join_side()
         if phase == 'Dmain':
-            if self.share_D_trunk and hasattr(self.D, 'trunk'):
-                fork = _TrunkFork(self.D, background, self.fork_D_trunk)   # overlaps G's no-grad forward inside d_gen_loss
-                l_gen = self.d_gen_loss(bbox_real, bbox_class, bbox_text, bbox_patch, padding_mask, background, gen_z, gen_c, trunk_out=fork)
-                l_real = self.d_real_loss(bbox_real, bbox_class, bbox_text, bbox_patch, padding_mask, background, real_c, trunk_out=fork.join())
+            if self.share_D_trunk and hasattr(self.D, 'trunk'):   # True / 'phase' / 'iteration'
+                cached = self._cached_trunk(background, detach=False, pop=True)
+                if cached is not None:
+                    l_gen = self.d_gen_loss(bbox_real, bbox_class, bbox_text, bbox_patch, padding_mask, background, gen_z, gen_c, trunk_out=cached)
+                    l_real = self.d_real_loss(bbox_real, bbox_class, bbox_text, bbox_patch, padding_mask, background, real_c, trunk_out=cached)
+                else:
+                    fork = _TrunkFork(self.D, background, self.fork_D_trunk)   # overlaps G's no-grad forward inside d_gen_loss
+                    l_gen = self.d_gen_loss(bbox_real, bbox_class, bbox_text, bbox_patch, padding_mask, background, gen_z, gen_c, trunk_out=fork)
+                    l_real = self.d_real_loss(bbox_real, bbox_class, bbox_text, bbox_patch, padding_mask, background, real_c, trunk_out=fork.join())
                 (l_gen + l_real).mul(gain).backward()   # one backward: the trunk sees the summed gradient of both passes
                 core.join_side()
             else:

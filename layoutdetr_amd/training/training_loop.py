@@ -171,6 +171,9 @@ def training_iteration(loss, phases, dp, batch, batch_gpu, gen_z_per_phase, ema=
     """
     b = batch['bbox_real'].shape[0]
     core.reseed(batch['bbox_real'].device)   # fresh device-side dropout seed word for this iteration
+    if getattr(loss, 'share_D_trunk', None) == 'iteration' and any(p.name == 'Dmain' for p in phases):
+        for s in range(0, b, batch_gpu):
+            loss.precompute_D_trunk(batch['background'][s:s + batch_gpu])
     for phase, gen_z in zip(phases, gen_z_per_phase):
         phase.fm.zero_grad()
         phase.module.requires_grad_(True)
@@ -204,6 +207,16 @@ class GraphedIteration(object):
         self.graphs = []
         dev = batch['bbox_real'].device
         b = batch['bbox_real'].shape[0]
+        self.pre_graph = None
+        pool = None
+        if getattr(loss, 'share_D_trunk', None) == 'iteration' and any(p.name == 'Dmain' for p in phases):
+            # D's trunk forward gets its own graph, replayed before the phases; its activations stay alive in the shared pool until
+            # the Dmain graph (captured below, replayed after it) runs the trunk's backward
+            pool = torch.cuda.graph_pool_handle()
+            self.pre_graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.pre_graph, pool=pool):
+                for s in range(0, b, batch_gpu):
+                    loss.precompute_D_trunk(batch['background'][s:s + batch_gpu])
         for phase in phases:
             for m in (loss.G, loss.D):
                 if not getattr(m, 'static_shapes', False):
@@ -212,7 +225,7 @@ class GraphedIteration(object):
             phase.module.requires_grad_(True)
             phase.module.text_encoder.requires_grad_(False)
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            with torch.cuda.graph(g, pool=pool):
                 core.reseed(dev)
                 phase.fm.gflat.zero_()
                 gen_z = torch.randn(b, batch['bbox_class'].shape[1], z_dim, device=dev)
@@ -226,6 +239,8 @@ class GraphedIteration(object):
             self.graphs.append(g)
 
     def run(self):
+        if self.pre_graph is not None:
+            self.pre_graph.replay()
         for phase, g in zip(self.phases, self.graphs):
             g.replay()
             self.dp.apply(phase)
