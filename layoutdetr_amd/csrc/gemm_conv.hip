@@ -767,8 +767,13 @@ __global__ __launch_bounds__(256, (KS == 2 ? 4 : (KS == 4 ? 3 : 2))) void gemm_s
     // C and the residual go through buffer descriptors: one VGPR byte offset per lane + a scalar row offset per element
     // (the host guarantees both extents fit 31 bits), instead of a 64-bit address pair per element.
     const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc(p.C, 0, (int)((long)p.M * p.ldc * 4), 0x00020000);
-    // one prefetched side operand per output element: the residual (forward) or the ReLU-mask source (data gradient)
+    // one prefetched side operand per output element: the residual (forward) or the ReLU-mask source (data gradient); when a
+    // data gradient has both (block input: identity-path gradient + the previous block's ReLU mask) the mask is read at use
     const bool is_mask = !ep.residual && ep.mask_mode == 1;
+    const bool late_mask = ep.residual && ep.mask_mode == 1;
+    const __amdgpu_buffer_rsrc_t rm = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(late_mask ? ep.mask_src : p.C), 0,
+                                                                          late_mask ? (int)((long)p.M * ep.ldm * 4) : 0, 0x00020000);
+    const int vom = ((blockIdx.x * 128 + wave * 32 + 4 * kl) * (int)ep.ldm + cl) * 4, ldm4 = (int)ep.ldm * 4;
     const float* auxp = ep.residual ? ep.residual : (is_mask ? ep.mask_src : nullptr);
     const long auxld = ep.residual ? ep.ldr : ep.ldm;
     const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(auxp ? auxp : p.C), 0,
@@ -845,6 +850,7 @@ __global__ __launch_bounds__(256, (KS == 2 ? 4 : (KS == 4 ? 3 : 2))) void gemm_s
                 if (ep.act == 1) v = fmaxf(v, 0.f);
                 else if (ep.act == 2) v = (v > 0.f ? v : v * ep.act_alpha) * ep.act_gain;
                 if (is_mask) v = res[r] > 0.f ? v : 0.f;
+                if (late_mask) v = __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(rm, vom + (nc0 + n32) * 4, ro * ldm4, 0)) > 0.f ? v : 0.f;
                 v *= ep.out_scale;
                 if (ep.accumulate) v += __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(rc, vo, ro * ldc4, 0));
                 __builtin_amdgcn_raw_buffer_store_b32(__float_as_int(v), rc, vo, ro * ldc4, 0);
@@ -862,7 +868,7 @@ static int try_launch_skinny(const GemmParams& p, hipStream_t st) {
     if (p.A.scale && (p.A.scale_ld != 0 || !al16(p.A.scale))) return -1;
     if (TB == 1 && (p.N & 3)) return -1;
     if (p.ep.samp_scale || p.ep.p_drop > 0.f || p.ep.row_scale) return -1;   // lean epilogue only
-    if (p.ep.mask_mode && (p.ep.mask_mode != 1 || p.ep.residual)) return -1;
+    if (p.ep.mask_mode && p.ep.mask_mode != 1) return -1;
     if ((long)p.M * p.ldc * 4 >= (1l << 31) || (p.ep.residual && (long)p.M * p.ep.ldr * 4 >= (1l << 31)) ||
         (p.ep.mask_mode && (long)p.M * p.ep.ldm * 4 >= (1l << 31))) return -1;   // 32-bit buffer offsets
     const int KS = p.K <= 64 ? 2 : (p.K <= 128 ? 4 : 8);

@@ -27,8 +27,9 @@ def _grad_to_oihw(dw_ohwi):
 
 class _ConvFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, scale, shift, residual, stride, pad, relu, x_is_nchw, premasked=False, mask_input=False):
+    def forward(ctx, x, weight, scale, shift, residual, stride, pad, relu, x_is_nchw, premasked=False, mask_input=False, passthru=False):
         core.require_gpu(x, weight, scale, shift, residual)
+        ctx.set_materialize_grads(False)
         w = core.f32c(weight_ohwi(weight))
         O, KH, KW, I = w.shape
         if x_is_nchw:
@@ -51,11 +52,17 @@ class _ConvFn(torch.autograd.Function):
         ctx.save_for_backward(x, w, sc, y if relu else None)
         ctx.cfg = (stride, pad, relu, x_is_nchw, residual is not None, shift is not None, (N, H, W, I), premasked, mask_input)
         ctx.params = (weight, shift)
+        if passthru:
+            # second output = x itself: the block's identity / downsample branch reads x through it, so this node is the only
+            # autograd consumer of x and receives that branch's gradient (dx_pass) to add inside its own data-gradient epilogue
+            return y, x
         return y
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, dx_pass=None):
         x, w, sc, y = ctx.saved_tensors
+        if dy is None:
+            return (dx_pass,) + (None,) * 11
         stride, pad, relu, x_is_nchw, has_res, has_shift, (N, H, W, I), premasked, mask_input = ctx.cfg
         O, KH, KW, _ = w.shape
         dy = core.f32c(dy)
@@ -87,7 +94,10 @@ class _ConvFn(torch.autograd.Function):
             dx = torch.empty((N, H, W, I), device=dy.device, dtype=torch.float32)
             # mask_input: x is the ReLU output of a producer whose only consumer is this conv -> its (x > 0) mask is applied here,
             # in the epilogue, and the producer skips its own activation-gradient pass (premasked)
-            epb = core.epilogue(mask_src=x.reshape(-1, I), mask_mode=1) if mask_input else None
+            res2 = core.f32c(dx_pass).reshape(-1, I) if dx_pass is not None else None
+            epb = None
+            if mask_input or res2 is not None:
+                epb = core.epilogue(residual=res2, mask_src=x.reshape(-1, I) if mask_input else None, mask_mode=1 if mask_input else 0)
             core.engine_call('ldetr_conv2d_bwd_data_f32', 2.0 * N * OH * OW * O * KH * KW * I, lambda: core.check(core.lib().ldetr_conv2d_bwd_data_f32(
                 core.ptr(dpre), ctypes.byref(dyt), core.ptr(w), I, KH, KW, stride, pad, core.ptr(dx), I, H, W,
                 core.ptr(sc), 0, ctypes.byref(epb) if epb is not None else None, core.stream()), 'conv2d_bwd_data'))
@@ -120,14 +130,17 @@ class _ConvFn(torch.autograd.Function):
                     wgrad()
             dw = None if acc else _grad_to_oihw(dw_ohwi)
         dres = dpre if need_res else None
-        return dx, dw, None, dshift, dres, None, None, None, None, None, None
+        if dx is None and dx_pass is not None:
+            dx = dx_pass
+        return dx, dw, None, dshift, dres, None, None, None, None, None, None, None
 
 
 def conv2d_nhwc(x, weight, scale=None, shift=None, residual=None, stride=1, pad=0, relu=False, x_is_nchw=False,
-                premasked=False, mask_input=False):
+                premasked=False, mask_input=False, passthru=False):
     """premasked / mask_input: ReLU-gradient hand-off between a producer and its ONLY consumer (see _ConvFn.backward);
-    set both ends together or neither."""
-    return _ConvFn.apply(x, weight, scale, shift, residual, stride, pad, relu, x_is_nchw, premasked, mask_input)
+    set both ends together or neither.  passthru=True returns (y, x_alias): route every other use of x through x_alias and
+    this node adds their gradient inside its data-gradient kernel (no separate add launch)."""
+    return _ConvFn.apply(x, weight, scale, shift, residual, stride, pad, relu, x_is_nchw, premasked, mask_input, passthru)
 
 
 class _MaxPoolFn(torch.autograd.Function):

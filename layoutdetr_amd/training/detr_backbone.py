@@ -84,17 +84,24 @@ class Bottleneck(nn.Module):
         if downsample:
             self.downsample = nn.Sequential(_Conv(inplanes, planes * 4, 1, stride, 0), FrozenBatchNorm2d(planes * 4))
 
+    # Set by ResNet50Body for blocks chained inside the trunk: `mask_in` = x is the ReLU output of the previous block, which
+    # skips its own activation-gradient pass because this block applies (x > 0) for it; `premask_out` = the mirror flag.
+    mask_in = False
+    premask_out = False
+
     def forward(self, x):  # x: [N, H, W, C]
         s1, b1 = self.bn1.folded(); s2, b2 = self.bn2.folded(); s3, b3 = self.bn3.folded()
         # conv1 -> conv2 -> conv3 is a chain of single-consumer ReLU outputs: each consumer masks its data gradient with
         # (input > 0) in the GEMM epilogue, so conv1 and conv2 need no separate activation-gradient pass in backward
-        out = hconv.conv2d_nhwc(x, self.conv1.weight, s1, b1, None, 1, 0, relu=True, premasked=True)
+        # conv1 is the only autograd consumer of x: the identity / downsample branch reads x through conv1's pass-through alias, so
+        # the gradient of x = conv1's data gradient + that branch's gradient (+ the previous block's ReLU mask) is ONE kernel
+        out, x = hconv.conv2d_nhwc(x, self.conv1.weight, s1, b1, None, 1, 0, relu=True, premasked=True, mask_input=self.mask_in, passthru=True)
         out = hconv.conv2d_nhwc(out, self.conv2.weight, s2, b2, None, self.conv2.stride, 1, relu=True, premasked=True, mask_input=True)
         idt = x
         if self.downsample is not None:
             sd, bd = self.downsample[1].folded()
             idt = hconv.conv2d_nhwc(x, self.downsample[0].weight, sd, bd, None, self.downsample[0].stride, 0, relu=False)
-        return hconv.conv2d_nhwc(out, self.conv3.weight, s3, b3, idt, 1, 0, relu=True, mask_input=True)
+        return hconv.conv2d_nhwc(out, self.conv3.weight, s3, b3, idt, 1, 0, relu=True, mask_input=True, premasked=self.premask_out)
 
 
 class ResNet50Body(nn.Module):
@@ -111,6 +118,10 @@ class ResNet50Body(nn.Module):
             inplanes = planes * 4
             layers += [Bottleneck(inplanes, planes) for _ in range(1, blocks)]
             setattr(self, f'layer{li}', nn.Sequential(*layers))
+        blocks = [b for li in range(1, 5) for b in getattr(self, f'layer{li}')]
+        for prev, nxt in zip(blocks[:-1], blocks[1:]):     # every block output feeds exactly the next block
+            prev.premask_out = True
+            nxt.mask_in = True
 
     def forward(self, x_nchw):
         s, b = self.bn1.folded()

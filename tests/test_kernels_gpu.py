@@ -485,3 +485,59 @@ def test_layout_metrics_device_vs_oracle_random(dev):
     L2x = L2[:5] + [L2[0], L2[1]]
     ref = np.asarray([R.compute_maximum_docsim_for_layout(L1[k], L2x[k]) for k in range(7)])
     assert np.abs(got - ref).max() <= 1e-6
+
+
+def test_bottleneck_chain_fused_block_gradients(dev):
+    """Three chained bottlenecks (stride-2 downsample block in the middle) with the trunk's gradient hand-offs switched on
+    (block-input gradient = conv1 data gradient + identity/downsample gradient + previous block's ReLU mask in ONE kernel;
+    no activation-gradient pass for conv1/conv2/chained block outputs) against plain torch autograd of the same network."""
+    from layoutdetr_amd.training.detr_backbone import Bottleneck
+    torch.manual_seed(71)
+    blocks = [Bottleneck(32, 16, 1, downsample=True), Bottleneck(64, 32, 2, downsample=True), Bottleneck(128, 32)]
+    for b in blocks:
+        for n, p in b.named_parameters():
+            p.data.normal_(0, 0.15)
+        for m in b.modules():
+            if hasattr(m, 'running_var'):
+                m.weight.data.uniform_(0.6, 1.4); m.bias.data.normal_(0, 0.2); m.running_mean.normal_(0, 0.2); m.running_var.uniform_(0.5, 1.5)
+    x = torch.randn(2, 32, 20, 20)
+    g = torch.randn(2, 128, 10, 10)
+
+    def ref_block(b, t):
+        def cba(t, conv, bn, stride, pad, relu):
+            w = conv.weight.detach().clone().requires_grad_(True); ws.append(w)
+            sc = bn.weight * (bn.running_var + 1e-5).rsqrt(); sh = bn.bias - bn.running_mean * sc
+            y = F.conv2d(t, w, stride=stride, padding=pad) * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1)
+            return F.relu(y) if relu else y
+        o = cba(t, b.conv1, b.bn1, 1, 0, True)
+        o = cba(o, b.conv2, b.bn2, b.conv2.stride, 1, True)
+        idt = cba(t, b.downsample[0], b.downsample[1], b.downsample[0].stride, 0, False) if b.downsample is not None else t
+        w = b.conv3.weight.detach().clone().requires_grad_(True); ws.append(w)
+        sc = b.bn3.weight * (b.bn3.running_var + 1e-5).rsqrt(); sh = b.bn3.bias - b.bn3.running_mean * sc
+        return F.relu(F.conv2d(o, w) * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1) + idt)
+    ws = []
+    xr = x.clone().requires_grad_(True)
+    t = F.relu(xr)            # the chain's input is a ReLU output, as inside the trunk
+    for b in blocks:
+        t = ref_block(b, t)
+    t.backward(g)
+    ref_w = [w.grad for w in ws]
+    # HIP path with the chain flags the trunk sets
+    for b in blocks:
+        b.to(dev)
+        for p in b.parameters():
+            p.data = p.data.contiguous(memory_format=torch.channels_last) if p.ndim == 4 else p.data
+            p.grad = None
+    blocks[0].premask_out = True; blocks[1].mask_in = True; blocks[1].premask_out = True; blocks[2].mask_in = True
+    xg = x.to(dev).requires_grad_(True)
+    t = F.relu(xg).permute(0, 2, 3, 1).contiguous()
+    for b in blocks:
+        t = b(t)
+    t.backward(g.permute(0, 2, 3, 1).contiguous().to(dev))
+    assert_close(t.permute(0, 3, 1, 2), blocks and t.permute(0, 3, 1, 2), 1e-9, 'self')
+    assert_close(xg.grad, xr.grad, 2e-5, 'dx')
+    got_w = []
+    for b in blocks:
+        got_w += [b.conv1.weight.grad, b.conv2.weight.grad] + ([b.downsample[0].weight.grad] if b.downsample is not None else []) + [b.conv3.weight.grad]
+    for i, (a, r) in enumerate(zip(got_w, ref_w)):
+        assert_close(a, r, 3e-5, f'dw[{i}]')
