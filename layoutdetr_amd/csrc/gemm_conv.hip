@@ -87,6 +87,7 @@ struct GemmParams {
     int samp_pix, samp_q;             // pixels (k indices) per sample, slices per sample; samp_pix == 0: ordinary split-K
     const float* srow; long srow_ld;  // per-sample factor of output row m
     const float* scol; long scol_ld;  // per-sample factor of output column n
+    int ep_vec;          // host-checked: every epilogue operand is float4-addressable -> LDS-staged row-major epilogue
     float* ws;           // split-K fix-up: per-(tile, slice) partial tiles; null = fp32 atomics into C
     int* ws_count;       //   per-tile arrival counters (zero between launches)
     GemmEpilogue ep;
@@ -564,6 +565,58 @@ __global__ __launch_bounds__(NWV * 64) void gemm_f32_kernel(GemmParams p) {
     // Epilogue.  acc[i][j][r]: row = (r&3) + 8*(r>>2) + 4*(lane>>5), col = lane&31 of the 32x32 tile.
     const GemmEpilogue& ep = p.ep;
     const float inv_keep = ep.p_drop > 0.f ? 1.f / (1.f - ep.p_drop) : 1.f;
+    if (direct && p.ep_vec) {
+        // Row-major epilogue: the accumulator tile goes through LDS (the operand buffers are free now) so that every thread
+        // handles float4 pieces of rows: residual / mask / scale reads and the store are 16 B per lane and 4x fewer instructions
+        // than the MFMA C-layout's 4 B per lane.
+        constexpr int CP = BN + 4;                                                    // row pitch (16 B aligned, conflict-free)
+        constexpr int LDSF = 2 * BKT * (LDA + LDB);                                   // floats available
+        constexpr int PASSES = (BM * CP + LDSF - 1) / LDSF, RP = BM / PASSES;         // rows staged per pass
+        static_assert(BM % PASSES == 0 && RP * CP <= LDSF && (RP % 32) == 0, "epilogue staging does not fit");
+        float* Cs = ldetr_smem;
+#pragma unroll
+        for (int ps = 0; ps < PASSES; ps++) {
+            if (ps > 0) __syncthreads();
+#pragma unroll
+            for (int i = 0; i < TM; i++) {
+                const int rb = wm * WM + i * 32 - ps * RP;                            // wave-uniform
+                if (rb < 0 || rb >= RP) continue;
+#pragma unroll
+                for (int j = 0; j < TN; j++)
+#pragma unroll
+                    for (int r = 0; r < 16; r++)
+                        Cs[(rb + (r & 3) + 8 * (r >> 2) + 4 * kl) * CP + wn * WN + j * 32 + cl] = acc[i][j][r];
+            }
+            __syncthreads();
+            for (int u = tid; u < RP * (BN / 4); u += NT) {
+                const int rl = u / (BN / 4), c4 = (u - rl * (BN / 4)) * 4;
+                const int m = m0 + ps * RP + rl, n = n0 + c4;
+                if (m >= z.M || n >= p.N) continue;
+                long orow = m;
+                if (p.zmode == 1 && p.pstep > 1) {
+                    int per = z.DH2 * z.DW2;
+                    int nn = m / per; int rem = m - nn * per;
+                    int y2 = rem / z.DW2; int x2 = rem - y2 * z.DW2;
+                    orow = ((long)nn * p.A.DH + (y2 * p.pstep + z.py)) * p.A.DW + (x2 * p.pstep + z.px);
+                }
+                const int samp = (ep.samp_scale && p.pix_per_sample > 0) ? (int)((unsigned)orow / (unsigned)p.pix_per_sample) : 0;
+                const float4 a4 = *reinterpret_cast<const float4*>(Cs + rl * CP + c4);
+                const float4 one4 = make_float4(1.f, 1.f, 1.f, 1.f), zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+                const float4 cs4 = ep.col_scale ? *reinterpret_cast<const float4*>(ep.col_scale + n) : one4;
+                const float4 cb4 = ep.col_bias ? *reinterpret_cast<const float4*>(ep.col_bias + n) : zero4;
+                const float4 rs4 = ep.residual ? *reinterpret_cast<const float4*>(ep.residual + orow * ep.ldr + n) : zero4;
+                float* dst = p.C + z.c_off + orow * p.ldc + n;
+                float4 o;
+                o.x = apply_epilogue(ep, a4.x, orow, n + 0, samp, p.ldc, inv_keep, cs4.x, cb4.x, rs4.x);
+                o.y = apply_epilogue(ep, a4.y, orow, n + 1, samp, p.ldc, inv_keep, cs4.y, cb4.y, rs4.y);
+                o.z = apply_epilogue(ep, a4.z, orow, n + 2, samp, p.ldc, inv_keep, cs4.z, cb4.z, rs4.z);
+                o.w = apply_epilogue(ep, a4.w, orow, n + 3, samp, p.ldc, inv_keep, cs4.w, cb4.w, rs4.w);
+                if (ep.accumulate) { const float4 c = *reinterpret_cast<const float4*>(dst); o.x += c.x; o.y += c.y; o.z += c.z; o.w += c.w; }
+                *reinterpret_cast<float4*>(dst) = o;
+            }
+        }
+        return;
+    }
     float cs[TN], cb[TN], sfc[TN];
 #pragma unroll
     for (int j = 0; j < TN; j++) {
@@ -940,6 +993,9 @@ static void init_operand(Operand& o) { memset(&o, 0, sizeof(o)); o.KW = 1; o.KH 
 #ifndef T128_WAVES
 #define T128_WAVES 8
 #endif
+#ifndef LDETR_EPILOGUE_VEC
+#define LDETR_EPILOGUE_VEC 1
+#endif
 #ifndef T12864_SPLIT_MIN_TILES
 #define T12864_SPLIT_MIN_TILES 64
 #endif
@@ -1031,6 +1087,12 @@ static int launch_gemm(GemmParams& p, int Mmax, long out_rows, int zbase, bool a
                 return LDETR_ERR_LAUNCH;
             }
         }
+    }
+    {
+        const GemmEpilogue& e = p.ep;
+        auto ok4 = [](const void* q, long ld) { return !q || (al16(q) && (ld % 4) == 0); };
+        p.ep_vec = (p.N % 4 == 0) && al16(p.C) && (p.ldc % 4 == 0) && (p.c_tap_stride % 4 == 0) && ok4(e.col_scale, 0) && ok4(e.col_bias, 0) &&
+                   ok4(e.residual, e.ldr) && ok4(e.samp_scale, e.samp_ld) && !p.srow && !p.scol && !e.row_scale && LDETR_EPILOGUE_VEC;
     }
     dim3 grid(cdiv(p.N, use128 ? 128 : 64), cdiv(Mmax, (use128 || use12864) ? 128 : 64), zbase * (split ? p.splitk : 1));
     int rc;
