@@ -601,10 +601,11 @@ __global__ __launch_bounds__(NWV * 64) void gemm_f32_kernel(GemmParams p) {
                 }
                 const int samp = (ep.samp_scale && p.pix_per_sample > 0) ? (int)((unsigned)orow / (unsigned)p.pix_per_sample) : 0;
                 const float4 a4 = *reinterpret_cast<const float4*>(Cs + rl * CP + c4);
-                const float4 one4 = make_float4(1.f, 1.f, 1.f, 1.f), zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
-                const float4 cs4 = ep.col_scale ? *reinterpret_cast<const float4*>(ep.col_scale + n) : one4;
-                const float4 cb4 = ep.col_bias ? *reinterpret_cast<const float4*>(ep.col_bias + n) : zero4;
-                const float4 rs4 = ep.residual ? *reinterpret_cast<const float4*>(ep.residual + orow * ep.ldr + n) : zero4;
+                // (plain ifs: a `cond ? *ptr : constant` on float4 makes hipcc select between ADDRESSES and park the constant in scratch)
+                float4 cs4 = make_float4(1.f, 1.f, 1.f, 1.f), cb4 = make_float4(0.f, 0.f, 0.f, 0.f), rs4 = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (ep.col_scale) cs4 = *reinterpret_cast<const float4*>(ep.col_scale + n);
+                if (ep.col_bias) cb4 = *reinterpret_cast<const float4*>(ep.col_bias + n);
+                if (ep.residual) rs4 = *reinterpret_cast<const float4*>(ep.residual + orow * ep.ldr + n);
                 float* dst = p.C + z.c_off + orow * p.ldc + n;
                 float4 o;
                 o.x = apply_epilogue(ep, a4.x, orow, n + 0, samp, p.ldc, inv_keep, cs4.x, cb4.x, rs4.x);
