@@ -339,7 +339,7 @@ __device__ __forceinline__ ZCtx make_zctx(const GemmParams& p) {
 // One output element through the epilogue chain documented in include/ldetr_hip.h.
 // cs / cb: the column's scale and bias, fetched once per column by the caller (not once per element).
 __device__ __forceinline__ float apply_epilogue(const GemmEpilogue& ep, float v, long orow, int n, int samp, long ldc, float inv_keep,
-                                                float cs, float cb, float res) {
+                                                float cs, float cb, float res, float mval) {
     v *= ep.alpha;
     if (ep.row_scale) v *= ep.row_scale[orow];
     v *= cs;
@@ -348,10 +348,9 @@ __device__ __forceinline__ float apply_epilogue(const GemmEpilogue& ep, float v,
     v += res;
     if (ep.act == 1) v = fmaxf(v, 0.f);
     else if (ep.act == 2) v = (v > 0.f ? v : v * ep.act_alpha) * ep.act_gain;
-    if (ep.mask_mode) {
-        float s = ep.mask_src[orow * ep.ldm + n];
-        if (ep.mask_mode == 1) v = s > 0.f ? v : 0.f;
-        else v *= (s > 0.f ? ep.act_gain : ep.act_gain * ep.act_alpha);
+    if (ep.mask_mode) {   // mval = mask_src[orow][n], fetched by the caller (float4 in the row-major epilogue)
+        if (ep.mask_mode == 1) v = mval > 0.f ? v : 0.f;
+        else v *= (mval > 0.f ? ep.act_gain : ep.act_gain * ep.act_alpha);
     }
     if (ep.p_drop > 0.f) v *= drop_scale(ep.seed + (ep.seed_ptr ? *ep.seed_ptr : 0ull), (uint64_t)(orow * ldc + n), ep.p_drop, inv_keep);
     return v * ep.out_scale;
@@ -606,12 +605,14 @@ __global__ __launch_bounds__(NWV * 64) void gemm_f32_kernel(GemmParams p) {
                 if (ep.col_scale) cs4 = *reinterpret_cast<const float4*>(ep.col_scale + n);
                 if (ep.col_bias) cb4 = *reinterpret_cast<const float4*>(ep.col_bias + n);
                 if (ep.residual) rs4 = *reinterpret_cast<const float4*>(ep.residual + orow * ep.ldr + n);
+                float4 mk4 = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (ep.mask_mode) mk4 = *reinterpret_cast<const float4*>(ep.mask_src + orow * ep.ldm + n);
                 float* dst = p.C + z.c_off + orow * p.ldc + n;
                 float4 o;
-                o.x = apply_epilogue(ep, a4.x, orow, n + 0, samp, p.ldc, inv_keep, cs4.x, cb4.x, rs4.x);
-                o.y = apply_epilogue(ep, a4.y, orow, n + 1, samp, p.ldc, inv_keep, cs4.y, cb4.y, rs4.y);
-                o.z = apply_epilogue(ep, a4.z, orow, n + 2, samp, p.ldc, inv_keep, cs4.z, cb4.z, rs4.z);
-                o.w = apply_epilogue(ep, a4.w, orow, n + 3, samp, p.ldc, inv_keep, cs4.w, cb4.w, rs4.w);
+                o.x = apply_epilogue(ep, a4.x, orow, n + 0, samp, p.ldc, inv_keep, cs4.x, cb4.x, rs4.x, mk4.x);
+                o.y = apply_epilogue(ep, a4.y, orow, n + 1, samp, p.ldc, inv_keep, cs4.y, cb4.y, rs4.y, mk4.y);
+                o.z = apply_epilogue(ep, a4.z, orow, n + 2, samp, p.ldc, inv_keep, cs4.z, cb4.z, rs4.z, mk4.z);
+                o.w = apply_epilogue(ep, a4.w, orow, n + 3, samp, p.ldc, inv_keep, cs4.w, cb4.w, rs4.w, mk4.w);
                 if (ep.accumulate) { const float4 c = *reinterpret_cast<const float4*>(dst); o.x += c.x; o.y += c.y; o.z += c.z; o.w += c.w; }
                 *reinterpret_cast<float4*>(dst) = o;
             }
@@ -651,7 +652,8 @@ __global__ __launch_bounds__(NWV * 64) void gemm_f32_kernel(GemmParams p) {
                 if (!direct) {
                     atomicAdd(dst, a * (ep.row_scale ? ep.alpha * ep.row_scale[orow] : ep.alpha));   // raw partial sums; the rest of the epilogue runs in epilogue_kernel
                 } else {
-                    float v = apply_epilogue(ep, a, orow, n, samp, p.ldc, inv_keep, cs[j], cb[j], ep.residual ? ep.residual[orow * ep.ldr + n] : 0.f);
+                    float v = apply_epilogue(ep, a, orow, n, samp, p.ldc, inv_keep, cs[j], cb[j], ep.residual ? ep.residual[orow * ep.ldr + n] : 0.f,
+                                           ep.mask_mode ? ep.mask_src[orow * ep.ldm + n] : 0.f);
                     if (ep.accumulate) *dst += v; else *dst = v;
                 }
             }
@@ -765,7 +767,8 @@ __global__ __launch_bounds__(NW * 64) void gemm_small_kernel(GemmParams p) {
 #pragma unroll
         for (int e = 0; e < 4; e++)
             if (n0 + c4 + e < p.N) v[e] = apply_epilogue(ep, v[e], m, n0 + c4 + e, samp, p.ldc, inv_keep, ep.col_scale ? ep.col_scale[n0 + c4 + e] : 1.f, ep.col_bias ? ep.col_bias[n0 + c4 + e] : 0.f,
-                                                             ep.residual ? ep.residual[(long)m * ep.ldr + n0 + c4 + e] : 0.f);
+                                                             ep.residual ? ep.residual[(long)m * ep.ldr + n0 + c4 + e] : 0.f,
+                                                             ep.mask_mode ? ep.mask_src[(long)m * ep.ldm + n0 + c4 + e] : 0.f);
         if (n0 + c4 + 3 < p.N && (p.ldc & 3) == 0 && ((((uintptr_t)p.C) & 15) == 0)) {
             float4 o = make_float4(v[0], v[1], v[2], v[3]);
             if (ep.accumulate) { float4 c = *reinterpret_cast<float4*>(dst); o.x += c.x; o.y += c.y; o.z += c.z; o.w += c.w; }
@@ -970,7 +973,8 @@ __global__ __launch_bounds__(256) void gemm_epilogue_kernel(EpiParams q) {
         int samp = (q.ep.samp_scale && q.pix_per_sample > 0) ? (int)(row / q.pix_per_sample) : 0;
         float* dst = q.C + row * q.ldc + n;
         *dst = apply_epilogue(q.ep, *dst, row, n, samp, q.ldc, inv_keep, q.ep.col_scale ? q.ep.col_scale[n] : 1.f, q.ep.col_bias ? q.ep.col_bias[n] : 0.f,
-                              q.ep.residual ? q.ep.residual[row * q.ep.ldr + n] : 0.f);
+                              q.ep.residual ? q.ep.residual[row * q.ep.ldr + n] : 0.f,
+                              q.ep.mask_mode ? q.ep.mask_src[row * q.ep.ldm + n] : 0.f);
     }
 }
 
@@ -1093,7 +1097,7 @@ static int launch_gemm(GemmParams& p, int Mmax, long out_rows, int zbase, bool a
         const GemmEpilogue& e = p.ep;
         auto ok4 = [](const void* q, long ld) { return !q || (al16(q) && (ld % 4) == 0); };
         p.ep_vec = (p.N % 4 == 0) && al16(p.C) && (p.ldc % 4 == 0) && (p.c_tap_stride % 4 == 0) && ok4(e.col_scale, 0) && ok4(e.col_bias, 0) &&
-                   ok4(e.residual, e.ldr) && ok4(e.samp_scale, e.samp_ld) && !p.srow && !p.scol && !e.row_scale && LDETR_EPILOGUE_VEC;
+                   ok4(e.residual, e.ldr) && ok4(e.samp_scale, e.samp_ld) && ok4(e.mask_mode ? e.mask_src : nullptr, e.ldm) && !p.srow && !p.scol && !e.row_scale && LDETR_EPILOGUE_VEC;
     }
     dim3 grid(cdiv(p.N, use128 ? 128 : 64), cdiv(Mmax, (use128 || use12864) ? 128 : 64), zbase * (split ? p.splitk : 1));
     int rc;
