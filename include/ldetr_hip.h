@@ -127,15 +127,17 @@ int ldetr_conv_transpose2d_bwd_weight_f32(const float* x, const ldetr_tensor4* x
                                           int splitk, const float* x_scale, int64_t x_scale_ld, const float* dy_scale,
                                           int64_t dy_scale_ld, int accumulate, void* stream);
 
+/* head_dim: multiple of 32 up to 192.  causal != 0 (self-attention only, Lq == Lk): key j is visible to query i iff j <= i
+ * (BertSelfAttention of an is_decoder config, training/med.py:704-739), on top of the key-padding mask. */
 int ldetr_attention_fwd_f32(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v, int64_t ldv,
                             const unsigned char* key_padding_mask, float* out, int64_t ldo, float* lse, int B, int H,
                             int Lq, int Lk, int head_dim, float scale, float p_drop, uint64_t seed, const uint64_t* seed_ptr,
-                            void* stream);
+                            int causal, void* stream);
 int ldetr_attention_bwd_f32(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v, int64_t ldv,
                             const unsigned char* key_padding_mask, const float* out, int64_t ldo, const float* lse,
                             const float* dout, int64_t lddo, float* dq, int64_t lddq, float* dk, int64_t lddk,
                             float* dv, int64_t lddv, int B, int H, int Lq, int Lk, int head_dim, float scale,
-                            float p_drop, uint64_t seed, const uint64_t* seed_ptr, void* stream);
+                            float p_drop, uint64_t seed, const uint64_t* seed_ptr, int causal, void* stream);
 
 int ldetr_layernorm_fwd_f32(const float* x, const float* residual, const float* gamma, const float* beta, float* y,
                             float* z, float* mean, float* rstd, int64_t rows, int D, float eps, float p_drop,

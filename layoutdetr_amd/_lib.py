@@ -45,9 +45,9 @@ SIGNATURES = {
     'ldetr_conv_transpose2d_fwd_f32': [_P, _T4, _P, _I, _I, _I, _I, _I, _P, _L, _I, _I, _P, _L, _EP, _P],
     'ldetr_conv_transpose2d_bwd_data_f32': [_P, _T4, _P, _I, _I, _I, _I, _I, _P, _L, _I, _I, _P, _L, _EP, _P],
     'ldetr_conv_transpose2d_bwd_weight_f32': [_P, _T4, _P, _T4, _P, _I, _I, _I, _I, _I, _P, _L, _P, _L, _I, _P],
-    'ldetr_attention_fwd_f32': [_P, _L, _P, _L, _P, _L, _P, _P, _L, _P, _I, _I, _I, _I, _I, _F, _F, c_uint64, _P, _P],
+    'ldetr_attention_fwd_f32': [_P, _L, _P, _L, _P, _L, _P, _P, _L, _P, _I, _I, _I, _I, _I, _F, _F, c_uint64, _P, _I, _P],
     'ldetr_attention_bwd_f32': [_P, _L, _P, _L, _P, _L, _P, _P, _L, _P, _P, _L, _P, _L, _P, _L, _P, _L,
-                                _I, _I, _I, _I, _I, _F, _F, c_uint64, _P, _P],
+                                _I, _I, _I, _I, _I, _F, _F, c_uint64, _P, _I, _P],
     'ldetr_layernorm_fwd_f32': [_P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _F, _F, c_uint64, _P, _P],
     'ldetr_layernorm_bwd_f32': [_P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _F, c_uint64, _P, _P],
     'ldetr_colsum_f32': [_P, _P, _I, _L, _I, _P],
@@ -83,7 +83,7 @@ def load():
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported
         fn.restype = c_int
         fn.argtypes = argtypes
-    if lib.ldetr_abi_version() != 5:
+    if lib.ldetr_abi_version() != 6:
         raise RuntimeError('libldetr_hip.so ABI version mismatch; rebuild it')
     _lib = lib
     return lib

@@ -29,6 +29,7 @@ struct AttnParams {
     float scale, p_drop;
     unsigned long long seed;
     const unsigned long long* seed_ptr;
+    int causal;   // self-attention of a decoder: key j visible to query i only if j <= i (BertSelfAttention with is_decoder, med.py:704-739)
 };
 
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
@@ -74,7 +75,7 @@ __global__ __launch_bounds__(64) void attn_fwd_kernel(AttnParams p) {
 #pragma unroll
         for (int r = 0; r < 4; r++) {
             int key = 16 * j + 4 * g + r;
-            bool masked = (key >= p.Lk) || (kpm && kpm[key]);
+            bool masked = (key >= p.Lk) || (kpm && kpm[key]) || (p.causal && key > qrow);
             acc[r] = masked ? -INFINITY : acc[r];
             mx = fmaxf(mx, acc[r]);
         }
@@ -117,24 +118,25 @@ __global__ __launch_bounds__(64) void attn_fwd_kernel(AttnParams p) {
 }
 
 // Backward, query-major half: dQ for one 16-query tile.
-template <int NKT>
+template <int NKT, int DHC>
 __device__ __forceinline__ void attn_bwd_dq(const AttnParams& p, int bh, int qt) {
+    constexpr int DH = 32 * DHC;
     const int b = bh / p.H, h = bh - b * p.H;
     const int lane = threadIdx.x, li = lane & 15, g = lane >> 4;
     const int qrow = (qt << 4) + li;
     const bool qok = qrow < p.Lq;
-    const float* qp = p.q + ((long)b * p.Lq + qrow) * p.ldq + h * 32;
-    const float* dop = p.dout + ((long)b * p.Lq + qrow) * p.lddo + h * 32;
-    const float* op = p.o + ((long)b * p.Lq + qrow) * p.ldo + h * 32;
-    const float* kb = p.k + (long)b * p.Lk * p.ldk + h * 32;
-    const float* vb = p.v + (long)b * p.Lk * p.ldv + h * 32;
+    const float* qp = p.q + ((long)b * p.Lq + qrow) * p.ldq + h * DH;
+    const float* dop = p.dout + ((long)b * p.Lq + qrow) * p.lddo + h * DH;
+    const float* op = p.o + ((long)b * p.Lq + qrow) * p.ldo + h * DH;
+    const float* kb = p.k + (long)b * p.Lk * p.ldk + h * DH;
+    const float* vb = p.v + (long)b * p.Lk * p.ldv + h * DH;
     const unsigned char* kpm = p.kpm ? p.kpm + (long)b * p.Lk : nullptr;
     const float inv_keep = p.p_drop > 0.f ? 1.f / (1.f - p.p_drop) : 1.f;
 
-    float qf[8], dof[8];
+    float qf[8 * DHC], dof[8 * DHC];
     float delta = 0.f;
 #pragma unroll
-    for (int kk = 0; kk < 8; kk++) {
+    for (int kk = 0; kk < 8 * DHC; kk++) {
         qf[kk] = ldz(qp + 4 * kk + g, qok) * p.scale;
         dof[kk] = ldz(dop + 4 * kk + g, qok);
         delta += dof[kk] * ldz(op + 4 * kk + g, qok);
@@ -143,7 +145,9 @@ __device__ __forceinline__ void attn_bwd_dq(const AttnParams& p, int bh, int qt)
     delta += __shfl_xor(delta, 32, 64);
     const float lse = qok ? p.lse[(long)bh * p.Lq + qrow] : 0.f;
 
-    f32x4 dq0 = {0.f, 0.f, 0.f, 0.f}, dq1 = {0.f, 0.f, 0.f, 0.f};
+    f32x4 dq[2 * DHC];
+#pragma unroll
+    for (int c = 0; c < 2 * DHC; c++) dq[c] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int j = 0; j < NKT; j++) {
         f32x4 sacc = {0.f, 0.f, 0.f, 0.f}, dpacc = {0.f, 0.f, 0.f, 0.f};
@@ -152,7 +156,7 @@ __device__ __forceinline__ void attn_bwd_dq(const AttnParams& p, int bh, int qt)
         const float* kp = kb + (long)krow * p.ldk;
         const float* vp = vb + (long)krow * p.ldv;
 #pragma unroll
-        for (int kk = 0; kk < 8; kk++) {
+        for (int kk = 0; kk < 8 * DHC; kk++) {
             sacc = MFMA16(ldz(kp + 4 * kk + g, kok), qf[kk], sacc);
             dpacc = MFMA16(ldz(vp + 4 * kk + g, kok), dof[kk], dpacc);
         }
@@ -160,7 +164,7 @@ __device__ __forceinline__ void attn_bwd_dq(const AttnParams& p, int bh, int qt)
 #pragma unroll
         for (int r = 0; r < 4; r++) {
             int key = 16 * j + 4 * g + r;
-            bool masked = (key >= p.Lk) || (kpm && kpm[key]);
+            bool masked = (key >= p.Lk) || (kpm && kpm[key]) || (p.causal && key > qrow);
             float pr = masked ? 0.f : expf(sacc[r] - lse);
             float dpv = dpacc[r];
             if (p.p_drop > 0.f) dpv *= attn_drop(p, bh, qrow, key, inv_keep);
@@ -171,44 +175,50 @@ __device__ __forceinline__ void attn_bwd_dq(const AttnParams& p, int bh, int qt)
             const int key = 16 * j + 4 * g + t;
             const bool k2 = key < p.Lk;
             const float* kp2 = kb + (long)key * p.ldk;
-            dq0 = MFMA16(ldz(kp2 + li, k2), ds[t], dq0);
-            dq1 = MFMA16(ldz(kp2 + 16 + li, k2), ds[t], dq1);
+#pragma unroll
+            for (int c = 0; c < 2 * DHC; c++) dq[c] = MFMA16(ldz(kp2 + 16 * c + li, k2), ds[t], dq[c]);
         }
     }
     if (qok) {
-        float* dqp = p.dq + ((long)b * p.Lq + qrow) * p.lddq + h * 32 + 4 * g;
-        *reinterpret_cast<float4*>(dqp) = make_float4(dq0[0], dq0[1], dq0[2], dq0[3]);
-        *reinterpret_cast<float4*>(dqp + 16) = make_float4(dq1[0], dq1[1], dq1[2], dq1[3]);
+        float* dqp = p.dq + ((long)b * p.Lq + qrow) * p.lddq + h * DH + 4 * g;
+#pragma unroll
+        for (int c = 0; c < 2 * DHC; c++) *reinterpret_cast<float4*>(dqp + 16 * c) = make_float4(dq[c][0], dq[c][1], dq[c][2], dq[c][3]);
     }
 }
 
-// Backward, key-major half: dK and dV for one 16-key tile; loops over query tiles.
+// Backward, key-major half: dK and dV for one 16-key tile; loops over query tiles.  Wide heads are processed in 32-column
+// slabs of the head dimension for the OUTPUT (dK/dV accumulators), with the score recomputation over the full width: the
+// accumulators of a 192-wide head would not fit the register file next to the K/V fragments.
+template <int DHC>
 __device__ __forceinline__ void attn_bwd_dkv(const AttnParams& p, int bh, int kt) {
+    constexpr int DH = 32 * DHC;
     const int b = bh / p.H, h = bh - b * p.H;
     const int lane = threadIdx.x, li = lane & 15, g = lane >> 4;
     const int krow = (kt << 4) + li;
     const bool kok = krow < p.Lk;
-    const float* kp = p.k + ((long)b * p.Lk + krow) * p.ldk + h * 32;
-    const float* vp = p.v + ((long)b * p.Lk + krow) * p.ldv + h * 32;
+    const float* kp = p.k + ((long)b * p.Lk + krow) * p.ldk + h * DH;
+    const float* vp = p.v + ((long)b * p.Lk + krow) * p.ldv + h * DH;
     const unsigned char* kpm = p.kpm ? p.kpm + (long)b * p.Lk : nullptr;
     const bool kmasked = !kok || (kpm && kpm[krow]);
     const float inv_keep = p.p_drop > 0.f ? 1.f / (1.f - p.p_drop) : 1.f;
     // B operands (k = d, j = key): K^T and V^T fragments, loaded once.
-    float kf[8], vf[8];
+    float kf[8 * DHC], vf[8 * DHC];
 #pragma unroll
-    for (int kk = 0; kk < 8; kk++) { kf[kk] = ldz(kp + 4 * kk + g, kok); vf[kk] = ldz(vp + 4 * kk + g, kok); }
+    for (int kk = 0; kk < 8 * DHC; kk++) { kf[kk] = ldz(kp + 4 * kk + g, kok); vf[kk] = ldz(vp + 4 * kk + g, kok); }
 
-    f32x4 dk0 = {0.f, 0.f, 0.f, 0.f}, dk1 = dk0, dv0 = dk0, dv1 = dk0;
+    f32x4 dk[2 * DHC], dv[2 * DHC];
+#pragma unroll
+    for (int c = 0; c < 2 * DHC; c++) { dk[c] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[c] = dk[c]; }
     const int nqt = (p.Lq + 15) >> 4;
     for (int jq = 0; jq < nqt; jq++) {
         // A operands (i = query, k = d)
         const int qa = 16 * jq + li;
         const bool qaok = qa < p.Lq;
-        const float* qp = p.q + ((long)b * p.Lq + qa) * p.ldq + h * 32;
-        const float* dop = p.dout + ((long)b * p.Lq + qa) * p.lddo + h * 32;
+        const float* qp = p.q + ((long)b * p.Lq + qa) * p.ldq + h * DH;
+        const float* dop = p.dout + ((long)b * p.Lq + qa) * p.lddo + h * DH;
         f32x4 sacc = {0.f, 0.f, 0.f, 0.f}, dpacc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int kk = 0; kk < 8; kk++) {
+        for (int kk = 0; kk < 8 * DHC; kk++) {
             sacc = MFMA16(ldz(qp + 4 * kk + g, qaok) * p.scale, kf[kk], sacc);
             dpacc = MFMA16(ldz(dop + 4 * kk + g, qaok), vf[kk], dpacc);
         }
@@ -218,14 +228,16 @@ __device__ __forceinline__ void attn_bwd_dkv(const AttnParams& p, int bh, int kt
         for (int r = 0; r < 4; r++) {
             const int qr = 16 * jq + 4 * g + r;
             const bool qok = qr < p.Lq;
-            // delta[qr] = sum_d O*dO over 32 dims: 16 lanes of the group each take 2 dims.
-            const float* o_r = p.o + ((long)b * p.Lq + qr) * p.ldo + h * 32;
-            const float* do_r = p.dout + ((long)b * p.Lq + qr) * p.lddo + h * 32;
-            float part = ldz(o_r + li, qok) * ldz(do_r + li, qok) + ldz(o_r + 16 + li, qok) * ldz(do_r + 16 + li, qok);
+            // delta[qr] = sum_d O*dO over DH dims: the 16 lanes of the group each take 2*DHC dims.
+            const float* o_r = p.o + ((long)b * p.Lq + qr) * p.ldo + h * DH;
+            const float* do_r = p.dout + ((long)b * p.Lq + qr) * p.lddo + h * DH;
+            float part = 0.f;
+#pragma unroll
+            for (int c = 0; c < 2 * DHC; c++) part += ldz(o_r + 16 * c + li, qok) * ldz(do_r + 16 * c + li, qok);
             part += __shfl_xor(part, 1, 64); part += __shfl_xor(part, 2, 64);
             part += __shfl_xor(part, 4, 64); part += __shfl_xor(part, 8, 64);
             const float lse = qok ? p.lse[(long)bh * p.Lq + qr] : 0.f;
-            float pr = (kmasked || !qok) ? 0.f : expf(sacc[r] - lse);
+            float pr = (kmasked || !qok || (p.causal && krow > qr)) ? 0.f : expf(sacc[r] - lse);
             float dm = 1.f;
             if (p.p_drop > 0.f) dm = attn_drop(p, bh, qr, krow, inv_keep);
             pd[r] = pr * dm;
@@ -236,32 +248,34 @@ __device__ __forceinline__ void attn_bwd_dkv(const AttnParams& p, int bh, int kt
         for (int t = 0; t < 4; t++) {
             const int qr = 16 * jq + 4 * g + t;
             const bool qok = qr < p.Lq;
-            const float* q_r = p.q + ((long)b * p.Lq + qr) * p.ldq + h * 32;
-            const float* do_r = p.dout + ((long)b * p.Lq + qr) * p.lddo + h * 32;
-            dv0 = MFMA16(ldz(do_r + li, qok), pd[t], dv0);
-            dv1 = MFMA16(ldz(do_r + 16 + li, qok), pd[t], dv1);
-            dk0 = MFMA16(ldz(q_r + li, qok), ds[t], dk0);
-            dk1 = MFMA16(ldz(q_r + 16 + li, qok), ds[t], dk1);
+            const float* q_r = p.q + ((long)b * p.Lq + qr) * p.ldq + h * DH;
+            const float* do_r = p.dout + ((long)b * p.Lq + qr) * p.lddo + h * DH;
+#pragma unroll
+            for (int c = 0; c < 2 * DHC; c++) {
+                dv[c] = MFMA16(ldz(do_r + 16 * c + li, qok), pd[t], dv[c]);
+                dk[c] = MFMA16(ldz(q_r + 16 * c + li, qok), ds[t], dk[c]);
+            }
         }
     }
     if (kok) {
-        float* dkp = p.dk + ((long)b * p.Lk + krow) * p.lddk + h * 32 + 4 * g;
-        float* dvp = p.dv + ((long)b * p.Lk + krow) * p.lddv + h * 32 + 4 * g;
-        *reinterpret_cast<float4*>(dkp) = make_float4(dk0[0], dk0[1], dk0[2], dk0[3]);
-        *reinterpret_cast<float4*>(dkp + 16) = make_float4(dk1[0], dk1[1], dk1[2], dk1[3]);
-        *reinterpret_cast<float4*>(dvp) = make_float4(dv0[0], dv0[1], dv0[2], dv0[3]);
-        *reinterpret_cast<float4*>(dvp + 16) = make_float4(dv1[0], dv1[1], dv1[2], dv1[3]);
+        float* dkp = p.dk + ((long)b * p.Lk + krow) * p.lddk + h * DH + 4 * g;
+        float* dvp = p.dv + ((long)b * p.Lk + krow) * p.lddv + h * DH + 4 * g;
+#pragma unroll
+        for (int c = 0; c < 2 * DHC; c++) {
+            *reinterpret_cast<float4*>(dkp + 16 * c) = make_float4(dk[c][0], dk[c][1], dk[c][2], dk[c][3]);
+            *reinterpret_cast<float4*>(dvp + 16 * c) = make_float4(dv[c][0], dv[c][1], dv[c][2], dv[c][3]);
+        }
     }
 }
 
-template <int NKT>
+template <int NKT, int DHC>
 __global__ __launch_bounds__(64) void attn_bwd_kernel(AttnParams p) {
     const int nqt = (p.Lq + 15) >> 4, nkt = (p.Lk + 15) >> 4;
     const int per = nqt + nkt;
     const int bh = blockIdx.x / per;
     const int w = blockIdx.x - bh * per;
-    if (w < nqt) attn_bwd_dq<NKT>(p, bh, w);
-    else attn_bwd_dkv(p, bh, w - nqt);
+    if (w < nqt) attn_bwd_dq<NKT, DHC>(p, bh, w);
+    else attn_bwd_dkv<DHC>(p, bh, w - nqt);
 }
 
 static int check_attn(const AttnParams& p, const char* what) {
@@ -280,12 +294,13 @@ using namespace ldetr;
 extern "C" int ldetr_attention_fwd_f32(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v, int64_t ldv,
                                        const unsigned char* key_padding_mask, float* out, int64_t ldo, float* lse,
                                        int B, int H, int Lq, int Lk, int head_dim, float scale,
-                                       float p_drop, uint64_t seed, const uint64_t* seed_ptr, void* stream) {
+                                       float p_drop, uint64_t seed, const uint64_t* seed_ptr, int causal, void* stream) {
     LDETR_CHECK(head_dim >= 32 && head_dim <= 192 && head_dim % 32 == 0, "attention_fwd: head_dim must be a multiple of 32 up to 192 (got %d)", head_dim);
     AttnParams p; memset(&p, 0, sizeof(p));
     p.q = q; p.k = k; p.v = v; p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.kpm = key_padding_mask;
     p.o = out; p.ldo = ldo; p.lse = lse; p.B = B; p.H = H; p.Lq = Lq; p.Lk = Lk;
-    p.scale = scale; p.p_drop = p_drop; p.seed = seed; p.seed_ptr = (const unsigned long long*)seed_ptr;
+    p.scale = scale; p.p_drop = p_drop; p.seed = seed; p.seed_ptr = (const unsigned long long*)seed_ptr; p.causal = causal;
+    LDETR_CHECK(!causal || Lq == Lk, "attention_fwd: the causal mask is defined for self-attention (Lq == Lk)");
     int rc = check_attn(p, "attention_fwd");
     if (rc) return rc;
     const int nqt = (Lq + 15) / 16, nkt = (Lk + 15) / 16;
@@ -316,14 +331,16 @@ extern "C" int ldetr_attention_bwd_f32(const float* q, int64_t ldq, const float*
                                        const float* dout, int64_t lddo,
                                        float* dq, int64_t lddq, float* dk, int64_t lddk, float* dv, int64_t lddv,
                                        int B, int H, int Lq, int Lk, int head_dim, float scale,
-                                       float p_drop, uint64_t seed, const uint64_t* seed_ptr, void* stream) {
-    LDETR_CHECK(head_dim == 32, "attention: head_dim must be 32 (got %d)", head_dim);
+                                       float p_drop, uint64_t seed, const uint64_t* seed_ptr, int causal, void* stream) {
+    LDETR_CHECK(head_dim >= 32 && head_dim <= 192 && head_dim % 32 == 0, "attention_bwd: head_dim must be a multiple of 32 up to 192 (got %d)", head_dim);
     LDETR_CHECK(lse && dout && dq && dk && dv, "attention_bwd: null pointer");
+    LDETR_CHECK(!causal || Lq == Lk, "attention_bwd: the causal mask is defined for self-attention (Lq == Lk)");
     AttnParams p; memset(&p, 0, sizeof(p));
     p.q = q; p.k = k; p.v = v; p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.kpm = key_padding_mask;
     p.o = const_cast<float*>(out); p.ldo = ldo; p.lse = const_cast<float*>(lse);
     p.dout = dout; p.lddo = lddo; p.dq = dq; p.lddq = lddq; p.dk = dk; p.lddk = lddk; p.dv = dv; p.lddv = lddv;
     p.B = B; p.H = H; p.Lq = Lq; p.Lk = Lk; p.scale = scale; p.p_drop = p_drop; p.seed = seed; p.seed_ptr = (const unsigned long long*)seed_ptr;
+    p.causal = causal;
     int rc = check_attn(p, "attention_bwd");
     if (rc) return rc;
     LDETR_CHECK((lddq % 4) == 0 && (lddk % 4) == 0 && (lddv % 4) == 0 &&
@@ -331,10 +348,22 @@ extern "C" int ldetr_attention_bwd_f32(const float* q, int64_t ldq, const float*
     const int nqt = (Lq + 15) / 16, nkt = (Lk + 15) / 16;
     const int grid = B * H * (nqt + nkt);
     hipStream_t st = (hipStream_t)stream;
-    if (nkt <= 1) hipLaunchKernelGGL(attn_bwd_kernel<1>, grid, 64, 0, st, p);
-    else if (nkt <= 2) hipLaunchKernelGGL(attn_bwd_kernel<2>, grid, 64, 0, st, p);
-    else if (nkt <= 4) hipLaunchKernelGGL(attn_bwd_kernel<4>, grid, 64, 0, st, p);
-    else if (nkt <= 8) hipLaunchKernelGGL(attn_bwd_kernel<8>, grid, 64, 0, st, p);
-    else hipLaunchKernelGGL(attn_bwd_kernel<16>, grid, 64, 0, st, p);
+#define LDETR_ATTN_BWD(DHC)                                                                     \
+    do {                                                                                         \
+        if (nkt <= 1) hipLaunchKernelGGL((attn_bwd_kernel<1, DHC>), grid, 64, 0, st, p);         \
+        else if (nkt <= 2) hipLaunchKernelGGL((attn_bwd_kernel<2, DHC>), grid, 64, 0, st, p);    \
+        else if (nkt <= 4) hipLaunchKernelGGL((attn_bwd_kernel<4, DHC>), grid, 64, 0, st, p);    \
+        else if (nkt <= 8) hipLaunchKernelGGL((attn_bwd_kernel<8, DHC>), grid, 64, 0, st, p);    \
+        else hipLaunchKernelGGL((attn_bwd_kernel<16, DHC>), grid, 64, 0, st, p);                 \
+    } while (0)
+    switch (head_dim / 32) {
+        case 1: LDETR_ATTN_BWD(1); break;
+        case 2: LDETR_ATTN_BWD(2); break;
+        case 3: LDETR_ATTN_BWD(3); break;
+        case 4: LDETR_ATTN_BWD(4); break;
+        case 5: LDETR_ATTN_BWD(5); break;
+        default: LDETR_ATTN_BWD(6); break;
+    }
+#undef LDETR_ATTN_BWD
     return check_launch("attention_bwd");
 }

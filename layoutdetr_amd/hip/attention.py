@@ -30,7 +30,7 @@ class _AttnFn(torch.autograd.Function):
         core.check(core.lib().ldetr_attention_fwd_f32(
             core.ptr(q), q.stride(0), core.ptr(k), k.stride(0), core.ptr(v), v.stride(0), core.ptr(kpm),
             core.ptr(out), d, core.ptr(lse), B, H, Lq, Lk, dh, scale, p_drop, seed, core.seed_ptr() if p_drop > 0 else None,
-            core.stream()), 'attention_fwd')
+            0, core.stream()), 'attention_fwd')
         ctx.save_for_backward(q, k, v, kpm, out, lse)
         ctx.cfg = (B, H, Lq, Lk, dh, scale, p_drop, seed)
         return out
@@ -47,7 +47,7 @@ class _AttnFn(torch.autograd.Function):
         core.check(core.lib().ldetr_attention_bwd_f32(
             core.ptr(q), q.stride(0), core.ptr(k), k.stride(0), core.ptr(v), v.stride(0), core.ptr(kpm),
             core.ptr(out), d, core.ptr(lse), core.ptr(dout), d, core.ptr(dq), d, core.ptr(dk), d, core.ptr(dv), d,
-            B, H, Lq, Lk, dh, scale, p_drop, seed, core.seed_ptr() if p_drop > 0 else None, core.stream()), 'attention_bwd')
+            B, H, Lq, Lk, dh, scale, p_drop, seed, core.seed_ptr() if p_drop > 0 else None, 0, core.stream()), 'attention_bwd')
         return dq, dk, dv, None, None, None, None, None, None
 
 
@@ -57,7 +57,7 @@ class _AttnPackedFn(torch.autograd.Function):
     a zero-fill + copy per slice and two adds per attention in backward (SliceBackward), 8 launches of pure overhead."""
 
     @staticmethod
-    def forward(ctx, qkv, v_sep, kpm, B, H, L, p_drop):
+    def forward(ctx, qkv, v_sep, kpm, B, H, L, p_drop, causal=False):
         core.require_gpu(qkv, v_sep, kpm)
         assert qkv.stride(1) == 1
         d = qkv.shape[1] // (3 if v_sep is None else 2)
@@ -72,15 +72,15 @@ class _AttnPackedFn(torch.autograd.Function):
         core.check(core.lib().ldetr_attention_fwd_f32(
             core.ptr(q), q.stride(0), core.ptr(k), k.stride(0), core.ptr(v), v.stride(0), core.ptr(kpm),
             core.ptr(out), d, core.ptr(lse), B, H, L, L, dh, scale, p_drop, seed, core.seed_ptr() if p_drop > 0 else None,
-            core.stream()), 'attention_fwd')
+            1 if causal else 0, core.stream()), 'attention_fwd')
         ctx.save_for_backward(qkv, v_sep, kpm, out, lse)
-        ctx.cfg = (B, H, L, dh, scale, p_drop, seed)
+        ctx.cfg = (B, H, L, dh, scale, p_drop, seed, 1 if causal else 0)
         return out
 
     @staticmethod
     def backward(ctx, dout):
         qkv, v_sep, kpm, out, lse = ctx.saved_tensors
-        B, H, L, dh, scale, p_drop, seed = ctx.cfg
+        B, H, L, dh, scale, p_drop, seed, causal = ctx.cfg
         d = H * dh
         q, k = qkv[:, :d], qkv[:, d:2 * d]
         v = qkv[:, 2 * d:] if v_sep is None else v_sep
@@ -92,8 +92,8 @@ class _AttnPackedFn(torch.autograd.Function):
             core.ptr(q), q.stride(0), core.ptr(k), k.stride(0), core.ptr(v), v.stride(0), core.ptr(kpm),
             core.ptr(out), d, core.ptr(lse), core.ptr(dout), d, core.ptr(dq), dq.stride(0), core.ptr(dk), dk.stride(0),
             core.ptr(dv), dv.stride(0), B, H, L, L, dh, scale, p_drop, seed, core.seed_ptr() if p_drop > 0 else None,
-            core.stream()), 'attention_bwd')
-        return dqkv, (None if v_sep is None else dv), None, None, None, None, None
+            causal, core.stream()), 'attention_bwd')
+        return dqkv, (None if v_sep is None else dv), None, None, None, None, None, None
 
 
 def _kpm_u8(key_padding_mask):

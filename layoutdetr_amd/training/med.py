@@ -134,7 +134,7 @@ class BertLayer(nn.Module):
         core.check(core.lib().ldetr_attention_fwd_f32(
             core.ptr(q), qkv.stride(0), core.ptr(k), qkv.stride(0), core.ptr(v), qkv.stride(0), core.ptr(kpm),
             core.ptr(ctx), d, None, B, H, T, T, dh, 1.0 / math.sqrt(dh), p_attn, seed,
-            core.seed_ptr() if p_attn > 0 else None, core.stream()), 'bert attention')
+            core.seed_ptr() if p_attn > 0 else None, 0, core.stream()), 'bert attention')
         so = self.attention.output
         a = core.gemm(ctx, so.dense.weight.detach(), 0, 0, M, d, d, ep=core.epilogue(col_bias=so.dense.bias.detach()))
         x2 = add_layernorm(x2, a, so.LayerNorm.weight, so.LayerNorm.bias, so.LayerNorm.eps, p_hid)

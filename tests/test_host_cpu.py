@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), f'{name} declared in include/ldetr_hip.h but not exported'
     assert declared - {'ldetr_last_error', 'ldetr_abi_version'} == set(_lib.SIGNATURES), 'ctypes table out of sync with the header'
-    assert lib.ldetr_abi_version() == 5
+    assert lib.ldetr_abi_version() == 6
 
 
 def test_no_cpu_fallback():
@@ -53,7 +53,7 @@ def test_argument_validation_without_gpu():
     lib = _lib.load()
     rc = lib.ldetr_bias_act_f32(None, None, None, None, None, None, 16, 0, 1, 0, 3, 0.2, 1.0, -1.0, None)
     assert rc != 0 and b'non-null' in lib.ldetr_last_error()
-    rc = lib.ldetr_attention_fwd_f32(None, 0, None, 0, None, 0, None, None, 0, None, 1, 8, 9, 9, 48, 1.0, 0.0, 0, None, None)
+    rc = lib.ldetr_attention_fwd_f32(None, 0, None, 0, None, 0, None, None, 0, None, 1, 8, 9, 9, 48, 1.0, 0.0, 0, None, 0, None)
     assert rc != 0 and b'head_dim' in lib.ldetr_last_error()
     rc = lib.ldetr_lsap_f64(ctypes.c_void_p(8), 1, 99, 0, ctypes.c_void_p(8), ctypes.c_void_p(8), None)
     assert rc != 0 and b'n must be' in lib.ldetr_last_error()

@@ -541,3 +541,28 @@ def test_bottleneck_chain_fused_block_gradients(dev):
         got_w += [b.conv1.weight.grad, b.conv2.weight.grad] + ([b.downsample[0].weight.grad] if b.downsample is not None else []) + [b.conv3.weight.grad]
     for i, (a, r) in enumerate(zip(got_w, ref_w)):
         assert_close(a, r, 3e-5, f'dw[{i}]')
+
+
+@pytest.mark.parametrize('B,H,L,dh,causal', [(2, 4, 40, 192, True), (3, 3, 21, 64, True), (2, 2, 70, 96, False), (2, 4, 40, 192, False), (2, 8, 19, 32, True)])
+def test_attention_wide_heads_and_causal(dev, B, H, L, dh, causal):
+    """Packed self-attention for 32..192-wide heads, forward + backward, with the decoder's causal mask on top of a ragged
+    key-padding mask (BertSelfAttention shapes of the text encoder / LM decoder)."""
+    from layoutdetr_amd.hip.attention import _AttnPackedFn
+    torch.manual_seed(21)
+    d = H * dh
+    qkv = torch.randn(B * L, 3 * d) * 0.5
+    kpm = torch.zeros(B, L, dtype=torch.bool); kpm[0, L - 5:] = True; kpm[-1, L // 2:] = True
+    g = torch.randn(B * L, d)
+    qr = qkv.clone().requires_grad_(True)
+    q, k, v = [t.reshape(B, L, H, dh).permute(0, 2, 1, 3) for t in qr.split(d, dim=1)]
+    s = (q @ k.transpose(-1, -2)) / math.sqrt(dh)
+    s = s.masked_fill(kpm[:, None, None, :], float('-inf'))
+    if causal:
+        s = s.masked_fill(torch.triu(torch.ones(L, L, dtype=torch.bool), 1), float('-inf'))
+    ref = (torch.softmax(s, -1) @ v).permute(0, 2, 1, 3).reshape(B * L, d)
+    ref.backward(g)
+    qg = qkv.to(dev).requires_grad_(True)
+    out = _AttnPackedFn.apply(qg, None, kpm.to(torch.uint8).to(dev), B, H, L, 0.0, causal)
+    out.backward(g.to(dev))
+    assert_close(out, ref.detach(), 1e-5, 'out')
+    assert_close(qg.grad, qr.grad, 2e-5, 'dqkv')
