@@ -69,7 +69,10 @@ __device__ __forceinline__ float bias_act_elem(float x, float b, float xref, flo
             yref = (xref < -expRange) ? 0.f : xref / (expf(-xref) + one) * gain;
         }
     }
-    if (A == 10) { y = 0.5f * x * (one + erff(x * 0.70710678118654752f)); }   // erf-GELU, forward only (BERT intermediate, training/med.py:296-307)
+    if (A == 10) {   // erf-GELU (BERT intermediate / LM-head transform, training/med.py:296-307, 504-518); grad 1: x = dy, xref = pre-activation
+        if (G == 0) y = 0.5f * x * (one + erff(x * 0.70710678118654752f));
+        if (G == 1) y = x * (0.5f * (one + erff(xref * 0.70710678118654752f)) + xref * 0.3989422804014327f * expf(-0.5f * xref * xref));
+    }
     y *= gain * dy;
     if (clamp >= 0.f) {
         if (G == 0) y = (y > -clamp && y < clamp) ? y : (y >= 0.f) ? clamp : -clamp;
@@ -158,7 +161,7 @@ extern "C" int ldetr_bias_act_f32(const float* x, const float* b, const float* x
     LDETR_CHECK(sizeX >= 0 && sizeX <= 2147483647LL, "bias_act: x is too large");
     LDETR_CHECK(grad >= 0 && grad <= 2, "bias_act: grad must be 0, 1 or 2");
     LDETR_CHECK(act >= 1 && act <= 10, "bias_act: no kernel found for the specified activation func");
-    LDETR_CHECK(act != 10 || grad == 0, "bias_act: gelu (10) is forward only");
+    LDETR_CHECK(act != 10 || grad <= 1, "bias_act: gelu (10) has no second-order gradient");
     LDETR_CHECK(!b || (sizeB > 0 && stepB > 0), "bias_act: b has wrong number of elements");
     if (sizeX == 0) return LDETR_OK;
     BiasActParams p{x, b, xref, yref, dy, y, (long)sizeX, b ? sizeB : 1, b ? (long)stepB : 1, alpha, gain, clamp};
@@ -173,6 +176,6 @@ extern "C" int ldetr_bias_act_f32(const float* x, const float* b, const float* x
         case 7: return dispatch_grad<7>(p, grad, st);
         case 8: return dispatch_grad<8>(p, grad, st);
         case 9: return dispatch_grad<9>(p, grad, st);
-        default: return launch_bias_act<10, 0>(p, st);
+        default: return grad == 0 ? launch_bias_act<10, 0>(p, st) : launch_bias_act<10, 1>(p, st);
     }
 }

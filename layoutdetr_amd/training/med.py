@@ -185,3 +185,120 @@ class BertModel(nn.Module):
                 x2 = layer.forward2d(x2, B, T, kpm)
             hs = x2.reshape(B, T, -1)
         return SimpleNamespace(last_hidden_state=hs) if return_dict else (hs,)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# LM text decoder (second half): the reference's `BertLMHeadModel` as the hot path calls it
+# (networks_detr.py:169-181, 328-340): `text_decoder(decoder_input_ids, attention_mask=..., encoder_hidden_states=xx,
+# labels=decoder_targets, return_dict=True, mode='text')`.  With mode='text' BertLayer skips the cross-attention block
+# (training/med.py:361), so `encoder_hidden_states` is accepted and ignored exactly as in the reference: the decoder is a causal
+# BERT LM over the text tokens (is_decoder=True -> causal + padding mask, med.py:704-739), trained with a label-smoothed (0.1)
+# next-token cross entropy (med.py:911-916).  Trainable: every op below has a backward on the HIP kernels (GEMM engine, causal
+# wide-head attention fwd/bwd, fused add+dropout+LayerNorm, erf-GELU fwd/grad); embedding lookups and the softmax cross entropy
+# over the vocabulary are torch glue.
+class _GeluFn(torch.autograd.Function):
+    """y = gelu(h + bias) with the erf form; backward through bias_act's gradient kernel (activation 10)."""
+
+    @staticmethod
+    def forward(ctx, h, bias):
+        core.require_gpu(h, bias)
+        h = core.f32c(h)
+        y = torch.empty_like(h)
+        C = h.shape[-1]
+        core.check(core.lib().ldetr_bias_act_f32(core.ptr(h), core.ptr(bias), None, None, None, core.ptr(y), h.numel(), C, 1, 0, 10,
+                                                 0.0, 1.0, -1.0, core.stream()), 'gelu fwd')
+        ctx.save_for_backward(h, bias)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        h, bias = ctx.saved_tensors
+        dy = core.f32c(dy)
+        dh = torch.empty_like(h)
+        C = h.shape[-1]
+        core.check(core.lib().ldetr_bias_act_f32(core.ptr(dy), core.ptr(bias), core.ptr(h), None, None, core.ptr(dh), h.numel(), C, 1, 1, 10,
+                                                 0.0, 1.0, -1.0, core.stream()), 'gelu bwd')
+        db = core.colsum(dh.reshape(-1, C)).reshape(-1) if ctx.needs_input_grad[1] else None
+        return dh, db
+
+
+def _layer_train(layer, x2, B, T, kpm, causal):
+    """Differentiable twin of BertLayer.forward2d (autograd Functions of hip/linear.py, hip/attention.py, hip/layernorm.py)."""
+    from ..hip.attention import _AttnPackedFn
+    from ..hip.linear import linear
+    cfg = layer.config
+    H = cfg.num_attention_heads
+    p_attn = cfg.attention_probs_dropout_prob if layer.training else 0.0
+    p_hid = cfg.hidden_dropout_prob if layer.training else 0.0
+    a = layer.attention.self
+    qkv = linear(x2, torch.cat([a.query.weight, a.key.weight, a.value.weight], 0), torch.cat([a.query.bias, a.key.bias, a.value.bias], 0))
+    ctx = _AttnPackedFn.apply(qkv, None, kpm, B, H, T, p_attn, causal)
+    so = layer.attention.output
+    x2 = add_layernorm(x2, linear(ctx, so.dense.weight, so.dense.bias), so.LayerNorm.weight, so.LayerNorm.bias, so.LayerNorm.eps, p_hid)
+    h = _GeluFn.apply(linear(x2, layer.intermediate.dense.weight, None), layer.intermediate.dense.bias)
+    out = layer.output
+    return add_layernorm(x2, linear(h, out.dense.weight, out.dense.bias), out.LayerNorm.weight, out.LayerNorm.bias, out.LayerNorm.eps, p_hid)
+
+
+class _PredictionHeadTransform(nn.Module):
+    def __init__(self, config):
+        super().__init__()
+        self.dense = nn.Linear(config.hidden_size, config.hidden_size)
+        self.LayerNorm = nn.LayerNorm(config.hidden_size, eps=config.layer_norm_eps)
+
+
+class _LMPredictionHead(nn.Module):
+    def __init__(self, config):
+        super().__init__()
+        self.transform = _PredictionHeadTransform(config)
+        self.decoder = nn.Linear(config.hidden_size, config.vocab_size, bias=False)
+        self.bias = nn.Parameter(torch.zeros(config.vocab_size))
+
+
+class BertOnlyMLMHead(nn.Module):
+    def __init__(self, config):
+        super().__init__()
+        self.predictions = _LMPredictionHead(config)
+
+
+class BertLMHeadModel(nn.Module):
+    """Parameter names of the reference's BertLMHeadModel: `bert.*`, `cls.predictions.{transform.dense, transform.LayerNorm,
+    decoder, bias}`; `cls.predictions.decoder.weight` is tied to `bert.embeddings.word_embeddings.weight` (HF tie_weights)."""
+
+    def __init__(self, config):
+        super().__init__()
+        self.config = config
+        self.bert = BertModel(config, add_pooling_layer=False)
+        self.cls = BertOnlyMLMHead(config)
+        self.cls.predictions.decoder.weight = self.bert.embeddings.word_embeddings.weight
+
+    def forward(self, input_ids, attention_mask=None, encoder_hidden_states=None, encoder_attention_mask=None, labels=None,
+                return_dict=True, mode='text', reduction='mean'):
+        from ..hip.linear import linear
+        if mode != 'text':
+            raise NotImplementedError("the hot path calls the text decoder with mode='text' (cross-attention skipped, med.py:361)")
+        core.require_gpu(input_ids)
+        cfg = self.config
+        B, T = input_ids.shape
+        emb = self.bert.embeddings
+        x = emb.word_embeddings(input_ids) + emb.position_embeddings(emb.position_ids[:, :T])
+        x2 = add_layernorm(x.reshape(-1, cfg.hidden_size), None, emb.LayerNorm.weight, emb.LayerNorm.bias, emb.LayerNorm.eps)
+        x2 = emb.dropout(x2)
+        kpm = None if attention_mask is None else (attention_mask == 0).to(torch.uint8).contiguous()
+        for layer in self.bert.encoder.layer:
+            x2 = _layer_train(layer, x2, B, T, kpm, True)
+        hs = x2.reshape(B, T, cfg.hidden_size)
+        # next-token prediction: scores of positions 0..T-2 against tokens 1..T-1 (med.py:911-913); only those rows reach the
+        # vocabulary-sized GEMM
+        hsh = hs[:, :-1].reshape(-1, cfg.hidden_size)
+        tr = self.cls.predictions.transform
+        t = _GeluFn.apply(linear(hsh, tr.dense.weight, None), tr.dense.bias)
+        t = add_layernorm(t, None, tr.LayerNorm.weight, tr.LayerNorm.bias, tr.LayerNorm.eps)
+        logits = linear(t, self.cls.predictions.decoder.weight, self.cls.predictions.bias)        # [B*(T-1), vocab]
+        loss = None
+        if labels is not None:
+            tgt = labels[:, 1:].reshape(-1)
+            loss = F.cross_entropy(logits, tgt, ignore_index=-100, label_smoothing=0.1, reduction=reduction)
+            if reduction == 'none':
+                loss = loss.view(B, -1).sum(1)
+        return SimpleNamespace(loss=loss, logits=logits.reshape(B, T - 1, -1)) if return_dict else (loss, logits)

@@ -302,6 +302,54 @@ def gen_bert():
         save('bert_text' + tag, d)
 
 
+def gen_bert_lm():
+    """Text-mode LM decoder (second half): the reference's BertEmbeddings + BertEncoder + BertOnlyMLMHead driven as
+    BertLMHeadModel.forward drives them in mode='text' (causal x padding mask from get_extended_attention_mask, med.py:704-739;
+    decoder weight tied to the word embeddings; shifted cross entropy with label_smoothing=0.1, :911-916), loss + the gradient of
+    every parameter.  Same transformers-5.x workaround as gen_bert (the PreTrainedModel wrapper cannot be constructed)."""
+    hidden = {k: sys.modules.pop(k) for k in list(sys.modules) if k.split('.')[0] == 'torchvision'}
+    import transformers.modeling_utils as mu
+    import transformers.pytorch_utils as pu
+    mu.apply_chunking_to_forward = pu.apply_chunking_to_forward
+    mu.prune_linear_layer = pu.prune_linear_layer
+
+    def _unused(*a, **k):
+        raise NotImplementedError
+    mu.find_pruneable_heads_and_indices = _unused
+    from training.med import BertConfig, BertEmbeddings, BertEncoder, BertOnlyMLMHead
+    sys.modules.update(hidden)
+    torch.manual_seed(520)
+    hid, heads, layers, inter, T, B, V = 64, 2, 2, 128, 12, 4, 70
+    cfg = BertConfig(vocab_size=V, hidden_size=hid, num_hidden_layers=layers, num_attention_heads=heads, intermediate_size=inter,
+                     max_position_embeddings=40, add_cross_attention=True, encoder_width=hid, is_decoder=True)
+    emb, enc, head = BertEmbeddings(cfg).eval(), BertEncoder(cfg).eval(), BertOnlyMLMHead(cfg).eval()
+    head.predictions.decoder.weight = emb.word_embeddings.weight     # HF tie_weights
+    params = {}
+    for prefix, mod in (('bert.embeddings.', emb), ('bert.encoder.', enc), ('cls.', head)):
+        for nm, prm in mod.named_parameters():
+            if 'crossattention' in nm or (prefix == 'cls.' and nm == 'predictions.decoder.weight'):
+                continue
+            prm.data.normal_(0, 0.08)
+            if 'LayerNorm.weight' in nm:
+                prm.data.add_(1.0)
+            params[prefix + nm] = prm
+    ids = torch.randint(1, V, (B, T)); am = torch.ones(B, T, dtype=torch.long)
+    am[1, 7:] = 0; am[3, 2:] = 0; ids[am == 0] = 0
+    ids[:, 0] = V - 2                                      # "[DEC]" bos id, as networks_detr.py:172 writes it
+    labels = ids.masked_fill(ids == 0, -100)
+    labels[2] = -100                                       # a padded layout slot: contributes nothing
+    causal = torch.tril(torch.ones(T, T))[None, None]
+    ext = (1.0 - causal * am[:, None, None, :].float()) * -10000.0
+    hs = enc(emb(input_ids=ids), attention_mask=ext, return_dict=True, mode='text').last_hidden_state
+    scores = head(hs)[:, :-1, :].contiguous()
+    loss = torch.nn.CrossEntropyLoss(reduction='mean', label_smoothing=0.1)(scores.view(-1, V), labels[:, 1:].contiguous().view(-1))
+    loss.backward()
+    d = {'input_ids': ids, 'attention_mask': am, 'labels': labels, 'loss': loss.detach(), 'logits': scores.detach(), 'num_heads': np.asarray(heads)}
+    for k, prm in params.items():
+        d['sd/' + k] = prm.detach(); d['grad/' + k] = prm.grad
+    save('bert_lm', d)
+
+
 def gen_dp_step():
     from torch_utils import misc
     torch.manual_seed(600)
@@ -326,7 +374,7 @@ if __name__ == '__main__':
     if '--only-metrics' in sys.argv:
         gen_metrics(); sys.exit(0)
     if '--only-bert' in sys.argv:
-        gen_bert(); sys.exit(0)
+        gen_bert(); gen_bert_lm(); sys.exit(0)
     if '--skip-done' not in sys.argv:
         gen_ops(); gen_transformer()
-    gen_losses(); gen_decoder(); gen_frozen_bn(); gen_lsap(); gen_dp_step(); gen_metrics(); gen_bert()
+    gen_losses(); gen_decoder(); gen_frozen_bn(); gen_lsap(); gen_dp_step(); gen_metrics(); gen_bert(); gen_bert_lm()

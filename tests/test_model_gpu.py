@@ -379,3 +379,33 @@ def test_iteration_level_D_trunk_sharing_matches_reference_call_pattern(dev):
         e = ((a - b).norm() / a.norm()).item()
         assert e <= 5e-3 and torch.isfinite(a).all(), f'{name}: graph replays differ: {e:.3e}'
     assert len(grads['Dmain']) == n0 + 1
+
+
+@pytest.mark.gpu
+def test_bert_lm_decoder_vs_reference_golden(dev):
+    """HIP LM decoder (causal attention fwd/bwd, GELU fwd/grad, tied LM head, label-smoothed CE) against the reference pieces:
+    loss, shifted logits and the gradient of every parameter."""
+    from layoutdetr_amd.training import med
+    d = np.load(os.path.join(G_DIR, 'bert_lm.npz'))
+    sd = {k[3:]: torch.from_numpy(d[k]) for k in d.files if k.startswith('sd/')}
+    V, hid = sd['bert.embeddings.word_embeddings.weight'].shape
+    cfg = med.BertConfig(vocab_size=V, hidden_size=hid, num_hidden_layers=2, num_attention_heads=int(d['num_heads']),
+                         intermediate_size=sd['bert.encoder.layer.0.intermediate.dense.weight'].shape[0],
+                         max_position_embeddings=sd['bert.embeddings.position_embeddings.weight'].shape[0], add_cross_attention=False)
+    m = med.BertLMHeadModel(cfg).eval()
+    missing, unexpected = m.load_state_dict(sd, strict=False)
+    assert not unexpected and set(missing) <= {'bert.embeddings.position_ids', 'cls.predictions.decoder.weight'}, (missing, unexpected)
+    m.to(dev)
+    out = m(torch.from_numpy(d['input_ids']).to(dev), attention_mask=torch.from_numpy(d['attention_mask']).to(dev),
+            encoder_hidden_states=torch.zeros(4, 1, hid, device=dev), labels=torch.from_numpy(d['labels']).to(dev), return_dict=True, mode='text')
+    out.loss.backward()
+    assert abs(out.loss.item() - float(d['loss'])) <= 2e-5, (out.loss.item(), float(d['loss']))
+    ref_logits = torch.from_numpy(d['logits'])
+    assert (out.logits.detach().cpu() - ref_logits).abs().max().item() <= 2e-5 * ref_logits.abs().max().item()
+    gmax = max(float(np.abs(d['grad/' + k]).max()) for k in sd)
+    named = dict(m.named_parameters())
+    for k in sd:
+        g = named[k].grad
+        assert g is not None, k
+        err = (g.cpu() - torch.from_numpy(d['grad/' + k])).abs().max().item()
+        assert err <= 3e-5 * gmax, f'{k}: {err / gmax:.3e}'

@@ -207,3 +207,18 @@ def test_bert_text_encoder_oracle(tag):
     sd = {k[3:]: torch.from_numpy(d[k]) for k in d.files if k.startswith('sd/')}
     out = bert_ref.bert_text_forward(sd, int(d['num_heads']), torch.from_numpy(d['input_ids']), torch.from_numpy(d['attention_mask']))
     close(out, d['last_hidden_state'], 2e-6)
+
+
+def test_bert_lm_decoder_oracle():
+    """oracle/bert_ref.bert_lm_loss against the reference's text-mode LM decoder pieces: loss, logits and every gradient."""
+    from oracle import bert_ref
+    d = np.load(os.path.join(G, 'bert_lm.npz'))
+    sd = {k[3:]: torch.from_numpy(d[k]).clone().requires_grad_(True) for k in d.files if k.startswith('sd/')}
+    loss, logits = bert_ref.bert_lm_loss(sd, int(d['num_heads']), torch.from_numpy(d['input_ids']), torch.from_numpy(d['attention_mask']),
+                                         torch.from_numpy(d['labels']))
+    loss.backward()
+    assert abs(loss.item() - float(d['loss'])) <= 1e-6
+    close(logits.detach(), d['logits'], 2e-6)
+    gmax = max(float(np.abs(d['grad/' + k]).max()) for k in sd)
+    for k in sd:   # absolute, against the largest gradient: the key biases' true gradient is 0 (softmax shift invariance), i.e. noise
+        assert (sd[k].grad - torch.from_numpy(d['grad/' + k])).abs().max().item() <= 2e-6 * gmax, k
