@@ -11,7 +11,9 @@ Text path (SURVEY §8a rows a16/a17 are *boundary inputs*, not kernel rows): `bb
     requires `text_mode='encoder'`: the frozen BERT text encoder (training/med.py) then runs on the HIP
     kernels inside forward(), exactly where the reference calls it (networks_detr.py:145-147, 289-291).
 Strings are not accepted: tokenisation is host-side work outside this package (the reference's `init_tokenizer` needs the
-`bert-base-uncased` vocabulary).  The LM-decoder reconstruction loss (`loss_lm`, §8f-1 second half) is a zero tensor.
+`bert-base-uncased` vocabulary).  `text_mode='encoder+lm'` additionally builds the trainable LM text decoder
+(`text_decoder`, training/med.py BertLMHeadModel) and returns its label-smoothed next-token loss as `loss_lm`; in the other
+modes `loss_lm` is a zero tensor.
 
 `module.static_shapes = True` (opt-in, used by bench.py) switches the reconstruction heads from the reference's
 boolean gathers `x[~padding_mask]` (dynamic shape M -> device-to-host sync, SURVEY §7 "launch-bound regime") to
@@ -79,27 +81,61 @@ class TextFeatures(object):
 class TextTokens(object):
     """Tokenizer output for one batch: input_ids / attention_mask [B, N, T] int64, text_len [B, N] (character counts)."""
 
-    def __init__(self, input_ids, attention_mask, text_len):
+    def __init__(self, input_ids, attention_mask, text_len, bos_token_id=30522, pad_token_id=0):
         self.input_ids, self.attention_mask, self.text_len = input_ids, attention_mask, text_len
+        # blip.init_tokenizer (:190-195) appends [DEC] (bos) and [ENC] to bert-base-uncased: ids 30522 / 30523, vocabulary 30524
+        self.bos_token_id, self.pad_token_id = bos_token_id, pad_token_id
 
     def __len__(self):
         return self.input_ids.shape[0]
 
     def __getitem__(self, idx):
-        return TextTokens(self.input_ids[idx], self.attention_mask[idx], self.text_len[idx])
+        return TextTokens(self.input_ids[idx], self.attention_mask[idx], self.text_len[idx], self.bos_token_id, self.pad_token_id)
 
 
 def _build_text_encoder(text_mode, med_config, num_layers, num_heads):
     """reference: networks_detr.py:88-93 (encoder_config from med_config.json with layers / heads overridden)."""
     if text_mode == 'features':
         return _NoTextEncoder()
-    if text_mode != 'encoder':
-        raise ValueError("text_mode must be 'features' (TextFeatures in) or 'encoder' (TextTokens in)")
+    if text_mode not in ('encoder', 'encoder+lm'):
+        raise ValueError("text_mode must be 'features' (TextFeatures in), 'encoder' or 'encoder+lm' (TextTokens in)")
     import os
     from . import med
     cfg = med.BertConfig.from_json_file(med_config) if (med_config and os.path.exists(med_config)) else med.BertConfig()
     cfg.num_hidden_layers, cfg.num_attention_heads = num_layers, num_heads
     return med.BertModel(cfg, add_pooling_layer=False)
+
+
+def _build_text_decoder(text_mode, med_config, num_layers, num_heads, encoder_width, vocab_size=30524):
+    """reference: networks_detr.py:122-128 (decoder_config; BertLMHeadModel resized to the tokenizer's 30524 entries)."""
+    if text_mode != 'encoder+lm':
+        return None
+    import os
+    from . import med
+    cfg = med.BertConfig.from_json_file(med_config) if (med_config and os.path.exists(med_config)) else med.BertConfig()
+    cfg.num_hidden_layers, cfg.num_attention_heads, cfg.encoder_width, cfg.vocab_size = num_layers, num_heads, encoder_width, vocab_size
+    return med.BertLMHeadModel(cfg)
+
+
+def _lm_loss(module, bbox_text, padding_mask, B, N, static):
+    """Text reconstruction loss of the reconstructor heads (reference networks_detr.py:169-181 / 328-340): the text decoder in
+    mode='text' on the element texts with [DEC] as first token; padded slots contribute nothing (the reference gathers
+    `[~padding_mask]` rows; here their labels are -100, the same mean over the same tokens, without a dynamic shape)."""
+    if module.text_decoder is None or not isinstance(bbox_text, TextTokens):
+        return None
+    dev = padding_mask.device
+    T = bbox_text.input_ids.shape[-1]
+    ids = bbox_text.input_ids.reshape(B * N, T).to(dev).clone()
+    am = bbox_text.attention_mask.reshape(B * N, T).to(dev)
+    ids[:, 0] = bbox_text.bos_token_id
+    targets = ids.masked_fill(ids == bbox_text.pad_token_id, -100)
+    pm = padding_mask.reshape(B * N)
+    if static:
+        targets = targets.masked_fill(pm[:, None], -100)
+    else:
+        keep = ~pm
+        ids, am, targets = ids[keep], am[keep], targets[keep]
+    return module.text_decoder(ids, attention_mask=am, labels=targets, return_dict=True, mode='text').loss
 
 
 class _NoTextEncoder(nn.Module):
@@ -173,6 +209,7 @@ class Generator(nn.Module):
         self.fc_z = Linear(z_dim * 9, bert_f_dim)
         self.emb_label = nn.Embedding(num_bbox_labels, bert_f_dim)
         self.text_encoder = _build_text_encoder(text_mode, med_config, bert_num_encoder_layers, bert_num_heads)
+        self.text_decoder = _build_text_decoder(text_mode, med_config, bert_num_decoder_layers, bert_num_heads, im_f_dim)
         self.enc_text_len = nn.Embedding(max_text_length, bert_f_dim)
         self.fc_in = MLP(input_dim=4 * bert_f_dim, hidden_dim=bert_f_dim, output_dim=hidden_dim, num_layers=3)
         self.transformer = Transformer(d_model=hidden_dim, dropout=0.1, nhead=8, dim_feedforward=2048, num_encoder_layers=6,
@@ -213,12 +250,14 @@ class Generator(nn.Module):
             logit_cls = self.fc_out_cls(x)                                   # [B, N, L]: every slot, masked by the caller
             ce = F.cross_entropy(self.fc_text_len_rec(x).flatten(0, 1), text_len.flatten(), reduction='none')
             loss_text_len = (ce * vf.flatten()).sum() / cnt
-            return bbox_fake, loss_z, logit_cls, _zero_like_loss(loss_z), loss_text_len
+            loss_lm = _lm_loss(self, bbox_text, padding_mask, B, N, True)
+            return bbox_fake, loss_z, logit_cls, (loss_lm if loss_lm is not None else _zero_like_loss(loss_z)), loss_text_len
         xv = x[valid]
         z_rec = self.fc_z_rec(xv)
         loss_z = F.mse_loss(z_rec, z0.unsqueeze(1).expand(-1, N, -1)[valid])
         logit_cls = self.fc_out_cls(xv)
-        loss_lm = _zero_like_loss(loss_z)
+        loss_lm = _lm_loss(self, bbox_text, padding_mask, B, N, False)
+        loss_lm = loss_lm if loss_lm is not None else _zero_like_loss(loss_z)
         text_len_rec = self.fc_text_len_rec(xv)
         loss_text_len = F.cross_entropy(text_len_rec, text_len[valid])
         return bbox_fake, loss_z, logit_cls, loss_lm, loss_text_len
@@ -242,6 +281,7 @@ class Discriminator(nn.Module):
         self.fc_bbox = Linear(4, bert_f_dim)
         self.emb_label = nn.Embedding(num_bbox_labels, bert_f_dim)
         self.text_encoder = _build_text_encoder(text_mode, med_config, bert_num_encoder_layers, bert_num_heads)
+        self.text_decoder = _build_text_decoder(text_mode, med_config, bert_num_decoder_layers, bert_num_heads, im_f_dim)
         self.enc_text_len = nn.Embedding(max_text_length, bert_f_dim)
         self.enc_fc_in = MLP(input_dim=4 * bert_f_dim, hidden_dim=bert_f_dim, output_dim=hidden_dim, num_layers=3)
         self.enc_transformer = TransformerWithToken(d_model=hidden_dim, dropout=0.1, nhead=8, dim_feedforward=2048,
@@ -324,7 +364,8 @@ class Discriminator(nn.Module):
             loss_text_len = (ce * vf.flatten()).sum() / vf.sum().clamp_min(1.0)
         else:
             loss_text_len = F.cross_entropy(text_len_rec, text_len[valid])
-        loss_lm = _zero_like_loss(loss_text_len)
+        loss_lm = _lm_loss(self, bbox_text, padding_mask, B, N, static)
+        loss_lm = loss_lm if loss_lm is not None else _zero_like_loss(loss_text_len)
         bg_rec = self.bg_decoder(x0)
 
         x_uncond = x0_uncond.unsqueeze(0).expand(N, -1, -1)

@@ -409,3 +409,54 @@ def test_bert_lm_decoder_vs_reference_golden(dev):
         assert g is not None, k
         err = (g.cpu() - torch.from_numpy(d['grad/' + k])).abs().max().item()
         assert err <= 3e-5 * gmax, f'{k}: {err / gmax:.3e}'
+
+
+@pytest.mark.gpu
+def test_text_mode_encoder_lm_full_iteration(dev):
+    """text_mode='encoder+lm': G's reconstructor returns the LM decoder's loss (= oracle on the same tokens / masks / padded
+    slots, static and gather formulations alike) and a full G+D iteration trains the decoder while the encoder stays frozen."""
+    from layoutdetr_amd.training.networks_detr import Discriminator, Generator, TextTokens
+    from layoutdetr_amd.training import training_loop as tl
+    from layoutdetr_amd.training.loss import StyleGAN2Loss
+    from oracle import bert_ref
+    torch.manual_seed(14)
+    bg, B, N, T = 64, 2, 9, 16
+    kw = dict(num_bbox_labels=8, img_channels=3, img_height=bg, img_width=bg, c_dim=0, background_size=bg, bert_f_dim=768, im_f_dim=512,
+              bert_num_encoder_layers=1, bert_num_decoder_layers=2, bert_num_heads=4, text_mode='encoder+lm')
+    G = Generator(z_dim=4, **kw).eval().requires_grad_(False).to(dev)
+    D = Discriminator(**kw).eval().requires_grad_(False).to(dev)
+    ids = torch.randint(1, 30000, (B, N, T), device=dev); am = torch.ones(B, N, T, dtype=torch.long, device=dev)
+    am[0, 2, 9:] = 0; am[1, :, 11:] = 0; ids[am == 0] = 0
+    toks = TextTokens(ids, am, torch.randint(1, 40, (B, N), device=dev))
+    xy = torch.rand(B, N, 2, device=dev) * 0.6 + 0.2; wh = torch.rand(B, N, 2, device=dev) * 0.35 + 0.05
+    bbox = torch.cat([xy, wh], -1); cls = torch.randint(0, 8, (B, N), device=dev)
+    patch = torch.zeros(B, N, 1, 1, 1, device=dev).expand(B, N, 3, 8, 8)
+    pm = torch.zeros(B, N, dtype=torch.bool, device=dev); pm[1, 6:] = True
+    back = torch.randn(B, 3, bg, bg, device=dev); z = torch.randn(B, N, 4, device=dev)
+    # oracle value of loss_lm
+    sd = {k: v.detach().cpu() for k, v in G.text_decoder.state_dict().items()}
+    dec_ids = ids.reshape(B * N, T).cpu().clone(); dec_ids[:, 0] = toks.bos_token_id
+    tg = dec_ids.masked_fill(dec_ids == 0, -100); keep = ~pm.reshape(-1).cpu()
+    ref, _ = bert_ref.bert_lm_loss(sd, 4, dec_ids[keep], am.reshape(B * N, T).cpu()[keep], tg[keep])
+    with torch.no_grad():
+        lm_gather = G(z, cls, bbox, toks, patch, pm, back, None, reconst=True)[3]
+        G.static_shapes = True
+        lm_static = G(z, cls, bbox, toks, patch, pm, back, None, reconst=True)[3]
+    assert abs(lm_gather.item() - ref.item()) <= 2e-4 * abs(ref.item()), (lm_gather.item(), ref.item())
+    assert abs(lm_static.item() - ref.item()) <= 2e-4 * abs(ref.item()), (lm_static.item(), ref.item())
+    # one training iteration: decoder moves, encoder does not
+    G.train(); D.train(); D.static_shapes = True
+    pG = tl.Phase('Gmain', G, lr=1e-4); pD = tl.Phase('Dmain', D, lr=1e-4)
+    batch = dict(bbox_real=bbox, bbox_class=cls, bbox_text=toks, bbox_patch=patch, padding_mask=pm, background=back,
+                 real_c=torch.zeros(B, 0, device=dev), gen_c=torch.zeros(B, 0, device=dev))
+    enc0 = G.text_encoder.encoder.layer[0].intermediate.dense.weight.clone()
+    dec0 = {n: p.detach().clone() for n, p in G.text_decoder.named_parameters() if 'crossattention' not in n}
+    ddec0 = D.text_decoder.cls.predictions.transform.dense.weight.detach().clone()
+    loss = StyleGAN2Loss(dev, G, D)
+    tl.training_iteration(loss, [pG, pD], tl.DataParallelStep(1), batch, B, [z, z])
+    torch.cuda.synchronize()
+    assert torch.equal(G.text_encoder.encoder.layer[0].intermediate.dense.weight, enc0)
+    moved = [n for n, p in G.text_decoder.named_parameters() if n in dec0 and not torch.equal(p.detach(), dec0[n])]
+    assert len(moved) >= len(dec0) - 4, f'only {len(moved)} of {len(dec0)} decoder tensors were updated'   # key biases have zero gradient
+    assert not torch.equal(D.text_decoder.cls.predictions.transform.dense.weight.detach(), ddec0)
+    assert loss.last['loss_Ggen_text_rec'].abs().item() > 0
