@@ -39,11 +39,19 @@ def make_batch(b, bg, device, seed):
     return bt
 
 
-def to_device_batch(bt, device):
-    from layoutdetr_amd.training.networks_detr import TextFeatures
+def to_device_batch(bt, device, text_mode='features', text_tokens=40):
+    from layoutdetr_amd.training.networks_detr import TextFeatures, TextTokens
     b = bt['bbox_real'].shape[0]
+    if text_mode == 'features':
+        text = TextFeatures(bt['text_feat'].to(device), bt['text_len'].to(device))
+    else:   # synthetic tokenizer output: random word ids, ragged lengths, [PAD] = 0 behind them
+        g = torch.Generator().manual_seed(7)
+        ids = torch.randint(1000, 30000, (b, 9, text_tokens), generator=g)
+        lens = torch.randint(3, text_tokens + 1, (b, 9), generator=g)
+        am = (torch.arange(text_tokens)[None, None, :] < lens[..., None]).long()
+        text = TextTokens((ids * am).to(device), am.to(device), bt['text_len'].to(device))
     return dict(bbox_real=bt['bbox_real'].to(device), bbox_class=bt['bbox_class'].to(device),
-                bbox_text=TextFeatures(bt['text_feat'].to(device), bt['text_len'].to(device)),
+                bbox_text=text,
                 bbox_patch=torch.zeros(b, 9, 1, 1, 1, device=device).expand(b, 9, 3, 256, 256),  # shape only (0-stride view)
                 padding_mask=bt['padding_mask'].to(device), background=bt['background'].to(device),
                 real_c=torch.zeros(b, 0, device=device), gen_c=torch.zeros(b, 0, device=device))
@@ -84,6 +92,10 @@ def main():
     ap.add_argument('--bg', type=int, default=256)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
+    ap.add_argument('--text-mode', default='features', choices=['features', 'encoder', 'encoder+lm'],
+                    help="'features' (headline config: frozen-BERT CLS features are the input); 'encoder': token ids in, the frozen text encoder runs "
+                         "inside every G/D forward; 'encoder+lm': plus the trainable LM text decoder and its loss (SURVEY 8f-1)")
+    ap.add_argument('--text-tokens', type=int, default=40, help='tokens per element text (reference: padding to max_text_length)')
     ap.add_argument('--no-share-trunk', action='store_true', help="evaluate D's ResNet trunk separately for the fake and the real pass of Dmain, as the reference does")
     ap.add_argument('--share-trunk', default='phase', choices=['phase', 'iteration'], help="'iteration': one D-trunk evaluation also serves Gmain's D(fake) (D's weights do not change between the two phases)")
     args = ap.parse_args()
@@ -116,10 +128,10 @@ def main():
     torch.manual_seed(0)   # identical initial parameters on every rank (stands in for the rank-0 broadcast, training_loop.py:176-179)
     kw = dict(num_bbox_labels=8, img_channels=3, img_height=bg, img_width=bg, c_dim=0, background_size=bg, bert_f_dim=768,
               bert_num_heads=4, bert_num_encoder_layers=12, bert_num_decoder_layers=2, im_f_dim=512)
-    G = Generator(z_dim=4, f_dim=256, num_heads=4, num_layers=8, **kw).train().requires_grad_(False)
-    D = Discriminator(f_dim=256, num_heads=4, num_layers=8, **kw).train().requires_grad_(False)
+    G = Generator(z_dim=4, f_dim=256, num_heads=4, num_layers=8, text_mode=args.text_mode, **kw).train().requires_grad_(False)
+    D = Discriminator(f_dim=256, num_heads=4, num_layers=8, text_mode=args.text_mode, **kw).train().requires_grad_(False)
     G_sd_cpu = D_sd_cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.text_mode == 'features':
         G_sd_cpu = {k: v.clone() for k, v in G.state_dict().items()}
         D_sd_cpu = {k: v.clone() for k, v in D.state_dict().items()}
     G_names = {n for n, _ in G.named_parameters()}
@@ -134,7 +146,7 @@ def main():
     dp = tl.DataParallelStep(world_size=world)
 
     torch.manual_seed(0 * world + rank)   # training_loop.py:101-102 seed rule
-    batch = to_device_batch(make_batch(b_local, bg, device, 1000 + rank), device)
+    batch = to_device_batch(make_batch(b_local, bg, device, 1000 + rank), device, args.text_mode, args.text_tokens)
     n_params = (pG.fm.total, pD.fm.total)
     cur_nimg = [0]
 
@@ -146,8 +158,15 @@ def main():
 
     step = eager_step
     if not args.no_graph:
-        for _ in range(2):        # eager warm-up before capture (allocator, folded-BN / position-encoding caches)
-            eager_step()
+        # eager warm-up before capture (allocator, folded-BN / position-encoding caches) on a SIDE stream: autograd's AccumulateGrad
+        # nodes remember the stream they were first used on, and one bound to the default stream breaks a later capture
+        # (torch CUDA-graphs note); with the LM decoder many parameter gradients go through AccumulateGrad
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(2):
+                eager_step()
+        torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         graphed = tl.GraphedIteration(loss, [pG, pD], dp, batch, b_local, 4, ema=ema, batch_size=args.batch, ema_kimg=args.batch * 10 / 32)
         graphed.cur_nimg = cur_nimg[0]
@@ -245,10 +264,10 @@ def main():
                    steps=args.steps, warmup=args.warmup, ms_per_step=round(ms_per_step, 3), higher_is_better=True,
                    scaling=scaling, vs_baseline=None, dtype='f32', data='synthetic',
                    config=dict(workload=f'BASELINE configs[2] (16 samples per GPU): global batch {args.batch}, {bg}x{bg} backgrounds x 9 elements, full G+D adversarial '
-                                        'step (Gmain+Dmain fwd/bwd, grad exchange + nan_to_num, Adam, EMA), train mode (dropout 0.1); '
-                                        'hot-path-only: frozen-BERT text features are an input, LM-decoder loss excluded',
+                                        'step (Gmain+Dmain fwd/bwd, grad exchange + nan_to_num, Adam, EMA), train mode (dropout 0.1); ' +
+                                        ('hot-path-only: frozen-BERT text features are an input, LM-decoder loss excluded' if args.text_mode == 'features' else f'text path on: {args.text_mode}, {args.text_tokens} tokens per element'),
                                global_batch=args.batch, per_gpu_batch=b_local, background=bg, elements=9,
-                               parallelism=f'dp{world}', hip_graph=not args.no_graph, d_trunk_shared=False if args.no_share_trunk else args.share_trunk, params_G=n_params[0], params_D=n_params[1]),
+                               parallelism=f'dp{world}', hip_graph=not args.no_graph, text_mode=args.text_mode, text_tokens=(args.text_tokens if args.text_mode != 'features' else None), d_trunk_shared=False if args.no_share_trunk else args.share_trunk, params_G=n_params[0], params_D=n_params[1]),
                    roofline=roofline, cpu_baseline=cpu)
         print(json.dumps(out), flush=True)
     if world > 1:

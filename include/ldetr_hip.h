@@ -166,6 +166,17 @@ int ldetr_adam_step_f32(float* p, const float* g, float* m, float* v, int64_t n,
                         float neginf, void* stream);
 int ldetr_ema_lerp_f32(float* p_ema, const float* p, int64_t n, float beta, void* stream);
 
+/* Label-smoothed softmax cross entropy of the LM text decoder (CrossEntropyLoss(reduction='mean', label_smoothing) on the shifted
+ * prediction scores, training/med.py:911-916; ignore_index marks padded tokens).  fwd: one pass over logits [rows, V] (row pitch
+ * ld): row_lse[i] = logsumexp, *loss_sum += sum_i loss_i, *count += #(targets != ignore_index) (both zeroed by the caller; the mean
+ * is loss_sum / count).  bwd: dlogits[i, c] = (softmax - (1 - eps) onehot - eps / V) * (*grad_out) / (*count), zero rows for
+ * ignored targets; dlogits may alias logits. */
+int ldetr_softmax_xent_fwd_f32(const float* logits, int64_t ld, const int64_t* targets, float* row_lse, float* loss_sum, float* count,
+                               int64_t rows, int V, int64_t ignore_index, float label_smoothing, void* stream);
+int ldetr_softmax_xent_bwd_f32(const float* logits, int64_t ld, const int64_t* targets, const float* row_lse, const float* count,
+                               const float* grad_out, float* dlogits, int64_t ldd, int64_t rows, int V, int64_t ignore_index,
+                               float label_smoothing, void* stream);
+
 /* Batched linear-sum-assignment (Hungarian / shortest augmenting path) on device.
  * cost: [batch][n][n] float64 row-major; maximize != 0 negates the costs first;
  * row_ind / col_ind: [batch][n] int32 outputs with scipy's ordering (row_ind sorted ascending). n <= 16. */

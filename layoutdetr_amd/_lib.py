@@ -60,6 +60,8 @@ SIGNATURES = {
     'ldetr_adam_step_f32': [_P, _P, _P, _P, _L, _L, _F, _F, _F, _F, _I, _F, _F, _F, _F, _P],
     'ldetr_ema_lerp_f32': [_P, _P, _L, _F, _P],
     'ldetr_lsap_f64': [_P, _I, _I, _I, _P, _P, _P],
+    'ldetr_softmax_xent_fwd_f32': [_P, _L, _P, _P, _P, _P, _L, _I, _L, _F, _P],
+    'ldetr_softmax_xent_bwd_f32': [_P, _L, _P, _P, _P, _P, _P, _L, _L, _I, _L, _F, _P],
 }
 
 _lib = None
@@ -83,7 +85,7 @@ def load():
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported
         fn.restype = c_int
         fn.argtypes = argtypes
-    if lib.ldetr_abi_version() != 6:
+    if lib.ldetr_abi_version() != 7:
         raise RuntimeError('libldetr_hip.so ABI version mismatch; rebuild it')
     _lib = lib
     return lib

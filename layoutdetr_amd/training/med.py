@@ -15,6 +15,7 @@ matrices are concatenated once and cached), fused attention for head widths 32..
 projection, residual + dropout + LayerNorm in one kernel, bias + erf-GELU as one in-place streaming pass.
 Tokenisation (strings -> ids) stays on the host and outside this package: pass token ids.
 """
+import ctypes
 import math
 from types import SimpleNamespace
 
@@ -194,8 +195,8 @@ class BertModel(nn.Module):
 # (training/med.py:361), so `encoder_hidden_states` is accepted and ignored exactly as in the reference: the decoder is a causal
 # BERT LM over the text tokens (is_decoder=True -> causal + padding mask, med.py:704-739), trained with a label-smoothed (0.1)
 # next-token cross entropy (med.py:911-916).  Trainable: every op below has a backward on the HIP kernels (GEMM engine, causal
-# wide-head attention fwd/bwd, fused add+dropout+LayerNorm, erf-GELU fwd/grad); embedding lookups and the softmax cross entropy
-# over the vocabulary are torch glue.
+# wide-head attention fwd/bwd, fused add+dropout+LayerNorm, erf-GELU fwd/grad, label-smoothed softmax cross entropy over the
+# vocabulary, csrc/xent.hip); only the embedding lookups are torch glue.
 class _GeluFn(torch.autograd.Function):
     """y = gelu(h + bias) with the erf form; backward through bias_act's gradient kernel (activation 10)."""
 
@@ -220,6 +221,43 @@ class _GeluFn(torch.autograd.Function):
                                                  0.0, 1.0, -1.0, core.stream()), 'gelu bwd')
         db = core.colsum(dh.reshape(-1, C)).reshape(-1) if ctx.needs_input_grad[1] else None
         return dh, db
+
+
+class _SoftmaxXentFn(torch.autograd.Function):
+    """mean_i over targets != ignore_index of the label-smoothed cross entropy; logits [rows, V] fp32, targets [rows] int64.
+    The gradient overwrites nothing the forward needs except the logits themselves, which autograd does not reuse after this
+    node: it is written into a fresh buffer (logits may be another node's saved output)."""
+
+    @staticmethod
+    def forward(ctx, logits, targets, ignore_index, label_smoothing):
+        core.require_gpu(logits, targets)
+        logits = core.f32c(logits)
+        targets = targets.to(torch.int64).contiguous()
+        rows, V = logits.shape
+        lse = torch.empty(rows, device=logits.device, dtype=torch.float32)
+        acc = torch.zeros(2, device=logits.device, dtype=torch.float32)      # [loss_sum, count]
+        core.check(core.lib().ldetr_softmax_xent_fwd_f32(core.ptr(logits), logits.stride(0), core.ptr(targets), core.ptr(lse),
+                                                         ctypes.c_void_p(acc.data_ptr()), ctypes.c_void_p(acc.data_ptr() + 4), rows, V,
+                                                         ignore_index, label_smoothing, core.stream()), 'softmax_xent_fwd')
+        ctx.save_for_backward(logits, targets, lse, acc)
+        ctx.cfg = (ignore_index, label_smoothing)
+        return acc[0] / acc[1]
+
+    @staticmethod
+    def backward(ctx, g):
+        logits, targets, lse, acc = ctx.saved_tensors
+        ignore_index, label_smoothing = ctx.cfg
+        rows, V = logits.shape
+        g = g.to(torch.float32).contiguous()
+        dx = torch.empty_like(logits)
+        core.check(core.lib().ldetr_softmax_xent_bwd_f32(core.ptr(logits), logits.stride(0), core.ptr(targets), core.ptr(lse),
+                                                         ctypes.c_void_p(acc.data_ptr() + 4), core.ptr(g), core.ptr(dx), dx.stride(0), rows, V,
+                                                         ignore_index, label_smoothing, core.stream()), 'softmax_xent_bwd')
+        return dx, None, None, None
+
+
+def softmax_cross_entropy(logits, targets, ignore_index=-100, label_smoothing=0.0):
+    return _SoftmaxXentFn.apply(logits, targets, ignore_index, label_smoothing)
 
 
 def _layer_train(layer, x2, B, T, kpm, causal):
@@ -298,7 +336,7 @@ class BertLMHeadModel(nn.Module):
         loss = None
         if labels is not None:
             tgt = labels[:, 1:].reshape(-1)
-            loss = F.cross_entropy(logits, tgt, ignore_index=-100, label_smoothing=0.1, reduction=reduction)
-            if reduction == 'none':
-                loss = loss.view(B, -1).sum(1)
+            if reduction != 'mean':
+                raise NotImplementedError("the hot path uses reduction='mean' (training/med.py:886 default)")
+            loss = softmax_cross_entropy(logits, tgt, ignore_index=-100, label_smoothing=0.1)
         return SimpleNamespace(loss=loss, logits=logits.reshape(B, T - 1, -1)) if return_dict else (loss, logits)

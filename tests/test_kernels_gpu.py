@@ -566,3 +566,22 @@ def test_attention_wide_heads_and_causal(dev, B, H, L, dh, causal):
     out.backward(g.to(dev))
     assert_close(out, ref.detach(), 1e-5, 'out')
     assert_close(qg.grad, qr.grad, 2e-5, 'dqkv')
+
+
+@pytest.mark.parametrize('rows,V,eps', [(37, 30524, 0.1), (64, 1000, 0.0), (5, 70, 0.1), (300, 4098, 0.2)])
+def test_softmax_cross_entropy_label_smoothing(dev, rows, V, eps):
+    """Fused label-smoothed softmax cross entropy (LM decoder loss) vs F.cross_entropy: value and gradient, ignored rows,
+    a vocabulary that is not a multiple of 4, an upstream gradient != 1, and the all-ignored corner."""
+    from layoutdetr_amd.training.med import softmax_cross_entropy
+    torch.manual_seed(31)
+    x = torch.randn(rows, V) * 3; t = torch.randint(0, V, (rows,)); t[::4] = -100
+    xr = x.clone().requires_grad_(True)
+    ref = F.cross_entropy(xr, t, ignore_index=-100, label_smoothing=eps); (ref * 2.5).backward()
+    if V % 4:
+        xg = torch.zeros(rows, (V + 3) // 4 * 4, device=dev)[:, :V]; xg.copy_(x.to(dev)); xg.requires_grad_(True)   # 16-byte aligned row pitch
+    else:
+        xg = x.to(dev).requires_grad_(True)
+    out = softmax_cross_entropy(xg, t.to(dev), -100, eps); (out * 2.5).backward()
+    assert abs(out.item() - ref.item()) <= 2e-6 * abs(ref.item()) + 1e-6
+    assert_close(xg.grad, xr.grad, 2e-5, 'dlogits')
+    assert float(xg.grad[::4].abs().max()) == 0.0
