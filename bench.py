@@ -168,7 +168,8 @@ def main():
                 eager_step()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
-        graphed = tl.GraphedIteration(loss, [pG, pD], dp, batch, b_local, 4, ema=ema, batch_size=args.batch, ema_kimg=args.batch * 10 / 32)
+        graphed = tl.GraphedIteration(loss, [pG, pD], dp, batch, b_local, 4, ema=ema, batch_size=args.batch, ema_kimg=args.batch * 10 / 32,
+                                      capture_stream=side)
         graphed.cur_nimg = cur_nimg[0]
         step = graphed.run
 

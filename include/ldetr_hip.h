@@ -39,7 +39,8 @@ int ldetr_abi_version(void);
 
 /* Scratch memory for the contraction engine's in-kernel split-K reduction on the calling thread's current device.
  * `ptr`: zero-filled, 16-byte aligned device memory the caller keeps alive and uses from one stream at a time
- * (the first 256 KiB hold per-tile arrival counters, the rest partial tiles); (NULL, 0) unregisters it and the
+ * (the first 1 MiB holds per-tile arrival counters, the rest partial tiles; both are handed out as rings, a fresh
+ * slice per launch, so that independent branches of a captured graph do not share scratch); (NULL, 0) unregisters it and the
  * engine falls back to fp32 atomics into a zero-filled C plus a second epilogue launch.  No reference counterpart:
  * the reference leaves split-K decisions to cuBLAS/cuDNN workspaces (torch.backends.cudnn.benchmark, train.py:330). */
 int ldetr_set_workspace(void* ptr, int64_t bytes);

@@ -1019,11 +1019,15 @@ constexpr long SMALL_GEMM_MNK = 1l << 30;
 #endif
 
 // Caller-provided scratch for the split-K fix-up (ldetr_set_workspace): WS_COUNTERS ints of arrival counters, then partial tiles.
-constexpr long WS_COUNTERS = 65536;
-struct Workspace { void* ptr; size_t bytes; };
-static Workspace g_workspace[64];
-static const Workspace& workspace_for_current_device() {
-    static const Workspace none = {nullptr, 0};
+// Both areas are handed out as RINGS, one fresh slice per launch: launches of one stream are ordered anyway, but a captured
+// hipGraph may run independent branches concurrently (autograd hops streams for AccumulateGrad nodes), and two split-K
+// kernels sharing one counter / partial area corrupted each other (seen as a memory fault on replay with the LM decoder).
+// Counters are zero at rest (the last-arriving block re-arms its own), so a counter slice can be reused without clearing;
+// partial tiles need no clearing at all.  A launch that needs more than the whole ring falls back to fp32 atomics.
+constexpr long WS_COUNTERS = 262144;
+struct Workspace { void* ptr; size_t bytes; size_t counter_cursor; size_t partial_cursor; };
+static Workspace& workspace_for_current_device() {
+    static Workspace none = {nullptr, 0, 0, 0};
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return none;
     return g_workspace[dev];
@@ -1076,12 +1080,18 @@ static int launch_gemm(GemmParams& p, int Mmax, long out_rows, int zbase, bool a
     bool fixup = false;
     if (split && !(caller_zeroed && epilogue_is_linear(p.ep)) && !(p.ep.accumulate && epilogue_is_linear(p.ep))) {
         // in-kernel fix-up when the caller registered a workspace that can hold this launch's partial tiles
-        const Workspace& w = workspace_for_current_device();
+        Workspace& w = workspace_for_current_device();
         const int bm = (use128 || use12864) ? 128 : 64, bn = use128 ? 128 : 64;
         const long tiles = (long)cdiv(p.N, bn) * cdiv(Mmax, bm) * zbase;
-        if (w.ptr && tiles <= WS_COUNTERS && (size_t)tiles * p.splitk * bm * bn * sizeof(float) + WS_COUNTERS * sizeof(int) <= w.bytes) {
-            p.ws_count = reinterpret_cast<int*>(w.ptr);
-            p.ws = reinterpret_cast<float*>(reinterpret_cast<char*>(w.ptr) + WS_COUNTERS * sizeof(int));
+        const size_t need = ((size_t)tiles * p.splitk * bm * bn * sizeof(float) + 255) & ~(size_t)255;
+        const size_t pbytes = w.bytes > WS_COUNTERS * sizeof(int) ? w.bytes - WS_COUNTERS * sizeof(int) : 0;
+        if (w.ptr && tiles <= WS_COUNTERS && need <= pbytes) {
+            if (w.counter_cursor + tiles > (size_t)WS_COUNTERS) w.counter_cursor = 0;
+            if (w.partial_cursor + need > pbytes) w.partial_cursor = 0;
+            p.ws_count = reinterpret_cast<int*>(w.ptr) + w.counter_cursor;
+            p.ws = reinterpret_cast<float*>(reinterpret_cast<char*>(w.ptr) + WS_COUNTERS * sizeof(int) + w.partial_cursor);
+            w.counter_cursor += tiles;
+            w.partial_cursor += need;
             fixup = true;
         }
     }
@@ -1178,6 +1188,7 @@ extern "C" int ldetr_set_workspace(void* ptr, int64_t bytes) {
     LDETR_CHECK(!ptr || (((uintptr_t)ptr) & 15) == 0, "set_workspace: pointer must be 16-byte aligned");
     LDETR_CHECK(!ptr || bytes > (int64_t)(WS_COUNTERS * sizeof(int)), "set_workspace: too small");
     g_workspace[dev].ptr = ptr; g_workspace[dev].bytes = ptr ? (size_t)bytes : 0;
+    g_workspace[dev].counter_cursor = 0; g_workspace[dev].partial_cursor = 0;
     return LDETR_OK;
 }
 

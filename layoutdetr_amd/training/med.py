@@ -231,7 +231,8 @@ class _SoftmaxXentFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, logits, targets, ignore_index, label_smoothing):
         core.require_gpu(logits, targets)
-        logits = core.f32c(logits)
+        if logits.dtype != torch.float32 or logits.stride(1) != 1 or logits.stride(0) % 4 != 0:
+            logits = core.f32c(logits)          # (a padded row pitch is kept: rows must start 16-byte aligned)
         targets = targets.to(torch.int64).contiguous()
         rows, V = logits.shape
         lse = torch.empty(rows, device=logits.device, dtype=torch.float32)

@@ -200,7 +200,11 @@ class GraphedIteration(object):
     The gradient exchange, Adam and EMA stay outside the graphs (RCCL collectives and host-side step counters).
     """
 
-    def __init__(self, loss, phases, dp, batch, batch_gpu, z_dim, ema=None, batch_size=None, ema_kimg=None):
+    def __init__(self, loss, phases, dp, batch, batch_gpu, z_dim, ema=None, batch_size=None, ema_kimg=None, capture_stream=None):
+        # capture_stream: the side stream the eager warm-up iterations ran on.  Autograd's AccumulateGrad nodes remember the stream of
+        # their first use; capturing on that same stream keeps the whole backward on ONE stream (a mismatch makes the engine hop
+        # streams inside the capture, and the private-pool allocator then recycles blocks across branches: corrupted replays)
+        self.capture_stream = capture_stream
         self.loss, self.phases, self.dp, self.batch, self.batch_gpu = loss, phases, dp, batch, batch_gpu
         self.ema, self.batch_size, self.ema_kimg = ema, batch_size, ema_kimg
         self.cur_nimg = 0
@@ -214,7 +218,7 @@ class GraphedIteration(object):
             # the Dmain graph (captured below, replayed after it) runs the trunk's backward
             pool = torch.cuda.graph_pool_handle()
             self.pre_graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.pre_graph, pool=pool):
+            with torch.cuda.graph(self.pre_graph, pool=pool, stream=self.capture_stream):
                 for s in range(0, b, batch_gpu):
                     loss.precompute_D_trunk(batch['background'][s:s + batch_gpu])
         for phase in phases:
@@ -225,7 +229,7 @@ class GraphedIteration(object):
             phase.module.requires_grad_(True)
             phase.module.text_encoder.requires_grad_(False)
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, pool=pool):
+            with torch.cuda.graph(g, pool=pool, stream=self.capture_stream):
                 core.reseed(dev)
                 phase.fm.gflat.zero_()
                 gen_z = torch.randn(b, batch['bbox_class'].shape[1], z_dim, device=dev)

@@ -222,7 +222,7 @@ def test_gemm_splitk_fixup_and_atomic_paths(dev, M, N, K, sk):
     assert torch.equal(c1, c2), 'fix-up path is not deterministic / counters not re-armed'
     ws = core._workspace[torch.cuda.current_device()]
     torch.cuda.synchronize()
-    assert int(ws[:65536].view(torch.int32).abs().sum().item()) == 0, 'arrival counters left non-zero'
+    assert int(ws[:262144].view(torch.int32).abs().sum().item()) == 0, 'arrival counters left non-zero'
     lib = core.lib()
     try:
         core.check(lib.ldetr_set_workspace(None, 0), 'unregister')

@@ -44,7 +44,7 @@ with torch.cuda.stream(side):
     for _ in range(2):
         tl.training_iteration(loss, phases, dp, batch, B, [torch.randn(B, 9, 4, device=dev) for _ in phases])
 torch.cuda.current_stream().wait_stream(side); torch.cuda.synchronize(); print('eager ok', flush=True)
-gi = tl.GraphedIteration(loss, phases, dp, batch, B, 4)
+gi = tl.GraphedIteration(loss, phases, dp, batch, B, 4, capture_stream=side)
 torch.cuda.synchronize(); print('captured', flush=True)
 for i in range(3):
     gi.run(); torch.cuda.synchronize(); print('replay', i, flush=True)
