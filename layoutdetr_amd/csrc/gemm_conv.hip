@@ -1026,6 +1026,7 @@ constexpr long SMALL_GEMM_MNK = 1l << 30;
 // partial tiles need no clearing at all.  A launch that needs more than the whole ring falls back to fp32 atomics.
 constexpr long WS_COUNTERS = 262144;
 struct Workspace { void* ptr; size_t bytes; size_t counter_cursor; size_t partial_cursor; };
+static Workspace g_workspace[64];
 static Workspace& workspace_for_current_device() {
     static Workspace none = {nullptr, 0, 0, 0};
     int dev = 0;
