@@ -538,7 +538,8 @@ __global__ __launch_bounds__(NWV * 64) void gemm_f32_kernel(GemmParams p) {
         if (tid == 0) {
             int old = atomicAdd(p.ws_count + tile, 1);
             s_last = (old == p.splitk - 1);
-            if (s_last) p.ws_count[tile] = 0;   // re-armed for the next launch (stream order makes it visible)
+            // re-armed for the next launch; agent-scope store like the atomics that read it (a plain store would sit in this XCD's L2)
+            if (s_last) __hip_atomic_store(p.ws_count + tile, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         __syncthreads();
         if (!s_last) return;

@@ -231,7 +231,7 @@ class _SoftmaxXentFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, logits, targets, ignore_index, label_smoothing):
         core.require_gpu(logits, targets)
-        if logits.dtype != torch.float32 or logits.stride(1) != 1 or logits.stride(0) % 4 != 0:
+        if logits.dtype != torch.float32 or logits.stride(1) != 1 or logits.stride(0) % 4 != 0 or logits.data_ptr() % 16 != 0:
             logits = core.f32c(logits)          # (a padded row pitch is kept: rows must start 16-byte aligned)
         targets = targets.to(torch.int64).contiguous()
         rows, V = logits.shape
@@ -250,7 +250,7 @@ class _SoftmaxXentFn(torch.autograd.Function):
         ignore_index, label_smoothing = ctx.cfg
         rows, V = logits.shape
         g = g.to(torch.float32).contiguous()
-        dx = torch.empty_like(logits)
+        dx = torch.empty((rows, logits.stride(0)), device=logits.device, dtype=torch.float32)[:, :V]   # same (padded) row pitch
         core.check(core.lib().ldetr_softmax_xent_bwd_f32(core.ptr(logits), logits.stride(0), core.ptr(targets), core.ptr(lse),
                                                          ctypes.c_void_p(acc.data_ptr() + 4), core.ptr(g), core.ptr(dx), dx.stride(0), rows, V,
                                                          ignore_index, label_smoothing, core.stream()), 'softmax_xent_bwd')
