@@ -49,6 +49,15 @@ _workspace = {}
 WORKSPACE_BYTES = 256 << 20
 
 
+def disable_splitk_workspace():
+    """Unregister the in-kernel split-K scratch on the current device: the engine then reduces split-K with fp32 atomics + an
+    epilogue pass (non-deterministic summation order, otherwise equivalent)."""
+    l = _lib.load()
+    dev = torch.cuda.current_device()
+    _workspace[dev] = None
+    check(l.ldetr_set_workspace(None, 0), 'set_workspace')
+
+
 def lib():
     l = _lib.load()
     if torch.cuda.is_available():
