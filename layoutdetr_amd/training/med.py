@@ -232,7 +232,10 @@ class _SoftmaxXentFn(torch.autograd.Function):
     def forward(ctx, logits, targets, ignore_index, label_smoothing):
         core.require_gpu(logits, targets)
         if logits.dtype != torch.float32 or logits.stride(1) != 1 or logits.stride(0) % 4 != 0 or logits.data_ptr() % 16 != 0:
-            logits = core.f32c(logits)          # (a padded row pitch is kept: rows must start 16-byte aligned)
+            # rows must start 16-byte aligned: copy into a padded pitch (never taken for the 30524-entry vocabulary)
+            buf = torch.empty((logits.shape[0], (logits.shape[1] + 3) // 4 * 4), device=logits.device, dtype=torch.float32)
+            buf[:, :logits.shape[1]] = logits
+            logits = buf[:, :logits.shape[1]]
         targets = targets.to(torch.int64).contiguous()
         rows, V = logits.shape
         lse = torch.empty(rows, device=logits.device, dtype=torch.float32)
