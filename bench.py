@@ -124,11 +124,6 @@ def main():
     from layoutdetr_amd.training.loss import StyleGAN2Loss
     from layoutdetr_amd.training.networks_detr import Discriminator, Generator
 
-    if args.text_mode == 'encoder+lm' and not args.no_graph:
-        # KNOWN ISSUE: with the LM decoder in the Dmain graph at 16 x 9 texts x 40 tokens, hipGraph replays fault
-        # (memory aperture violation on the 2nd replay) when split-K goes through the in-kernel fix-up scratch; eager launches and
-        # graph replays on the fp32-atomic split-K path are clean.  Until that is understood this mode uses the atomic path.
-        core.disable_splitk_workspace()
     bg, b_local = args.bg, args.batch // world
     torch.manual_seed(0)   # identical initial parameters on every rank (stands in for the rank-0 broadcast, training_loop.py:176-179)
     kw = dict(num_bbox_labels=8, img_channels=3, img_height=bg, img_width=bg, c_dim=0, background_size=bg, bert_f_dim=768,

@@ -178,6 +178,15 @@ int ldetr_softmax_xent_bwd_f32(const float* logits, int64_t ld, const int64_t* t
                                const float* grad_out, float* dlogits, int64_t ldd, int64_t rows, int V, int64_t ignore_index,
                                float label_smoothing, void* stream);
 
+/* Token embedding of the LM text decoder (nn.Embedding(vocab, hidden, padding_idx=pad) + the position rows added right after it,
+ * training/med.py:60-61,88-94).  fwd: out[i, :] = weight[ids[i], :] (+ pos[i % T, :] when pos != NULL); ids outside [0, V) give
+ * a zero row.  bwd: dweight[ids[i], :] += dy[i, :] (fp32 atomics into a caller-zeroed or accumulating buffer); rows with
+ * ids[i] == padding_idx or outside [0, V) contribute nothing.  d % 4 == 0 and 16-byte aligned rows for fwd. */
+int ldetr_embedding_fwd_f32(const float* weight, const float* pos, const int64_t* ids, float* out, int64_t n, int d, int V, int T,
+                            void* stream);
+int ldetr_embedding_bwd_f32(const float* dy, const int64_t* ids, float* dweight, int64_t n, int d, int V, int64_t padding_idx,
+                            void* stream);
+
 /* Batched linear-sum-assignment (Hungarian / shortest augmenting path) on device.
  * cost: [batch][n][n] float64 row-major; maximize != 0 negates the costs first;
  * row_ind / col_ind: [batch][n] int32 outputs with scipy's ordering (row_ind sorted ascending). n <= 16. */

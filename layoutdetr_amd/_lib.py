@@ -62,6 +62,8 @@ SIGNATURES = {
     'ldetr_lsap_f64': [_P, _I, _I, _I, _P, _P, _P],
     'ldetr_softmax_xent_fwd_f32': [_P, _L, _P, _P, _P, _P, _L, _I, _L, _F, _P],
     'ldetr_softmax_xent_bwd_f32': [_P, _L, _P, _P, _P, _P, _P, _L, _L, _I, _L, _F, _P],
+    'ldetr_embedding_fwd_f32': [_P, _P, _P, _P, _L, _I, _I, _I, _P],
+    'ldetr_embedding_bwd_f32': [_P, _P, _P, _L, _I, _I, _L, _P],
 }
 
 _lib = None
@@ -85,7 +87,7 @@ def load():
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported
         fn.restype = c_int
         fn.argtypes = argtypes
-    if lib.ldetr_abi_version() != 7:
+    if lib.ldetr_abi_version() != 8:
         raise RuntimeError('libldetr_hip.so ABI version mismatch; rebuild it')
     _lib = lib
     return lib

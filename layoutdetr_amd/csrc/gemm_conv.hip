@@ -1035,6 +1035,24 @@ static Workspace& workspace_for_current_device() {
     return g_workspace[dev];
 }
 
+// Zero-fill of a pitched fp32 matrix for the atomic split-K path.  A kernel rather than hipMemset2DAsync: memset nodes captured into
+// a hipGraph were observed to replay out of order with their neighbouring kernel nodes on ROCm 7.2 (garbage gradients on replay).
+__global__ void __launch_bounds__(256) zero_fill_kernel(float* __restrict__ dst, long pitch, long width, long rows) {
+    const long total = rows * width;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const long r = i / width;
+        dst[r * pitch + (i - r * width)] = 0.f;
+    }
+}
+static int zero_fill(float* dst, long pitch, long width, long rows, hipStream_t st) {
+    if (rows <= 0 || width <= 0) return LDETR_OK;
+    if (pitch == width) { width *= rows; pitch = width; rows = 1; }   // dense: one long row
+    long total = rows * width;
+    int g = (int)((total + 255) / 256); if (g > 2048) g = 2048;
+    hipLaunchKernelGGL(zero_fill_kernel, g, 256, 0, st, dst, pitch, width, rows);
+    return check_launch("zero_fill");
+}
+
 template <int BM, int BN, int BKT, int AMODE, int BMODE, int NWV = 4>
 static int launch_tile(const GemmParams& p, dim3 grid, hipStream_t st) {
     constexpr size_t lds = (size_t)2 * BKT * ((BM + 2) + (BN + 2)) * sizeof(float);
@@ -1099,10 +1117,7 @@ static int launch_gemm(GemmParams& p, int Mmax, long out_rows, int zbase, bool a
     }
     if (split && !fixup) {
         if (!p.ep.accumulate && !caller_zeroed) {
-            if (hipMemset2DAsync(p.C, (size_t)p.ldc * sizeof(float), 0, (size_t)p.N * sizeof(float), (size_t)out_rows, st) != hipSuccess) {
-                set_error("gemm: memset of the split-K output failed");
-                return LDETR_ERR_LAUNCH;
-            }
+            if (int zrc = zero_fill(p.C, p.ldc, p.N, out_rows, st)) return zrc;
         }
     }
     {
@@ -1332,7 +1347,7 @@ extern "C" int ldetr_conv2d_bwd_weight_f32(const float* x, const ldetr_tensor4* 
     fill_epilogue(p.ep, nullptr);
     p.splitk = splitk; p.pstep = 1; p.nsamp = xt->N; p.pix_per_sample = 0;
     long wsz = (long)Cout * KH * KW * Cin;
-    if (!accumulate && hipMemsetAsync(dw, 0, wsz * sizeof(float), st) != hipSuccess) { set_error("conv2d_bwd_weight: memset failed"); return LDETR_ERR_LAUNCH; }
+    if (!accumulate) { if (int zrc = zero_fill(dw, wsz, wsz, 1, st)) return zrc; }
     if (splitk == 1 && accumulate) p.ep.accumulate = 1;
     if (gather) {
         // 3-channel (or strided-channel) input, e.g. the ResNet stem on an NCHW image: a single GEMM with
@@ -1453,7 +1468,7 @@ extern "C" int ldetr_conv_transpose2d_bwd_weight_f32(const float* x, const ldetr
     fill_epilogue(p.ep, nullptr);
     p.splitk = splitk; p.pstep = 1; p.nsamp = xt->N; p.pix_per_sample = 0;
     long wsz = (long)Cout * KH * KW * Cin;
-    if (!accumulate && hipMemsetAsync(dw, 0, wsz * sizeof(float), st) != hipSuccess) { set_error("conv_transpose2d_bwd_weight: memset failed"); return LDETR_ERR_LAUNCH; }
+    if (!accumulate) { if (int zrc = zero_fill(dw, wsz, wsz, 1, st)) return zrc; }
     if (splitk == 1 && accumulate) p.ep.accumulate = 1;
     if ((dy_scale || x_scale) && (!dy_scale || dy_scale_ld != 0) && (!x_scale || x_scale_ld != 0) && xt->H * xt->W >= 64) {
         set_sample_slices(p, xt->N, xt->H * xt->W, splitk, dy_scale, dy_scale_ld, x_scale, x_scale_ld);   // scales out of the k-loop

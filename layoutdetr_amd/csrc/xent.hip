@@ -32,7 +32,7 @@ __global__ __launch_bounds__(256) void xent_fwd_kernel(XentParams p) {
     const long row = blockIdx.x;
     const float* x = p.x + row * p.ld;
     const long long t = p.tgt[row];
-    const bool valid = t != p.ignore_index;
+    const bool valid = t != p.ignore_index && t >= 0 && t < p.V;   // out-of-range labels never become addresses
     float m = -INFINITY, s = 0.f, sx = 0.f;
     if (valid) {
         const int V4 = p.V >> 2;
@@ -83,7 +83,7 @@ __global__ __launch_bounds__(256) void xent_bwd_kernel(XentParams p) {
     const float* x = p.x + row * p.ld;
     float* dx = p.dx + row * p.ldd;
     const long long t = p.tgt[row];
-    const bool valid = t != p.ignore_index;
+    const bool valid = t != p.ignore_index && t >= 0 && t < p.V;   // out-of-range labels never become addresses
     const float cnt = *p.count;
     const float g = (valid && cnt > 0.f) ? (*p.gscale) / cnt : 0.f;
     const float lse = p.row_lse[row];
@@ -103,6 +103,42 @@ __global__ __launch_bounds__(256) void xent_bwd_kernel(XentParams p) {
     }
     for (int i = (V4 << 2) + threadIdx.x; i < p.V; i += 256)
         dx[i] = valid ? (__expf(x[i] - lse) - sm - (i == t ? 1.f - p.eps : 0.f)) * g : 0.f;
+}
+
+
+// Token embedding of the LM decoder (nn.Embedding(vocab, hidden, padding_idx), training/med.py:60,88 of the reference).
+// fwd: out[i, :] = W[ids[i], :] (+ pos[i % T, :] when pos is given: the position rows the BertEmbeddings forward adds right after).
+// bwd: dW[ids[i], :] += dy[i, :] with fp32 atomics, rows whose id is padding_idx or out of range are skipped.  (aten's
+// embedding_dense_backward sorts the ids with rocPRIM above 3072 tokens; that sort did not survive hipGraph replay on ROCm 7.2.)
+struct EmbParams {
+    const float* W; const float* pos; const long long* ids; float* out; const float* dy; float* dW;
+    long n; int d; int V; int T; long long padding_idx;
+};
+
+__global__ __launch_bounds__(256) void embedding_fwd_kernel(EmbParams p) {
+    const int d4 = p.d >> 2;
+    const long total = p.n * d4;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const long row = i / d4; const int c = (int)(i - row * d4);
+        const long long id = p.ids[row];
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (id >= 0 && id < p.V) v = reinterpret_cast<const float4*>(p.W + id * p.d)[c];
+        if (p.pos) {
+            const float4 q = reinterpret_cast<const float4*>(p.pos + (row % p.T) * p.d)[c];
+            v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w;
+        }
+        reinterpret_cast<float4*>(p.out + row * p.d)[c] = v;
+    }
+}
+
+__global__ __launch_bounds__(256) void embedding_bwd_kernel(EmbParams p) {
+    const long total = p.n * p.d;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const long row = i / p.d; const int c = (int)(i - row * p.d);
+        const long long id = p.ids[row];
+        if (id < 0 || id >= p.V || id == p.padding_idx) continue;
+        atomicAdd(p.dW + id * p.d + c, p.dy[i]);
+    }
 }
 
 }  // namespace ldetr
@@ -141,4 +177,29 @@ extern "C" int ldetr_softmax_xent_bwd_f32(const float* logits, int64_t ld, const
     if (rows == 0) return LDETR_OK;
     hipLaunchKernelGGL(xent_bwd_kernel, dim3((unsigned)rows), 256, 0, (hipStream_t)stream, p);
     return check_launch("softmax_xent_bwd");
+}
+
+extern "C" int ldetr_embedding_fwd_f32(const float* weight, const float* pos, const int64_t* ids, float* out, int64_t n, int d, int V,
+                                       int T, void* stream) {
+    LDETR_CHECK(weight && ids && out, "embedding_fwd: null pointer");
+    LDETR_CHECK(n >= 0 && d > 0 && (d % 4) == 0 && V > 0 && (!pos || T > 0), "embedding_fwd: bad shape (hidden size must be a multiple of 4)");
+    LDETR_CHECK(((((uintptr_t)weight) | ((uintptr_t)out) | ((uintptr_t)pos)) & 15) == 0, "embedding_fwd: rows must be 16-byte aligned");
+    if (n == 0) return LDETR_OK;
+    EmbParams p; memset(&p, 0, sizeof(p));
+    p.W = weight; p.pos = pos; p.ids = (const long long*)ids; p.out = out; p.n = n; p.d = d; p.V = V; p.T = T > 0 ? T : 1;
+    long blocks = (n * (d / 4) + 255) / 256; if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(embedding_fwd_kernel, dim3((unsigned)blocks), 256, 0, (hipStream_t)stream, p);
+    return check_launch("embedding_fwd");
+}
+
+extern "C" int ldetr_embedding_bwd_f32(const float* dy, const int64_t* ids, float* dweight, int64_t n, int d, int V, int64_t padding_idx,
+                                       void* stream) {
+    LDETR_CHECK(dy && ids && dweight, "embedding_bwd: null pointer");
+    LDETR_CHECK(n >= 0 && d > 0 && V > 0, "embedding_bwd: bad shape");
+    if (n == 0) return LDETR_OK;
+    EmbParams p; memset(&p, 0, sizeof(p));
+    p.dy = dy; p.ids = (const long long*)ids; p.dW = dweight; p.n = n; p.d = d; p.V = V; p.padding_idx = padding_idx;
+    long blocks = (n * (long)d + 255) / 256; if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(embedding_bwd_kernel, dim3((unsigned)blocks), 256, 0, (hipStream_t)stream, p);
+    return check_launch("embedding_bwd");
 }

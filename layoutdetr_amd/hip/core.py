@@ -46,7 +46,7 @@ def engine_call(tag, flops, thunk):
 
 
 _workspace = {}
-WORKSPACE_BYTES = 256 << 20
+WORKSPACE_BYTES = int(os.environ.get('LDETR_WORKSPACE_MIB', '256')) << 20   # split-K scratch per device
 
 
 def disable_splitk_workspace():
@@ -56,6 +56,12 @@ def disable_splitk_workspace():
     dev = torch.cuda.current_device()
     _workspace[dev] = None
     check(l.ldetr_set_workspace(None, 0), 'set_workspace')
+
+
+def enable_splitk_workspace():
+    """(Re-)register the in-kernel split-K scratch on the current device (the default state)."""
+    _workspace.pop(torch.cuda.current_device(), None)
+    lib()
 
 
 def lib():

@@ -46,6 +46,50 @@ class BertConfig(SimpleNamespace):
             return cls(**json.load(f))
 
 
+class _TokenEmbeddingFn(torch.autograd.Function):
+    """word_embeddings(input_ids) + position_embeddings(position_ids[:, :T]) (training/med.py:88-94) as one gather kernel; the
+    backward scatters with fp32 atomics straight into the (tied) vocabulary gradient instead of aten's sort-based
+    embedding_dense_backward (whose rocPRIM sort produced wild indices under hipGraph replay once B*T exceeded 3072 tokens)."""
+
+    @staticmethod
+    def forward(ctx, input_ids, word, pos, padding_idx):
+        core.require_gpu(input_ids, word, pos)
+        B, T = input_ids.shape
+        V, d = word.shape
+        ids = input_ids.to(torch.int64).contiguous()
+        wd, pd = word.detach().contiguous(), pos.detach().contiguous()
+        out = torch.empty((B * T, d), device=word.device, dtype=torch.float32)
+        core.check(core.lib().ldetr_embedding_fwd_f32(core.ptr(wd), core.ptr(pd), core.ptr(ids), core.ptr(out), B * T, d, V, T,
+                                                      core.stream()), 'embedding_fwd')
+        ctx.save_for_backward(ids)
+        ctx.params = (word, pos)
+        ctx.cfg = (B, T, V, d, -1 if padding_idx is None else int(padding_idx), pos.shape[0])
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        ids, = ctx.saved_tensors
+        word, pos = ctx.params
+        B, T, V, d, padding_idx, P = ctx.cfg
+        dy = dy.to(torch.float32).contiguous()
+        gw = gp = None
+        if ctx.needs_input_grad[1]:
+            acc = core.flat_grad(word)
+            tgt = acc if acc is not None else torch.zeros((V, d), device=dy.device, dtype=torch.float32)
+            core.check(core.lib().ldetr_embedding_bwd_f32(core.ptr(dy), core.ptr(ids), core.ptr(tgt), B * T, d, V, padding_idx,
+                                                          core.stream()), 'embedding_bwd')
+            gw = None if acc is not None else tgt
+        if ctx.needs_input_grad[2]:
+            gp = torch.zeros((P, d), device=dy.device, dtype=torch.float32)
+            gp[:T] = dy.view(B, T, d).sum(0)
+        return None, gw, gp, None
+
+
+def token_embedding(emb, input_ids):
+    """[B*T, hidden] rows of BertEmbeddings before its LayerNorm."""
+    return _TokenEmbeddingFn.apply(input_ids, emb.word_embeddings.weight, emb.position_embeddings.weight, emb.word_embeddings.padding_idx)
+
+
 class BertEmbeddings(nn.Module):
     def __init__(self, config):
         super().__init__()
@@ -56,9 +100,7 @@ class BertEmbeddings(nn.Module):
         self.register_buffer('position_ids', torch.arange(config.max_position_embeddings).expand((1, -1)))
 
     def forward(self, input_ids):
-        T = input_ids.shape[1]
-        x = self.word_embeddings(input_ids) + self.position_embeddings(self.position_ids[:, :T])
-        x = add_layernorm(x.reshape(-1, x.shape[-1]), None, self.LayerNorm.weight, self.LayerNorm.bias, self.LayerNorm.eps)
+        x = add_layernorm(token_embedding(self, input_ids), None, self.LayerNorm.weight, self.LayerNorm.bias, self.LayerNorm.eps)
         return self.dropout(x)   # [B*T, hidden]
 
 
@@ -323,8 +365,7 @@ class BertLMHeadModel(nn.Module):
         cfg = self.config
         B, T = input_ids.shape
         emb = self.bert.embeddings
-        x = emb.word_embeddings(input_ids) + emb.position_embeddings(emb.position_ids[:, :T])
-        x2 = add_layernorm(x.reshape(-1, cfg.hidden_size), None, emb.LayerNorm.weight, emb.LayerNorm.bias, emb.LayerNorm.eps)
+        x2 = add_layernorm(token_embedding(emb, input_ids), None, emb.LayerNorm.weight, emb.LayerNorm.bias, emb.LayerNorm.eps)
         x2 = emb.dropout(x2)
         kpm = None if attention_mask is None else (attention_mask == 0).to(torch.uint8).contiguous()
         for layer in self.bert.encoder.layer:

@@ -585,3 +585,25 @@ def test_softmax_cross_entropy_label_smoothing(dev, rows, V, eps):
     assert abs(out.item() - ref.item()) <= 2e-6 * abs(ref.item()) + 1e-6
     assert_close(xg.grad, xr.grad, 2e-5, 'dlogits')
     assert float(xg.grad[::4].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize('B,T,V,d', [(144, 40, 30524, 768), (3, 7, 50, 64), (2, 512, 1000, 128)])
+def test_token_embedding_gather_and_scatter(dev, B, T, V, d):
+    """word + position embedding of the text models vs nn.Embedding: the gather is bit-exact, the atomic scatter of the backward
+    matches aten's embedding_dense_backward (padding_idx rows get no gradient); 144 x 40 tokens is the B=16 hot-path shape, the
+    size class where aten switches to its sort-based backward."""
+    import torch.nn as nn
+    from layoutdetr_amd.training.med import _TokenEmbeddingFn
+    torch.manual_seed(5)
+    word = nn.Embedding(V, d, padding_idx=0); pos = nn.Embedding(max(T, 512), d)
+    ids = torch.randint(0, V, (B, T)); ids[:, -3:] = 0; ids[0, 0] = V - 1
+    ref = word(ids) + pos(torch.arange(T)[None])
+    g = torch.randn(B, T, d)
+    ref.backward(g)
+    wg = word.weight.detach().clone().to(dev).requires_grad_(True); pg = pos.weight.detach().clone().to(dev).requires_grad_(True)
+    out = _TokenEmbeddingFn.apply(ids.to(dev), wg, pg, 0)
+    assert torch.equal(out.cpu(), ref.detach().reshape(B * T, d))
+    out.backward(g.reshape(B * T, d).to(dev))
+    assert_close(wg.grad, word.weight.grad, 2e-5, 'dword')
+    assert_close(pg.grad, pos.weight.grad, 2e-5, 'dpos')
+    assert float(wg.grad[0].abs().max()) == 0.0

@@ -8,7 +8,7 @@ from layoutdetr_amd.training.networks_detr import Discriminator, Generator
 dev = torch.device('cuda:0'); B = int(sys.argv[2]); bg = 256; which = sys.argv[1]; T = int(sys.argv[3])
 torch.manual_seed(0)
 kw = dict(num_bbox_labels=8, img_channels=3, img_height=bg, img_width=bg, c_dim=0, background_size=bg, bert_f_dim=768, im_f_dim=512,
-          bert_num_heads=4, bert_num_encoder_layers=2, bert_num_decoder_layers=2, text_mode='encoder+lm')
+          bert_num_heads=4, bert_num_encoder_layers=2, bert_num_decoder_layers=2, text_mode=os.environ.get('LDETR_TM', 'encoder+lm'))
 import torch.nn.functional as F
 from layoutdetr_amd.training import med
 mode = os.environ.get('LDETR_DBG', '')
@@ -37,14 +37,29 @@ G = Generator(z_dim=4, **kw).train().requires_grad_(False).to(dev); D = Discrimi
 G.static_shapes = D.static_shapes = True
 LR = float(os.environ.get('LDETR_LR', '1e-5')); pG = tl.Phase('Gmain', G, lr=LR); pD = tl.Phase('Dmain', D, lr=LR)
 loss = StyleGAN2Loss(dev, G, D); dp = tl.DataParallelStep(1)
-batch = to_device_batch(make_batch(B, bg, dev, 1), dev, 'encoder+lm', T)
+batch = to_device_batch(make_batch(B, bg, dev, 1), dev, os.environ.get('LDETR_TM', 'encoder+lm'), T)
 phases = {'G': [pG], 'D': [pD], 'GD': [pG, pD]}[which]
 side = torch.cuda.Stream(); side.wait_stream(torch.cuda.current_stream())
 with torch.cuda.stream(side):
     for _ in range(2):
         tl.training_iteration(loss, phases, dp, batch, B, [torch.randn(B, 9, 4, device=dev) for _ in phases])
 torch.cuda.current_stream().wait_stream(side); torch.cuda.synchronize(); print('eager ok', flush=True)
+from layoutdetr_amd.hip import core as _c
+_ws = _c._workspace.get(torch.cuda.current_device())
+if _ws is not None and os.environ.get('LDETR_DBG_COUNTERS'):
+    cnt = _ws[:262144].view(torch.int32)
+    nz = (cnt != 0).nonzero().flatten()
+    print('non-zero counters after eager iterations:', nz.numel(), nz[:10].tolist(), cnt[nz[:10]].tolist(), flush=True)
+if os.environ.get('LDETR_EAGER_ONLY'):
+    sys.exit(0)
 gi = tl.GraphedIteration(loss, phases, dp, batch, B, 4, capture_stream=side)
 torch.cuda.synchronize(); print('captured', flush=True)
+if os.environ.get('LDETR_DBG_EMPTY'):
+    import gc; gc.collect(); torch.cuda.empty_cache(); print('cache emptied', flush=True)
 for i in range(3):
-    gi.run(); torch.cuda.synchronize(); print('replay', i, flush=True)
+    gi.run(); torch.cuda.synchronize()
+    mods = [ph.module for ph in phases]
+    bad = [n for m in mods for n, q in m.named_parameters() if not torch.isfinite(q).all()]
+    gmax = max(float(q.grad.abs().max()) for m in mods for q in m.parameters() if q.grad is not None)
+    worst = sorted(((float(q.grad.abs().max()), n) for m in mods for n, q in m.named_parameters() if q.grad is not None), reverse=True)[:3]
+    print('replay', i, 'non-finite params:', len(bad), bad[:4], 'max|grad|', gmax, worst, flush=True)
