@@ -188,7 +188,7 @@ def _text_inputs(module, bbox_text, B, N, device):
 
 
 def _zero_like_loss(ref):
-    return ref.new_zeros(())
+    return ref.new_full((), 0.0)   # a fill kernel: new_zeros(()) becomes a 4-byte memset node under capture (see DESIGN §6 on memset nodes)
 
 
 class Generator(nn.Module):
