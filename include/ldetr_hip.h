@@ -21,6 +21,10 @@
  *   ldetr_maxpool3x3s2_*_f32      torchvision ResNet stem max-pool (called via detr_backbone.py:105)
  *   ldetr_grad_sanitize_f32, ldetr_adam_step_f32, ldetr_ema_lerp_f32
  *                                 training/training_loop.py:303-313, 320-328
+ *   ldetr_softmax_xent_*_f32, ldetr_embedding_*_f32
+ *                                 LM text decoder head: training/med.py:60-61,88-94 (embeddings), 911-916 (loss)
+ *   ldetr_resample_coeffs, ldetr_resize_normalize_u8
+ *                                 PIL resize + normalise of the page background: training/dataset_layoutganpp.py:330-338
  *   ldetr_lsap_f64                scipy.optimize.linear_sum_assignment as used at metrics/metric_layoutnet.py:111,125,240
  */
 #ifndef LDETR_HIP_H
@@ -186,6 +190,19 @@ int ldetr_embedding_fwd_f32(const float* weight, const float* pos, const int64_t
                             void* stream);
 int ldetr_embedding_bwd_f32(const float* dy, const int64_t* ids, float* dweight, int64_t n, int d, int V, int64_t padding_idx,
                             void* stream);
+
+/* Page-background preprocessing of a dataset item (training/dataset_layoutganpp.py:330-338): Pillow's 8-bit Lanczos ("ANTIALIAS")
+ * resize of a decoded uint8 RGB page, then (x / 255 - mean) / std in fp32, CHW.  Bit-identical to Pillow + numpy.
+ * ldetr_resample_coeffs (HOST memory, no GPU work): window bounds [out][2] = (first input index, tap count) and 22-bit fixed-point
+ * weights, stored tap-major [ksize][out]; call with bounds = weights = NULL to query ksize.
+ * ldetr_resize_normalize_u8: src [images][H][W][3] uint8 -> tmp [images][H][out_w][3] uint8 (scratch, horizontal pass) ->
+ * out_u8 [images][out_h][out_w][3] (optional) and out_chw [images][3][out_h][out_w] fp32 (optional).  hbounds/hweights are
+ * ldetr_resample_coeffs(W, out_w) and vbounds/vweights ldetr_resample_coeffs(H, out_h), copied to device memory. */
+int ldetr_resample_coeffs(int in_size, int out_size, int32_t* bounds, int32_t* weights, int64_t weights_capacity, int* ksize_out);
+int ldetr_resize_normalize_u8(const uint8_t* src, int64_t images, int H, int W, int out_h, int out_w, const int32_t* hbounds,
+                              const int32_t* hweights, int hksize, const int32_t* vbounds, const int32_t* vweights, int vksize,
+                              uint8_t* tmp, uint8_t* out_u8, float* out_chw, float mean0, float mean1, float mean2, float std0,
+                              float std1, float std2, void* stream);
 
 /* Batched linear-sum-assignment (Hungarian / shortest augmenting path) on device.
  * cost: [batch][n][n] float64 row-major; maximize != 0 negates the costs first;

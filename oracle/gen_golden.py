@@ -350,6 +350,34 @@ def gen_bert_lm():
     save('bert_lm', d)
 
 
+def gen_resample():
+    """Background preprocessing of a dataset item (dataset_layoutganpp.py:330-338): PIL Lanczos resize of a uint8 RGB page image,
+    then (x / 255 - mean) / std in fp32, CHW.  The resize arithmetic is Pillow's (pinned 9.3.0, environment.yaml:46; 12.x here); the
+    two numpy lines are evaluated exactly as the reference writes them."""
+    import PIL
+    from PIL import Image
+    rng = np.random.default_rng(77)
+    rgb_mean = np.reshape(np.array([0.485, 0.456, 0.406]).astype(np.float32), (1, 1, 3))
+    rgb_std = np.reshape(np.array([0.229, 0.224, 0.225]).astype(np.float32), (1, 1, 3))
+    d = {'pillow_version': np.array([int(v) for v in PIL.__version__.split('.')[:2]])}
+    cases = [(64, 64, 16), (70, 100, 32), (96, 33, 24), (24, 20, 48), (48, 48, 48), (129, 65, 31)]   # (H, W, background_size)
+    for i, (h, w, s) in enumerate(cases):
+        if i % 2 == 0:
+            img = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)          # noise: exercises the clip8 overshoot of the negative lobes
+        else:                                                               # smooth gradients + hard edges, like a rendered page
+            yy, xx = np.mgrid[0:h, 0:w]
+            img = np.stack([(yy * 255 // max(h - 1, 1)), (xx * 255 // max(w - 1, 1)), ((xx // 7 + yy // 5) % 2) * 255], -1).astype(np.uint8)
+        lanczos = getattr(Image, 'ANTIALIAS', Image.LANCZOS)                # ANTIALIAS is the old name of LANCZOS
+        background = np.array(Image.fromarray(img).resize((s, s), lanczos))
+        d[f'in{i}'] = img
+        d[f'u8_{i}'] = background
+        background = (background.astype(np.float32) / 255.0 - rgb_mean) / rgb_std
+        d[f'out{i}'] = background.transpose(2, 0, 1)
+    d['n'] = np.array(len(cases))
+    np.savez_compressed(os.path.join(OUT, 'resample.npz'), **d)
+    print('wrote resample.npz')
+
+
 def gen_dp_step():
     from torch_utils import misc
     torch.manual_seed(600)
@@ -373,8 +401,10 @@ if __name__ == '__main__':
     torch.set_num_threads(8)
     if '--only-metrics' in sys.argv:
         gen_metrics(); sys.exit(0)
+    if '--only-resample' in sys.argv:
+        gen_resample(); sys.exit(0)
     if '--only-bert' in sys.argv:
         gen_bert(); gen_bert_lm(); sys.exit(0)
     if '--skip-done' not in sys.argv:
         gen_ops(); gen_transformer()
-    gen_losses(); gen_decoder(); gen_frozen_bn(); gen_lsap(); gen_dp_step(); gen_metrics(); gen_bert(); gen_bert_lm()
+    gen_losses(); gen_decoder(); gen_frozen_bn(); gen_lsap(); gen_dp_step(); gen_metrics(); gen_bert(); gen_bert_lm(); gen_resample()

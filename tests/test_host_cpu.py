@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), f'{name} declared in include/ldetr_hip.h but not exported'
     assert declared - {'ldetr_last_error', 'ldetr_abi_version'} == set(_lib.SIGNATURES), 'ctypes table out of sync with the header'
-    assert lib.ldetr_abi_version() == 8
+    assert lib.ldetr_abi_version() == 9
 
 
 def test_no_cpu_fallback():
@@ -198,3 +198,23 @@ def test_register_budgeted_kernels_use_no_scratch():
                 n += 1
                 assert ' scratch=0 ' in line, line
     assert n > 50
+
+
+def test_resample_coefficients_match_pillow_restatement():
+    """ldetr_resample_coeffs (host-side, part of the C-ABI) reproduces the oracle's Lanczos windows bit-for-bit: bounds and the 22-bit
+    fixed-point weights, for down-scaling, up-scaling, equal sizes and extreme ratios; and it rejects a short weight buffer."""
+    import ctypes
+    import numpy as np
+    from layoutdetr_amd import _lib
+    from oracle import resample_ref
+    lib = _lib.load()
+    for i, o in [(1024, 256), (700, 256), (37, 256), (48, 48), (129, 31), (64, 512), (1000, 7), (1, 5)]:
+        ks = ctypes.c_int(0)
+        assert lib.ldetr_resample_coeffs(i, o, None, None, 0, ctypes.byref(ks)) == 0
+        b = np.zeros((o, 2), np.int32); k = np.zeros((ks.value, o), np.int32)
+        assert lib.ldetr_resample_coeffs(i, o, b.ctypes.data_as(ctypes.c_void_p), k.ctypes.data_as(ctypes.c_void_p), k.size, ctypes.byref(ks)) == 0
+        rb, rk, rks = resample_ref.precompute_coeffs(i, o)
+        assert ks.value == rks and np.array_equal(b, rb) and np.array_equal(k.T, rk), (i, o)
+        assert int(k.sum(0).min()) > (1 << 22) - 64 and int(k.sum(0).max()) < (1 << 22) + 64   # every window sums to ~1.0
+    assert lib.ldetr_resample_coeffs(1024, 256, b.ctypes.data_as(ctypes.c_void_p), k.ctypes.data_as(ctypes.c_void_p), 10, ctypes.byref(ks)) != 0
+    assert b'too small' in lib.ldetr_last_error()

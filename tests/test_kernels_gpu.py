@@ -607,3 +607,34 @@ def test_token_embedding_gather_and_scatter(dev, B, T, V, d):
     assert_close(wg.grad, word.weight.grad, 2e-5, 'dword')
     assert_close(pg.grad, pos.weight.grad, 2e-5, 'dpos')
     assert float(wg.grad[0].abs().max()) == 0.0
+
+
+def test_background_resize_normalize_vs_pillow_golden(dev):
+    """Device resize + normalise of the dataset item's page background against Pillow's own outputs and the
+    reference's fp32 normalisation lines (tests/golden/resample.npz): uint8 and float results bit-exact."""
+    from layoutdetr_amd.training.dataset_layoutganpp import background_to_tensor
+    d = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'resample.npz'))
+    for i in range(int(d['n'])):
+        img = torch.from_numpy(d[f'in{i}']).to(dev)
+        s = d[f'u8_{i}'].shape[0]
+        out, u8 = background_to_tensor(img, s, return_u8=True)
+        assert torch.equal(u8.cpu(), torch.from_numpy(d[f'u8_{i}'])), f'case {i}: uint8'
+        assert torch.equal(out.cpu(), torch.from_numpy(d[f'out{i}'])), f'case {i}: float CHW'
+
+
+@pytest.mark.parametrize('n,H,W,S', [(2, 1024, 1024, 256), (3, 700, 1000, 256), (1, 300, 200, 512), (2, 4000, 90, 64), (1, 64, 20000, 128)])
+def test_background_resize_normalize_vs_oracle_full_size(dev, n, H, W, S):
+    """Same at the dataset's real page size (1024 x 1024 -> 256) and ragged / extreme shapes (up-scaling, a row segment too wide
+    for the LDS staging) against the CPU oracle, bit-exact; plus batch independence."""
+    from layoutdetr_amd.training.dataset_layoutganpp import background_to_tensor
+    from oracle import resample_ref
+    rng = np.random.default_rng(n * 1000 + S)
+    imgs = rng.integers(0, 256, (n, H, W, 3), dtype=np.uint8)
+    imgs[0, : H // 2] = (np.arange(W)[None, :, None] * 255 // max(W - 1, 1)).astype(np.uint8)      # smooth half
+    out, u8 = background_to_tensor(torch.from_numpy(imgs).to(dev), S, return_u8=True)
+    for i in range(n):
+        ref_u8 = resample_ref.resize_antialias_u8(imgs[i], S, S)
+        assert np.array_equal(u8[i].cpu().numpy(), ref_u8), f'image {i}: uint8'
+        assert np.array_equal(out[i].cpu().numpy(), resample_ref.normalize_chw(ref_u8)), f'image {i}: float'
+    one = background_to_tensor(torch.from_numpy(imgs[n - 1]).to(dev), S)
+    assert torch.equal(one, out[n - 1])

@@ -222,3 +222,18 @@ def test_bert_lm_decoder_oracle():
     gmax = max(float(np.abs(d['grad/' + k]).max()) for k in sd)
     for k in sd:   # absolute, against the largest gradient: the key biases' true gradient is 0 (softmax shift invariance), i.e. noise
         assert (sd[k].grad - torch.from_numpy(d['grad/' + k])).abs().max().item() <= 2e-6 * gmax, k
+
+
+def test_background_resample_oracle_bit_exact():
+    """oracle/resample_ref.py against Pillow's own Lanczos resize (uint8, bit-exact) and the reference's two normalisation lines
+    (fp32, bit-exact) on the committed fixtures: noise and page-like images, down- and up-scaling, ragged and equal sizes."""
+    from oracle import resample_ref
+    d = np.load(os.path.join(G, 'resample.npz'))
+    for i in range(int(d['n'])):
+        img = d[f'in{i}']
+        s = d[f'u8_{i}'].shape[0]
+        u8 = resample_ref.resize_antialias_u8(img, s, s)
+        assert np.array_equal(u8, d[f'u8_{i}']), f'case {i}: uint8 resize differs'
+        out = resample_ref.background_to_tensor(img, s)
+        assert out.dtype == np.float32 and out.shape == (3, s, s)
+        assert np.array_equal(out, d[f'out{i}']), f'case {i}: normalised tensor differs'
