@@ -1035,6 +1035,19 @@ static Workspace& workspace_for_current_device() {
     return g_workspace[dev];
 }
 
+// Transient scratch for other kernels of the library (partial sums of the row reductions): a slice of the same ring, valid for
+// the launches the caller enqueues next on its stream.  nullptr when no workspace is registered or the request does not fit.
+float* scratch_alloc(size_t bytes) {
+    Workspace& w = workspace_for_current_device();
+    const size_t pbytes = w.bytes > WS_COUNTERS * sizeof(int) ? w.bytes - WS_COUNTERS * sizeof(int) : 0;
+    bytes = (bytes + 255) & ~(size_t)255;
+    if (!w.ptr || bytes > pbytes) return nullptr;
+    if (w.partial_cursor + bytes > pbytes) w.partial_cursor = 0;
+    float* r = reinterpret_cast<float*>(reinterpret_cast<char*>(w.ptr) + WS_COUNTERS * sizeof(int) + w.partial_cursor);
+    w.partial_cursor += bytes;
+    return r;
+}
+
 // Zero-fill of a pitched fp32 matrix for the atomic split-K path.  A kernel rather than hipMemset2DAsync: memset nodes captured into
 // a hipGraph were observed to replay out of order with their neighbouring kernel nodes on ROCm 7.2 (garbage gradients on replay).
 __global__ void __launch_bounds__(256) zero_fill_kernel(float* __restrict__ dst, long pitch, long width, long rows) {

@@ -15,6 +15,10 @@ namespace ldetr {
 
 void set_error(const char* fmt, ...);
 
+// Slice of the caller-registered workspace (ldetr_set_workspace) for the launches enqueued next; nullptr if unavailable.
+// Defined in gemm_conv.hip next to the split-K ring it shares.
+float* scratch_alloc(size_t bytes);
+
 inline int check_launch(const char* what) {
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {

@@ -14,6 +14,7 @@ struct RRParams {
     const float* sampv;  // [B][C]
     float* red1; long red1_bs;
     float* red2; long red2_bs;
+    float* part;         // [2][blocks][C] partial sums instead of atomics (finished by rr_finish_kernel), or NULL
     long P; int B, C, mode, act, rows_pb;
     float alpha, gain;
 };
@@ -38,14 +39,12 @@ __global__ __launch_bounds__(256) void rowreduce_kernel(RRParams p) {
         if (p.sampv) sv = *reinterpret_cast<const float4*>(p.sampv + (long)b * p.C + c);
         const long r0 = (long)blockIdx.x * p.rows_pb;
         const long r1e = min(p.P, r0 + p.rows_pb);
-        for (long r = r0 + ty; r < r1e; r += RL) {
-            const long off = ((long)b * p.P + r) * p.C + c;
-            float4 a = *reinterpret_cast<const float4*>(p.a + off);
+        auto process = [&](const float4& a, const float4& x2, long off) {
             if (MODE == RR_COLSUM) {
                 r1.x += a.x; r1.y += a.y; r1.z += a.z; r1.w += a.w;
             } else if (MODE == RR_ACTGRAD) {
-                // a = dy, b = y (saved output).  dv = dy * gain * (y > 0 ? 1 : alpha)   [act 2: lrelu, 1: relu, 0: linear]
-                float4 y = *reinterpret_cast<const float4*>(p.b + off);
+                // a = dy, x2 = y (saved output).  dv = dy * gain * (y > 0 ? 1 : alpha)   [act 2: lrelu, 1: relu, 0: linear]
+                const float4& y = x2;
                 float4 dv;
                 float gp = p.gain, gn = (p.act == 2) ? p.gain * p.alpha : (p.act == 1 ? 0.f : p.gain);
                 dv.x = a.x * (y.x > 0.f ? gp : gn); dv.y = a.y * (y.y > 0.f ? gp : gn);
@@ -59,13 +58,32 @@ __global__ __launch_bounds__(256) void rowreduce_kernel(RRParams p) {
                     float vz = y.z * (y.z > 0.f ? ip : in) - cv.z, vw = y.w * (y.w > 0.f ? ip : in) - cv.w;
                     r2.x += dv.x * vx / sv.x; r2.y += dv.y * vy / sv.y; r2.z += dv.z * vz / sv.z; r2.w += dv.w * vw / sv.w;
                 }
-            } else {  // RR_MULRED: out = a * sampv (optional), red1 += a * b  (optionally / colv-less divisor in red2 slot)
-                float4 x2 = *reinterpret_cast<const float4*>(p.b + off);
+            } else {  // RR_MULRED: out = a * sampv (optional), red1 += a * b
                 if (p.out) {
                     float4 o = make_float4(a.x * sv.x, a.y * sv.y, a.z * sv.z, a.w * sv.w);
                     *reinterpret_cast<float4*>(p.out + off) = o;
                 }
                 r1.x += a.x * x2.x; r1.y += a.y * x2.y; r1.z += a.z * x2.z; r1.w += a.w * x2.w;
+            }
+        };
+        // four rows per trip, all loads issued before the first store (the output may alias an input, so the compiler
+        // cannot hoist them itself): 8 float4 loads in flight per lane
+        constexpr int UN = 4;
+        for (long r = r0 + ty; r < r1e; r += (long)RL * UN) {
+            float4 av[UN], bv[UN];
+#pragma unroll
+            for (int u = 0; u < UN; u++) {
+                const long rr = r + (long)u * RL;
+                if (rr < r1e) {
+                    const long off = ((long)b * p.P + rr) * p.C + c;
+                    av[u] = *reinterpret_cast<const float4*>(p.a + off);
+                    if (MODE != RR_COLSUM) bv[u] = *reinterpret_cast<const float4*>(p.b + off);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < UN; u++) {
+                const long rr = r + (long)u * RL;
+                if (rr < r1e) process(av[u], bv[u], ((long)b * p.P + rr) * p.C + c);
             }
         }
     }
@@ -77,6 +95,12 @@ __global__ __launch_bounds__(256) void rowreduce_kernel(RRParams p) {
             float4 u = sh2[j * TQ + tx]; r2.x += u.x; r2.y += u.y; r2.z += u.z; r2.w += u.w;
         }
         const int c = cq << 2;
+        if (p.part) {
+            const long nblk = (long)gridDim.x * gridDim.y, blk = (long)blockIdx.y * gridDim.x + blockIdx.x;
+            *reinterpret_cast<float4*>(p.part + blk * p.C + c) = r1;
+            if (p.red2) *reinterpret_cast<float4*>(p.part + (nblk + blk) * p.C + c) = r2;
+            return;
+        }
         if (p.red1) {
             float* d = p.red1 + (long)b * p.red1_bs + c;
             atomicAdd(d, r1.x); atomicAdd(d + 1, r1.y); atomicAdd(d + 2, r1.z); atomicAdd(d + 3, r1.w);
@@ -88,20 +112,62 @@ __global__ __launch_bounds__(256) void rowreduce_kernel(RRParams p) {
     }
 }
 
+// Second stage of the row reductions: red[b][c] += sum over the row chunks' partial sums (all samples' chunks when the
+// reduction is shared by the batch, bs == 0).  No long same-address atomic queues: with one atomic per block and channel the
+// first stage's time was (#blocks x ~0.1 us) whatever the bandwidth; here at most `segs` (<= 16) atomics meet per address.
+// grid (ceil(C / 64), B or 1, 2 * segs): z / segs = 0 -> red1, 1 -> red2; z % segs = slice of the partial rows.
+// Block = 64 channels x 4 partial-row lanes.
+__global__ __launch_bounds__(256) void rr_finish_kernel(RRParams p, int chunks, int segs) {
+    __shared__ float sh[256];
+    const int which = blockIdx.z / segs, seg = blockIdx.z % segs;
+    float* red = which ? p.red2 : p.red1;
+    const long bs = which ? p.red2_bs : p.red1_bs;
+    if (!red) return;
+    const bool shared_by_batch = bs == 0;
+    if (shared_by_batch && blockIdx.y > 0) return;
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), lane = threadIdx.x >> 6;
+    const long nblk = (long)chunks * p.B;
+    const float* part = p.part + (which ? nblk * p.C : 0);
+    const long first = shared_by_batch ? 0 : (long)blockIdx.y * chunks, count = shared_by_batch ? nblk : chunks;
+    const long per = (count + segs - 1) / segs, i0 = seg * per, i1 = min(count, i0 + per);
+    float acc = 0.f;
+    if (c < p.C) {
+#pragma unroll 4
+        for (long i = i0 + lane; i < i1; i += 4) acc += part[(first + i) * p.C + c];
+    }
+    sh[threadIdx.x] = acc;
+    __syncthreads();
+    if (lane == 0 && c < p.C && i0 < i1) {
+        acc += sh[threadIdx.x + 64] + sh[threadIdx.x + 128] + sh[threadIdx.x + 192];
+        float* d = red + (shared_by_batch ? 0 : (long)blockIdx.y * bs) + c;
+        if (segs > 1) atomicAdd(d, acc); else *d += acc;
+    }
+}
+
 static int launch_rr(RRParams& p, hipStream_t st) {
     const int C4 = p.C / 4;
     const int TQ = C4 < 256 ? C4 : 256;
     const int RL = 256 / TQ;
-    long rows_pb = (long)RL * 16;
-    // keep the grid between ~1k and ~8k blocks
-    long nb = ((p.P + rows_pb - 1) / rows_pb) * p.B * cdiv(C4, TQ);
-    while (nb > 8192) { rows_pb *= 2; nb = ((p.P + rows_pb - 1) / rows_pb) * p.B * cdiv(C4, TQ); }
+    // a few blocks per CU in total, never straddling a sample; their partial sums go through the workspace to rr_finish_kernel
+    static const long target = getenv("LDETR_RR_BLOCKS") ? atol(getenv("LDETR_RR_BLOCKS")) : 2048;
+    const long groups = (long)p.B * cdiv(C4, TQ);
+    long chunks = target / groups; if (chunks < 1) chunks = 1;
+    long rows_pb = (p.P + chunks - 1) / chunks;
+    const long min_rows = (long)RL * 4;
+    if (rows_pb < min_rows) rows_pb = min_rows;
+    rows_pb = (rows_pb + RL - 1) / RL * RL;
     p.rows_pb = (int)rows_pb;
     dim3 grid((unsigned)((p.P + rows_pb - 1) / rows_pb), p.B, cdiv(C4, TQ));
+    const long nblk = (long)grid.x * grid.y;
+    p.part = (p.red1 || p.red2) && nblk > 8 ? scratch_alloc((size_t)nblk * p.C * sizeof(float) * (p.red2 ? 2 : 1)) : nullptr;
     if (p.mode == RR_COLSUM) hipLaunchKernelGGL(rowreduce_kernel<RR_COLSUM>, grid, 256, 0, st, p);
     else if (p.mode == RR_ACTGRAD) hipLaunchKernelGGL(rowreduce_kernel<RR_ACTGRAD>, grid, 256, 0, st, p);
     else hipLaunchKernelGGL(rowreduce_kernel<RR_MULRED>, grid, 256, 0, st, p);
-    return check_launch("rowreduce");
+    int rc = check_launch("rowreduce"); if (rc || !p.part) return rc;
+    const long longest = p.red1 && p.red1_bs == 0 ? nblk : (long)grid.x;     // partial rows behind one output element
+    int segs = (int)(longest / 32); if (segs < 1) segs = 1; if (segs > 16) segs = 16;
+    hipLaunchKernelGGL(rr_finish_kernel, dim3(cdiv(p.C, 64), p.B, (p.red2 ? 2 : 1) * segs), 256, 0, st, p, (int)grid.x, segs);
+    return check_launch("rowreduce_finish");
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -316,7 +382,8 @@ extern "C" int ldetr_torgb_bwd_f32(const float* x, const float* dy, const float*
     const int C4 = C / 4; const int TQ = C4 < 256 ? C4 : 256; const int RL = 256 / TQ;
     long rows_pb = (long)RL * 16;
     long nb = ((P + rows_pb - 1) / rows_pb) * B * cdiv(C4, TQ);
-    while (nb > 8192) { rows_pb *= 2; nb = ((P + rows_pb - 1) / rows_pb) * B * cdiv(C4, TQ); }
+    static const long max_blocks = getenv("LDETR_RR_MAXBLOCKS") ? atol(getenv("LDETR_RR_MAXBLOCKS")) : 8192;
+    while (nb > max_blocks) { rows_pb *= 2; nb = ((P + rows_pb - 1) / rows_pb) * B * cdiv(C4, TQ); }
     p.rows_pb = (int)rows_pb;
     dim3 grid((unsigned)((P + rows_pb - 1) / rows_pb), B, cdiv(C4, TQ));
     hipLaunchKernelGGL(torgb_bwd_kernel, grid, 256, 0, (hipStream_t)stream, p);
