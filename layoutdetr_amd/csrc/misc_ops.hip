@@ -297,7 +297,19 @@ __global__ __launch_bounds__(256) void torgb_bwd_kernel(RgbParams p) {
         d += p.C;
         atomicAdd(d, a2.x); atomicAdd(d + 1, a2.y); atomicAdd(d + 2, a2.z); atomicAdd(d + 3, a2.w);
     }
-    if (active && cq == 0 && p.dbias) { atomicAdd(p.dbias, db0); atomicAdd(p.dbias + 1, db1); atomicAdd(p.dbias + 2, db2); }
+    // bias gradient: the block's row lanes are summed through LDS first, so one block issues 3 atomics instead of 3 x RL onto the
+    // same cache line (at 256^2 x 16 samples that queue of 65536 same-line atomics WAS the kernel: 340 us)
+    if (p.dbias && blockIdx.z == 0) {
+        __syncthreads();
+        float* f = reinterpret_cast<float*>(&sh[0][0]);
+        if (tx == 0 && ty < RL) { f[ty * 3] = db0; f[ty * 3 + 1] = db1; f[ty * 3 + 2] = db2; }
+        __syncthreads();
+        if (threadIdx.x < 3) {
+            float t = 0.f;
+            for (int j = 0; j < RL; j++) t += f[j * 3 + threadIdx.x];
+            atomicAdd(p.dbias + threadIdx.x, t);
+        }
+    }
 }
 
 }  // namespace ldetr
@@ -382,8 +394,7 @@ extern "C" int ldetr_torgb_bwd_f32(const float* x, const float* dy, const float*
     const int C4 = C / 4; const int TQ = C4 < 256 ? C4 : 256; const int RL = 256 / TQ;
     long rows_pb = (long)RL * 16;
     long nb = ((P + rows_pb - 1) / rows_pb) * B * cdiv(C4, TQ);
-    static const long max_blocks = getenv("LDETR_RR_MAXBLOCKS") ? atol(getenv("LDETR_RR_MAXBLOCKS")) : 8192;
-    while (nb > max_blocks) { rows_pb *= 2; nb = ((P + rows_pb - 1) / rows_pb) * B * cdiv(C4, TQ); }
+    while (nb > 2048) { rows_pb *= 2; nb = ((P + rows_pb - 1) / rows_pb) * B * cdiv(C4, TQ); }
     p.rows_pb = (int)rows_pb;
     dim3 grid((unsigned)((P + rows_pb - 1) / rows_pb), B, cdiv(C4, TQ));
     hipLaunchKernelGGL(torgb_bwd_kernel, grid, 256, 0, (hipStream_t)stream, p);
