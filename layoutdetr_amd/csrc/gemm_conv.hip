@@ -700,8 +700,12 @@ __global__ __launch_bounds__(NW * 64) void gemm_small_kernel(GemmParams p) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int cl = lane & 31, kl = lane >> 5;
     const int m0 = blockIdx.y * 32, n0 = blockIdx.x * 32;
-    const int chunks = (p.K + 31) / 32, per = (chunks + NW - 1) / NW;
-    const int kbeg = wave * per * 32, kend = min(p.K, kbeg + per * 32);
+    // reduction range of this block (split-K over blockIdx.z when the launch asked for it), then of this wave
+    const int chunks_all = (p.K + 31) / 32, sk = gridDim.z;
+    const int cper = (chunks_all + sk - 1) / sk;
+    const int kblk0 = blockIdx.z * cper * 32, kblk1 = min(p.K, kblk0 + cper * 32);
+    const int chunks = kblk1 > kblk0 ? (kblk1 - kblk0 + 31) / 32 : 0, per = (chunks + NW - 1) / NW;
+    const int kbeg = kblk0 + wave * per * 32, kend = min(kblk1, kbeg + per * 32);
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; r++) acc[r] = 0.f;
@@ -747,21 +751,65 @@ __global__ __launch_bounds__(NW * 64) void gemm_small_kernel(GemmParams p) {
         float tot = 0.f;
 #pragma unroll
         for (int w = 0; w < NW; w++) tot += rsum[w][tid];
-        p.ep.a_rowsum[m0 + tid] += tot;   // unique writer per m (column block 0), launches on one stream are ordered
+        if (sk > 1) atomicAdd(p.ep.a_rowsum + m0 + tid, tot);   // one writer per K slice
+        else p.ep.a_rowsum[m0 + tid] += tot;                    // unique writer per m (column block 0), launches on one stream are ordered
     }
     const GemmEpilogue& ep = p.ep;
     const float inv_keep = ep.p_drop > 0.f ? 1.f / (1.f - ep.p_drop) : 1.f;
+    // Split-K: every slice parks its 32x32 partial in the workspace, the slice arriving last at the tile's counter adds them up
+    // in slice order and runs the epilogue (same protocol as gemm_f32_kernel's fix-up: agent-scope stores / loads + vmcnt(0)).
+    float* slot0 = nullptr;
+    if (sk > 1) {
+        const long tile = (long)blockIdx.y * gridDim.x + blockIdx.x;
+        slot0 = p.ws + tile * sk * 1024;
+        float* mine = slot0 + (long)blockIdx.z * 1024;
+        for (int q = tid; q < 256; q += NW * 64) {
+            const int row = q >> 3, c4 = (q & 7) * 4;
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                float sum = 0.f;
+#pragma unroll
+                for (int w = 0; w < NW; w++) sum += red[w][row][c4 + e];
+                __hip_atomic_store(mine + q * 4 + e, sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __shared__ int s_last_small;
+        __syncthreads();
+        if (tid == 0) {
+            const int old = atomicAdd(p.ws_count + tile, 1);
+            s_last_small = (old == sk - 1);
+            if (s_last_small) __hip_atomic_store(p.ws_count + tile, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __syncthreads();
+        if (!s_last_small) return;
+    }
     for (int q = tid; q < 256; q += NW * 64) {   // 256 float4 groups: row = q / 8, cols 4*(q % 8) .. +3
         const int row = q >> 3, c4 = (q & 7) * 4;
         const int m = m0 + row;
         if (m >= p.M) continue;
         float v[4];
+        if (sk > 1) {
 #pragma unroll
-        for (int e = 0; e < 4; e++) {
-            float sum = 0.f;
+            for (int e = 0; e < 4; e++) v[e] = 0.f;
+            float part[8][4];                       // sk <= 8: every slice's loads are issued before the first add (one latency, not sk)
 #pragma unroll
-            for (int w = 0; w < NW; w++) sum += red[w][row][c4 + e];
-            v[e] = sum;
+            for (int z = 0; z < 8; z++)
+#pragma unroll
+                for (int e = 0; e < 4; e++)
+                    part[z][e] = z < sk ? __hip_atomic_load(slot0 + (long)z * 1024 + q * 4 + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.f;
+#pragma unroll
+            for (int z = 0; z < 8; z++)
+#pragma unroll
+                for (int e = 0; e < 4; e++) v[e] += part[z][e];
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                float sum = 0.f;
+#pragma unroll
+                for (int w = 0; w < NW; w++) sum += red[w][row][c4 + e];
+                v[e] = sum;
+            }
         }
         const int samp = (ep.samp_scale && p.pix_per_sample > 0) ? m / p.pix_per_sample : 0;
         float* dst = p.C + (long)m * p.ldc + n0 + c4;
@@ -954,11 +1002,49 @@ static int try_launch_skinny(const GemmParams& p, hipStream_t st) {
     return go(gemm_skinny_kernel<TB, 8>, r8);
 }
 
+// Caller-provided scratch for the split-K fix-up (ldetr_set_workspace): WS_COUNTERS ints of arrival counters, then partial tiles.
+// Both areas are handed out as RINGS, one fresh slice per launch: launches of one stream are ordered anyway, but a captured
+// hipGraph may run independent branches concurrently (autograd hops streams for AccumulateGrad nodes),, and two split-K
+// kernels must never share a counter / partial area.
+// Counters are zero at rest (the last-arriving block re-arms its own), so a counter slice can be reused without clearing;
+// partial tiles need no clearing at all.  A launch that needs more than the whole ring falls back to fp32 atomics.
+constexpr long WS_COUNTERS = 262144;
+struct Workspace { void* ptr; size_t bytes; size_t counter_cursor; size_t partial_cursor; };
+static Workspace g_workspace[64];
+static Workspace& workspace_for_current_device() {
+    static Workspace none = {nullptr, 0, 0, 0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return none;
+    return g_workspace[dev];
+}
+
 template <int TA, int TB>
-static int launch_small(const GemmParams& p, hipStream_t st) {
+static int launch_small(GemmParams& p, hipStream_t st) {
     dim3 grid(cdiv(p.N, 32), cdiv(p.M, 32), 1);
     const long blocks = (long)grid.x * grid.y;
-    if (blocks <= 256 && p.K >= 512) hipLaunchKernelGGL((gemm_small_kernel<TA, TB, 8>), grid, 512, 0, st, p);
+    // few tiles + a long reduction (the decoders' 2048-wide FFN on 144 rows): 40 blocks would walk K one after the other; split K
+    // over up to 8 blocks per tile (>= 256 of K each) and reduce through the workspace inside the kernel
+    static const int small_split = getenv("LDETR_SMALL_SPLIT") ? atoi(getenv("LDETR_SMALL_SPLIT")) : 1;
+    int sk = 1;
+    if (small_split && blocks <= 128 && p.K >= 1024) {
+        sk = p.K / 256; if (sk > 8) sk = 8;
+        while (sk > 1 && blocks * sk > 640) sk--;
+        if (sk > 1) {
+            Workspace& w = workspace_for_current_device();
+            const size_t need = ((size_t)blocks * sk * 1024 * sizeof(float) + 255) & ~(size_t)255;
+            const size_t pbytes = w.bytes > WS_COUNTERS * sizeof(int) ? w.bytes - WS_COUNTERS * sizeof(int) : 0;
+            if (w.ptr && need <= pbytes) {
+                if (w.counter_cursor + blocks > (size_t)WS_COUNTERS) w.counter_cursor = 0;
+                if (w.partial_cursor + need > pbytes) w.partial_cursor = 0;
+                p.ws_count = reinterpret_cast<int*>(w.ptr) + w.counter_cursor;
+                p.ws = reinterpret_cast<float*>(reinterpret_cast<char*>(w.ptr) + WS_COUNTERS * sizeof(int) + w.partial_cursor);
+                w.counter_cursor += blocks; w.partial_cursor += need;
+            } else sk = 1;
+        }
+    }
+    grid.z = sk;
+    const int kblock = (p.K + sk - 1) / sk;
+    if (blocks * sk <= 256 && kblock >= 512) hipLaunchKernelGGL((gemm_small_kernel<TA, TB, 8>), grid, 512, 0, st, p);
     else hipLaunchKernelGGL((gemm_small_kernel<TA, TB, 4>), grid, 256, 0, st, p);
     return check_launch("gemm_small");
 }
@@ -1018,22 +1104,6 @@ constexpr long SMALL_GEMM_MNK = 1l << 30;
 #ifndef WGRAD_MIN_K
 #define WGRAD_MIN_K 512
 #endif
-
-// Caller-provided scratch for the split-K fix-up (ldetr_set_workspace): WS_COUNTERS ints of arrival counters, then partial tiles.
-// Both areas are handed out as RINGS, one fresh slice per launch: launches of one stream are ordered anyway, but a captured
-// hipGraph may run independent branches concurrently (autograd hops streams for AccumulateGrad nodes), and two split-K
-// kernels sharing one counter / partial area corrupted each other (seen as a memory fault on replay with the LM decoder).
-// Counters are zero at rest (the last-arriving block re-arms its own), so a counter slice can be reused without clearing;
-// partial tiles need no clearing at all.  A launch that needs more than the whole ring falls back to fp32 atomics.
-constexpr long WS_COUNTERS = 262144;
-struct Workspace { void* ptr; size_t bytes; size_t counter_cursor; size_t partial_cursor; };
-static Workspace g_workspace[64];
-static Workspace& workspace_for_current_device() {
-    static Workspace none = {nullptr, 0, 0, 0};
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return none;
-    return g_workspace[dev];
-}
 
 // Transient scratch for other kernels of the library (partial sums of the row reductions): a slice of the same ring, valid for
 // the launches the caller enqueues next on its stream.  nullptr when no workspace is registered or the request does not fit.
@@ -1245,16 +1315,17 @@ extern "C" int ldetr_gemm_f32(const float* A, int64_t lda, int ta, const float* 
     LDETR_CHECK(!(p.splitk > 1 && p.ep.accumulate && !epilogue_is_linear(p.ep)), "gemm: split-K + accumulate needs a linear epilogue");
     hipStream_t st = (hipStream_t)stream;
     const bool auto_split = (splitk == 0);   // splitk: 0 = let the launch policy decide, 1 = never split, >1 = explicit
+    static const int small_maxk = getenv("LDETR_SMALL_MAXK") ? atoi(getenv("LDETR_SMALL_MAXK")) : (1 << 30);
     if (p.ep.a_rowsum) {
         LDETR_CHECK(ta == 1 && lda == M, "gemm: a_rowsum needs ta == 1 and a packed A (lda == M)");
-        const bool small = auto_split && (long)cdiv(M, 64) * cdiv(N, 64) < SMALL_GEMM_TILES && (long)M * N * K <= SMALL_GEMM_MNK && tb;
+        const bool small = auto_split && (long)cdiv(M, 64) * cdiv(N, 64) < SMALL_GEMM_TILES && (long)M * N * K <= SMALL_GEMM_MNK && tb && K <= small_maxk;
         if (!small) {   // not the kernel that folds the row sums in: one column-sum pass over A = [K, M]
             int rc = ldetr_colsum_f32(A, p.ep.a_rowsum, 1, K, M, stream);
             if (rc) return rc;
             p.ep.a_rowsum = nullptr;
         }
     }
-    if (auto_split && (long)cdiv(M, 64) * cdiv(N, 64) < SMALL_GEMM_TILES && (long)M * N * K <= SMALL_GEMM_MNK) {
+    if (auto_split && (long)cdiv(M, 64) * cdiv(N, 64) < SMALL_GEMM_TILES && (long)M * N * K <= SMALL_GEMM_MNK && K <= small_maxk) {
         if (!ta && !tb) return launch_small<0, 0>(p, st);
         if (!ta && tb) return launch_small<0, 1>(p, st);
         if (ta && tb) return launch_small<1, 1>(p, st);

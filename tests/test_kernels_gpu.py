@@ -140,6 +140,36 @@ def test_gemm_variants(dev, M, N, K):
     assert_close(c, At.t() @ Bt, 2e-6, 'TN split-K')
 
 
+@pytest.mark.parametrize('M,N,K', [(144, 256, 2048), (160, 256, 2048), (144, 768, 3072), (70, 36, 1100), (9, 4, 1024), (33, 65, 4100)])
+def test_gemm_small_tiles_long_reduction(dev, M, N, K):
+    """Few 32x32 tiles with K >= 1024 (the decoders' FFN on 9-10 tokens per sample): the small-tile kernel splits K over blocks and
+    reduces through the workspace in-kernel; all operand layouts, the full epilogue, accumulate, the folded row sums, repeated
+    launches (the arrival counters must re-arm), and the no-workspace route."""
+    from layoutdetr_amd.hip import core
+    torch.manual_seed(46)
+    A = torch.randn(M, K); W = torch.randn(N, K); Bt = torch.randn(K, N); At = torch.randn(K, M)
+    b = torch.randn(N); R = torch.randn(M, N)
+    Ad, Wd, Btd, Atd, bd, Rd = [t.to(dev) for t in (A, W, Bt, At, b, R)]
+    ref_nt = (A.double() @ W.double().t()).float()
+    for _ in range(3):
+        c = core.gemm(Ad, Wd, 0, 0, M, N, K, ep=core.epilogue(col_bias=bd, residual=Rd, act=core.ACT_RELU))
+        assert_close(c, F.relu(ref_nt + b + R), 3e-6, 'NT + epilogue')
+    assert_close(core.gemm(Ad, Btd, 0, 1, M, N, K), (A.double() @ Bt.double()).float(), 3e-6, 'NN')
+    ref_tn = (At.double().t() @ Bt.double()).float()
+    assert_close(core.gemm(Atd, Btd, 1, 1, M, N, K), ref_tn, 3e-6, 'TN')
+    base = torch.randn(M, N); out = base.to(dev).clone()
+    core.gemm(Atd, Btd, 1, 1, M, N, K, out=out, ep=core.epilogue(accumulate=True))
+    assert_close(out, base + ref_tn, 3e-6, 'TN accumulate')
+    rs = torch.zeros(M, device=dev)
+    core.gemm(Atd, Btd, 1, 1, M, N, K, ep=core.epilogue(a_rowsum=rs))
+    assert_close(rs, At.double().sum(0).float(), 3e-6, 'row sums')
+    try:
+        core.disable_splitk_workspace()
+        assert_close(core.gemm(Ad, Wd, 0, 0, M, N, K), ref_nt, 3e-6, 'NT without workspace')
+    finally:
+        core.enable_splitk_workspace()
+
+
 @pytest.mark.parametrize('M,N,K', [(20000, 77, 100), (4096, 256, 64), (33000, 36, 256), (8192, 300, 132), (16384, 512, 128), (4100, 1000, 32)])
 def test_gemm_skinny_k(dev, M, N, K):
     """Dense GEMMs with M >= 4096 and K <= 256 take the register-stationary kernel: both B layouts, full epilogue."""

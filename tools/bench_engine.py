@@ -58,9 +58,11 @@ def main():
              ('l4 3x3 512->512 s2', B, 16, 512, 512, 3, 2, 1), ('l4 1x1 512->2048', B, 8, 512, 2048, 1, 1, 0), ('l4 1x1 2048->512', B, 8, 2048, 512, 1, 1, 0), ('l4 3x3 512->512', B, 8, 512, 512, 3, 1, 1),
              ('sg 3x3 512->512 @16', B, 16, 512, 512, 3, 1, 1), ('sg 3x3 256->256 @32', B, 32, 256, 256, 3, 1, 1), ('sg 3x3 128->128 @64', B, 64, 128, 128, 3, 1, 1),
              ('sg 3x3 64->64 @128', B, 128, 64, 64, 3, 1, 1), ('sg 3x3 32->32 @256', B, 256, 32, 32, 3, 1, 1)]
+    if os.environ.get('LDETR_BENCH_GEMM_ONLY'):
+        cases = []
     for c in cases:
         conv_case(*c)
-    for g in [('enc proj 256', B * 64, 256, 256), ('encdec proj 256', B * 80, 256, 256), ('dec proj 256', B * 9, 256, 256), ('dec proj 256 (10)', B * 10, 256, 256), ('enc qk proj', B * 64, 512, 256), ('enc ffn1', B * 64, 2048, 256), ('enc ffn2', B * 64, 256, 2048), ('dec ffn1', B * 9, 2048, 256), ('fc_in 3072->768', B * 9, 768, 3072), ('mapping 512', B, 512, 512)]:
+    for g in [('enc proj 256', B * 64, 256, 256), ('encdec proj 256', B * 80, 256, 256), ('dec proj 256', B * 9, 256, 256), ('dec proj 256 (10)', B * 10, 256, 256), ('enc qk proj', B * 64, 512, 256), ('enc ffn1', B * 64, 2048, 256), ('enc ffn2', B * 64, 256, 2048), ('dec ffn1', B * 9, 2048, 256), ('dec ffn2', B * 9, 256, 2048), ('dec ffn2 (10)', B * 10, 256, 2048), ('fc_in 3072->768', B * 9, 768, 3072), ('mapping 512', B, 512, 512)]:
         gemm_case(*g)
 
 
