@@ -27,7 +27,7 @@ FLAGS = ['-O3', '-std=c++17', '-fPIC', f'--offload-arch={ARCH}', '-munsafe-fp-at
          '-Wno-unused-result', '-Rpass-analysis=kernel-resource-usage']
 # kernels whose register budget is the design: any scratch (spill / stack object) is a build error, not a silent 10x slowdown
 # (an erf in the engine's epilogue once cost 320 bytes of scratch per lane and every 128x128 GEMM ran 14x slower)
-NO_SCRATCH = ('gemm_f32_kernel', 'gemm_skinny_kernel', 'gemm_small_kernel', 'attn_fwd_kernel', 'attn_bwd_kernel')
+NO_SCRATCH = ('gemm_f32_kernel', 'gemm_skinny_kernel', 'gemm_small_kernel', 'attn_fwd_kernel', 'attn_fwd_wide_kernel', 'attn_bwd_kernel')
 
 
 def _hipcc():

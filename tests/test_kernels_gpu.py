@@ -573,7 +573,8 @@ def test_bottleneck_chain_fused_block_gradients(dev):
         assert_close(a, r, 3e-5, f'dw[{i}]')
 
 
-@pytest.mark.parametrize('B,H,L,dh,causal', [(2, 4, 40, 192, True), (3, 3, 21, 64, True), (2, 2, 70, 96, False), (2, 4, 40, 192, False), (2, 8, 19, 32, True)])
+@pytest.mark.parametrize('B,H,L,dh,causal', [(2, 4, 40, 192, True), (3, 3, 21, 64, True), (2, 2, 70, 96, False), (2, 4, 40, 192, False), (2, 8, 19, 32, True),
+                                             (2, 2, 256, 192, False), (2, 2, 200, 64, True), (1, 3, 130, 160, False), (2, 1, 64, 128, True)])
 def test_attention_wide_heads_and_causal(dev, B, H, L, dh, causal):
     """Packed self-attention for 32..192-wide heads, forward + backward, with the decoder's causal mask on top of a ragged
     key-padding mask (BertSelfAttention shapes of the text encoder / LM decoder)."""

@@ -62,6 +62,8 @@ def main():
         cases = []
     for c in cases:
         conv_case(*c)
+    if os.environ.get('LDETR_BENCH_CONV_ONLY'):
+        return
     for g in [('enc proj 256', B * 64, 256, 256), ('encdec proj 256', B * 80, 256, 256), ('dec proj 256', B * 9, 256, 256), ('dec proj 256 (10)', B * 10, 256, 256), ('enc qk proj', B * 64, 512, 256), ('enc ffn1', B * 64, 2048, 256), ('enc ffn2', B * 64, 256, 2048), ('dec ffn1', B * 9, 2048, 256), ('dec ffn2', B * 9, 256, 2048), ('dec ffn2 (10)', B * 10, 256, 2048), ('fc_in 3072->768', B * 9, 768, 3072), ('mapping 512', B, 512, 512)]:
         gemm_case(*g)
 
