@@ -23,6 +23,8 @@
  *                                 training/training_loop.py:303-313, 320-328
  *   ldetr_softmax_xent_*_f32, ldetr_embedding_*_f32
  *                                 LM text decoder head: training/med.py:60-61,88-94 (embeddings), 911-916 (loss)
+ *   ldetr_layout_losses_*_f32     compute_overlap / compute_alignment / generalized_iou_loss / mse on the generated boxes:
+ *                                 metrics/metric_layoutnet.py:153-201,245-275, training/loss.py:94-97
  *   ldetr_resample_coeffs, ldetr_resize_normalize_u8
  *                                 PIL resize + normalise of the page background: training/dataset_layoutganpp.py:330-338
  *   ldetr_lsap_f64                scipy.optimize.linear_sum_assignment as used at metrics/metric_layoutnet.py:111,125,240
@@ -203,6 +205,16 @@ int ldetr_resize_normalize_u8(const uint8_t* src, int64_t images, int H, int W, 
                               const int32_t* hweights, int hksize, const int32_t* vbounds, const int32_t* vweights, int vksize,
                               uint8_t* tmp, uint8_t* out_u8, float* out_chw, float mean0, float mean1, float mean2, float std0,
                               float std1, float std2, void* stream);
+
+/* The generator phase's four layout losses on one set of generated boxes, fused with their gradients (training/loss.py:94,
+ * metrics/metric_layoutnet.py:153-201,245-275): bbox, bbox_ref [B][N][4] (xc, yc, w, h), valid [B][N] (non-zero = real element),
+ * N <= 16.  losses [4][B]: per-sample shares of (0) mse_loss(bbox[valid], bbox_ref[valid]), (1) generalized_iou_loss(same),
+ * (2) compute_overlap(bbox, valid)[b], (3) compute_alignment(bbox, valid)[b] -- rows 0 and 1 sum to the reference's scalars.
+ * grads [4][B][N][4] = d losses[t][b] / d bbox[b] (autograd's subgradient conventions).  bbox_ref may be NULL (rows 0, 1 = 0).
+ * bwd: dbbox[b] = sum_t grad_losses[t][b] * grads[t][b]. */
+int ldetr_layout_losses_f32(const float* bbox, const float* bbox_ref, const uint8_t* valid, int B, int N, float* losses,
+                            float* grads, void* stream);
+int ldetr_layout_losses_bwd_f32(const float* grads, const float* grad_losses, int B, int N, float* dbbox, void* stream);
 
 /* Batched linear-sum-assignment (Hungarian / shortest augmenting path) on device.
  * cost: [batch][n][n] float64 row-major; maximize != 0 negates the costs first;

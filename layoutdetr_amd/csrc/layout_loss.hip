@@ -1,0 +1,205 @@
+// Layout losses of the generator phase, fused: on one [B, N, 4] set of generated boxes (xc, yc, w, h) the
+// reference evaluates, each as a chain of ~40 elementwise / reduction launches plus as many in the backward,
+//     F.mse_loss(bbox_fake[valid], bbox_real[valid])                       training/loss.py:94
+//     generalized_iou_loss(bbox_fake[valid], bbox_real[valid])             metrics/metric_layoutnet.py:245-275
+//     compute_overlap(bbox_fake, valid)                                    metrics/metric_layoutnet.py:153-179
+//     compute_alignment(bbox_fake, valid)                                  metrics/metric_layoutnet.py:182-201
+// Here one wave per sample computes the four values AND their gradients with respect to bbox_fake in the same pass (N <= 16
+// boxes: everything lives in registers / 1 KiB of LDS); the backward is a 4-term weighted sum of the saved gradients.
+// Subgradient conventions are autograd's: maximum / minimum split a tie half-half, where() passes the gradient of the taken
+// branch only, abs' = sign, min(dim) routes to the first arg-min, nan_to_num blocks the gradient of the entries it replaced, and
+// compute_alignment keeps its quirk of comparing valid boxes against padded ones too (the mask is applied to rows only).
+//   losses [4][B]: per-sample shares, so that  mse = losses[0].sum(), gIoU = losses[1].sum(), overlap = losses[2] ([B]),
+//                  alignment = losses[3] ([B]).   grads [4][B][N][4] = d losses[t][b] / d bbox[b].
+#include "ldetr_common.hpp"
+#include "../../include/ldetr_hip.h"
+
+namespace ldetr {
+
+struct LayoutLossParams {
+    const float* box; const float* ref; const unsigned char* valid;
+    float* losses; float* grads;
+    const float* gout; float* dbox;
+    int B, N;
+};
+
+struct Ltrb { float l, t, r, b; };
+__device__ __forceinline__ Ltrb to_ltrb(const float (&x)[4]) { return {x[0] - x[2] / 2, x[1] - x[3] / 2, x[0] + x[2] / 2, x[1] + x[3] / 2}; }
+// d max(a, b) / da and d min(a, b) / da with autograd's tie rule
+__device__ __forceinline__ float dmax_a(float a, float b) { return a > b ? 1.f : (a == b ? 0.5f : 0.f); }
+__device__ __forceinline__ float dmin_a(float a, float b) { return a < b ? 1.f : (a == b ? 0.5f : 0.f); }
+// gradient on (l, t, r, b) -> gradient on (xc, yc, w, h)
+__device__ __forceinline__ void ltrb_to_xywh(float dl, float dt, float dr, float db, float s, float (&g)[4]) {
+    g[0] += s * (dl + dr); g[1] += s * (dt + db); g[2] += s * (dr - dl) * 0.5f; g[3] += s * (db - dt) * 0.5f;
+}
+
+__global__ __launch_bounds__(64) void layout_losses_kernel(LayoutLossParams p) {
+    __shared__ float sb[16][4];
+    __shared__ int sv[16];
+    __shared__ int aj[16], ac[16];
+    __shared__ float as_[16];
+    const int b = blockIdx.x, k = threadIdx.x, N = p.N;
+    // number of valid boxes in the whole batch (mse / gIoU are means over all valid boxes) and in this sample
+    int tot = 0;
+    for (int i = k; i < p.B * N; i += 64) tot += p.valid[i] ? 1 : 0;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) tot += __shfl_xor(tot, o, 64);
+    const float cnt = tot > 0 ? (float)tot : 1.f;
+    float a[4] = {0.f, 0.f, 0.f, 0.f}, r[4] = {0.f, 0.f, 0.f, 0.f};
+    bool vk = false;
+    if (k < N) {
+        vk = p.valid[b * N + k] != 0;
+#pragma unroll
+        for (int c = 0; c < 4; c++) { a[c] = p.box[((long)b * N + k) * 4 + c]; r[c] = p.ref ? p.ref[((long)b * N + k) * 4 + c] : 0.f; sb[k][c] = a[c]; }
+        sv[k] = vk;
+        aj[k] = -1; ac[k] = 0; as_[k] = 0.f;
+    }
+    __syncthreads();
+    int nb = 0;
+    for (int j = 0; j < N; j++) nb += sv[j];
+    const float inv_nb = 1.f / (float)nb;     // a sample without valid boxes gives 0 / 0 in the reference as well
+
+    float l_mse = 0.f, l_giou = 0.f, l_ovl = 0.f, l_aln = 0.f;
+    float g_mse[4] = {0.f, 0.f, 0.f, 0.f}, g_giou[4] = {0.f, 0.f, 0.f, 0.f}, g_ovl[4] = {0.f, 0.f, 0.f, 0.f}, g_aln[4] = {0.f, 0.f, 0.f, 0.f};
+    if (k < N && vk) {
+        const Ltrb A = to_ltrb(a);
+        const float wA = A.r - A.l, hA = A.b - A.t, a1 = wA * hA;
+        if (p.ref) {
+            // ---- MSE: sum_c (a - r)^2 / (4 cnt)
+#pragma unroll
+            for (int c = 0; c < 4; c++) { const float d = a[c] - r[c]; l_mse += d * d; g_mse[c] = 2.f * d / (4.f * cnt); }
+            l_mse /= 4.f * cnt;
+            // ---- gIoU: per = 2 - ai / au - au / ah, mean over valid boxes
+            const Ltrb R = to_ltrb(r);
+            const float a2 = (R.r - R.l) * (R.b - R.t);
+            const float lmx = fmaxf(A.l, R.l), rmn = fminf(A.r, R.r), tmx = fmaxf(A.t, R.t), bmn = fminf(A.b, R.b);
+            const bool cond = (lmx < rmn) && (tmx < bmn);
+            const float W = rmn - lmx, H = bmn - tmx, ai = cond ? W * H : 0.f;
+            const float au = a1 + a2 - ai;
+            const float lmn = fminf(A.l, R.l), rmx = fmaxf(A.r, R.r), tmn = fminf(A.t, R.t), bmx = fmaxf(A.b, R.b);
+            const float Wh = rmx - lmn, Hh = bmx - tmn, ah = Wh * Hh;
+            l_giou = (1.f - (ai / au - (ah - au) / ah)) / cnt;
+            // derivatives on (l, t, r, b) of the generated box
+            float dai[4] = {0.f, 0.f, 0.f, 0.f};
+            if (cond) { dai[0] = -dmax_a(A.l, R.l) * H; dai[1] = -dmax_a(A.t, R.t) * W; dai[2] = dmin_a(A.r, R.r) * H; dai[3] = dmin_a(A.b, R.b) * W; }
+            const float da1[4] = {-hA, -wA, hA, wA};
+            const float dah[4] = {-dmin_a(A.l, R.l) * Hh, -dmin_a(A.t, R.t) * Wh, dmax_a(A.r, R.r) * Hh, dmax_a(A.b, R.b) * Wh};
+            float dper[4];
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                const float dau = da1[c] - dai[c];
+                const float diou = (dai[c] * au - ai * dau) / (au * au);
+                const float dq = (dau * ah - au * dah[c]) / (ah * ah);     // d (au / ah)
+                dper[c] = -diou - dq;
+            }
+            ltrb_to_xywh(dper[0], dper[1], dper[2], dper[3], 1.f / cnt, g_giou);
+        }
+        // ---- overlap: sum_{j != k} ai_kj / a1_k / n_b  (as box i) and the terms ai_jk / a1_j where k is box j
+        float dl = 0.f, dt = 0.f, dr = 0.f, db = 0.f, sum_ai = 0.f;
+        for (int j = 0; j < N; j++) {
+            if (j == k || !sv[j]) continue;
+            const float x[4] = {sb[j][0], sb[j][1], sb[j][2], sb[j][3]};
+            const Ltrb J = to_ltrb(x);
+            const float a1j = (J.r - J.l) * (J.b - J.t);
+            const float lmx = fmaxf(A.l, J.l), rmn = fminf(A.r, J.r), tmx = fmaxf(A.t, J.t), bmn = fminf(A.b, J.b);
+            if (!((lmx < rmn) && (tmx < bmn))) continue;
+            const float W = rmn - lmx, H = bmn - tmx, ai = W * H;
+            // nan_to_num(ai / a1): a zero-area box contributes nothing and passes no gradient
+            const float wk = a1 != 0.f ? 1.f / a1 : 0.f, wj = a1j != 0.f ? 1.f / a1j : 0.f;
+            if (a1 != 0.f) sum_ai += ai;
+            const float ws = wk + wj;
+            dl += -dmax_a(A.l, J.l) * H * ws; dt += -dmax_a(A.t, J.t) * W * ws;
+            dr += dmin_a(A.r, J.r) * H * ws; db += dmin_a(A.b, J.b) * W * ws;
+        }
+        if (a1 != 0.f) {
+            l_ovl = sum_ai / a1 * inv_nb;
+            const float q = -sum_ai / (a1 * a1);
+            dl += q * -hA; dt += q * -wA; dr += q * hA; db += q * wA;
+        }
+        ltrb_to_xywh(dl, dt, dr, db, inv_nb, g_ovl);
+        // ---- alignment: min over the six edge / centre coordinates and over the OTHER boxes (padded ones included) of |delta|
+        const float X[6] = {A.l, a[0], A.r, A.t, a[1], A.b};
+        float best = 0.f; int bj = -1, bc = 0; float bsign = 0.f; bool have = false;
+        for (int c = 0; c < 6; c++) {
+            float m = 1.f; int mj = k; float ms = 0.f;                      // the diagonal entry is 1 (index j = k)
+            bool first = true;
+            for (int j = 0; j < N; j++) {
+                float v, sg;
+                if (j == k) { v = 1.f; sg = 0.f; }
+                else {
+                    const float x[4] = {sb[j][0], sb[j][1], sb[j][2], sb[j][3]};
+                    const Ltrb J = to_ltrb(x);
+                    const float Xj = c == 0 ? J.l : c == 1 ? x[0] : c == 2 ? J.r : c == 3 ? J.t : c == 4 ? x[1] : J.b;
+                    const float d = X[c] - Xj;
+                    v = fabsf(d); sg = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
+                }
+                if (first || v < m) { m = v; mj = j; ms = sg; first = false; }
+            }
+            if (!have || m < best) { best = m; bj = mj; bc = c; bsign = ms; have = true; }
+        }
+        if (best != 1.f) {
+            l_aln = -logf(1.f - best) * inv_nb;
+            const float s = bsign / (1.f - best) * inv_nb;
+            if (bj != k) { aj[k] = bj; ac[k] = bc; as_[k] = s; }
+            // own coordinate bc: xl, xc, xr, yt, yc, yb
+            if (bc == 0) { g_aln[0] += s; g_aln[2] -= 0.5f * s; } else if (bc == 1) g_aln[0] += s; else if (bc == 2) { g_aln[0] += s; g_aln[2] += 0.5f * s; }
+            else if (bc == 3) { g_aln[1] += s; g_aln[3] -= 0.5f * s; } else if (bc == 4) g_aln[1] += s; else { g_aln[1] += s; g_aln[3] += 0.5f * s; }
+        }
+    }
+    __syncthreads();
+    if (k < N) {
+        // alignment: boxes that were some other box's nearest neighbour receive the opposite gradient (padded boxes too)
+        for (int i = 0; i < N; i++) {
+            if (aj[i] != k) continue;
+            const float s = -as_[i]; const int bc = ac[i];
+            if (bc == 0) { g_aln[0] += s; g_aln[2] -= 0.5f * s; } else if (bc == 1) g_aln[0] += s; else if (bc == 2) { g_aln[0] += s; g_aln[2] += 0.5f * s; }
+            else if (bc == 3) { g_aln[1] += s; g_aln[3] -= 0.5f * s; } else if (bc == 4) g_aln[1] += s; else { g_aln[1] += s; g_aln[3] += 0.5f * s; }
+        }
+        const long per = (long)p.B * N * 4, o = ((long)b * N + k) * 4;
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            p.grads[o + c] = g_mse[c]; p.grads[per + o + c] = g_giou[c]; p.grads[2 * per + o + c] = g_ovl[c]; p.grads[3 * per + o + c] = g_aln[c];
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        l_mse += __shfl_xor(l_mse, o, 64); l_giou += __shfl_xor(l_giou, o, 64);
+        l_ovl += __shfl_xor(l_ovl, o, 64); l_aln += __shfl_xor(l_aln, o, 64);
+    }
+    if (k == 0) { p.losses[b] = l_mse; p.losses[p.B + b] = l_giou; p.losses[2 * p.B + b] = l_ovl; p.losses[3 * p.B + b] = l_aln; }
+}
+
+__global__ __launch_bounds__(256) void layout_losses_bwd_kernel(LayoutLossParams p) {
+    const long per = (long)p.B * p.N * 4;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < per; i += (long)gridDim.x * 256) {
+        const int b = (int)(i / (p.N * 4));
+        float s = 0.f;
+#pragma unroll
+        for (int t = 0; t < 4; t++) s += p.gout[t * p.B + b] * p.grads[t * per + i];
+        p.dbox[i] = s;
+    }
+}
+
+}  // namespace ldetr
+
+using namespace ldetr;
+
+extern "C" int ldetr_layout_losses_f32(const float* bbox, const float* bbox_ref, const uint8_t* valid, int B, int N, float* losses,
+                                       float* grads, void* stream) {
+    LDETR_CHECK(bbox && valid && losses && grads, "layout_losses: null pointer");
+    LDETR_CHECK(B > 0 && N > 0 && N <= 16, "layout_losses: needs 1 <= N <= 16 boxes per sample (got %d)", N);
+    LayoutLossParams p; memset(&p, 0, sizeof(p));
+    p.box = bbox; p.ref = bbox_ref; p.valid = valid; p.losses = losses; p.grads = grads; p.B = B; p.N = N;
+    hipLaunchKernelGGL(layout_losses_kernel, dim3(B), 64, 0, (hipStream_t)stream, p);
+    return check_launch("layout_losses");
+}
+
+extern "C" int ldetr_layout_losses_bwd_f32(const float* grads, const float* grad_losses, int B, int N, float* dbbox, void* stream) {
+    LDETR_CHECK(grads && grad_losses && dbbox, "layout_losses_bwd: null pointer");
+    LDETR_CHECK(B > 0 && N > 0 && N <= 16, "layout_losses_bwd: needs 1 <= N <= 16 boxes per sample (got %d)", N);
+    LayoutLossParams p; memset(&p, 0, sizeof(p));
+    p.grads = const_cast<float*>(grads); p.gout = grad_losses; p.dbox = dbbox; p.B = B; p.N = N;
+    const long per = (long)B * N * 4;
+    hipLaunchKernelGGL(layout_losses_bwd_kernel, dim3((unsigned)((per + 255) / 256 > 1024 ? 1024 : (per + 255) / 256)), 256, 0, (hipStream_t)stream, p);
+    return check_launch("layout_losses_bwd");
+}

@@ -58,6 +58,46 @@ def generalized_iou_loss(layout_1, layout_2):
     return (1.0 - g_iou).mean()
 
 
+class _LayoutLossesFn(torch.autograd.Function):
+    """The four layout losses of the generator phase in one launch (csrc/layout_loss.hip): values and d/d bbox together; the
+    backward is one weighted sum of the saved gradients.  Returns per-sample shares [4, B]."""
+
+    @staticmethod
+    def forward(ctx, bbox, bbox_ref, valid):
+        from ..hip import core
+        core.require_gpu(bbox, bbox_ref, valid)
+        B, N, _ = bbox.shape
+        x = bbox.detach().to(torch.float32).contiguous()
+        r = bbox_ref.detach().to(torch.float32).contiguous()
+        v = valid.to(torch.uint8).contiguous()
+        losses = torch.empty((4, B), device=x.device, dtype=torch.float32)
+        grads = torch.empty((4, B, N, 4), device=x.device, dtype=torch.float32)
+        core.check(core.lib().ldetr_layout_losses_f32(core.ptr(x), core.ptr(r), core.ptr(v), B, N, core.ptr(losses), core.ptr(grads),
+                                                      core.stream()), 'layout_losses')
+        ctx.save_for_backward(grads)
+        ctx.shape = (B, N)
+        return losses
+
+    @staticmethod
+    def backward(ctx, g):
+        from ..hip import core
+        grads, = ctx.saved_tensors
+        B, N = ctx.shape
+        g = g.to(torch.float32).contiguous()
+        d = torch.empty((B, N, 4), device=g.device, dtype=torch.float32)
+        core.check(core.lib().ldetr_layout_losses_bwd_f32(core.ptr(grads), core.ptr(g), B, N, core.ptr(d), core.stream()), 'layout_losses_bwd')
+        return d, None, None
+
+
+def layout_losses_fused(bbox_fake, bbox_real, valid):
+    """(mse_loss(fake[valid], real[valid]), generalized_iou_loss(fake[valid], real[valid]), compute_overlap(fake, valid) [B],
+    compute_alignment(fake, valid) [B]) with gradients to bbox_fake only; N <= 16 boxes per sample, GPU tensors."""
+    if bbox_real.requires_grad:
+        raise NotImplementedError('layout_losses_fused: the reference boxes are data (no gradient is produced for them)')
+    out = _LayoutLossesFn.apply(bbox_fake, bbox_real, valid)
+    return out[0].sum(), out[1].sum(), out[2], out[3]
+
+
 def linear_sum_assignment_batched(cost, maximize=False):
     """Batched Hungarian on device: cost [batch, n, n] float64 -> (row_ind, col_ind) int32 [batch, n], bit-exact with
     scipy.optimize.linear_sum_assignment as used by compute_maximum_iou_for_layout (metric_layoutnet.py:100-113)."""

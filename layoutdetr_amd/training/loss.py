@@ -10,7 +10,7 @@ import torch.nn.functional as F
 
 from ..hip import core
 
-from ..metrics.metric_layoutnet import compute_alignment, compute_overlap, generalized_iou_loss
+from ..metrics.metric_layoutnet import compute_alignment, compute_overlap, generalized_iou_loss, layout_losses_fused
 
 
 def _masked_mse(a, b, valid):
@@ -102,6 +102,7 @@ class StyleGAN2Loss(Loss):
         # gradient (the reference recomputes it, training/loss.py:176-210: two run_D calls, two backward calls).  Same losses and
         # gradients up to fp32 summation order; share_D_trunk=False restores the reference's call pattern.
         self.share_D_trunk = share_D_trunk
+        self.fused_layout_losses = os.environ.get('LDETR_FUSED_LAYOUT_LOSSES', '1') != '0'   # csrc/layout_loss.hip (static-shape path)
         # share_D_trunk='iteration' goes one step further: D's weights do not change between the Gmain and the Dmain phase of one
         # iteration (Gmain updates G only, training_loop.py:281-313), so ONE trunk evaluation per iteration serves D(fake) in Gmain
         # (values only: D is frozen there) and both D passes of Dmain (with its autograd graph).  The iteration driver calls
@@ -160,13 +161,22 @@ class StyleGAN2Loss(Loss):
         bbox_fake, loss_z, cls_logits, loss_lm, loss_text_len = self.run_G(gen_z, bbox_class, bbox_real, bbox_text, bbox_patch, padding_mask, background, gen_c, reconst=True)
         gen_logits, gen_logits_uncond = self.run_D(bbox_fake, bbox_class, bbox_text, bbox_patch, padding_mask, background, gen_c,
                                                    trunk_out=cached if cached is not None else (fork.join() if fork is not None else None))
+        if static and self.fused_layout_losses and bbox_fake.is_cuda and bbox_fake.shape[1] <= 16:
+            # one launch for the four layout terms and their gradients (csrc/layout_loss.hip) instead of ~280 elementwise ones
+            l_rec, l_giou, l_ovl, l_aln = layout_losses_fused(bbox_fake, bbox_real, valid)
+        elif static:
+            l_rec, l_giou = _masked_mse(bbox_fake, bbox_real, valid), _masked_giou(bbox_fake, bbox_real, valid)
+            l_ovl, l_aln = compute_overlap(bbox_fake, valid), compute_alignment(bbox_fake, valid)
+        else:
+            l_rec, l_giou = F.mse_loss(bbox_fake[valid], bbox_real[valid]), generalized_iou_loss(bbox_fake[valid], bbox_real[valid])
+            l_ovl, l_aln = compute_overlap(bbox_fake, valid), compute_alignment(bbox_fake, valid)
         terms = dict(
             loss_Ggen=F.softplus(-gen_logits),
             loss_Ggen_uncond=F.softplus(-gen_logits_uncond),
-            loss_Ggen_bbox_rec=(_masked_mse(bbox_fake, bbox_real, valid) if static else F.mse_loss(bbox_fake[valid], bbox_real[valid])) * w['Ggen_bbox_rec'],
-            loss_Ggen_bbox_gIoU=(_masked_giou(bbox_fake, bbox_real, valid) if static else generalized_iou_loss(bbox_fake[valid], bbox_real[valid])) * w['Ggen_bbox_gIoU'],
-            loss_Ggen_overlapping=compute_overlap(bbox_fake, valid) * w['Ggen_overlapping'],
-            loss_Ggen_alignment=compute_alignment(bbox_fake, valid) * w['Ggen_alignment'],
+            loss_Ggen_bbox_rec=l_rec * w['Ggen_bbox_rec'],
+            loss_Ggen_bbox_gIoU=l_giou * w['Ggen_bbox_gIoU'],
+            loss_Ggen_overlapping=l_ovl * w['Ggen_overlapping'],
+            loss_Ggen_alignment=l_aln * w['Ggen_alignment'],
             loss_Ggen_z_rec=loss_z * w['Ggen_z_rec'],
             loss_Ggen_bbox_cls=(_masked_ce(cls_logits, bbox_class, valid) if static else F.cross_entropy(cls_logits, bbox_class[valid])) * w['Ggen_bbox_cls'],
             loss_Ggen_text_rec=loss_lm * w['Ggen_text_rec'],

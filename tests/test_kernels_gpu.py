@@ -669,3 +669,39 @@ def test_background_resize_normalize_vs_oracle_full_size(dev, n, H, W, S):
         assert np.array_equal(out[i].cpu().numpy(), resample_ref.normalize_chw(ref_u8)), f'image {i}: float'
     one = background_to_tensor(torch.from_numpy(imgs[n - 1]).to(dev), S)
     assert torch.equal(one, out[n - 1])
+
+
+@pytest.mark.parametrize('B,N,seed', [(16, 9, 0), (3, 10, 1), (5, 16, 2), (2, 1, 3), (4, 2, 4)])
+def test_fused_layout_losses_match_reference_formulation(dev, B, N, seed):
+    """csrc/layout_loss.hip: mse / gIoU / overlap / alignment of generated boxes and their gradients in one
+    launch, against the oracle's restatement of the reference functions (golden-pinned in tests/test_oracle_golden.py) run through
+    autograd on the CPU: ragged masks, padded slots with arbitrary contents (compute_alignment looks at them), touching /
+    nested / disjoint boxes, upstream weights per term."""
+    from layoutdetr_amd.metrics.metric_layoutnet import layout_losses_fused
+    from oracle import losses_ref
+    g = torch.Generator().manual_seed(100 + seed)
+    xy = torch.rand(B, N, 2, generator=g) * 0.6 + 0.2; wh = torch.rand(B, N, 2, generator=g) * 0.35 + 0.05
+    fake = torch.cat([xy, wh], -1)
+    real = torch.cat([torch.rand(B, N, 2, generator=g) * 0.6 + 0.2, torch.rand(B, N, 2, generator=g) * 0.35 + 0.05], -1)
+    if N >= 3:
+        fake[0, 1] = fake[0, 0] * torch.tensor([1.0, 1.0, 0.5, 0.5])        # nested box, shared centre
+        fake[0, 2, :2] = fake[0, 0, :2] + 0.9                                 # far away: disjoint
+    valid = torch.ones(B, N, dtype=torch.bool)
+    if N >= 2:
+        valid[-1, N // 2:] = False
+        if B > 1:
+            valid[1, -1] = False
+    wts = torch.tensor([100.0, 4.0, 7.0, 17.0])
+    fr = fake.clone().requires_grad_(True)
+    ref_terms = [F.mse_loss(fr[valid], real[valid]), losses_ref.generalized_iou_loss(fr[valid], real[valid]),
+                 losses_ref.compute_overlap(fr, valid), losses_ref.compute_alignment(fr, valid)]
+    up = torch.rand(B, generator=g) + 0.5
+    total_ref = ref_terms[0] * wts[0] + ref_terms[1] * wts[1] + (ref_terms[2] * up).sum() * wts[2] + (ref_terms[3] * up).mean() * wts[3]
+    total_ref.backward()
+    fg = fake.to(dev).requires_grad_(True)
+    out = layout_losses_fused(fg, real.to(dev), valid.to(dev))
+    total = out[0] * wts[0] + out[1] * wts[1] + (out[2] * up.to(dev)).sum() * wts[2] + (out[3] * up.to(dev)).mean() * wts[3]
+    total.backward()
+    for name, a, b in zip(('mse', 'giou', 'overlap', 'alignment'), out, ref_terms):
+        assert_close(a, b.detach(), 2e-5, name)
+    assert_close(fg.grad, fr.grad, 5e-5, 'd bbox')
