@@ -23,6 +23,7 @@
  *                                 training/training_loop.py:303-313, 320-328
  *   ldetr_softmax_xent_*_f32, ldetr_embedding_*_f32
  *                                 LM text decoder head: training/med.py:60-61,88-94 (embeddings), 911-916 (loss)
+ *   ldetr_demod_*_f32             demodulation coefficients of modulated_conv2d: training/networks_stylegan2.py:57-61
  *   ldetr_layout_losses_*_f32     compute_overlap / compute_alignment / generalized_iou_loss / mse on the generated boxes:
  *                                 metrics/metric_layoutnet.py:153-201,245-275, training/loss.py:94-97
  *   ldetr_resample_coeffs, ldetr_resize_normalize_u8
@@ -205,6 +206,17 @@ int ldetr_resize_normalize_u8(const uint8_t* src, int64_t images, int H, int W, 
                               const int32_t* hweights, int hksize, const int32_t* vbounds, const int32_t* vweights, int vksize,
                               uint8_t* tmp, uint8_t* out_u8, float* out_chw, float mean0, float mean1, float mean2, float std0,
                               float std1, float std2, void* stream);
+
+/* Demodulation coefficients of the modulated convolution (training/networks_stylegan2.py:57-61), forward and backward:
+ * dcoefs[b][o] = rsqrt(sum_{i,kh,kw} (weight[o][i][kh][kw] * styles[b][i])^2 + eps).  weight is addressed through its element
+ * strides (so, si, sh, sw): OIHW or channels_last memory.  fwd also writes w2[o][i] = sum_taps weight^2 for the backward.
+ * bwd: dweight (same strides as weight; += when accumulate_dweight != 0; may be NULL) and dstyles [B][I] (may be NULL) from
+ * grad_dcoefs [B][O].  B <= 64. */
+int ldetr_demod_fwd_f32(const float* weight, int64_t so, int64_t si, int64_t sh, int64_t sw, const float* styles, float* dcoefs,
+                        float* w2, int B, int O, int I, int KH, int KW, float eps, void* stream);
+int ldetr_demod_bwd_f32(const float* weight, int64_t so, int64_t si, int64_t sh, int64_t sw, const float* styles, const float* dcoefs,
+                        const float* w2, const float* grad_dcoefs, float* dweight, int accumulate_dweight, float* dstyles, int B, int O,
+                        int I, int KH, int KW, void* stream);
 
 /* The generator phase's four layout losses on one set of generated boxes, fused with their gradients (training/loss.py:94,
  * metrics/metric_layoutnet.py:153-201,245-275): bbox, bbox_ref [B][N][4] (xc, yc, w, h), valid [B][N] (non-zero = real element),

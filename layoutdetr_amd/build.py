@@ -20,7 +20,7 @@ LIBNAME = 'libldetr_hip.so'
 ARCH = 'gfx950'
 
 SOURCES = ['ldetr_core.cpp', 'bias_act.hip', 'upfirdn2d.hip', 'gemm_conv.hip', 'attention.hip', 'layernorm.hip',
-           'misc_ops.hip', 'optim.hip', 'lsap.hip', 'xent.hip', 'resample.hip', 'layout_loss.hip']
+           'misc_ops.hip', 'optim.hip', 'lsap.hip', 'xent.hip', 'resample.hip', 'layout_loss.hip', 'demod.hip']
 HEADERS = ['ldetr_common.hpp', os.path.join('..', '..', 'include', 'ldetr_hip.h')]
 
 FLAGS = ['-O3', '-std=c++17', '-fPIC', f'--offload-arch={ARCH}', '-munsafe-fp-atomics', '-fno-gpu-rdc',

@@ -186,12 +186,52 @@ class _ToRGBFn(torch.autograd.Function):
         return dx, dw, ds, dbias
 
 
+class _DemodFn(torch.autograd.Function):
+    """dcoefs[b,o] = rsqrt(sum_{i,kh,kw} (w[o,i,kh,kw] * s[b,i])^2 + 1e-8)  (networks_stylegan2.py:57-61) as one launch
+    (csrc/demod.hip: the sum over taps of w^2 once per output channel, then a dot product per sample) and two for the backward,
+    the weight gradient going straight into the flat gradient buffer when there is one."""
+
+    @staticmethod
+    def forward(ctx, weight, styles):
+        core.require_gpu(weight, styles)
+        w = weight.detach()
+        if w.dtype != torch.float32:
+            w = w.float()
+        s = core.f32c(styles.detach())
+        O, I, KH, KW = w.shape
+        B = s.shape[0]
+        d = torch.empty((B, O), device=s.device, dtype=torch.float32)
+        w2 = torch.empty((O, I), device=s.device, dtype=torch.float32)
+        st = w.stride()
+        core.check(core.lib().ldetr_demod_fwd_f32(core.ptr(w), st[0], st[1], st[2], st[3], core.ptr(s), core.ptr(d), core.ptr(w2),
+                                                  B, O, I, KH, KW, 1e-8, core.stream()), 'demod_fwd')
+        ctx.save_for_backward(w, s, d, w2)
+        ctx.wparam = weight
+        return d
+
+    @staticmethod
+    def backward(ctx, g):
+        w, s, d, w2 = ctx.saved_tensors
+        O, I, KH, KW = w.shape
+        B = s.shape[0]
+        g = core.f32c(g)
+        need_w, need_s = ctx.needs_input_grad
+        acc = core.flat_grad(ctx.wparam) if need_w else None
+        accumulate = acc is not None and acc.stride() == w.stride()
+        dw = acc if accumulate else (torch.empty_strided(w.shape, w.stride(), device=w.device, dtype=torch.float32) if need_w else None)
+        ds = torch.empty_like(s) if need_s else None
+        st = w.stride()
+        core.check(core.lib().ldetr_demod_bwd_f32(core.ptr(w), st[0], st[1], st[2], st[3], core.ptr(s), core.ptr(d), core.ptr(w2), core.ptr(g),
+                                                  core.ptr(dw), 1 if accumulate else 0, core.ptr(ds), B, O, I, KH, KW, core.stream()), 'demod_bwd')
+        return (None if accumulate else dw), ds
+
+
 def demod_coefs(weight, styles):
-    """dcoefs[b,o] = rsqrt(sum_{i,kh,kw} (w[o,i,kh,kw] * s[b,i])^2 + 1e-8)  (networks_stylegan2.py:57-61), evaluated as
-    a [B,I]x[I,O] GEMM over squared operands instead of materialising the [B,O,I,k,k] tensor."""
-    from .linear import linear
-    w2 = weight.square().sum(dim=[2, 3])          # [O, I]
-    return (linear(styles.square(), w2) + 1e-8).rsqrt()
+    """Demodulation coefficients [B, O] of a modulated convolution."""
+    if styles.shape[0] > 64:       # the fused kernels keep one value per sample in LDS; larger micro-batches take the GEMM form
+        from .linear import linear
+        return (linear(styles.square(), weight.square().sum(dim=[2, 3])) + 1e-8).rsqrt()
+    return _DemodFn.apply(weight, styles)
 
 
 def modconv3x3(x, weight, styles, bias, act_alpha=0.2, act_gain=math.sqrt(2)):

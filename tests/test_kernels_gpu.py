@@ -705,3 +705,25 @@ def test_fused_layout_losses_match_reference_formulation(dev, B, N, seed):
     for name, a, b in zip(('mse', 'giou', 'overlap', 'alignment'), out, ref_terms):
         assert_close(a, b.detach(), 2e-5, name)
     assert_close(fg.grad, fr.grad, 5e-5, 'd bbox')
+
+
+@pytest.mark.parametrize('B,O,I,K,cl', [(16, 512, 512, 3, True), (4, 64, 128, 3, False), (2, 32, 32, 1, False), (3, 100, 36, 3, True)])
+def test_demod_coefficients_fwd_bwd(dev, B, O, I, K, cl):
+    """Fused demodulation coefficients (csrc/demod.hip) vs the reference's formulation through autograd
+    (networks_stylegan2.py:57-61: (w[None] * s[:, None, :, None, None]).square().sum([2, 3, 4]) + 1e-8).rsqrt()), both parameter
+    memory layouts, gradients to the weight and to the styles."""
+    from layoutdetr_amd.hip.modconv import _DemodFn
+    torch.manual_seed(60)
+    w = torch.randn(O, I, K, K) * 0.3; s = torch.randn(B, I); g = torch.randn(B, O)
+    wr = w.clone().requires_grad_(True); sr = s.clone().requires_grad_(True)
+    ref = ((wr.unsqueeze(0) * sr.reshape(B, 1, I, 1, 1)).square().sum(dim=[2, 3, 4]) + 1e-8).rsqrt()
+    ref.backward(g)
+    wd = w.to(dev)
+    if cl:
+        wd = wd.contiguous(memory_format=torch.channels_last)
+    wd.requires_grad_(True); sd = s.to(dev).requires_grad_(True)
+    out = _DemodFn.apply(wd, sd)
+    out.backward(g.to(dev))
+    assert_close(out, ref.detach(), 5e-6, 'dcoefs')
+    assert_close(wd.grad, wr.grad, 2e-5, 'dweight')
+    assert_close(sd.grad, sr.grad, 2e-5, 'dstyles')
