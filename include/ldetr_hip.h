@@ -44,6 +44,11 @@ const char* ldetr_last_error(void);
 /* ABI version; bumped whenever a signature changes. */
 int ldetr_abi_version(void);
 
+/* Development aid (tools/trace_tiles.py): while `buffer` (device memory, 5 int64 per block of the traced launch) is non-NULL,
+ * every block of the LDS-tiled contraction kernel records wall-clock stamps (100 MHz) at entry, after its prologue, after its
+ * main loop and at exit, and its (XCC_ID << 32 | HW_ID) placement word.  Pass NULL to switch it off (the default). */
+int ldetr_debug_trace_tiles(int64_t* buffer);
+
 /* Scratch memory for the contraction engine's in-kernel split-K reduction on the calling thread's current device.
  * `ptr`: zero-filled, 16-byte aligned device memory the caller keeps alive and uses from one stream at a time
  * (the first 1 MiB holds per-tile arrival counters, the rest partial tiles; both are handed out as rings, a fresh

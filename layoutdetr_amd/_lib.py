@@ -64,6 +64,7 @@ SIGNATURES = {
     'ldetr_softmax_xent_bwd_f32': [_P, _L, _P, _P, _P, _P, _P, _L, _L, _I, _L, _F, _P],
     'ldetr_embedding_fwd_f32': [_P, _P, _P, _P, _L, _I, _I, _I, _P],
     'ldetr_embedding_bwd_f32': [_P, _P, _P, _L, _I, _I, _L, _P],
+    'ldetr_debug_trace_tiles': [_P],
     'ldetr_demod_fwd_f32': [_P, _L, _L, _L, _L, _P, _P, _P, _I, _I, _I, _I, _I, _F, _P],
     'ldetr_demod_bwd_f32': [_P, _L, _L, _L, _L, _P, _P, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _P],
     'ldetr_layout_losses_f32': [_P, _P, _P, _I, _I, _P, _P, _P],
@@ -93,7 +94,7 @@ def load():
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported
         fn.restype = c_int
         fn.argtypes = argtypes
-    if lib.ldetr_abi_version() != 11:
+    if lib.ldetr_abi_version() != 12:
         raise RuntimeError('libldetr_hip.so ABI version mismatch; rebuild it')
     _lib = lib
     return lib

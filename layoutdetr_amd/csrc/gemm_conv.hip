@@ -90,6 +90,8 @@ struct GemmParams {
     int ep_vec;          // host-checked: every epilogue operand is float4-addressable -> LDS-staged row-major epilogue
     float* ws;           // split-K fix-up: per-(tile, slice) partial tiles; null = fp32 atomics into C
     int* ws_count;       //   per-tile arrival counters (zero between launches)
+    int fast_loads;      // bit 0: scalar-addressed A (conv) loads, bit 1: B (dense weight) loads; LDETR_FAST_LOADS, default 3
+    long long* trace;    // development aid (tools/trace_tiles.py): 4 wall-clock stamps per block, or null
     GemmEpilogue ep;
 };
 
@@ -374,6 +376,7 @@ __global__ __launch_bounds__(NWV * 64) void gemm_f32_kernel(GemmParams p) {
     float (*As)[BKT][LDA] = reinterpret_cast<float (*)[BKT][LDA]>(ldetr_smem);
     float (*Bs)[BKT][LDB] = reinterpret_cast<float (*)[BKT][LDB]>(ldetr_smem + 2 * BKT * LDA);
 
+    const long long tr0 = p.trace ? wall_clock64() : 0;
     const ZCtx z = make_zctx<BKT>(p);
     const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
     if (m0 >= z.M) return;  // uniform per block (parity classes may be smaller than the launch grid)
@@ -411,6 +414,54 @@ __global__ __launch_bounds__(NWV * 64) void gemm_f32_kernel(GemmParams p) {
         }
     }
 
+    // Scalar-addressed operand loads.  PMC on the ResNet 3x3 shapes: ~100 VALU instructions per wave per k-tile went into the
+    // gather addressing (tap decode, bounds tests, 64-bit address arithmetic per float4 unit) next to 16 MFMAs, and VALU issue
+    // does not overlap the matrix pipe on this part: the loop ran at 64 % MFMA utilisation, 93 % with the loads removed.  When the
+    // channel count is a multiple of the k-tile, a whole k-tile lies inside ONE filter tap, so tap and channel offset are
+    // block-uniform: they live in SGPRs and go into the buffer load's scalar offset; each unit keeps a byte offset of its pixel
+    // (computed once) and a bit mask of the taps that fall inside the image.  Per unit and k-tile: one bit test, one select, one
+    // buffer_load_dwordx4 (an out-of-range vector offset returns zeros: that is the padding).
+    constexpr bool A_FAST = (AMODE == OP_KC_CONV), B_FAST = (BMODE == OP_KC_DENSE);
+    bool fastA = false, fastB = false;
+    int a_voff[NUA]; unsigned a_msk[NUA]; int b_voff[NUB];
+    __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.A.p), 0, 0, 0x00020000), rsB = rsA;
+    int f_c0 = 0, f_tx = 0, f_ty = 0, f_tap = 0;   // tap / channel of the next k-tile to load (block-uniform)
+    if constexpr (A_FAST) {
+        const long padoff = (long)p.A.pad * p.A.sh + (long)p.A.pad * p.A.sw;
+        const long span = (long)p.nsamp * p.A.sn + padoff;
+        fastA = (p.fast_loads & 1) && p.A.vec && p.zmode == 0 && (p.A.C % BKT) == 0 && p.A.C >= 2 * BKT && z.tm.nty * z.tm.ntx <= 32 && span * 4 < 0x7fffffffL && p.samp_pix == 0;   // (C == k-tile: measured slower, 483 vs 420 us on the 32-channel 256^2 layer)
+        if (fastA) {
+            rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.A.p) - padoff, 0, 0x7fffffff, 0x00020000);
+#pragma unroll
+            for (int i = 0; i < NUA; i++) {
+                const RowCtx& rc = a_rc[i];
+                a_voff[i] = (int)((rc.base + (long)(rc.y + p.A.pad) * p.A.sh + (long)(rc.x + p.A.pad) * p.A.sw + a_k[i]) * 4);
+                // taps inside the image: ty in [ylo, yhi), tx in [xlo, xhi) -- closed form, then one OR per valid tap row
+                unsigned m = 0;
+                if (rc.valid) {
+                    const int ylo = max(0, -rc.y), yhi = min(z.tm.nty, p.A.SH - rc.y);
+                    const int xlo = max(0, -rc.x), xhi = min(z.tm.ntx, p.A.SW - rc.x);
+                    if (xhi > xlo) {
+                        const unsigned xm = ((1u << xhi) - 1u) & ~((1u << xlo) - 1u);
+                        for (int ty = ylo; ty < yhi; ty++) m |= xm << (ty * z.tm.ntx);
+                    }
+                }
+                a_msk[i] = m;
+            }
+            f_tap = z.kbeg / p.A.C; f_c0 = z.kbeg - f_tap * p.A.C;
+            f_ty = f_tap / z.tm.ntx; f_tx = f_tap - f_ty * z.tm.ntx;
+        }
+    }
+    if constexpr (B_FAST) {
+        fastB = (p.fast_loads & 2) && p.B.vec && (z.K % BKT) == 0 && (long)p.N * p.B.ld * 4 < 0x7fffffffL && ((z.kend - z.kbeg) % BKT) == 0;
+        if (fastB) {
+            rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.B.p), 0, 0x7fffffff, 0x00020000);
+#pragma unroll
+            for (int i = 0; i < NUB; i++) b_voff[i] = b_rc[i].valid ? (int)((b_rc[i].base + b_k[i]) * 4) : (int)0x80000000;
+        }
+    }
+    auto as_float4 = [](auto v) { return make_float4(__int_as_float(v[0]), __int_as_float(v[1]), __int_as_float(v[2]), __int_as_float(v[3])); };
+
     f32x16 acc[TM][TN];
 #pragma unroll
     for (int i = 0; i < TM; i++)
@@ -425,6 +476,19 @@ __global__ __launch_bounds__(NWV * 64) void gemm_f32_kernel(GemmParams p) {
     auto gload = [&](int k0, float4 (&ra)[NUA], float4 (&rb)[NUB]) {
 #pragma unroll
         for (int i = 0; i < NUA; i++) {
+            if constexpr (A_FAST) {
+                if (fastA) {
+                    const int soff = (f_ty * (int)p.A.sh + f_tx * (int)p.A.sw + f_c0) * 4;
+                    const bool tap_ok = (a_msk[i] >> f_tap) & 1u;
+                    const int vo = tap_ok ? a_voff[i] : (int)0x80000000;
+                    ra[i] = as_float4(__builtin_amdgcn_raw_buffer_load_b128(rsA, vo, soff, 0));
+                    if (p.A.scale && tap_ok) {   // (rows past the end carry no sample index: never touch the scale table for them)
+                        const float4 sc = *reinterpret_cast<const float4*>(p.A.scale + (long)a_rc[i].samp * p.A.scale_ld + f_c0 + a_k[i]);
+                        ra[i].x *= sc.x; ra[i].y *= sc.y; ra[i].z *= sc.z; ra[i].w *= sc.w;
+                    }
+                    continue;
+                }
+            }
             if constexpr (A_KC) {
                 ra[i] = load_kc<AMODE>(p.A, z, a_rc[i], k0 + a_k[i], a_d[i]);
                 if constexpr (AMODE != OP_KC_DENSE) kdec_step_tap(a_d[i], z.tm, BKT, p.A.C);
@@ -434,8 +498,17 @@ __global__ __launch_bounds__(NWV * 64) void gemm_f32_kernel(GemmParams p) {
                 if constexpr (AMODE == OP_RC_PIX || AMODE == OP_RC_CONVK) kdec_step_pix(a_d[i], BKT, p.A.DH, p.A.DW);
             }
         }
+        if constexpr (A_FAST) {
+            if (fastA) {   // next k-tile: 32 channels further, or the next tap
+                f_c0 += BKT;
+                if (f_c0 >= p.A.C) { f_c0 = 0; f_tap++; f_tx++; if (f_tx == z.tm.ntx) { f_tx = 0; f_ty++; } }
+            }
+        }
 #pragma unroll
         for (int i = 0; i < NUB; i++) {
+            if constexpr (B_FAST) {
+                if (fastB) { rb[i] = as_float4(__builtin_amdgcn_raw_buffer_load_b128(rsB, b_voff[i], k0 * 4, 0)); continue; }
+            }
             if constexpr (B_KC) {
                 rb[i] = load_kc<BMODE>(p.B, z, b_rc[i], k0 + b_k[i], b_d[i]);
                 if constexpr (BMODE != OP_KC_DENSE) kdec_step_tap(b_d[i], z.tm, BKT, p.B.C);
@@ -502,8 +575,10 @@ __global__ __launch_bounds__(NWV * 64) void gemm_f32_kernel(GemmParams p) {
         gload(z.kbeg, ra0, rb0);
         lstore(0, ra0, rb0);
     }
+    long long tr1 = 0, tr2 = 0;
     {
         __syncthreads();
+        if (p.trace) tr1 = wall_clock64();
         for (int kt = 0; kt < nk; kt++) {
             const int buf = kt & 1;
             if (kt + 1 < nk) gload(z.kbeg + (kt + 1) * BKT, ra0, rb0);
@@ -513,6 +588,14 @@ __global__ __launch_bounds__(NWV * 64) void gemm_f32_kernel(GemmParams p) {
         }
     }
 
+    if (p.trace) tr2 = wall_clock64();
+    auto trace_out = [&]() {
+        if (p.trace && threadIdx.x == 0) {
+            long long* t = p.trace + 5 * (((long)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x);
+            t[0] = tr0; t[1] = tr1; t[2] = tr2; t[3] = wall_clock64();
+            t[4] = ((long long)__builtin_amdgcn_s_getreg(20 | (31 << 11)) << 32) | (unsigned)__builtin_amdgcn_s_getreg(4 | (31 << 11));   // XCC_ID, HW_ID
+        }
+    };
     // Split-K fix-up: every slice parks its raw tile in the workspace (register order, so all traffic is coalesced), the slice
     // that arrives last at the tile's counter sums the slices in slice order (deterministic, unlike the atomic path) and
     // carries on into the ordinary fused epilogue.  No zero-fill of C and no second epilogue launch.
@@ -542,7 +625,7 @@ __global__ __launch_bounds__(NWV * 64) void gemm_f32_kernel(GemmParams p) {
             if (s_last) __hip_atomic_store(p.ws_count + tile, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         __syncthreads();
-        if (!s_last) return;
+        if (!s_last) { trace_out(); return; }
 #pragma unroll
         for (int i = 0; i < TM; i++)
 #pragma unroll
@@ -618,7 +701,7 @@ __global__ __launch_bounds__(NWV * 64) void gemm_f32_kernel(GemmParams p) {
                 *reinterpret_cast<float4*>(dst) = o;
             }
         }
-        return;
+        trace_out(); return;
     }
     float cs[TN], cb[TN], sfc[TN];
 #pragma unroll
@@ -660,6 +743,7 @@ __global__ __launch_bounds__(NWV * 64) void gemm_f32_kernel(GemmParams p) {
             }
         }
     }
+    trace_out();
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1136,8 +1220,13 @@ static int zero_fill(float* dst, long pitch, long width, long rows, hipStream_t 
     return check_launch("zero_fill");
 }
 
+static long long* g_trace_buffer = nullptr;   // ldetr_debug_trace_tiles
+
 template <int BM, int BN, int BKT, int AMODE, int BMODE, int NWV = 4>
-static int launch_tile(const GemmParams& p, dim3 grid, hipStream_t st) {
+static int launch_tile(GemmParams& p, dim3 grid, hipStream_t st) {
+    p.trace = g_trace_buffer;
+    static const int fast_loads = getenv("LDETR_FAST_LOADS") ? atoi(getenv("LDETR_FAST_LOADS")) : 3;
+    p.fast_loads = fast_loads;
     constexpr size_t lds = (size_t)2 * BKT * ((BM + 2) + (BN + 2)) * sizeof(float);
     auto kern = gemm_f32_kernel<BM, BN, BKT, AMODE, BMODE, NWV>;
     if (lds > 64 * 1024) {
@@ -1289,6 +1378,11 @@ using namespace ldetr;
 
 // Scratch memory for the in-kernel split-K reduction on the calling thread's current device.  `ptr` must be zero-filled
 // device memory that stays alive (and is used by one stream at a time); null/0 unregisters (atomic split-K path).
+extern "C" int ldetr_debug_trace_tiles(int64_t* buffer) {
+    g_trace_buffer = reinterpret_cast<long long*>(buffer);
+    return LDETR_OK;
+}
+
 extern "C" int ldetr_set_workspace(void* ptr, int64_t bytes) {
     int dev = 0;
     LDETR_CHECK(hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64, "set_workspace: no current device");
