@@ -90,7 +90,6 @@ struct GemmParams {
     int ep_vec;          // host-checked: every epilogue operand is float4-addressable -> LDS-staged row-major epilogue
     float* ws;           // split-K fix-up: per-(tile, slice) partial tiles; null = fp32 atomics into C
     int* ws_count;       //   per-tile arrival counters (zero between launches)
-    int fast_loads;      // bit 0: scalar-addressed A (conv) loads, bit 1: B (dense weight) loads; LDETR_FAST_LOADS, default 3
     long long* trace;    // development aid (tools/trace_tiles.py): 4 wall-clock stamps per block, or null
     GemmEpilogue ep;
 };
@@ -360,7 +359,7 @@ __device__ __forceinline__ float apply_epilogue(const GemmEpilogue& ep, float v,
 
 // NWV waves per block: 4 (2x2 wave grid) or 8 (2x4: same tile, half the accumulators per wave, twice the waves per SIMD to
 // cover each other's barrier / staging phases).
-template <int BM, int BN, int BKT, int AMODE, int BMODE, int NWV>
+template <int BM, int BN, int BKT, int AMODE, int BMODE, int NWV, bool FAST>
 __global__ __launch_bounds__(NWV * 64) void gemm_f32_kernel(GemmParams p) {
     constexpr int NT = NWV * 64;
     constexpr int WGN = (NWV == 8 && BN >= 128) ? 4 : 2, WGM = NWV / WGN;
@@ -376,7 +375,10 @@ __global__ __launch_bounds__(NWV * 64) void gemm_f32_kernel(GemmParams p) {
     float (*As)[BKT][LDA] = reinterpret_cast<float (*)[BKT][LDA]>(ldetr_smem);
     float (*Bs)[BKT][LDB] = reinterpret_cast<float (*)[BKT][LDB]>(ldetr_smem + 2 * BKT * LDA);
 
-    const long long tr0 = p.trace ? wall_clock64() : 0;
+#ifndef LDETR_TILE_TRACE
+#define LDETR_TILE_TRACE 1
+#endif
+    const long long tr0 = (LDETR_TILE_TRACE && p.trace) ? wall_clock64() : 0;
     const ZCtx z = make_zctx<BKT>(p);
     const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
     if (m0 >= z.M) return;  // uniform per block (parity classes may be smaller than the launch grid)
@@ -421,15 +423,19 @@ __global__ __launch_bounds__(NWV * 64) void gemm_f32_kernel(GemmParams p) {
     // block-uniform: they live in SGPRs and go into the buffer load's scalar offset; each unit keeps a byte offset of its pixel
     // (computed once) and a bit mask of the taps that fall inside the image.  Per unit and k-tile: one bit test, one select, one
     // buffer_load_dwordx4 (an out-of-range vector offset returns zeros: that is the padding).
-    constexpr bool A_FAST = (AMODE == OP_KC_CONV), B_FAST = (BMODE == OP_KC_DENSE);
-    bool fastA = false, fastB = false;
+    // FAST is chosen by the host (fast_operands_ok in launch_gemm checks every condition below); the generic instantiation carries
+    // none of this code (as runtime branches it slowed the generic path of the 32-channel 256^2 layer from 420 to 510 us).
+    constexpr bool A_FAST = FAST && (AMODE == OP_KC_CONV || AMODE == OP_KC_CONVT || AMODE == OP_KC_DENSE);
+    constexpr bool B_FAST = FAST && (BMODE == OP_KC_DENSE || BMODE == OP_RC_WT);
+    constexpr bool TAP_STATE = FAST && (AMODE == OP_KC_CONV || AMODE == OP_KC_CONVT || BMODE == OP_RC_WT);
+    constexpr bool fastA = A_FAST, fastB = B_FAST;
     int a_voff[NUA]; unsigned a_msk[NUA]; int b_voff[NUB];
     __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.A.p), 0, 0, 0x00020000), rsB = rsA;
     int f_c0 = 0, f_tx = 0, f_ty = 0, f_tap = 0;   // tap / channel of the next k-tile to load (block-uniform)
-    if constexpr (A_FAST) {
+    const int f_C = A_KC ? p.A.C : p.B.C;           // channels per tap of the reduction index
+    constexpr bool k_tiles_in_taps = TAP_STATE;
+    if constexpr (FAST && AMODE == OP_KC_CONV) {
         const long padoff = (long)p.A.pad * p.A.sh + (long)p.A.pad * p.A.sw;
-        const long span = (long)p.nsamp * p.A.sn + padoff;
-        fastA = (p.fast_loads & 1) && p.A.vec && p.zmode == 0 && (p.A.C % BKT) == 0 && p.A.C >= 2 * BKT && z.tm.nty * z.tm.ntx <= 32 && span * 4 < 0x7fffffffL && p.samp_pix == 0;   // (C == k-tile: measured slower, 483 vs 420 us on the 32-channel 256^2 layer)
         if (fastA) {
             rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.A.p) - padoff, 0, 0x7fffffff, 0x00020000);
 #pragma unroll
@@ -448,16 +454,59 @@ __global__ __launch_bounds__(NWV * 64) void gemm_f32_kernel(GemmParams p) {
                 }
                 a_msk[i] = m;
             }
-            f_tap = z.kbeg / p.A.C; f_c0 = z.kbeg - f_tap * p.A.C;
-            f_ty = f_tap / z.tm.ntx; f_tx = f_tap - f_ty * z.tm.ntx;
         }
     }
-    if constexpr (B_FAST) {
-        fastB = (p.fast_loads & 2) && p.B.vec && (z.K % BKT) == 0 && (long)p.N * p.B.ld * 4 < 0x7fffffffL && ((z.kend - z.kbeg) % BKT) == 0;
+    if constexpr (FAST && AMODE == OP_KC_CONVT) {
+        // data gradient of a strided conv, one parity class per blockIdx.z: source pixel of tap (ty, tx) is (sy0 - ty, sx0 - tx) with
+        // sy0 = (y - kh0) / stride exact; the descriptor base is moved back by the largest tap offset so the scalar offset
+        // ((nty-1-ty) sh + (ntx-1-tx) sw + c0) stays non-negative
+        const long shift = (long)(z.tm.nty - 1) * p.A.sh + (long)(z.tm.ntx - 1) * p.A.sw;
+        if (fastA) {
+            rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.A.p) - shift, 0, 0x7fffffff, 0x00020000);
+#pragma unroll
+            for (int i = 0; i < NUA; i++) {
+                const RowCtx& rc = a_rc[i];
+                unsigned m = 0; int vo = 0;
+                if (rc.valid) {
+                    const int sy0 = (rc.y - z.tm.kh0) / p.A.stride, sx0 = (rc.x - z.tm.kw0) / p.A.stride;
+                    vo = (int)((rc.base + (long)sy0 * p.A.sh + (long)sx0 * p.A.sw + a_k[i]) * 4);
+                    const int ylo = max(0, sy0 - p.A.SH + 1), yhi = min(z.tm.nty, sy0 + 1);
+                    const int xlo = max(0, sx0 - p.A.SW + 1), xhi = min(z.tm.ntx, sx0 + 1);
+                    if (xhi > xlo) {
+                        const unsigned xm = ((1u << xhi) - 1u) & ~((1u << xlo) - 1u);
+                        for (int ty = ylo; ty < yhi; ty++) m |= xm << (ty * z.tm.ntx);
+                    }
+                }
+                a_voff[i] = vo; a_msk[i] = m;
+            }
+        }
+    }
+    if constexpr (FAST && AMODE == OP_KC_DENSE) {
+        if (fastA) {
+            rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.A.p), 0, 0x7fffffff, 0x00020000);
+#pragma unroll
+            for (int i = 0; i < NUA; i++) a_voff[i] = a_rc[i].valid ? (int)((a_rc[i].base + a_k[i]) * 4) : (int)0x80000000;
+        }
+    }
+    if constexpr (FAST && BMODE == OP_KC_DENSE) {
         if (fastB) {
             rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.B.p), 0, 0x7fffffff, 0x00020000);
 #pragma unroll
             for (int i = 0; i < NUB; i++) b_voff[i] = b_rc[i].valid ? (int)((b_rc[i].base + b_k[i]) * 4) : (int)0x80000000;
+        }
+    }
+    if constexpr (FAST && BMODE == OP_RC_WT) {
+        // weights read row-contiguous: element (k = (tap, c), r) at c * ld + tap * Cr + r; tap and c0 are block-uniform per k-tile
+        if (fastB) {
+            rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.B.p), 0, 0x7fffffff, 0x00020000);
+#pragma unroll
+            for (int i = 0; i < NUB; i++) b_voff[i] = (n0 + b_r[i] < p.N) ? (int)(((long)b_k[i] * p.B.ld + n0 + b_r[i]) * 4) : (int)0x80000000;
+        }
+    }
+    if constexpr (TAP_STATE) {
+        if (k_tiles_in_taps) {
+            f_tap = z.kbeg / f_C; f_c0 = z.kbeg - f_tap * f_C;
+            f_ty = f_tap / z.tm.ntx; f_tx = f_tap - f_ty * z.tm.ntx;
         }
     }
     auto as_float4 = [](auto v) { return make_float4(__int_as_float(v[0]), __int_as_float(v[1]), __int_as_float(v[2]), __int_as_float(v[3])); };
@@ -478,13 +527,18 @@ __global__ __launch_bounds__(NWV * 64) void gemm_f32_kernel(GemmParams p) {
         for (int i = 0; i < NUA; i++) {
             if constexpr (A_FAST) {
                 if (fastA) {
-                    const int soff = (f_ty * (int)p.A.sh + f_tx * (int)p.A.sw + f_c0) * 4;
-                    const bool tap_ok = (a_msk[i] >> f_tap) & 1u;
-                    const int vo = tap_ok ? a_voff[i] : (int)0x80000000;
-                    ra[i] = as_float4(__builtin_amdgcn_raw_buffer_load_b128(rsA, vo, soff, 0));
-                    if (p.A.scale && tap_ok) {   // (rows past the end carry no sample index: never touch the scale table for them)
-                        const float4 sc = *reinterpret_cast<const float4*>(p.A.scale + (long)a_rc[i].samp * p.A.scale_ld + f_c0 + a_k[i]);
-                        ra[i].x *= sc.x; ra[i].y *= sc.y; ra[i].z *= sc.z; ra[i].w *= sc.w;
+                    if constexpr (AMODE == OP_KC_DENSE) {
+                        ra[i] = as_float4(__builtin_amdgcn_raw_buffer_load_b128(rsA, a_voff[i], k0 * 4, 0));
+                    } else {
+                        const int soff = AMODE == OP_KC_CONV ? (f_ty * (int)p.A.sh + f_tx * (int)p.A.sw + f_c0) * 4
+                                                             : ((z.tm.nty - 1 - f_ty) * (int)p.A.sh + (z.tm.ntx - 1 - f_tx) * (int)p.A.sw + f_c0) * 4;
+                        const bool tap_ok = (a_msk[i] >> f_tap) & 1u;
+                        const int vo = tap_ok ? a_voff[i] : (int)0x80000000;
+                        ra[i] = as_float4(__builtin_amdgcn_raw_buffer_load_b128(rsA, vo, soff, 0));
+                        if (p.A.scale && tap_ok) {   // (rows past the end carry no sample index: never touch the scale table for them)
+                            const float4 sc = *reinterpret_cast<const float4*>(p.A.scale + (long)a_rc[i].samp * p.A.scale_ld + f_c0 + a_k[i]);
+                            ra[i].x *= sc.x; ra[i].y *= sc.y; ra[i].z *= sc.z; ra[i].w *= sc.w;
+                        }
                     }
                     continue;
                 }
@@ -498,16 +552,18 @@ __global__ __launch_bounds__(NWV * 64) void gemm_f32_kernel(GemmParams p) {
                 if constexpr (AMODE == OP_RC_PIX || AMODE == OP_RC_CONVK) kdec_step_pix(a_d[i], BKT, p.A.DH, p.A.DW);
             }
         }
-        if constexpr (A_FAST) {
-            if (fastA) {   // next k-tile: 32 channels further, or the next tap
-                f_c0 += BKT;
-                if (f_c0 >= p.A.C) { f_c0 = 0; f_tap++; f_tx++; if (f_tx == z.tm.ntx) { f_tx = 0; f_ty++; } }
-            }
-        }
 #pragma unroll
         for (int i = 0; i < NUB; i++) {
             if constexpr (B_FAST) {
-                if (fastB) { rb[i] = as_float4(__builtin_amdgcn_raw_buffer_load_b128(rsB, b_voff[i], k0 * 4, 0)); continue; }
+                if (fastB) {
+                    if constexpr (BMODE == OP_KC_DENSE) {
+                        rb[i] = as_float4(__builtin_amdgcn_raw_buffer_load_b128(rsB, b_voff[i], k0 * 4, 0));
+                    } else {
+                        const int kh = z.tm.kh0 + z.tm.tstep * f_ty, kw = z.tm.kw0 + z.tm.tstep * f_tx;
+                        rb[i] = as_float4(__builtin_amdgcn_raw_buffer_load_b128(rsB, b_voff[i], (f_c0 * (int)p.B.ld + (kh * p.B.KW + kw) * p.B.Cr) * 4, 0));
+                    }
+                    continue;
+                }
             }
             if constexpr (B_KC) {
                 rb[i] = load_kc<BMODE>(p.B, z, b_rc[i], k0 + b_k[i], b_d[i]);
@@ -516,6 +572,12 @@ __global__ __launch_bounds__(NWV * 64) void gemm_f32_kernel(GemmParams p) {
                 rb[i] = load_rc<BMODE>(p.B, p, z, k0 + b_k[i], n0 + b_r[i], p.N, b_d[i]);
                 if constexpr (BMODE == OP_RC_WT) kdec_step_tap(b_d[i], z.tm, BKT, p.B.C);
                 if constexpr (BMODE == OP_RC_PIX || BMODE == OP_RC_CONVK) kdec_step_pix(b_d[i], BKT, p.B.DH, p.B.DW);
+            }
+        }
+        if constexpr (TAP_STATE) {
+            if (k_tiles_in_taps) {   // next k-tile: one k-tile of channels further, or the next tap
+                f_c0 += BKT;
+                if (f_c0 >= f_C) { f_c0 = 0; f_tap++; f_tx++; if (f_tx == z.tm.ntx) { f_tx = 0; f_ty++; } }
             }
         }
     };
@@ -578,7 +640,7 @@ __global__ __launch_bounds__(NWV * 64) void gemm_f32_kernel(GemmParams p) {
     long long tr1 = 0, tr2 = 0;
     {
         __syncthreads();
-        if (p.trace) tr1 = wall_clock64();
+        if (LDETR_TILE_TRACE && p.trace) tr1 = wall_clock64();
         for (int kt = 0; kt < nk; kt++) {
             const int buf = kt & 1;
             if (kt + 1 < nk) gload(z.kbeg + (kt + 1) * BKT, ra0, rb0);
@@ -588,9 +650,9 @@ __global__ __launch_bounds__(NWV * 64) void gemm_f32_kernel(GemmParams p) {
         }
     }
 
-    if (p.trace) tr2 = wall_clock64();
+    if (LDETR_TILE_TRACE && p.trace) tr2 = wall_clock64();
     auto trace_out = [&]() {
-        if (p.trace && threadIdx.x == 0) {
+        if (LDETR_TILE_TRACE && p.trace && threadIdx.x == 0) {
             long long* t = p.trace + 5 * (((long)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x);
             t[0] = tr0; t[1] = tr1; t[2] = tr2; t[3] = wall_clock64();
             t[4] = ((long long)__builtin_amdgcn_s_getreg(20 | (31 << 11)) << 32) | (unsigned)__builtin_amdgcn_s_getreg(4 | (31 << 11));   // XCC_ID, HW_ID
@@ -1222,13 +1284,48 @@ static int zero_fill(float* dst, long pitch, long width, long rows, hipStream_t 
 
 static long long* g_trace_buffer = nullptr;   // ldetr_debug_trace_tiles
 
-template <int BM, int BN, int BKT, int AMODE, int BMODE, int NWV = 4>
-static int launch_tile(GemmParams& p, dim3 grid, hipStream_t st) {
+// Host-side conditions of the kernel's scalar-addressed loads (FAST instantiation): every operand whose view supports them must
+// qualify, otherwise the generic instantiation runs.  BKT is 32 for every tile shape.
+template <int AMODE, int BMODE>
+static bool fast_operands_ok(const GemmParams& p, int Mmax) {
+    static const int fast_loads = getenv("LDETR_FAST_LOADS") ? atoi(getenv("LDETR_FAST_LOADS")) : 15;   // 1 conv, 2 dense B, 4 transposed conv, 8 dense A
+    constexpr int BKT = 32;
+    constexpr bool a_cap = (AMODE == OP_KC_CONV || AMODE == OP_KC_CONVT || AMODE == OP_KC_DENSE);
+    constexpr bool b_cap = (BMODE == OP_KC_DENSE || BMODE == OP_RC_WT);
+    if (!a_cap && !b_cap) return false;
+    const long lim = 0x7fffffffL;
+    auto taps_ok = [&](int C, int KH, int KW) {   // a k-tile never straddles a tap (C == k-tile measured slower: 483 vs 420 us on the 32-channel 256^2 layer)
+        return C > 0 && (C % BKT) == 0 && C >= 2 * BKT && (long)KH * KW <= 32 && p.samp_pix == 0;
+    };
+    if (AMODE == OP_KC_CONV) {
+        const long padoff = (long)p.A.pad * p.A.sh + (long)p.A.pad * p.A.sw;
+        if (!((fast_loads & 1) && p.A.vec && p.zmode == 0 && taps_ok(p.A.C, p.A.KH, p.A.KW) && ((long)p.nsamp * p.A.sn + padoff) * 4 < lim)) return false;
+    }
+    if (AMODE == OP_KC_CONVT) {
+        const long shift = (long)(p.A.KH - 1) * p.A.sh + (long)(p.A.KW - 1) * p.A.sw;
+        const int tstep = p.zmode == 1 ? p.pstep : 1;
+        if (!((fast_loads & 4) && p.A.vec && taps_ok(p.A.C, p.A.KH, p.A.KW) && tstep == p.A.stride &&
+              ((long)p.nsamp * p.A.sn + 2 * shift + p.A.sh + p.A.sw) * 4 < lim)) return false;
+    }
+    if (AMODE == OP_KC_DENSE) {
+        if (!((fast_loads & 8) && p.A.vec && (p.K % BKT) == 0 && (long)Mmax * p.A.ld * 4 < lim && p.samp_pix == 0 && p.zmode == 0)) return false;
+    }
+    if (BMODE == OP_KC_DENSE) {
+        if (!((fast_loads & 2) && p.B.vec && (p.K % BKT) == 0 && (long)p.N * p.B.ld * 4 < lim && p.samp_pix == 0 && (p.zmode == 0 || a_cap))) return false;
+    }
+    if (BMODE == OP_RC_WT) {
+        const int C = (AMODE <= OP_KC_WTAP) ? p.A.C : p.B.C;
+        if (!((fast_loads & 4) && p.B.vec && taps_ok(p.B.C, p.B.KH, p.B.KW) && p.B.C == C &&
+              ((long)p.B.C * p.B.ld + (long)p.B.KH * p.B.KW * p.B.Cr) * 4 < lim)) return false;
+    }
+    return true;
+}
+
+template <int BM, int BN, int BKT, int AMODE, int BMODE, int NWV, bool FAST>
+static int launch_tile_impl(GemmParams& p, dim3 grid, hipStream_t st) {
     p.trace = g_trace_buffer;
-    static const int fast_loads = getenv("LDETR_FAST_LOADS") ? atoi(getenv("LDETR_FAST_LOADS")) : 3;
-    p.fast_loads = fast_loads;
     constexpr size_t lds = (size_t)2 * BKT * ((BM + 2) + (BN + 2)) * sizeof(float);
-    auto kern = gemm_f32_kernel<BM, BN, BKT, AMODE, BMODE, NWV>;
+    auto kern = gemm_f32_kernel<BM, BN, BKT, AMODE, BMODE, NWV, FAST>;
     if (lds > 64 * 1024) {
         static bool raised = false;   // one-time opt-in to > 64 KiB of dynamic LDS for this instantiation
         if (!raised) {
@@ -1241,6 +1338,15 @@ static int launch_tile(GemmParams& p, dim3 grid, hipStream_t st) {
     }
     hipLaunchKernelGGL(kern, grid, NWV * 64, lds, st, p);
     return check_launch("gemm_f32");
+}
+
+template <int BM, int BN, int BKT, int AMODE, int BMODE, int NWV = 4>
+static int launch_tile(GemmParams& p, dim3 grid, int Mmax, hipStream_t st) {
+    constexpr bool cap = (AMODE == OP_KC_CONV || AMODE == OP_KC_CONVT || AMODE == OP_KC_DENSE || BMODE == OP_KC_DENSE || BMODE == OP_RC_WT);
+    if constexpr (cap) {
+        if (fast_operands_ok<AMODE, BMODE>(p, Mmax)) return launch_tile_impl<BM, BN, BKT, AMODE, BMODE, NWV, true>(p, grid, st);
+    }
+    return launch_tile_impl<BM, BN, BKT, AMODE, BMODE, NWV, false>(p, grid, st);
 }
 
 template <int AMODE, int BMODE>
@@ -1308,9 +1414,9 @@ static int launch_gemm(GemmParams& p, int Mmax, long out_rows, int zbase, bool a
     }
     dim3 grid(cdiv(p.N, use128 ? 128 : 64), cdiv(Mmax, (use128 || use12864) ? 128 : 64), zbase * (split ? p.splitk : 1));
     int rc;
-    if (use128) rc = launch_tile<128, 128, T128_BK, AMODE, BMODE, T128_WAVES>(p, grid, st);
-    else if (use12864) rc = launch_tile<128, 64, T12864_BK, AMODE, BMODE, T12864_WAVES>(p, grid, st);
-    else rc = launch_tile<64, 64, 32, AMODE, BMODE>(p, grid, st);
+    if (use128) rc = launch_tile<128, 128, T128_BK, AMODE, BMODE, T128_WAVES>(p, grid, Mmax, st);
+    else if (use12864) rc = launch_tile<128, 64, T12864_BK, AMODE, BMODE, T12864_WAVES>(p, grid, Mmax, st);
+    else rc = launch_tile<64, 64, 32, AMODE, BMODE>(p, grid, Mmax, st);
     if (rc) return rc;
     if (split && !fixup && !epilogue_is_linear(full)) {
         EpiParams q;
