@@ -425,8 +425,8 @@ __global__ __launch_bounds__(NWV * 64) void gemm_f32_kernel(GemmParams p) {
     // buffer_load_dwordx4 (an out-of-range vector offset returns zeros: that is the padding).
     // FAST is chosen by the host (fast_operands_ok in launch_gemm checks every condition below); the generic instantiation carries
     // none of this code (as runtime branches it slowed the generic path of the 32-channel 256^2 layer from 420 to 510 us).
-    constexpr bool A_FAST = FAST && (AMODE == OP_KC_CONV || AMODE == OP_KC_CONVT || AMODE == OP_KC_DENSE);
-    constexpr bool B_FAST = FAST && (BMODE == OP_KC_DENSE || BMODE == OP_RC_WT);
+    constexpr bool A_FAST = FAST && (AMODE == OP_KC_CONV || AMODE == OP_KC_CONVT || AMODE == OP_KC_DENSE || AMODE == OP_RC_DENSE);
+    constexpr bool B_FAST = FAST && (BMODE == OP_KC_DENSE || BMODE == OP_RC_WT || BMODE == OP_RC_DENSE);
     constexpr bool TAP_STATE = FAST && (AMODE == OP_KC_CONV || AMODE == OP_KC_CONVT || BMODE == OP_RC_WT);
     constexpr bool fastA = A_FAST, fastB = B_FAST;
     int a_voff[NUA]; unsigned a_msk[NUA]; int b_voff[NUB];
@@ -488,6 +488,16 @@ __global__ __launch_bounds__(NWV * 64) void gemm_f32_kernel(GemmParams p) {
             for (int i = 0; i < NUA; i++) a_voff[i] = a_rc[i].valid ? (int)((a_rc[i].base + a_k[i]) * 4) : (int)0x80000000;
         }
     }
+    if constexpr (FAST && AMODE == OP_RC_DENSE) {   // A[k][m], m contiguous: row k0 + a_k of the tile, columns m0 + a_r .. + 3
+        rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.A.p), 0, 0x7fffffff, 0x00020000);
+#pragma unroll
+        for (int i = 0; i < NUA; i++) a_voff[i] = (m0 + a_r[i] < z.M) ? (int)(((long)a_k[i] * p.A.ld + m0 + a_r[i]) * 4) : (int)0x80000000;
+    }
+    if constexpr (FAST && BMODE == OP_RC_DENSE) {
+        rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.B.p), 0, 0x7fffffff, 0x00020000);
+#pragma unroll
+        for (int i = 0; i < NUB; i++) b_voff[i] = (n0 + b_r[i] < p.N) ? (int)(((long)b_k[i] * p.B.ld + n0 + b_r[i]) * 4) : (int)0x80000000;
+    }
     if constexpr (FAST && BMODE == OP_KC_DENSE) {
         if (fastB) {
             rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.B.p), 0, 0x7fffffff, 0x00020000);
@@ -529,6 +539,8 @@ __global__ __launch_bounds__(NWV * 64) void gemm_f32_kernel(GemmParams p) {
                 if (fastA) {
                     if constexpr (AMODE == OP_KC_DENSE) {
                         ra[i] = as_float4(__builtin_amdgcn_raw_buffer_load_b128(rsA, a_voff[i], k0 * 4, 0));
+                    } else if constexpr (AMODE == OP_RC_DENSE) {   // rows of the tile past the end of the reduction read as zeros
+                        ra[i] = as_float4(__builtin_amdgcn_raw_buffer_load_b128(rsA, a_k[i] < z.kend - k0 ? a_voff[i] : (int)0x80000000, k0 * (int)p.A.ld * 4, 0));
                     } else {
                         const int soff = AMODE == OP_KC_CONV ? (f_ty * (int)p.A.sh + f_tx * (int)p.A.sw + f_c0) * 4
                                                              : ((z.tm.nty - 1 - f_ty) * (int)p.A.sh + (z.tm.ntx - 1 - f_tx) * (int)p.A.sw + f_c0) * 4;
@@ -558,6 +570,8 @@ __global__ __launch_bounds__(NWV * 64) void gemm_f32_kernel(GemmParams p) {
                 if (fastB) {
                     if constexpr (BMODE == OP_KC_DENSE) {
                         rb[i] = as_float4(__builtin_amdgcn_raw_buffer_load_b128(rsB, b_voff[i], k0 * 4, 0));
+                    } else if constexpr (BMODE == OP_RC_DENSE) {
+                        rb[i] = as_float4(__builtin_amdgcn_raw_buffer_load_b128(rsB, b_k[i] < z.kend - k0 ? b_voff[i] : (int)0x80000000, k0 * (int)p.B.ld * 4, 0));
                     } else {
                         const int kh = z.tm.kh0 + z.tm.tstep * f_ty, kw = z.tm.kw0 + z.tm.tstep * f_tx;
                         rb[i] = as_float4(__builtin_amdgcn_raw_buffer_load_b128(rsB, b_voff[i], (f_c0 * (int)p.B.ld + (kh * p.B.KW + kw) * p.B.Cr) * 4, 0));
@@ -1288,10 +1302,10 @@ static long long* g_trace_buffer = nullptr;   // ldetr_debug_trace_tiles
 // qualify, otherwise the generic instantiation runs.  BKT is 32 for every tile shape.
 template <int AMODE, int BMODE>
 static bool fast_operands_ok(const GemmParams& p, int Mmax) {
-    static const int fast_loads = getenv("LDETR_FAST_LOADS") ? atoi(getenv("LDETR_FAST_LOADS")) : 15;   // 1 conv, 2 dense B, 4 transposed conv, 8 dense A
+    static const int fast_loads = getenv("LDETR_FAST_LOADS") ? atoi(getenv("LDETR_FAST_LOADS")) : 31;   // 1 conv, 2 dense B, 4 transposed conv, 8 dense A, 16 row-contiguous dense
     constexpr int BKT = 32;
-    constexpr bool a_cap = (AMODE == OP_KC_CONV || AMODE == OP_KC_CONVT || AMODE == OP_KC_DENSE);
-    constexpr bool b_cap = (BMODE == OP_KC_DENSE || BMODE == OP_RC_WT);
+    constexpr bool a_cap = (AMODE == OP_KC_CONV || AMODE == OP_KC_CONVT || AMODE == OP_KC_DENSE || AMODE == OP_RC_DENSE);
+    constexpr bool b_cap = (BMODE == OP_KC_DENSE || BMODE == OP_RC_WT || BMODE == OP_RC_DENSE);
     if (!a_cap && !b_cap) return false;
     const long lim = 0x7fffffffL;
     auto taps_ok = [&](int C, int KH, int KW) {   // a k-tile never straddles a tap (C == k-tile measured slower: 483 vs 420 us on the 32-channel 256^2 layer)
@@ -1312,6 +1326,12 @@ static bool fast_operands_ok(const GemmParams& p, int Mmax) {
     }
     if (BMODE == OP_KC_DENSE) {
         if (!((fast_loads & 2) && p.B.vec && (p.K % BKT) == 0 && (long)p.N * p.B.ld * 4 < lim && p.samp_pix == 0 && (p.zmode == 0 || a_cap))) return false;
+    }
+    if (AMODE == OP_RC_DENSE) {   // (k0 * ld) * 4 must fit the 32-bit scalar offset
+        if (!((fast_loads & 16) && p.A.vec && (long)p.K * p.A.ld * 4 < lim)) return false;
+    }
+    if (BMODE == OP_RC_DENSE) {
+        if (!((fast_loads & 16) && p.B.vec && (long)p.K * p.B.ld * 4 < lim)) return false;
     }
     if (BMODE == OP_RC_WT) {
         const int C = (AMODE <= OP_KC_WTAP) ? p.A.C : p.B.C;
@@ -1342,7 +1362,7 @@ static int launch_tile_impl(GemmParams& p, dim3 grid, hipStream_t st) {
 
 template <int BM, int BN, int BKT, int AMODE, int BMODE, int NWV = 4>
 static int launch_tile(GemmParams& p, dim3 grid, int Mmax, hipStream_t st) {
-    constexpr bool cap = (AMODE == OP_KC_CONV || AMODE == OP_KC_CONVT || AMODE == OP_KC_DENSE || BMODE == OP_KC_DENSE || BMODE == OP_RC_WT);
+    constexpr bool cap = (AMODE == OP_KC_CONV || AMODE == OP_KC_CONVT || AMODE == OP_KC_DENSE || AMODE == OP_RC_DENSE || BMODE == OP_KC_DENSE || BMODE == OP_RC_WT || BMODE == OP_RC_DENSE);
     if constexpr (cap) {
         if (fast_operands_ok<AMODE, BMODE>(p, Mmax)) return launch_tile_impl<BM, BN, BKT, AMODE, BMODE, NWV, true>(p, grid, st);
     }
