@@ -426,7 +426,7 @@ __global__ __launch_bounds__(NWV * 64) void gemm_f32_kernel(GemmParams p) {
     // FAST is chosen by the host (fast_operands_ok in launch_gemm checks every condition below); the generic instantiation carries
     // none of this code (as runtime branches it slowed the generic path of the 32-channel 256^2 layer from 420 to 510 us).
     constexpr bool A_FAST = FAST && (AMODE == OP_KC_CONV || AMODE == OP_KC_CONVT || AMODE == OP_KC_DENSE || AMODE == OP_RC_DENSE);
-    constexpr bool B_FAST = FAST && (BMODE == OP_KC_DENSE || BMODE == OP_RC_WT || BMODE == OP_RC_DENSE);
+    constexpr bool B_FAST = FAST && (BMODE == OP_KC_DENSE || BMODE == OP_RC_WT || BMODE == OP_RC_DENSE || BMODE == OP_RC_PIX);
     constexpr bool TAP_STATE = FAST && (AMODE == OP_KC_CONV || AMODE == OP_KC_CONVT || BMODE == OP_RC_WT);
     constexpr bool fastA = A_FAST, fastB = B_FAST;
     int a_voff[NUA]; unsigned a_msk[NUA]; int b_voff[NUB];
@@ -497,6 +497,27 @@ __global__ __launch_bounds__(NWV * 64) void gemm_f32_kernel(GemmParams p) {
         rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.B.p), 0, 0x7fffffff, 0x00020000);
 #pragma unroll
         for (int i = 0; i < NUB; i++) b_voff[i] = (n0 + b_r[i] < p.N) ? (int)(((long)b_k[i] * p.B.ld + n0 + b_r[i]) * 4) : (int)0x80000000;
+    }
+    // B[k = pixel][r = channel] (the input operand of a weight gradient).  With the row width a multiple (or a divisor) of the
+    // k-tile, the 32 pixels of a k-tile start at a block-uniform (sample, row, column): those live in SGPRs, each unit keeps its
+    // fixed offset inside the tile's pixel patch; per unit and k-tile: two adds, two range tests, one select, one buffer load.
+    int g_n = 0, g_y0 = 0, g_x0 = 0;          // first pixel of the next k-tile
+    int b_sy[NUB], b_sx[NUB];
+    const int pix_st = p.B.tapped ? p.B.stride : 1, pix_pad = p.B.tapped ? p.B.pad : 0;
+    const int pix_kh = p.B.tapped ? z.fkh : 0, pix_kw = p.B.tapped ? z.fkw : 0;
+    if constexpr (FAST && BMODE == OP_RC_PIX) {
+        const long padoff = (long)pix_pad * p.B.sh + (long)pix_pad * p.B.sw;
+        rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.B.p) - padoff, 0, 0x7fffffff, 0x00020000);
+        const int wrow = p.B.DW >= BKT ? BKT : p.B.DW;     // pixels of the tile per image row
+#pragma unroll
+        for (int i = 0; i < NUB; i++) {
+            const int uy = b_k[i] / wrow, ux = b_k[i] - uy * wrow;
+            b_sy[i] = uy * pix_st - pix_pad + pix_kh; b_sx[i] = ux * pix_st - pix_pad + pix_kw;
+            b_voff[i] = (n0 + b_r[i] < p.N) ? (int)(((long)uy * pix_st * p.B.sh + (long)ux * pix_st * p.B.sw + n0 + b_r[i]) * 4) : (int)0x80000000;
+        }
+        const int per = p.B.DH * p.B.DW;
+        g_n = z.kbeg / per; const int rem = z.kbeg - g_n * per;
+        g_y0 = rem / p.B.DW; g_x0 = rem - g_y0 * p.B.DW;
     }
     if constexpr (FAST && BMODE == OP_KC_DENSE) {
         if (fastB) {
@@ -572,6 +593,15 @@ __global__ __launch_bounds__(NWV * 64) void gemm_f32_kernel(GemmParams p) {
                         rb[i] = as_float4(__builtin_amdgcn_raw_buffer_load_b128(rsB, b_voff[i], k0 * 4, 0));
                     } else if constexpr (BMODE == OP_RC_DENSE) {
                         rb[i] = as_float4(__builtin_amdgcn_raw_buffer_load_b128(rsB, b_k[i] < z.kend - k0 ? b_voff[i] : (int)0x80000000, k0 * (int)p.B.ld * 4, 0));
+                    } else if constexpr (BMODE == OP_RC_PIX) {
+                        const int sy = b_sy[i] + g_y0 * pix_st, sx = b_sx[i] + g_x0 * pix_st;
+                        const bool ok = ((unsigned)sy < (unsigned)p.B.SH) & ((unsigned)sx < (unsigned)p.B.SW);
+                        const int soff = (int)(((long)g_n * p.B.sn + (long)(g_y0 * pix_st + pix_kh) * p.B.sh + (long)(g_x0 * pix_st + pix_kw) * p.B.sw) * 4);
+                        rb[i] = as_float4(__builtin_amdgcn_raw_buffer_load_b128(rsB, ok ? b_voff[i] : (int)0x80000000, soff, 0));
+                        if (p.B.scale && ok && n0 + b_r[i] < p.N) {
+                            const float4 sc = *reinterpret_cast<const float4*>(p.B.scale + (long)g_n * p.B.scale_ld + n0 + b_r[i]);
+                            rb[i].x *= sc.x; rb[i].y *= sc.y; rb[i].z *= sc.z; rb[i].w *= sc.w;
+                        }
                     } else {
                         const int kh = z.tm.kh0 + z.tm.tstep * f_ty, kw = z.tm.kw0 + z.tm.tstep * f_tx;
                         rb[i] = as_float4(__builtin_amdgcn_raw_buffer_load_b128(rsB, b_voff[i], (f_c0 * (int)p.B.ld + (kh * p.B.KW + kw) * p.B.Cr) * 4, 0));
@@ -587,6 +617,11 @@ __global__ __launch_bounds__(NWV * 64) void gemm_f32_kernel(GemmParams p) {
                 if constexpr (BMODE == OP_RC_WT) kdec_step_tap(b_d[i], z.tm, BKT, p.B.C);
                 if constexpr (BMODE == OP_RC_PIX || BMODE == OP_RC_CONVK) kdec_step_pix(b_d[i], BKT, p.B.DH, p.B.DW);
             }
+        }
+        if constexpr (FAST && BMODE == OP_RC_PIX) {   // next k-tile: 32 pixels further along the (sample, row, column) order
+            if (p.B.DW >= BKT) { g_x0 += BKT; if (g_x0 >= p.B.DW) { g_x0 = 0; g_y0++; } }
+            else g_y0 += BKT / p.B.DW;
+            if (g_y0 >= p.B.DH) { g_y0 = 0; g_n++; }
         }
         if constexpr (TAP_STATE) {
             if (k_tiles_in_taps) {   // next k-tile: one k-tile of channels further, or the next tap
@@ -1302,10 +1337,10 @@ static long long* g_trace_buffer = nullptr;   // ldetr_debug_trace_tiles
 // qualify, otherwise the generic instantiation runs.  BKT is 32 for every tile shape.
 template <int AMODE, int BMODE>
 static bool fast_operands_ok(const GemmParams& p, int Mmax) {
-    static const int fast_loads = getenv("LDETR_FAST_LOADS") ? atoi(getenv("LDETR_FAST_LOADS")) : 31;   // 1 conv, 2 dense B, 4 transposed conv, 8 dense A, 16 row-contiguous dense
+    static const int fast_loads = getenv("LDETR_FAST_LOADS") ? atoi(getenv("LDETR_FAST_LOADS")) : 63;   // 1 conv, 2 dense B, 4 transposed conv, 8 dense A, 16 row-contiguous dense, 32 pixel-major (weight gradient input)
     constexpr int BKT = 32;
     constexpr bool a_cap = (AMODE == OP_KC_CONV || AMODE == OP_KC_CONVT || AMODE == OP_KC_DENSE || AMODE == OP_RC_DENSE);
-    constexpr bool b_cap = (BMODE == OP_KC_DENSE || BMODE == OP_RC_WT || BMODE == OP_RC_DENSE);
+    constexpr bool b_cap = (BMODE == OP_KC_DENSE || BMODE == OP_RC_WT || BMODE == OP_RC_DENSE || BMODE == OP_RC_PIX);
     if (!a_cap && !b_cap) return false;
     const long lim = 0x7fffffffL;
     auto taps_ok = [&](int C, int KH, int KW) {   // a k-tile never straddles a tap (C == k-tile measured slower: 483 vs 420 us on the 32-channel 256^2 layer)
@@ -1332,6 +1367,12 @@ static bool fast_operands_ok(const GemmParams& p, int Mmax) {
     }
     if (BMODE == OP_RC_DENSE) {
         if (!((fast_loads & 16) && p.B.vec && (long)p.K * p.B.ld * 4 < lim)) return false;
+    }
+    if (BMODE == OP_RC_PIX) {   // k-tiles of 32 pixels aligned to the image rows
+        const int DH = p.B.DH, DW = p.B.DW, pad = p.B.tapped ? p.B.pad : 0;
+        const bool rows_ok = DH > 0 && DW > 0 && ((DW % BKT) == 0 || ((BKT % DW) == 0 && ((long)DH * DW) % BKT == 0));
+        if (!((fast_loads & 32) && p.B.vec && rows_ok && (p.K % BKT) == 0 &&
+              ((long)p.nsamp * p.B.sn + (long)pad * (p.B.sh + p.B.sw) + (long)BKT * (p.B.sh + p.B.sw)) * 4 < lim)) return false;
     }
     if (BMODE == OP_RC_WT) {
         const int C = (AMODE <= OP_KC_WTAP) ? p.A.C : p.B.C;
@@ -1362,7 +1403,7 @@ static int launch_tile_impl(GemmParams& p, dim3 grid, hipStream_t st) {
 
 template <int BM, int BN, int BKT, int AMODE, int BMODE, int NWV = 4>
 static int launch_tile(GemmParams& p, dim3 grid, int Mmax, hipStream_t st) {
-    constexpr bool cap = (AMODE == OP_KC_CONV || AMODE == OP_KC_CONVT || AMODE == OP_KC_DENSE || AMODE == OP_RC_DENSE || BMODE == OP_KC_DENSE || BMODE == OP_RC_WT || BMODE == OP_RC_DENSE);
+    constexpr bool cap = (AMODE == OP_KC_CONV || AMODE == OP_KC_CONVT || AMODE == OP_KC_DENSE || AMODE == OP_RC_DENSE || BMODE == OP_KC_DENSE || BMODE == OP_RC_WT || BMODE == OP_RC_DENSE || BMODE == OP_RC_PIX);
     if constexpr (cap) {
         if (fast_operands_ok<AMODE, BMODE>(p, Mmax)) return launch_tile_impl<BM, BN, BKT, AMODE, BMODE, NWV, true>(p, grid, st);
     }
