@@ -426,8 +426,8 @@ __global__ __launch_bounds__(NWV * 64) void gemm_f32_kernel(GemmParams p) {
     // FAST is chosen by the host (fast_operands_ok in launch_gemm checks every condition below); the generic instantiation carries
     // none of this code (as runtime branches it slowed the generic path of the 32-channel 256^2 layer from 420 to 510 us).
     constexpr bool A_FAST = FAST && (AMODE == OP_KC_CONV || AMODE == OP_KC_CONVT || AMODE == OP_KC_DENSE || AMODE == OP_RC_DENSE);
-    constexpr bool B_FAST = FAST && (BMODE == OP_KC_DENSE || BMODE == OP_RC_WT || BMODE == OP_RC_DENSE || BMODE == OP_RC_PIX);
-    constexpr bool TAP_STATE = FAST && (AMODE == OP_KC_CONV || AMODE == OP_KC_CONVT || BMODE == OP_RC_WT);
+    constexpr bool B_FAST = FAST && (BMODE == OP_KC_DENSE || BMODE == OP_RC_WT || BMODE == OP_RC_DENSE || BMODE == OP_RC_PIX || BMODE == OP_KC_WTAP);
+    constexpr bool TAP_STATE = FAST && (AMODE == OP_KC_CONV || AMODE == OP_KC_CONVT || BMODE == OP_RC_WT || BMODE == OP_KC_WTAP);
     constexpr bool fastA = A_FAST, fastB = B_FAST;
     int a_voff[NUA]; unsigned a_msk[NUA]; int b_voff[NUB];
     __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.A.p), 0, 0, 0x00020000), rsB = rsA;
@@ -519,6 +519,11 @@ __global__ __launch_bounds__(NWV * 64) void gemm_f32_kernel(GemmParams p) {
         g_n = z.kbeg / per; const int rem = z.kbeg - g_n * per;
         g_y0 = rem / p.B.DW; g_x0 = rem - g_y0 * p.B.DW;
     }
+    if constexpr (FAST && BMODE == OP_KC_WTAP) {   // weights [n][tap][c]: row base + (tap * C + c0) scalar
+        rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.B.p), 0, 0x7fffffff, 0x00020000);
+#pragma unroll
+        for (int i = 0; i < NUB; i++) b_voff[i] = b_rc[i].valid ? (int)((b_rc[i].base + b_k[i]) * 4) : (int)0x80000000;
+    }
     if constexpr (FAST && BMODE == OP_KC_DENSE) {
         if (fastB) {
             rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.B.p), 0, 0x7fffffff, 0x00020000);
@@ -591,6 +596,9 @@ __global__ __launch_bounds__(NWV * 64) void gemm_f32_kernel(GemmParams p) {
                 if (fastB) {
                     if constexpr (BMODE == OP_KC_DENSE) {
                         rb[i] = as_float4(__builtin_amdgcn_raw_buffer_load_b128(rsB, b_voff[i], k0 * 4, 0));
+                    } else if constexpr (BMODE == OP_KC_WTAP) {
+                        const int kh = z.tm.kh0 + z.tm.tstep * f_ty, kw = z.tm.kw0 + z.tm.tstep * f_tx;
+                        rb[i] = as_float4(__builtin_amdgcn_raw_buffer_load_b128(rsB, b_voff[i], ((kh * p.B.KW + kw) * p.B.C + f_c0) * 4, 0));
                     } else if constexpr (BMODE == OP_RC_DENSE) {
                         rb[i] = as_float4(__builtin_amdgcn_raw_buffer_load_b128(rsB, b_k[i] < z.kend - k0 ? b_voff[i] : (int)0x80000000, k0 * (int)p.B.ld * 4, 0));
                     } else if constexpr (BMODE == OP_RC_PIX) {
@@ -1340,7 +1348,7 @@ static bool fast_operands_ok(const GemmParams& p, int Mmax) {
     static const int fast_loads = getenv("LDETR_FAST_LOADS") ? atoi(getenv("LDETR_FAST_LOADS")) : 63;   // 1 conv, 2 dense B, 4 transposed conv, 8 dense A, 16 row-contiguous dense, 32 pixel-major (weight gradient input)
     constexpr int BKT = 32;
     constexpr bool a_cap = (AMODE == OP_KC_CONV || AMODE == OP_KC_CONVT || AMODE == OP_KC_DENSE || AMODE == OP_RC_DENSE);
-    constexpr bool b_cap = (BMODE == OP_KC_DENSE || BMODE == OP_RC_WT || BMODE == OP_RC_DENSE || BMODE == OP_RC_PIX);
+    constexpr bool b_cap = (BMODE == OP_KC_DENSE || BMODE == OP_RC_WT || BMODE == OP_RC_DENSE || BMODE == OP_RC_PIX || BMODE == OP_KC_WTAP);
     if (!a_cap && !b_cap) return false;
     const long lim = 0x7fffffffL;
     auto taps_ok = [&](int C, int KH, int KW) {   // a k-tile never straddles a tap (C == k-tile measured slower: 483 vs 420 us on the 32-channel 256^2 layer)
@@ -1367,6 +1375,9 @@ static bool fast_operands_ok(const GemmParams& p, int Mmax) {
     }
     if (BMODE == OP_RC_DENSE) {
         if (!((fast_loads & 16) && p.B.vec && (long)p.K * p.B.ld * 4 < lim)) return false;
+    }
+    if (BMODE == OP_KC_WTAP) {
+        if (!((fast_loads & 4) && p.B.vec && taps_ok(p.B.C, p.B.KH, p.B.KW) && p.B.C == p.A.C && (long)p.N * p.B.ld * 4 < lim)) return false;
     }
     if (BMODE == OP_RC_PIX) {   // k-tiles of 32 pixels aligned to the image rows
         const int DH = p.B.DH, DW = p.B.DW, pad = p.B.tapped ? p.B.pad : 0;
@@ -1403,7 +1414,7 @@ static int launch_tile_impl(GemmParams& p, dim3 grid, hipStream_t st) {
 
 template <int BM, int BN, int BKT, int AMODE, int BMODE, int NWV = 4>
 static int launch_tile(GemmParams& p, dim3 grid, int Mmax, hipStream_t st) {
-    constexpr bool cap = (AMODE == OP_KC_CONV || AMODE == OP_KC_CONVT || AMODE == OP_KC_DENSE || AMODE == OP_RC_DENSE || BMODE == OP_KC_DENSE || BMODE == OP_RC_WT || BMODE == OP_RC_DENSE || BMODE == OP_RC_PIX);
+    constexpr bool cap = (AMODE == OP_KC_CONV || AMODE == OP_KC_CONVT || AMODE == OP_KC_DENSE || AMODE == OP_RC_DENSE || BMODE == OP_KC_DENSE || BMODE == OP_RC_WT || BMODE == OP_RC_DENSE || BMODE == OP_RC_PIX || BMODE == OP_KC_WTAP);
     if constexpr (cap) {
         if (fast_operands_ok<AMODE, BMODE>(p, Mmax)) return launch_tile_impl<BM, BN, BKT, AMODE, BMODE, NWV, true>(p, grid, st);
     }

@@ -289,6 +289,18 @@ CONV_CASES = [
     (2, 48, 48, 128, 36, 1, 1, 0),
     (1, 65, 65, 40, 260, 1, 1, 0),
     (2, 64, 64, 192, 96, 1, 1, 0),
+    # scalar-addressed (FAST) instantiation and its boundaries: channel counts of 2+ k-tiles, 5x5 (25 taps fit the tap mask) vs 7x7
+    # (49 do not: generic path), stride 2 with even / odd sizes, image rows that are multiples / divisors / neither of the 32-pixel
+    # k-tile (the weight gradient's pixel-major operand), a pad larger than 1, and channel counts that are not k-tile multiples
+    (2, 32, 32, 64, 64, 3, 1, 1),
+    (2, 64, 32, 128, 64, 3, 1, 1),
+    (1, 20, 24, 64, 96, 3, 1, 1),
+    (2, 32, 32, 64, 64, 5, 1, 2),
+    (1, 16, 16, 64, 64, 7, 1, 3),
+    (2, 33, 31, 128, 64, 3, 2, 1),
+    (2, 32, 32, 96, 64, 3, 2, 1),
+    (3, 8, 4, 128, 128, 3, 1, 1),
+    (2, 16, 16, 80, 64, 3, 1, 1),
 ]
 
 
@@ -727,3 +739,28 @@ def test_demod_coefficients_fwd_bwd(dev, B, O, I, K, cl):
     assert_close(out, ref.detach(), 5e-6, 'dcoefs')
     assert_close(wd.grad, wr.grad, 2e-5, 'dweight')
     assert_close(sd.grad, sr.grad, 2e-5, 'dstyles')
+
+
+@pytest.mark.parametrize('B,R,Ci,Co,up', [(2, 16, 64, 64, 1), (2, 8, 128, 64, 2), (3, 16, 64, 128, 2), (2, 32, 96, 64, 1), (2, 4, 512, 512, 2)])
+def test_modulated_conv_layers_vs_oracle(dev, B, R, Ci, Co, up):
+    """One StyleGAN2 synthesis layer (modulate -> 3x3 conv or transposed conv + 4x4 FIR -> demodulate -> bias -> lrelu * sqrt 2,
+    networks_stylegan2.py:30-75,307-326) against the oracle's non-fused formulation, forward and all gradients, at channel counts
+    that take the scalar-addressed (FAST) kernels for the conv, the transposed conv, their data and weight gradients."""
+    from layoutdetr_amd.hip import modconv
+    torch.manual_seed(70 + R + up)
+    x = torch.randn(B, Ci, R, R); w = torch.randn(Co, Ci, 3, 3) / math.sqrt(Ci * 9); s = torch.randn(B, Ci) * 0.5 + 1.0; b = torch.randn(Co) * 0.1
+    f = ops_ref.setup_filter([1, 3, 3, 1])
+    xr, wr, sr, br = [t.clone().requires_grad_(True) for t in (x, w, s, b)]
+    y = ops_ref.modulated_conv2d(xr, wr, sr, up=up, padding=1, resample_filter=f, demodulate=True, flip_weight=(up == 1))
+    y = ops_ref.bias_act(y, br, act='lrelu', gain=math.sqrt(2))
+    g = torch.randn_like(y); y.backward(g)
+    xd = x.permute(0, 2, 3, 1).contiguous().to(dev).requires_grad_(True)
+    wd = w.to(dev).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    sd = s.to(dev).requires_grad_(True); bd = b.to(dev).requires_grad_(True)
+    out = modconv.modconv3x3(xd, wd, sd, bd) if up == 1 else modconv.modconv3x3_up2(xd, wd, sd, bd, f.to(dev))
+    out.backward(g.permute(0, 2, 3, 1).contiguous().to(dev))
+    assert_close(out.permute(0, 3, 1, 2), y.detach(), 2e-5, 'y')
+    assert_close(xd.grad.permute(0, 3, 1, 2), xr.grad, 5e-5, 'dx')
+    assert_close(wd.grad, wr.grad, 5e-5, 'dw')
+    assert_close(sd.grad, sr.grad, 1e-4, 'dstyles')
+    assert_close(bd.grad, br.grad, 5e-5, 'dbias')
