@@ -36,4 +36,13 @@ for name, args in [('l3 3x3 256->256 fwd', (16, 16, 256, 256, 3, 1, 1, 'fwd')), 
     t0 = t[:, 0].min()
     start = t[:, 0] - t0; end = t[:, 3] - t0
     q = lambda v: ' '.join(f'{float(v.quantile(x)):6.1f}' for x in (0.0, 0.5, 0.9, 1.0))
+    loop = (raw[:, 2] - raw[:, 1]).double() * 0.01
+    xcc = ((raw[:, 4] >> 32) & 0xF)
+    by_xcc = [round(float(loop[xcc == x].mean()), 1) for x in sorted(set(xcc.tolist()))]
+    nb = len(raw); idx = torch.arange(nb)
+    quarters = [round(float(loop[(idx * 4 // nb) == qq].mean()), 1) for qq in range(4)]
+    cu_mean = {}
+    for pl, lv in zip(place.tolist(), loop.tolist()): cu_mean.setdefault(pl, []).append(lv)
+    cu_means = torch.tensor([sum(v) / len(v) for v in cu_mean.values()])
+    print(f'    loop mean by XCC {by_xcc} | by quarter of the tile order {quarters} | per-CU mean min/median/max {float(cu_means.min()):.1f}/{float(cu_means.median()):.1f}/{float(cu_means.max()):.1f}')
     print(f'{name:26s} blocks {len(t):5d} | start  {q(start)} | prologue {q(t[:, 1] - t[:, 0])} | loop {q(t[:, 2] - t[:, 1])} | tail {q(t[:, 3] - t[:, 2])} | end {q(end)}   (us; min/median/p90/max) | CUs used {len(per_cu)}, blocks per CU {int(per_cu.min())}..{int(per_cu.max())} hist {torch.bincount(per_cu).tolist()}', flush=True)
