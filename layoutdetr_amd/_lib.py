@@ -85,6 +85,9 @@ def load():
         raise RuntimeError(
             f'{LIB_PATH} not found: build the gfx950 kernels first (python -m layoutdetr_amd.build or '
             f'__graft_entry__.build()).  layoutdetr_amd has no CPU/PyTorch fallback path.')
+    # torch first: its wheel carries its own HIP runtime; loading this library before it pulls in /opt/rocm's copy as a SECOND runtime
+    # in the process (seen as hipGetDevice failing in ldetr_set_workspace when __graft_entry__.build() ran before smoke())
+    import torch  # noqa: F401
     lib = ctypes.CDLL(LIB_PATH)
     lib.ldetr_last_error.restype = c_char_p
     lib.ldetr_last_error.argtypes = []
