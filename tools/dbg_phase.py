@@ -56,8 +56,12 @@ gi = tl.GraphedIteration(loss, phases, dp, batch, B, 4, capture_stream=side)
 torch.cuda.synchronize(); print('captured', flush=True)
 if os.environ.get('LDETR_DBG_EMPTY'):
     import gc; gc.collect(); torch.cuda.empty_cache(); print('cache emptied', flush=True)
-for i in range(3):
-    gi.run(); torch.cuda.synchronize()
+NREP = int(os.environ.get('LDETR_DBG_REPLAYS', '3'))
+for i in range(NREP):
+    gi.run()
+    if NREP > 10 and i % 50 != 49 and i != NREP - 1:
+        continue
+    torch.cuda.synchronize()
     mods = [ph.module for ph in phases]
     bad = [n for m in mods for n, q in m.named_parameters() if not torch.isfinite(q).all()]
     gmax = max(float(q.grad.abs().max()) for m in mods for q in m.parameters() if q.grad is not None)
