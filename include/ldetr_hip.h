@@ -116,6 +116,19 @@ int ldetr_upfirdn2d_f32(const float* x, const float* f, float* y, int N, int C, 
 int ldetr_gemm_f32(const float* A, int64_t lda, int ta, const float* B, int64_t ldb, int tb, float* C, int64_t ldc,
                    int M, int N, int K, int splitk, const ldetr_epilogue* ep, int pix_per_sample, void* stream);
 
+/* Two ldetr_gemm_f32 problems in one call, executed in order g0 then g1 (they may read the same operands; their outputs must not
+ * overlap each other's inputs).  With g0 = (ta 0, tb 1) and g1 = (ta 1, tb 1) -- the data and the weight gradient of a linear layer --
+ * and both in the small-tile class, they run as ONE kernel launch; otherwise as two.  Same results either way. */
+typedef struct ldetr_gemm_desc {
+    const float* A; int64_t lda; int ta;
+    const float* B; int64_t ldb; int tb;
+    float* C; int64_t ldc;
+    int M, N, K, splitk;
+    const ldetr_epilogue* ep;
+    int pix_per_sample;
+} ldetr_gemm_desc;
+int ldetr_gemm_pair_f32(const ldetr_gemm_desc* g0, const ldetr_gemm_desc* g1, void* stream);
+
 int ldetr_conv2d_fwd_f32(const float* x, const ldetr_tensor4* xt, const float* w, int Cout, int KH, int KW, int stride,
                          int pad, float* y, int64_t ldy, int OH, int OW, const float* in_scale, int64_t in_scale_ld,
                          const ldetr_epilogue* ep, void* stream);

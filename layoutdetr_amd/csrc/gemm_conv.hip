@@ -896,24 +896,25 @@ __device__ __forceinline__ void small_load(const Operand& o, int row, int R, int
     }
 }
 
+// Body of one 32x32 tile (bx, by) and K slice bz of `sk`; shared by the single-problem kernel and the paired launch below.
 template <int TA, int TB, int NW>
-__global__ __launch_bounds__(NW * 64) void gemm_small_kernel(GemmParams p) {
+__device__ __forceinline__ void gemm_small_body(const GemmParams& p, const int bx, const int by, const int bz, const int sk, const int gx) {
     using f32x16 = __attribute__((__vector_size__(16 * sizeof(float)))) float;
     __shared__ float red[NW][32][33];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int cl = lane & 31, kl = lane >> 5;
-    const int m0 = blockIdx.y * 32, n0 = blockIdx.x * 32;
+    const int m0 = by * 32, n0 = bx * 32;
     // reduction range of this block (split-K over blockIdx.z when the launch asked for it), then of this wave
-    const int chunks_all = (p.K + 31) / 32, sk = gridDim.z;
+    const int chunks_all = (p.K + 31) / 32;
     const int cper = (chunks_all + sk - 1) / sk;
-    const int kblk0 = blockIdx.z * cper * 32, kblk1 = min(p.K, kblk0 + cper * 32);
+    const int kblk0 = bz * cper * 32, kblk1 = min(p.K, kblk0 + cper * 32);
     const int chunks = kblk1 > kblk0 ? (kblk1 - kblk0 + 31) / 32 : 0, per = (chunks + NW - 1) / NW;
     const int kbeg = kblk0 + wave * per * 32, kend = min(kblk1, kbeg + per * 32);
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; r++) acc[r] = 0.f;
     float a0[16], b0[16], a1[16], b1[16];
-    const bool want_rs = TA == 1 && p.ep.a_rowsum != nullptr && blockIdx.x == 0;   // the A panel is the same for every column block
+    const bool want_rs = TA == 1 && p.ep.a_rowsum != nullptr && bx == 0;   // the A panel is the same for every column block
     float rs = 0.f;
     if (kbeg < kend) {
         small_load<TA>(p.A, m0 + cl, p.M, kbeg, kl, kend, a0);
@@ -963,9 +964,9 @@ __global__ __launch_bounds__(NW * 64) void gemm_small_kernel(GemmParams p) {
     // in slice order and runs the epilogue (same protocol as gemm_f32_kernel's fix-up: agent-scope stores / loads + vmcnt(0)).
     float* slot0 = nullptr;
     if (sk > 1) {
-        const long tile = (long)blockIdx.y * gridDim.x + blockIdx.x;
+        const long tile = (long)by * gx + bx;
         slot0 = p.ws + tile * sk * 1024;
-        float* mine = slot0 + (long)blockIdx.z * 1024;
+        float* mine = slot0 + (long)bz * 1024;
         for (int q = tid; q < 256; q += NW * 64) {
             const int row = q >> 3, c4 = (q & 7) * 4;
 #pragma unroll
@@ -1031,6 +1032,21 @@ __global__ __launch_bounds__(NW * 64) void gemm_small_kernel(GemmParams p) {
                 if (n0 + c4 + e < p.N) { if (ep.accumulate) dst[e] += v[e]; else dst[e] = v[e]; }
         }
     }
+}
+
+template <int TA, int TB, int NW>
+__global__ __launch_bounds__(NW * 64) void gemm_small_kernel(GemmParams p) {
+    gemm_small_body<TA, TB, NW>(p, blockIdx.x, blockIdx.y, blockIdx.z, gridDim.z, gridDim.x);
+}
+
+// Two independent small problems in ONE launch (the data and the weight gradient of a linear layer: both read dY).  These
+// GEMMs sit at the launch-latency floor (~6 us for 20 MFLOP), so a launch saved is their whole cost saved.  Tiles of problem 0
+// come first in the linear block order, then problem 1's; no split-K here.
+template <int TA0, int TB0, int TA1, int TB1, int NW>
+__global__ __launch_bounds__(NW * 64) void gemm_small_pair_kernel(GemmParams p0, GemmParams p1, int gx0, int nt0, int gx1) {
+    const int b = blockIdx.x;
+    if (b < nt0) gemm_small_body<TA0, TB0, NW>(p0, b % gx0, b / gx0, 0, 1, gx0);
+    else { const int c = b - nt0; gemm_small_body<TA1, TB1, NW>(p1, c % gx1, c / gx1, 0, 1, gx1); }
 }
 
 static inline bool al16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
@@ -1619,6 +1635,53 @@ extern "C" int ldetr_gemm_f32(const float* A, int64_t lda, int ta, const float* 
     if (ta && tb) return launch_gemm<OP_RC_DENSE, OP_RC_DENSE>(p, M, M, 1, auto_split, false, st);
     set_error("gemm: (ta=1, tb=0) is not instantiated");
     return LDETR_ERR_UNSUPPORTED;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Two dense GEMMs in one call (the data gradient dX = dY W and the weight gradient dW += dY^T X of a linear layer).  When both are
+// plain small-tile problems (the usual case on the transformers' token counts) they run as ONE launch of gemm_small_pair_kernel;
+// anything else falls back to two ldetr_gemm_f32 calls in order.  Same semantics either way.
+static bool small_plain(const ldetr_gemm_desc& g, int& nw) {
+    static const int small_maxk = getenv("LDETR_SMALL_MAXK") ? atoi(getenv("LDETR_SMALL_MAXK")) : (1 << 30);
+    if (g.splitk != 0 || g.M <= 0 || g.N <= 0 || g.K <= 0) return false;
+    if (!((long)cdiv(g.M, 64) * cdiv(g.N, 64) < SMALL_GEMM_TILES && (long)g.M * g.N * g.K <= SMALL_GEMM_MNK && g.K <= small_maxk)) return false;
+    const long blocks = (long)cdiv(g.N, 32) * cdiv(g.M, 32);
+    if (blocks <= 128 && g.K >= 1024) return false;          // takes the in-kernel split-K route on its own
+    nw = (blocks <= 256 && g.K >= 512) ? 8 : 4;
+    return true;
+}
+
+static void fill_dense(GemmParams& p, const ldetr_gemm_desc& g) {
+    memset(&p, 0, sizeof(p));
+    init_operand(p.A); init_operand(p.B);
+    p.A.p = g.A; p.A.ld = g.lda; p.B.p = g.B; p.B.ld = g.ldb;
+    p.A.vec = al16(g.A) && (g.lda % 4 == 0) && (g.ta ? (g.M % 4 == 0) : (g.K % 4 == 0));
+    p.B.vec = al16(g.B) && (g.ldb % 4 == 0) && (g.tb ? (g.N % 4 == 0) : (g.K % 4 == 0));
+    p.M = g.M; p.N = g.N; p.K = g.K; p.C = g.C; p.ldc = g.ldc;
+    p.zmode = 0; p.splitk = 1; p.pstep = 1; p.nsamp = 1; p.pix_per_sample = g.pix_per_sample;
+    fill_epilogue(p.ep, g.ep);
+}
+
+extern "C" int ldetr_gemm_pair_f32(const ldetr_gemm_desc* g0, const ldetr_gemm_desc* g1, void* stream) {
+    LDETR_CHECK(g0 && g1, "gemm_pair: null descriptor");
+    static const int pair_on = getenv("LDETR_GEMM_PAIR") ? atoi(getenv("LDETR_GEMM_PAIR")) : 1;
+    int nw0 = 0, nw1 = 0;
+    const bool layouts = g0->ta == 0 && g0->tb == 1 && g1->ta == 1 && g1->tb == 1;    // the instantiated pairing: NN + TN
+    if (pair_on && layouts && g0->A && g0->B && g0->C && g1->A && g1->B && g1->C && small_plain(*g0, nw0) && small_plain(*g1, nw1) && nw0 == nw1 &&
+        (!g1->ep || !g1->ep->a_rowsum || g1->lda == g1->M)) {
+        GemmParams p0, p1;
+        fill_dense(p0, *g0); fill_dense(p1, *g1);
+        if (!p0.ep.a_rowsum) {
+            const int gx0 = cdiv(p0.N, 32), nt0 = gx0 * cdiv(p0.M, 32), gx1 = cdiv(p1.N, 32), nt1 = gx1 * cdiv(p1.M, 32);
+            hipStream_t st = (hipStream_t)stream;
+            if (nw0 == 8) hipLaunchKernelGGL((gemm_small_pair_kernel<0, 1, 1, 1, 8>), dim3(nt0 + nt1), 512, 0, st, p0, p1, gx0, nt0, gx1);
+            else hipLaunchKernelGGL((gemm_small_pair_kernel<0, 1, 1, 1, 4>), dim3(nt0 + nt1), 256, 0, st, p0, p1, gx0, nt0, gx1);
+            return check_launch("gemm_small_pair");
+        }
+    }
+    int rc = ldetr_gemm_f32(g0->A, g0->lda, g0->ta, g0->B, g0->ldb, g0->tb, g0->C, g0->ldc, g0->M, g0->N, g0->K, g0->splitk, g0->ep, g0->pix_per_sample, stream);
+    if (rc) return rc;
+    return ldetr_gemm_f32(g1->A, g1->lda, g1->ta, g1->B, g1->ldb, g1->tb, g1->C, g1->ldc, g1->M, g1->N, g1->K, g1->splitk, g1->ep, g1->pix_per_sample, stream);
 }
 
 static void set_conv_src(Operand& o, const float* x, const ldetr_tensor4* t) {

@@ -247,6 +247,25 @@ def gemm(A, B, ta, tb, M, N, K, out=None, ep=None, splitk=0, pix_per_sample=0, l
     return out
 
 
+def gemm_pair(g0, g1):
+    """Two gemm() calls as one C-ABI call (ldetr_gemm_pair_f32): g = dict(A, B, ta, tb, M, N, K, out, ep).  The data and the weight
+    gradient of a linear layer run as ONE kernel launch when both are small-tile problems; otherwise as two, in order."""
+    descs = []
+    flops = 0.0
+    for g in (g0, g1):
+        require_gpu(g['A'], g['B'], g['out'])
+        d = _lib.GemmDesc()
+        d.A = g['A'].data_ptr(); d.lda = g['A'].stride(0); d.ta = int(g['ta'])
+        d.B = g['B'].data_ptr(); d.ldb = g['B'].stride(0); d.tb = int(g['tb'])
+        d.C = g['out'].data_ptr(); d.ldc = g['out'].stride(0)
+        d.M, d.N, d.K, d.splitk = int(g['M']), int(g['N']), int(g['K']), 0
+        d.ep = ctypes.addressof(g['ep']) if g.get('ep') is not None else None
+        d.pix_per_sample = 0
+        descs.append(d)
+        flops += 2.0 * d.M * d.N * d.K
+    engine_call('gemm', flops, lambda: check(lib().ldetr_gemm_pair_f32(ctypes.byref(descs[0]), ctypes.byref(descs[1]), stream()), 'gemm_pair'))
+
+
 def colsum(a2d, B=1):
     """a2d: [B*P, C] -> [B, C] column sums per group of P rows."""
     require_gpu(a2d)

@@ -98,6 +98,15 @@ class _LinearFn(torch.autograd.Function):
                 else:
                     db = core.colsum(dpre).reshape(-1)
         dx = dw = None
+        if need_x and need_w and gw is not None and gw.is_contiguous() and not core.SIDE_WGRAD:
+            # dX = dY W and dW += dY^T X through one C-ABI call: one kernel launch when both are small-tile problems
+            res = core.f32c(dx_pass.reshape(-1, K)) if dx_pass is not None else None
+            dx2 = torch.empty((M, K), device=dpre.device, dtype=torch.float32)
+            rsum = gb if (act == ACT_NONE and fold_db) else None
+            core.gemm_pair(dict(A=dpre, B=w, ta=0, tb=1, M=M, N=K, K=N, out=dx2, ep=core.epilogue(alpha=wscale, residual=res)),
+                           dict(A=dpre, B=x2, ta=1, tb=1, M=N, N=K, K=M, out=gw, ep=core.epilogue(alpha=wscale, accumulate=True, a_rowsum=rsum)))
+            dx = dx2.reshape(xshape)
+            need_x = need_w = False
         if need_x:
             res = core.f32c(dx_pass.reshape(-1, K)) if dx_pass is not None else None
             dx = core.gemm(dpre, w, 0, 1, M, K, N, ep=core.epilogue(alpha=wscale, residual=res)).reshape(xshape)

@@ -764,3 +764,25 @@ def test_modulated_conv_layers_vs_oracle(dev, B, R, Ci, Co, up):
     assert_close(wd.grad, wr.grad, 5e-5, 'dw')
     assert_close(sd.grad, sr.grad, 1e-4, 'dstyles')
     assert_close(bd.grad, br.grad, 5e-5, 'dbias')
+
+
+@pytest.mark.parametrize('tokens,N,K', [(144, 256, 256), (160, 2048, 256), (1024, 256, 256), (144, 256, 2048), (1024, 512, 512), (9000, 256, 256), (70, 36, 52)])
+def test_gemm_pair_data_and_weight_gradient(dev, tokens, N, K):
+    """ldetr_gemm_pair_f32: the data gradient dX = dY W (+ residual) and the weight gradient dW += dY^T X (+ bias row sums) of one
+    linear layer through one call -- one launch when both are small-tile problems, two otherwise (long K, many tokens, ragged
+    sizes): results must equal the separate calls and the fp64 reference."""
+    from layoutdetr_amd.hip import core
+    torch.manual_seed(90)
+    dy = torch.randn(tokens, N); w = torch.randn(N, K) / math.sqrt(K); x = torch.randn(tokens, K); res = torch.randn(tokens, K)
+    gw0 = torch.randn(N, K); gb0 = torch.randn(N)
+    dyd, wd, xd, resd = [t.to(dev) for t in (dy, w, x, res)]
+    use_rs = N % 4 == 0
+    gw = gw0.to(dev).clone(); gb = gb0.to(dev).clone(); dx = torch.empty(tokens, K, device=dev)
+    core.gemm_pair(dict(A=dyd, B=wd, ta=0, tb=1, M=tokens, N=K, K=N, out=dx, ep=core.epilogue(alpha=0.5, residual=resd)),
+                   dict(A=dyd, B=xd, ta=1, tb=1, M=N, N=K, K=tokens, out=gw, ep=core.epilogue(alpha=0.5, accumulate=True, a_rowsum=gb if use_rs else None)))
+    assert_close(dx, (0.5 * (dy.double() @ w.double()) + res.double()).float(), 3e-6, 'dX')
+    assert_close(gw, (gw0.double() + 0.5 * (dy.double().t() @ x.double())).float(), 3e-6, 'dW')
+    if use_rs:
+        assert_close(gb, (gb0.double() + dy.double().sum(0)).float(), 3e-6, 'dbias')
+    dx2 = core.gemm(dyd, wd, 0, 1, tokens, K, N, ep=core.epilogue(alpha=0.5, residual=resd))
+    assert_close(dx, dx2, 1e-6, 'pair vs single dX')
