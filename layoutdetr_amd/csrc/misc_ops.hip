@@ -159,13 +159,17 @@ static int launch_rr(RRParams& p, hipStream_t st) {
     p.rows_pb = (int)rows_pb;
     dim3 grid((unsigned)((p.P + rows_pb - 1) / rows_pb), p.B, cdiv(C4, TQ));
     const long nblk = (long)grid.x * grid.y;
-    p.part = (p.red1 || p.red2) && nblk > 8 ? scratch_alloc((size_t)nblk * p.C * sizeof(float) * (p.red2 ? 2 : 1)) : nullptr;
+    // atomics queue up per output cache line: 32 per block and line at ~5 ns each, i.e. ~0.16 us per sharing block -- cheaper than
+    // the ~4.5 us of a second launch up to ~30 sharers (measured: 48 us vs 10 us at 256 sharers); beyond that the partial sums go
+    // through the workspace to rr_finish_kernel
+    static const long finish_min = getenv("LDETR_RR_FINISH_MIN") ? atol(getenv("LDETR_RR_FINISH_MIN")) : 32;
+    const long sharers = p.red1 && p.red1_bs == 0 ? nblk : (long)grid.x;     // blocks adding into one output element
+    p.part = (p.red1 || p.red2) && sharers > finish_min ? scratch_alloc((size_t)nblk * p.C * sizeof(float) * (p.red2 ? 2 : 1)) : nullptr;
     if (p.mode == RR_COLSUM) hipLaunchKernelGGL(rowreduce_kernel<RR_COLSUM>, grid, 256, 0, st, p);
     else if (p.mode == RR_ACTGRAD) hipLaunchKernelGGL(rowreduce_kernel<RR_ACTGRAD>, grid, 256, 0, st, p);
     else hipLaunchKernelGGL(rowreduce_kernel<RR_MULRED>, grid, 256, 0, st, p);
     int rc = check_launch("rowreduce"); if (rc || !p.part) return rc;
-    const long longest = p.red1 && p.red1_bs == 0 ? nblk : (long)grid.x;     // partial rows behind one output element
-    int segs = (int)(longest / 32); if (segs < 1) segs = 1; if (segs > 16) segs = 16;
+    int segs = (int)(sharers / 32); if (segs < 1) segs = 1; if (segs > 16) segs = 16;
     hipLaunchKernelGGL(rr_finish_kernel, dim3(cdiv(p.C, 64), p.B, (p.red2 ? 2 : 1) * segs), 256, 0, st, p, (int)grid.x, segs);
     return check_launch("rowreduce_finish");
 }
