@@ -1041,12 +1041,12 @@ __global__ __launch_bounds__(NW * 64) void gemm_small_kernel(GemmParams p) {
 
 // Two independent small problems in ONE launch (the data and the weight gradient of a linear layer: both read dY).  These
 // GEMMs sit at the launch-latency floor (~6 us for 20 MFLOP), so a launch saved is their whole cost saved.  Tiles of problem 0
-// come first in the linear block order, then problem 1's; no split-K here.
+// come first in the linear block order (K slice major), then problem 1's; each problem may carry its own in-kernel split-K.
 template <int TA0, int TB0, int TA1, int TB1, int NW>
-__global__ __launch_bounds__(NW * 64) void gemm_small_pair_kernel(GemmParams p0, GemmParams p1, int gx0, int nt0, int gx1) {
+__global__ __launch_bounds__(NW * 64) void gemm_small_pair_kernel(GemmParams p0, GemmParams p1, int gx0, int nt0, int sk0, int gx1, int nt1, int sk1) {
     const int b = blockIdx.x;
-    if (b < nt0) gemm_small_body<TA0, TB0, NW>(p0, b % gx0, b / gx0, 0, 1, gx0);
-    else { const int c = b - nt0; gemm_small_body<TA1, TB1, NW>(p1, c % gx1, c / gx1, 0, 1, gx1); }
+    if (b < nt0 * sk0) { const int t = b % nt0; gemm_small_body<TA0, TB0, NW>(p0, t % gx0, t / gx0, b / nt0, sk0, gx0); }
+    else { const int c = b - nt0 * sk0, t = c % nt1; gemm_small_body<TA1, TB1, NW>(p1, t % gx1, t / gx1, c / nt1, sk1, gx1); }
 }
 
 static inline bool al16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
@@ -1237,12 +1237,9 @@ static Workspace& workspace_for_current_device() {
     return g_workspace[dev];
 }
 
-template <int TA, int TB>
-static int launch_small(GemmParams& p, hipStream_t st) {
-    dim3 grid(cdiv(p.N, 32), cdiv(p.M, 32), 1);
-    const long blocks = (long)grid.x * grid.y;
-    // few tiles + a long reduction (the decoders' 2048-wide FFN on 144 rows): 40 blocks would walk K one after the other; split K
-    // over up to 8 blocks per tile (>= 256 of K each) and reduce through the workspace inside the kernel
+// Split-K plan of a small-tile problem: few tiles + a long reduction (the decoders' 2048-wide FFN on 144 rows) would have 40 blocks
+// walk K one after the other; split K over up to 8 blocks per tile (>= 256 of K each) and reduce through the workspace in-kernel.
+static int plan_small_split(GemmParams& p, long blocks) {
     static const int small_split = getenv("LDETR_SMALL_SPLIT") ? atoi(getenv("LDETR_SMALL_SPLIT")) : 1;
     int sk = 1;
     if (small_split && blocks <= 128 && p.K >= 1024) {
@@ -1261,6 +1258,14 @@ static int launch_small(GemmParams& p, hipStream_t st) {
             } else sk = 1;
         }
     }
+    return sk;
+}
+
+template <int TA, int TB>
+static int launch_small(GemmParams& p, hipStream_t st) {
+    dim3 grid(cdiv(p.N, 32), cdiv(p.M, 32), 1);
+    const long blocks = (long)grid.x * grid.y;
+    const int sk = plan_small_split(p, blocks);
     grid.z = sk;
     const int kblock = (p.K + sk - 1) / sk;
     if (blocks * sk <= 256 && kblock >= 512) hipLaunchKernelGGL((gemm_small_kernel<TA, TB, 8>), grid, 512, 0, st, p);
@@ -1641,14 +1646,10 @@ extern "C" int ldetr_gemm_f32(const float* A, int64_t lda, int ta, const float* 
 // Two dense GEMMs in one call (the data gradient dX = dY W and the weight gradient dW += dY^T X of a linear layer).  When both are
 // plain small-tile problems (the usual case on the transformers' token counts) they run as ONE launch of gemm_small_pair_kernel;
 // anything else falls back to two ldetr_gemm_f32 calls in order.  Same semantics either way.
-static bool small_plain(const ldetr_gemm_desc& g, int& nw) {
+static bool small_class(const ldetr_gemm_desc& g) {
     static const int small_maxk = getenv("LDETR_SMALL_MAXK") ? atoi(getenv("LDETR_SMALL_MAXK")) : (1 << 30);
     if (g.splitk != 0 || g.M <= 0 || g.N <= 0 || g.K <= 0) return false;
-    if (!((long)cdiv(g.M, 64) * cdiv(g.N, 64) < SMALL_GEMM_TILES && (long)g.M * g.N * g.K <= SMALL_GEMM_MNK && g.K <= small_maxk)) return false;
-    const long blocks = (long)cdiv(g.N, 32) * cdiv(g.M, 32);
-    if (blocks <= 128 && g.K >= 1024) return false;          // takes the in-kernel split-K route on its own
-    nw = (blocks <= 256 && g.K >= 512) ? 8 : 4;
-    return true;
+    return (long)cdiv(g.M, 64) * cdiv(g.N, 64) < SMALL_GEMM_TILES && (long)g.M * g.N * g.K <= SMALL_GEMM_MNK && g.K <= small_maxk;
 }
 
 static void fill_dense(GemmParams& p, const ldetr_gemm_desc& g) {
@@ -1665,17 +1666,21 @@ static void fill_dense(GemmParams& p, const ldetr_gemm_desc& g) {
 extern "C" int ldetr_gemm_pair_f32(const ldetr_gemm_desc* g0, const ldetr_gemm_desc* g1, void* stream) {
     LDETR_CHECK(g0 && g1, "gemm_pair: null descriptor");
     static const int pair_on = getenv("LDETR_GEMM_PAIR") ? atoi(getenv("LDETR_GEMM_PAIR")) : 1;
-    int nw0 = 0, nw1 = 0;
     const bool layouts = g0->ta == 0 && g0->tb == 1 && g1->ta == 1 && g1->tb == 1;    // the instantiated pairing: NN + TN
-    if (pair_on && layouts && g0->A && g0->B && g0->C && g1->A && g1->B && g1->C && small_plain(*g0, nw0) && small_plain(*g1, nw1) && nw0 == nw1 &&
+    if (pair_on && layouts && g0->A && g0->B && g0->C && g1->A && g1->B && g1->C && small_class(*g0) && small_class(*g1) &&
         (!g1->ep || !g1->ep->a_rowsum || g1->lda == g1->M)) {
         GemmParams p0, p1;
         fill_dense(p0, *g0); fill_dense(p1, *g1);
+        const int gx0 = cdiv(p0.N, 32), nt0 = gx0 * cdiv(p0.M, 32), gx1 = cdiv(p1.N, 32), nt1 = gx1 * cdiv(p1.M, 32);
+        // one block size for both: 8 waves only when both problems would take them on their own
+        auto wants8 = [](long blocks, int sk, int K) { return blocks * sk <= 256 && (K + sk - 1) / sk >= 512; };
         if (!p0.ep.a_rowsum) {
-            const int gx0 = cdiv(p0.N, 32), nt0 = gx0 * cdiv(p0.M, 32), gx1 = cdiv(p1.N, 32), nt1 = gx1 * cdiv(p1.M, 32);
+            const int sk0 = plan_small_split(p0, nt0), sk1 = plan_small_split(p1, nt1);
+            const bool w8 = wants8(nt0, sk0, p0.K) && wants8(nt1, sk1, p1.K);
             hipStream_t st = (hipStream_t)stream;
-            if (nw0 == 8) hipLaunchKernelGGL((gemm_small_pair_kernel<0, 1, 1, 1, 8>), dim3(nt0 + nt1), 512, 0, st, p0, p1, gx0, nt0, gx1);
-            else hipLaunchKernelGGL((gemm_small_pair_kernel<0, 1, 1, 1, 4>), dim3(nt0 + nt1), 256, 0, st, p0, p1, gx0, nt0, gx1);
+            const dim3 grid((unsigned)(nt0 * sk0 + nt1 * sk1));
+            if (w8) hipLaunchKernelGGL((gemm_small_pair_kernel<0, 1, 1, 1, 8>), grid, 512, 0, st, p0, p1, gx0, nt0, sk0, gx1, nt1, sk1);
+            else hipLaunchKernelGGL((gemm_small_pair_kernel<0, 1, 1, 1, 4>), grid, 256, 0, st, p0, p1, gx0, nt0, sk0, gx1, nt1, sk1);
             return check_launch("gemm_small_pair");
         }
     }
