@@ -8,8 +8,9 @@
 // arithmetic end to end, so the device result is bit-identical to Pillow's; the fp32 normalisation uses correctly rounded
 // division / subtraction in the reference's order, so the float tensor is bit-identical too.
 //
-// HBM-bound byte work: per image the passes read H*W*3 bytes once, write and re-read the H*S*3 intermediate (L2-resident) and
-// write 3*S*S floats.  Horizontal pass: one block per (row, 256 output columns), the row segment staged in LDS with 4-byte loads;
+// Byte work whose algorithmic traffic is tiny (per image: read H*W*3 bytes once, write and re-read the H*S*3 intermediate, write
+// 3*S*S floats); the passes are bound by instruction issue instead: ~75 integer multiply-adds + 75 LDS byte reads per output pixel
+// of the horizontal pass (ablation: without the LDS reads 85 of 144 us remain, the bare multiply-add loop is 57 us).  Horizontal pass: one block per (row, 256 output columns), the row segment staged in LDS with 4-byte loads;
 // vertical pass: plane-major threads so the float stores are fully coalesced.  Weights are stored tap-major ([ksize][out]) so
 // neighbouring lanes read neighbouring weights.
 #include <math.h>
@@ -94,7 +95,16 @@ __global__ __launch_bounds__(256) void resample_v_norm_kernel(ResampleParams p) 
     const unsigned char* col = p.tmp + ((img * p.H + ymin) * (long)p.OW + x) * 3 + c;
     const long pitch = (long)p.OW * 3;
     int acc = 1 << (RS_PRECISION_BITS - 1);
-    for (int t = 0; t < cnt; t++) acc += col[t * pitch] * p.vk[(long)t * p.OH + yy];
+    if (p.vks <= 32) {                          // every tap's byte load in flight at once (8-bit x 23-bit: the 24-bit multiply is full rate)
+        int v[32];
+#pragma unroll
+        for (int t = 0; t < 32; t++) v[t] = t < cnt ? (int)col[t * pitch] : 0;
+#pragma unroll
+        for (int t = 0; t < 32; t++)
+            if (t < cnt) acc += __mul24(v[t], p.vk[(long)t * p.OH + yy]);
+    } else {
+        for (int t = 0; t < cnt; t++) acc += __mul24((int)col[t * pitch], p.vk[(long)t * p.OH + yy]);
+    }
     const int u8 = clip8(acc);
     if (p.out_u8) p.out_u8[((img * p.OH + yy) * (long)p.OW + x) * 3 + c] = (unsigned char)u8;
     if (p.out_chw) {
