@@ -896,8 +896,25 @@ __device__ __forceinline__ void small_load(const Operand& o, int row, int R, int
     }
 }
 
+// Scalar-addressed variant (K a multiple of 32, operand below 2 GiB): the lane's byte offset is computed once, the k position goes
+// into the buffer load's scalar offset -- no per-round 64-bit address arithmetic or bounds tests (11 VALU instructions per MFMA
+// were going into them; VALU issue is not hidden behind the matrix pipe here either).
+template <int T>
+__device__ __forceinline__ void small_load_fast(const __amdgpu_buffer_rsrc_t& rs, int voff, int k0, int ld, float (&f)[16]) {
+    if (T == 0) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const auto v = __builtin_amdgcn_raw_buffer_load_b128(rs, voff + 16 * j, k0 * 4, 0);
+            f[4 * j] = __int_as_float(v[0]); f[4 * j + 1] = __int_as_float(v[1]); f[4 * j + 2] = __int_as_float(v[2]); f[4 * j + 3] = __int_as_float(v[3]);
+        }
+    } else {
+#pragma unroll
+        for (int t = 0; t < 16; t++) f[t] = __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, voff, (k0 + t) * ld * 4, 0));
+    }
+}
+
 // Body of one 32x32 tile (bx, by) and K slice bz of `sk`; shared by the single-problem kernel and the paired launch below.
-template <int TA, int TB, int NW>
+template <int TA, int TB, int NW, bool FAST = false>
 __device__ __forceinline__ void gemm_small_body(const GemmParams& p, const int bx, const int by, const int bz, const int sk, const int gx) {
     using f32x16 = __attribute__((__vector_size__(16 * sizeof(float)))) float;
     __shared__ float red[NW][32][33];
@@ -910,6 +927,16 @@ __device__ __forceinline__ void gemm_small_body(const GemmParams& p, const int b
     const int kblk0 = bz * cper * 32, kblk1 = min(p.K, kblk0 + cper * 32);
     const int chunks = kblk1 > kblk0 ? (kblk1 - kblk0 + 31) / 32 : 0, per = (chunks + NW - 1) / NW;
     const int kbeg = kblk0 + wave * per * 32, kend = min(kblk1, kbeg + per * 32);
+    __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.A.p), 0, FAST ? 0x7fffffff : 0, 0x00020000);
+    __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.B.p), 0, FAST ? 0x7fffffff : 0, 0x00020000);
+    const int voffA = (m0 + cl < p.M) ? (TA == 0 ? ((m0 + cl) * (int)p.A.ld + 16 * kl) * 4 : (16 * kl * (int)p.A.ld + m0 + cl) * 4) : (int)0x80000000;
+    const int voffB = (n0 + cl < p.N) ? (TB == 0 ? ((n0 + cl) * (int)p.B.ld + 16 * kl) * 4 : (16 * kl * (int)p.B.ld + n0 + cl) * 4) : (int)0x80000000;
+    auto loadA = [&](int k0, float (&f)[16]) {
+        if constexpr (FAST) small_load_fast<TA>(rsA, voffA, k0, (int)p.A.ld, f); else small_load<TA>(p.A, m0 + cl, p.M, k0, kl, kend, f);
+    };
+    auto loadB = [&](int k0, float (&f)[16]) {
+        if constexpr (FAST) small_load_fast<TB>(rsB, voffB, k0, (int)p.B.ld, f); else small_load<TB>(p.B, n0 + cl, p.N, k0, kl, kend, f);
+    };
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; r++) acc[r] = 0.f;
@@ -917,13 +944,13 @@ __device__ __forceinline__ void gemm_small_body(const GemmParams& p, const int b
     const bool want_rs = TA == 1 && p.ep.a_rowsum != nullptr && bx == 0;   // the A panel is the same for every column block
     float rs = 0.f;
     if (kbeg < kend) {
-        small_load<TA>(p.A, m0 + cl, p.M, kbeg, kl, kend, a0);
-        small_load<TB>(p.B, n0 + cl, p.N, kbeg, kl, kend, b0);
+        loadA(kbeg, a0);
+        loadB(kbeg, b0);
     }
     for (int k = kbeg; k < kend; k += 64) {
         if (k + 32 < kend) {
-            small_load<TA>(p.A, m0 + cl, p.M, k + 32, kl, kend, a1);
-            small_load<TB>(p.B, n0 + cl, p.N, k + 32, kl, kend, b1);
+            loadA(k + 32, a1);
+            loadB(k + 32, b1);
         }
 #pragma unroll
         for (int t = 0; t < 16; t++) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[t], b0[t], acc, 0, 0, 0);
@@ -933,8 +960,8 @@ __device__ __forceinline__ void gemm_small_body(const GemmParams& p, const int b
         }
         if (k + 32 >= kend) break;
         if (k + 64 < kend) {
-            small_load<TA>(p.A, m0 + cl, p.M, k + 64, kl, kend, a0);
-            small_load<TB>(p.B, n0 + cl, p.N, k + 64, kl, kend, b0);
+            loadA(k + 64, a0);
+            loadB(k + 64, b0);
         }
 #pragma unroll
         for (int t = 0; t < 16; t++) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[t], b1[t], acc, 0, 0, 0);
@@ -1034,19 +1061,19 @@ __device__ __forceinline__ void gemm_small_body(const GemmParams& p, const int b
     }
 }
 
-template <int TA, int TB, int NW>
+template <int TA, int TB, int NW, bool FAST = false>
 __global__ __launch_bounds__(NW * 64) void gemm_small_kernel(GemmParams p) {
-    gemm_small_body<TA, TB, NW>(p, blockIdx.x, blockIdx.y, blockIdx.z, gridDim.z, gridDim.x);
+    gemm_small_body<TA, TB, NW, FAST>(p, blockIdx.x, blockIdx.y, blockIdx.z, gridDim.z, gridDim.x);
 }
 
 // Two independent small problems in ONE launch (the data and the weight gradient of a linear layer: both read dY).  These
 // GEMMs sit at the launch-latency floor (~6 us for 20 MFLOP), so a launch saved is their whole cost saved.  Tiles of problem 0
 // come first in the linear block order (K slice major), then problem 1's; each problem may carry its own in-kernel split-K.
-template <int TA0, int TB0, int TA1, int TB1, int NW>
+template <int TA0, int TB0, int TA1, int TB1, int NW, bool FAST = false>
 __global__ __launch_bounds__(NW * 64) void gemm_small_pair_kernel(GemmParams p0, GemmParams p1, int gx0, int nt0, int sk0, int gx1, int nt1, int sk1) {
     const int b = blockIdx.x;
-    if (b < nt0 * sk0) { const int t = b % nt0; gemm_small_body<TA0, TB0, NW>(p0, t % gx0, t / gx0, b / nt0, sk0, gx0); }
-    else { const int c = b - nt0 * sk0, t = c % nt1; gemm_small_body<TA1, TB1, NW>(p1, t % gx1, t / gx1, c / nt1, sk1, gx1); }
+    if (b < nt0 * sk0) { const int t = b % nt0; gemm_small_body<TA0, TB0, NW, FAST>(p0, t % gx0, t / gx0, b / nt0, sk0, gx0); }
+    else { const int c = b - nt0 * sk0, t = c % nt1; gemm_small_body<TA1, TB1, NW, FAST>(p1, t % gx1, t / gx1, c / nt1, sk1, gx1); }
 }
 
 static inline bool al16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
@@ -1261,6 +1288,13 @@ static int plan_small_split(GemmParams& p, long blocks) {
     return sk;
 }
 
+static bool small_fast_ok(const GemmParams& p, int ta, int tb) {
+    static const int on = getenv("LDETR_SMALL_FAST") ? atoi(getenv("LDETR_SMALL_FAST")) : 1;
+    const long a_bytes = (ta ? (long)p.K * p.A.ld : (long)p.M * p.A.ld) * 4, b_bytes = (tb ? (long)p.K * p.B.ld : (long)p.N * p.B.ld) * 4;
+    return on && (p.K % 32) == 0 && a_bytes < 0x7fffffffL && b_bytes < 0x7fffffffL && (ta || (p.A.ld % 4) == 0) && (tb || (p.B.ld % 4) == 0) &&
+           ((((uintptr_t)p.A.p) | ((uintptr_t)p.B.p)) & 15) == 0;
+}
+
 template <int TA, int TB>
 static int launch_small(GemmParams& p, hipStream_t st) {
     dim3 grid(cdiv(p.N, 32), cdiv(p.M, 32), 1);
@@ -1268,8 +1302,15 @@ static int launch_small(GemmParams& p, hipStream_t st) {
     const int sk = plan_small_split(p, blocks);
     grid.z = sk;
     const int kblock = (p.K + sk - 1) / sk;
-    if (blocks * sk <= 256 && kblock >= 512) hipLaunchKernelGGL((gemm_small_kernel<TA, TB, 8>), grid, 512, 0, st, p);
-    else hipLaunchKernelGGL((gemm_small_kernel<TA, TB, 4>), grid, 256, 0, st, p);
+    const bool fast = small_fast_ok(p, TA, TB);
+    const bool w8 = blocks * sk <= 256 && kblock >= 512;
+    if (fast) {
+        if (w8) hipLaunchKernelGGL((gemm_small_kernel<TA, TB, 8, true>), grid, 512, 0, st, p);
+        else hipLaunchKernelGGL((gemm_small_kernel<TA, TB, 4, true>), grid, 256, 0, st, p);
+    } else {
+        if (w8) hipLaunchKernelGGL((gemm_small_kernel<TA, TB, 8>), grid, 512, 0, st, p);
+        else hipLaunchKernelGGL((gemm_small_kernel<TA, TB, 4>), grid, 256, 0, st, p);
+    }
     return check_launch("gemm_small");
 }
 
@@ -1679,7 +1720,10 @@ extern "C" int ldetr_gemm_pair_f32(const ldetr_gemm_desc* g0, const ldetr_gemm_d
             const bool w8 = wants8(nt0, sk0, p0.K) && wants8(nt1, sk1, p1.K);
             hipStream_t st = (hipStream_t)stream;
             const dim3 grid((unsigned)(nt0 * sk0 + nt1 * sk1));
-            if (w8) hipLaunchKernelGGL((gemm_small_pair_kernel<0, 1, 1, 1, 8>), grid, 512, 0, st, p0, p1, gx0, nt0, sk0, gx1, nt1, sk1);
+            if (small_fast_ok(p0, 0, 1) && small_fast_ok(p1, 1, 1)) {
+                if (w8) hipLaunchKernelGGL((gemm_small_pair_kernel<0, 1, 1, 1, 8, true>), grid, 512, 0, st, p0, p1, gx0, nt0, sk0, gx1, nt1, sk1);
+                else hipLaunchKernelGGL((gemm_small_pair_kernel<0, 1, 1, 1, 4, true>), grid, 256, 0, st, p0, p1, gx0, nt0, sk0, gx1, nt1, sk1);
+            } else if (w8) hipLaunchKernelGGL((gemm_small_pair_kernel<0, 1, 1, 1, 8>), grid, 512, 0, st, p0, p1, gx0, nt0, sk0, gx1, nt1, sk1);
             else hipLaunchKernelGGL((gemm_small_pair_kernel<0, 1, 1, 1, 4>), grid, 256, 0, st, p0, p1, gx0, nt0, sk0, gx1, nt1, sk1);
             return check_launch("gemm_small_pair");
         }
