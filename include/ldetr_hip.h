@@ -126,8 +126,14 @@ typedef struct ldetr_gemm_desc {
     int M, N, K, splitk;
     const ldetr_epilogue* ep;
     int pix_per_sample;
+    /* single-launch path only: every element of op(A) is replaced by (a_mask > 0 ? A * a_mask_gain : 0), a_mask laid out like A --
+     * the gradient of a ReLU (+ dropout) layer folded into the dY loads of both problems; NULL = off */
+    const float* a_mask;
+    float a_mask_gain;
 } ldetr_gemm_desc;
 int ldetr_gemm_pair_f32(const ldetr_gemm_desc* g0, const ldetr_gemm_desc* g1, void* stream);
+/* 1 if the pair would run as one launch (then a_mask may be used), else 0. */
+int ldetr_gemm_pair_is_single_launch(const ldetr_gemm_desc* g0, const ldetr_gemm_desc* g1);
 
 int ldetr_conv2d_fwd_f32(const float* x, const ldetr_tensor4* xt, const float* w, int Cout, int KH, int KW, int stride,
                          int pad, float* y, int64_t ldy, int OH, int OW, const float* in_scale, int64_t in_scale_ld,

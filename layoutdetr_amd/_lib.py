@@ -20,7 +20,7 @@ class Tensor4(Structure):
 class GemmDesc(Structure):
     _fields_ = [('A', c_void_p), ('lda', c_int64), ('ta', c_int), ('B', c_void_p), ('ldb', c_int64), ('tb', c_int),
                 ('C', c_void_p), ('ldc', c_int64), ('M', c_int), ('N', c_int), ('K', c_int), ('splitk', c_int),
-                ('ep', c_void_p), ('pix_per_sample', c_int)]
+                ('ep', c_void_p), ('pix_per_sample', c_int), ('a_mask', c_void_p), ('a_mask_gain', c_float)]
 
 
 class Epilogue(Structure):
@@ -72,6 +72,7 @@ SIGNATURES = {
     'ldetr_embedding_bwd_f32': [_P, _P, _P, _L, _I, _I, _L, _P],
     'ldetr_debug_trace_tiles': [_P],
     'ldetr_gemm_pair_f32': [_P, _P, _P],
+    'ldetr_gemm_pair_is_single_launch': [_P, _P],
     'ldetr_demod_fwd_f32': [_P, _L, _L, _L, _L, _P, _P, _P, _I, _I, _I, _I, _I, _F, _P],
     'ldetr_demod_bwd_f32': [_P, _L, _L, _L, _L, _P, _P, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _P],
     'ldetr_layout_losses_f32': [_P, _P, _P, _I, _I, _P, _P, _P],
@@ -104,7 +105,7 @@ def load():
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported
         fn.restype = c_int
         fn.argtypes = argtypes
-    if lib.ldetr_abi_version() != 13:
+    if lib.ldetr_abi_version() != 14:
         raise RuntimeError('libldetr_hip.so ABI version mismatch; rebuild it')
     _lib = lib
     return lib

@@ -90,6 +90,7 @@ struct GemmParams {
     int ep_vec;          // host-checked: every epilogue operand is float4-addressable -> LDS-staged row-major epilogue
     float* ws;           // split-K fix-up: per-(tile, slice) partial tiles; null = fp32 atomics into C
     int* ws_count;       //   per-tile arrival counters (zero between launches)
+    const float* a_mask; float a_mask_gain;   // small-tile kernels: A element := mask > 0 ? A * gain : 0 (ReLU gradient folded into the dY loads)
     long long* trace;    // development aid (tools/trace_tiles.py): 4 wall-clock stamps per block, or null
     GemmEpilogue ep;
 };
@@ -931,8 +932,16 @@ __device__ __forceinline__ void gemm_small_body(const GemmParams& p, const int b
     __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.B.p), 0, FAST ? 0x7fffffff : 0, 0x00020000);
     const int voffA = (m0 + cl < p.M) ? (TA == 0 ? ((m0 + cl) * (int)p.A.ld + 16 * kl) * 4 : (16 * kl * (int)p.A.ld + m0 + cl) * 4) : (int)0x80000000;
     const int voffB = (n0 + cl < p.N) ? (TB == 0 ? ((n0 + cl) * (int)p.B.ld + 16 * kl) * 4 : (16 * kl * (int)p.B.ld + n0 + cl) * 4) : (int)0x80000000;
+    __amdgpu_buffer_rsrc_t rsM = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.a_mask ? p.a_mask : p.A.p), 0, FAST ? 0x7fffffff : 0, 0x00020000);
     auto loadA = [&](int k0, float (&f)[16]) {
         if constexpr (FAST) small_load_fast<TA>(rsA, voffA, k0, (int)p.A.ld, f); else small_load<TA>(p.A, m0 + cl, p.M, k0, kl, kend, f);
+        if (p.a_mask) {   // dY of a ReLU (+ dropout) layer: the saved output decides which elements carry gradient
+            float mk[16];
+            if constexpr (FAST) small_load_fast<TA>(rsM, voffA, k0, (int)p.A.ld, mk);
+            else { Operand om = p.A; om.p = p.a_mask; small_load<TA>(om, m0 + cl, p.M, k0, kl, kend, mk); }
+#pragma unroll
+            for (int t = 0; t < 16; t++) f[t] = mk[t] > 0.f ? f[t] * p.a_mask_gain : 0.f;
+        }
     };
     auto loadB = [&](int k0, float (&f)[16]) {
         if constexpr (FAST) small_load_fast<TB>(rsB, voffB, k0, (int)p.B.ld, f); else small_load<TB>(p.B, n0 + cl, p.N, k0, kl, kend, f);
@@ -1701,15 +1710,24 @@ static void fill_dense(GemmParams& p, const ldetr_gemm_desc& g) {
     p.B.vec = al16(g.B) && (g.ldb % 4 == 0) && (g.tb ? (g.N % 4 == 0) : (g.K % 4 == 0));
     p.M = g.M; p.N = g.N; p.K = g.K; p.C = g.C; p.ldc = g.ldc;
     p.zmode = 0; p.splitk = 1; p.pstep = 1; p.nsamp = 1; p.pix_per_sample = g.pix_per_sample;
+    p.a_mask = g.a_mask; p.a_mask_gain = g.a_mask_gain;
     fill_epilogue(p.ep, g.ep);
+}
+
+static bool pair_single_launch(const ldetr_gemm_desc* g0, const ldetr_gemm_desc* g1) {
+    static const int pair_on = getenv("LDETR_GEMM_PAIR") ? atoi(getenv("LDETR_GEMM_PAIR")) : 1;
+    const bool layouts = g0->ta == 0 && g0->tb == 1 && g1->ta == 1 && g1->tb == 1;    // the instantiated pairing: NN + TN
+    return pair_on && layouts && g0->A && g0->B && g0->C && g1->A && g1->B && g1->C && small_class(*g0) && small_class(*g1) &&
+           (!g1->ep || !g1->ep->a_rowsum || g1->lda == g1->M) && !(g0->ep && g0->ep->a_rowsum);
+}
+
+extern "C" int ldetr_gemm_pair_is_single_launch(const ldetr_gemm_desc* g0, const ldetr_gemm_desc* g1) {
+    return (g0 && g1 && pair_single_launch(g0, g1)) ? 1 : 0;
 }
 
 extern "C" int ldetr_gemm_pair_f32(const ldetr_gemm_desc* g0, const ldetr_gemm_desc* g1, void* stream) {
     LDETR_CHECK(g0 && g1, "gemm_pair: null descriptor");
-    static const int pair_on = getenv("LDETR_GEMM_PAIR") ? atoi(getenv("LDETR_GEMM_PAIR")) : 1;
-    const bool layouts = g0->ta == 0 && g0->tb == 1 && g1->ta == 1 && g1->tb == 1;    // the instantiated pairing: NN + TN
-    if (pair_on && layouts && g0->A && g0->B && g0->C && g1->A && g1->B && g1->C && small_class(*g0) && small_class(*g1) &&
-        (!g1->ep || !g1->ep->a_rowsum || g1->lda == g1->M)) {
+    if (pair_single_launch(g0, g1)) {
         GemmParams p0, p1;
         fill_dense(p0, *g0); fill_dense(p1, *g1);
         const int gx0 = cdiv(p0.N, 32), nt0 = gx0 * cdiv(p0.M, 32), gx1 = cdiv(p1.N, 32), nt1 = gx1 * cdiv(p1.M, 32);
@@ -1728,6 +1746,7 @@ extern "C" int ldetr_gemm_pair_f32(const ldetr_gemm_desc* g0, const ldetr_gemm_d
             return check_launch("gemm_small_pair");
         }
     }
+    LDETR_CHECK(!g0->a_mask && !g1->a_mask, "gemm_pair: a_mask is only available on the single-launch path (ask ldetr_gemm_pair_is_single_launch first)");
     int rc = ldetr_gemm_f32(g0->A, g0->lda, g0->ta, g0->B, g0->ldb, g0->tb, g0->C, g0->ldc, g0->M, g0->N, g0->K, g0->splitk, g0->ep, g0->pix_per_sample, stream);
     if (rc) return rc;
     return ldetr_gemm_f32(g1->A, g1->lda, g1->ta, g1->B, g1->ldb, g1->tb, g1->C, g1->ldc, g1->M, g1->N, g1->K, g1->splitk, g1->ep, g1->pix_per_sample, stream);

@@ -247,9 +247,7 @@ def gemm(A, B, ta, tb, M, N, K, out=None, ep=None, splitk=0, pix_per_sample=0, l
     return out
 
 
-def gemm_pair(g0, g1):
-    """Two gemm() calls as one C-ABI call (ldetr_gemm_pair_f32): g = dict(A, B, ta, tb, M, N, K, out, ep).  The data and the weight
-    gradient of a linear layer run as ONE kernel launch when both are small-tile problems; otherwise as two, in order."""
+def _pair_descs(g0, g1):
     descs = []
     flops = 0.0
     for g in (g0, g1):
@@ -261,8 +259,25 @@ def gemm_pair(g0, g1):
         d.M, d.N, d.K, d.splitk = int(g['M']), int(g['N']), int(g['K']), 0
         d.ep = ctypes.addressof(g['ep']) if g.get('ep') is not None else None
         d.pix_per_sample = 0
+        m = g.get('a_mask')
+        d.a_mask = m.data_ptr() if m is not None else None
+        d.a_mask_gain = float(g.get('a_mask_gain', 1.0))
         descs.append(d)
         flops += 2.0 * d.M * d.N * d.K
+    return descs, flops
+
+
+def gemm_pair_is_single_launch(g0, g1):
+    """True if gemm_pair(g0, g1) runs as one kernel launch (only then may the descriptors carry `a_mask`)."""
+    descs, _ = _pair_descs(g0, g1)
+    return lib().ldetr_gemm_pair_is_single_launch(ctypes.byref(descs[0]), ctypes.byref(descs[1])) == 1
+
+
+def gemm_pair(g0, g1):
+    """Two gemm() calls as one C-ABI call (ldetr_gemm_pair_f32): g = dict(A, B, ta, tb, M, N, K, out, ep[, a_mask, a_mask_gain]).
+    The data and the weight gradient of a linear layer run as ONE kernel launch when both are small-tile problems; otherwise as
+    two, in order.  a_mask (laid out like A) folds a ReLU gradient into the loads of A: single-launch path only."""
+    descs, flops = _pair_descs(g0, g1)
     engine_call('gemm', flops, lambda: check(lib().ldetr_gemm_pair_f32(ctypes.byref(descs[0]), ctypes.byref(descs[1]), stream()), 'gemm_pair'))
 
 

@@ -5,6 +5,7 @@ Replaces ATen addmm/matmul behind every nn.Linear on the hot path: FFN 256<->204
 FullyConnectedLayer (training/networks_stylegan2.py:117-123).
 """
 import ctypes
+import os
 
 import torch
 
@@ -36,6 +37,11 @@ def act_backward(dy2, y2, act, act_alpha, act_gain, want_dbias, bias=None, demod
         core.ptr(dy2), core.ptr(y2), core.ptr(dv), core.ptr(bias), core.ptr(demod), core.ptr(dbias), core.ptr(ddemod),
         B, R // B, C, act, act_alpha, act_gain, core.stream()), 'act_bwd_reduce')
     return dv, (None if dbias_out is not None else dbias), ddemod
+
+
+# ReLU gradient folded into the paired kernel's dY loads (ldetr_gemm_desc.a_mask): measured neutral (293.1 vs 292.7 images/s: the
+# second read of the hidden activations costs what the two saved launches gain), so it stays opt-in
+_FUSED_RELU = os.environ.get('LDETR_FUSED_RELU', '0') != '0'
 
 
 class _LinearFn(torch.autograd.Function):
@@ -84,7 +90,25 @@ class _LinearFn(torch.autograd.Function):
             gw = gw[r0:r1]
         if gb is not None:
             gb = gb[r0:r1] if (N % 4 == 0 and r0 % 4 == 0) else None
-        if act != ACT_NONE:
+        pairable = need_x and need_w and gw is not None and gw.is_contiguous() and not core.SIDE_WGRAD
+        dx = dw = db = None
+        fused_relu = False
+        if _FUSED_RELU and act == ACT_RELU and pairable and (gb is not None or not need_b) and y.is_contiguous() and dy2.is_contiguous():
+            # ReLU (+ dropout) gradient folded into the paired kernel's dY loads: no activation-gradient pass, no bias column sums
+            gain = act_gain / (1.0 - p_drop) if p_drop > 0 else act_gain
+            res = core.f32c(dx_pass.reshape(-1, K)) if dx_pass is not None else None
+            dx2 = torch.empty((M, K), device=dy2.device, dtype=torch.float32)
+            g0 = dict(A=dy2, B=w, ta=0, tb=1, M=M, N=K, K=N, out=dx2, ep=core.epilogue(alpha=wscale, residual=res), a_mask=y, a_mask_gain=gain)
+            g1 = dict(A=dy2, B=x2, ta=1, tb=1, M=N, N=K, K=M, out=gw, ep=core.epilogue(alpha=wscale, accumulate=True, a_rowsum=gb if need_b else None),
+                      a_mask=y, a_mask_gain=gain)
+            if core.gemm_pair_is_single_launch(g0, g1):
+                core.gemm_pair(g0, g1)
+                dx = dx2.reshape(xshape)
+                fused_relu = True
+        if fused_relu:
+            need_x = need_w = False
+            dpre = None
+        elif act != ACT_NONE:
             gain = act_gain / (1.0 - p_drop) if p_drop > 0 else act_gain
             dpre, db, _ = act_backward(dy2, y, act, act_alpha, gain, need_b, dbias_out=gb)
         else:
@@ -97,8 +121,7 @@ class _LinearFn(torch.autograd.Function):
                                      keep=(dpre,))
                 else:
                     db = core.colsum(dpre).reshape(-1)
-        dx = dw = None
-        if need_x and need_w and gw is not None and gw.is_contiguous() and not core.SIDE_WGRAD:
+        if need_x and need_w and pairable:
             # dX = dY W and dW += dY^T X through one C-ABI call: one kernel launch when both are small-tile problems
             res = core.f32c(dx_pass.reshape(-1, K)) if dx_pass is not None else None
             dx2 = torch.empty((M, K), device=dpre.device, dtype=torch.float32)

@@ -786,3 +786,25 @@ def test_gemm_pair_data_and_weight_gradient(dev, tokens, N, K):
         assert_close(gb, (gb0.double() + dy.double().sum(0)).float(), 3e-6, 'dbias')
     dx2 = core.gemm(dyd, wd, 0, 1, tokens, K, N, ep=core.epilogue(alpha=0.5, residual=resd))
     assert_close(dx, dx2, 1e-6, 'pair vs single dX')
+
+
+def test_gemm_pair_relu_mask_fold(dev):
+    """ldetr_gemm_desc.a_mask: the ReLU (+ dropout scale) gradient applied to dY inside the paired launch equals masking dY first;
+    the bias row sums see the masked values; the query tells when the single-launch path (and with it a_mask) is available."""
+    from layoutdetr_amd.hip import core
+    torch.manual_seed(91)
+    tokens, N, K = 1024, 2048, 256
+    dy = torch.randn(tokens, N); y = torch.relu(torch.randn(tokens, N)); w = torch.randn(N, K) / 16; x = torch.randn(tokens, K)
+    gain = 1.0 / 0.9
+    dpre = torch.where(y > 0, dy * gain, torch.zeros_like(dy))
+    dyd, yd, wd, xd = [t.to(dev) for t in (dy, y, w, x)]
+    gw = torch.zeros(N, K, device=dev); gb = torch.zeros(N, device=dev); dx = torch.empty(tokens, K, device=dev)
+    g0 = dict(A=dyd, B=wd, ta=0, tb=1, M=tokens, N=K, K=N, out=dx, ep=core.epilogue(), a_mask=yd, a_mask_gain=gain)
+    g1 = dict(A=dyd, B=xd, ta=1, tb=1, M=N, N=K, K=tokens, out=gw, ep=core.epilogue(accumulate=True, a_rowsum=gb), a_mask=yd, a_mask_gain=gain)
+    assert core.gemm_pair_is_single_launch(g0, g1)
+    core.gemm_pair(g0, g1)
+    assert_close(dx, (dpre.double() @ w.double()).float(), 3e-6, 'dX')
+    assert_close(gw, (dpre.double().t() @ x.double()).float(), 3e-6, 'dW')
+    assert_close(gb, dpre.double().sum(0).float(), 3e-6, 'dbias')
+    big = dict(A=torch.zeros(40000, 256, device=dev), B=wd[:256], ta=0, tb=1, M=40000, N=K, K=256, out=torch.empty(40000, K, device=dev), ep=core.epilogue())
+    assert not core.gemm_pair_is_single_launch(big, g1)
