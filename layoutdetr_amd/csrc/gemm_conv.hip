@@ -426,7 +426,7 @@ __global__ __launch_bounds__(NWV * 64) void gemm_f32_kernel(GemmParams p) {
     // buffer_load_dwordx4 (an out-of-range vector offset returns zeros: that is the padding).
     // FAST is chosen by the host (fast_operands_ok in launch_gemm checks every condition below); the generic instantiation carries
     // none of this code (as runtime branches it slowed the generic path of the 32-channel 256^2 layer from 420 to 510 us).
-    constexpr bool A_FAST = FAST && (AMODE == OP_KC_CONV || AMODE == OP_KC_CONVT || AMODE == OP_KC_DENSE || AMODE == OP_RC_DENSE);
+    constexpr bool A_FAST = FAST && (AMODE == OP_KC_CONV || AMODE == OP_KC_CONVT || AMODE == OP_KC_DENSE || AMODE == OP_RC_DENSE || AMODE == OP_RC_PIX);
     constexpr bool B_FAST = FAST && (BMODE == OP_KC_DENSE || BMODE == OP_RC_WT || BMODE == OP_RC_DENSE || BMODE == OP_RC_PIX || BMODE == OP_KC_WTAP);
     constexpr bool TAP_STATE = FAST && (AMODE == OP_KC_CONV || AMODE == OP_KC_CONVT || BMODE == OP_RC_WT || BMODE == OP_KC_WTAP);
     constexpr bool fastA = A_FAST, fastB = B_FAST;
@@ -506,6 +506,27 @@ __global__ __launch_bounds__(NWV * 64) void gemm_f32_kernel(GemmParams p) {
     int b_sy[NUB], b_sx[NUB];
     const int pix_st = p.B.tapped ? p.B.stride : 1, pix_pad = p.B.tapped ? p.B.pad : 0;
     const int pix_kh = p.B.tapped ? z.fkh : 0, pix_kw = p.B.tapped ? z.fkw : 0;
+    constexpr bool PIX_STATE = FAST && (AMODE == OP_RC_PIX || BMODE == OP_RC_PIX);
+    const int pixDH = AMODE == OP_RC_PIX ? p.A.DH : p.B.DH, pixDW = AMODE == OP_RC_PIX ? p.A.DW : p.B.DW;   // the pixel grid k runs over
+    int a_sy[NUA], a_sx[NUA];
+    const int apix_st = p.A.tapped ? p.A.stride : 1, apix_pad = p.A.tapped ? p.A.pad : 0;
+    const int apix_kh = p.A.tapped ? z.fkh : 0, apix_kw = p.A.tapped ? z.fkw : 0;
+    if constexpr (FAST && AMODE == OP_RC_PIX) {   // the same view as the A operand (transposed-conv weight gradient)
+        const long padoff = (long)apix_pad * p.A.sh + (long)apix_pad * p.A.sw;
+        rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.A.p) - padoff, 0, 0x7fffffff, 0x00020000);
+        const int wrow = pixDW >= BKT ? BKT : pixDW;
+#pragma unroll
+        for (int i = 0; i < NUA; i++) {
+            const int uy = a_k[i] / wrow, ux = a_k[i] - uy * wrow;
+            a_sy[i] = uy * apix_st - apix_pad + apix_kh; a_sx[i] = ux * apix_st - apix_pad + apix_kw;
+            a_voff[i] = (m0 + a_r[i] < z.M) ? (int)(((long)uy * apix_st * p.A.sh + (long)ux * apix_st * p.A.sw + m0 + a_r[i]) * 4) : (int)0x80000000;
+        }
+    }
+    if constexpr (PIX_STATE) {
+        const int per = pixDH * pixDW;
+        g_n = z.kbeg / per; const int rem = z.kbeg - g_n * per;
+        g_y0 = rem / pixDW; g_x0 = rem - g_y0 * pixDW;
+    }
     if constexpr (FAST && BMODE == OP_RC_PIX) {
         const long padoff = (long)pix_pad * p.B.sh + (long)pix_pad * p.B.sw;
         rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.B.p) - padoff, 0, 0x7fffffff, 0x00020000);
@@ -516,9 +537,6 @@ __global__ __launch_bounds__(NWV * 64) void gemm_f32_kernel(GemmParams p) {
             b_sy[i] = uy * pix_st - pix_pad + pix_kh; b_sx[i] = ux * pix_st - pix_pad + pix_kw;
             b_voff[i] = (n0 + b_r[i] < p.N) ? (int)(((long)uy * pix_st * p.B.sh + (long)ux * pix_st * p.B.sw + n0 + b_r[i]) * 4) : (int)0x80000000;
         }
-        const int per = p.B.DH * p.B.DW;
-        g_n = z.kbeg / per; const int rem = z.kbeg - g_n * per;
-        g_y0 = rem / p.B.DW; g_x0 = rem - g_y0 * p.B.DW;
     }
     if constexpr (FAST && BMODE == OP_KC_WTAP) {   // weights [n][tap][c]: row base + (tap * C + c0) scalar
         rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.B.p), 0, 0x7fffffff, 0x00020000);
@@ -566,6 +584,15 @@ __global__ __launch_bounds__(NWV * 64) void gemm_f32_kernel(GemmParams p) {
                 if (fastA) {
                     if constexpr (AMODE == OP_KC_DENSE) {
                         ra[i] = as_float4(__builtin_amdgcn_raw_buffer_load_b128(rsA, a_voff[i], k0 * 4, 0));
+                    } else if constexpr (AMODE == OP_RC_PIX) {
+                        const int sy = a_sy[i] + g_y0 * apix_st, sx = a_sx[i] + g_x0 * apix_st;
+                        const bool ok = ((unsigned)sy < (unsigned)p.A.SH) & ((unsigned)sx < (unsigned)p.A.SW);
+                        const int soff = (int)(((long)g_n * p.A.sn + (long)(g_y0 * apix_st + apix_kh) * p.A.sh + (long)(g_x0 * apix_st + apix_kw) * p.A.sw) * 4);
+                        ra[i] = as_float4(__builtin_amdgcn_raw_buffer_load_b128(rsA, ok ? a_voff[i] : (int)0x80000000, soff, 0));
+                        if (p.A.scale && ok && m0 + a_r[i] < z.M) {
+                            const float4 sc = *reinterpret_cast<const float4*>(p.A.scale + (long)g_n * p.A.scale_ld + m0 + a_r[i]);
+                            ra[i].x *= sc.x; ra[i].y *= sc.y; ra[i].z *= sc.z; ra[i].w *= sc.w;
+                        }
                     } else if constexpr (AMODE == OP_RC_DENSE) {   // rows of the tile past the end of the reduction read as zeros
                         ra[i] = as_float4(__builtin_amdgcn_raw_buffer_load_b128(rsA, a_k[i] < z.kend - k0 ? a_voff[i] : (int)0x80000000, k0 * (int)p.A.ld * 4, 0));
                     } else {
@@ -627,10 +654,10 @@ __global__ __launch_bounds__(NWV * 64) void gemm_f32_kernel(GemmParams p) {
                 if constexpr (BMODE == OP_RC_PIX || BMODE == OP_RC_CONVK) kdec_step_pix(b_d[i], BKT, p.B.DH, p.B.DW);
             }
         }
-        if constexpr (FAST && BMODE == OP_RC_PIX) {   // next k-tile: 32 pixels further along the (sample, row, column) order
-            if (p.B.DW >= BKT) { g_x0 += BKT; if (g_x0 >= p.B.DW) { g_x0 = 0; g_y0++; } }
-            else g_y0 += BKT / p.B.DW;
-            if (g_y0 >= p.B.DH) { g_y0 = 0; g_n++; }
+        if constexpr (PIX_STATE) {   // next k-tile: 32 pixels further along the (sample, row, column) order
+            if (pixDW >= BKT) { g_x0 += BKT; if (g_x0 >= pixDW) { g_x0 = 0; g_y0++; } }
+            else g_y0 += BKT / pixDW;
+            if (g_y0 >= pixDH) { g_y0 = 0; g_n++; }
         }
         if constexpr (TAP_STATE) {
             if (k_tiles_in_taps) {   // next k-tile: one k-tile of channels further, or the next tap
@@ -1418,7 +1445,7 @@ template <int AMODE, int BMODE>
 static bool fast_operands_ok(const GemmParams& p, int Mmax) {
     static const int fast_loads = getenv("LDETR_FAST_LOADS") ? atoi(getenv("LDETR_FAST_LOADS")) : 63;   // 1 conv, 2 dense B, 4 transposed conv, 8 dense A, 16 row-contiguous dense, 32 pixel-major (weight gradient input)
     constexpr int BKT = 32;
-    constexpr bool a_cap = (AMODE == OP_KC_CONV || AMODE == OP_KC_CONVT || AMODE == OP_KC_DENSE || AMODE == OP_RC_DENSE);
+    constexpr bool a_cap = (AMODE == OP_KC_CONV || AMODE == OP_KC_CONVT || AMODE == OP_KC_DENSE || AMODE == OP_RC_DENSE || AMODE == OP_RC_PIX);
     constexpr bool b_cap = (BMODE == OP_KC_DENSE || BMODE == OP_RC_WT || BMODE == OP_RC_DENSE || BMODE == OP_RC_PIX || BMODE == OP_KC_WTAP);
     if (!a_cap && !b_cap) return false;
     const long lim = 0x7fffffffL;
@@ -1449,6 +1476,12 @@ static bool fast_operands_ok(const GemmParams& p, int Mmax) {
     }
     if (BMODE == OP_KC_WTAP) {
         if (!((fast_loads & 4) && p.B.vec && taps_ok(p.B.C, p.B.KH, p.B.KW) && p.B.C == p.A.C && (long)p.N * p.B.ld * 4 < lim)) return false;
+    }
+    if (AMODE == OP_RC_PIX) {
+        const int DH = p.A.DH, DW = p.A.DW, pad = p.A.tapped ? p.A.pad : 0;
+        const bool rows_ok = DH > 0 && DW > 0 && ((DW % BKT) == 0 || ((BKT % DW) == 0 && ((long)DH * DW) % BKT == 0));
+        if (!((fast_loads & 32) && p.A.vec && rows_ok && (p.K % BKT) == 0 && (BMODE != OP_RC_PIX || (p.B.DH == DH && p.B.DW == DW)) &&
+              ((long)p.nsamp * p.A.sn + (long)pad * (p.A.sh + p.A.sw) + (long)BKT * (p.A.sh + p.A.sw)) * 4 < lim)) return false;
     }
     if (BMODE == OP_RC_PIX) {   // k-tiles of 32 pixels aligned to the image rows
         const int DH = p.B.DH, DW = p.B.DW, pad = p.B.tapped ? p.B.pad : 0;
@@ -1485,7 +1518,7 @@ static int launch_tile_impl(GemmParams& p, dim3 grid, hipStream_t st) {
 
 template <int BM, int BN, int BKT, int AMODE, int BMODE, int NWV = 4>
 static int launch_tile(GemmParams& p, dim3 grid, int Mmax, hipStream_t st) {
-    constexpr bool cap = (AMODE == OP_KC_CONV || AMODE == OP_KC_CONVT || AMODE == OP_KC_DENSE || AMODE == OP_RC_DENSE || BMODE == OP_KC_DENSE || BMODE == OP_RC_WT || BMODE == OP_RC_DENSE || BMODE == OP_RC_PIX || BMODE == OP_KC_WTAP);
+    constexpr bool cap = (AMODE == OP_KC_CONV || AMODE == OP_KC_CONVT || AMODE == OP_KC_DENSE || AMODE == OP_RC_DENSE || AMODE == OP_RC_PIX || BMODE == OP_KC_DENSE || BMODE == OP_RC_WT || BMODE == OP_RC_DENSE || BMODE == OP_RC_PIX || BMODE == OP_KC_WTAP);
     if constexpr (cap) {
         if (fast_operands_ok<AMODE, BMODE>(p, Mmax)) return launch_tile_impl<BM, BN, BKT, AMODE, BMODE, NWV, true>(p, grid, st);
     }
