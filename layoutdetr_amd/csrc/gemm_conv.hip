@@ -299,7 +299,7 @@ __device__ __forceinline__ ZCtx make_zctx(const GemmParams& p) {
     if (p.zmode == 1) {
         int s = p.pstep;
         int ncls = s * s;
-        int cls = blockIdx.z % ncls;
+        int cls = ncls - 1 - blockIdx.z % ncls;   // heaviest parity class (most taps) first: blocks are dispatched in z order and the light classes fill the tail
         ks = blockIdx.z / ncls;
         z.py = cls / s; z.px = cls - z.py * s;
         z.DH2 = (p.A.DH - z.py + s - 1) / s; z.DW2 = (p.A.DW - z.px + s - 1) / s;
