@@ -38,15 +38,19 @@ inline int check_launch(const char* what) {
 
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
-// Counter-based RNG: splitmix64 finaliser over (seed, element index).
-// The same (seed, idx) pair is evaluated in forward and backward, so dropout
-// masks are regenerated rather than stored.
+// Counter-based RNG over (seed, element index): the same pair is evaluated in forward and backward, so dropout masks are
+// regenerated rather than stored.  32-bit mixing (murmur3 finaliser over the folded index, keyed by both seed halves): two
+// quarter-rate 32-bit multiplies per element instead of the 64-bit multiplies of a splitmix64 finaliser, which cost ~200 cycles
+// per element and were half of the VALU work of the attention kernels (VALU issue is not hidden behind the matrix pipe).
 __device__ __forceinline__ uint32_t rng_bits(uint64_t seed, uint64_t idx) {
-    uint64_t z = seed + idx * 0x9E3779B97F4A7C15ull + 0x632BE59BD9B4E019ull;
-    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-    z = z ^ (z >> 31);
-    return (uint32_t)(z >> 32);
+    uint32_t x = (uint32_t)idx ^ (uint32_t)seed;
+    x *= 0xcc9e2d51u;
+    x = (x << 15) | (x >> 17);
+    x ^= (uint32_t)(seed >> 32) + (uint32_t)(idx >> 32) * 0x1b873593u;
+    x ^= x >> 16; x *= 0x85ebca6bu;
+    x ^= x >> 13; x *= 0xc2b2ae35u;
+    x ^= x >> 16;
+    return x;
 }
 // keep-scale for dropout: 0 if dropped else 1/(1-p). p_drop in [0,1).
 __device__ __forceinline__ float drop_scale(uint64_t seed, uint64_t idx, float p_drop, float inv_keep) {
