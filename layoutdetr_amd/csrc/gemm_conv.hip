@@ -726,6 +726,7 @@ __global__ __launch_bounds__(NWV * 64) void gemm_f32_kernel(GemmParams p) {
     {
         __syncthreads();
         if (LDETR_TILE_TRACE && p.trace) tr1 = wall_clock64();
+        if (!LDETR_TILE_TRACE) __builtin_amdgcn_sched_barrier(0);   // (the stamp sites double as scheduling fences: without either, hipcc's schedule of this kernel is 7 % slower end to end)
         for (int kt = 0; kt < nk; kt++) {
             const int buf = kt & 1;
             if (kt + 1 < nk) gload(z.kbeg + (kt + 1) * BKT, ra0, rb0);
@@ -736,6 +737,7 @@ __global__ __launch_bounds__(NWV * 64) void gemm_f32_kernel(GemmParams p) {
     }
 
     if (LDETR_TILE_TRACE && p.trace) tr2 = wall_clock64();
+    if (!LDETR_TILE_TRACE) __builtin_amdgcn_sched_barrier(0);
     auto trace_out = [&]() {
         if (LDETR_TILE_TRACE && p.trace && threadIdx.x == 0) {
             long long* t = p.trace + 5 * (((long)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x);
