@@ -808,3 +808,42 @@ def test_gemm_pair_relu_mask_fold(dev):
     assert_close(gb, dpre.double().sum(0).float(), 3e-6, 'dbias')
     big = dict(A=torch.zeros(40000, 256, device=dev), B=wd[:256], ta=0, tb=1, M=40000, N=K, K=256, out=torch.empty(40000, K, device=dev), ep=core.epilogue())
     assert not core.gemm_pair_is_single_launch(big, g1)
+
+
+def test_fast_and_generic_instantiations_agree(dev, tmp_path):
+    """The scalar-addressed (FAST) kernels and the paired launch only change how addresses are formed and how work is batched:
+    a subprocess with them switched off (LDETR_FAST_LOADS=0, LDETR_SMALL_FAST=0, LDETR_GEMM_PAIR=0) must produce the same
+    conv / linear forward, data gradient and weight gradient as this process, to the last bit for the tiled conv kernels
+    (same reduction order) and to 1e-6 where split-K decisions may differ."""
+    import subprocess, sys
+    script = r'''
+import sys, math, numpy as np, torch
+import torch.nn.functional as F
+from layoutdetr_amd.hip import conv
+from layoutdetr_amd.hip.linear import linear
+dev = torch.device('cuda:0'); out = {}
+torch.manual_seed(123)
+for i, (N, H, Ci, Co, k, s, p) in enumerate([(2, 32, 64, 128, 3, 1, 1), (2, 32, 128, 64, 3, 2, 1), (2, 16, 256, 256, 1, 1, 0)]):
+    x = torch.randn(N, H, H, Ci, device=dev, requires_grad=True); w = (torch.randn(Co, Ci, k, k, device=dev) / math.sqrt(Ci * k * k)).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    y = conv.conv2d_nhwc(x, w, None, None, None, s, p, relu=False)
+    g = torch.randn_like(y); y.backward(g)
+    out[f'y{i}'] = y.detach().cpu().numpy(); out[f'dx{i}'] = x.grad.cpu().numpy(); out[f'dw{i}'] = w.grad.cpu().numpy()
+xl = torch.randn(1024, 256, device=dev, requires_grad=True); wl = (torch.randn(2048, 256, device=dev) / 16).requires_grad_(True); bl = torch.randn(2048, device=dev, requires_grad=True)
+yl = linear(xl, wl, bl); yl.backward(torch.randn_like(yl))
+out['yl'] = yl.detach().cpu().numpy(); out['dxl'] = xl.grad.cpu().numpy(); out['dwl'] = wl.grad.cpu().numpy(); out['dbl'] = bl.grad.cpu().numpy()
+np.savez(sys.argv[1], **out)
+'''
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = {}
+    for tag, env in (('fast', {}), ('generic', {'LDETR_FAST_LOADS': '0', 'LDETR_SMALL_FAST': '0', 'LDETR_GEMM_PAIR': '0'})):
+        path = str(tmp_path / f'{tag}.npz')
+        e = dict(os.environ); e.update(env); e['PYTHONPATH'] = root + os.pathsep + e.get('PYTHONPATH', '')
+        subprocess.run([sys.executable, '-c', script, path], check=True, env=e, cwd=root, timeout=300, stdin=subprocess.DEVNULL)
+        res[tag] = np.load(path)
+    for key in res['fast'].files:
+        a, b = res['fast'][key], res['generic'][key]
+        if key.startswith(('y', 'dx')) and not key.endswith('l'):
+            assert np.array_equal(a, b), f'{key}: FAST and generic tiled kernels differ'
+        else:
+            err = np.abs(a.astype(np.float64) - b).max() / (np.abs(b).max() + 1e-12)
+            assert err <= 1e-6, f'{key}: rel err {err:.2e}'
