@@ -1254,7 +1254,11 @@ __global__ __launch_bounds__(256, (KS == 2 ? 4 : (KS == 4 ? 3 : 2))) void gemm_s
 // Eligibility + launch of the skinny-K kernel; returns -1 when the problem does not qualify (caller falls through).
 template <int TB>
 static int try_launch_skinny(const GemmParams& p, hipStream_t st) {
-    if (p.K > 256 || p.M < SKINNY_MIN_M || !p.A.vec || !p.B.vec || (p.K & 3) || p.zmode != 0 || p.splitk > 1) return -1;
+    // With the scalar-addressed loads the LDS-tiled kernel overtook this register-stationary one on almost every 1x1 shape (e.g.
+    // 65536 x 128 x 256: 47.6 vs 89.4 us, 65536 x 64 x 256: 27.2 vs 47.7 us, 4096 x 1024 x 256: 26.8 vs 43.4 us); it stays available
+    // (LDETR_SKINNY_MAXK=256 restores the old routing) but is off by default.
+    static const int skinny_maxk = getenv("LDETR_SKINNY_MAXK") ? atoi(getenv("LDETR_SKINNY_MAXK")) : 0;
+    if (p.K > skinny_maxk || p.M < SKINNY_MIN_M || !p.A.vec || !p.B.vec || (p.K & 3) || p.zmode != 0 || p.splitk > 1) return -1;
     if (p.A.scale && (p.A.scale_ld != 0 || !al16(p.A.scale))) return -1;
     if (TB == 1 && (p.N & 3)) return -1;
     if (p.ep.samp_scale || p.ep.p_drop > 0.f || p.ep.row_scale) return -1;   // lean epilogue only

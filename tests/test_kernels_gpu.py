@@ -823,7 +823,7 @@ from layoutdetr_amd.hip import conv
 from layoutdetr_amd.hip.linear import linear
 dev = torch.device('cuda:0'); out = {}
 torch.manual_seed(123)
-for i, (N, H, Ci, Co, k, s, p) in enumerate([(2, 32, 64, 128, 3, 1, 1), (2, 32, 128, 64, 3, 2, 1), (2, 16, 256, 256, 1, 1, 0)]):
+for i, (N, H, Ci, Co, k, s, p) in enumerate([(2, 32, 64, 128, 3, 1, 1), (2, 32, 128, 64, 3, 2, 1), (2, 16, 256, 256, 1, 1, 0), (4, 32, 64, 256, 1, 1, 0), (4, 32, 256, 128, 1, 1, 0)]):
     x = torch.randn(N, H, H, Ci, device=dev, requires_grad=True); w = (torch.randn(Co, Ci, k, k, device=dev) / math.sqrt(Ci * k * k)).contiguous(memory_format=torch.channels_last).requires_grad_(True)
     y = conv.conv2d_nhwc(x, w, None, None, None, s, p, relu=False)
     g = torch.randn_like(y); y.backward(g)
@@ -835,7 +835,8 @@ np.savez(sys.argv[1], **out)
 '''
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     res = {}
-    for tag, env in (('fast', {}), ('generic', {'LDETR_FAST_LOADS': '0', 'LDETR_SMALL_FAST': '0', 'LDETR_GEMM_PAIR': '0'})):
+    for tag, env in (('fast', {}), ('generic', {'LDETR_FAST_LOADS': '0', 'LDETR_SMALL_FAST': '0', 'LDETR_GEMM_PAIR': '0'}),
+                     ('skinny', {'LDETR_SKINNY_MAXK': '256'})):   # the register-stationary 1x1 kernel (off by default since the FAST loads)
         path = str(tmp_path / f'{tag}.npz')
         e = dict(os.environ); e.update(env); e['PYTHONPATH'] = root + os.pathsep + e.get('PYTHONPATH', '')
         subprocess.run([sys.executable, '-c', script, path], check=True, env=e, cwd=root, timeout=300, stdin=subprocess.DEVNULL)
@@ -847,3 +848,6 @@ np.savez(sys.argv[1], **out)
         else:
             err = np.abs(a.astype(np.float64) - b).max() / (np.abs(b).max() + 1e-12)
             assert err <= 1e-6, f'{key}: rel err {err:.2e}'
+        c = res['skinny'][key]
+        err = np.abs(a.astype(np.float64) - c).max() / (np.abs(c).max() + 1e-12)
+        assert err <= 2e-6, f'{key}: skinny-K routing differs, rel err {err:.2e}'
