@@ -1404,9 +1404,7 @@ static void init_operand(Operand& o) { memset(&o, 0, sizeof(o)); o.KW = 1; o.KH 
 #endif
 
 // Dense GEMMs with fewer 64x64 tiles than this (and at most this much work) take the register-streaming 32x32 kernel.
-#ifndef SMALL_GEMM_TILES
-#define SMALL_GEMM_TILES 256
-#endif
+static const long SMALL_GEMM_TILES = getenv("LDETR_SMALL_TILES") ? atol(getenv("LDETR_SMALL_TILES")) : 256;   // 64x64-tile count below which the small-tile kernels run
 constexpr long SMALL_GEMM_MNK = 1l << 30;
 #ifndef WGRAD_MIN_K
 #define WGRAD_MIN_K 512
