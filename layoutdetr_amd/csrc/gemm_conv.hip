@@ -1556,7 +1556,8 @@ static int launch_gemm(GemmParams& p, int Mmax, long out_rows, int zbase, bool a
     {   // development override for policy sweeps (tools/sweep_policy.py): LDETR_FORCE_TILE 1 = 64x64, 2 = 128x64, 3 = 128x128; LDETR_FORCE_SK n
         static const int ft = getenv("LDETR_FORCE_TILE") ? atoi(getenv("LDETR_FORCE_TILE")) : 0;
         static const int fs = getenv("LDETR_FORCE_SK") ? atoi(getenv("LDETR_FORCE_SK")) : 0;
-        if (ft && auto_split && zbase == 1) {
+        static const int fall = getenv("LDETR_FORCE_TILE_ALL") ? atoi(getenv("LDETR_FORCE_TILE_ALL")) : 0;   // also weight gradients / per-tap launches
+        if (ft && ((auto_split && zbase == 1) || fall)) {
             use128 = ft == 3 && Mmax >= 128 && p.N >= 128; use12864 = ft == 2 && Mmax >= 128;
             if (fs) { int s2 = fs; while (s2 > 1 && p.K / s2 < 64) s2--; p.splitk = (p.ep.accumulate && !epilogue_is_linear(p.ep)) ? 1 : s2; }
         }
