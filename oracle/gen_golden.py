@@ -394,11 +394,237 @@ def gen_dp_step():
         d[f'g{i}'] = g
     save('dp_step', d)
 
+def _import_ref_networks():
+    """`training.networks_detr` of the reference, imported with the absent third-party packages stubbed: timm / fairscale are only
+    touched by training/vit.py + blip.py at import time (class decorators, base-class helpers), never by Generator/Discriminator.forward."""
+    hidden = {k: sys.modules.pop(k) for k in list(sys.modules) if k.split('.')[0] == 'torchvision'}
+    import transformers.modeling_utils as mu
+    import transformers.pytorch_utils as pu
+    from transformers import BertTokenizer  # noqa: F401  (blip.py imports it)
+    mu.apply_chunking_to_forward = pu.apply_chunking_to_forward
+    mu.prune_linear_layer = pu.prune_linear_layer
+    if not hasattr(mu, 'find_pruneable_heads_and_indices'):
+        def _unused(*a, **k):
+            raise NotImplementedError
+        mu.find_pruneable_heads_and_indices = _unused
+    sys.modules.update(hidden)
+
+    def mod(name, **attrs):
+        m = types.ModuleType(name); m.__path__ = []
+        for k, v in attrs.items():
+            setattr(m, k, v)
+        sys.modules[name] = m
+        return m
+    ident = lambda *a, **k: (a[0] if a else None)
+    mod('timm'); mod('timm.models')
+    mod('timm.models.vision_transformer', _cfg=lambda **k: {}, PatchEmbed=torch.nn.Module)
+    mod('timm.models.registry', register_model=lambda f: f)
+    mod('timm.models.layers', trunc_normal_=ident, DropPath=torch.nn.Identity)
+    mod('timm.models.helpers', named_apply=ident, adapt_input_conv=ident)
+    mod('timm.models.hub', download_cached_file=ident)
+    mod('fairscale'); mod('fairscale.nn'); mod('fairscale.nn.checkpoint')
+    mod('fairscale.nn.checkpoint.checkpoint_activations', checkpoint_wrapper=ident)
+    import training.networks_detr as nd
+    return nd
+
+
+class _Tok(object):
+    """Stand-in for the BERT tokenizer (needs the bert-base-uncased vocabulary file: no network here).  Deterministic character
+    hashing; only the container protocol Generator/Discriminator.forward uses (`input_ids`, `attention_mask`, `.to`)."""
+    bos_token_id, pad_token_id, T = 30522, 0, 12
+
+    def __call__(self, texts, padding=None, truncation=None, max_length=None, return_tensors=None):
+        ids = torch.zeros(len(texts), self.T, dtype=torch.long); am = torch.zeros_like(ids)
+        for i, t in enumerate(texts):
+            toks = [101] + [1000 + (ord(c) * 7) % 20000 for c in t][:self.T - 2] + [102]
+            ids[i, :len(toks)] = torch.tensor(toks); am[i, :len(toks)] = 1
+        out = types.SimpleNamespace(input_ids=ids, attention_mask=am)
+        out.to = lambda dev: out
+        return out
+
+
+class _TextEnc(torch.nn.Module):
+    """Stand-in for the frozen BERT text encoder (pinned separately: bert_text*.npz): a fixed table lookup, so that the CLS
+    feature handed to fc_in is a known function of the token ids."""
+
+    def __init__(self):
+        super().__init__()
+        from oracle import seeded
+        self.register_buffer('table', seeded.uniform('text_encoder.table', (97, 768), 0, -1.0, 1.0))
+
+    def forward(self, input_ids, attention_mask=None, return_dict=True, mode='text'):
+        h = self.table[(input_ids * 31 + torch.arange(input_ids.shape[1])[None]) % 97] * attention_mask[..., None].float()
+        return types.SimpleNamespace(last_hidden_state=h.cumsum(1).flip(1))   # CLS position sees the whole text
+
+
+class _TextDec(torch.nn.Module):
+    """Stand-in for the LM text decoder (pinned separately: bert_lm.npz).  Returns a zero loss, as the product does in
+    text_mode='features'; the arguments the reference builds for it are recorded for the wiring fixture."""
+
+    def __init__(self):
+        super().__init__()
+        self.calls = []
+
+    def forward(self, input_ids, attention_mask=None, encoder_hidden_states=None, encoder_attention_mask=None, labels=None,
+                return_dict=True, mode='text'):
+        self.calls.append(dict(input_ids=input_ids.clone(), attention_mask=attention_mask.clone(), labels=labels.clone()))
+        return types.SimpleNamespace(loss=encoder_hidden_states.new_zeros(()))
+
+
+class _Body(torch.nn.Module):
+    """Stand-in for torchvision's ResNet-50 body behind IntermediateLayerGetter (absent here): a learnable feature map per
+    canvas shape, so the gradient that reaches the trunk output is captured like any parameter gradient."""
+
+    def __init__(self, feats):
+        super().__init__()
+        self.feats = torch.nn.Parameter(feats)
+
+    def forward(self, x):
+        assert x.shape[0] == self.feats.shape[0] and x.shape[2] // 32 == self.feats.shape[2] and x.shape[3] // 32 == self.feats.shape[3]
+        return {'0': self.feats}
+
+
+def _ref_G_D(nd, bg, feats_g, feats_d):
+    """Generator / Discriminator instances of the REFERENCE classes whose __init__ (network access, torchvision) is bypassed: the
+    attributes are the reference's own sub-module classes with the constructor arguments of networks_detr.py:66-131 / 191-277."""
+    from torch import nn
+    from training.detr_backbone import BackboneBase, Joiner
+    from training.detr_position_encoding import PositionEmbeddingSine
+    from training.detr_transformer import Transformer, TransformerWithToken
+    from training.networks_stylegan2 import Decoder
+    from training.util import TransformerWithToken_layoutganpp
+    hd, bf, L, T = 256, 768, 8, 256
+
+    def backbone(feats):
+        bb = BackboneBase.__new__(BackboneBase); nn.Module.__init__(bb)
+        bb.body = _Body(feats); bb.num_channels = 2048
+        j = Joiner(bb, PositionEmbeddingSine(num_pos_feats=128, normalize=True)); j.num_channels = 2048
+        return j
+    tr = dict(d_model=hd, dropout=0.1, nhead=8, dim_feedforward=2048, num_encoder_layers=6, num_decoder_layers=6, normalize_before=False,
+              return_intermediate_dec=False)
+    G = nd.Generator.__new__(nd.Generator); nn.Module.__init__(G)
+    G.z_dim, G.num_bbox_labels, G.c_dim, G.max_text_length = 4, L, 0, T
+    G.backbone = backbone(feats_g); G.input_proj = nn.Conv2d(2048, hd, kernel_size=1)
+    G.fc_z = nn.Linear(4 * 9, bf); G.emb_label = nn.Embedding(L, bf)
+    G.tokenizer = _Tok(); G.text_encoder = _TextEnc(); G.enc_text_len = nn.Embedding(T, bf)
+    G.fc_in = nd.MLP(input_dim=4 * bf, hidden_dim=bf, output_dim=hd, num_layers=3)
+    G.transformer = Transformer(**tr)
+    G.bbox_embed = nd.MLP(input_dim=hd, hidden_dim=hd, output_dim=4, num_layers=3)
+    G.fc_z_rec = nn.Linear(hd, 4 * 9); G.fc_out_cls = nn.Linear(hd, L); G.text_decoder = _TextDec(); G.fc_text_len_rec = nn.Linear(hd, T)
+
+    D = nd.Discriminator.__new__(nd.Discriminator); nn.Module.__init__(D)
+    D.num_bbox_labels, D.c_dim, D.max_text_length = L, 0, T
+    D.backbone = backbone(feats_d); D.input_proj = nn.Conv2d(2048, hd, kernel_size=1)
+    D.fc_bbox = nn.Linear(4, bf); D.emb_label = nn.Embedding(L, bf)
+    D.tokenizer = _Tok(); D.text_encoder = _TextEnc(); D.enc_text_len = nn.Embedding(T, bf)
+    D.enc_fc_in = nd.MLP(input_dim=4 * bf, hidden_dim=bf, output_dim=hd, num_layers=3)
+    D.enc_transformer = TransformerWithToken(**tr)
+    D.fc_out_disc = nn.Linear(hd, 1)
+    D.pos_token = nn.Parameter(torch.rand(50, 1, hd)); D.dec_fc_in = nn.Linear(2 * hd, hd)
+    D.dec_transformer = nn.TransformerEncoder(nn.TransformerEncoderLayer(d_model=hd, nhead=8, dim_feedforward=2048), num_layers=6)
+    D.bbox_embed = nn.Linear(hd, 4); D.fc_out_cls = nn.Linear(hd, L); D.text_decoder = _TextDec(); D.fc_text_len_rec = nn.Linear(hd, T)
+    D.bg_decoder = Decoder(z_dim=hd, w_dim=512, channel_max=512, channel_base=8192, img_channels=3, img_resolution=bg, use_noise=False,
+                           num_fp16_res=0, conv_clamp=None, fused_modconv_default=False)
+    D.fc_bbox_uncond = nn.Linear(4, bf); D.emb_label_uncond = nn.Embedding(L, bf)
+    D.enc_fc_in_uncond = nd.MLP(input_dim=2 * bf, hidden_dim=bf, output_dim=hd, num_layers=3)
+    D.enc_transformer_uncond = TransformerWithToken_layoutganpp(d_model=hd, dim_feedforward=2048, nhead=8, num_layers=6)
+    D.fc_out_disc_uncond = nn.Linear(hd, 1)
+    D.pos_token_uncond = nn.Parameter(torch.rand(50, 1, hd)); D.dec_fc_in_uncond = nn.Linear(2 * hd, hd)
+    D.dec_transformer_uncond = nn.TransformerEncoder(nn.TransformerEncoderLayer(d_model=hd, nhead=8, dim_feedforward=2048), num_layers=6)
+    D.bbox_embed_uncond = nn.Linear(hd, 4); D.fc_out_cls_uncond = nn.Linear(hd, L)
+    return G.eval(), D.eval()      # eval: dropout off (numeric parity runs with dropout off; SURVEY §7)
+
+
+def gen_composition():
+    """Rows a13 / a14: the reference's OWN Generator.forward / Discriminator.forward (networks_detr.py:133-187, 279-361) and
+    StyleGAN2Loss.accumulate_gradients (loss.py:75-218) at the real layer sizes (hidden 256, 6+6 layers, 8 heads, 768-wide text
+    features, StyleGAN2 Decoder at the background size), driven on CPU.  Only the three pieces that cannot exist in this container
+    are stand-ins (classes above): the torchvision ResNet-50 body (a learnable feature map: the gradient reaching the trunk is
+    captured), the BERT tokenizer / text encoder (table lookup) and the LM decoder (zero loss; its call arguments are recorded).
+    Weights and inputs are pure functions of their names (oracle/seeded.py), so the fixture holds expected values only."""
+    from oracle import seeded
+    nd = _import_ref_networks()
+    from torch_utils import training_stats
+    from training.loss import StyleGAN2Loss
+    B, bg, seed = 3, 64, 11
+    inp = seeded.comp_inputs(B, bg, seed)
+    G, D = _ref_G_D(nd, bg, inp['feats_g'], inp['feats_d'])
+    skip = ('backbone.0.body.', 'text_encoder.', 'text_decoder.')
+    G.load_state_dict(seeded.seeded_state_dict(G, 1, skip)); D.load_state_dict(seeded.seeded_state_dict(D, 2, skip))
+    d = {'B': np.asarray(B), 'bg': np.asarray(bg), 'seed': np.asarray(seed)}
+    d['G_keys'] = np.asarray([f'{k}:{"x".join(map(str, v.shape))}' for k, v in G.state_dict().items() if not k.startswith(skip)])
+    d['D_keys'] = np.asarray([f'{k}:{"x".join(map(str, v.shape))}' for k, v in D.state_dict().items() if not k.startswith(skip)])
+    patch = torch.zeros(B, 9, 1, 1, 1)
+    c = torch.zeros(B, 0)
+    tok = G.tokenizer(sum(inp['texts'], []))
+    d['input_ids'] = tok.input_ids; d['attention_mask'] = tok.attention_mask
+    d['text_feat'] = G.text_encoder(tok.input_ids, tok.attention_mask).last_hidden_state[:, 0, :].view(B, 9, -1)
+    d['text_len'] = torch.tensor([len(t) for t in sum(inp['texts'], [])]).view(B, 9)
+    # ---- forward tuples (a13)
+    with torch.no_grad():
+        out = G(inp['z_g'], inp['bbox_class'], inp['bbox_real'], inp['texts'], patch, inp['padding_mask'], inp['background'], c, True)
+        for k, v in zip(('bbox_fake', 'loss_z', 'logit_cls', 'loss_lm', 'loss_text_len'), out):
+            d['G/' + k] = v
+        d['G/bbox_fake_noreconst'] = G(inp['z_g'], inp['bbox_class'], inp['bbox_real'], inp['texts'], patch, inp['padding_mask'], inp['background'], c)
+        out = D(inp['bbox_real'], inp['bbox_class'], inp['texts'], patch, inp['padding_mask'], inp['background'], c, True)
+        for k, v in zip(('logit', 'logit_uncond', 'bbox_pred', 'logit_cls', 'loss_lm', 'loss_text_len', 'bg_rec', 'bbox_pred_uncond', 'logit_cls_uncond'), out):
+            d['D/' + k] = v
+        lo = D(inp['bbox_real'], inp['bbox_class'], inp['texts'], patch, inp['padding_mask'], inp['background'], c)
+        d['D/logit_noreconst'] = lo[0]; d['D/logit_uncond_noreconst'] = lo[1]
+        # LM-decoder wiring (networks_detr.py:169-181): what the reference hands to text_decoder
+        call = G.text_decoder.calls[0]
+        d['G/lm_input_ids'] = call['input_ids']; d['G/lm_attention_mask'] = call['attention_mask']; d['G/lm_labels'] = call['labels']
+        # ragged canvas: a list of different-sized backgrounds (nested_tensor_from_tensor_list + mask interpolation, detr_backbone.py:82-95)
+        sizes = [(64, 64), (32, 64), (64, 32)]
+        bgl = [inp['background'][i, :, :h, :w].clone() for i, (h, w) in enumerate(sizes)]
+        d['ragged_sizes'] = np.asarray(sizes)
+        d['G/bbox_fake_ragged'] = G(inp['z_g'], inp['bbox_class'], inp['bbox_real'], inp['texts'], patch, inp['padding_mask'], bgl, c)
+        lo = D(inp['bbox_real'], inp['bbox_class'], inp['texts'], patch, inp['padding_mask'], bgl, c)
+        d['D/logit_ragged'] = lo[0]; d['D/logit_uncond_ragged'] = lo[1]
+    # ---- loss phases (a14) exactly as training_loop.py:281-313 drives them: zero_grad, requires_grad_(True) on the phase's module only.
+    # Run twice: fp32 (the reference's arithmetic; tag '') and fp64 (tag '64': the same reference code in double precision, the
+    # yardstick that tells fp32 rounding noise from a real discrepancy: a path is right when it is as close to the fp64 values as
+    # the reference's own fp32 run is).
+    reports = {}
+    real_report = training_stats.report
+    training_stats.report = lambda name, value: reports.setdefault(name, []).append(torch.as_tensor(value).detach().clone()) or value
+    import training.loss as loss_mod
+    loss_mod.training_stats.report = training_stats.report
+    for tag, dt in (('', torch.float32), ('64', torch.float64)):
+        G.to(dt); D.to(dt)
+        D.bg_decoder.float()      # the StyleGAN2 blocks cast their activations to fp32 themselves (networks_stylegan2.py:402-433): this sub-network stays fp32 in the '64' run
+        cast = lambda t: t.to(dt) if t.dtype.is_floating_point else t
+        loss = StyleGAN2Loss(torch.device('cpu'), G, D)        # default weights = train.py:263-275
+        G.requires_grad_(False); D.requires_grad_(False)
+        for phase, mod_ in (('Gmain', G), ('Dmain', D)):
+            reports.clear()
+            mod_.requires_grad_(True); mod_.text_encoder.requires_grad_(False)
+            for p in mod_.parameters():
+                p.grad = None
+            loss.accumulate_gradients(phase=phase, bbox_real=cast(inp['bbox_real']), bbox_class=inp['bbox_class'], bbox_text=inp['texts'], bbox_patch=cast(patch),
+                                      padding_mask=inp['padding_mask'], background=inp['background'], real_c=cast(c),   # background: only mse_loss(bg_rec, background) reads it (the body is a stand-in), and bg_rec is fp32
+                                     
+                                      gen_z=cast(inp['z_g'] if phase == 'Gmain' else inp['z_d']), gen_c=cast(c), gain=1, cur_nimg=0)
+            mod_.requires_grad_(False)
+            for name, vals in reports.items():
+                for i, v in enumerate(vals):
+                    d[f'{phase}/report{tag}/{name}' + (f'#{i}' if len(vals) > 1 else '')] = v
+            for name, p in mod_.named_parameters():
+                if p.grad is None:
+                    continue
+                st, sub = seeded.grad_digest(p.grad)
+                d[f'{phase}/gstat{tag}/{name}'] = st; d[f'{phase}/gsub{tag}/{name}'] = sub if tag else sub.astype(np.float32)
+    training_stats.report = real_report
+    save('composition', d)
+
 
 if __name__ == '__main__':
     sys.path.insert(0, REF)
+    sys.path.insert(1, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))   # `oracle.seeded` (the reference has no `oracle` package)
     _stub_modules()
     torch.set_num_threads(8)
+    if '--only-composition' in sys.argv:
+        gen_composition(); sys.exit(0)
     if '--only-metrics' in sys.argv:
         gen_metrics(); sys.exit(0)
     if '--only-resample' in sys.argv:
@@ -407,4 +633,4 @@ if __name__ == '__main__':
         gen_bert(); gen_bert_lm(); sys.exit(0)
     if '--skip-done' not in sys.argv:
         gen_ops(); gen_transformer()
-    gen_losses(); gen_decoder(); gen_frozen_bn(); gen_lsap(); gen_dp_step(); gen_metrics(); gen_bert(); gen_bert_lm(); gen_resample()
+    gen_losses(); gen_decoder(); gen_frozen_bn(); gen_lsap(); gen_dp_step(); gen_metrics(); gen_bert(); gen_bert_lm(); gen_resample(); gen_composition()

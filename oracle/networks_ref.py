@@ -4,10 +4,10 @@ CPU fp32 restatement of `training/networks_detr.py` Generator.forward (:133-187)
 (:279-361) as pure functions over a state dict, in hot-path-only mode (BASELINE.md variant A): the frozen
 BERT text encoder output `text_feat` [B,N,768] and the character counts `text_len` [B,N] are inputs, and the
 LM-decoder loss is 0 (SURVEY §8a rows a16/a17 are boundary inputs).  Dropout = identity (eval parity).
-The literal reference classes cannot be constructed in this container (timm/fairscale/torchvision
-absent, weights downloaded at construction: SURVEY §8c), so this composition is pinned through its parts:
-detr_ref.transformer / torch_encoder, stylegan2_ref.decoder, ops_ref — each pinned to reference vectors —
-plus the unpinned torchvision ResNet-50 restatement (detr_ref.resnet50_layer4).
+PINNED: tests/golden/composition.npz holds the outputs of the reference's own Generator.forward / Discriminator.forward
+(driven by oracle/gen_golden.py:gen_composition at the real layer sizes, with stand-ins only for the torchvision ResNet-50
+body, the BERT tokenizer/encoder and the LM decoder); tests/test_oracle_golden.py checks these functions against it.
+Only the torchvision ResNet-50 restatement (detr_ref.resnet50_layer4) stays unpinned (torchvision is absent here).
 """
 import torch
 import torch.nn.functional as F
@@ -25,19 +25,34 @@ def _lin(sd, pre, x):
     return F.linear(x, sd[pre + 'weight'], sd[pre + 'bias'])
 
 
-def _backbone(sd, pre, background):
-    """Joiner(Backbone, PositionEmbeddingSine): uniform-size tensor batch -> (feat, all-False mask, pos)."""
-    feat = detr_ref.resnet50_layer4(sd, pre + 'backbone.0.body.', background)
+def _backbone(sd, pre, background, feats=None):
+    """Joiner(Backbone, PositionEmbeddingSine) -> (input_proj(feat), mask, pos).
+    `background`: a [B,3,H,W] tensor (uniform canvas: all-False mask) or a list of [3,Hi,Wi] tensors, zero-padded to the largest
+    with mask = True on the padding (detr_util/misc.py:315-337), the mask resized to the feature map by nearest-neighbour
+    interpolation (detr_backbone.py:87-92).  `feats` replaces the ResNet-50 body's output (the composition fixtures pin everything
+    around the torchvision body, which does not exist in the build container)."""
+    if isinstance(background, (list, tuple)):
+        C = background[0].shape[0]
+        H = max(t.shape[1] for t in background); W = max(t.shape[2] for t in background)
+        canvas = torch.zeros(len(background), C, H, W, dtype=background[0].dtype)
+        m = torch.ones(len(background), H, W, dtype=torch.bool)
+        for i, t in enumerate(background):
+            canvas[i, :, :t.shape[1], :t.shape[2]] = t
+            m[i, :t.shape[1], :t.shape[2]] = False
+    else:
+        canvas = background
+        m = torch.zeros(background.shape[0], background.shape[2], background.shape[3], dtype=torch.bool)
+    feat = detr_ref.resnet50_layer4(sd, pre + 'backbone.0.body.', canvas) if feats is None else feats
     B, _, h, w = feat.shape
-    mask = torch.zeros(B, h, w, dtype=torch.bool)
+    mask = F.interpolate(m[None].float(), size=(h, w)).to(torch.bool)[0]
     pos = detr_ref.position_embedding_sine(mask, 128)
     src = F.conv2d(feat, sd[pre + 'input_proj.weight'], sd[pre + 'input_proj.bias'])
     return src, mask, pos
 
 
-def generator(sd, z, bbox_class, text_feat, text_len, padding_mask, background, reconst=False):
+def generator(sd, z, bbox_class, text_feat, text_len, padding_mask, background, reconst=False, feats=None):
     B, N = bbox_class.shape
-    src, mask, pos = _backbone(sd, '', background)
+    src, mask, pos = _backbone(sd, '', background, feats)
     z0 = normalize_2nd_moment(z.reshape(B, -1))
     zf = _lin(sd, 'fc_z.', z0).unsqueeze(1).expand(-1, N, -1)
     l = sd['emb_label.weight'][bbox_class]
@@ -57,9 +72,9 @@ def generator(sd, z, bbox_class, text_feat, text_len, padding_mask, background, 
     return bbox_fake, loss_z, logit_cls, loss_lm, loss_text_len
 
 
-def discriminator(sd, bbox, bbox_class, text_feat, text_len, padding_mask, background, reconst=False, bg_size=256):
+def discriminator(sd, bbox, bbox_class, text_feat, text_len, padding_mask, background, reconst=False, bg_size=256, feats=None):
     B, N = bbox_class.shape
-    src, mask, pos = _backbone(sd, '', background)
+    src, mask, pos = _backbone(sd, '', background, feats)
     b = _lin(sd, 'fc_bbox.', bbox)
     l = sd['emb_label.weight'][bbox_class]
     tl = sd['enc_text_len.weight'][text_len]

@@ -4,7 +4,9 @@ CPU fp32 restatement of one G/D training iteration in hot-path-only mode:
   StyleGAN2Loss.accumulate_gradients, phases Gmain and Dmain with gamma=0, pl_weight=0
       training/loss.py:84-116 (Gmain), :146-157 (Dgen), :161-218 (Dreal); weights from train.py:263-275
   gradient post-processing + Adam(betas=(0,0.99), eps=1e-8)      training/training_loop.py:303-313, train.py:204-205
-Built on the pinned pieces (networks_ref / detr_ref / stylegan2_ref / losses_ref).  Used by the GPU parity
+Built on the pinned pieces (networks_ref / detr_ref / stylegan2_ref / losses_ref), and PINNED as a whole: tests/golden/composition.npz
+holds every training_stats-reported term and the parameter gradients of the reference's own StyleGAN2Loss.accumulate_gradients
+('Gmain', 'Dmain') at the real layer sizes (oracle/gen_golden.py:gen_composition); tests/test_oracle_golden.py compares.  Used by the GPU parity
 tests, by __graft_entry__.smoke() and as bench.py's `cpu_baseline` ("port").
 """
 import torch
@@ -17,44 +19,59 @@ WEIGHTS = dict(Dreal_bbox_cls=50.0, Dreal_bbox_rec=500.0, Dreal_text_rec=0.1, Dr
                Ggen_bbox_cls=50.0, Ggen_text_rec=1.0, Ggen_text_len_rec=1.0)
 
 
-def g_main_loss(G, D, bt, z, w=WEIGHTS, bg_size=256):
+def g_main_loss(G, D, bt, z, w=WEIGHTS, bg_size=256, terms=None):
+    """loss.py:84-116.  `terms` (dict, optional) receives every value the reference hands to training_stats.report."""
     pm = bt['padding_mask']; valid = ~pm
     bbox_fake, loss_z, cls_logits, loss_lm, loss_tl = networks_ref.generator(
-        G, z, bt['bbox_class'], bt['text_feat'], bt['text_len'], pm, bt['background'], reconst=True)
-    logits, logits_u = networks_ref.discriminator(D, bbox_fake, bt['bbox_class'], bt['text_feat'], bt['text_len'], pm, bt['background'])
+        G, z, bt['bbox_class'], bt['text_feat'], bt['text_len'], pm, bt['background'], reconst=True, feats=bt.get('feats_G'))
+    logits, logits_u = networks_ref.discriminator(D, bbox_fake, bt['bbox_class'], bt['text_feat'], bt['text_len'], pm, bt['background'],
+                                                  feats=bt.get('feats_D'))
     real = bt['bbox_real']
-    total = (F.softplus(-logits) + F.softplus(-logits_u)
-             + F.mse_loss(bbox_fake[valid], real[valid]) * w['Ggen_bbox_rec']
-             + losses_ref.generalized_iou_loss(bbox_fake[valid], real[valid]) * w['Ggen_bbox_gIoU']
-             + losses_ref.compute_overlap(bbox_fake, valid) * w['Ggen_overlapping']
-             + losses_ref.compute_alignment(bbox_fake, valid) * w['Ggen_alignment']
-             + loss_z * w['Ggen_z_rec']
-             + F.cross_entropy(cls_logits, bt['bbox_class'][valid]) * w['Ggen_bbox_cls']
-             + loss_lm * w['Ggen_text_rec'] + loss_tl * w['Ggen_text_len_rec'])
+    t = {'Loss/scores/fake': logits, 'Loss/signs/fake': logits.sign(),
+         'Loss/G/loss_Ggen': F.softplus(-logits), 'Loss/G/loss_Ggen_uncond': F.softplus(-logits_u),
+         'Loss/G/loss_Ggen_bbox_rec': F.mse_loss(bbox_fake[valid], real[valid]) * w['Ggen_bbox_rec'],
+         'Loss/G/loss_Ggen_bbox_gIoU': losses_ref.generalized_iou_loss(bbox_fake[valid], real[valid]) * w['Ggen_bbox_gIoU'],
+         'Loss/G/loss_Ggen_overlapping': losses_ref.compute_overlap(bbox_fake, valid) * w['Ggen_overlapping'],
+         'Loss/G/loss_Ggen_alignment': losses_ref.compute_alignment(bbox_fake, valid) * w['Ggen_alignment'],
+         'Loss/G/loss_Ggen_z_rec': loss_z * w['Ggen_z_rec'],
+         'Loss/G/loss_Ggen_bbox_cls': F.cross_entropy(cls_logits, bt['bbox_class'][valid]) * w['Ggen_bbox_cls'],
+         'Loss/G/loss_Ggen_text_rec': loss_lm * w['Ggen_text_rec'], 'Loss/G/loss_Ggen_text_len_rec': loss_tl * w['Ggen_text_len_rec']}
+    if terms is not None:
+        terms.update({k: v.detach() for k, v in t.items()})
+    total = sum(v for k, v in t.items() if k.startswith('Loss/G/'))
     return total.mean(), bbox_fake
 
 
-def d_gen_loss(G, D, bt, z):
+def d_gen_loss(G, D, bt, z, terms=None):
+    """loss.py:146-157."""
     pm = bt['padding_mask']
     with torch.no_grad():
-        bbox_fake = networks_ref.generator(G, z, bt['bbox_class'], bt['text_feat'], bt['text_len'], pm, bt['background'])
-    logits, logits_u = networks_ref.discriminator(D, bbox_fake, bt['bbox_class'], bt['text_feat'], bt['text_len'], pm, bt['background'])
-    return (F.softplus(logits) + F.softplus(logits_u)).mean()
+        bbox_fake = networks_ref.generator(G, z, bt['bbox_class'], bt['text_feat'], bt['text_len'], pm, bt['background'], feats=bt.get('feats_G'))
+    logits, logits_u = networks_ref.discriminator(D, bbox_fake, bt['bbox_class'], bt['text_feat'], bt['text_len'], pm, bt['background'],
+                                                  feats=bt.get('feats_D'))
+    t = {'Loss/scores/fake': logits, 'Loss/signs/fake': logits.sign(), 'Loss/D/loss_Dgen': F.softplus(logits), 'Loss/D/loss_Dgen_uncond': F.softplus(logits_u)}
+    if terms is not None:
+        terms.update({k: v.detach() for k, v in t.items()})
+    return (t['Loss/D/loss_Dgen'] + t['Loss/D/loss_Dgen_uncond']).mean()
 
 
-def d_real_loss(D, bt, w=WEIGHTS, bg_size=256):
+def d_real_loss(D, bt, w=WEIGHTS, bg_size=256, terms=None):
+    """loss.py:161-218 (phase Dmain: no R1 term)."""
     pm = bt['padding_mask']; valid = ~pm
     real = bt['bbox_real']
     (logits, logits_u, bbox_rec, cls_logits, loss_lm, loss_tl, bg_rec, bbox_rec_u, cls_logits_u) = networks_ref.discriminator(
-        D, real, bt['bbox_class'], bt['text_feat'], bt['text_len'], pm, bt['background'], reconst=True, bg_size=bg_size)
-    total = (F.softplus(-logits) + F.softplus(-logits_u)
-             + F.mse_loss(bbox_rec, real[valid]) * w['Dreal_bbox_rec']
-             + F.cross_entropy(cls_logits, bt['bbox_class'][valid]) * w['Dreal_bbox_cls']
-             + loss_lm * w['Dreal_text_rec'] + loss_tl * w['Dreal_text_len_rec']
-             + F.mse_loss(bg_rec, bt['background']) * w['Dreal_im_rec']
-             + F.mse_loss(bbox_rec_u, real[valid]) * w['Dreal_bbox_rec']
-             + F.cross_entropy(cls_logits_u, bt['bbox_class'][valid]) * w['Dreal_bbox_cls'])
-    return total.mean()
+        D, real, bt['bbox_class'], bt['text_feat'], bt['text_len'], pm, bt['background'], reconst=True, bg_size=bg_size, feats=bt.get('feats_D'))
+    t = {'Loss/scores/real': logits, 'Loss/signs/real': logits.sign(),
+         'Loss/D/loss_Dreal': F.softplus(-logits), 'Loss/D/loss_Dreal_uncond': F.softplus(-logits_u),
+         'Loss/D/loss_Dreal_bbox_rec': F.mse_loss(bbox_rec, real[valid]) * w['Dreal_bbox_rec'],
+         'Loss/D/loss_Dreal_bbox_cls': F.cross_entropy(cls_logits, bt['bbox_class'][valid]) * w['Dreal_bbox_cls'],
+         'Loss/D/loss_Dreal_text_rec': loss_lm * w['Dreal_text_rec'], 'Loss/D/loss_Dreal_text_len_rec': loss_tl * w['Dreal_text_len_rec'],
+         'Loss/D/loss_Dreal_bg_rec': F.mse_loss(bg_rec, bt['background']) * w['Dreal_im_rec'],
+         'Loss/D/loss_Dreal_bbox_rec_uncond': F.mse_loss(bbox_rec_u, real[valid]) * w['Dreal_bbox_rec'],
+         'Loss/D/loss_Dreal_bbox_cls_uncond': F.cross_entropy(cls_logits_u, bt['bbox_class'][valid]) * w['Dreal_bbox_cls']}
+    if terms is not None:
+        terms.update({k: v.detach() for k, v in t.items()})
+    return sum(v for k, v in t.items() if k.startswith('Loss/D/')).mean()
 
 
 def _params(sd, param_names=None):
@@ -77,17 +94,20 @@ def training_iteration(G_sd, D_sd, bt, z_g, z_d, lr=1e-5, world=1, bg_size=256, 
     out = {}
     # Gmain: D is frozen (its parameters get no gradient), gradient flows through D to bbox_fake.
     Dfrozen = {k: v.detach() for k, v in D.items()}
-    lg, bbox_fake = g_main_loss(G, Dfrozen, bt, z_g, bg_size=bg_size)
+    tG, tD = {}, {}
+    btG = dict(bt, **({'feats_D': bt['feats_D'].detach()} if 'feats_D' in bt else {}))     # D (and its trunk output) is frozen in Gmain
+    btD = dict(bt, **({'feats_G': bt['feats_G'].detach()} if 'feats_G' in bt else {}))
+    lg, bbox_fake = g_main_loss(G, Dfrozen, btG, z_g, bg_size=bg_size, terms=tG)
     lg.backward()
-    out['loss_G'] = lg.detach(); out['bbox_fake'] = bbox_fake.detach()
+    out['loss_G'] = lg.detach(); out['bbox_fake'] = bbox_fake.detach(); out['terms_G'] = tG; out['terms_D'] = tD
     gG = {k: v.grad for k, v in G.items() if v.requires_grad and v.grad is not None}
     G_new = dict(G_sd)
     if apply_adam:
         G_new = adam_step(G, gG, lr, world)
     # Dmain uses the *updated* generator (phases run sequentially within an iteration).
     Gd = {k: v.detach() for k, v in (G_new if apply_adam else G).items()}
-    ld1 = d_gen_loss(Gd, D, bt, z_d); ld1.backward()
-    ld2 = d_real_loss(D, bt, bg_size=bg_size); ld2.backward()
+    ld1 = d_gen_loss(Gd, D, btD, z_d, terms=tD); ld1.backward()
+    ld2 = d_real_loss(D, btD, bg_size=bg_size, terms=tD); ld2.backward()
     out['loss_Dgen'] = ld1.detach(); out['loss_Dreal'] = ld2.detach()
     gD = {k: v.grad for k, v in D.items() if v.requires_grad and v.grad is not None}
     D_new = adam_step(D, gD, lr, world) if apply_adam else dict(D_sd)

@@ -237,3 +237,99 @@ def test_background_resample_oracle_bit_exact():
         out = resample_ref.background_to_tensor(img, s)
         assert out.dtype == np.float32 and out.shape == (3, s, s)
         assert np.array_equal(out, d[f'out{i}']), f'case {i}: normalised tensor differs'
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Rows a13 / a14: the composition.  tests/golden/composition.npz = outputs of the reference's own Generator.forward,
+# Discriminator.forward and StyleGAN2Loss.accumulate_gradients (oracle/gen_golden.py:gen_composition); weights and inputs
+# are rebuilt from their names (oracle/seeded.py), the fixture holds expected values only.
+
+COMP_SKIP = ('backbone.0.body.', 'text_encoder.', 'text_decoder.')
+
+
+def comp_modules(bg):
+    """Product-named state dicts for the oracle: the product modules are constructed on CPU for their parameter names and
+    shapes only (no forward runs here), then every entry is overwritten by the seeded rule."""
+    from layoutdetr_amd.training.networks_detr import Discriminator, Generator
+    from oracle import seeded
+    kw = dict(num_bbox_labels=8, img_channels=3, img_height=bg, img_width=bg, c_dim=0, background_size=bg, bert_f_dim=768, im_f_dim=512)
+    Gm, Dm = Generator(z_dim=4, **kw), Discriminator(**kw)
+    return Gm, Dm, seeded.seeded_state_dict(Gm, 1, COMP_SKIP), seeded.seeded_state_dict(Dm, 2, COMP_SKIP)
+
+
+def comp_keys(sd):
+    return sorted(f'{k}:{"x".join(map(str, v.shape))}' for k, v in sd.items() if not k.startswith(COMP_SKIP))
+
+
+def digest_errors(g, d, phase, name):
+    """(error of g, error of the reference's own fp32 run), both against the reference's fp64 run, relative to the largest entry
+    of the fp64 gradient: the yardstick that separates fp32 summation noise from a real discrepancy."""
+    from oracle import seeded
+    st, sb = seeded.grad_digest(g)
+    s32 = np.asarray(d[f'{phase}/gsub/{name}']).astype(np.float64); s64 = np.asarray(d[f'{phase}/gsub64/{name}'])
+    st64 = np.asarray(d[f'{phase}/gstat64/{name}'])
+    mx = float(st64[2]) + 1e-300
+    e = max(float(np.abs(sb - s64).max()) / mx, abs(st[0] - float(st64[0])) / (float(st64[0]) + 1e-300))
+    return e, float(np.abs(s32 - s64).max()) / mx
+
+
+def test_composition_state_dict_names_match_reference():
+    d = load('composition')
+    Gm, Dm, Gsd, Dsd = comp_modules(int(d['bg']))
+    assert comp_keys(Gsd) == sorted(d['G_keys'].tolist())
+    assert comp_keys(Dsd) == sorted(d['D_keys'].tolist())
+
+
+def test_composition_forward_tuples_vs_reference():
+    from oracle import networks_ref, seeded
+    d = load('composition')
+    B, bg, seed = int(d['B']), int(d['bg']), int(d['seed'])
+    inp = seeded.comp_inputs(B, bg, seed)
+    _, _, Gsd, Dsd = comp_modules(bg)
+    tf, tl, pm = d['text_feat'], d['text_len'], inp['padding_mask']
+    with torch.no_grad():
+        out = networks_ref.generator(Gsd, inp['z_g'], inp['bbox_class'], tf, tl, pm, inp['background'], reconst=True, feats=inp['feats_g'])
+        for k, v in zip(('bbox_fake', 'loss_z', 'logit_cls', 'loss_lm', 'loss_text_len'), out):
+            close(v, d['G/' + k], 1e-5)
+        close(networks_ref.generator(Gsd, inp['z_g'], inp['bbox_class'], tf, tl, pm, inp['background'], feats=inp['feats_g']), d['G/bbox_fake_noreconst'], 1e-5)
+        out = networks_ref.discriminator(Dsd, inp['bbox_real'], inp['bbox_class'], tf, tl, pm, inp['background'], reconst=True, bg_size=bg, feats=inp['feats_d'])
+        for k, v in zip(('logit', 'logit_uncond', 'bbox_pred', 'logit_cls', 'loss_lm', 'loss_text_len', 'bg_rec', 'bbox_pred_uncond', 'logit_cls_uncond'), out):
+            close(v, d['D/' + k], 2e-5)
+        # ragged canvas (list of different-sized backgrounds): padding mask -> feature-map mask -> position encoding + attention masking
+        bgl = [inp['background'][i, :, :h, :w] for i, (h, w) in enumerate(d['ragged_sizes'].tolist())]
+        close(networks_ref.generator(Gsd, inp['z_g'], inp['bbox_class'], tf, tl, pm, bgl, feats=inp['feats_g']), d['G/bbox_fake_ragged'], 1e-5)
+        lo = networks_ref.discriminator(Dsd, inp['bbox_real'], inp['bbox_class'], tf, tl, pm, bgl, feats=inp['feats_d'])
+        close(lo[0], d['D/logit_ragged'], 1e-5); close(lo[1], d['D/logit_uncond_ragged'], 1e-5)
+        assert not torch.equal(d['D/logit_ragged'], d['D/logit']), 'the ragged case must exercise the mask'
+
+
+def test_composition_loss_phases_vs_reference():
+    """StyleGAN2Loss.accumulate_gradients('Gmain' / 'Dmain'): every reported term and every parameter gradient."""
+    from oracle import seeded, step_ref
+    d = load('composition')
+    B, bg, seed = int(d['B']), int(d['bg']), int(d['seed'])
+    inp = seeded.comp_inputs(B, bg, seed)
+    Gm, Dm, Gsd, Dsd = comp_modules(bg)
+    fg, fd = inp['feats_g'].clone().requires_grad_(True), inp['feats_d'].clone().requires_grad_(True)
+    bt = dict(bbox_real=inp['bbox_real'], bbox_class=inp['bbox_class'], text_feat=d['text_feat'], text_len=d['text_len'],
+              padding_mask=inp['padding_mask'], background=inp['background'], feats_G=fg, feats_D=fd)
+    out, gG, gD, _, _ = step_ref.training_iteration(Gsd, Dsd, bt, inp['z_g'], inp['z_d'], bg_size=bg, apply_adam=False,
+                                                    G_param_names={n for n, _ in Gm.named_parameters()},
+                                                    D_param_names={n for n, _ in Dm.named_parameters()})
+    for phase, terms in (('Gmain', out['terms_G']), ('Dmain', out['terms_D'])):
+        want = {k[len(phase) + 8:]: v for k, v in d.items() if k.startswith(phase + '/report/')}
+        assert set(want) == set(terms), set(want) ^ set(terms)
+        for k, v in want.items():
+            close(terms[k], v, 2e-5)
+    gG['backbone.0.body.feats'] = fg.grad; gD['backbone.0.body.feats'] = fd.grad
+    worst = ref_worst = 0.0
+    for phase, grads in (('Gmain', gG), ('Dmain', gD)):
+        names = [k[len(phase) + 7:] for k in d if k.startswith(phase + '/gstat/')]
+        body = [n for n in grads if n.startswith('backbone.0.body.') and n != 'backbone.0.body.feats']
+        assert set(names) == set(grads) - set(body), set(names) ^ (set(grads) - set(body))
+        for n in names:
+            e, e_ref = digest_errors(grads[n], d, phase, n)
+            # as close to the fp64 values as the reference's own fp32 run is (x3 for the luck of the sampled entries), floor 1e-5
+            assert e <= max(3 * e_ref, 1e-5), f'{phase} {n}: {e:.3e} vs fp64 (reference fp32 run: {e_ref:.3e})'
+            worst, ref_worst = max(worst, e), max(ref_worst, e_ref)
+    print(f'composition gradients vs the fp64 reference run: oracle worst {worst:.2e}, reference fp32 run worst {ref_worst:.2e}')
