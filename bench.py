@@ -7,9 +7,12 @@ gradient exchange + /world + nan_to_num, Adam, G_ema lerp — in train mode (dro
 Workload (BASELINE.json configs[2]/[3]): global batch 16, 256x256 synthetic backgrounds, 9 elements per layout,
 hot-path-only (BASELINE.md variant A): the frozen BERT text encoder's CLS features are an input tensor and the
 LM-decoder loss is excluded (SURVEY §8a rows a16/a17 are boundary inputs).
-N > 1: one process per GPU (torchrun); by default every GPU keeps 16 samples ("weak" scaling: global batch 16 x N,
-the regime in which the north-star's >= 6.5x at 8 GPUs is meaningful); `--global-batch 16` reproduces configs[3]
-(global batch fixed at 16, "strong").  Gradients are exchanged with RCCL all-reduce over xGMI.
+N > 1: one process per GPU.  `python bench.py --gpus N` spawns the N ranks itself (torch.multiprocessing.spawn, as the reference's
+train.py:27-47 does); under torch.distributed.run it reads RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment instead.
+The headline `value` at N > 1 is BASELINE configs[3]: GLOBAL batch 16 sharded over the ranks ("scaling": "strong"); the same
+process then also times 16 samples PER GPU and reports it as `weak_scaling` (global batch 16 x N).  At N = 1 both coincide
+(configs[2]) and the line also carries `value_reference_call_pattern` (D's trunk evaluated per pass, as the reference does).
+Gradients are exchanged with RCCL all-reduce over xGMI, bucketed and overlapped with the backward graphs.
 
 Prints ONE JSON line on rank 0.
 """
@@ -81,41 +84,66 @@ def cpu_baseline(G_sd, D_sd, G_names, D_names, bg, budget_s=25.0):
                 sample=f'{n} timed iteration(s) of the same Gmain+Dmain step at batch {B}, {bg}x{bg} (oracle/step_ref.py, torch CPU fp32, dropout off) after 1 warm-up')
 
 
-def main():
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=10)
     ap.add_argument('--warmup', type=int, default=3)
-    ap.add_argument('--per-gpu-batch', type=int, default=16, help='samples per GPU (weak scaling: global batch = 16 x N)')
-    ap.add_argument('--global-batch', type=int, default=0, help='fix the GLOBAL batch instead (strong scaling, BASELINE configs[3] uses 16)')
+    ap.add_argument('--per-gpu-batch', type=int, default=0, help='time ONLY this many samples per GPU (weak scaling: global batch = this x N)')
+    ap.add_argument('--global-batch', type=int, default=0, help='time ONLY this GLOBAL batch (strong scaling); default: 16 = BASELINE configs[2]/[3]')
     ap.add_argument('--no-graph', action='store_true', help='eager launches instead of hipGraph replay of each phase')
     ap.add_argument('--bg', type=int, default=256)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
+    ap.add_argument('--no-extra', action='store_true', help='skip the secondary measurements (reference call pattern at N=1, weak scaling at N>1)')
     ap.add_argument('--text-mode', default='features', choices=['features', 'encoder', 'encoder+lm'],
                     help="'features' (headline config: frozen-BERT CLS features are the input); 'encoder': token ids in, the frozen text encoder runs "
                          "inside every G/D forward; 'encoder+lm': plus the trainable LM text decoder and its loss (SURVEY 8f-1)")
     ap.add_argument('--text-tokens', type=int, default=40, help='tokens per element text (reference: padding to max_text_length)')
     ap.add_argument('--no-share-trunk', action='store_true', help="evaluate D's ResNet trunk separately for the fake and the real pass of Dmain, as the reference does")
     ap.add_argument('--share-trunk', default='phase', choices=['phase', 'iteration'], help="'iteration': one D-trunk evaluation also serves Gmain's D(fake) (D's weights do not change between the two phases)")
-    args = ap.parse_args()
+    ap.add_argument('--no-overlap', action='store_true', help='N>1: exchange gradients after each backward graph instead of overlapping the all-reduce with it')
+    return ap.parse_args()
 
-    world = int(os.environ.get('WORLD_SIZE', '1'))
-    rank = int(os.environ.get('RANK', '0'))
-    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+
+def _free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        return sk.getsockname()[1]
+
+
+def _spawned(local_rank, args, port):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(local_rank), LOCAL_RANK=str(local_rank), WORLD_SIZE=str(args.gpus))
+    run(args, local_rank, local_rank, args.gpus)
+
+
+def main():
+    args = parse_args()
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')   # dmabuf IPC only on this host driver (RCCL needs it)
+    env_world = int(os.environ.get('WORLD_SIZE', '0') or 0)
+    if env_world >= 1 and 'RANK' in os.environ:            # launched by torch.distributed.run: one process per GPU already exists
+        if env_world != args.gpus:
+            raise SystemExit(f'bench.py: --gpus {args.gpus} but WORLD_SIZE={env_world}')
+        run(args, int(os.environ['RANK']), int(os.environ.get('LOCAL_RANK', '0')), env_world)
+    elif args.gpus > 1:                                      # plain `python bench.py --gpus N`: spawn the ranks (train.py:27-47 does the same)
+        import torch.multiprocessing as mp
+        assert torch.cuda.is_available() and torch.cuda.device_count() >= args.gpus, f'--gpus {args.gpus} but {torch.cuda.device_count()} visible'
+        mp.spawn(_spawned, args=(args, _free_port()), nprocs=args.gpus, join=True)
+    else:
+        run(args, 0, 0, 1)
+
+
+def run(args, rank, local_rank, world):
     assert torch.cuda.is_available(), 'bench.py needs a GPU'
     torch.cuda.set_device(local_rank)
     device = torch.device('cuda', local_rank)
+    dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         dist.init_process_group('nccl', device_id=device)
-    assert args.gpus == world, f'--gpus {args.gpus} but WORLD_SIZE={world} (launch with torch.distributed.run)'
-    if args.global_batch:
-        assert args.global_batch % world == 0
-        args.batch, scaling = args.global_batch, 'strong'
-    else:
-        args.batch, scaling = args.per_gpu_batch * world, 'weak'
+        assert dist.get_world_size() == world
 
     from layoutdetr_amd import _lib
     _lib.load()   # fails loudly if the HIP library is missing: there is no fallback path
@@ -124,7 +152,7 @@ def main():
     from layoutdetr_amd.training.loss import StyleGAN2Loss
     from layoutdetr_amd.training.networks_detr import Discriminator, Generator
 
-    bg, b_local = args.bg, args.batch // world
+    bg = args.bg
     torch.manual_seed(0)   # identical initial parameters on every rank (stands in for the rank-0 broadcast, training_loop.py:176-179)
     kw = dict(num_bbox_labels=8, img_channels=3, img_height=bg, img_width=bg, c_dim=0, background_size=bg, bert_f_dim=768,
               bert_num_heads=4, bert_num_encoder_layers=12, bert_num_decoder_layers=2, im_f_dim=512)
@@ -142,58 +170,78 @@ def main():
     pG = tl.Phase('Gmain', G, lr=1e-5, betas=(0.0, 0.99), eps=1e-8, reg_interval=4)     # train.py:204,281; training_loop.py:191-194
     pD = tl.Phase('Dmain', D, lr=1e-5, betas=(0.0, 0.99), eps=1e-8, reg_interval=16)
     ema = tl.EmaTracker(pG, G_ema)
-    loss = StyleGAN2Loss(device, G, D, share_D_trunk=False if args.no_share_trunk else (True if args.share_trunk == 'phase' else 'iteration'))
     dp = tl.DataParallelStep(world_size=world)
-
-    torch.manual_seed(0 * world + rank)   # training_loop.py:101-102 seed rule
-    batch = to_device_batch(make_batch(b_local, bg, device, 1000 + rank), device, args.text_mode, args.text_tokens)
     n_params = (pG.fm.total, pD.fm.total)
-    cur_nimg = [0]
-
-    def eager_step():
-        gen_z = [torch.randn(b_local, 9, 4, device=device) for _ in range(2)]
-        tl.training_iteration(loss, [pG, pD], dp, batch, b_local, gen_z, ema=ema, batch_size=args.batch,
-                              ema_kimg=args.batch * 10 / 32, cur_nimg=cur_nimg[0])
-        cur_nimg[0] += args.batch
-
-    step = eager_step
-    if not args.no_graph:
-        # eager warm-up before capture (allocator, folded-BN / position-encoding caches) on a SIDE stream: autograd's AccumulateGrad
-        # nodes remember the stream they were first used on, and one bound to the default stream breaks a later capture
-        # (torch CUDA-graphs note); with the LM decoder many parameter gradients go through AccumulateGrad
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
-            for _ in range(2):
-                eager_step()
-        torch.cuda.current_stream().wait_stream(side)
-        torch.cuda.synchronize()
-        graphed = tl.GraphedIteration(loss, [pG, pD], dp, batch, b_local, 4, ema=ema, batch_size=args.batch, ema_kimg=args.batch * 10 / 32,
-                                      capture_stream=side)
-        graphed.cur_nimg = cur_nimg[0]
-        step = graphed.run
+    torch.manual_seed(0 * world + rank)   # training_loop.py:101-102 seed rule
+    side = torch.cuda.Stream()
 
     def barrier():
         if world > 1:
-            import torch.distributed as dist
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        import torch.distributed as dist
-        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = t.item()
-    ms_per_step = elapsed / args.steps * 1e3
-    value = args.batch * args.steps / elapsed
+    def measure(b_local, share, want_eager=False):
+        """W warm-up + K timed iterations at `b_local` samples per GPU; -> dict(value, ms_per_step, global_batch[, eager_step])."""
+        gb = b_local * world
+        loss = StyleGAN2Loss(device, G, D, share_D_trunk=share)
+        batch = to_device_batch(make_batch(b_local, bg, device, 1000 + rank), device, args.text_mode, args.text_tokens)
+        cur_nimg = [0]
+
+        def eager_step():
+            gen_z = [torch.randn(b_local, 9, 4, device=device) for _ in range(2)]
+            tl.training_iteration(loss, [pG, pD], dp, batch, b_local, gen_z, ema=ema, batch_size=gb, ema_kimg=gb * 10 / 32, cur_nimg=cur_nimg[0])
+            cur_nimg[0] += gb
+
+        step = eager_step
+        if not args.no_graph:
+            # eager warm-up before capture (allocator, folded-BN / position-encoding caches) on a SIDE stream: autograd's AccumulateGrad
+            # nodes remember the stream they were first used on, and one bound to the default stream breaks a later capture
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(2):
+                    eager_step()
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            graphed = tl.GraphedIteration(loss, [pG, pD], dp, batch, b_local, 4, ema=ema, batch_size=gb, ema_kimg=gb * 10 / 32,
+                                          capture_stream=side, overlap=not args.no_overlap)
+            graphed.cur_nimg = cur_nimg[0]
+            step = graphed.run
+        for _ in range(args.warmup):
+            step()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        barrier()
+        elapsed = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = t.item()
+        out = dict(value=round(gb * args.steps / elapsed, 3), ms_per_step=round(elapsed / args.steps * 1e3, 3), global_batch=gb, per_gpu_batch=b_local)
+        if want_eager:
+            out['eager_step'] = eager_step
+        return out
+
+    share = False if args.no_share_trunk else (True if args.share_trunk == 'phase' else 'iteration')
+    extra = {}
+    if args.per_gpu_batch:
+        primary, scaling = measure(args.per_gpu_batch, share, want_eager=True), 'weak'
+    else:
+        gbatch = args.global_batch or 16
+        assert gbatch % world == 0, f'global batch {gbatch} does not divide over {world} GPUs'
+        primary, scaling = measure(gbatch // world, share, want_eager=True), ('strong' if world > 1 else 'weak')
+        if not args.no_extra and not args.global_batch:
+            if world > 1:      # the same ranks at 16 samples per GPU (weak scaling: global batch 16 x N)
+                w = measure(16, share)
+                extra['weak_scaling'] = dict(value=w['value'], ms_per_step=w['ms_per_step'], global_batch=w['global_batch'], per_gpu_batch=16, unit='images/s')
+            elif share is not False:   # N = 1: the reference's call pattern (one D-trunk evaluation per D pass: 25 % more conv FLOPs per step)
+                r = measure(16, False)
+                extra['value_reference_call_pattern'] = r['value']
+                extra['ms_per_step_reference_call_pattern'] = r['ms_per_step']
+    eager_step = primary.pop('eager_step')
+    args.batch, b_local = primary['global_batch'], primary['per_gpu_batch']
+    value, ms_per_step = primary['value'], primary['ms_per_step']
 
     roofline = None
     if not args.no_roofline:
@@ -261,18 +309,18 @@ def main():
         cpu = None
         if G_sd_cpu is not None:
             cpu = cpu_baseline(G_sd_cpu, D_sd_cpu, G_names, D_names, bg)
-        out = dict(metric='images/sec G+D fwd-bwd, 256x256 bg x9 elems', value=round(value, 3), unit='images/s', n_gpus=world,
+        out = dict(metric='images/sec G+D fwd-bwd, 256x256 bg x9 elems', value=round(value, 3), unit='images/s', n_gpus=world, rccl_ranks=(dist.get_world_size() if world > 1 else 1),
                    steps=args.steps, warmup=args.warmup, ms_per_step=round(ms_per_step, 3), higher_is_better=True,
                    scaling=scaling, vs_baseline=None, dtype='f32', data='synthetic',
-                   config=dict(workload=f'BASELINE configs[2] (16 samples per GPU): global batch {args.batch}, {bg}x{bg} backgrounds x 9 elements, full G+D adversarial '
+                   config=dict(workload=f'BASELINE configs[{2 if world == 1 else 3}]: global batch {args.batch} ({b_local} per GPU), {bg}x{bg} backgrounds x 9 elements, full G+D adversarial '
                                         'step (Gmain+Dmain fwd/bwd, grad exchange + nan_to_num, Adam, EMA), train mode (dropout 0.1); ' +
                                         ('hot-path-only: frozen-BERT text features are an input, LM-decoder loss excluded' if args.text_mode == 'features' else f'text path on: {args.text_mode}, {args.text_tokens} tokens per element'),
                                global_batch=args.batch, per_gpu_batch=b_local, background=bg, elements=9,
-                               parallelism=f'dp{world}', hip_graph=not args.no_graph, text_mode=args.text_mode, text_tokens=(args.text_tokens if args.text_mode != 'features' else None), d_trunk_shared=False if args.no_share_trunk else args.share_trunk, params_G=n_params[0], params_D=n_params[1]),
-                   roofline=roofline, cpu_baseline=cpu)
+                               parallelism=f'dp{world}', hip_graph=not args.no_graph, allreduce_overlapped_with_backward=(world > 1 and not args.no_graph and not args.no_overlap), text_mode=args.text_mode, text_tokens=(args.text_tokens if args.text_mode != 'features' else None), d_trunk_shared=False if args.no_share_trunk else args.share_trunk, params_G=n_params[0], params_D=n_params[1]),
+                   roofline=roofline, cpu_baseline=cpu, **extra)
         print(json.dumps(out), flush=True)
     if world > 1:
-        import torch.distributed as dist
+        dist.barrier()
         dist.destroy_process_group()
 
 

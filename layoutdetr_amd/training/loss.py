@@ -109,6 +109,7 @@ class StyleGAN2Loss(Loss):
         # precompute_D_trunk() before the phases; without that call the per-phase behaviour above applies.
         self._trunk_cache = {}
         self.fork_D_trunk = os.environ.get('LDETR_FORK_TRUNK', '0') != '0'   # measured: no gain inside hipGraphs (negative results)
+        self._reporting = report_fn is not None   # the sign() statistics cost a launch each: only formed when someone listens
         self.report = report_fn if report_fn is not None else (lambda name, value: None)
         self.last = {}
 
@@ -183,6 +184,8 @@ class StyleGAN2Loss(Loss):
             loss_Ggen_text_len_rec=loss_text_len * w['Ggen_text_len_rec'],
         )
         self.report('Loss/scores/fake', gen_logits)
+        if self._reporting:
+            self.report('Loss/signs/fake', gen_logits.sign())
         for k, v in terms.items():
             self.report('Loss/G/' + k, v)
         total = sum(terms.values())
@@ -197,6 +200,9 @@ class StyleGAN2Loss(Loss):
                                                    trunk_out=trunk_out)
         loss_Dgen = F.softplus(gen_logits)
         loss_Dgen_uncond = F.softplus(gen_logits_uncond)
+        self.report('Loss/scores/fake', gen_logits)
+        if self._reporting:
+            self.report('Loss/signs/fake', gen_logits.sign())
         self.report('Loss/D/loss_Dgen', loss_Dgen)
         self.report('Loss/D/loss_Dgen_uncond', loss_Dgen_uncond)
         return (loss_Dgen + loss_Dgen_uncond).mean()
@@ -220,6 +226,8 @@ class StyleGAN2Loss(Loss):
             loss_Dreal_bbox_cls_uncond=(_masked_ce(cls_logits_uncond, bbox_class, valid) if static else F.cross_entropy(cls_logits_uncond, bbox_class[valid])) * w['Dreal_bbox_cls'],
         )
         self.report('Loss/scores/real', real_logits)
+        if self._reporting:
+            self.report('Loss/signs/real', real_logits.sign())
         for k, v in terms.items():
             self.report('Loss/D/' + k, v)
         return sum(terms.values()).mean()

@@ -1,0 +1,350 @@
+"""GPU parity of the composed hot path against the REFERENCE ITSELF and at BASELINE sizes.
+
+(1) tests/golden/composition.npz holds what the reference's own Generator.forward / Discriminator.forward and
+    StyleGAN2Loss.accumulate_gradients produce at the real layer sizes (oracle/gen_golden.py:gen_composition drives the imported
+    reference; weights and inputs are rebuilt from their names, oracle/seeded.py).  The HIP modules are compared with it directly:
+    output tuples, every training_stats-reported loss term (north_star: <= 1e-3 relative; asserted tighter), and every parameter
+    gradient against the reference's fp64 run, with the reference's own fp32 run as the yardstick for rounding noise.
+(2) Full iterations at BASELINE.json's sizes (configs[1] B=2 256x256, configs[2] B=16 256x256, configs[4]'s per-GPU share
+    B=4 512x512 with the text encoder on) against the CPU oracle, which tests/test_oracle_golden.py pins to the same fixture.
+    Gradient outliers are adjudicated with an fp64 run of the oracle: |GPU - fp64| <= 3 |CPU-fp32 - fp64| per tensor.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+G_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+SKIP = ('backbone.0.body.', 'text_encoder.', 'text_decoder.')
+KW = dict(num_bbox_labels=8, img_channels=3, c_dim=0, bert_f_dim=768, im_f_dim=512)
+
+
+def load(name):
+    d = np.load(os.path.join(G_DIR, name + '.npz'), allow_pickle=False)
+    return {k: (torch.from_numpy(d[k]) if d[k].dtype.kind in 'fbiu' and d[k].ndim > 0 else d[k]) for k in d.files}
+
+
+def rel(a, b):
+    a, b = torch.as_tensor(a).detach().double().cpu(), torch.as_tensor(b).detach().double().cpu()
+    return ((a - b).abs().max() / (b.abs().max() + 1e-12)).item()
+
+
+def check(a, b, tol, what):
+    e = rel(a, b)
+    assert e <= tol, f'{what}: rel err {e:.3e} > {tol:.1e}'
+    return e
+
+
+class StubBody(torch.nn.Module):
+    """Stands where the ResNet-50 body stands (BackboneBase.body, NHWC out): the fixture's learnable feature map."""
+
+    def __init__(self, feats_nchw):
+        super().__init__()
+        self.feats = torch.nn.Parameter(feats_nchw.permute(0, 2, 3, 1).contiguous())
+
+    def forward(self, x):
+        return self.feats
+
+
+def build(dev, bg, inp):
+    from layoutdetr_amd.training.networks_detr import Discriminator, Generator
+    from oracle import seeded
+    G = Generator(z_dim=4, img_height=bg, img_width=bg, background_size=bg, **KW)
+    D = Discriminator(img_height=bg, img_width=bg, background_size=bg, **KW)
+    G.load_state_dict(seeded.seeded_state_dict(G, 1, SKIP)); D.load_state_dict(seeded.seeded_state_dict(D, 2, SKIP))
+    G.backbone[0].body = StubBody(inp['feats_g']); D.backbone[0].body = StubBody(inp['feats_d'])
+    return G.eval().requires_grad_(False).to(dev), D.eval().requires_grad_(False).to(dev)
+
+
+def test_forward_tuples_vs_reference_fixture(dev):
+    from layoutdetr_amd.training.networks_detr import TextFeatures
+    from oracle import seeded
+    d = load('composition')
+    B, bg, seed = int(d['B']), int(d['bg']), int(d['seed'])
+    inp = seeded.comp_inputs(B, bg, seed)
+    G, D = build(dev, bg, inp)
+    t = {k: v.to(dev) for k, v in inp.items() if isinstance(v, torch.Tensor)}
+    tf = TextFeatures(d['text_feat'].to(dev), d['text_len'].to(dev))
+    patch = torch.zeros(B, 9, 1, 1, 1, device=dev)
+    pm = inp['padding_mask']
+    with torch.no_grad():
+        out = G(t['z_g'], t['bbox_class'], t['bbox_real'], tf, patch, t['padding_mask'], t['background'], None, True)
+        for k, v in zip(('bbox_fake', 'loss_z', 'logit_cls', 'loss_lm', 'loss_text_len'), out):
+            check(v, d['G/' + k], 2e-5, 'G ' + k)
+        check(G(t['z_g'], t['bbox_class'], t['bbox_real'], tf, patch, t['padding_mask'], t['background'], None), d['G/bbox_fake_noreconst'], 2e-5, 'bbox_fake')
+        out = D(t['bbox_real'], t['bbox_class'], tf, patch, t['padding_mask'], t['background'], None, True)
+        for k, v in zip(('logit', 'logit_uncond', 'bbox_pred', 'logit_cls', 'loss_lm', 'loss_text_len', 'bg_rec', 'bbox_pred_uncond', 'logit_cls_uncond'), out):
+            check(v, d['D/' + k], 5e-5, 'D ' + k)
+        # ragged canvas: list of different-sized backgrounds -> padding mask -> masked position encoding / attention
+        bgl = [t['background'][i, :, :h, :w] for i, (h, w) in enumerate(d['ragged_sizes'].tolist())]
+        check(G(t['z_g'], t['bbox_class'], t['bbox_real'], tf, patch, t['padding_mask'], bgl, None), d['G/bbox_fake_ragged'], 2e-5, 'ragged bbox_fake')
+        lo = D(t['bbox_real'], t['bbox_class'], tf, patch, t['padding_mask'], bgl, None)
+        check(lo[0], d['D/logit_ragged'], 2e-5, 'ragged logit'); check(lo[1], d['D/logit_uncond_ragged'], 2e-5, 'ragged logit_uncond')
+        # static-shape heads (what bench.py runs): same numbers on the valid slots
+        G.static_shapes = D.static_shapes = True
+        out = G(t['z_g'], t['bbox_class'], t['bbox_real'], tf, patch, t['padding_mask'], t['background'], None, True)
+        check(out[1], d['G/loss_z'], 2e-5, 'static loss_z'); check(out[4], d['G/loss_text_len'], 2e-5, 'static loss_text_len')
+        check(out[2][(~pm).to(dev)], d['G/logit_cls'], 2e-5, 'static logit_cls')
+        out = D(t['bbox_real'], t['bbox_class'], tf, patch, t['padding_mask'], t['background'], None, True)
+        check(out[2][(~pm).to(dev)], d['D/bbox_pred'], 5e-5, 'static bbox_pred'); check(out[5], d['D/loss_text_len'], 5e-5, 'static D loss_text_len')
+        check(out[7][(~pm).to(dev)], d['D/bbox_pred_uncond'], 5e-5, 'static bbox_pred_uncond')
+
+
+def digest_errors(g, d, phase, name):
+    from oracle import seeded
+    st, sb = seeded.grad_digest(g.detach().cpu())
+    s32 = np.asarray(d[f'{phase}/gsub/{name}']).astype(np.float64); s64 = np.asarray(d[f'{phase}/gsub64/{name}'])
+    st64 = np.asarray(d[f'{phase}/gstat64/{name}'])
+    mx = float(st64[2]) + 1e-300
+    e = max(float(np.abs(sb - s64).max()) / mx, abs(st[0] - float(st64[0])) / (float(st64[0]) + 1e-300))
+    return e, float(np.abs(s32 - s64).max()) / mx
+
+
+@pytest.mark.parametrize('static,share', [(False, False), (False, True), (True, True)])
+def test_loss_phases_vs_reference_fixture(dev, static, share):
+    """accumulate_gradients('Gmain'), ('Dmain') on the HIP modules == the reference's own run: every reported term and every gradient.
+    static/share: the reference-shaped path (boolean gathers, two D passes) and the bench path (masked full-slot heads, one D trunk)."""
+    from layoutdetr_amd.training.loss import StyleGAN2Loss
+    from layoutdetr_amd.training.networks_detr import TextFeatures
+    from oracle import seeded
+    d = load('composition')
+    B, bg, seed = int(d['B']), int(d['bg']), int(d['seed'])
+    inp = seeded.comp_inputs(B, bg, seed)
+    G, D = build(dev, bg, inp)
+    G.static_shapes = D.static_shapes = static
+    t = {k: v.to(dev) for k, v in inp.items() if isinstance(v, torch.Tensor)}
+    tf = TextFeatures(d['text_feat'].to(dev), d['text_len'].to(dev))
+    patch = torch.zeros(B, 9, 1, 1, 1, device=dev)
+    c = torch.zeros(B, 0, device=dev)
+    reports = {}
+    loss = StyleGAN2Loss(dev, G, D, share_D_trunk=share, report_fn=lambda n, v: reports.setdefault(n, []).append(v.detach().clone()))
+    worst_term = worst = ref_worst = 0.0
+    top = []
+    for phase, mod, z in (('Gmain', G, t['z_g']), ('Dmain', D, t['z_d'])):
+        reports.clear()
+        mod.requires_grad_(True); mod.text_encoder.requires_grad_(False)
+        for p in mod.parameters():
+            p.grad = None
+        loss.accumulate_gradients(phase=phase, bbox_real=t['bbox_real'], bbox_class=t['bbox_class'], bbox_text=tf, bbox_patch=patch,
+                                  padding_mask=t['padding_mask'], background=t['background'], real_c=c, gen_z=z, gen_c=c, gain=1, cur_nimg=0)
+        mod.requires_grad_(False)
+        want = {k[len(phase) + 8:]: v for k, v in d.items() if k.startswith(phase + '/report/')}
+        got = {k + (f'#{i}' if len(vs) > 1 else ''): v for k, vs in reports.items() for i, v in enumerate(vs)}
+        got = {k.replace('Loss/G/loss_', 'Loss/G/loss_').replace('Loss/D/loss_', 'Loss/D/loss_'): v for k, v in got.items()}
+        assert set(want) == set(got), sorted(set(want) ^ set(got))
+        for k, v in want.items():
+            v64 = d[f'{phase}/report64/{k}']
+            e, e_ref = rel(got[k], v64), rel(v, v64)
+            # north_star: 1e-3 on losses.  Asserted tighter (1e-4) except where the reference's own fp32 value is no closer to its fp64
+            # value: the alignment term is -log(1 - min |x_i - x_j|) of nearly equal coordinates (cancellation: ~1e-3 in ANY fp32 run)
+            assert e <= max(1e-4, 3 * e_ref) and e <= 1e-3, f'{phase} {k}: {e:.3e} vs fp64 reference (reference fp32: {e_ref:.3e})'
+            worst_term = max(worst_term, e)
+        names = [k[len(phase) + 7:] for k in d if k.startswith(phase + '/gstat/')]
+        grads = {n: p.grad for n, p in mod.named_parameters() if p.grad is not None}
+        grads['backbone.0.body.feats'] = grads['backbone.0.body.feats'].permute(0, 3, 1, 2)
+        assert set(names) == set(grads), sorted(set(names) ^ set(grads))
+        for n in names:
+            e, e_ref = digest_errors(grads[n], d, phase, n)
+            # floor 3e-4 of the tensor's largest entry: the key-bias third of an in_proj_bias has a true gradient of exactly 0 (pure
+            # rounding noise), and one FFN unit whose pre-activation rounds to the other side of 0 moves one row of linear1's dW
+            assert e <= max(3 * e_ref, 3e-4), f'{phase} {n}: {e:.3e} vs the fp64 reference run (reference fp32 run: {e_ref:.3e})'
+            worst, ref_worst = max(worst, e), max(ref_worst, e_ref)
+            top.append((e, e_ref, phase, n))
+    print('  largest gradient errors vs fp64 (HIP, reference fp32):', [(f'{a:.1e}', f'{b:.1e}', n) for a, b, _, n in sorted(top, reverse=True)[:4]])
+    print(f'[composition static={static} share={share}] worst term err {worst_term:.2e}; gradients vs fp64: HIP worst {worst:.2e}, reference fp32 worst {ref_worst:.2e}')
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# BASELINE.json sizes against the (fixture-pinned) CPU oracle
+
+def make_modules(bg, seed, text_mode='features', **extra):
+    from layoutdetr_amd.training.networks_detr import Discriminator, Generator
+    torch.manual_seed(seed)
+    G = Generator(z_dim=4, img_height=bg, img_width=bg, background_size=bg, text_mode=text_mode, **KW, **extra)
+    D = Discriminator(img_height=bg, img_width=bg, background_size=bg, text_mode=text_mode, **KW, **extra)
+    for m in list(G.modules()) + list(D.modules()):
+        if m.__class__.__name__ == 'FrozenBatchNorm2d':   # non-trivial frozen statistics
+            m.weight.uniform_(0.5, 1.5); m.bias.normal_(0, 0.1); m.running_mean.normal_(0, 0.1); m.running_var.uniform_(0.5, 1.5)
+    return G, D
+
+
+def make_batch(B, bg, seed, ragged=True):
+    g = torch.Generator().manual_seed(seed)
+    bt = dict(bbox_real=torch.cat([torch.rand(B, 9, 2, generator=g) * 0.6 + 0.2, torch.rand(B, 9, 2, generator=g) * 0.35 + 0.05], -1),
+              bbox_class=torch.randint(0, 8, (B, 9), generator=g), text_feat=torch.randn(B, 9, 768, generator=g),
+              text_len=torch.randint(1, 40, (B, 9), generator=g), padding_mask=torch.zeros(B, 9, dtype=torch.bool),
+              background=torch.randn(B, 3, bg, bg, generator=g))
+    if ragged:
+        bt['padding_mask'][0, 6:] = True
+        if B > 2:
+            bt['padding_mask'][2, 1:] = True
+    return bt, torch.randn(B, 9, 4, generator=g), torch.randn(B, 9, 4, generator=g)
+
+
+def device_batch(bt, dev):
+    from layoutdetr_amd.training.networks_detr import TextFeatures
+    B = bt['bbox_real'].shape[0]
+    return dict(bbox_real=bt['bbox_real'].to(dev), bbox_class=bt['bbox_class'].to(dev),
+                bbox_text=TextFeatures(bt['text_feat'].to(dev), bt['text_len'].to(dev)), bbox_patch=torch.zeros(B, 9, 1, 1, 1, device=dev),
+                padding_mask=bt['padding_mask'].to(dev), background=bt['background'].to(dev), real_c=torch.zeros(B, 0, device=dev),
+                gen_c=torch.zeros(B, 0, device=dev))
+
+
+def cast_sd(sd, dt):
+    return {k: (v.to(dt) if v.dtype.is_floating_point else v.clone()) for k, v in sd.items()}
+
+
+def test_full_iteration_configs1_b2_256_vs_oracle_fp64_adjudicated(dev):
+    """BASELINE configs[1] size (B=2, 256x256, S=64 image tokens): one Gmain + Dmain iteration through the flat-parameter step.
+    Every loss term and bbox_fake within 1e-3 (north_star) of the CPU oracle; every gradient tensor judged against an fp64 run
+    of the oracle, with the oracle's own fp32 run as yardstick — the step is piecewise linear (ReLU, max-pool, min/max in the
+    layout losses), so a pre-activation within rounding distance of 0 flips a mask in ANY fp32 evaluation, CPU or GPU."""
+    from layoutdetr_amd.training import training_loop as tl
+    from layoutdetr_amd.training.loss import StyleGAN2Loss
+    from oracle import step_ref
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    bg, B = 256, 2
+    G, D = make_modules(bg, seed=21)
+    bt, zg, zd = make_batch(B, bg, seed=22)
+    Gsd = {k: v.clone() for k, v in G.state_dict().items()}; Dsd = {k: v.clone() for k, v in D.state_dict().items()}
+    names = dict(G_param_names={n for n, _ in G.named_parameters()}, D_param_names={n for n, _ in D.named_parameters()})
+    o32 = step_ref.training_iteration(Gsd, Dsd, bt, zg, zd, bg_size=bg, apply_adam=False, **names)
+    bt64 = {k: (v.double() if v.dtype.is_floating_point else v) for k, v in bt.items()}
+    o64 = step_ref.training_iteration(cast_sd(Gsd, torch.float64), cast_sd(Dsd, torch.float64), bt64, zg.double(), zd.double(), bg_size=bg,
+                                      apply_adam=False, **names)
+    G.eval().requires_grad_(False).to(dev); D.eval().requires_grad_(False).to(dev)
+    pG = tl.Phase('Gmain', G, lr=0.0); pD = tl.Phase('Dmain', D, lr=0.0)     # lr 0: Dmain sees the same G as the oracle's apply_adam=False
+    reports = {}
+    loss = StyleGAN2Loss(dev, G, D, share_D_trunk=False, report_fn=lambda n, v: reports.setdefault(n, []).append(v.detach().clone()))
+    dp = tl.DataParallelStep(world_size=1)
+    grads, terms = {}, {}
+    orig = dp.apply
+
+    def spy(phase):
+        grads[phase.name] = {n: p.grad.detach().clone() for n, p in phase.module.named_parameters()}
+        terms[phase.name] = {k + (f'#{i}' if len(vs) > 1 else ''): v for k, vs in reports.items() for i, v in enumerate(vs)}
+        reports.clear()
+        orig(phase)
+    dp.apply = spy
+    tl.training_iteration(loss, [pG, pD], dp, device_batch(bt, dev), B, [zg.to(dev), zd.to(dev)])
+    valid = ~bt['padding_mask']
+    check(loss.last['bbox_fake'][valid.to(dev)], o64[0]['bbox_fake'][valid], 1e-3, 'bbox_fake')
+    worst_term = 0.0
+    for phase, key in (('Gmain', 'terms_G'), ('Dmain', 'terms_D')):
+        ref = o64[0][key]
+        got = terms[phase]
+        # the reference reports 'Loss/scores/fake' + 'Loss/signs/fake' twice in Dmain?  no: once per phase (Dgen); '#i' only if repeated
+        assert set(ref) == set(got), sorted(set(ref) ^ set(got))
+        for k, v in ref.items():
+            e, e_cpu32 = rel(got[k], v), rel(o32[0][key][k], v)
+            assert e <= max(1e-3, 3 * e_cpu32), f'{phase} {k}: {e:.3e} vs fp64 oracle (CPU fp32 oracle: {e_cpu32:.3e})'
+            worst_term = max(worst_term, e)
+    e_gpu, e_cpu, bad = [], [], []
+    for phase, i in (('Gmain', 1), ('Dmain', 2)):
+        for k, g64 in o64[i].items():
+            a, b = rel(grads[phase][k], g64), rel(o32[i][k], g64)
+            e_gpu.append(a); e_cpu.append(b)
+            if a > max(3 * b, 1e-4):
+                bad.append((a, b, phase, k))
+    e_gpu, e_cpu = np.array(e_gpu), np.array(e_cpu)
+    print(f'[configs1 B=2 256] worst loss-term err {worst_term:.2e}; gradient error vs fp64 oracle: HIP median {np.median(e_gpu):.2e} p90 {np.quantile(e_gpu, .9):.2e} '
+          f'max {e_gpu.max():.2e} | CPU fp32 median {np.median(e_cpu):.2e} p90 {np.quantile(e_cpu, .9):.2e} max {e_cpu.max():.2e}; '
+          f'{len(bad)} of {len(e_gpu)} tensors beyond 3x the CPU-fp32 error: {sorted(bad, reverse=True)[:3]}')
+    # As close to fp64 as the CPU fp32 evaluation is, IN DISTRIBUTION.  Not tensor by tensor: one flipped ReLU in layer2 perturbs the
+    # gradient of every tensor upstream of it (all of layer1 + the stem move together by the same ~2e-2), and the CPU and the GPU
+    # run flip different units (CPU fp32's own worst tensor here is 1.4e-1 off its fp64 value).  The flip-free parts of the step
+    # are held tensor by tensor at 1e-4 by test_loss_phases_vs_reference_fixture, the trunk's kernels by tests/test_kernels_gpu.py.
+    assert np.median(e_gpu) <= max(2 * np.median(e_cpu), 2e-5)
+    assert np.quantile(e_gpu, 0.9) <= max(3 * np.quantile(e_cpu, 0.9), 1e-4)
+    assert e_gpu.max() <= max(2 * e_cpu.max(), 1e-3)
+    assert len(bad) <= 0.15 * len(e_gpu), bad[:5]
+
+
+def test_forward_and_losses_configs2_b16_256_vs_oracle(dev):
+    """BASELINE configs[2] size (B=16, 256x256), all 9 slots valid as bench.py runs it (static-shape heads, shared D trunk):
+    bbox_fake and every Gmain / Dmain loss term within 1e-3 of the CPU oracle."""
+    from layoutdetr_amd.training.loss import StyleGAN2Loss
+    from oracle import step_ref
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    bg, B = 256, 16
+    G, D = make_modules(bg, seed=31)
+    bt, zg, zd = make_batch(B, bg, seed=32, ragged=False)
+    Gsd = {k: v.clone() for k, v in G.state_dict().items()}; Dsd = {k: v.clone() for k, v in D.state_dict().items()}
+    def oracle(dt):
+        tG, tD = {}, {}
+        b_ = {k: (v.to(dt) if v.dtype.is_floating_point else v) for k, v in bt.items()}
+        Gs, Ds = cast_sd(Gsd, dt), cast_sd(Dsd, dt)
+        with torch.no_grad():
+            _, bf = step_ref.g_main_loss(Gs, Ds, b_, zg.to(dt), bg_size=bg, terms=tG)
+            step_ref.d_gen_loss(Gs, Ds, b_, zd.to(dt), terms=tD); step_ref.d_real_loss(Ds, b_, bg_size=bg, terms=tD)
+        return tG, tD, bf
+    tG, tD, bbox_fake = oracle(torch.float64)
+    tG32, tD32, _ = oracle(torch.float32)
+    G.eval().requires_grad_(False).to(dev); D.eval().requires_grad_(False).to(dev)
+    G.static_shapes = D.static_shapes = True
+    reports = {}
+    loss = StyleGAN2Loss(dev, G, D, share_D_trunk=True, report_fn=lambda n, v: reports.setdefault(n, []).append(v.detach().clone()))
+    b = device_batch(bt, dev)
+    args = (b['bbox_real'], b['bbox_class'], b['bbox_text'], b['bbox_patch'], b['padding_mask'], b['background'])
+    with torch.no_grad():
+        loss.g_main_loss(*args, zg.to(dev), b['gen_c'])
+        got_G = {k: vs[0] for k, vs in reports.items()}; reports.clear()
+        trunk = D.trunk(b['background'])
+        loss.d_gen_loss(*args, zd.to(dev), b['gen_c'], trunk_out=trunk); loss.d_real_loss(*args, b['real_c'], trunk_out=trunk)
+        got_D = {k: vs[0] for k, vs in reports.items()}
+    worst = check(loss.last['bbox_fake'], bbox_fake, 1e-3, 'bbox_fake')
+    for ref, ref32, got, nm in ((tG, tG32, got_G, 'Gmain'), (tD, tD32, got_D, 'Dmain')):
+        assert set(ref) == set(got), sorted(set(ref) ^ set(got))
+        for k, v in ref.items():
+            e, e_cpu32 = rel(got[k], v), rel(ref32[k], v)     # vs the fp64 oracle; yardstick = the fp32 oracle (alignment term: cancellation)
+            assert e <= max(1e-3, 3 * e_cpu32), f'{nm} {k}: {e:.3e} vs fp64 oracle (CPU fp32 oracle: {e_cpu32:.3e})'
+            worst = max(worst, e)
+    print(f'[configs2 B=16 256] worst bbox / loss-term err {worst:.2e}')
+
+
+def test_forward_configs4_share_b4_512_text_encoder_on(dev):
+    """BASELINE configs[4]'s per-GPU share (B=4, 512x512 -> S=256 image tokens) with the text path ON: token ids in, the 12-layer
+    frozen BERT text encoder (4 heads x 192) runs inside G.forward / D.forward on the HIP kernels.  Against the CPU oracle
+    (bert_ref for the encoder, networks_ref for G / D): bbox_fake, logits and reconstruction heads within 1e-3."""
+    from layoutdetr_amd.training.networks_detr import TextTokens
+    from oracle import bert_ref, networks_ref
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    bg, B, T = 512, 4, 40
+    G, D = make_modules(bg, seed=41, text_mode='encoder', bert_num_encoder_layers=12, bert_num_heads=4)
+    for m in (G, D):
+        for n, p in m.text_encoder.named_parameters():
+            p.data.normal_(0, 0.03)
+            if 'LayerNorm.weight' in n:
+                p.data.add_(1.0)
+    bt, zg, _ = make_batch(B, bg, seed=42)
+    g = torch.Generator().manual_seed(43)
+    ids = torch.randint(1000, 30000, (B, 9, T), generator=g)
+    lens = torch.randint(3, T + 1, (B, 9), generator=g)
+    am = (torch.arange(T)[None, None, :] < lens[..., None]).long()
+    ids = ids * am
+    Gsd = {k: v.clone() for k, v in G.state_dict().items()}; Dsd = {k: v.clone() for k, v in D.state_dict().items()}
+    with torch.no_grad():
+        feats = []
+        for sd in (Gsd, Dsd):
+            enc = {k[len('text_encoder.'):]: v for k, v in sd.items() if k.startswith('text_encoder.')}
+            feats.append(bert_ref.bert_text_forward(enc, 4, ids.reshape(B * 9, T), am.reshape(B * 9, T))[:, 0].reshape(B, 9, -1))
+        ref_g = networks_ref.generator(Gsd, zg, bt['bbox_class'], feats[0], bt['text_len'], bt['padding_mask'], bt['background'], reconst=True)
+        ref_d = networks_ref.discriminator(Dsd, bt['bbox_real'], bt['bbox_class'], feats[1], bt['text_len'], bt['padding_mask'], bt['background'],
+                                           reconst=True, bg_size=bg)
+    G.eval().requires_grad_(False).to(dev); D.eval().requires_grad_(False).to(dev)
+    toks = TextTokens(ids.to(dev), am.to(dev), bt['text_len'].to(dev))
+    patch = torch.zeros(B, 9, 1, 1, 1, device=dev)
+    valid = ~bt['padding_mask']
+    with torch.no_grad():
+        out_g = G(zg.to(dev), bt['bbox_class'].to(dev), bt['bbox_real'].to(dev), toks, patch, bt['padding_mask'].to(dev), bt['background'].to(dev), None, True)
+        out_d = D(bt['bbox_real'].to(dev), bt['bbox_class'].to(dev), toks, patch, bt['padding_mask'].to(dev), bt['background'].to(dev), None, True)
+    worst = check(out_g[0][valid.to(dev)], ref_g[0][valid], 1e-3, 'bbox_fake')
+    for i, nm in [(1, 'loss_z'), (2, 'logit_cls'), (4, 'loss_text_len')]:
+        worst = max(worst, check(out_g[i], ref_g[i], 1e-3, 'G ' + nm))
+    for i, nm in enumerate(['logit', 'logit_uncond', 'bbox_pred', 'logit_cls', 'loss_lm', 'loss_text_len', 'bg_rec', 'bbox_pred_uncond', 'logit_cls_uncond']):
+        if nm != 'loss_lm':
+            worst = max(worst, check(out_d[i], ref_d[i], 1e-3, 'D ' + nm))
+    print(f'[configs4 share B=4 512 text on] worst err {worst:.2e}')

@@ -59,8 +59,23 @@ def test_layoutganpp_encoder_matches_reference_golden(dev):
     y = m(x, src_key_padding_mask=d['kpm'].to(dev))
     valid = torch.cat([torch.ones(2, 1, dtype=torch.bool), ~d['kpm']], 1).t()  # [L+1, B]; padded rows are never compared
     check(y[valid.to(dev)], d['y'][valid], 2e-5, 'y')
+    # the fixture's backward used the full upstream gradient g (padded rows included).  Padded rows only feed themselves (they are
+    # masked out as keys), so zeroing their upstream gradient on BOTH sides isolates the defined part: the reference value of that
+    # is recomputed by the pinned CPU oracle (tests/test_oracle_golden.py holds it to the fixture's full-g gradients).
+    from oracle import detr_ref
     g = d['g'].clone(); g[~valid] = 0
     (y * g.to(dev)).sum().backward()
+    sd = {k: v.clone().requires_grad_(v.dtype.is_floating_point) for k, v in sd_of(d).items()}
+    xr = d['x'].clone().requires_grad_(True)
+    yr = detr_ref.token_encoder_layoutganpp(sd, '', xr, d['kpm'], 2)
+    check(yr[valid], d['y'][valid], 2e-5, 'oracle y')
+    (yr * g).sum().backward()
+    check(x.grad, xr.grad, 1e-4, 'd_x')
+    n_checked = 0
+    for k, p in m.named_parameters():
+        if sd[k].grad is not None and sd[k].grad.abs().max() > 0:
+            check(p.grad, sd[k].grad, 2e-4, 'grad ' + k); n_checked += 1
+    assert n_checked >= 20
 
 
 def test_stylegan2_decoder_matches_reference_golden(dev):
