@@ -128,7 +128,7 @@ def main():
         run(args, int(os.environ['RANK']), int(os.environ.get('LOCAL_RANK', '0')), env_world)
     elif args.gpus > 1:                                      # plain `python bench.py --gpus N`: spawn the ranks (train.py:27-47 does the same)
         import torch.multiprocessing as mp
-        assert torch.cuda.is_available() and torch.cuda.device_count() >= args.gpus, f'--gpus {args.gpus} but {torch.cuda.device_count()} visible'
+        assert torch.cuda.is_available() and (torch.cuda.device_count() >= args.gpus or os.environ.get('LDETR_BENCH_SHARE_GPU')), f'--gpus {args.gpus} but {torch.cuda.device_count()} visible'
         mp.spawn(_spawned, args=(args, _free_port()), nprocs=args.gpus, join=True)
     else:
         run(args, 0, 0, 1)
@@ -136,13 +136,21 @@ def main():
 
 def run(args, rank, local_rank, world):
     assert torch.cuda.is_available(), 'bench.py needs a GPU'
+    # development aid (a 1-GPU box): LDETR_BENCH_SHARE_GPU=1 puts every rank on cuda:0 and exchanges through gloo (RCCL refuses two ranks
+    # on one device); it exercises the rank logic, the staged graphs and the overlap plumbing, not xGMI
+    share_gpu = bool(os.environ.get('LDETR_BENCH_SHARE_GPU'))
+    if share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device('cuda', local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', device_id=device)
+        if share_gpu:
+            dist.init_process_group('gloo')
+        else:
+            dist.init_process_group('nccl', device_id=device)
         assert dist.get_world_size() == world
 
     from layoutdetr_amd import _lib
@@ -309,7 +317,7 @@ def run(args, rank, local_rank, world):
         cpu = None
         if G_sd_cpu is not None:
             cpu = cpu_baseline(G_sd_cpu, D_sd_cpu, G_names, D_names, bg)
-        out = dict(metric='images/sec G+D fwd-bwd, 256x256 bg x9 elems', value=round(value, 3), unit='images/s', n_gpus=world, rccl_ranks=(dist.get_world_size() if world > 1 else 1),
+        out = dict(metric='images/sec G+D fwd-bwd, 256x256 bg x9 elems', value=round(value, 3), unit='images/s', n_gpus=world, rccl_ranks=(dist.get_world_size() if world > 1 else 1), **({'shared_single_gpu_gloo': True} if share_gpu else {}),
                    steps=args.steps, warmup=args.warmup, ms_per_step=round(ms_per_step, 3), higher_is_better=True,
                    scaling=scaling, vs_baseline=None, dtype='f32', data='synthetic',
                    config=dict(workload=f'BASELINE configs[{2 if world == 1 else 3}]: global batch {args.batch} ({b_local} per GPU), {bg}x{bg} backgrounds x 9 elements, full G+D adversarial '

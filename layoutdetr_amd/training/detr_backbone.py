@@ -104,8 +104,39 @@ class Bottleneck(nn.Module):
         return hconv.conv2d_nhwc(out, self.conv3.weight, s3, b3, idt, 1, 0, relu=True, mask_input=True, premasked=self.premask_out)
 
 
+class BackwardStages(object):
+    """Cuts a phase's backward pass into stages so that the gradient exchange of the part that is already complete can run
+    (RCCL, side stream) while the rest of the backward is still computing (reference site: training_loop.py:303-312 reduces
+    after the whole backward; north_star asks for the overlap).
+
+    Stage 1 = everything downstream of the trunk (heads, transformers, decoder) — runs inside `loss.backward()`;
+    stage 2 = layer4 + layer3 of the trunk; stage 3 = layer2, layer1, stem.  `ResNet50Body.forward` calls `cut()` at the two
+    boundaries: the activation is detached into a fresh leaf, so `loss.backward()` stops there and leaves the boundary gradient in
+    `leaf.grad`; `run(stage)` then continues from it.  Parameter order in the flat gradient buffer is (stem, layer1..layer4, rest),
+    so each stage completes one contiguous segment (`training_loop.FlatModule.stage_segments`)."""
+
+    def __init__(self):
+        self.records = {2: [], 3: []}
+
+    def cut(self, x, stage):
+        leaf = x.detach().requires_grad_(True)
+        self.records[stage].append((x, leaf))
+        return leaf
+
+    def run(self, stage):
+        recs, self.records[stage] = self.records[stage], []
+        for x, leaf in recs:
+            if leaf.grad is not None:
+                x.backward(leaf.grad)
+
+    def pending(self):
+        return any(self.records.values())
+
+
 class ResNet50Body(nn.Module):
     """conv1/bn1/maxpool/layer1..4 of torchvision resnet50 (what IntermediateLayerGetter keeps, detr_backbone.py:78-79)."""
+
+    stages = None   # a BackwardStages while a staged phase runs (set by training_loop.run_phase), else None
 
     def __init__(self):
         super().__init__()
@@ -127,7 +158,13 @@ class ResNet50Body(nn.Module):
         s, b = self.bn1.folded()
         x = hconv.conv2d_nhwc(x_nchw, self.conv1.weight, s, b, None, 2, 3, relu=True, x_is_nchw=True)
         x = hconv.maxpool3x3s2_nhwc(x)
-        x = self.layer1(x); x = self.layer2(x); x = self.layer3(x); x = self.layer4(x)
+        x = self.layer1(x); x = self.layer2(x)
+        st = self.stages if (self.stages is not None and x.requires_grad and torch.is_grad_enabled()) else None
+        if st is not None:
+            x = st.cut(x, 3)
+        x = self.layer3(x); x = self.layer4(x)
+        if st is not None:
+            x = st.cut(x, 2)
         return x  # [N, H/32, W/32, 2048]
 
 

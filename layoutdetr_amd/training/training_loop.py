@@ -41,7 +41,9 @@ class FlatModule(object):
 
     def __init__(self, module):
         self.module = module
-        params = list(module.parameters())
+        named = list(module.named_parameters())
+        params = [p for _, p in named]
+        self.names = [n for n, _ in named]
         self.params = params
         device = params[0].device
         # keep every segment 16-byte aligned so the float4 kernels and conv loaders stay on the vector path
@@ -68,6 +70,22 @@ class FlatModule(object):
 
     def numel(self):
         return self.total
+
+    def stage_segments(self):
+        """Per backward stage (detr_backbone.BackwardStages) the list of (lo, hi) ranges of the flat buffer it completes: stage 1 =
+        everything but the trunk (the module's own direct parameters, e.g. D.pos_token, precede `backbone` in parameter order: two
+        ranges), stage 2 = trunk layer3 + layer4, stage 3 = stem + layer1 + layer2 — or None when the trunk is not one contiguous
+        run of parameters ending in layer3/layer4 (then the phase is exchanged in one piece)."""
+        pre = 'backbone.0.body.'
+        trunk = [i for i, n in enumerate(self.names) if n.startswith(pre)]
+        if not trunk or trunk != list(range(trunk[0], trunk[0] + len(trunk))):
+            return None
+        late = [i for i in trunk if self.names[i].startswith((pre + 'layer3.', pre + 'layer4.'))]
+        if not late or late != list(range(late[0], trunk[-1] + 1)):
+            return None
+        off = lambda i: self.offsets[i] if i < len(self.offsets) else self.total
+        o0, o2, oT = off(trunk[0]), off(late[0]), off(trunk[-1] + 1)
+        return [[r for r in ((0, o0), (oT, self.total)) if r[1] > r[0]], [(o2, oT)], [(o0, o2)]]
 
 
 class Phase(object):
@@ -113,10 +131,35 @@ class DataParallelStep(object):
             for s in range(0, n, self.bucket):
                 dist.all_reduce(gflat[s:min(n, s + self.bucket)])
 
-    def apply(self, phase):
+    def exchange_async(self, gflat, lo, hi):
+        """SUM all-reduce of gflat[lo:hi] on the communication stream, ordered after everything queued so far on the current
+        stream; the current stream keeps going (the next backward stage).  `finish()` joins."""
+        if self.world <= 1 or hi <= lo:
+            return
+        import torch.distributed as dist
+        if self.comm_stream is not None:
+            self.comm_stream.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(self.comm_stream):
+                for s in range(lo, hi, self.bucket):
+                    dist.all_reduce(gflat[s:min(hi, s + self.bucket)])
+        else:  # gloo / CPU tests: synchronous
+            for s in range(lo, hi, self.bucket):
+                dist.all_reduce(gflat[s:min(hi, s + self.bucket)])
+        self._pending = True
+
+    def finish(self):
+        if self.comm_stream is not None and getattr(self, '_pending', False):
+            torch.cuda.current_stream().wait_stream(self.comm_stream)
+        self._pending = False
+
+    def apply(self, phase, exchanged=False):
+        """exchanged=True: the caller already reduced the gradient segment by segment (exchange_async); only join here."""
         fm = phase.fm
         core.join_side()   # weight-gradient launches of a backward that was not run through Loss.accumulate_gradients
-        self.exchange(fm.gflat)
+        if exchanged:
+            self.finish()
+        else:
+            self.exchange(fm.gflat)
         phase.step += 1
         scale = 1.0 / self.world
         if fm.flat.device.type != 'cuda':
@@ -163,7 +206,44 @@ def broadcast_module(module, src=0):
         dist.broadcast(t.data, src=src)
 
 
-def training_iteration(loss, phases, dp, batch, batch_gpu, gen_z_per_phase, ema=None, batch_size=None, ema_kimg=None, cur_nimg=0):
+def _trunk_body(module):
+    bb = getattr(module, 'backbone', None)
+    return bb[0].body if bb is not None and hasattr(bb[0], 'body') else None
+
+
+def staged_backward(loss, phase, dp, run_stage1, between=None, exchange=None):
+    """One phase's forward + backward in three stages with the gradient exchange of each finished segment launched behind it
+    (DataParallelStep.exchange_async) -> True if the gradients were exchanged here.  `run_stage1()` runs the forward passes and
+    `loss.backward()`; `between(i)` (optional) is called after stage i's work has been queued (graph capture boundaries);
+    `exchange(ranges)` replaces the RCCL launch (graph capture: the collectives stay outside the graphs)."""
+    from .detr_backbone import BackwardStages
+    segs = phase.fm.stage_segments()
+    body = _trunk_body(phase.module)
+    if segs is None or body is None or not hasattr(body, 'stages'):
+        run_stage1()
+        return False
+    st = BackwardStages()
+    body.stages = st
+    if exchange is None:
+        exchange = lambda ranges: [dp.exchange_async(phase.fm.gflat, lo, hi) for lo, hi in ranges]
+    try:
+        run_stage1()
+        core.join_side()
+        if between is not None:
+            between(1)
+        exchange(segs[0])
+        for i in (2, 3):
+            st.run(i)
+            core.join_side()
+            if between is not None:
+                between(i)
+            exchange(segs[i - 1])
+    finally:
+        body.stages = None
+    return True
+
+
+def training_iteration(loss, phases, dp, batch, batch_gpu, gen_z_per_phase, ema=None, batch_size=None, ema_kimg=None, cur_nimg=0, overlap=None):
     """One iteration = all phases (Gmain, Dmain) over the rank-local batch, as training_loop.py:274-328.
 
     batch: dict with bbox_real [b,9,4], bbox_class [b,9], bbox_text (TextFeatures), bbox_patch, padding_mask [b,9] bool,
@@ -171,21 +251,28 @@ def training_iteration(loss, phases, dp, batch, batch_gpu, gen_z_per_phase, ema=
     """
     b = batch['bbox_real'].shape[0]
     core.reseed(batch['bbox_real'].device)   # fresh device-side dropout seed word for this iteration
-    if getattr(loss, 'share_D_trunk', None) == 'iteration' and any(p.name == 'Dmain' for p in phases):
+    iter_share = getattr(loss, 'share_D_trunk', None) == 'iteration' and any(p.name == 'Dmain' for p in phases)
+    if iter_share:
         for s in range(0, b, batch_gpu):
             loss.precompute_D_trunk(batch['background'][s:s + batch_gpu])
+    if overlap is None:     # overlap the exchange with backward whenever there is an exchange (one micro-batch: the last one is the only one)
+        overlap = dp.world > 1
     for phase, gen_z in zip(phases, gen_z_per_phase):
         phase.fm.zero_grad()
         phase.module.requires_grad_(True)
         phase.module.text_encoder.requires_grad_(False)
-        for s in range(0, b, batch_gpu):
-            sl = slice(s, s + batch_gpu)
-            loss.accumulate_gradients(phase=phase.name, bbox_real=batch['bbox_real'][sl], bbox_class=batch['bbox_class'][sl],
-                                      bbox_text=batch['bbox_text'][sl], bbox_patch=batch['bbox_patch'][sl],
-                                      padding_mask=batch['padding_mask'][sl], background=batch['background'][sl],
-                                      real_c=batch['real_c'][sl], gen_z=gen_z[sl], gen_c=batch['gen_c'][sl], gain=1, cur_nimg=cur_nimg)
+
+        def accumulate(phase=phase, gen_z=gen_z):
+            for s in range(0, b, batch_gpu):
+                sl = slice(s, s + batch_gpu)
+                loss.accumulate_gradients(phase=phase.name, bbox_real=batch['bbox_real'][sl], bbox_class=batch['bbox_class'][sl],
+                                          bbox_text=batch['bbox_text'][sl], bbox_patch=batch['bbox_patch'][sl],
+                                          padding_mask=batch['padding_mask'][sl], background=batch['background'][sl],
+                                          real_c=batch['real_c'][sl], gen_z=gen_z[sl], gen_c=batch['gen_c'][sl], gain=1, cur_nimg=cur_nimg)
+        staged = overlap and b <= batch_gpu and not (iter_share and phase.name == 'Dmain')
+        exchanged = staged_backward(loss, phase, dp, accumulate) if staged else (accumulate() or False)
         phase.module.requires_grad_(False)
-        dp.apply(phase)
+        dp.apply(phase, exchanged=exchanged)
     if ema is not None:
         ema.update(batch_size, ema_kimg, cur_nimg)
 
@@ -200,23 +287,27 @@ class GraphedIteration(object):
     The gradient exchange, Adam and EMA stay outside the graphs (RCCL collectives and host-side step counters).
     """
 
-    def __init__(self, loss, phases, dp, batch, batch_gpu, z_dim, ema=None, batch_size=None, ema_kimg=None, capture_stream=None):
+    def __init__(self, loss, phases, dp, batch, batch_gpu, z_dim, ema=None, batch_size=None, ema_kimg=None, capture_stream=None, overlap=None):
         # capture_stream: the side stream the eager warm-up iterations ran on.  Autograd's AccumulateGrad nodes remember the stream of
         # their first use; capturing on that same stream keeps the whole backward on ONE stream (a mismatch makes the engine hop
         # streams inside the capture, and the private-pool allocator then recycles blocks across branches: corrupted replays)
+        # overlap (default: world > 1): each phase becomes THREE chained graphs (backward stages, detr_backbone.BackwardStages); between
+        # their replays the finished gradient segment goes to RCCL on the communication stream while the next graph computes.
         self.capture_stream = capture_stream
         self.loss, self.phases, self.dp, self.batch, self.batch_gpu = loss, phases, dp, batch, batch_gpu
         self.ema, self.batch_size, self.ema_kimg = ema, batch_size, ema_kimg
         self.cur_nimg = 0
-        self.graphs = []
+        self.graphs = []       # per phase: [(graph, flat segment exchanged after it | None)]
         dev = batch['bbox_real'].device
         b = batch['bbox_real'].shape[0]
         self.pre_graph = None
-        pool = None
-        if getattr(loss, 'share_D_trunk', None) == 'iteration' and any(p.name == 'Dmain' for p in phases):
+        iter_share = getattr(loss, 'share_D_trunk', None) == 'iteration' and any(p.name == 'Dmain' for p in phases)
+        if overlap is None:
+            overlap = dp.world > 1
+        pool = torch.cuda.graph_pool_handle() if (iter_share or overlap) else None
+        if iter_share:
             # D's trunk forward gets its own graph, replayed before the phases; its activations stay alive in the shared pool until
             # the Dmain graph (captured below, replayed after it) runs the trunk's backward
-            pool = torch.cuda.graph_pool_handle()
             self.pre_graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.pre_graph, pool=pool, stream=self.capture_stream):
                 for s in range(0, b, batch_gpu):
@@ -228,8 +319,19 @@ class GraphedIteration(object):
             phase.fm.zero_grad()
             phase.module.requires_grad_(True)
             phase.module.text_encoder.requires_grad_(False)
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, pool=pool, stream=self.capture_stream):
+            staged = overlap and b <= batch_gpu and not (iter_share and phase.name == 'Dmain') and phase.fm.stage_segments() is not None
+            chain, cur = [], {}
+
+            def begin():
+                cur['g'] = torch.cuda.CUDAGraph()
+                cur['ctx'] = torch.cuda.graph(cur['g'], pool=pool, stream=self.capture_stream)
+                cur['ctx'].__enter__()
+
+            def end(seg):
+                cur['ctx'].__exit__(None, None, None)
+                chain.append((cur['g'], seg))
+
+            def stage1(phase=phase):
                 core.reseed(dev)
                 phase.fm.gflat.zero_()
                 gen_z = torch.randn(b, batch['bbox_class'].shape[1], z_dim, device=dev)
@@ -239,15 +341,38 @@ class GraphedIteration(object):
                                               bbox_text=batch['bbox_text'][sl], bbox_patch=batch['bbox_patch'][sl],
                                               padding_mask=batch['padding_mask'][sl], background=batch['background'][sl],
                                               real_c=batch['real_c'][sl], gen_z=gen_z[sl], gen_c=batch['gen_c'][sl], gain=1, cur_nimg=0)
+            begin()
+            try:
+                if staged:
+                    segs = phase.fm.stage_segments()
+
+                    def between(i):
+                        end(segs[i - 1])
+                        if i < 3:
+                            begin()
+                    staged_backward(loss, phase, dp, stage1, between=between, exchange=lambda ranges: None)
+                else:
+                    stage1()
+                    end(None)
+            except BaseException:
+                if cur.get('ctx') is not None and (not chain or chain[-1][0] is not cur['g']):
+                    cur['ctx'].__exit__(None, None, None)
+                raise
             phase.module.requires_grad_(False)
-            self.graphs.append(g)
+            self.graphs.append(chain)
 
     def run(self):
         if self.pre_graph is not None:
             self.pre_graph.replay()
-        for phase, g in zip(self.phases, self.graphs):
-            g.replay()
-            self.dp.apply(phase)
+        for phase, chain in zip(self.phases, self.graphs):
+            exchanged = False
+            for g, seg in chain:
+                g.replay()
+                if seg is not None:      # this stage's gradient segment is complete: reduce it while the next graph computes
+                    for lo, hi in seg:
+                        self.dp.exchange_async(phase.fm.gflat, lo, hi)
+                    exchanged = True
+            self.dp.apply(phase, exchanged=exchanged)
         if self.ema is not None:
             self.ema.update(self.batch_size, self.ema_kimg, self.cur_nimg)
         if self.batch_size:

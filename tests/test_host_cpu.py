@@ -147,7 +147,11 @@ def _dp_worker(rank, world, port, q):
         local[7] = -float('inf')
     fm.gflat.copy_(local)
     dp = DataParallelStep(world_size=world, bucket_bytes=64)   # 16-float buckets: exercises the bucket loop
-    dp.exchange(fm.gflat)
+    # segment by segment, as the staged backward hands the flat gradient over (training_loop.staged_backward): last segment first
+    cuts = [0, 11, 30, fm.total]
+    for lo, hi in reversed(list(zip(cuts[:-1], cuts[1:]))):
+        dp.exchange_async(fm.gflat, lo, hi)
+    dp.finish()
     # expected: sum over ranks; the /world + nan_to_num that the fused Adam kernel applies is checked through the oracle
     parts = [torch.randn(fm.total, generator=torch.Generator().manual_seed(100 + r)) for r in range(world)]
     parts[0][3] = float('nan'); parts[0][5] = float('inf'); parts[1][7] = -float('inf')

@@ -462,6 +462,21 @@ def test_adam_sanitize_ema(dev):
     gbad = torch.tensor([float('nan'), float('inf'), -float('inf'), 2.0, -4.0] * 3, device=dev)
     core.check(core.lib().ldetr_grad_sanitize_f32(core.ptr(gbad), gbad.numel(), 0.5, 0.0, 1e5, -1e5, core.stream()))
     assert gbad.cpu().tolist() == [0.0, 1e5, -1e5, 1.0, -2.0] * 3
+    # the data-parallel form: `/world` and nan_to_num(0, 1e5, -1e5) fused into the Adam pass (fuse_sanitize=1, gscale=1/world) on a
+    # gradient that holds NaN / +-Inf, as the SUM all-reduce of two ranks can (training_loop.py:306-309 then :313)
+    from oracle import losses_ref
+    world = 2
+    gsum = torch.randn(n) * 3
+    gsum[5] = float('nan'); gsum[77] = float('inf'); gsum[1000] = -float('inf'); gsum[-1] = float('nan')
+    g_ref = losses_ref.dp_postprocess(gsum.clone(), world)          # golden-pinned restatement of the reference's post-processing
+    pr2 = p0.clone().requires_grad_(True); opt2 = torch.optim.Adam([pr2], lr=1e-3, betas=(0.0, 0.99), eps=1e-8)
+    pr2.grad = g_ref.clone(); opt2.step()
+    pg2 = p0.to(dev); m2 = torch.zeros(n, device=dev); v2 = torch.zeros(n, device=dev); gd = gsum.to(dev)
+    core.check(core.lib().ldetr_adam_step_f32(core.ptr(pg2), core.ptr(gd), core.ptr(m2), core.ptr(v2), n, 1, 1e-3, 0.0, 0.99, 1e-8,
+                                              1, 1.0 / world, 0.0, 1e5, -1e5, core.stream()))
+    assert torch.isfinite(pg2).all() and torch.isfinite(v2).all()
+    assert_close(pg2, pr2, 1e-6, 'adam fused sanitize')
+    assert_close(m2, g_ref, 1e-6, 'first moment = sanitized gradient (beta1 = 0)')
     pe = torch.randn(n); pe_g = pe.to(dev)
     core.check(core.lib().ldetr_ema_lerp_f32(core.ptr(pe_g), core.ptr(pg), n, 0.9, core.stream()))
     assert_close(pe_g, pg.cpu().lerp(pe, 0.9), 1e-6, 'ema')
