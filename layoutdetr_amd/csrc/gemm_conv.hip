@@ -92,6 +92,7 @@ struct GemmParams {
     int* ws_count;       //   per-tile arrival counters (zero between launches)
     const float* a_mask; float a_mask_gain;   // small-tile kernels: A element := mask > 0 ? A * gain : 0 (ReLU gradient folded into the dY loads)
     long long* trace;    // development aid (tools/trace_tiles.py): 4 wall-clock stamps per block, or null
+    int narrow;          // host: the 256x32 tile was chosen (lets one-k-tile-per-tap channel counts take the scalar-addressed loads)
     GemmEpilogue ep;
 };
 
@@ -363,7 +364,7 @@ __device__ __forceinline__ float apply_epilogue(const GemmEpilogue& ep, float v,
 template <int BM, int BN, int BKT, int AMODE, int BMODE, int NWV, bool FAST>
 __global__ __launch_bounds__(NWV * 64) void gemm_f32_kernel(GemmParams p) {
     constexpr int NT = NWV * 64;
-    constexpr int WGN = (NWV == 8 && BN >= 128) ? 4 : 2, WGM = NWV / WGN;
+    constexpr int WGN = BN == 32 ? 1 : ((NWV == 8 && BN >= 128) ? 4 : 2), WGM = NWV / WGN;   // BN == 32: all waves along M (narrow-N tile)
     constexpr bool A_KC = AMODE <= OP_KC_WTAP;
     constexpr bool B_KC = BMODE <= OP_KC_WTAP;
     constexpr int LDA = BM + 2, LDB = BN + 2;
@@ -1454,7 +1455,8 @@ static bool fast_operands_ok(const GemmParams& p, int Mmax) {
     if (!a_cap && !b_cap) return false;
     const long lim = 0x7fffffffL;
     auto taps_ok = [&](int C, int KH, int KW) {   // a k-tile never straddles a tap (C == k-tile measured slower: 483 vs 420 us on the 32-channel 256^2 layer)
-        return C > 0 && (C % BKT) == 0 && C >= 2 * BKT && (long)KH * KW <= 32 && p.samp_pix == 0;
+        static const int c32 = getenv("LDETR_NARROW_FAST") ? atoi(getenv("LDETR_NARROW_FAST")) : 1;
+        return C > 0 && (C % BKT) == 0 && C >= ((p.narrow && c32) ? BKT : 2 * BKT) && (long)KH * KW <= 32 && p.samp_pix == 0;
     };
     if (AMODE == OP_KC_CONV) {
         const long padoff = (long)p.A.pad * p.A.sh + (long)p.A.pad * p.A.sw;
@@ -1562,6 +1564,16 @@ static int launch_gemm(GemmParams& p, int Mmax, long out_rows, int zbase, bool a
             if (fs) { int s2 = fs; while (s2 > 1 && p.K / s2 < 64) s2--; p.splitk = (p.ep.accumulate && !epilogue_is_linear(p.ep)) ? 1 : s2; }
         }
     }
+    // Narrow outputs (N <= 32: the 32-channel 256^2 StyleGAN2 layers): a 64-wide tile leaves half of every MFMA's columns empty.
+    // 256 x 32 tile, four waves stacked along M (each 64 x 32: two accumulator chains, 1.5 LDS operand reads per MFMA).
+    constexpr bool narrow_cap = (AMODE == OP_KC_CONV || AMODE == OP_KC_CONVT) && (BMODE == OP_KC_DENSE || BMODE == OP_RC_WT || BMODE == OP_KC_WTAP);
+    static const int narrow_on = getenv("LDETR_NARROW_TILE") ? atoi(getenv("LDETR_NARROW_TILE")) : 1;
+    bool use_narrow = false;
+    if constexpr (narrow_cap) {
+        if (narrow_on && p.N <= 32 && p.N % 4 == 0 && p.splitk <= 1 && (long)cdiv(Mmax, 256) * zbase >= 512) {
+            use_narrow = true; use128 = use12864 = false; p.narrow = 1;
+        }
+    }
     GemmEpilogue full = p.ep;
     const bool split = p.splitk > 1;
     bool fixup = false;
@@ -1595,6 +1607,9 @@ static int launch_gemm(GemmParams& p, int Mmax, long out_rows, int zbase, bool a
     }
     dim3 grid(cdiv(p.N, use128 ? 128 : 64), cdiv(Mmax, (use128 || use12864) ? 128 : 64), zbase * (split ? p.splitk : 1));
     int rc;
+    if constexpr (narrow_cap) {
+        if (use_narrow) return launch_tile<256, 32, 32, AMODE, BMODE, 4>(p, dim3(1, cdiv(Mmax, 256), zbase), Mmax, st);
+    }
     if (use128) rc = launch_tile<128, 128, T128_BK, AMODE, BMODE, T128_WAVES>(p, grid, Mmax, st);
     else if (use12864) rc = launch_tile<128, 64, T12864_BK, AMODE, BMODE, T12864_WAVES>(p, grid, Mmax, st);
     else rc = launch_tile<64, 64, 32, AMODE, BMODE>(p, grid, Mmax, st);

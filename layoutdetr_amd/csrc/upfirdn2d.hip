@@ -139,6 +139,82 @@ __global__ __launch_bounds__(256) void upfirdn2d_nhwc4_kernel(UpfirdnParams p) {
     }
 }
 
+// The StyleGAN2 up-layer FIR (upfirdn2d.py:191-198 with up = down = 1, 4x4 taps; forward pad [1,1,1,1] on the (2r+1)^2 transposed-conv
+// output, backward pad [2,2,2,2] on the (2r)^2 gradient), channels_last.  HBM-bound: 8 bytes per output element.
+// One thread = 4 channels x TC output columns x TR output rows: the 4-row x (TC+3)-column input window lives in registers and slides
+// down the strip, so each input float4 is requested (TC+3)(TR+3)/(TC*TR) ~ 2x per output instead of 16x (the generic kernel's
+// one-output-per-thread form saturates the vector L1 at 1.7 TB/s); lanes run along channels, then column blocks: every request is a
+// fully used 64..128-byte segment.
+template <int TC, int TR>
+__global__ __launch_bounds__(256) void fir4x4_nhwc4_kernel(UpfirdnParams p) {
+    __shared__ float fl[16];
+    if (threadIdx.x < 16) {
+        int ky = threadIdx.x >> 2, kx = threadIdx.x & 3;
+        // tap applied to the input sample at window offset (jy, jx): f[3-jy][3-jx], or f[jy][jx] when flipped (see the generic kernel)
+        int sy = p.flip ? ky : 3 - ky, sx = p.flip ? kx : 3 - kx;
+        fl[threadIdx.x] = p.f[sx * p.fs_w + sy * p.fs_h] * p.gain;
+    }
+    __syncthreads();
+    float ft[4][4];
+#pragma unroll
+    for (int i = 0; i < 16; i++) ft[i >> 2][i & 3] = fl[i];
+    const int C4 = p.C >> 2;
+    const int XB = (p.outW + TC - 1) / TC, YB = (p.outH + TR - 1) / TR;
+    const long total = (long)p.N * YB * XB * C4;
+    long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int c = (int)(idx % C4) << 2;
+    long t = idx / C4;
+    const int x0 = (int)(t % XB) * TC;
+    t /= XB;
+    const int y0 = (int)(t % YB) * TR;
+    const int n = (int)(t / YB);
+    const float* xb = p.x + c + n * p.xs_n;
+    float* yb = p.y + c + n * p.ys_n;
+    const int ix0 = x0 - p.padx0, iy0 = y0 - p.pady0;
+    bool colok[TC + 3];
+#pragma unroll
+    for (int j = 0; j < TC + 3; j++) colok[j] = (unsigned)(ix0 + j) < (unsigned)p.inW;
+    float4 win[4][TC + 3];
+    auto load_row = [&](int slot, int iy) {
+        const bool rowok = (unsigned)iy < (unsigned)p.inH;
+        const float* rp = xb + (long)iy * p.xs_h + (long)ix0 * p.xs_w;
+#pragma unroll
+        for (int j = 0; j < TC + 3; j++)
+            win[slot][j] = (rowok && colok[j]) ? *reinterpret_cast<const float4*>(rp + j * p.xs_w) : make_float4(0.f, 0.f, 0.f, 0.f);
+    };
+#pragma unroll
+    for (int r = 0; r < 3; r++) load_row(r, iy0 + r);
+    float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (p.has_act && p.bias) bias4 = *reinterpret_cast<const float4*>(p.bias + c);
+#pragma unroll
+    for (int oy = 0; oy < TR; oy++) {
+        load_row((oy + 3) & 3, iy0 + oy + 3);
+        if (y0 + oy < p.outH) {
+#pragma unroll
+            for (int ox = 0; ox < TC; ox++) {
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                for (int jy = 0; jy < 4; jy++) {
+#pragma unroll
+                    for (int jx = 0; jx < 4; jx++) {
+                        const float4 xv = win[(oy + jy) & 3][ox + jx];
+                        const float fv = ft[jy][jx];
+                        v.x = fmaf(xv.x, fv, v.x); v.y = fmaf(xv.y, fv, v.y); v.z = fmaf(xv.z, fv, v.z); v.w = fmaf(xv.w, fv, v.w);
+                    }
+                }
+                if (p.has_act) {
+                    v.x += bias4.x; v.y += bias4.y; v.z += bias4.z; v.w += bias4.w;
+                    v.x = (v.x > 0.f ? v.x : v.x * p.act_alpha) * p.act_gain; v.y = (v.y > 0.f ? v.y : v.y * p.act_alpha) * p.act_gain;
+                    v.z = (v.z > 0.f ? v.z : v.z * p.act_alpha) * p.act_gain; v.w = (v.w > 0.f ? v.w : v.w * p.act_alpha) * p.act_gain;
+                }
+                if (x0 + ox < p.outW)
+                    *reinterpret_cast<float4*>(yb + (long)(y0 + oy) * p.ys_h + (long)(x0 + ox) * p.ys_w) = v;
+            }
+        }
+    }
+}
+
 }  // namespace ldetr
 
 extern "C" int ldetr_upfirdn2d_f32(const float* x, const float* f, float* y,
@@ -177,7 +253,16 @@ extern "C" int ldetr_upfirdn2d_f32(const float* x, const float* f, float* y,
     long total = nhwc4 ? (long)N * outH * outW * (C / 4) : (long)N * C * outH * outW;
     int grid = (int)((total + 255) / 256);
     if (grid > 256 * 32) grid = 256 * 32;
-    if (nhwc4) hipLaunchKernelGGL(upfirdn2d_nhwc4_kernel, grid, 256, 0, st, p);
+    static const int fir_mode = getenv("LDETR_FIR_TILED") ? atoi(getenv("LDETR_FIR_TILED")) : 1;   // 0: generic kernel everywhere (development switch)
+    if (nhwc4 && fir_mode && upx == 1 && upy == 1 && downx == 1 && downy == 1 && fw == 4 && fh == 4 && (long)outH * outW >= 64) {
+        // register-tiled sliding-window form: 4 columns x 16 rows per thread on the large layers, 2 x 4 where threads are scarce
+        const bool big = (long)N * outH * outW * (C / 4) >= (1L << 20);
+        const int TC = big ? 4 : 2, TR = big ? 16 : 4;
+        long threads = (long)N * ((outH + TR - 1) / TR) * ((outW + TC - 1) / TC) * (C / 4);
+        int g = (int)((threads + 255) / 256);
+        if (big) hipLaunchKernelGGL((fir4x4_nhwc4_kernel<4, 16>), g, 256, 0, st, p);
+        else hipLaunchKernelGGL((fir4x4_nhwc4_kernel<2, 4>), g, 256, 0, st, p);
+    } else if (nhwc4) hipLaunchKernelGGL(upfirdn2d_nhwc4_kernel, grid, 256, 0, st, p);
     else hipLaunchKernelGGL(upfirdn2d_planar_kernel, grid, 256, 0, st, p);
     return check_launch("upfirdn2d");
 }

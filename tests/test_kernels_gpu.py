@@ -108,6 +108,29 @@ def test_upfirdn2d(dev, case, layout):
     assert_close(y, yr, 3e-6, 'y'); assert_close(xg.grad, xr.grad, 3e-6, 'dx')
 
 
+@pytest.mark.parametrize('pad,flip', [([1, 1, 1, 1], False), ([2, 2, 2, 2], True), ([3, 0, -1, 2], False)])
+@pytest.mark.parametrize('shape', [(4, 32, 257, 131), (2, 64, 33, 35)])
+def test_upfirdn2d_up_layer_fir_register_tiled(dev, pad, flip, shape):
+    """The StyleGAN2 up-layer FIR (up = down = 1, 4x4 taps, channels_last) on the sliding-window kernel, both tile shapes
+    (4 columns x 16 rows / 2 x 4), ragged right / bottom edges, the backward's pads and flipped taps, cropping pads, and the fused
+    bias + lrelu epilogue — against the golden-pinned oracle."""
+    from layoutdetr_amd.torch_utils.ops import upfirdn2d
+    torch.manual_seed(5)
+    x = torch.randn(*shape)
+    f = ops_ref.setup_filter([1, 3, 3, 1]) + 0.01 * torch.arange(16.).reshape(4, 4)
+    xr = x.clone().requires_grad_(True)
+    yr = ops_ref.upfirdn2d(xr, f, padding=pad, gain=4.0, flip_filter=flip)
+    g = torch.randn_like(yr); yr.backward(g)
+    xg = x.to(dev).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    y = upfirdn2d.upfirdn2d(xg, f.to(dev), padding=pad, gain=4.0, flip_filter=flip)
+    assert y.shape == yr.shape and y.is_contiguous(memory_format=torch.channels_last)
+    y.backward(g.to(dev))
+    assert_close(y, yr, 3e-6, 'y'); assert_close(xg.grad, xr.grad, 3e-6, 'dx')
+    b = torch.randn(shape[1])
+    ya = upfirdn2d._kernel_call(xg.detach(), f.to(dev), 1, 1, 1, 1, *pad, flip, 4.0, act_bias=b.to(dev), act=(0.2, 2 ** 0.5))
+    assert_close(ya, torch.nn.functional.leaky_relu(yr.detach() + b.view(1, -1, 1, 1), 0.2) * 2 ** 0.5, 3e-6, 'fused bias+lrelu')
+
+
 def test_upfirdn2d_separable_and_helpers(dev):
     from layoutdetr_amd.torch_utils.ops import upfirdn2d
     torch.manual_seed(3)
@@ -301,6 +324,11 @@ CONV_CASES = [
     (2, 32, 32, 96, 64, 3, 2, 1),
     (3, 8, 4, 128, 128, 3, 1, 1),
     (2, 16, 16, 80, 64, 3, 1, 1),
+    # narrow outputs on many pixels: the 256x32 tile (Cout <= 32 forward, Cin <= 32 data gradient), ragged last tile, stride 2, 24 channels
+    (2, 256, 257, 32, 32, 3, 1, 1),
+    (3, 212, 208, 64, 32, 3, 1, 1),
+    (2, 300, 300, 32, 64, 3, 2, 1),
+    (2, 256, 256, 24, 24, 3, 1, 1),
 ]
 
 

@@ -60,6 +60,8 @@ def main():
              ('sg 3x3 64->64 @128', B, 128, 64, 64, 3, 1, 1), ('sg 3x3 32->32 @256', B, 256, 32, 32, 3, 1, 1)]
     if os.environ.get('LDETR_BENCH_GEMM_ONLY'):
         cases = []
+    if os.environ.get('LDETR_BENCH_ONLY'):
+        cases = [c for c in cases if c[0].startswith(os.environ['LDETR_BENCH_ONLY'])]
     for c in cases:
         conv_case(*c)
     if os.environ.get('LDETR_BENCH_CONV_ONLY'):
