@@ -67,7 +67,7 @@ class _ConvFn(torch.autograd.Function):
         O, KH, KW, _ = w.shape
         dy = core.f32c(dy)
         _, OH, OW, _ = dy.shape
-        need_x, need_w = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        need_x, need_w = ctx.needs_input_grad[0], ctx.needs_input_grad[1] and not core.WEIGHT_GRADIENTS_DISABLED[0]
         need_shift = has_shift and ctx.needs_input_grad[3]
         need_res = has_res and ctx.needs_input_grad[4]
         dy2 = dy.reshape(-1, O)
@@ -171,3 +171,49 @@ class _MaxPoolFn(torch.autograd.Function):
 
 def maxpool3x3s2_nhwc(x):
     return _MaxPoolFn.apply(x)
+
+
+class _ConvTransposeFn(torch.autograd.Function):
+    """y[n,oh,ow,co] = sum x[n,ih,iw,ci] * w[co,kh,kw,ci],  oh = ih*stride + kh - pad  (F.conv_transpose2d with the weight given
+    un-transposed, OHWI): the plain (unmodulated) form behind torch_utils.ops.conv2d_gradfix.conv_transpose2d."""
+
+    @staticmethod
+    def forward(ctx, x, w_ohwi, stride, pad):
+        core.require_gpu(x, w_ohwi)
+        x = core.f32c(x); w = core.f32c(w_ohwi)
+        N, H, W, I = x.shape
+        O, KH, KW, _ = w.shape
+        if I % 4 != 0:
+            raise NotImplementedError('conv_transpose2d: input channel count must be a multiple of 4 on the gfx950 path')
+        OH, OW = (H - 1) * stride - 2 * pad + KH, (W - 1) * stride - 2 * pad + KW
+        y = torch.empty((N, OH, OW, O), device=x.device, dtype=torch.float32)
+        xt = core.tensor4_nhwc(x)
+        core.engine_call('ldetr_conv_transpose2d_fwd_f32', 2.0 * N * H * W * O * KH * KW * I, lambda: core.check(core.lib().ldetr_conv_transpose2d_fwd_f32(
+            core.ptr(x), ctypes.byref(xt), core.ptr(w), O, KH, KW, stride, pad, core.ptr(y), O, OH, OW, None, 0, None, core.stream()), 'conv_transpose2d_fwd'))
+        ctx.save_for_backward(x, w)
+        ctx.cfg = (stride, pad)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        stride, pad = ctx.cfg
+        N, H, W, I = x.shape
+        O, KH, KW, _ = w.shape
+        dy = core.f32c(dy)
+        dyt = core.tensor4_nhwc(dy)
+        dx = dw = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            core.engine_call('ldetr_conv_transpose2d_bwd_data_f32', 2.0 * N * H * W * O * KH * KW * I, lambda: core.check(core.lib().ldetr_conv_transpose2d_bwd_data_f32(
+                core.ptr(dy), ctypes.byref(dyt), core.ptr(w), I, KH, KW, stride, pad, core.ptr(dx), I, H, W, None, 0, None, core.stream()), 'conv_transpose2d_bwd_data'))
+        if ctx.needs_input_grad[1] and not core.WEIGHT_GRADIENTS_DISABLED[0]:
+            dw = torch.empty_like(w)
+            xt = core.tensor4_nhwc(x)
+            core.engine_call('ldetr_conv_transpose2d_bwd_weight_f32', 2.0 * N * H * W * O * KH * KW * I, lambda: core.check(core.lib().ldetr_conv_transpose2d_bwd_weight_f32(
+                core.ptr(x), ctypes.byref(xt), core.ptr(dy), ctypes.byref(dyt), core.ptr(dw), KH, KW, stride, pad, 0, None, 0, None, 0, 0, core.stream()), 'conv_transpose2d_bwd_weight'))
+        return dx, dw, None, None
+
+
+def conv_transpose2d_nhwc(x, w_ohwi, stride=1, pad=0):
+    return _ConvTransposeFn.apply(x, w_ohwi, stride, pad)

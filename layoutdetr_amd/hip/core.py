@@ -11,6 +11,9 @@ ACT_NONE, ACT_RELU, ACT_LRELU = 0, 1, 2
 
 _seed_counter = [0x5EED]
 
+# torch_utils.ops.conv2d_gradfix.no_weight_gradients(): weight gradients of the conv Functions are skipped while this is set
+WEIGHT_GRADIENTS_DISABLED = [False]
+
 
 class _EngineProfile(object):
     """Optional per-launch accounting of the f32-MFMA contraction engine (bench.py roofline leg): HIP events are

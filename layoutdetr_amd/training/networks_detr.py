@@ -10,8 +10,9 @@ Text path (SURVEY §8a rows a16/a17 are *boundary inputs*, not kernel rows): `bb
   * a `TextTokens` carrying the tokenizer's output (`input_ids`, `attention_mask` [B, N, T]) and the character counts —
     requires `text_mode='encoder'`: the frozen BERT text encoder (training/med.py) then runs on the HIP
     kernels inside forward(), exactly where the reference calls it (networks_detr.py:145-147, 289-291).
-Strings are not accepted: tokenisation is host-side work outside this package (the reference's `init_tokenizer` needs the
-`bert-base-uncased` vocabulary).  `text_mode='encoder+lm'` additionally builds the trainable LM text decoder
+  * the reference's own form, a list (batch) of lists (elements) of strings (networks_detr.py:145), when the module was built with
+    `tokenizer_vocab=<path to bert-base-uncased vocab.txt>` (or LDETR_BERT_VOCAB is set): training/tokenizer.py (host-side WordPiece,
+    id-for-id equal to transformers.BertTokenizer, no download) turns them into `TextTokens`; needs text_mode 'encoder' / 'encoder+lm'.  `text_mode='encoder+lm'` additionally builds the trainable LM text decoder
 (`text_decoder`, training/med.py BertLMHeadModel) and returns its label-smoothed next-token loss as `loss_lm`; in the other
 modes `loss_lm` is a zero tensor.
 
@@ -176,6 +177,28 @@ class MLP(nn.Module):
         return x
 
 
+def _build_tokenizer(tokenizer_vocab):
+    import os
+    path = tokenizer_vocab or os.environ.get('LDETR_BERT_VOCAB')
+    if not path:
+        return None
+    from .tokenizer import BertWordPieceTokenizer
+    return BertWordPieceTokenizer(path)
+
+
+def _coerce_text(module, bbox_text, device):
+    """strings (the reference's input form) -> TextTokens through the module's host tokenizer; other forms pass through."""
+    if isinstance(bbox_text, (list, tuple)) and len(bbox_text) and isinstance(bbox_text[0], (list, tuple)):
+        if module.tokenizer is None:
+            raise NotImplementedError('bbox_text strings need the BERT vocabulary: construct the module with tokenizer_vocab=<vocab.txt> '
+                                      '(or set LDETR_BERT_VOCAB), or pass TextTokens / TextFeatures')
+        if module.text_mode == 'features':
+            raise NotImplementedError("bbox_text strings need the text encoder: construct the module with text_mode='encoder' (or 'encoder+lm')")
+        from .tokenizer import texts_to_tokens
+        return texts_to_tokens(module.tokenizer, bbox_text, module.max_text_length, device)
+    return bbox_text
+
+
 def _text_inputs(module, bbox_text, B, N, device):
     if isinstance(bbox_text, TextFeatures):
         return bbox_text.text_feat.to(device=device, dtype=torch.float32), bbox_text.text_len.to(device=device, dtype=torch.int64)
@@ -195,9 +218,10 @@ class Generator(nn.Module):
     def __init__(self, z_dim, num_bbox_labels, img_channels, img_height, img_width, c_dim,
                  f_dim=256, num_heads=4, num_layers=8, hidden_dim=256,
                  med_config='configs/med_config.json', bert_f_dim=768, bert_num_encoder_layers=12, bert_num_decoder_layers=12,
-                 bert_num_heads=12, background_size=1024, im_f_dim=512, max_text_length=256, text_mode='features'):
+                 bert_num_heads=12, background_size=1024, im_f_dim=512, max_text_length=256, text_mode='features', tokenizer_vocab=None):
         super().__init__()
         self.z_dim = z_dim
+        self.tokenizer = _build_tokenizer(tokenizer_vocab)
         self.num_bbox_labels = num_bbox_labels
         self.c_dim = c_dim
         self.max_text_length = max_text_length
@@ -228,6 +252,7 @@ class Generator(nn.Module):
         assert mask is not None
 
         B, N = bbox_patch.shape[0], bbox_patch.shape[1]
+        bbox_text = _coerce_text(self, bbox_text, bbox_class.device)
         z0 = normalize_2nd_moment(z.view(B, -1))
         zf = self.fc_z(z0).unsqueeze(1).expand(-1, N, -1)
         l = self.emb_label(bbox_class)
@@ -267,8 +292,9 @@ class Discriminator(nn.Module):
     def __init__(self, num_bbox_labels, img_channels, img_height, img_width, c_dim,
                  f_dim=256, num_heads=4, num_layers=8, max_bbox=50, hidden_dim=256,
                  med_config='configs/med_config.json', bert_f_dim=768, bert_num_encoder_layers=12, bert_num_decoder_layers=12,
-                 bert_num_heads=12, background_size=1024, im_f_dim=512, max_text_length=256, text_mode='features'):
+                 bert_num_heads=12, background_size=1024, im_f_dim=512, max_text_length=256, text_mode='features', tokenizer_vocab=None):
         super().__init__()
+        self.tokenizer = _build_tokenizer(tokenizer_vocab)
         self.num_bbox_labels = num_bbox_labels
         self.c_dim = c_dim
         self.max_text_length = max_text_length
@@ -326,6 +352,7 @@ class Discriminator(nn.Module):
         assert mask is not None
 
         B, N = bbox_patch.shape[0], bbox_patch.shape[1]
+        bbox_text = _coerce_text(self, bbox_text, bbox_class.device)
         b = self.fc_bbox(bbox)
         l = self.emb_label(bbox_class)
         text_feat, text_len = _text_inputs(self, bbox_text, B, N, bbox_class.device)

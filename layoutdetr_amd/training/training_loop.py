@@ -377,3 +377,126 @@ class GraphedIteration(object):
             self.ema.update(self.batch_size, self.ema_kimg, self.cur_nimg)
         if self.batch_size:
             self.cur_nimg += self.batch_size
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# training_loop(): the reference's entry point (training/training_loop.py:63-100), same keyword arguments, driving the step above.
+
+def construct_class_by_name(*args, class_name=None, **kwargs):
+    """dnnlib.util.construct_class_by_name (dnnlib/util.py:302-304): 'pkg.module.Class' -> Class(*args, **kwargs)."""
+    import importlib
+    mod, _, name = class_name.rpartition('.')
+    return getattr(importlib.import_module(mod), name)(*args, **kwargs)
+
+
+class InfiniteSampler(torch.utils.data.Sampler):
+    """torch_utils/misc.py:118-150: an endless shuffled index stream; rank r takes every index whose position is r mod W."""
+
+    def __init__(self, dataset, rank=0, num_replicas=1, shuffle=True, seed=0, window_size=0.5):
+        self.n, self.rank, self.world, self.shuffle, self.seed, self.window = len(dataset), rank, num_replicas, shuffle, seed, window_size
+
+    def __iter__(self):
+        order = np.arange(self.n)
+        rnd, window = None, 0
+        if self.shuffle:
+            rnd = np.random.RandomState(self.seed)
+            rnd.shuffle(order)
+            window = int(np.rint(order.size * self.window))
+        idx = 0
+        while True:
+            i = idx % order.size
+            if idx % self.world == self.rank:
+                yield order[i]
+            if window >= 2:
+                j = (i - rnd.randint(window)) % order.size
+                order[i], order[j] = order[j], order[i]
+            idx += 1
+
+
+def training_loop(run_dir='.', training_set_kwargs={}, validation_set_kwargs={}, data_loader_kwargs={}, G_kwargs={}, D_kwargs={},
+                  G_opt_kwargs={}, D_opt_kwargs={}, augment_kwargs=None, loss_kwargs={}, metrics=[], random_seed=0, num_gpus=1, rank=0,
+                  batch_size=4, batch_gpu=4, ema_kimg=10, ema_rampup=0.05, G_reg_interval=None, D_reg_interval=16, augment_p=0,
+                  ada_target=None, ada_interval=4, ada_kimg=500, total_kimg=25000, kimg_per_tick=4, image_snapshot_ticks=50,
+                  network_snapshot_ticks=50, resume_pkl=None, resume_kimg=0, cudnn_benchmark=True, abort_fn=None, progress_fn=None):
+    """Same keyword arguments as the reference's `training_loop` (train.py:47 calls it with `**c`), so `train.py` drives this one
+    unchanged (through layoutdetr_amd.dropin.install() or by importing it).  What it runs: dataset + DataLoader + InfiniteSampler
+    exactly as :112-118, networks / loss by class name (:127-135,158), then per iteration the flat-parameter step of this module
+    (phases Gmain / Dmain; the reg phases are no-ops at r1_gamma = pl_weight = 0, which is all `train.py` configures: :135-136).
+    Out of this path's scope and therefore NOT done here (a note is printed): augment pipe, ADA, image / network snapshots, metric
+    evaluation, tensorboard — SURVEY §8 marks them outside the hot path.  Returns dict(stats of the last tick, G, D, G_ema)."""
+    import time
+    assert augment_kwargs is None and ada_target is None, 'the augment pipe / ADA are not part of the hot path'
+    device = torch.device('cuda', rank)
+    torch.cuda.set_device(device)
+    np.random.seed(random_seed * num_gpus + rank)
+    torch.manual_seed(random_seed * num_gpus + rank)
+    if rank == 0:
+        print('Loading training set...')
+    training_set = construct_class_by_name(**training_set_kwargs)
+    sampler = InfiniteSampler(dataset=training_set, rank=rank, num_replicas=num_gpus, seed=random_seed)
+    it = iter(torch.utils.data.DataLoader(dataset=training_set, sampler=sampler, batch_size=batch_size // num_gpus, **data_loader_kwargs))
+    common = dict(num_bbox_labels=training_set.num_bbox_labels, img_channels=training_set.num_channels, img_height=training_set.height,
+                  img_width=training_set.width, background_size=training_set.background_size_for_training, c_dim=training_set.label_dim)
+    if rank == 0:
+        print('Constructing networks...')
+    G = construct_class_by_name(**G_kwargs, **common).train().requires_grad_(False).to(device)
+    D = construct_class_by_name(**D_kwargs, **common).train().requires_grad_(False).to(device)
+    if num_gpus > 1:
+        for module in (G, D):
+            broadcast_module(module, src=0)          # :176-179
+    G_ema = copy.deepcopy(G).eval()
+    stats = {}
+
+    def report(name, value):
+        stats.setdefault(name, []).append(value.detach().float().mean())
+    lk = dict(loss_kwargs)
+    loss = construct_class_by_name(device=device, G=G, D=D, augment_pipe=None, report_fn=report, **lk)
+    phases = []
+    for name, module, opt, reg in (('G', G, G_opt_kwargs, G_reg_interval), ('D', D, D_opt_kwargs, D_reg_interval)):
+        opt = dict(opt)
+        opt.pop('class_name', None)                   # torch.optim.Adam in the reference; the fused Adam kernel here
+        phases.append(Phase(name + ('both' if reg is None else 'main'), module, lr=opt.get('lr', 1e-3), betas=tuple(opt.get('betas', (0.9, 0.999))),
+                            eps=opt.get('eps', 1e-8), reg_interval=reg))
+    dp = DataParallelStep(world_size=num_gpus)
+    ema = EmaTracker(phases[0], G_ema)
+    if rank == 0:
+        print('Not run on this path: augment pipe, ADA, image/network snapshots, metrics (outside the hot path)')
+        print(f'Training for {total_kimg} kimg...')
+    cur_nimg, cur_tick, tick_start_nimg, tick_start = resume_kimg * 1000, 0, resume_kimg * 1000, time.time()
+    if progress_fn is not None:
+        progress_fn(0, total_kimg)
+    last = {}
+    while True:
+        samples, real_c = next(it)
+        texts = list(map(list, zip(*samples['texts']))) if isinstance(samples.get('texts'), (list, tuple)) else samples['texts']   # :246
+        b = samples['bboxes'].shape[0]
+        if isinstance(texts, list):     # strings -> tokens ONCE per iteration (the reference re-tokenises inside each of the 5 G/D forwards)
+            from .networks_detr import _coerce_text
+            texts = _coerce_text(G, texts, device)
+        batch = dict(bbox_real=samples['bboxes'].to(device).float(), bbox_class=samples['labels'].to(device).long(), bbox_text=texts,
+                     bbox_patch=samples['patches'].to(device), padding_mask=~samples['mask'].to(device).bool(),
+                     background=samples['background'].to(device).float(), real_c=real_c.to(device))
+        batch['gen_c'] = torch.zeros_like(batch['real_c'])
+        gen_z = [torch.randn(b, batch['bbox_class'].shape[1], G.z_dim, device=device) for _ in phases]
+        training_iteration(loss, phases, dp, batch, batch_gpu, gen_z, ema=ema, batch_size=batch_size, ema_kimg=ema_kimg, cur_nimg=cur_nimg)
+        cur_nimg += batch_size
+        done = cur_nimg >= total_kimg * 1000
+        if not done and cur_tick != 0 and cur_nimg < tick_start_nimg + kimg_per_tick * 1000:
+            continue
+        torch.cuda.synchronize()
+        now = time.time()
+        last = {k: torch.stack(v).mean().item() for k, v in stats.items()}
+        stats.clear()
+        if rank == 0:
+            print(f'tick {cur_tick:<5d} kimg {cur_nimg / 1e3:<8.1f} sec/kimg {(now - tick_start) / max(cur_nimg - tick_start_nimg, 1) * 1e3:<7.2f} ' +
+                  ' '.join(f'{k.split("/")[-1]} {v:.3f}' for k, v in sorted(last.items()) if k.startswith('Loss/scores')))
+        if abort_fn is not None and abort_fn():
+            done = True
+        cur_tick += 1
+        tick_start_nimg, tick_start = cur_nimg, time.time()
+        if progress_fn is not None:
+            progress_fn(cur_nimg // 1000, total_kimg)
+        if done:
+            break
+    last['cur_nimg'] = cur_nimg
+    return dict(stats=last, G=G, D=D, G_ema=G_ema)

@@ -1,0 +1,148 @@
+"""Drop-in boundary on the GPU: the seam-2 wrappers with the reference's signatures (conv2d_resample, conv2d_gradfix),
+the pybind-shaped plugin bindings a maintainer would add (layoutdetr_amd.dropin), and the seam-1 `training_loop(**c)` entry driven
+the way the reference's train.py drives it (class names, dataset object, strings as bbox_text)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import ops_ref
+
+pytestmark = pytest.mark.gpu
+G_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+
+
+def load(name):
+    d = np.load(os.path.join(G_DIR, name + '.npz'), allow_pickle=False)
+    return {k: torch.from_numpy(d[k]) for k in d.files if d[k].ndim > 0 or d[k].dtype.kind in 'fiub'}
+
+
+def close(a, b, tol, what=''):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    e = ((a - b).abs().max() / (b.abs().max() + 1e-12)).item()
+    assert e <= tol, f'{what}: rel err {e:.3e}'
+
+
+def test_conv2d_resample_matches_reference_golden_and_gradients(dev):
+    """All four branch families against vectors captured from the reference's conv2d_resample (ops.npz cr_*), gradients against
+    autograd through the golden-pinned oracle."""
+    from layoutdetr_amd.torch_utils.ops import conv2d_resample
+    d = load('ops')
+    f = d['f']
+    cases = [('cr_up2', 'cr_w3', dict(f=f, up=2, padding=1, flip_weight=False)), ('cr_up1', 'cr_w3', dict(f=f, up=1, padding=1, flip_weight=True)),
+             ('cr_1x1', 'cr_w1', dict(f=None, up=1, padding=0, flip_weight=True)), ('cr_down2', 'cr_w3', dict(f=f, down=2, padding=1))]
+    for key, wk, kw in cases:
+        x = d['cr_x'].to(dev).requires_grad_(True); w = d[wk].to(dev).requires_grad_(True)
+        kg = dict(kw); kg['f'] = None if kw['f'] is None else kw['f'].to(dev)
+        y = conv2d_resample.conv2d_resample(x, w, **kg)
+        close(y, d[key], 2e-5, key)
+        g = torch.randn(y.shape, generator=torch.Generator().manual_seed(3))
+        y.backward(g.to(dev))
+        xr = d['cr_x'].clone().requires_grad_(True); wr = d[wk].clone().requires_grad_(True)
+        yr = ops_ref.conv2d_resample(xr, wr, **{k: v for k, v in kw.items() if k != 'flip_filter'})
+        yr.backward(g)
+        close(x.grad, xr.grad, 3e-5, key + ' dx'); close(w.grad, wr.grad, 3e-5, key + ' dw')
+
+
+def test_conv2d_gradfix_surface(dev):
+    from layoutdetr_amd.torch_utils.ops import conv2d_gradfix
+    import torch.nn.functional as F
+    torch.manual_seed(1)
+    x = torch.randn(2, 8, 9, 7); w = torch.randn(12, 8, 3, 3) * 0.2; b = torch.randn(12); wt = torch.randn(8, 6, 3, 3) * 0.2
+    for fn, ref, wgt, kw in ((conv2d_gradfix.conv2d, F.conv2d, w, dict(stride=2, padding=1)), (conv2d_gradfix.conv2d, F.conv2d, w, dict(padding=[1, 1])),
+                             (conv2d_gradfix.conv_transpose2d, F.conv_transpose2d, wt, dict(stride=2, padding=1))):
+        bias = b[:wgt.shape[0] if fn is conv2d_gradfix.conv2d else wgt.shape[1]]
+        xr = x.clone().requires_grad_(True); wr = wgt.clone().requires_grad_(True); br = bias.clone().requires_grad_(True)
+        yr = ref(xr, wr, br, **kw); g = torch.randn_like(yr); yr.backward(g)
+        xg = x.to(dev).requires_grad_(True); wg = wgt.to(dev).requires_grad_(True); bg = bias.to(dev).requires_grad_(True)
+        y = fn(xg, wg, bg, **kw); y.backward(g.to(dev))
+        close(y, yr, 2e-5, 'y'); close(xg.grad, xr.grad, 3e-5, 'dx'); close(wg.grad, wr.grad, 3e-5, 'dw'); close(bg.grad, br.grad, 3e-5, 'db')
+    assert conv2d_gradfix.enabled is True
+    xg = x.to(dev).requires_grad_(True); wg = w.to(dev).requires_grad_(True)
+    with conv2d_gradfix.no_weight_gradients():
+        assert conv2d_gradfix.weight_gradients_disabled
+        conv2d_gradfix.conv2d(xg, wg, padding=1).sum().backward()
+    assert wg.grad is None and xg.grad is not None and not conv2d_gradfix.weight_gradients_disabled
+    with pytest.raises(NotImplementedError):
+        conv2d_gradfix.conv2d(xg, wg, groups=2)
+
+
+def test_plugin_bindings_with_the_pybind_argument_lists(dev):
+    """dropin.bias_act_plugin.bias_act(x, b, xref, yref, dy, grad, dim, act, alpha, gain, clamp) and
+    dropin.upfirdn2d_plugin.upfirdn2d(x, f, upx, upy, downx, downy, padx0, padx1, pady0, pady1, flip, gain): the calls the reference's
+    torch_utils/ops wrappers make (bias_act.py:140,178,199; upfirdn2d.py:238), empty tensor = absent, RuntimeError on bad arguments."""
+    from layoutdetr_amd import dropin
+    d = load('ops')
+    null = torch.empty([0], device=dev)
+    x = d['ba_x'].to(dev); b = d['ba_b'].to(dev)
+    y = dropin.bias_act_plugin.bias_act(x, b, null, null, null, 0, 1, 3, 0.2, 2 ** 0.5, -1.0)         # lrelu = cuda_idx 3
+    close(y, d['ba_lrelu_y'], 2e-6, 'bias_act fwd')
+    dy = torch.ones_like(y) * 0.5 + y * 0.1
+    dx = dropin.bias_act_plugin.bias_act(dy, b, x, y, null, 1, 1, 3, 0.2, 2 ** 0.5, -1.0)
+    close(dx, d['ba_lrelu_dx'], 2e-6, 'bias_act grad=1')
+    xcl = x.contiguous(memory_format=torch.channels_last)
+    ycl = dropin.bias_act_plugin.bias_act(xcl, b, null, null, null, 0, 1, 3, 0.2, 2 ** 0.5, -1.0)
+    assert ycl.is_contiguous(memory_format=torch.channels_last); close(ycl, d['ba_lrelu_y'], 2e-6, 'channels_last')
+    with pytest.raises(RuntimeError, match='wrong number of elements'):
+        dropin.bias_act_plugin.bias_act(x, b[:3], null, null, null, 0, 1, 3, 0.2, 1.0, -1.0)
+    with pytest.raises(RuntimeError, match='same layout'):
+        dropin.bias_act_plugin.bias_act(x, b, xcl, null, null, 1, 1, 3, 0.2, 1.0, -1.0)
+    fa = d['fa'].to(dev); xu = d['up_x'].to(dev)
+    # case 1 of gen_ops: up=2, pad [2,1,2,1], gain 4 -> the wrapper passes gain * up^0... exactly: upfirdn2d.py hands `gain` through
+    y = dropin.upfirdn2d_plugin.upfirdn2d(xu, fa, 2, 2, 1, 1, 2, 1, 2, 1, False, 4.0)
+    close(y, d['up1_y'], 3e-6, 'upfirdn2d plugin')
+    y = dropin.upfirdn2d_plugin.upfirdn2d(xu.contiguous(memory_format=torch.channels_last), fa, 3, 3, 2, 2, -1, 4, 2, 0, True, 1.5)
+    assert y.is_contiguous(memory_format=torch.channels_last); close(y, d['up4_y'], 3e-6, 'upfirdn2d plugin flip / crop')
+    with pytest.raises(RuntimeError, match='rank 2'):
+        dropin.upfirdn2d_plugin.upfirdn2d(xu, fa[0], 1, 1, 1, 1, 0, 0, 0, 0, False, 1.0)
+
+
+class SyntheticLayouts(torch.utils.data.Dataset):
+    """Stands for training.dataset_layoutganpp.LayoutDataset: the attributes training_loop reads (:127-132) and items shaped as its
+    __getitem__ returns them (dict of bboxes / labels / texts / patches / mask / background, label)."""
+    num_bbox_labels, num_channels, height, width, label_dim = 8, 3, 64, 64, 0
+
+    def __init__(self, n=8, background_size_for_training=64):
+        self.n, self.background_size_for_training = n, background_size_for_training
+        self.words = ['sale', 'shop now', 'up to 50% off', 'new', 'free shipping', 'ok', 'limited time only!', 'x', 'sign up']
+
+    def __len__(self):
+        return self.n
+
+    def __getitem__(self, i):
+        i = int(i)
+        g = torch.Generator().manual_seed(i)
+        bb = torch.cat([torch.rand(9, 2, generator=g) * 0.6 + 0.2, torch.rand(9, 2, generator=g) * 0.35 + 0.05], -1)
+        mask = torch.ones(9, dtype=torch.bool); mask[5 + i % 4:] = False
+        return dict(bboxes=bb.numpy(), labels=torch.randint(0, 8, (9,), generator=g).numpy(), texts=[self.words[(i + j) % 9] for j in range(9)],
+                    patches=np.zeros((9, 3, 4, 4), np.float32), mask=mask.numpy(),
+                    background=torch.randn(3, 64, 64, generator=g).numpy()), np.zeros((0,), np.float32)
+
+
+def test_training_loop_entry_runs_like_train_py_drives_it(dev, tmp_path):
+    """training_loop(**c) with the reference's keyword arguments (train.py:47,197-283): networks and loss by class name THROUGH THE
+    REFERENCE'S MODULE NAMES (dropin.install()), a dataset object, strings as bbox_text (host WordPiece tokenizer from a local vocab)."""
+    from layoutdetr_amd import dropin
+    dropin.install()
+    import importlib
+    tl = importlib.import_module('training.training_loop')
+    vocab = ['[PAD]', '[unused0]', '[UNK]', '[CLS]', '[SEP]', '[MASK]'] + sorted({w for s in SyntheticLayouts().words for w in s.replace('%', ' % ').replace('!', ' !').split()})
+    vf = tmp_path / 'vocab.txt'
+    vf.write_text('\n'.join(vocab) + '\n')
+    net = dict(bert_f_dim=768, bert_num_heads=4, bert_num_encoder_layers=2, bert_num_decoder_layers=2, im_f_dim=512, text_mode='encoder', tokenizer_vocab=str(vf))
+    seen = []
+    out = tl.training_loop(
+        run_dir=str(tmp_path), training_set_kwargs=dict(class_name='test_boundary_gpu.SyntheticLayouts', n=8),
+        data_loader_kwargs=dict(num_workers=0), random_seed=0, num_gpus=1, rank=0, batch_size=4, batch_gpu=4,
+        G_kwargs=dict(class_name='training.networks_detr.Generator', z_dim=4, **net), D_kwargs=dict(class_name='training.networks_detr.Discriminator', **net),
+        G_opt_kwargs=dict(class_name='torch.optim.Adam', betas=[0, 0.99], eps=1e-8, lr=1e-5), D_opt_kwargs=dict(class_name='torch.optim.Adam', betas=[0, 0.99], eps=1e-8, lr=1e-5),
+        loss_kwargs=dict(class_name='training.loss.StyleGAN2Loss', r1_gamma=0.0, pl_weight=0.0, Ggen_bbox_rec_weight=100.0), G_reg_interval=4, D_reg_interval=16,
+        ema_kimg=4 * 10 / 32, total_kimg=0.012, kimg_per_tick=0.004, progress_fn=lambda cur, tot: seen.append(cur))
+    assert out['stats']['cur_nimg'] == 12 and len(seen) >= 3
+    assert type(out['G']).__module__ == 'layoutdetr_amd.training.networks_detr'
+    for k in ('Loss/scores/fake', 'Loss/scores/real', 'Loss/G/loss_Ggen_bbox_rec', 'Loss/D/loss_Dreal_bg_rec'):
+        assert k in out['stats'] and np.isfinite(out['stats'][k]), k
+    assert all(torch.isfinite(p).all() for p in out['G'].parameters())
+    moved = sum(float((a - b).abs().max()) > 0 for a, b in zip(out['G'].parameters(), out['G_ema'].parameters()))
+    assert moved > 100, 'G was not updated / EMA not tracking'

@@ -222,3 +222,55 @@ def test_resample_coefficients_match_pillow_restatement():
         assert int(k.sum(0).min()) > (1 << 22) - 64 and int(k.sum(0).max()) < (1 << 22) + 64   # every window sums to ~1.0
     assert lib.ldetr_resample_coeffs(1024, 256, b.ctypes.data_as(ctypes.c_void_p), k.ctypes.data_as(ctypes.c_void_p), 10, ctypes.byref(ks)) != 0
     assert b'too small' in lib.ldetr_last_error()
+
+
+def test_wordpiece_tokenizer_matches_transformers(tmp_path):
+    """training/tokenizer.py == transformers.BertTokenizer (+ the two tokens blip.init_tokenizer adds) id for id: casing, accents,
+    punctuation splitting, CJK, unknown words, truncation, padding; bos / pad ids as networks_detr.py:172-173 uses them."""
+    from transformers import BertTokenizer
+    from layoutdetr_amd.training.tokenizer import BertWordPieceTokenizer, texts_to_tokens
+    vocab = ['[PAD]', '[unused0]', '[UNK]', '[CLS]', '[SEP]', '[MASK]', 'sale', 'up', 'to', '50', '%', 'off', 'shop', 'now', 'new', 'arrival', '##s', 'this', 'week',
+             'free', 'ship', '##ping', 'on', 'order', 'over', '$', '25', '!', 'sign', 'limit', '##ed', 'time', 'only', 'x', 'ok', 'cafe', '##teria', 'a', 'b', '##c',
+             ',', '.', '-', '中', '国']
+    vf = tmp_path / 'vocab.txt'
+    vf.write_text('\n'.join(vocab) + '\n', encoding='utf-8')
+    mine = BertWordPieceTokenizer(str(vf))
+    ref = BertTokenizer(vocab={t: i for i, t in enumerate(vocab)})
+    ref.add_special_tokens({'bos_token': '[DEC]'}); ref.add_special_tokens({'additional_special_tokens': ['[ENC]']})
+    texts = ['Sale', 'Up to 50% off', 'Shop now', 'New arrivals this week', 'x', 'Free shipping on orders over $25', 'Sign up', 'Limited time only!', 'ok',
+             'Café-teria, abc.  a\tb', '中国 sale', 'unknownword zzz', '', 'Free shipping on orders over $25 new arrivals this week sale sale sale']
+    for L in (16, 8):
+        r = ref(texts, padding='max_length', truncation=True, max_length=L, return_tensors='pt')
+        ids, am = mine(texts, max_length=L)
+        assert torch.equal(ids, r.input_ids) and torch.equal(am, r.attention_mask)
+    assert mine.bos_token_id == ref.bos_token_id == len(vocab) and mine.pad_token_id == ref.pad_token_id == 0 and len(mine) == len(ref)
+    tok = texts_to_tokens(mine, [texts[:3], texts[3:6]], 256)
+    assert tok.input_ids.shape[:2] == (2, 3) and tok.input_ids.shape[2] == int(tok.attention_mask.sum(-1).max())
+    assert tok.text_len.tolist() == [[4, 13, 8], [22, 1, 32]]
+
+
+def test_dropin_aliases_and_training_loop_signature():
+    """`training.networks_detr.Generator` etc. resolve to this package after dropin.install(); training_loop takes exactly the
+    reference's keyword arguments (training/training_loop.py:63-99), so train.py's `training_loop.training_loop(rank=rank, **c)` binds."""
+    import importlib
+    import inspect
+    from layoutdetr_amd import dropin
+    dropin.install()
+    nd = importlib.import_module('training.networks_detr')
+    assert nd.Generator.__module__ == 'layoutdetr_amd.training.networks_detr' and hasattr(nd, 'split_list')
+    assert importlib.import_module('training.loss').StyleGAN2Loss.__module__ == 'layoutdetr_amd.training.loss'
+    for m in ('bias_act', 'upfirdn2d', 'conv2d_resample', 'conv2d_gradfix'):
+        assert importlib.import_module('torch_utils.ops.' + m).__name__ == 'layoutdetr_amd.torch_utils.ops.' + m
+    ref_args = ['run_dir', 'training_set_kwargs', 'validation_set_kwargs', 'data_loader_kwargs', 'G_kwargs', 'D_kwargs', 'G_opt_kwargs', 'D_opt_kwargs',
+                'augment_kwargs', 'loss_kwargs', 'metrics', 'random_seed', 'num_gpus', 'rank', 'batch_size', 'batch_gpu', 'ema_kimg', 'ema_rampup',
+                'G_reg_interval', 'D_reg_interval', 'augment_p', 'ada_target', 'ada_interval', 'ada_kimg', 'total_kimg', 'kimg_per_tick',
+                'image_snapshot_ticks', 'network_snapshot_ticks', 'resume_pkl', 'resume_kimg', 'cudnn_benchmark', 'abort_fn', 'progress_fn']
+    tl = importlib.import_module('training.training_loop')
+    assert list(inspect.signature(tl.training_loop).parameters) == ref_args
+    # the Generator / Discriminator constructors accept every keyword train.py passes (train.py:250-261 + training_loop.py:127-132)
+    kw = dict(z_dim=4, f_dim=256, num_heads=4, num_layers=8, bert_f_dim=768, bert_num_heads=4, bert_num_encoder_layers=12, bert_num_decoder_layers=2, im_f_dim=512,
+              num_bbox_labels=8, img_channels=3, img_height=64, img_width=64, background_size=64, c_dim=0)
+    inspect.signature(nd.Generator.__init__).bind(None, **kw)
+    kw.pop('z_dim'); inspect.signature(nd.Discriminator.__init__).bind(None, **kw)
+    sampler = tl.InfiniteSampler(list(range(10)), rank=1, num_replicas=2, shuffle=False)
+    it = iter(sampler); assert [next(it) for _ in range(6)] == [1, 3, 5, 7, 9, 1]
