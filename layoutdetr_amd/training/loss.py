@@ -102,6 +102,8 @@ class StyleGAN2Loss(Loss):
         # gradient (the reference recomputes it, training/loss.py:176-210: two run_D calls, two backward calls).  Same losses and
         # gradients up to fp32 summation order; share_D_trunk=False restores the reference's call pattern.
         self.share_D_trunk = share_D_trunk
+        # with a shared trunk, D(fake) and D(real) of Dmain also run as one batch of 2B (values identical; LDETR_PAIR_D=0 = two calls)
+        self.pair_D_passes = bool(share_D_trunk) and os.environ.get('LDETR_PAIR_D', '1') != '0'
         self.fused_layout_losses = os.environ.get('LDETR_FUSED_LAYOUT_LOSSES', '1') != '0'   # csrc/layout_loss.hip (static-shape path)
         # share_D_trunk='iteration' goes one step further: D's weights do not change between the Gmain and the Dmain phase of one
         # iteration (Gmain updates G only, training_loop.py:281-313), so ONE trunk evaluation per iteration serves D(fake) in Gmain
@@ -192,12 +194,13 @@ class StyleGAN2Loss(Loss):
         self.last = dict(bbox_fake=bbox_fake.detach(), **{k: v.detach() for k, v in terms.items()})
         return total.mean()
 
-    def d_gen_loss(self, bbox_real, bbox_class, bbox_text, bbox_patch, padding_mask, background, gen_z, gen_c, trunk_out=None):
-        bbox_fake = self.run_G(gen_z, bbox_class, bbox_real, bbox_text, bbox_patch, padding_mask, background, gen_c, update_emas=True)
-        if isinstance(trunk_out, _TrunkFork):
-            trunk_out = trunk_out.join()
-        gen_logits, gen_logits_uncond = self.run_D(bbox_fake, bbox_class, bbox_text, bbox_patch, padding_mask, background, gen_c, update_emas=True,
-                                                   trunk_out=trunk_out)
+    def d_gen_loss(self, bbox_real, bbox_class, bbox_text, bbox_patch, padding_mask, background, gen_z, gen_c, trunk_out=None, gen_out=None):
+        if gen_out is None:
+            bbox_fake = self.run_G(gen_z, bbox_class, bbox_real, bbox_text, bbox_patch, padding_mask, background, gen_c, update_emas=True)
+            if isinstance(trunk_out, _TrunkFork):
+                trunk_out = trunk_out.join()
+            gen_out = self.run_D(bbox_fake, bbox_class, bbox_text, bbox_patch, padding_mask, background, gen_c, update_emas=True, trunk_out=trunk_out)
+        gen_logits, gen_logits_uncond = gen_out
         loss_Dgen = F.softplus(gen_logits)
         loss_Dgen_uncond = F.softplus(gen_logits_uncond)
         self.report('Loss/scores/fake', gen_logits)
@@ -207,13 +210,14 @@ class StyleGAN2Loss(Loss):
         self.report('Loss/D/loss_Dgen_uncond', loss_Dgen_uncond)
         return (loss_Dgen + loss_Dgen_uncond).mean()
 
-    def d_real_loss(self, bbox_real, bbox_class, bbox_text, bbox_patch, padding_mask, background, real_c, trunk_out=None):
+    def d_real_loss(self, bbox_real, bbox_class, bbox_text, bbox_patch, padding_mask, background, real_c, trunk_out=None, real_out=None):
         w = self.w
         valid = ~padding_mask
         static = bool(getattr(self.D, 'static_shapes', False))
         bbox_real_tmp = bbox_real.detach()
-        (real_logits, real_logits_uncond, bbox_rec, cls_logits, loss_lm, loss_text_len, bg_rec, bbox_rec_uncond,
-         cls_logits_uncond) = self.run_D(bbox_real_tmp, bbox_class, bbox_text, bbox_patch, padding_mask, background, real_c, reconst=True, trunk_out=trunk_out)
+        if real_out is None:
+            real_out = self.run_D(bbox_real_tmp, bbox_class, bbox_text, bbox_patch, padding_mask, background, real_c, reconst=True, trunk_out=trunk_out)
+        (real_logits, real_logits_uncond, bbox_rec, cls_logits, loss_lm, loss_text_len, bg_rec, bbox_rec_uncond, cls_logits_uncond) = real_out
         terms = dict(
             loss_Dreal=F.softplus(-real_logits),
             loss_Dreal_uncond=F.softplus(-real_logits_uncond),
@@ -244,7 +248,14 @@ class StyleGAN2Loss(Loss):
         if phase == 'Dmain':
             if self.share_D_trunk and hasattr(self.D, 'trunk'):   # True / 'phase' / 'iteration'
                 cached = self._cached_trunk(background, detach=False, pop=True)
-                if cached is not None:
+                if self.pair_D_passes and hasattr(self.D, 'forward_pair'):
+                    # both D passes of the phase as ONE batch of 2B layouts (Discriminator.forward_pair): half the transformer / head launches
+                    bbox_fake = self.run_G(gen_z, bbox_class, bbox_real, bbox_text, bbox_patch, padding_mask, background, gen_c, update_emas=True)
+                    trunk = cached if cached is not None else self.D.trunk(background)
+                    gen_out, real_out = self.D.forward_pair(bbox_fake, bbox_real.detach(), bbox_class, bbox_text, bbox_patch, padding_mask, background, real_c, trunk_out=trunk)
+                    l_gen = self.d_gen_loss(bbox_real, bbox_class, bbox_text, bbox_patch, padding_mask, background, gen_z, gen_c, gen_out=gen_out)
+                    l_real = self.d_real_loss(bbox_real, bbox_class, bbox_text, bbox_patch, padding_mask, background, real_c, real_out=real_out)
+                elif cached is not None:
                     l_gen = self.d_gen_loss(bbox_real, bbox_class, bbox_text, bbox_patch, padding_mask, background, gen_z, gen_c, trunk_out=cached)
                     l_real = self.d_real_loss(bbox_real, bbox_class, bbox_text, bbox_patch, padding_mask, background, real_c, trunk_out=cached)
                 else:

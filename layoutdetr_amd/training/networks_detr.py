@@ -346,35 +346,22 @@ class Discriminator(nn.Module):
             background = nested_tensor_from_tensor_list(background)
         return self.backbone(background)
 
-    def forward(self, bbox, bbox_class, bbox_text, bbox_patch, padding_mask, background, c, reconst=False, trunk_out=None):
-        bg_feat, pos = self.trunk(background) if trunk_out is None else trunk_out
-        bg_feat, mask = bg_feat[-1].decompose()
-        assert mask is not None
-
-        B, N = bbox_patch.shape[0], bbox_patch.shape[1]
-        bbox_text = _coerce_text(self, bbox_text, bbox_class.device)
+    def _logits(self, bbox, l, text_feat, text_len_feat, l_uncond, padding_mask, src, mask, pos):
+        """The two discriminator scores of a batch of layouts: -> (x0, logit, x0_uncond, logit_uncond)."""
         b = self.fc_bbox(bbox)
-        l = self.emb_label(bbox_class)
-        text_feat, text_len = _text_inputs(self, bbox_text, B, N, bbox_class.device)
-        text_len_feat = self.enc_text_len(text_len)
         x = torch.cat([b, l, text_feat, text_len_feat], dim=-1)
         x = self.enc_fc_in(x, final_relu=True).permute(1, 0, 2)
-
-        x = self.enc_transformer(src=self.input_proj(bg_feat), mask=mask, pos_embed=pos[-1], tgt=x,
-                                 tgt_key_padding_mask=padding_mask)[0].transpose(0, 1)
+        x = self.enc_transformer(src=src, mask=mask, pos_embed=pos, tgt=x, tgt_key_padding_mask=padding_mask)[0].transpose(0, 1)
         x0 = x[0]
         logit_disc = self.fc_out_disc(x0).squeeze(-1)
-
-        b_uncond = self.fc_bbox_uncond(bbox)
-        l_uncond = self.emb_label_uncond(bbox_class)
-        x_uncond = torch.cat([b_uncond, l_uncond], dim=-1)
+        x_uncond = torch.cat([self.fc_bbox_uncond(bbox), l_uncond], dim=-1)
         x_uncond = self.enc_fc_in_uncond(x_uncond, final_relu=True).permute(1, 0, 2)
         x_uncond = self.enc_transformer_uncond(x_uncond, src_key_padding_mask=padding_mask)
         x0_uncond = x_uncond[0]
-        logit_disc_uncond = self.fc_out_disc_uncond(x0_uncond).squeeze(-1)
-        if not reconst:
-            return logit_disc, logit_disc_uncond
+        return x0, logit_disc, x0_uncond, self.fc_out_disc_uncond(x0_uncond).squeeze(-1)
 
+    def _reconstruct(self, x0, x0_uncond, bbox_text, text_len, padding_mask, B, N):
+        """The reconstruction heads on the layout token(s) (reference networks_detr.py:312-359)."""
         valid = ~padding_mask
         x = x0.unsqueeze(0).expand(N, -1, -1)
         t = self.pos_token[:N].expand(-1, B, -1)
@@ -402,4 +389,40 @@ class Discriminator(nn.Module):
         x_uncond = x_uncond.permute(1, 0, 2) if static else x_uncond.permute(1, 0, 2)[valid]
         bbox_pred_uncond = self.bbox_embed_uncond(x_uncond).sigmoid()
         logit_cls_uncond = self.fc_out_cls_uncond(x_uncond)
-        return (logit_disc, logit_disc_uncond, bbox_pred, logit_cls, loss_lm, loss_text_len, bg_rec, bbox_pred_uncond, logit_cls_uncond)
+        return bbox_pred, logit_cls, loss_lm, loss_text_len, bg_rec, bbox_pred_uncond, logit_cls_uncond
+
+    def forward(self, bbox, bbox_class, bbox_text, bbox_patch, padding_mask, background, c, reconst=False, trunk_out=None):
+        bg_feat, pos = self.trunk(background) if trunk_out is None else trunk_out
+        bg_feat, mask = bg_feat[-1].decompose()
+        assert mask is not None
+
+        B, N = bbox_patch.shape[0], bbox_patch.shape[1]
+        bbox_text = _coerce_text(self, bbox_text, bbox_class.device)
+        l = self.emb_label(bbox_class)
+        text_feat, text_len = _text_inputs(self, bbox_text, B, N, bbox_class.device)
+        text_len_feat = self.enc_text_len(text_len)
+        x0, logit_disc, x0_uncond, logit_disc_uncond = self._logits(bbox, l, text_feat, text_len_feat, self.emb_label_uncond(bbox_class), padding_mask,
+                                                                    self.input_proj(bg_feat), mask, pos[-1])
+        if not reconst:
+            return logit_disc, logit_disc_uncond
+        return (logit_disc, logit_disc_uncond) + self._reconstruct(x0, x0_uncond, bbox_text, text_len, padding_mask, B, N)
+
+    def forward_pair(self, bbox_fake, bbox_real, bbox_class, bbox_text, bbox_patch, padding_mask, background, c, trunk_out=None):
+        """D(bbox_fake) and D(bbox_real, reconst=True) of the SAME layouts' conditions in one pass — what phase Dmain evaluates with two
+        calls (training/loss.py:149,165).  The samples of a batch are independent (FrozenBatchNorm, no batch statistics), so the two
+        score paths run as ONE batch of 2B layouts: trunk, input_proj, label / text embeddings and the text encoder are evaluated
+        once, every transformer launch covers both halves, and the reconstruction heads see the real half only.  Values equal the
+        two separate calls (dropout draws aside).  -> ((logit, logit_uncond) of the fake half, the 9-tuple of the real half)."""
+        bg_feat, pos = self.trunk(background) if trunk_out is None else trunk_out
+        bg_feat, mask = bg_feat[-1].decompose()
+        B, N = bbox_patch.shape[0], bbox_patch.shape[1]
+        bbox_text = _coerce_text(self, bbox_text, bbox_class.device)
+        l = self.emb_label(bbox_class)
+        text_feat, text_len = _text_inputs(self, bbox_text, B, N, bbox_class.device)
+        text_len_feat = self.enc_text_len(text_len)
+        l_uncond = self.emb_label_uncond(bbox_class)
+        two = lambda t: torch.cat([t, t], dim=0)
+        x0, logit, x0_uncond, logit_uncond = self._logits(torch.cat([bbox_fake, bbox_real], dim=0), two(l), two(text_feat), two(text_len_feat), two(l_uncond),
+                                                            two(padding_mask), two(self.input_proj(bg_feat)), two(mask), two(pos[-1]))
+        rec = self._reconstruct(x0[B:], x0_uncond[B:], bbox_text, text_len, padding_mask, B, N)
+        return (logit[:B], logit_uncond[:B]), (logit[B:], logit_uncond[B:]) + rec

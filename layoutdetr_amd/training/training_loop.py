@@ -272,7 +272,7 @@ def training_iteration(loss, phases, dp, batch, batch_gpu, gen_z_per_phase, ema=
         staged = overlap and b <= batch_gpu and not (iter_share and phase.name == 'Dmain')
         exchanged = staged_backward(loss, phase, dp, accumulate) if staged else (accumulate() or False)
         phase.module.requires_grad_(False)
-        dp.apply(phase, exchanged=exchanged)
+        dp.apply(phase, exchanged=True) if exchanged else dp.apply(phase)
     if ema is not None:
         ema.update(batch_size, ema_kimg, cur_nimg)
 
@@ -372,7 +372,7 @@ class GraphedIteration(object):
                     for lo, hi in seg:
                         self.dp.exchange_async(phase.fm.gflat, lo, hi)
                     exchanged = True
-            self.dp.apply(phase, exchanged=exchanged)
+            self.dp.apply(phase, exchanged=True) if exchanged else self.dp.apply(phase)
         if self.ema is not None:
             self.ema.update(self.batch_size, self.ema_kimg, self.cur_nimg)
         if self.batch_size:
