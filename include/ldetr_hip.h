@@ -171,6 +171,16 @@ int ldetr_attention_bwd_f32(const float* q, int64_t ldq, const float* k, int64_t
                             float* dv, int64_t lddv, int B, int H, int Lq, int Lk, int head_dim, float scale,
                             float p_drop, uint64_t seed, const uint64_t* seed_ptr, int causal, void* stream);
 
+/* ypos (optional, with pos [pos_rows, D]): second output ypos[row] = y[row] + pos[row % pos_rows] — the position-embedded copy the
+ * next attention block projects q and k from (training/detr_transformer.py:207,277 form it with one extra kernel per layer);
+ * dy2 (optional): gradient that arrived through ypos, summed into dy as it is loaded. */
+int ldetr_layernorm_fwd_pos_f32(const float* x, const float* residual, const float* gamma, const float* beta, float* y,
+                                float* z, float* mean, float* rstd, int64_t rows, int D, float eps, float p_drop,
+                                uint64_t seed, const uint64_t* seed_ptr, const float* pos, int64_t pos_rows, float* ypos,
+                                void* stream);
+int ldetr_layernorm_bwd2_f32(const float* dy, const float* dy2, const float* z, const float* mean, const float* rstd,
+                             const float* gamma, float* dx, float* dresidual, float* dgamma, float* dbeta, int64_t rows,
+                             int D, float p_drop, uint64_t seed, const uint64_t* seed_ptr, void* stream);
 int ldetr_layernorm_fwd_f32(const float* x, const float* residual, const float* gamma, const float* beta, float* y,
                             float* z, float* mean, float* rstd, int64_t rows, int D, float eps, float p_drop,
                             uint64_t seed, const uint64_t* seed_ptr, void* stream);

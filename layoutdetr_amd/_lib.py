@@ -56,6 +56,8 @@ SIGNATURES = {
                                 _I, _I, _I, _I, _I, _F, _F, c_uint64, _P, _I, _P],
     'ldetr_layernorm_fwd_f32': [_P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _F, _F, c_uint64, _P, _P],
     'ldetr_layernorm_bwd_f32': [_P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _F, c_uint64, _P, _P],
+    'ldetr_layernorm_fwd_pos_f32': [_P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _F, _F, c_uint64, _P, _P, _L, _P, _P],
+    'ldetr_layernorm_bwd2_f32': [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _F, c_uint64, _P, _P],
     'ldetr_colsum_f32': [_P, _P, _I, _L, _I, _P],
     'ldetr_act_bwd_reduce_f32': [_P, _P, _P, _P, _P, _P, _P, _I, _L, _I, _I, _F, _F, _P],
     'ldetr_mul_reduce_f32': [_P, _P, _P, _P, _P, _I, _L, _I, _P],
@@ -105,7 +107,7 @@ def load():
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported
         fn.restype = c_int
         fn.argtypes = argtypes
-    if lib.ldetr_abi_version() != 14:
+    if lib.ldetr_abi_version() != 15:
         raise RuntimeError('libldetr_hip.so ABI version mismatch; rebuild it')
     _lib = lib
     return lib

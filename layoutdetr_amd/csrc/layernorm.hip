@@ -14,6 +14,9 @@ struct LnParams {
     float* y; float* z; float* mean; float* rstd;
     const float* dy; float* dx; float* dr; float* dgamma; float* dbeta;
     long rows; int D; float eps, p_drop; unsigned long long seed; const unsigned long long* seed_ptr;
+    // second output ypos[row] = y[row] + pos[row % pos_rows] (the next attention's q/k input: detr_transformer.py:207,277 add the
+    // position embedding with a separate kernel per layer), and its gradient dy2 summed into dy on load
+    const float* pos; long pos_rows; float* ypos; const float* dy2;
 };
 
 // NV = float4 vectors per lane (D = 256*NV at most; lanes past D/4 idle)
@@ -70,6 +73,11 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(LnParams p) {
             o.x = (v[i].x - mean) * rstd * g.x + b.x; o.y = (v[i].y - mean) * rstd * g.y + b.y;
             o.z = (v[i].z - mean) * rstd * g.z + b.z; o.w = (v[i].w - mean) * rstd * g.w + b.w;
             reinterpret_cast<float4*>(p.y + row * p.D)[c4] = o;
+            if (p.ypos) {
+                const float4 pp = reinterpret_cast<const float4*>(p.pos + (row % p.pos_rows) * p.D)[c4];
+                o.x += pp.x; o.y += pp.y; o.z += pp.z; o.w += pp.w;
+                reinterpret_cast<float4*>(p.ypos + row * p.D)[c4] = o;
+            }
         }
     }
 }
@@ -98,6 +106,10 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(LnParams p) {
             if (c4 < D4) {
                 float4 zz = reinterpret_cast<const float4*>(p.z + row * p.D)[c4];
                 float4 dy = reinterpret_cast<const float4*>(p.dy + row * p.D)[c4];
+                if (p.dy2) {
+                    const float4 d2 = reinterpret_cast<const float4*>(p.dy2 + row * p.D)[c4];
+                    dy.x += d2.x; dy.y += d2.y; dy.z += d2.z; dy.w += d2.w;
+                }
                 float4 gm = reinterpret_cast<const float4*>(p.gamma)[c4];
                 xh[i].x = (zz.x - mean) * rstd; xh[i].y = (zz.y - mean) * rstd;
                 xh[i].z = (zz.z - mean) * rstd; xh[i].w = (zz.w - mean) * rstd;
@@ -153,12 +165,21 @@ using namespace ldetr;
 extern "C" int ldetr_layernorm_fwd_f32(const float* x, const float* residual, const float* gamma, const float* beta,
                                        float* y, float* z, float* mean, float* rstd, int64_t rows, int D, float eps,
                                        float p_drop, uint64_t seed, const uint64_t* seed_ptr, void* stream) {
+    return ldetr_layernorm_fwd_pos_f32(x, residual, gamma, beta, y, z, mean, rstd, rows, D, eps, p_drop, seed, seed_ptr, nullptr, 0, nullptr, stream);
+}
+
+extern "C" int ldetr_layernorm_fwd_pos_f32(const float* x, const float* residual, const float* gamma, const float* beta,
+                                           float* y, float* z, float* mean, float* rstd, int64_t rows, int D, float eps,
+                                           float p_drop, uint64_t seed, const uint64_t* seed_ptr,
+                                           const float* pos, int64_t pos_rows, float* ypos, void* stream) {
     LDETR_CHECK(x && gamma && beta && y, "layernorm_fwd: null pointer");
+    LDETR_CHECK((pos == nullptr) == (ypos == nullptr) && (!pos || pos_rows > 0), "layernorm_fwd: pos, pos_rows and ypos go together");
     LDETR_CHECK(D % 4 == 0 && D >= 4 && D <= 1024, "layernorm_fwd: D must be a multiple of 4 in [4, 1024]");
     if (rows == 0) return LDETR_OK;
     LnParams p; memset(&p, 0, sizeof(p));
     p.x = x; p.r = residual; p.gamma = gamma; p.beta = beta; p.y = y; p.z = z; p.mean = mean; p.rstd = rstd;
     p.rows = rows; p.D = D; p.eps = eps; p.p_drop = p_drop; p.seed = seed; p.seed_ptr = (const unsigned long long*)seed_ptr;
+    p.pos = pos; p.pos_rows = pos_rows; p.ypos = ypos;
     int grid = (int)((rows + 3) / 4);
     hipStream_t st = (hipStream_t)stream;
     int nv = (D + 255) / 256;
@@ -173,13 +194,19 @@ extern "C" int ldetr_layernorm_fwd_f32(const float* x, const float* residual, co
 extern "C" int ldetr_layernorm_bwd_f32(const float* dy, const float* z, const float* mean, const float* rstd, const float* gamma,
                                        float* dx, float* dresidual, float* dgamma, float* dbeta, int64_t rows, int D,
                                        float p_drop, uint64_t seed, const uint64_t* seed_ptr, void* stream) {
+    return ldetr_layernorm_bwd2_f32(dy, nullptr, z, mean, rstd, gamma, dx, dresidual, dgamma, dbeta, rows, D, p_drop, seed, seed_ptr, stream);
+}
+
+extern "C" int ldetr_layernorm_bwd2_f32(const float* dy, const float* dy2, const float* z, const float* mean, const float* rstd, const float* gamma,
+                                        float* dx, float* dresidual, float* dgamma, float* dbeta, int64_t rows, int D,
+                                        float p_drop, uint64_t seed, const uint64_t* seed_ptr, void* stream) {
     LDETR_CHECK(dy && z && mean && rstd && gamma, "layernorm_bwd: null pointer");
     LDETR_CHECK(D % 4 == 0 && D >= 4 && D <= 1024, "layernorm_bwd: D must be a multiple of 4 in [4, 1024]");
     LDETR_CHECK((dgamma == nullptr) == (dbeta == nullptr), "layernorm_bwd: dgamma and dbeta go together");
     if (rows == 0) return LDETR_OK;
     LnParams p; memset(&p, 0, sizeof(p));
     p.dy = dy; p.z = const_cast<float*>(z); p.mean = const_cast<float*>(mean); p.rstd = const_cast<float*>(rstd);
-    p.gamma = gamma; p.dx = dx; p.dr = dresidual; p.dgamma = dgamma; p.dbeta = dbeta;
+    p.gamma = gamma; p.dx = dx; p.dr = dresidual; p.dgamma = dgamma; p.dbeta = dbeta; p.dy2 = dy2;
     p.rows = rows; p.D = D; p.p_drop = p_drop; p.seed = seed; p.seed_ptr = (const unsigned long long*)seed_ptr;
     int grid = (int)((rows + 3) / 4);
     if (grid > 512) grid = 512;

@@ -108,7 +108,7 @@ def attention(q, k, v, key_padding_mask, B, H, Lq, Lk, p_drop=0.0):
 
 
 def mha_forward(query, key, value, in_proj_weight, in_proj_bias, out_w, out_b, nhead, B, Lq, Lk,
-                key_padding_mask=None, p_drop=0.0, same_qk=False, same_qkv=False, qk_pos=None, passthru=False):
+                key_padding_mask=None, p_drop=0.0, same_qk=False, same_qkv=False, qk_pos=None, passthru=False, qk_in=None, kv_alias=False):
     """query: [B*Lq, d]; key/value: [B*Lk, d].  Returns [B*Lq, d] (before the caller's residual/dropout/LN).
 
     same_qkv: query, key and value are one tensor  -> one packed [3d] projection (decoder self-attention).
@@ -116,6 +116,11 @@ def mha_forward(query, key, value, in_proj_weight, in_proj_bias, out_w, out_b, n
               -> one [2d] projection + one [d] projection; qk_pos is added inside the projection node.
     passthru: also return an alias of `query` that already went through the projection nodes; feeding the residual branch
               from it keeps autograd from summing the gradients of `query` with separate add launches (hip/linear.py).
+    qk_in:    (same_qk) the tensor `query + qk_pos` already formed by the producer (layernorm's second output): q / k are projected
+              from it with no add launch here; its gradient flows back to that producer.
+    kv_alias: (cross-attention) also return aliases of `key` and `value` that went through their projection nodes: the next decoder
+              layer reads the memory through them, so the memory's gradient accumulates inside the projection GEMMs' epilogues
+              instead of 2 x (layers - 1) autograd add launches per decoder stack.
     """
     d = query.shape[1]
     W, bvec = in_proj_weight, in_proj_bias
@@ -124,6 +129,11 @@ def mha_forward(query, key, value, in_proj_weight, in_proj_bias, out_w, out_b, n
         r = linear(query, W, bvec, passthru=passthru)
         qkv, alias = r if passthru else (r, query)
         o = _AttnPackedFn.apply(qkv, None, _kpm_u8(key_padding_mask), B, nhead, Lq, p_drop)
+    elif same_qk and qk_in is not None:
+        qk = linear(qk_in, W, bvec, rows=(0, 2 * d))
+        r = linear(query, W, bvec, rows=(2 * d, 3 * d), passthru=passthru)
+        v, alias = r if passthru else (r, query)
+        o = _AttnPackedFn.apply(qk, v, _kpm_u8(key_padding_mask), B, nhead, Lq, p_drop)
     elif same_qk:
         r = linear(query, W, bvec, rows=(0, 2 * d), add_input=qk_pos, passthru=passthru)
         qk, alias = r if passthru else (r, query)
@@ -134,8 +144,14 @@ def mha_forward(query, key, value, in_proj_weight, in_proj_bias, out_w, out_b, n
     else:
         r = linear(query, W, bvec, rows=(0, d), passthru=passthru)
         q, alias = r if passthru else (r, query)
-        k = linear(key, W, bvec, rows=(d, 2 * d))
-        v = linear(value, W, bvec, rows=(2 * d, 3 * d))
+        if kv_alias:
+            k, key = linear(key, W, bvec, rows=(d, 2 * d), passthru=True)
+            v, value = linear(value, W, bvec, rows=(2 * d, 3 * d), passthru=True)
+        else:
+            k = linear(key, W, bvec, rows=(d, 2 * d))
+            v = linear(value, W, bvec, rows=(2 * d, 3 * d))
         o = attention(q, k, v, key_padding_mask, B, nhead, Lq, Lk, p_drop)
     out = linear(o, out_w, out_b)
+    if kv_alias:
+        return out, alias, key, value
     return (out, alias) if passthru else out

@@ -7,8 +7,9 @@ from . import core
 
 class _AddLnFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, r, gamma, beta, eps, p_drop):
-        core.require_gpu(x, r, gamma, beta)
+    def forward(ctx, x, r, gamma, beta, eps, p_drop, pos=None):
+        core.require_gpu(x, r, gamma, beta, pos)
+        ctx.set_materialize_grads(False)
         D = x.shape[-1]
         x2 = core.f32c(x.reshape(-1, D))
         r2 = core.f32c(r.reshape(-1, D)) if r is not None else None
@@ -19,21 +20,30 @@ class _AddLnFn(torch.autograd.Function):
         mean = torch.empty(rows, device=x.device, dtype=torch.float32)
         rstd = torch.empty(rows, device=x.device, dtype=torch.float32)
         seed = core.next_seed() if (p_drop > 0 and r2 is not None) else 0
-        core.check(core.lib().ldetr_layernorm_fwd_f32(
+        pos2 = core.f32c(pos.reshape(-1, D)) if pos is not None else None
+        ypos = torch.empty_like(x2) if pos2 is not None else None
+        core.check(core.lib().ldetr_layernorm_fwd_pos_f32(
             core.ptr(x2), core.ptr(r2), core.ptr(g), core.ptr(b), core.ptr(y), core.ptr(z) if r2 is not None else None,
             core.ptr(mean), core.ptr(rstd), rows, D, eps, p_drop if r2 is not None else 0.0, seed,
-            core.seed_ptr() if seed else None, core.stream()),
+            core.seed_ptr() if seed else None, core.ptr(pos2), pos2.shape[0] if pos2 is not None else 0, core.ptr(ypos), core.stream()),
             'layernorm_fwd')
         ctx.save_for_backward(z, mean, rstd, g)
         ctx.cfg = (x.shape, r is not None, p_drop if r2 is not None else 0.0, seed, D)
         ctx.params = (gamma, beta)
+        if pos is not None:
+            return y.reshape(x.shape), ypos.reshape(x.shape)
         return y.reshape(x.shape)
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, dypos=None):
         z, mean, rstd, g = ctx.saved_tensors
         xshape, has_r, p_drop, seed, D = ctx.cfg
+        if dy is None and dypos is None:
+            return (None,) * 7
+        if dy is None:
+            dy, dypos = dypos, None
         dy2 = core.f32c(dy.reshape(-1, D))
+        dyp = core.f32c(dypos.reshape(-1, D)) if dypos is not None else None
         rows = dy2.shape[0]
         need_x, need_r = ctx.needs_input_grad[0], has_r and ctx.needs_input_grad[1]
         need_g = ctx.needs_input_grad[2] or ctx.needs_input_grad[3]
@@ -48,15 +58,17 @@ class _AddLnFn(torch.autograd.Function):
         else:
             dgamma = torch.zeros(D, device=dy2.device, dtype=torch.float32) if need_g else None
             dbeta = torch.zeros(D, device=dy2.device, dtype=torch.float32) if need_g else None
-        core.check(core.lib().ldetr_layernorm_bwd_f32(
-            core.ptr(dy2), core.ptr(z), core.ptr(mean), core.ptr(rstd), core.ptr(g), core.ptr(dx),
+        core.check(core.lib().ldetr_layernorm_bwd2_f32(
+            core.ptr(dy2), core.ptr(dyp), core.ptr(z), core.ptr(mean), core.ptr(rstd), core.ptr(g), core.ptr(dx),
             core.ptr(dr) if (need_r and p_drop > 0) else None, core.ptr(dgamma), core.ptr(dbeta), rows, D, p_drop, seed,
             core.seed_ptr() if p_drop > 0 else None, core.stream()), 'layernorm_bwd')
         if fused:
             dgamma = dbeta = None
-        return (dx.reshape(xshape) if need_x else None, dr.reshape(xshape) if need_r else None, dgamma, dbeta, None, None)
+        return (dx.reshape(xshape) if need_x else None, dr.reshape(xshape) if need_r else None, dgamma, dbeta, None, None, None)
 
 
-def add_layernorm(x, residual, gamma, beta, eps=1e-5, p_drop=0.0):
-    """LayerNorm(x + dropout(residual)); residual may be None (plain LayerNorm)."""
-    return _AddLnFn.apply(x, residual, gamma, beta, eps, p_drop)
+def add_layernorm(x, residual, gamma, beta, eps=1e-5, p_drop=0.0, pos=None):
+    """LayerNorm(x + dropout(residual)); residual may be None (plain LayerNorm).
+    pos ([S, D], rows broadcast over the batch): returns (y, y + pos) — the second tensor is what the next attention block projects
+    q / k from, produced by the same launch instead of a separate add; its gradient is summed inside the backward launch."""
+    return _AddLnFn.apply(x, residual, gamma, beta, eps, p_drop, pos)

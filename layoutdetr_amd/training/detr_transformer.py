@@ -26,11 +26,12 @@ class _MHAParams(nn.MultiheadAttention):
         raise RuntimeError('use layoutdetr_amd.hip.attention.mha_forward')
 
 
-def _mha(m: nn.MultiheadAttention, q2, k2, v2, B, Lq, Lk, kpm, training, same_qk=False, same_qkv=False, qk_pos=None):
-    """-> (attention block output, alias of q2 to feed the residual branch from)."""
+def _mha(m: nn.MultiheadAttention, q2, k2, v2, B, Lq, Lk, kpm, training, same_qk=False, same_qkv=False, qk_pos=None, qk_in=None, kv_alias=False):
+    """-> (attention block output, alias of q2 to feed the residual branch from[, aliases of k2 and v2])."""
     p = m.dropout if training else 0.0
     return mha_forward(q2, k2, v2, m.in_proj_weight, m.in_proj_bias, m.out_proj.weight, m.out_proj.bias, m.num_heads,
-                       B, Lq, Lk, key_padding_mask=kpm, p_drop=p, same_qk=same_qk, same_qkv=same_qkv, qk_pos=qk_pos, passthru=True)
+                       B, Lq, Lk, key_padding_mask=kpm, p_drop=p, same_qk=same_qk, same_qkv=same_qkv, qk_pos=qk_pos, passthru=True,
+                       qk_in=qk_in, kv_alias=kv_alias)
 
 
 def _mask_u8(kpm):
@@ -45,8 +46,8 @@ def _ffn(layer, x2):
     return linear(h, layer.linear2.weight, layer.linear2.bias), x2
 
 
-def _add_ln(norm: nn.LayerNorm, x2, r2, drop: nn.Dropout, training):
-    return add_layernorm(x2, r2, norm.weight, norm.bias, norm.eps, drop.p if training else 0.0)
+def _add_ln(norm: nn.LayerNorm, x2, r2, drop: nn.Dropout, training, pos=None):
+    return add_layernorm(x2, r2, norm.weight, norm.bias, norm.eps, drop.p if training else 0.0, pos=pos)
 
 
 class TransformerEncoderLayer(nn.Module):
@@ -64,11 +65,12 @@ class TransformerEncoderLayer(nn.Module):
         self.dropout2 = nn.Dropout(dropout)
         self.normalize_before = normalize_before
 
-    def forward2d(self, x2, B, L, kpm, pos2):
-        a, x2 = _mha(self.self_attn, x2, x2, x2, B, L, L, kpm, self.training, same_qk=pos2 is not None, same_qkv=pos2 is None, qk_pos=pos2)
+    def forward2d(self, x2, B, L, kpm, pos2, xpos2=None, emit_pos=False):
+        """xpos2: x2 + pos2 when the producer already formed it (the previous layer's norm2 emits it: emit_pos) -> (y2[, y2 + pos2])."""
+        a, x2 = _mha(self.self_attn, x2, x2, x2, B, L, L, kpm, self.training, same_qk=pos2 is not None, same_qkv=pos2 is None, qk_pos=pos2, qk_in=xpos2)
         x2 = _add_ln(self.norm1, x2, a, self.dropout1, self.training)
         f, x2 = _ffn(self, x2)
-        return _add_ln(self.norm2, x2, f, self.dropout2, self.training)
+        return _add_ln(self.norm2, x2, f, self.dropout2, self.training, pos=pos2 if emit_pos else None)
 
 
 class TransformerDecoderLayer(nn.Module):
@@ -90,12 +92,13 @@ class TransformerDecoderLayer(nn.Module):
         self.normalize_before = normalize_before
 
     def forward2d(self, t2, mem2, mem_pos2, B, Lq, S, tgt_kpm, mem_kpm):
+        """-> (t2, alias of mem2, alias of mem_pos2): the next layer reads the memory through the aliases (mha_forward kv_alias)."""
         a, t2 = _mha(self.self_attn, t2, t2, t2, B, Lq, Lq, tgt_kpm, self.training, same_qkv=True)
         t2 = _add_ln(self.norm1, t2, a, self.dropout1, self.training)
-        a, t2 = _mha(self.multihead_attn, t2, mem_pos2, mem2, B, Lq, S, mem_kpm, self.training)
+        a, t2, mem_pos2, mem2 = _mha(self.multihead_attn, t2, mem_pos2, mem2, B, Lq, S, mem_kpm, self.training, kv_alias=True)
         t2 = _add_ln(self.norm2, t2, a, self.dropout2, self.training)
         f, t2 = _ffn(self, t2)
-        return _add_ln(self.norm3, t2, f, self.dropout3, self.training)
+        return _add_ln(self.norm3, t2, f, self.dropout3, self.training), mem2, mem_pos2
 
 
 def _get_clones(module, N):
@@ -109,12 +112,24 @@ class TransformerEncoder(nn.Module):
         self.num_layers = num_layers
         self.norm = norm
 
-    def forward2d(self, x2, B, L, kpm, pos2):
+    def forward2d(self, x2, B, L, kpm, pos2, want_pos=False):
+        """want_pos (with pos2): also return x_out + pos2 (the decoder's cross-attention key input, detr_transformer.py:277), formed by
+        the last layer's LayerNorm launch.  Between layers the position-embedded copy comes from the previous layer's norm2 as well:
+        one add launch per stack (the first layer's input) instead of one per layer."""
         kpm = _mask_u8(kpm)   # one conversion per stack, not one per attention launch
-        for layer in self.layers:
-            x2 = layer.forward2d(x2, B, L, kpm, pos2)
+        xpos2 = None
+        n = len(self.layers)
+        for i, layer in enumerate(self.layers):
+            emit = pos2 is not None and (i + 1 < n or (want_pos and self.norm is None))
+            if pos2 is not None and xpos2 is None:
+                xpos2 = x2 + pos2
+            r = layer.forward2d(x2, B, L, kpm, pos2, xpos2=xpos2, emit_pos=emit)
+            x2, xpos2 = r if emit else (r, None)
         if self.norm is not None:
-            x2 = add_layernorm(x2, None, self.norm.weight, self.norm.bias, self.norm.eps)
+            r = add_layernorm(x2, None, self.norm.weight, self.norm.bias, self.norm.eps, pos=pos2 if want_pos else None)
+            x2, xpos2 = r if (want_pos and pos2 is not None) else (r, None)
+        if want_pos:
+            return x2, (xpos2 if xpos2 is not None else x2 + pos2)
         return x2
 
 
@@ -128,11 +143,12 @@ class TransformerDecoder(nn.Module):
         self.norm = norm
         self.return_intermediate = return_intermediate
 
-    def forward2d(self, t2, mem2, pos2, B, Lq, S, tgt_kpm, mem_kpm):
+    def forward2d(self, t2, mem2, pos2, B, Lq, S, tgt_kpm, mem_kpm, mem_pos2=None):
         tgt_kpm, mem_kpm = _mask_u8(tgt_kpm), _mask_u8(mem_kpm)
-        mem_pos2 = mem2 + pos2
+        if mem_pos2 is None:
+            mem_pos2 = mem2 + pos2
         for layer in self.layers:
-            t2 = layer.forward2d(t2, mem2, mem_pos2, B, Lq, S, tgt_kpm, mem_kpm)
+            t2, mem2, mem_pos2 = layer.forward2d(t2, mem2, mem_pos2, B, Lq, S, tgt_kpm, mem_kpm)
         if self.norm is not None:
             t2 = add_layernorm(t2, None, self.norm.weight, self.norm.bias, self.norm.eps)
         return t2
@@ -179,13 +195,13 @@ class Transformer(nn.Module):
         pos2, _ = _rows_from_nchw(pos_embed)
         pos2 = pos2.contiguous()
         mem_kpm = mask.flatten(1)
-        mem2 = self.encoder.forward2d(x2, bs, S, mem_kpm, pos2)
+        mem2, mem_pos2 = self.encoder.forward2d(x2, bs, S, mem_kpm, pos2, want_pos=True)
         if self._with_token:
             tgt = torch.cat([self.token.expand(-1, bs, -1), tgt], dim=0)
             tgt_key_padding_mask = torch.cat([self.token_mask.expand(bs, -1), tgt_key_padding_mask], dim=1)
         Lq = tgt.shape[0]
         t2 = tgt.permute(1, 0, 2).reshape(bs * Lq, c)
-        hs2 = self.decoder.forward2d(t2, mem2, pos2, bs, Lq, S, tgt_key_padding_mask, mem_kpm)
+        hs2 = self.decoder.forward2d(t2, mem2, pos2, bs, Lq, S, tgt_key_padding_mask, mem_kpm, mem_pos2=mem_pos2)
         hs = hs2.reshape(bs, Lq, c)
         memory = mem2.reshape(bs, h, w, c).permute(0, 3, 1, 2)
         return hs, memory
