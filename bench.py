@@ -312,6 +312,21 @@ def run(args, rank, local_rank, world):
                         traffic=None, launches_per_step=launches // 2, algorithmic_gflop_per_step=round(fl / 2 / 1e9, 2),
                         engine_ms_per_step=round(sec / 2 * 1e3, 3), engine_ms_per_step_uncorrected=round(sec_raw / 2 * 1e3, 3),
                         event_pair_overhead_us=round(ev_over_ms * 1e3, 2), by_entry=by_entry)
+        # HBM traffic of the engine from the PMC counters (FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 passes over the same step, eager):
+        # measured offline with tools/pmc_step.py (rocprofv3 cannot wrap this process from inside) and committed; per launch, like `achieved`
+        pmc_path = os.path.join(ROOT, 'profiles', 'r02_pmc_traffic.json')
+        if os.path.exists(pmc_path) and args.bg == 256 and b_local == 16 and args.text_mode == 'features':
+            pmc = json.load(open(pmc_path))
+            roofline['traffic'] = round(pmc['engine_bytes_per_launch'])
+            roofline['traffic_unit'] = 'HBM bytes per engine launch (mean over the step)'
+            roofline['traffic_gb_per_step'] = round((pmc['engine_total']['fetch'] + pmc['engine_total']['write']) / 1e9, 2)
+            roofline['traffic_source'] = 'profiles/r02_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, tools/pmc_step.py)'
+        try:    # the fractions north_star names, each as its own entry (HBM-bound kernels, modulated-conv layer at 256x256, DETR cross-attention)
+            sys.path.insert(0, os.path.join(ROOT, 'tools'))
+            import bench_hbm_kernels
+            roofline['kernels'] = bench_hbm_kernels.measure_named(16)
+        except Exception as err:   # a reporting leg: never fail the bench line for it
+            roofline['kernels'] = f'unavailable: {err!r}'
 
     if rank == 0:
         cpu = None

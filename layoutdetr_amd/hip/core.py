@@ -48,6 +48,7 @@ def engine_call(tag, flops, thunk):
     return r
 
 
+
 _workspace = {}
 WORKSPACE_BYTES = int(os.environ.get('LDETR_WORKSPACE_MIB', '256')) << 20   # split-K scratch per device
 

@@ -57,6 +57,59 @@ def measure(B=16):
     return out
 
 
+def measure_named(B=16):
+    """The fractions north_star names, each as its own roofline entry: HBM fraction of the HBM-bound kernels (FIR, bias_act, Adam, EMA,
+    the fused modulated-conv layer at 256x256) and MFMA utilisation of DETR cross-attention, in-kernel and device-level."""
+    import math
+    from layoutdetr_amd.hip import attention as hattn
+    from layoutdetr_amd.hip import core, modconv
+    dev = torch.device('cuda')
+    HBM, MFMA = 8.0, 157.3
+    out = []
+    for r in measure(B):
+        out.append(dict(kernel=r['kernel'], shape=r['shape'], bound='hbm', achieved=round(r['tbps'], 3), peak=HBM, unit='TB/s', frac=round(r['tbps'] / HBM, 4),
+                        algorithmic_bytes=r['bytes'], us=round(r['us'], 1)))
+    # fused modulated 3x3 conv layer at 256x256, 32 -> 32 channels (styles in the loader, demodulation + bias + lrelu in the epilogue): ONE launch;
+    # algorithmic bytes 4 (Cin r^2 + Cout r^2) per sample (SURVEY 8d); it is MFMA-bound (N = 32), so both fractions are given
+    C, R = 32, 256
+    x = torch.randn(B, R, R, C, device=dev); w = torch.randn(C, C, 3, 3, device=dev).contiguous(memory_format=torch.channels_last)
+    st = torch.rand(B, C, device=dev) + 0.5; bias = torch.randn(C, device=dev)
+    with torch.no_grad():
+        t = timed(lambda: modconv.modconv3x3(x, w, st, bias))
+    nbytes, fl = 4 * 2 * B * R * R * C, 2.0 * B * R * R * C * C * 9
+    out.append(dict(kernel='modulated conv3x3 layer fwd (1 launch + demod coefficients)', shape=f'{B}x{C}->{C}x{R}x{R}', bound='mfma', achieved=round(fl / t / 1e12, 2), peak=MFMA,
+                    unit='TFLOP/s', frac=round(fl / t / 1e12 / MFMA, 4), algorithmic_bytes=nbytes, hbm_tbps=round(nbytes / t / 1e12, 3), hbm_frac=round(nbytes / t / 1e12 / HBM, 4),
+                    us=round(t * 1e6, 1), note='N = 32 output channels: MFMA-bound (123 us at the f32 matrix peak vs 34 us at 8 TB/s); hbm_frac is what the north_star target reads'))
+    # optimiser: fused sanitize + Adam over (p, g, m, v) = 28 B per parameter; EMA lerp = 12 B per parameter (SURVEY 8d), at D's parameter count
+    P = 89928156
+    pbuf, g, m, vv, pe = (torch.randn(P, device=dev) * 0.01 for _ in range(5))
+    vv.abs_()
+    L = core.lib()
+    t = timed(lambda: core.check(L.ldetr_adam_step_f32(core.ptr(pbuf), core.ptr(g), core.ptr(m), core.ptr(vv), P, 3, 1e-5, 0.0, 0.99, 1e-8, 1, 1.0, 0.0, 1e5, -1e5, core.stream())), reps=5)
+    out.append(dict(kernel='adam_kernel (+ /world + nan_to_num)', shape=f'{P} params', bound='hbm', achieved=round(28.0 * P / t / 1e12, 3), peak=HBM, unit='TB/s', frac=round(28.0 * P / t / 1e12 / HBM, 4),
+                    algorithmic_bytes=28 * P, us=round(t * 1e6, 1)))
+    t = timed(lambda: core.check(L.ldetr_ema_lerp_f32(core.ptr(pe), core.ptr(pbuf), P, 0.999, core.stream())), reps=5)
+    out.append(dict(kernel='ema_kernel', shape=f'{P} params', bound='hbm', achieved=round(12.0 * P / t / 1e12, 3), peak=HBM, unit='TB/s', frac=round(12.0 * P / t / 1e12 / HBM, 4),
+                    algorithmic_bytes=12 * P, us=round(t * 1e6, 1)))
+    del pbuf, g, m, vv, pe
+    # DETR cross-attention (decoder layer, detr_transformer.py:277-280): (8B, Lq=9, S=64, dh=32)
+    H, Lq, S, dh = 8, 9, 64, 32
+    q = torch.randn(B * Lq, H * dh, device=dev); k = torch.randn(B * S, H * dh, device=dev); v = torch.randn(B * S, H * dh, device=dev)
+    with torch.no_grad():
+        t = timed(lambda: hattn.attention(q, k, v, None, B, H, Lq, S, 0.0))
+    fl = 4.0 * Lq * S * dh * B * H
+    # in-kernel: one wave per (b, h, 16-query tile) issues (S/16)(dh/4) MFMAs for K Q^T and as many for P V, v_mfma_f32_16x16x4_f32 at 32 cycles per SIMD issue
+    mfma_cycles = 2 * (S // 16) * (dh // 4) * 32
+    out.append(dict(kernel='DETR cross-attention fwd (attn_fwd_kernel)', shape=f'(b*h={B * H}, Lq={Lq}, Lk={S}, dh={dh})', bound='latency', achieved=round(fl / t / 1e12, 4), peak=MFMA, unit='TFLOP/s',
+                    frac=round(fl / t / 1e12 / MFMA, 6), us=round(t * 1e6, 2), mfma_util_device=round(fl / t / 1e12 / MFMA, 6),
+                    mfma_util_in_kernel=round(mfma_cycles / (t * 2.4e9), 4),
+                    note='1.2 MFLOP per sample and layer on 128 waves: launch / latency-bound at any utilisation (SURVEY 7); in-kernel = MFMA issue cycles of a wave / kernel duration at 2.4 GHz'))
+    return out
+
+
 if __name__ == '__main__':
     for r in measure():
         print(f"{r['kernel']:32s} {r['shape']:18s} {r['bytes'] / 1e6:8.1f} MB {r['us']:8.1f} us {r['tbps']:6.2f} TB/s ({r['tbps'] / 8.0:.2f} of 8 TB/s)")
+    import json
+    for r in measure_named()[-2:]:
+        print(json.dumps(r))
