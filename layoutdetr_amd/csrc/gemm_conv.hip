@@ -19,6 +19,8 @@
 #include "../../include/ldetr_hip.h"
 
 namespace ldetr {
+int try_launch_wgrad_smallc(const float* x, const ldetr_tensor4* xt, const float* dy, const ldetr_tensor4* dyt, float* dw, int KH, int KW, int stride, int pad,
+                            const float* x_scale, int64_t x_scale_ld, const float* dy_scale, int64_t dy_scale_ld, hipStream_t st);
 
 enum {
     OP_KC_DENSE = 0,  // (row r, k): src[r*ld + k]
@@ -1896,6 +1898,10 @@ extern "C" int ldetr_conv2d_bwd_weight_f32(const float* x, const ldetr_tensor4* 
     p.splitk = splitk; p.pstep = 1; p.nsamp = xt->N; p.pix_per_sample = 0;
     long wsz = (long)Cout * KH * KW * Cin;
     if (!accumulate) { if (int zrc = zero_fill(dw, wsz, wsz, 1, st)) return zrc; }
+    if (!gather) {   // 32 -> 32 channels on a large grid: the LDS-free operand-streaming kernel (wgrad_smallc.hip)
+        const int took = try_launch_wgrad_smallc(x, xt, dy, dyt, dw, KH, KW, stride, pad, x_scale, x_scale_ld, dy_scale, dy_scale_ld, st);
+        if (took != 0) return took > 0 ? LDETR_OK : LDETR_ERR_LAUNCH;
+    }
     if (splitk == 1 && accumulate) p.ep.accumulate = 1;
     if (gather) {
         // 3-channel (or strided-channel) input, e.g. the ResNet stem on an NCHW image: a single GEMM with
