@@ -1548,7 +1548,9 @@ static int launch_gemm(GemmParams& p, int Mmax, long out_rows, int zbase, bool a
         // mid-size problems (ResNet layer2-4 at batch 16): the 8-wave 128x64 tile with the reduction split until its grid fills the
         // chip beats the 4-wave 64x64 tile, as long as every slice keeps >= 512 of K
         const int sk = (int)((512 + t12864 - 1) / t12864);
-        if (sk >= 2 && sk <= 8 && p.K / sk >= 512) { use12864 = true; p.splitk = sk; }
+        static const int split_min_k = getenv("LDETR_SPLIT_MIN_K") ? atoi(getenv("LDETR_SPLIT_MIN_K")) : 512;
+        static const int split_max = getenv("LDETR_SPLIT_MAX") ? atoi(getenv("LDETR_SPLIT_MAX")) : 8;
+        if (sk >= 2 && sk <= split_max && p.K / sk >= split_min_k) { use12864 = true; p.splitk = sk; }
     }
     if (!use128 && !use12864 && auto_split && p.splitk <= 1 && t64 < 768 && !(p.ep.accumulate && !epilogue_is_linear(p.ep))) {
         // PMC: with <= 2 resident blocks per CU the single-accumulator waves leave the MFMA pipe ~55% idle; more, shorter blocks fill it
@@ -1632,21 +1634,25 @@ static int launch_gemm(GemmParams& p, int Mmax, long out_rows, int zbase, bool a
 // first (128-wide tiles when the channel counts allow them: two accumulator chains per wave, fewer LDS reads per MFMA),
 // then split K until that tile's grid fills the chip.  Mirrors the tile thresholds of launch_gemm.
 static int wgrad_auto_split(int M, int N, int K, int zbase) {
+    // few pixels (small per-GPU batches): shorter slices keep the chip busy; the floor of a weight-gradient launch is its serial k-loop
+    // (measured: 128-pixel slices help at 2 samples per GPU, 25.3 -> 24.8 ms per step, and cost 4 % at 16 per GPU: keyed on the launch's work)
+    static const int small_min_k = getenv("LDETR_WGRAD_SMALL_MIN_K") ? atoi(getenv("LDETR_WGRAD_SMALL_MIN_K")) : 128;
+    const int WMINK = ((double)M * N * K * zbase < 6e8) ? small_min_k : WGRAD_MIN_K;
     auto pick = [&](long tiles, long target, int min_k) {
         long s = (target + tiles - 1) / tiles, maxs = K / min_k;
         if (s > maxs) s = maxs;
         return (int)(s < 1 ? 1 : s);
     };
     if (M >= 128 && N >= 128) {
-        long t = (long)cdiv(M, 128) * cdiv(N, 128) * zbase; int s = pick(t, 512, WGRAD_MIN_K);
+        long t = (long)cdiv(M, 128) * cdiv(N, 128) * zbase; int s = pick(t, 512, WMINK);
         if (t * s >= 384) return s;
     }
     if (M >= 128) {
-        long t = (long)cdiv(M, 128) * cdiv(N, 64) * zbase; int s = pick(t, 768, WGRAD_MIN_K);
+        long t = (long)cdiv(M, 128) * cdiv(N, 64) * zbase; int s = pick(t, 768, WMINK);
         if (t * s >= 512) return s;
     }
     long t = (long)cdiv(M, 64) * cdiv(N, 64) * zbase;
-    return pick(t, 768, WGRAD_MIN_K);
+    return pick(t, 768, WMINK);
 }
 
 // Per-sample operand scales of a weight gradient -> sample-aligned K slices (see GemmParams::samp_pix).  `want` = split the

@@ -51,7 +51,9 @@ class _LinearFn(torch.autograd.Function):
         ctx.set_materialize_grads(False)
         r0, r1 = rows if rows is not None else (0, weight.shape[0])   # row range of a packed weight (MHA in_proj)
         N, K = r1 - r0, weight.shape[1]
-        x2 = core.f32c(x.reshape(-1, K))
+        x2 = x.reshape(-1, K)
+        if not (x2.dtype == torch.float32 and x2.stride(1) == 1 and x2.stride(0) >= K and x2.stride(0) % 4 == 0 and x2.data_ptr() % 16 == 0):
+            x2 = core.f32c(x2)        # (rows with a pitch, e.g. ws[:, i] of the StyleGAN2 mapping output or the layout token x[0], go to the GEMM as they are: lda)
         if add_input is not None:          # y = f((x + add_input) W^T): the position embedding of q/k (no gradient for it)
             x2 = x2 + add_input.reshape(-1, K)
         w = core.f32c(weight.detach()[r0:r1])

@@ -33,7 +33,7 @@ from ..hip import core
 from ..hip.linear import linear
 from .detr_backbone import Backbone, Joiner
 from .detr_position_encoding import PositionEmbeddingSine
-from .detr_transformer import Transformer, TransformerEncoder, TransformerEncoderLayer, TransformerWithToken
+from .detr_transformer import Transformer, TransformerEncoder, TransformerEncoderLayer, TransformerWithToken, mask_scope
 from .networks_stylegan2 import Decoder
 from .util import TransformerWithToken_layoutganpp, encode_seq_first
 
@@ -245,6 +245,10 @@ class Generator(nn.Module):
         self.fc_text_len_rec = Linear(hidden_dim, max_text_length)
 
     def forward(self, z, bbox_class, bbox_real, bbox_text, bbox_patch, padding_mask, background, c, reconst=False):
+        with mask_scope():
+            return self._forward(z, bbox_class, bbox_real, bbox_text, bbox_patch, padding_mask, background, c, reconst)
+
+    def _forward(self, z, bbox_class, bbox_real, bbox_text, bbox_patch, padding_mask, background, c, reconst=False):
         if isinstance(background, (list, torch.Tensor)):
             background = nested_tensor_from_tensor_list(background)
         bg_feat, pos = self.backbone(background)
@@ -392,6 +396,10 @@ class Discriminator(nn.Module):
         return bbox_pred, logit_cls, loss_lm, loss_text_len, bg_rec, bbox_pred_uncond, logit_cls_uncond
 
     def forward(self, bbox, bbox_class, bbox_text, bbox_patch, padding_mask, background, c, reconst=False, trunk_out=None):
+        with mask_scope():
+            return self._forward(bbox, bbox_class, bbox_text, bbox_patch, padding_mask, background, c, reconst, trunk_out)
+
+    def _forward(self, bbox, bbox_class, bbox_text, bbox_patch, padding_mask, background, c, reconst=False, trunk_out=None):
         bg_feat, pos = self.trunk(background) if trunk_out is None else trunk_out
         bg_feat, mask = bg_feat[-1].decompose()
         assert mask is not None
@@ -407,7 +415,11 @@ class Discriminator(nn.Module):
             return logit_disc, logit_disc_uncond
         return (logit_disc, logit_disc_uncond) + self._reconstruct(x0, x0_uncond, bbox_text, text_len, padding_mask, B, N)
 
-    def forward_pair(self, bbox_fake, bbox_real, bbox_class, bbox_text, bbox_patch, padding_mask, background, c, trunk_out=None):
+    def forward_pair(self, *args, **kwargs):
+        with mask_scope():
+            return self._forward_pair(*args, **kwargs)
+
+    def _forward_pair(self, bbox_fake, bbox_real, bbox_class, bbox_text, bbox_patch, padding_mask, background, c, trunk_out=None):
         """D(bbox_fake) and D(bbox_real, reconst=True) of the SAME layouts' conditions in one pass — what phase Dmain evaluates with two
         calls (training/loss.py:149,165).  The samples of a batch are independent (FrozenBatchNorm, no batch statistics), so the two
         score paths run as ONE batch of 2B layouts: trunk, input_proj, label / text embeddings and the text encoder are evaluated
