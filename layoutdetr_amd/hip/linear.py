@@ -55,6 +55,8 @@ class _LinearFn(torch.autograd.Function):
         if not (x2.dtype == torch.float32 and x2.stride(1) == 1 and x2.stride(0) >= K and x2.stride(0) % 4 == 0 and x2.data_ptr() % 16 == 0):
             x2 = core.f32c(x2)        # (rows with a pitch, e.g. ws[:, i] of the StyleGAN2 mapping output or the layout token x[0], go to the GEMM as they are: lda)
         if add_input is not None:          # y = f((x + add_input) W^T): the position embedding of q/k (no gradient for it)
+            if add_input.requires_grad:
+                raise RuntimeError('linear: add_input is a constant (the sine position embedding); a learned embedding must be added by the caller')
             x2 = x2 + add_input.reshape(-1, K)
         w = core.f32c(weight.detach()[r0:r1])
         b = core.f32c(bias.detach()[r0:r1]) if bias is not None else None

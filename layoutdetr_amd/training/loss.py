@@ -59,7 +59,9 @@ class _TrunkFork(object):
         self.side = None
         if enabled and background.is_cuda:
             main = torch.cuda.current_stream()
-            self.side = _TrunkFork.streams.setdefault(main.device.index, torch.cuda.Stream(device=main.device))
+            if main.device.index not in _TrunkFork.streams:      # (setdefault would build a new stream on every call)
+                _TrunkFork.streams[main.device.index] = torch.cuda.Stream(device=main.device)
+            self.side = _TrunkFork.streams[main.device.index]
             self.side.wait_stream(main)
             with torch.cuda.stream(self.side):
                 self.out = D.trunk(background)
@@ -68,7 +70,12 @@ class _TrunkFork(object):
 
     def join(self):
         if self.side is not None:
-            torch.cuda.current_stream().wait_stream(self.side)
+            main = torch.cuda.current_stream()
+            main.wait_stream(self.side)
+            for f in self.out[0]:                 # allocated on the side stream, consumed on the main one: tell the allocator
+                f.tensors.record_stream(main)
+            for q in self.out[1]:
+                q.record_stream(main)
             self.side = None
         return self.out
 
@@ -238,6 +245,8 @@ class StyleGAN2Loss(Loss):
 
     def accumulate_gradients(self, phase, bbox_real, bbox_class, bbox_text, bbox_patch, padding_mask, background, real_c, gen_z, gen_c, gain, cur_nimg):
         assert phase in ['Gmain', 'Greg', 'Gboth', 'Dmain', 'Dreg', 'Dboth']
+        if self.share_D_trunk != 'iteration':
+            self._trunk_cache.clear()          # nothing is carried across phases unless the iteration driver parked a trunk for this iteration
         if self.pl_weight == 0:
             phase = {'Greg': 'none', 'Gboth': 'Gmain'}.get(phase, phase)
         if self.r1_gamma == 0:

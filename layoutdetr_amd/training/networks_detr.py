@@ -210,6 +210,14 @@ def _text_inputs(module, bbox_text, B, N, device):
     raise NotImplementedError('pass TextFeatures (precomputed CLS features) or TextTokens (tokenizer output); strings need the host tokenizer')
 
 
+def _check_background_size(background_size):
+    """The fused attention kernels hold one sample's keys in registers / LDS: at most 256 memory tokens = a 512 x 512 background
+    (stride 32).  The reference's signature default (1024) is kept for compatibility; `train.py` passes 256."""
+    if (background_size // 32) ** 2 > 256:
+        raise NotImplementedError(f'background_size={background_size}: the gfx950 attention kernels support up to 256 image tokens '
+                                  '(backgrounds up to 512 x 512); pass background_size <= 512')
+
+
 def _zero_like_loss(ref):
     return ref.new_full((), 0.0)   # a fill kernel: new_zeros(()) becomes a 4-byte memset node under capture (see DESIGN §6 on memset nodes)
 
@@ -227,6 +235,7 @@ class Generator(nn.Module):
         self.max_text_length = max_text_length
         self.text_mode = text_mode
         self.static_shapes = False   # see module docstring: True = sync-free full-slot outputs (hipGraph-capturable)
+        _check_background_size(background_size)
 
         self.backbone = build_backbone()
         self.input_proj = Conv1x1(self.backbone.num_channels, hidden_dim, kernel_size=1)
@@ -304,6 +313,7 @@ class Discriminator(nn.Module):
         self.max_text_length = max_text_length
         self.text_mode = text_mode
         self.static_shapes = False
+        _check_background_size(background_size)
 
         # encoder
         self.backbone = build_backbone()

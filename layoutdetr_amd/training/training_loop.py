@@ -41,7 +41,10 @@ class FlatModule(object):
 
     def __init__(self, module):
         self.module = module
-        named = list(module.named_parameters())
+        # the frozen text encoder (training_loop.py:283 re-freezes it every phase; text_mode 'encoder': ~110 M weights) stays outside the flat
+        # buffers: no gradient, no Adam moments, no all-reduce and no optimizer traffic for weights that never change (the reference only
+        # flattens parameters whose .grad is not None, :303-305)
+        named = [(n, p) for n, p in module.named_parameters() if not n.startswith('text_encoder.')]
         params = [p for _, p in named]
         self.names = [n for n, _ in named]
         self.params = params
