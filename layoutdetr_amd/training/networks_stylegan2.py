@@ -48,8 +48,6 @@ class FullyConnectedLayer(torch.nn.Module):
         y = linear(x, self.weight, None, wscale=float(self.weight_gain))
         return bias_act.bias_act(y, b, act=self.activation)
 
-    def extra_repr(self):
-        return f'in_features={self.in_features:d}, out_features={self.out_features:d}, activation={self.activation:s}'
 
 
 class SynthesisLayer(torch.nn.Module):
@@ -106,8 +104,6 @@ class ToRGBLayer(torch.nn.Module):
         styles = self.affine(w) * float(self.weight_gain)
         return modconv.torgb(x, self.weight, styles, self.bias)
 
-    def extra_repr(self):
-        return f'in_channels={self.in_channels:d}, out_channels={self.out_channels:d}, w_dim={self.w_dim:d}'
 
 
 class SynthesisBlock(torch.nn.Module):
@@ -159,8 +155,6 @@ class SynthesisBlock(torch.nn.Module):
         img = img + y if img is not None else y
         return x, img
 
-    def extra_repr(self):
-        return f'resolution={self.resolution:d}, architecture={self.architecture:s}'
 
 
 class SynthesisNetwork(torch.nn.Module):
@@ -189,20 +183,18 @@ class SynthesisNetwork(torch.nn.Module):
             setattr(self, f'b{res}', block)
 
     def forward(self, ws, **block_kwargs):
-        block_ws = []
+        """ws: [B, num_ws, w_dim] (one latent per layer, the reference's form) or [B, w_dim] (the same latent for every layer — what
+        the Decoder's mapping network produces: handed over without materialising the num_ws copies)."""
         ws = ws.to(torch.float32)
-        w_idx = 0
+        x = img = None
+        first = 0
         for res in self.block_resolutions:
             block = getattr(self, f'b{res}')
-            block_ws.append(ws.narrow(1, w_idx, block.num_conv + block.num_torgb))
-            w_idx += block.num_conv
-        x = img = None
-        for res, cur_ws in zip(self.block_resolutions, block_ws):
-            x, img = getattr(self, f'b{res}')(x, img, cur_ws, **block_kwargs)
+            n = block.num_conv + block.num_torgb          # the block's toRGB shares its latent with the next block's first conv
+            cur = ws.unsqueeze(1).expand(-1, n, -1) if ws.ndim == 2 else ws[:, first:first + n]
+            x, img = block(x, img, cur, **block_kwargs)
+            first += block.num_conv
         return img.permute(0, 3, 1, 2)  # [B, 3, R, R] view (channels_last memory)
-
-    def extra_repr(self):
-        return f'w_dim={self.w_dim:d}, num_ws={self.num_ws:d}, img_resolution={self.img_resolution:d}, img_channels={self.img_channels:d}'
 
 
 class DecoderMappingNetwork(torch.nn.Module):
@@ -223,24 +215,27 @@ class DecoderMappingNetwork(torch.nn.Module):
         if num_ws is not None and w_avg_beta is not None:
             self.register_buffer('w_avg', torch.zeros([w_dim]))
 
-    def forward(self, z, truncation_psi=1, truncation_cutoff=None, update_emas=False):
-        x = z.to(torch.float32)
+    def forward(self, z, truncation_psi=1, truncation_cutoff=None, update_emas=False, broadcast=True):
+        """broadcast=False returns w as [B, w_dim] when every layer gets the same latent (no truncation cutoff): SynthesisNetwork takes
+        that form directly.  Semantics of the reference's mapping (networks_stylegan2.py:940-964) otherwise: w_avg tracking under
+        update_emas, truncation towards w_avg, optionally only for the first `truncation_cutoff` layers."""
+        w = z.to(torch.float32)
         for idx in range(self.num_layers):
-            x = getattr(self, f'fc{idx}')(x)
+            w = getattr(self, f'fc{idx}')(w)
         if update_emas and self.w_avg_beta is not None:
-            self.w_avg.copy_(x.detach().mean(dim=0).lerp(self.w_avg, self.w_avg_beta))
-        if self.num_ws is not None:
-            x = x.unsqueeze(1).repeat([1, self.num_ws, 1])
-        if truncation_psi != 1:
+            self.w_avg.copy_(torch.lerp(w.detach().mean(dim=0), self.w_avg, self.w_avg_beta))
+        per_layer = truncation_psi != 1 and self.num_ws is not None and truncation_cutoff is not None
+        if truncation_psi != 1 and not per_layer:
             assert self.w_avg_beta is not None
-            if self.num_ws is None or truncation_cutoff is None:
-                x = self.w_avg.lerp(x, truncation_psi)
-            else:
-                x[:, :truncation_cutoff] = self.w_avg.lerp(x[:, :truncation_cutoff], truncation_psi)
-        return x
-
-    def extra_repr(self):
-        return f'z_dim={self.z_dim:d}, w_dim={self.w_dim:d}, num_ws={self.num_ws:d}'
+            w = torch.lerp(self.w_avg, w, truncation_psi)
+        if self.num_ws is None or (not broadcast and not per_layer):
+            return w
+        ws = w.unsqueeze(1).repeat([1, self.num_ws, 1])
+        if per_layer:
+            assert self.w_avg_beta is not None
+            head = torch.lerp(self.w_avg, ws[:, :truncation_cutoff], truncation_psi)
+            ws = torch.cat([head, ws[:, truncation_cutoff:]], dim=1)
+        return ws
 
 
 class Decoder(torch.nn.Module):
@@ -256,5 +251,5 @@ class Decoder(torch.nn.Module):
         self.mapping = DecoderMappingNetwork(z_dim=z_dim, w_dim=w_dim, num_ws=self.num_ws, **mapping_kwargs)
 
     def forward(self, z, truncation_psi=1, truncation_cutoff=None, update_emas=False, **synthesis_kwargs):
-        ws = self.mapping(z, truncation_psi=truncation_psi, truncation_cutoff=truncation_cutoff, update_emas=update_emas)
+        ws = self.mapping(z, truncation_psi=truncation_psi, truncation_cutoff=truncation_cutoff, update_emas=update_emas, broadcast=False)
         return self.synthesis(ws, update_emas=update_emas, **synthesis_kwargs)

@@ -661,3 +661,27 @@ if world > 1:
         a, b = outs[0][k], outs[1][k]
         agree = torch.isclose(a, b, rtol=1e-4, atol=2e-5).float().mean().item()
         assert agree >= 0.99, f'{k}: only {agree:.4f} of the parameters agree between 1 rank x 4 and 2 ranks x 2'
+
+
+def test_decoder_mapping_latent_forms_and_truncation(dev):
+    """The Decoder hands its mapping output to the synthesis network as ONE [B, w_dim] latent (no num_ws copies); the reference's
+    [B, num_ws, w_dim] form, truncation towards w_avg and the per-layer cutoff (networks_stylegan2.py:951-964) give the same images."""
+    from layoutdetr_amd.training.networks_stylegan2 import Decoder
+    torch.manual_seed(8)
+    m = Decoder(z_dim=32, w_dim=32, img_resolution=16, img_channels=3, use_noise=False, channel_base=256, channel_max=32, num_fp16_res=0,
+                conv_clamp=None, fused_modconv_default=False).to(dev).eval()
+    m.mapping.w_avg.copy_(torch.randn(32, device=dev) * 0.3)
+    z = torch.randn(3, 32, device=dev)
+    with torch.no_grad():
+        w = m.mapping(z, broadcast=False); ws = m.mapping(z)
+        assert w.shape == (3, 32) and ws.shape == (3, m.num_ws, 32) and torch.equal(ws[:, 2], w)
+        img = m(z)
+        check(m.synthesis(ws), img, 1e-6, 'broadcast latent form')
+        wt = m.mapping.w_avg + 0.7 * (w - m.mapping.w_avg)
+        check(m(z, truncation_psi=0.7), m.synthesis(wt), 1e-5, 'truncation')
+        cut = m.mapping(z, truncation_psi=0.7, truncation_cutoff=3)
+        check(cut[:, :3], wt.unsqueeze(1).expand(-1, 3, -1), 1e-5, 'cutoff head'); assert torch.equal(cut[:, 3:], ws[:, 3:])
+        check(m(z, truncation_psi=0.7, truncation_cutoff=3), m.synthesis(cut), 1e-6, 'cutoff images')
+        before = m.mapping.w_avg.clone()
+        m(z, update_emas=True)
+        check(m.mapping.w_avg, w.mean(0).lerp(before, m.mapping.w_avg_beta), 1e-6, 'w_avg tracking')
