@@ -126,18 +126,24 @@ class StyleGAN2Loss(Loss):
     def _bg_key(background):
         return (background.data_ptr(), tuple(background.shape)) if isinstance(background, torch.Tensor) else id(background)
 
-    def precompute_D_trunk(self, background):
-        """Evaluate D's trunk on `background` with gradient tracking and park it for this iteration's phases."""
+    def precompute_D_trunk(self, background, stages=None):
+        """Evaluate D's trunk on `background` with gradient tracking and park it for this iteration's phases.
+        stages: a detr_backbone.BackwardStages that records the trunk's backward cuts (Dmain's staged backward continues from them)."""
         if self.share_D_trunk != 'iteration' or not hasattr(self.D, 'trunk'):
             return
         trunk_params = list(self.D.backbone.parameters())
         was = [p.requires_grad for p in trunk_params]
         for p in trunk_params:
             p.requires_grad_(True)     # the autograd graph is built now, used by Dmain's backward (training_loop.py:282 sets it there)
+        body = self.D.backbone[0].body
         try:
+            if stages is not None:
+                body.stages = stages
             with torch.enable_grad():
                 self._trunk_cache[self._bg_key(background)] = self.D.trunk(background)
         finally:
+            if stages is not None:
+                body.stages = None
             for p, w in zip(trunk_params, was):
                 p.requires_grad_(w)
 

@@ -214,19 +214,21 @@ def _trunk_body(module):
     return bb[0].body if bb is not None and hasattr(bb[0], 'body') else None
 
 
-def staged_backward(loss, phase, dp, run_stage1, between=None, exchange=None):
+def staged_backward(loss, phase, dp, run_stage1, between=None, exchange=None, stages=None):
     """One phase's forward + backward in three stages with the gradient exchange of each finished segment launched behind it
     (DataParallelStep.exchange_async) -> True if the gradients were exchanged here.  `run_stage1()` runs the forward passes and
     `loss.backward()`; `between(i)` (optional) is called after stage i's work has been queued (graph capture boundaries);
-    `exchange(ranges)` replaces the RCCL launch (graph capture: the collectives stay outside the graphs)."""
+    `exchange(ranges)` replaces the RCCL launch (graph capture: the collectives stay outside the graphs); `stages`: the
+    BackwardStages that already recorded this phase's trunk cuts (iteration-level D-trunk sharing evaluates D's trunk before the phases)."""
     from .detr_backbone import BackwardStages
     segs = phase.fm.stage_segments()
     body = _trunk_body(phase.module)
     if segs is None or body is None or not hasattr(body, 'stages'):
         run_stage1()
         return False
-    st = BackwardStages()
-    body.stages = st
+    st = stages if stages is not None else BackwardStages()
+    if stages is None:
+        body.stages = st
     if exchange is None:
         exchange = lambda ranges: [dp.exchange_async(phase.fm.gflat, lo, hi) for lo, hi in ranges]
     try:
@@ -255,11 +257,15 @@ def training_iteration(loss, phases, dp, batch, batch_gpu, gen_z_per_phase, ema=
     b = batch['bbox_real'].shape[0]
     core.reseed(batch['bbox_real'].device)   # fresh device-side dropout seed word for this iteration
     iter_share = getattr(loss, 'share_D_trunk', None) == 'iteration' and any(p.name == 'Dmain' for p in phases)
-    if iter_share:
-        for s in range(0, b, batch_gpu):
-            loss.precompute_D_trunk(batch['background'][s:s + batch_gpu])
     if overlap is None:     # overlap the exchange with backward whenever there is an exchange (one micro-batch: the last one is the only one)
         overlap = dp.world > 1
+    d_stages = None
+    if iter_share:
+        if overlap and b <= batch_gpu:
+            from .detr_backbone import BackwardStages
+            d_stages = BackwardStages()
+        for s in range(0, b, batch_gpu):
+            loss.precompute_D_trunk(batch['background'][s:s + batch_gpu], stages=d_stages)
     for phase, gen_z in zip(phases, gen_z_per_phase):
         phase.fm.zero_grad()
         phase.module.requires_grad_(True)
@@ -272,8 +278,8 @@ def training_iteration(loss, phases, dp, batch, batch_gpu, gen_z_per_phase, ema=
                                           bbox_text=batch['bbox_text'][sl], bbox_patch=batch['bbox_patch'][sl],
                                           padding_mask=batch['padding_mask'][sl], background=batch['background'][sl],
                                           real_c=batch['real_c'][sl], gen_z=gen_z[sl], gen_c=batch['gen_c'][sl], gain=1, cur_nimg=cur_nimg)
-        staged = overlap and b <= batch_gpu and not (iter_share and phase.name == 'Dmain')
-        exchanged = staged_backward(loss, phase, dp, accumulate) if staged else (accumulate() or False)
+        staged = overlap and b <= batch_gpu
+        exchanged = staged_backward(loss, phase, dp, accumulate, stages=(d_stages if (iter_share and phase.name == 'Dmain') else None)) if staged else (accumulate() or False)
         phase.module.requires_grad_(False)
         dp.apply(phase, exchanged=True) if exchanged else dp.apply(phase)
     if ema is not None:
@@ -308,13 +314,17 @@ class GraphedIteration(object):
         if overlap is None:
             overlap = dp.world > 1
         pool = torch.cuda.graph_pool_handle() if (iter_share or overlap) else None
+        d_stages = None
         if iter_share:
             # D's trunk forward gets its own graph, replayed before the phases; its activations stay alive in the shared pool until
             # the Dmain graph (captured below, replayed after it) runs the trunk's backward
+            if overlap and b <= batch_gpu:
+                from .detr_backbone import BackwardStages
+                d_stages = BackwardStages()
             self.pre_graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.pre_graph, pool=pool, stream=self.capture_stream):
                 for s in range(0, b, batch_gpu):
-                    loss.precompute_D_trunk(batch['background'][s:s + batch_gpu])
+                    loss.precompute_D_trunk(batch['background'][s:s + batch_gpu], stages=d_stages)
         for phase in phases:
             for m in (loss.G, loss.D):
                 if not getattr(m, 'static_shapes', False):
@@ -322,7 +332,7 @@ class GraphedIteration(object):
             phase.fm.zero_grad()
             phase.module.requires_grad_(True)
             phase.module.text_encoder.requires_grad_(False)
-            staged = overlap and b <= batch_gpu and not (iter_share and phase.name == 'Dmain') and phase.fm.stage_segments() is not None
+            staged = overlap and b <= batch_gpu and phase.fm.stage_segments() is not None
             chain, cur = [], {}
 
             def begin():
@@ -353,7 +363,8 @@ class GraphedIteration(object):
                         end(segs[i - 1])
                         if i < 3:
                             begin()
-                    staged_backward(loss, phase, dp, stage1, between=between, exchange=lambda ranges: None)
+                    staged_backward(loss, phase, dp, stage1, between=between, exchange=lambda ranges: None,
+                                    stages=(d_stages if (iter_share and phase.name == 'Dmain') else None))
                 else:
                     stage1()
                     end(None)

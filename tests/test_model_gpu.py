@@ -546,7 +546,7 @@ def test_graph_replay_with_lm_decoder_survives_allocator_churn(dev, workspace):
 
 
 # ------------------------------------------------------------------------------------------ staged backward / overlapped exchange
-def _iteration_grads(dev, mode, seed=5):
+def _iteration_grads(dev, mode, seed=5, share=True):
     """Gradients of both phases of one iteration at B=2, 64x64 (eval: dropout off).  mode: 'plain' | 'staged' | 'graph-staged'."""
     from layoutdetr_amd.training import training_loop as tl
     from layoutdetr_amd.training.loss import StyleGAN2Loss
@@ -557,7 +557,7 @@ def _iteration_grads(dev, mode, seed=5):
     G.eval().requires_grad_(False).to(dev); D.eval().requires_grad_(False).to(dev)
     G.static_shapes = D.static_shapes = True
     pG = tl.Phase('Gmain', G, lr=0.0); pD = tl.Phase('Dmain', D, lr=0.0)
-    loss = StyleGAN2Loss(dev, G, D)
+    loss = StyleGAN2Loss(dev, G, D, share_D_trunk=share)
     dp = tl.DataParallelStep(world_size=1)
     batch = dict(bbox_real=bt['bbox_real'].to(dev), bbox_class=bt['bbox_class'].to(dev),
                  bbox_text=TextFeatures(bt['text_feat'].to(dev), bt['text_len'].to(dev)), bbox_patch=torch.zeros(2, 9, 1, 1, 1, device=dev),
@@ -604,6 +604,13 @@ def test_staged_backward_equals_plain_backward(dev):
         assert plain[k][1] is False and staged[k][1] is True
         check(staged[k][0], plain[k][0], 2e-4, f'{k} flat gradient, staged vs plain')   # fp32 atomics in the split-K weight gradients: run-to-run ~5e-5
     _iteration_grads(dev, 'graph-staged')
+    # iteration-level D-trunk sharing (D's trunk evaluated once, before the phases): its cuts are recorded there and Dmain's staged
+    # backward continues from them
+    it_staged, _ = _iteration_grads(dev, 'staged', share='iteration')
+    for k in ('Gmain', 'Dmain'):
+        assert it_staged[k][1] is True
+        check(it_staged[k][0], plain[k][0], 2e-4, f'{k} flat gradient, iteration-shared + staged vs plain')
+    _iteration_grads(dev, 'graph-staged', share='iteration')
 
 
 def test_two_rank_sharded_step_equals_one_rank_global_batch(dev):

@@ -17,9 +17,13 @@ def conv(N, H, Ci, Co, k, s, p, what='fwd'):
         return lambda: L.ldetr_conv2d_fwd_f32(core.ptr(x), ctypes.byref(xt), core.ptr(w), Co, k, k, s, p, core.ptr(y), Co, OH, OH, None, 0, ctypes.byref(ep), core.stream())
     return lambda: L.ldetr_conv2d_bwd_data_f32(core.ptr(dy), ctypes.byref(dyt), core.ptr(w), Ci, k, k, s, p, core.ptr(dx), Ci, H, H, None, 0, None, core.stream())
 buf = torch.zeros(5 * 65536, dtype=torch.int64, device=dev)
-for name, args in [('l3 3x3 256->256 fwd', (16, 16, 256, 256, 3, 1, 1, 'fwd')), ('l2 3x3 128->128 fwd', (16, 32, 128, 128, 3, 1, 1, 'fwd')),
+CASES = [('l3 3x3 256->256 fwd', (16, 16, 256, 256, 3, 1, 1, 'fwd')), ('l2 3x3 128->128 fwd', (16, 32, 128, 128, 3, 1, 1, 'fwd')),
                    ('l3 1x1 256->1024 fwd', (16, 16, 256, 1024, 1, 1, 0, 'fwd')), ('l4 1x1 512->2048 bwdD', (16, 8, 512, 2048, 1, 1, 0, 'bwd')),
-                   ('sg 3x3 128->128 @64 fwd', (16, 64, 128, 128, 3, 1, 1, 'fwd'))]:
+                   ('sg 3x3 128->128 @64 fwd', (16, 64, 128, 128, 3, 1, 1, 'fwd'))]
+if len(sys.argv) > 1 and sys.argv[1] == '1x1':
+    CASES = [('l1 1x1 64->256 fwd', (16, 64, 64, 256, 1, 1, 0, 'fwd')), ('l1 1x1 256->64 fwd', (16, 64, 256, 64, 1, 1, 0, 'fwd')), ('l2 1x1 256->128 fwd', (16, 64, 256, 128, 1, 1, 0, 'fwd')),
+             ('l2 1x1 128->512 fwd', (16, 32, 128, 512, 1, 1, 0, 'fwd')), ('l3 1x1 1024->256 fwd', (16, 16, 1024, 256, 1, 1, 0, 'fwd')), ('l2 1x1 256->128 bwdD', (16, 64, 256, 128, 1, 1, 0, 'bwd'))]
+for name, args in CASES:
     f = conv(*args)
     for _ in range(3): f()
     torch.cuda.synchronize()
