@@ -34,7 +34,13 @@ struct AttnParams {
 
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
 
-__device__ __forceinline__ float ldz(const float* p, bool ok) { return ok ? *p : 0.f; }
+// Guarded element load WITHOUT control flow: an `ok ? *p : 0` form makes hipcc wrap every load in its own exec-masked region, and the
+// loads of a key tile then issue one by one, each waited for before its MFMA (encoder self-attention: 16 us for 0.13 GFLOP).  Selecting
+// the ADDRESS (any valid one when out of range) keeps the loads unconditional, so the unrolled tile issues them all at once.
+__device__ __forceinline__ float ldz(const float* p, bool ok, const float* safe) {
+    const float v = *(ok ? p : safe);
+    return ok ? v : 0.f;
+}
 
 // Dropout element index: ((b*H + h)*Lq + q)*Lk + key.
 __device__ __forceinline__ float attn_drop(const AttnParams& p, int bh, int q, int key, float inv_keep) {
@@ -60,7 +66,7 @@ __global__ __launch_bounds__(64) void attn_fwd_kernel(AttnParams p) {
 
     float qf[8 * DHC];
 #pragma unroll
-    for (int kk = 0; kk < 8 * DHC; kk++) qf[kk] = ldz(qp + 4 * kk + g, qok) * p.scale;
+    for (int kk = 0; kk < 8 * DHC; kk++) qf[kk] = ldz(qp + 4 * kk + g, qok, p.q) * p.scale;
 
     f32x4 s[NKT];
     float mx = -INFINITY;
@@ -71,7 +77,7 @@ __global__ __launch_bounds__(64) void attn_fwd_kernel(AttnParams p) {
         const bool kok = krow < p.Lk;
         const float* kp = kb + (long)krow * p.ldk;
 #pragma unroll
-        for (int kk = 0; kk < 8 * DHC; kk++) acc = MFMA16(ldz(kp + 4 * kk + g, kok), qf[kk], acc);
+        for (int kk = 0; kk < 8 * DHC; kk++) acc = MFMA16(ldz(kp + 4 * kk + g, kok, p.q), qf[kk], acc);
 #pragma unroll
         for (int r = 0; r < 4; r++) {
             int key = 16 * j + 4 * g + r;
@@ -107,7 +113,7 @@ __global__ __launch_bounds__(64) void attn_fwd_kernel(AttnParams p) {
             if (p.p_drop > 0.f) pv *= attn_drop(p, bh, qrow, key, inv_keep);
             const float* vp = vb + (long)key * p.ldv;
 #pragma unroll
-            for (int c = 0; c < 2 * DHC; c++) o[c] = MFMA16(ldz(vp + 16 * c + li, kok), pv, o[c]);
+            for (int c = 0; c < 2 * DHC; c++) o[c] = MFMA16(ldz(vp + 16 * c + li, kok, p.q), pv, o[c]);
         }
     }
     if (qok) {
@@ -151,7 +157,7 @@ __global__ __launch_bounds__(256) void attn_fwd_wide_kernel(AttnParams p) {
 
     float qf[8 * DHC];
 #pragma unroll
-    for (int kk = 0; kk < 8 * DHC; kk++) qf[kk] = ldz(qp + 4 * kk + g, qok) * p.scale;
+    for (int kk = 0; kk < 8 * DHC; kk++) qf[kk] = ldz(qp + 4 * kk + g, qok, p.q) * p.scale;
 
     f32x4 s[NKT];
     float mx = -INFINITY;
@@ -239,9 +245,9 @@ __device__ __forceinline__ void attn_bwd_dq(const AttnParams& p, int bh, int qt)
     float delta = 0.f;
 #pragma unroll
     for (int kk = 0; kk < 8 * DHC; kk++) {
-        qf[kk] = ldz(qp + 4 * kk + g, qok) * p.scale;
-        dof[kk] = ldz(dop + 4 * kk + g, qok);
-        delta += dof[kk] * ldz(op + 4 * kk + g, qok);
+        qf[kk] = ldz(qp + 4 * kk + g, qok, p.q) * p.scale;
+        dof[kk] = ldz(dop + 4 * kk + g, qok, p.q);
+        delta += dof[kk] * ldz(op + 4 * kk + g, qok, p.q);
     }
     delta += __shfl_xor(delta, 16, 64);
     delta += __shfl_xor(delta, 32, 64);
@@ -259,8 +265,8 @@ __device__ __forceinline__ void attn_bwd_dq(const AttnParams& p, int bh, int qt)
         const float* vp = vb + (long)krow * p.ldv;
 #pragma unroll
         for (int kk = 0; kk < 8 * DHC; kk++) {
-            sacc = MFMA16(ldz(kp + 4 * kk + g, kok), qf[kk], sacc);
-            dpacc = MFMA16(ldz(vp + 4 * kk + g, kok), dof[kk], dpacc);
+            sacc = MFMA16(ldz(kp + 4 * kk + g, kok, p.q), qf[kk], sacc);
+            dpacc = MFMA16(ldz(vp + 4 * kk + g, kok, p.q), dof[kk], dpacc);
         }
         f32x4 ds;
 #pragma unroll
@@ -278,7 +284,7 @@ __device__ __forceinline__ void attn_bwd_dq(const AttnParams& p, int bh, int qt)
             const bool k2 = key < p.Lk;
             const float* kp2 = kb + (long)key * p.ldk;
 #pragma unroll
-            for (int c = 0; c < 2 * DHC; c++) dq[c] = MFMA16(ldz(kp2 + 16 * c + li, k2), ds[t], dq[c]);
+            for (int c = 0; c < 2 * DHC; c++) dq[c] = MFMA16(ldz(kp2 + 16 * c + li, k2, p.q), ds[t], dq[c]);
         }
     }
     if (qok) {
@@ -306,7 +312,7 @@ __device__ __forceinline__ void attn_bwd_dkv(const AttnParams& p, int bh, int kt
     // B operands (k = d, j = key): K^T and V^T fragments, loaded once.
     float kf[8 * DHC], vf[8 * DHC];
 #pragma unroll
-    for (int kk = 0; kk < 8 * DHC; kk++) { kf[kk] = ldz(kp + 4 * kk + g, kok); vf[kk] = ldz(vp + 4 * kk + g, kok); }
+    for (int kk = 0; kk < 8 * DHC; kk++) { kf[kk] = ldz(kp + 4 * kk + g, kok, p.q); vf[kk] = ldz(vp + 4 * kk + g, kok, p.q); }
 
     f32x4 dk[2 * DHC], dv[2 * DHC];
 #pragma unroll
@@ -321,8 +327,8 @@ __device__ __forceinline__ void attn_bwd_dkv(const AttnParams& p, int bh, int kt
         f32x4 sacc = {0.f, 0.f, 0.f, 0.f}, dpacc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int kk = 0; kk < 8 * DHC; kk++) {
-            sacc = MFMA16(ldz(qp + 4 * kk + g, qaok) * p.scale, kf[kk], sacc);
-            dpacc = MFMA16(ldz(dop + 4 * kk + g, qaok), vf[kk], dpacc);
+            sacc = MFMA16(ldz(qp + 4 * kk + g, qaok, p.q) * p.scale, kf[kk], sacc);
+            dpacc = MFMA16(ldz(dop + 4 * kk + g, qaok, p.q), vf[kk], dpacc);
         }
         // C layout: row = query 16jq + 4g + r, col = key li.
         float pd[4], ds[4];
@@ -335,7 +341,7 @@ __device__ __forceinline__ void attn_bwd_dkv(const AttnParams& p, int bh, int kt
             const float* do_r = p.dout + ((long)b * p.Lq + qr) * p.lddo + h * DH;
             float part = 0.f;
 #pragma unroll
-            for (int c = 0; c < 2 * DHC; c++) part += ldz(o_r + 16 * c + li, qok) * ldz(do_r + 16 * c + li, qok);
+            for (int c = 0; c < 2 * DHC; c++) part += ldz(o_r + 16 * c + li, qok, p.q) * ldz(do_r + 16 * c + li, qok, p.q);
             part += __shfl_xor(part, 1, 64); part += __shfl_xor(part, 2, 64);
             part += __shfl_xor(part, 4, 64); part += __shfl_xor(part, 8, 64);
             const float lse = qok ? p.lse[(long)bh * p.Lq + qr] : 0.f;
@@ -354,8 +360,8 @@ __device__ __forceinline__ void attn_bwd_dkv(const AttnParams& p, int bh, int kt
             const float* do_r = p.dout + ((long)b * p.Lq + qr) * p.lddo + h * DH;
 #pragma unroll
             for (int c = 0; c < 2 * DHC; c++) {
-                dv[c] = MFMA16(ldz(do_r + 16 * c + li, qok), pd[t], dv[c]);
-                dk[c] = MFMA16(ldz(q_r + 16 * c + li, qok), ds[t], dk[c]);
+                dv[c] = MFMA16(ldz(do_r + 16 * c + li, qok, p.q), pd[t], dv[c]);
+                dk[c] = MFMA16(ldz(q_r + 16 * c + li, qok, p.q), ds[t], dk[c]);
             }
         }
     }
