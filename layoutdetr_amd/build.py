@@ -23,7 +23,9 @@ SOURCES = ['ldetr_core.cpp', 'bias_act.hip', 'upfirdn2d.hip', 'gemm_conv.hip', '
            'misc_ops.hip', 'optim.hip', 'lsap.hip', 'xent.hip', 'resample.hip', 'layout_loss.hip', 'demod.hip', 'wgrad_smallc.hip']
 HEADERS = ['ldetr_common.hpp', os.path.join('..', '..', 'include', 'ldetr_hip.h')]
 
-FLAGS = (['-DLDETR_TILE_TRACE=0'] if os.environ.get('LDETR_NO_TILE_TRACE') else []) + ['-O3', '-std=c++17', '-fPIC', f'--offload-arch={ARCH}', '-munsafe-fp-atomics', '-fno-gpu-rdc',
+# the per-block tracer of the tiled kernel (tools/trace_tiles.py) is a development build: LDETR_TILE_TRACE=1 python -m layoutdetr_amd.build --force
+# (the production kernel carries explicit sched_barrier(0) fences where the tracer's stamps used to sit)
+FLAGS = ([] if os.environ.get('LDETR_TILE_TRACE') else ['-DLDETR_TILE_TRACE=0']) + ['-O3', '-std=c++17', '-fPIC', f'--offload-arch={ARCH}', '-munsafe-fp-atomics', '-fno-gpu-rdc',
          '-Wno-unused-result', '-Rpass-analysis=kernel-resource-usage']
 # kernels whose register budget is the design: any scratch (spill / stack object) is a build error, not a silent 10x slowdown
 # (an erf in the engine's epilogue once cost 320 bytes of scratch per lane and every 128x128 GEMM ran 14x slower)
