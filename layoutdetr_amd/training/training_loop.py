@@ -490,7 +490,11 @@ def training_loop(run_dir='.', training_set_kwargs={}, validation_set_kwargs={},
         batch = dict(bbox_real=samples['bboxes'].to(device).float(), bbox_class=samples['labels'].to(device).long(), bbox_text=texts,
                      bbox_patch=samples['patches'].to(device), padding_mask=~samples['mask'].to(device).bool(),
                      background=samples['background'].to(device).float(), real_c=real_c.to(device))
-        batch['gen_c'] = torch.zeros_like(batch['real_c'])
+        if batch['real_c'].shape[1] > 0 and hasattr(training_set, 'get_label'):      # training_loop.py:257-259: labels of random dataset items
+            gen_c = np.stack([training_set.get_label(np.random.randint(len(training_set))) for _ in range(b)])
+            batch['gen_c'] = torch.from_numpy(gen_c).to(device)
+        else:
+            batch['gen_c'] = torch.zeros_like(batch['real_c'])
         gen_z = [torch.randn(b, batch['bbox_class'].shape[1], G.z_dim, device=device) for _ in phases]
         training_iteration(loss, phases, dp, batch, batch_gpu, gen_z, ema=ema, batch_size=batch_size, ema_kimg=ema_kimg, cur_nimg=cur_nimg)
         cur_nimg += batch_size
