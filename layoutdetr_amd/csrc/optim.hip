@@ -48,15 +48,19 @@ __global__ __launch_bounds__(256) void adam_kernel(AdamParams a) {
     const long n4 = a.n >> 2;
     const long stride = (long)gridDim.x * blockDim.x;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
-        float4 p = reinterpret_cast<float4*>(a.p)[i];
-        float4 g = reinterpret_cast<const float4*>(a.g)[i];
-        float4 m = reinterpret_cast<float4*>(a.m)[i];
-        float4 v = reinterpret_cast<float4*>(a.v)[i];
+        // g, m, v are touched once per step (2.5 GB for D: nothing of it survives in the 256 MB Infinity Cache anyway): non-temporal, so the
+        // stream does not evict the parameters, which the next phase's first kernels read
+        f32x4 pv = reinterpret_cast<f32x4*>(a.p)[i];
+        f32x4 gv = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(a.g) + i);
+        f32x4 mv = __builtin_nontemporal_load(reinterpret_cast<f32x4*>(a.m) + i);
+        f32x4 vv = __builtin_nontemporal_load(reinterpret_cast<f32x4*>(a.v) + i);
+        float4 p = make_float4(pv[0], pv[1], pv[2], pv[3]), g = make_float4(gv[0], gv[1], gv[2], gv[3]);
+        float4 m = make_float4(mv[0], mv[1], mv[2], mv[3]), v = make_float4(vv[0], vv[1], vv[2], vv[3]);
         adam_elem(p.x, g.x, m.x, v.x, a); adam_elem(p.y, g.y, m.y, v.y, a);
         adam_elem(p.z, g.z, m.z, v.z, a); adam_elem(p.w, g.w, m.w, v.w, a);
         reinterpret_cast<float4*>(a.p)[i] = p;
-        reinterpret_cast<float4*>(a.m)[i] = m;
-        reinterpret_cast<float4*>(a.v)[i] = v;
+        __builtin_nontemporal_store(f32x4{m.x, m.y, m.z, m.w}, reinterpret_cast<f32x4*>(a.m) + i);
+        __builtin_nontemporal_store(f32x4{v.x, v.y, v.z, v.w}, reinterpret_cast<f32x4*>(a.v) + i);
     }
     for (long i = (n4 << 2) + (long)blockIdx.x * blockDim.x + threadIdx.x; i < a.n; i += stride)
         adam_elem(a.p[i], a.g[i], a.m[i], a.v[i], a);
@@ -67,10 +71,11 @@ __global__ __launch_bounds__(256) void ema_kernel(float* pe, const float* p, lon
     const long stride = (long)gridDim.x * blockDim.x;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
         float4 a = reinterpret_cast<const float4*>(p)[i];
-        float4 e = reinterpret_cast<float4*>(pe)[i];
+        const f32x4 ev = __builtin_nontemporal_load(reinterpret_cast<f32x4*>(pe) + i);     // p_ema is touched once per iteration: streaming
+        float4 e = make_float4(ev[0], ev[1], ev[2], ev[3]);
         e.x = a.x + beta * (e.x - a.x); e.y = a.y + beta * (e.y - a.y);
         e.z = a.z + beta * (e.z - a.z); e.w = a.w + beta * (e.w - a.w);
-        reinterpret_cast<float4*>(pe)[i] = e;
+        __builtin_nontemporal_store(f32x4{e.x, e.y, e.z, e.w}, reinterpret_cast<f32x4*>(pe) + i);
     }
     for (long i = (n4 << 2) + (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
         pe[i] = p[i] + beta * (pe[i] - p[i]);
