@@ -218,6 +218,13 @@ def _check_background_size(background_size):
                                   '(backgrounds up to 512 x 512); pass background_size <= 512')
 
 
+def _masked_ce_static(logits, target, valid):
+    """mean cross entropy over the valid slots of full-slot logits [B, N, L] (static-shape heads): padded slots are ignored targets of the
+    fused softmax-cross-entropy kernel."""
+    from .med import softmax_cross_entropy
+    return softmax_cross_entropy(logits.flatten(0, 1), target.flatten().masked_fill(~valid.flatten(), -100))
+
+
 def _zero_like_loss(ref):
     return ref.new_full((), 0.0)   # a fill kernel: new_zeros(()) becomes a 4-byte memset node under capture (see DESIGN §6 on memset nodes)
 
@@ -286,8 +293,7 @@ class Generator(nn.Module):
             z_rec = self.fc_z_rec(x)
             loss_z = ((z_rec - z0.unsqueeze(1)).square().sum(-1) * vf).sum() / (cnt * z_rec.shape[-1])
             logit_cls = self.fc_out_cls(x)                                   # [B, N, L]: every slot, masked by the caller
-            ce = F.cross_entropy(self.fc_text_len_rec(x).flatten(0, 1), text_len.flatten(), reduction='none')
-            loss_text_len = (ce * vf.flatten()).sum() / cnt
+            loss_text_len = _masked_ce_static(self.fc_text_len_rec(x), text_len, valid)
             loss_lm = _lm_loss(self, bbox_text, padding_mask, B, N, True)
             return bbox_fake, loss_z, logit_cls, (loss_lm if loss_lm is not None else _zero_like_loss(loss_z)), loss_text_len
         xv = x[valid]
@@ -387,9 +393,7 @@ class Discriminator(nn.Module):
         logit_cls = self.fc_out_cls(x)
         text_len_rec = self.fc_text_len_rec(x)
         if static:
-            vf = valid.to(torch.float32)
-            ce = F.cross_entropy(text_len_rec.flatten(0, 1), text_len.flatten(), reduction='none')
-            loss_text_len = (ce * vf.flatten()).sum() / vf.sum().clamp_min(1.0)
+            loss_text_len = _masked_ce_static(text_len_rec, text_len, valid)
         else:
             loss_text_len = F.cross_entropy(text_len_rec, text_len[valid])
         loss_lm = _lm_loss(self, bbox_text, padding_mask, B, N, static)
