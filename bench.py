@@ -247,6 +247,9 @@ def run(args, rank, local_rank, world):
                 r = measure(16, False)
                 extra['value_reference_call_pattern'] = r['value']
                 extra['ms_per_step_reference_call_pattern'] = r['ms_per_step']
+                if share is True:      # and the other side of the headline: D's trunk evaluated once per ITERATION (opt-in `--share-trunk iteration`;
+                    r = measure(16, 'iteration')   # D's weights do not change between Gmain and Dmain, so Gmain's D(fake) can read Dmain's evaluation)
+                    extra['value_iteration_trunk_sharing'] = r['value']
     eager_step = primary.pop('eager_step')
     args.batch, b_local = primary['global_batch'], primary['per_gpu_batch']
     value, ms_per_step = primary['value'], primary['ms_per_step']
