@@ -160,7 +160,8 @@ int ldetr_conv_transpose2d_bwd_weight_f32(const float* x, const ldetr_tensor4* x
                                           int64_t dy_scale_ld, int accumulate, void* stream);
 
 /* head_dim: multiple of 32 up to 192.  causal != 0 (self-attention only, Lq == Lk): key j is visible to query i iff j <= i
- * (BertSelfAttention of an is_decoder config, training/med.py:704-739), on top of the key-padding mask. */
+ * (BertSelfAttention of an is_decoder config, training/med.py:704-739), on top of the key-padding mask.
+ * Lk <= 256: the score row stays in registers; 256 < Lk <= 16384: 256-key chunks with an online softmax (same results). */
 int ldetr_attention_fwd_f32(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v, int64_t ldv,
                             const unsigned char* key_padding_mask, float* out, int64_t ldo, float* lse, int B, int H,
                             int Lq, int Lk, int head_dim, float scale, float p_drop, uint64_t seed, const uint64_t* seed_ptr,

@@ -1,5 +1,5 @@
 // Fused multi-head attention (scaled QK^T + key-padding mask + softmax + dropout + PV), forward
-// and backward, for the DETR shapes of LayoutDETR: head_dim 32, Lq <= 256, Lk <= 256.
+// and backward, for the DETR shapes of LayoutDETR: head_dim 32, Lk <= 256 in registers (longer key sequences: chunked online softmax).
 // Replaces the attention core of nn.MultiheadAttention as called at
 // training/detr_transformer.py:208-209 (encoder self), :273-274 (decoder self), :277-280 (decoder cross)
 // and by nn.TransformerEncoderLayer in training/util.py:21-26 / networks_detr.py:242-243.
@@ -120,6 +120,95 @@ __global__ __launch_bounds__(64) void attn_fwd_kernel(AttnParams p) {
         float* op = p.o + ((long)b * p.Lq + qrow) * p.ldo + h * DH + 4 * g;
 #pragma unroll
         for (int c = 0; c < 2 * DHC; c++) *reinterpret_cast<float4*>(op + 16 * c) = make_float4(o[c][0], o[c][1], o[c][2], o[c][3]);
+    }
+}
+
+// Long-key forward (Lk > 256: background_size above 512, i.e. more than 16x16 trunk positions).  Same wave layout as
+// attn_fwd_kernel, but the keys are walked in chunks of 256 with a running maximum / denominator (online softmax): the output
+// accumulators are rescaled by exp(m_old - m_new) when the maximum moves and normalised once at the end, so registers stay at
+// the 16-tile footprint whatever Lk is.  The saved log-sum-exp is the global one, which is all the backward needs.
+template <int DHC>
+__global__ __launch_bounds__(64) void attn_fwd_long_kernel(AttnParams p) {
+    constexpr int DH = 32 * DHC, NKT = 16;
+    const int nqt = (p.Lq + 15) >> 4;
+    const int qt = blockIdx.x % nqt;
+    const int bh = blockIdx.x / nqt;
+    const int b = bh / p.H, h = bh - b * p.H;
+    const int lane = threadIdx.x, li = lane & 15, g = lane >> 4;
+    const int qrow = (qt << 4) + li;
+    const bool qok = qrow < p.Lq;
+    const float* qp = p.q + ((long)b * p.Lq + qrow) * p.ldq + h * DH;
+    const float* kb = p.k + (long)b * p.Lk * p.ldk + h * DH;
+    const float* vb = p.v + (long)b * p.Lk * p.ldv + h * DH;
+    const unsigned char* kpm = p.kpm ? p.kpm + (long)b * p.Lk : nullptr;
+    const float inv_keep = p.p_drop > 0.f ? 1.f / (1.f - p.p_drop) : 1.f;
+
+    float qf[8 * DHC];
+#pragma unroll
+    for (int kk = 0; kk < 8 * DHC; kk++) qf[kk] = ldz(qp + 4 * kk + g, qok, p.q) * p.scale;
+
+    f32x4 o[2 * DHC];
+#pragma unroll
+    for (int c = 0; c < 2 * DHC; c++) o[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float run_max = -INFINITY, run_sum = 0.f;
+    const int nkt = (p.Lk + 15) >> 4;
+    for (int j0 = 0; j0 < nkt; j0 += NKT) {
+        f32x4 s[NKT];
+        float mx = run_max;
+#pragma unroll
+        for (int j = 0; j < NKT; j++) {
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            const int krow = 16 * (j0 + j) + li;
+            const bool kok = krow < p.Lk;
+            const float* kp = kb + (long)krow * p.ldk;
+#pragma unroll
+            for (int kk = 0; kk < 8 * DHC; kk++) acc = MFMA16(ldz(kp + 4 * kk + g, kok, p.q), qf[kk], acc);
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int key = 16 * (j0 + j) + 4 * g + r;
+                const bool masked = (key >= p.Lk) || (kpm && kpm[key]) || (p.causal && key > qrow);
+                acc[r] = masked ? -INFINITY : acc[r];
+                mx = fmaxf(mx, acc[r]);
+            }
+            s[j] = acc;
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        // every key so far masked: keep the accumulators (all zero) untouched and avoid (-inf) - (-inf)
+        const float ref = (mx == -INFINITY) ? 0.f : mx;
+        const float alpha = expf(run_max - ref);          // run_max = -inf -> 0
+        float sum = 0.f;
+#pragma unroll
+        for (int j = 0; j < NKT; j++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) { const float e = expf(s[j][r] - ref); s[j][r] = e; sum += e; }
+        sum += __shfl_xor(sum, 16, 64);
+        sum += __shfl_xor(sum, 32, 64);
+        run_sum = run_sum * alpha + sum;
+        run_max = mx;
+#pragma unroll
+        for (int c = 0; c < 2 * DHC; c++) { o[c][0] *= alpha; o[c][1] *= alpha; o[c][2] *= alpha; o[c][3] *= alpha; }
+#pragma unroll
+        for (int j = 0; j < NKT; j++) {
+#pragma unroll
+            for (int t = 0; t < 4; t++) {
+                const int key = 16 * (j0 + j) + 4 * g + t;
+                const bool kok = key < p.Lk;
+                float pv = s[j][t];
+                if (p.p_drop > 0.f) pv *= attn_drop(p, bh, qrow, key, inv_keep);
+                const float* vp = vb + (long)key * p.ldv;
+#pragma unroll
+                for (int c = 0; c < 2 * DHC; c++) o[c] = MFMA16(ldz(vp + 16 * c + li, kok, p.q), pv, o[c]);
+            }
+        }
+    }
+    const float inv = 1.f / run_sum;
+    if (p.lse && g == 0 && qok) p.lse[(long)bh * p.Lq + qrow] = run_max + logf(run_sum);
+    if (qok) {
+        float* op = p.o + ((long)b * p.Lq + qrow) * p.ldo + h * DH + 4 * g;
+#pragma unroll
+        for (int c = 0; c < 2 * DHC; c++)
+            *reinterpret_cast<float4*>(op + 16 * c) = make_float4(o[c][0] * inv, o[c][1] * inv, o[c][2] * inv, o[c][3] * inv);
     }
 }
 
@@ -256,8 +345,13 @@ __device__ __forceinline__ void attn_bwd_dq(const AttnParams& p, int bh, int qt)
     f32x4 dq[2 * DHC];
 #pragma unroll
     for (int c = 0; c < 2 * DHC; c++) dq[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // Lk <= 16 NKT: one pass (the loop bound is a launch constant).  Longer key sequences walk chunks of NKT tiles: every tile
+    // is independent given the saved log-sum-exp, so nothing is rescaled.
+    const int nkt_all = (p.Lk + 15) >> 4;
+    for (int j0 = 0; j0 < nkt_all; j0 += NKT)
 #pragma unroll
-    for (int j = 0; j < NKT; j++) {
+    for (int jj = 0; jj < NKT; jj++) {
+        const int j = j0 + jj;
         f32x4 sacc = {0.f, 0.f, 0.f, 0.f}, dpacc = {0.f, 0.f, 0.f, 0.f};
         const int krow = 16 * j + li;
         const bool kok = krow < p.Lk;
@@ -389,7 +483,7 @@ __global__ __launch_bounds__(64) void attn_bwd_kernel(AttnParams p) {
 static int check_attn(const AttnParams& p, const char* what) {
     LDETR_CHECK(p.q && p.k && p.v && p.o, "%s: null pointer", what);
     LDETR_CHECK(p.B > 0 && p.H > 0 && p.Lq > 0 && p.Lk > 0, "%s: empty problem", what);
-    LDETR_CHECK(p.Lk <= 256, "%s: Lk > 256 is unsupported", what);
+    LDETR_CHECK(p.Lk <= 16384, "%s: Lk > 16384 is unsupported", what);
     LDETR_CHECK(p.p_drop >= 0.f && p.p_drop < 1.f, "%s: dropout must be in [0,1)", what);
     LDETR_CHECK((p.ldo % 4) == 0 && ((uintptr_t)p.o & 15) == 0, "%s: output must be 16-byte aligned", what);
     return LDETR_OK;
@@ -422,6 +516,17 @@ extern "C" int ldetr_attention_fwd_f32(const float* q, int64_t ldq, const float*
         else if (nkt <= 8) hipLaunchKernelGGL((attn_fwd_kernel<8, DHC>), grid, 64, 0, st, p);    \
         else hipLaunchKernelGGL((attn_fwd_kernel<16, DHC>), grid, 64, 0, st, p);                 \
     } while (0)
+    if (nkt > 16) {     // long key sequences: chunked online softmax
+        switch (head_dim / 32) {
+            case 1: hipLaunchKernelGGL((attn_fwd_long_kernel<1>), grid, 64, 0, st, p); break;
+            case 2: hipLaunchKernelGGL((attn_fwd_long_kernel<2>), grid, 64, 0, st, p); break;
+            case 3: hipLaunchKernelGGL((attn_fwd_long_kernel<3>), grid, 64, 0, st, p); break;
+            case 4: hipLaunchKernelGGL((attn_fwd_long_kernel<4>), grid, 64, 0, st, p); break;
+            case 5: hipLaunchKernelGGL((attn_fwd_long_kernel<5>), grid, 64, 0, st, p); break;
+            default: hipLaunchKernelGGL((attn_fwd_long_kernel<6>), grid, 64, 0, st, p); break;
+        }
+        return check_launch("attention_fwd_long");
+    }
     // wide heads (the BERT text models): LDS-staged K / V shared by four query tiles per block
     static const int wide_on = getenv("LDETR_ATTN_WIDE") ? atoi(getenv("LDETR_ATTN_WIDE")) : 1;
     if (wide_on && head_dim >= 64 && (ldk % 4) == 0 && (ldv % 4) == 0 && ((((uintptr_t)k) | ((uintptr_t)v)) & 15) == 0) {

@@ -211,11 +211,11 @@ def _text_inputs(module, bbox_text, B, N, device):
 
 
 def _check_background_size(background_size):
-    """The fused attention kernels hold one sample's keys in registers / LDS: at most 256 memory tokens = a 512 x 512 background
-    (stride 32).  The reference's signature default (1024) is kept for compatibility; `train.py` passes 256."""
-    if (background_size // 32) ** 2 > 256:
-        raise NotImplementedError(f'background_size={background_size}: the gfx950 attention kernels support up to 256 image tokens '
-                                  '(backgrounds up to 512 x 512); pass background_size <= 512')
+    """Up to 256 memory tokens (a 512 x 512 background, stride 32) the fused attention kernels keep a sample's whole score row in
+    registers; above that (the reference's signature default 1024 -> 1024 tokens) they walk the keys in chunks of 256 with an online
+    softmax (csrc/attention.hip attn_fwd_long_kernel).  The C ABI bounds Lk at 16384 tokens = 4096 x 4096 pixels."""
+    if ((background_size + 31) // 32) ** 2 > 16384:
+        raise NotImplementedError(f'background_size={background_size}: at most 4096 (16384 image tokens)')
 
 
 def _masked_ce_static(logits, target, valid):

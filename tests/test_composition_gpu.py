@@ -348,3 +348,36 @@ def test_forward_configs4_share_b4_512_text_encoder_on(dev):
         if nm != 'loss_lm':
             worst = max(worst, check(out_d[i], ref_d[i], 1e-3, 'D ' + nm))
     print(f'[configs4 share B=4 512 text on] worst err {worst:.2e}')
+
+
+def test_forward_backward_background_1024_long_key_attention(dev):
+    """The reference's constructor default background_size=1024 (training/networks_detr.py:70 / :195): 32 x 32 = 1024 memory tokens,
+    beyond the 256 keys the attention kernels hold in registers -> the chunked online-softmax path (forward) and the chunk-walking
+    dQ / per-key-tile dK,dV (backward).  G / D forward and the gradient wrt z and the real boxes against the CPU oracle."""
+    from oracle import networks_ref
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    bg, B = 1024, 1
+    G, D = make_modules(bg, seed=51)
+    bt, zg, _ = make_batch(B, bg, seed=52, ragged=True)
+    Gsd = {k: v.clone() for k, v in G.state_dict().items()}; Dsd = {k: v.clone() for k, v in D.state_dict().items()}
+    valid = ~bt['padding_mask']
+    zr = zg.clone().requires_grad_(True); br = bt['bbox_real'].clone().requires_grad_(True)
+    ref_g = networks_ref.generator(Gsd, zr, bt['bbox_class'], bt['text_feat'], bt['text_len'], bt['padding_mask'], bt['background'], reconst=True)
+    ref_d = networks_ref.discriminator(Dsd, br, bt['bbox_class'], bt['text_feat'], bt['text_len'], bt['padding_mask'], bt['background'],
+                                       reconst=True, bg_size=bg)
+    wg = torch.randn(ref_g[0][valid].shape, generator=torch.Generator().manual_seed(53))
+    (ref_g[0][valid] * wg).sum().backward()
+    (ref_d[0].sum() + ref_d[2].sum()).backward()          # bbox_pred is already the ragged [valid, 4] form
+    G.eval().requires_grad_(False).to(dev); D.eval().requires_grad_(False).to(dev)
+    db = device_batch(bt, dev)
+    zd = zg.to(dev).requires_grad_(True); bd = bt['bbox_real'].to(dev).requires_grad_(True)
+    out_g = G(zd, db['bbox_class'], db['bbox_real'], db['bbox_text'], db['bbox_patch'], db['padding_mask'], db['background'], None, True)
+    out_d = D(bd, db['bbox_class'], db['bbox_text'], db['bbox_patch'], db['padding_mask'], db['background'], None, True)
+    (out_g[0][valid.to(dev)] * wg.to(dev)).sum().backward()
+    (out_d[0].sum() + out_d[2].sum()).backward()
+    worst = check(out_g[0][valid.to(dev)], ref_g[0][valid].detach(), 1e-3, 'bbox_fake')
+    for i, nm in enumerate(['logit', 'logit_uncond', 'bbox_pred', 'logit_cls', 'loss_lm', 'loss_text_len', 'bg_rec', 'bbox_pred_uncond', 'logit_cls_uncond']):
+        if nm != 'loss_lm':
+            worst = max(worst, check(out_d[i], ref_d[i].detach(), 1e-3, 'D ' + nm))
+    worst = max(worst, check(zd.grad[valid.to(dev)], zr.grad[valid], 2e-3, 'dz'), check(bd.grad[valid.to(dev)], br.grad[valid], 2e-3, 'dbbox'))
+    print(f'[background 1024, 1024 memory tokens] worst err {worst:.2e}')

@@ -411,14 +411,18 @@ def test_maxpool(dev):
 
 
 # ------------------------------------------------------------------------------------------ attention
-@pytest.mark.parametrize('B,H,Lq,Lk', [(2, 8, 9, 9), (2, 8, 10, 64), (3, 2, 64, 64), (1, 4, 16, 256), (2, 8, 33, 100)])
+@pytest.mark.parametrize('B,H,Lq,Lk', [(2, 8, 9, 9), (2, 8, 10, 64), (3, 2, 64, 64), (1, 4, 16, 256), (2, 8, 33, 100),
+                                       (2, 8, 9, 257), (2, 2, 300, 400), (1, 4, 16, 1024), (1, 2, 1024, 1024), (2, 1, 40, 2100)])
 def test_attention(dev, B, H, Lq, Lk):
+    """Lk <= 256: scores in registers; above: 256-key chunks with an online softmax (background_size 1024 -> 1024 memory tokens)."""
     from layoutdetr_amd.hip import attention
     torch.manual_seed(9)
     d = H * 32
     q = torch.randn(B * Lq, d); k = torch.randn(B * Lk, d); v = torch.randn(B * Lk, d)
     kpm = torch.zeros(B, Lk, dtype=torch.bool)
     kpm[0, Lk - Lk // 3:] = True
+    if Lk > 256:
+        kpm[-1, :300 if Lk > 300 else 256] = True     # a whole first chunk masked: the running maximum starts at -inf
     qr, kr, vr = [t.clone().requires_grad_(True) for t in (q, k, v)]
 
     def heads(t, L):
@@ -445,6 +449,14 @@ def test_attention_dropout_statistics(dev):
     assert abs(o.mean().item() - 1.0) < 0.01 and o.std().item() > 1e-3
     o.sum().backward()  # mask is regenerated in backward: dV column sums equal the forward keep pattern
     assert abs(v.grad.mean().item() - 1.0) < 0.01
+    # long-key path (chunked): same statistics, and the backward regenerates the same mask (dV mean equals the forward's keep rate)
+    L2 = 512
+    q = torch.zeros(2 * 16, 256, device=dev); k = torch.zeros(2 * L2, 256, device=dev)
+    v = torch.ones(2 * L2, 256, device=dev).requires_grad_(True)
+    o = attention.attention(q, k, v, None, 2, 8, 16, L2, 0.1)
+    assert abs(o.mean().item() - 1.0) < 0.01 and o.std().item() > 1e-3
+    o.sum().backward()
+    assert abs(v.grad.sum().item() / (16 * 2 * 256) - o.mean().item()) < 1e-4
 
 
 # ------------------------------------------------------------------------------------------ layernorm
@@ -634,7 +646,8 @@ def test_bottleneck_chain_fused_block_gradients(dev):
 
 
 @pytest.mark.parametrize('B,H,L,dh,causal', [(2, 4, 40, 192, True), (3, 3, 21, 64, True), (2, 2, 70, 96, False), (2, 4, 40, 192, False), (2, 8, 19, 32, True),
-                                             (2, 2, 256, 192, False), (2, 2, 200, 64, True), (1, 3, 130, 160, False), (2, 1, 64, 128, True)])
+                                             (2, 2, 256, 192, False), (2, 2, 200, 64, True), (1, 3, 130, 160, False), (2, 1, 64, 128, True),
+                                             (2, 2, 300, 64, True), (1, 2, 520, 96, False)])
 def test_attention_wide_heads_and_causal(dev, B, H, L, dh, causal):
     """Packed self-attention for 32..192-wide heads, forward + backward, with the decoder's causal mask on top of a ragged
     key-padding mask (BertSelfAttention shapes of the text encoder / LM decoder)."""
