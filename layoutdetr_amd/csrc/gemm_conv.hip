@@ -579,6 +579,12 @@ __global__ __launch_bounds__(NWV * 64) void gemm_f32_kernel(GemmParams p) {
 
     // register staging of the next k-tile (global loads run one k-tile ahead of the MFMAs; two ahead measured slower)
     float4 ra0[NUA], rb0[NUB];
+    // Per-sample operand scale of the tap-addressed conv operands (style modulation of x / demodulation of dy): the factors are
+    // fetched next to the data but applied when the tile is written to LDS.  Multiplying right after the load made every k-tile
+    // wait for its own global loads before the MFMAs of the tile in flight could start.
+    constexpr bool A_DEFER = A_FAST && (AMODE == OP_KC_CONV || AMODE == OP_KC_CONVT);
+    float4 sa0[A_DEFER ? NUA : 1];
+    const bool a_defer = A_DEFER && fastA && p.A.scale != nullptr;
     // loads the k-tile starting at k0 and advances the decode state to the following tile
     auto gload = [&](int k0, float4 (&ra)[NUA], float4 (&rb)[NUB]) {
 #pragma unroll
@@ -604,9 +610,9 @@ __global__ __launch_bounds__(NWV * 64) void gemm_f32_kernel(GemmParams p) {
                         const bool tap_ok = (a_msk[i] >> f_tap) & 1u;
                         const int vo = tap_ok ? a_voff[i] : (int)0x80000000;
                         ra[i] = as_float4(__builtin_amdgcn_raw_buffer_load_b128(rsA, vo, soff, 0));
-                        if (p.A.scale && tap_ok) {   // (rows past the end carry no sample index: never touch the scale table for them)
-                            const float4 sc = *reinterpret_cast<const float4*>(p.A.scale + (long)a_rc[i].samp * p.A.scale_ld + f_c0 + a_k[i]);
-                            ra[i].x *= sc.x; ra[i].y *= sc.y; ra[i].z *= sc.z; ra[i].w *= sc.w;
+                        if constexpr (A_DEFER) {
+                            if (p.A.scale)   // (rows past the end carry no sample index: they read the table's first entry and hold zeros anyway)
+                                sa0[i] = *reinterpret_cast<const float4*>(tap_ok ? p.A.scale + (long)a_rc[i].samp * p.A.scale_ld + f_c0 + a_k[i] : p.A.scale);
                         }
                     }
                     continue;
@@ -669,9 +675,12 @@ __global__ __launch_bounds__(NWV * 64) void gemm_f32_kernel(GemmParams p) {
             }
         }
     };
-    auto lstore = [&](int buf, const float4 (&ra)[NUA], const float4 (&rb)[NUB]) {
+    auto lstore = [&](int buf, float4 (&ra)[NUA], const float4 (&rb)[NUB]) {
 #pragma unroll
         for (int i = 0; i < NUA; i++) {
+            if constexpr (A_DEFER) {
+                if (a_defer) { ra[i].x *= sa0[i].x; ra[i].y *= sa0[i].y; ra[i].z *= sa0[i].z; ra[i].w *= sa0[i].w; }
+            }
             if constexpr (A_KC) {
                 As[buf][a_k[i] + 0][a_r[i]] = ra[i].x; As[buf][a_k[i] + 1][a_r[i]] = ra[i].y;
                 As[buf][a_k[i] + 2][a_r[i]] = ra[i].z; As[buf][a_k[i] + 3][a_r[i]] = ra[i].w;
