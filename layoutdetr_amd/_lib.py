@@ -73,6 +73,7 @@ SIGNATURES = {
     'ldetr_embedding_fwd_f32': [_P, _P, _P, _P, _L, _I, _I, _I, _P],
     'ldetr_embedding_bwd_f32': [_P, _P, _P, _L, _I, _I, _L, _P],
     'ldetr_debug_trace_tiles': [_P],
+    'ldetr_set_split_bf16': [c_int],
     'ldetr_gemm_pair_f32': [_P, _P, _P],
     'ldetr_gemm_pair_is_single_launch': [_P, _P],
     'ldetr_demod_fwd_f32': [_P, _L, _L, _L, _L, _P, _P, _P, _I, _I, _I, _I, _I, _F, _P],
@@ -107,7 +108,7 @@ def load():
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported
         fn.restype = c_int
         fn.argtypes = argtypes
-    if lib.ldetr_abi_version() != 15:
+    if lib.ldetr_abi_version() != 16:
         raise RuntimeError('libldetr_hip.so ABI version mismatch; rebuild it')
     _lib = lib
     return lib

@@ -363,7 +363,29 @@ __device__ __forceinline__ float apply_epilogue(const GemmEpilogue& ep, float v,
 
 // NWV waves per block: 4 (2x2 wave grid) or 8 (2x4: same tile, half the accumulators per wave, twice the waves per SIMD to
 // cover each other's barrier / staging phases).
-template <int BM, int BN, int BKT, int AMODE, int BMODE, int NWV, bool FAST>
+// SPLIT: the contraction runs on the bf16 matrix pipe with fp32-equivalent results.  Every operand element is written to LDS as
+// three bf16 values x = hi + mid + lo (8 + 8 + 8 significant bits: together the whole fp32 significand, the split is exact) and
+// each k16 slab issues the six products of weight >= 2^-18 (hi.hi, hi.mid, mid.hi, hi.lo, lo.hi, mid.mid) into the same fp32
+// accumulators.  bf16 x bf16 products are exact in fp32, the dropped terms are <= 2^-26 relative: the result is at least as close
+// to the exact contraction as the f32 MFMA path (tools/proto_bf16x6: rms error 1.6e-7 vs 2.0e-7 against fp64 at K = 4096), while
+// the matrix pipe spends 6 x 8 passes (v_mfma_f32_32x32x16_bf16) where the f32 path spends 8 x 16 (v_mfma_f32_32x32x2_f32).
+// Same 32x32 accumulator layout, so loaders, split-K fix-up and epilogues are shared with the f32 path.  Not equivalent for
+// non-finite inputs (Inf splits into Inf + NaN) and for |x| within one bf16 ulp of FLT_MAX.
+__device__ __forceinline__ unsigned pk_bf16(float a, float b) {
+    typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+    bf16x2_t r = {(__bf16)a, (__bf16)b};
+    return *reinterpret_cast<unsigned*>(&r);
+}
+__device__ __forceinline__ void split2_bf16(float x0, float x1, unsigned& h, unsigned& m, unsigned& l) {
+    h = pk_bf16(x0, x1);
+    const float r0 = x0 - __uint_as_float(h << 16), r1 = x1 - __uint_as_float(h & 0xffff0000u);
+    m = pk_bf16(r0, r1);
+    const float s0 = r0 - __uint_as_float(m << 16), s1 = r1 - __uint_as_float(m & 0xffff0000u);
+    l = pk_bf16(s0, s1);
+}
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+
+template <int BM, int BN, int BKT, int AMODE, int BMODE, int NWV, bool FAST, bool SPLIT = false>
 __global__ __launch_bounds__(NWV * 64) void gemm_f32_kernel(GemmParams p) {
     constexpr int NT = NWV * 64;
     constexpr int WGN = BN == 32 ? 1 : ((NWV == 8 && BN >= 128) ? 4 : 2), WGM = NWV / WGN;   // BN == 32: all waves along M (narrow-N tile)
@@ -378,6 +400,23 @@ __global__ __launch_bounds__(NWV * 64) void gemm_f32_kernel(GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) float ldetr_smem[];
     float (*As)[BKT][LDA] = reinterpret_cast<float (*)[BKT][LDA]>(ldetr_smem);
     float (*Bs)[BKT][LDB] = reinterpret_cast<float (*)[BKT][LDB]>(ldetr_smem + 2 * BKT * LDA);
+    // SPLIT: one buffer of [part][k-block of 8][slot][8 bf16]: a lane's MFMA operand (8 consecutive k of one row) is one 16-byte
+    // read.  k-contiguous operands keep slot = row (the 32 lanes of a k-block read 512 contiguous bytes; writes are 8 bytes per
+    // (row, half k-block), and 128 bytes of padding per plane keep the four k-blocks a wave writes for one row off each other's
+    // banks).  Row-contiguous operands (a lane loads 4 adjacent rows of one k) use slot = (row % 4) * rows/4 + (row / 4 + 8 * (row & 1))
+    // mod rows/4: the lanes of a store hit consecutive slots, and the 32 rows of an operand read fall two per 16-byte bank group
+    // (the minimum); with slot = row those stores were 16-way bank conflicts.
+    char* const sbase = reinterpret_cast<char*>(ldetr_smem);
+    constexpr int PLA = A_KC ? BM * 16 + 128 : BM * 16, PLB = B_KC ? BN * 16 + 128 : BN * 16;   // bytes per (part, k-block) plane
+    constexpr int SB_OFF = 3 * (BKT / 8) * PLA;
+    auto slotA = [](int row) { return A_KC ? row : ((row & 3) * (BM / 4) + (((row >> 2) + 8 * (row & 1)) & (BM / 4 - 1))); };
+    auto slotB = [](int row) { return B_KC ? row : ((row & 3) * (BN / 4) + (((row >> 2) + 8 * (row & 1)) & (BN / 4 - 1))); };
+    auto adrA = [&](int part, int kb, int row, int koff) { return sbase + (part * (BKT / 8) + kb) * PLA + slotA(row) * 16 + koff * 2; };
+    auto adrB = [&](int part, int kb, int row, int koff) { return sbase + SB_OFF + (part * (BKT / 8) + kb) * PLB + slotB(row) * 16 + koff * 2; };
+    // row-contiguous operands under SPLIT: a thread's units are grouped G consecutive k for the same four rows, so the bf16 values
+    // it writes to one LDS row are adjacent (one 8 / 4 / 2-byte store per row and part instead of G 2-byte stores)
+    constexpr int GA = (SPLIT && !A_KC) ? (NUA % 4 == 0 ? 4 : (NUA % 2 == 0 ? 2 : 1)) : 1;
+    constexpr int GB = (SPLIT && !B_KC) ? (NUB % 4 == 0 ? 4 : (NUB % 2 == 0 ? 2 : 1)) : 1;
 
 #ifndef LDETR_TILE_TRACE
 #define LDETR_TILE_TRACE 1
@@ -401,7 +440,10 @@ __global__ __launch_bounds__(NWV * 64) void gemm_f32_kernel(GemmParams p) {
             a_r[i] = u / QK; a_k[i] = (u - a_r[i] * QK) << 2; a_rc[i] = make_row<AMODE>(p.A, p, z, m0 + a_r[i], z.M);
             if constexpr (AMODE != OP_KC_DENSE) kdec_init_tap(a_d[i], z.tm, z.kbeg + a_k[i], p.A.C);
         } else {
-            a_k[i] = u / (BM / 4); a_r[i] = (u - a_k[i] * (BM / 4)) << 2;
+            {
+                const int slot = tid + (i / GA) * NT, kg = slot / (BM / 4);
+                a_k[i] = kg * GA + (i % GA); a_r[i] = (slot - kg * (BM / 4)) << 2;
+            }
             if constexpr (AMODE == OP_RC_WT) kdec_init_tap(a_d[i], z.tm, z.kbeg + a_k[i], p.A.C);
             if constexpr (AMODE == OP_RC_PIX || AMODE == OP_RC_CONVK) kdec_init_pix(a_d[i], z.kbeg + a_k[i], p.A.DH, p.A.DW);
         }
@@ -414,7 +456,10 @@ __global__ __launch_bounds__(NWV * 64) void gemm_f32_kernel(GemmParams p) {
             b_r[i] = u / QK; b_k[i] = (u - b_r[i] * QK) << 2; b_rc[i] = make_row<BMODE>(p.B, p, z, n0 + b_r[i], p.N);
             if constexpr (BMODE != OP_KC_DENSE) kdec_init_tap(b_d[i], z.tm, z.kbeg + b_k[i], p.B.C);
         } else {
-            b_k[i] = u / (BN / 4); b_r[i] = (u - b_k[i] * (BN / 4)) << 2;
+            {
+                const int slot = tid + (i / GB) * NT, kg = slot / (BN / 4);
+                b_k[i] = kg * GB + (i % GB); b_r[i] = (slot - kg * (BN / 4)) << 2;
+            }
             if constexpr (BMODE == OP_RC_WT) kdec_init_tap(b_d[i], z.tm, z.kbeg + b_k[i], p.B.C);
             if constexpr (BMODE == OP_RC_PIX || BMODE == OP_RC_CONVK) kdec_init_pix(b_d[i], z.kbeg + b_k[i], p.B.DH, p.B.DW);
         }
@@ -583,10 +628,11 @@ __global__ __launch_bounds__(NWV * 64) void gemm_f32_kernel(GemmParams p) {
     // fetched next to the data but applied when the tile is written to LDS.  Multiplying right after the load made every k-tile
     // wait for its own global loads before the MFMAs of the tile in flight could start.
     constexpr bool A_DEFER = A_FAST && (AMODE == OP_KC_CONV || AMODE == OP_KC_CONVT);
-    float4 sa0[A_DEFER ? NUA : 1];
+    constexpr int NSA = A_DEFER ? NUA : 1;
+    float4 sa0[NSA];
     const bool a_defer = A_DEFER && fastA && p.A.scale != nullptr;
     // loads the k-tile starting at k0 and advances the decode state to the following tile
-    auto gload = [&](int k0, float4 (&ra)[NUA], float4 (&rb)[NUB]) {
+    auto gload = [&](int k0, float4 (&ra)[NUA], float4 (&rb)[NUB], float4 (&sa)[NSA]) {
 #pragma unroll
         for (int i = 0; i < NUA; i++) {
             if constexpr (A_FAST) {
@@ -612,7 +658,7 @@ __global__ __launch_bounds__(NWV * 64) void gemm_f32_kernel(GemmParams p) {
                         ra[i] = as_float4(__builtin_amdgcn_raw_buffer_load_b128(rsA, vo, soff, 0));
                         if constexpr (A_DEFER) {
                             if (p.A.scale)   // (rows past the end carry no sample index: they read the table's first entry and hold zeros anyway)
-                                sa0[i] = *reinterpret_cast<const float4*>(tap_ok ? p.A.scale + (long)a_rc[i].samp * p.A.scale_ld + f_c0 + a_k[i] : p.A.scale);
+                                sa[i] = *reinterpret_cast<const float4*>(tap_ok ? p.A.scale + (long)a_rc[i].samp * p.A.scale_ld + f_c0 + a_k[i] : p.A.scale);
                         }
                     }
                     continue;
@@ -675,12 +721,76 @@ __global__ __launch_bounds__(NWV * 64) void gemm_f32_kernel(GemmParams p) {
             }
         }
     };
-    auto lstore = [&](int buf, float4 (&ra)[NUA], const float4 (&rb)[NUB]) {
+    auto comp = [](const float4& v, int e) { return e == 0 ? v.x : (e == 1 ? v.y : (e == 2 ? v.z : v.w)); };
+    auto lstore = [&](int buf, float4 (&ra)[NUA], const float4 (&rb)[NUB], const float4 (&sa)[NSA]) {
+        if constexpr (A_DEFER) {
+            if (a_defer) {
+#pragma unroll
+                for (int i = 0; i < NUA; i++) { ra[i].x *= sa[i].x; ra[i].y *= sa[i].y; ra[i].z *= sa[i].z; ra[i].w *= sa[i].w; }
+            }
+        }
+        if constexpr (SPLIT) {
+            unsigned h0, m0_, l0, h1, m1, l1;
+            if constexpr (A_KC) {
+#pragma unroll
+                for (int i = 0; i < NUA; i++) {
+                    split2_bf16(ra[i].x, ra[i].y, h0, m0_, l0); split2_bf16(ra[i].z, ra[i].w, h1, m1, l1);
+                    *reinterpret_cast<uint2*>(adrA(0, a_k[i] >> 3, a_r[i], a_k[i] & 7)) = make_uint2(h0, h1);
+                    *reinterpret_cast<uint2*>(adrA(1, a_k[i] >> 3, a_r[i], a_k[i] & 7)) = make_uint2(m0_, m1);
+                    *reinterpret_cast<uint2*>(adrA(2, a_k[i] >> 3, a_r[i], a_k[i] & 7)) = make_uint2(l0, l1);
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < NUA; i += GA)
+#pragma unroll
+                    for (int e = 0; e < 4; e++) {
+                        unsigned short* dh = reinterpret_cast<unsigned short*>(adrA(0, a_k[i] >> 3, a_r[i] + e, a_k[i] & 7));
+                        unsigned short* dm = reinterpret_cast<unsigned short*>(adrA(1, a_k[i] >> 3, a_r[i] + e, a_k[i] & 7));
+                        unsigned short* dl = reinterpret_cast<unsigned short*>(adrA(2, a_k[i] >> 3, a_r[i] + e, a_k[i] & 7));
+                        if constexpr (GA == 4) {
+                            split2_bf16(comp(ra[i], e), comp(ra[i + 1], e), h0, m0_, l0); split2_bf16(comp(ra[i + 2], e), comp(ra[i + 3], e), h1, m1, l1);
+                            *reinterpret_cast<uint2*>(dh) = make_uint2(h0, h1); *reinterpret_cast<uint2*>(dm) = make_uint2(m0_, m1); *reinterpret_cast<uint2*>(dl) = make_uint2(l0, l1);
+                        } else if constexpr (GA == 2) {
+                            split2_bf16(comp(ra[i], e), comp(ra[i + 1], e), h0, m0_, l0);
+                            *reinterpret_cast<unsigned*>(dh) = h0; *reinterpret_cast<unsigned*>(dm) = m0_; *reinterpret_cast<unsigned*>(dl) = l0;
+                        } else {
+                            split2_bf16(comp(ra[i], e), 0.f, h0, m0_, l0);
+                            *dh = (unsigned short)h0; *dm = (unsigned short)m0_; *dl = (unsigned short)l0;
+                        }
+                    }
+            }
+            if constexpr (B_KC) {
+#pragma unroll
+                for (int i = 0; i < NUB; i++) {
+                    split2_bf16(rb[i].x, rb[i].y, h0, m0_, l0); split2_bf16(rb[i].z, rb[i].w, h1, m1, l1);
+                    *reinterpret_cast<uint2*>(adrB(0, b_k[i] >> 3, b_r[i], b_k[i] & 7)) = make_uint2(h0, h1);
+                    *reinterpret_cast<uint2*>(adrB(1, b_k[i] >> 3, b_r[i], b_k[i] & 7)) = make_uint2(m0_, m1);
+                    *reinterpret_cast<uint2*>(adrB(2, b_k[i] >> 3, b_r[i], b_k[i] & 7)) = make_uint2(l0, l1);
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < NUB; i += GB)
+#pragma unroll
+                    for (int e = 0; e < 4; e++) {
+                        unsigned short* dh = reinterpret_cast<unsigned short*>(adrB(0, b_k[i] >> 3, b_r[i] + e, b_k[i] & 7));
+                        unsigned short* dm = reinterpret_cast<unsigned short*>(adrB(1, b_k[i] >> 3, b_r[i] + e, b_k[i] & 7));
+                        unsigned short* dl = reinterpret_cast<unsigned short*>(adrB(2, b_k[i] >> 3, b_r[i] + e, b_k[i] & 7));
+                        if constexpr (GB == 4) {
+                            split2_bf16(comp(rb[i], e), comp(rb[i + 1], e), h0, m0_, l0); split2_bf16(comp(rb[i + 2], e), comp(rb[i + 3], e), h1, m1, l1);
+                            *reinterpret_cast<uint2*>(dh) = make_uint2(h0, h1); *reinterpret_cast<uint2*>(dm) = make_uint2(m0_, m1); *reinterpret_cast<uint2*>(dl) = make_uint2(l0, l1);
+                        } else if constexpr (GB == 2) {
+                            split2_bf16(comp(rb[i], e), comp(rb[i + 1], e), h0, m0_, l0);
+                            *reinterpret_cast<unsigned*>(dh) = h0; *reinterpret_cast<unsigned*>(dm) = m0_; *reinterpret_cast<unsigned*>(dl) = l0;
+                        } else {
+                            split2_bf16(comp(rb[i], e), 0.f, h0, m0_, l0);
+                            *dh = (unsigned short)h0; *dm = (unsigned short)m0_; *dl = (unsigned short)l0;
+                        }
+                    }
+            }
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < NUA; i++) {
-            if constexpr (A_DEFER) {
-                if (a_defer) { ra[i].x *= sa0[i].x; ra[i].y *= sa0[i].y; ra[i].z *= sa0[i].z; ra[i].w *= sa0[i].w; }
-            }
             if constexpr (A_KC) {
                 As[buf][a_k[i] + 0][a_r[i]] = ra[i].x; As[buf][a_k[i] + 1][a_r[i]] = ra[i].y;
                 As[buf][a_k[i] + 2][a_r[i]] = ra[i].z; As[buf][a_k[i] + 3][a_r[i]] = ra[i].w;
@@ -730,20 +840,57 @@ __global__ __launch_bounds__(NWV * 64) void gemm_f32_kernel(GemmParams p) {
             __builtin_amdgcn_sched_barrier(0);
         }
     };
+    auto compute_split = [&]() {
+#pragma unroll
+        for (int ks = 0; ks < BKT / 16; ks++) {
+            bf16x8_t a[TM][3], b[TN][3];
+#pragma unroll
+            for (int i = 0; i < TM; i++)
+#pragma unroll
+                for (int q = 0; q < 3; q++) a[i][q] = *reinterpret_cast<const bf16x8_t*>(adrA(q, 2 * ks + kl, wm * WM + i * 32 + cl, 0));
+#pragma unroll
+            for (int j = 0; j < TN; j++)
+#pragma unroll
+                for (int q = 0; q < 3; q++) b[j][q] = *reinterpret_cast<const bf16x8_t*>(adrB(q, 2 * ks + kl, wn * WN + j * 32 + cl, 0));
+#pragma unroll
+            for (int i = 0; i < TM; i++)
+#pragma unroll
+                for (int j = 0; j < TN; j++) {   // smallest terms first
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[j][1], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][2], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][2], b[j][0], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][1], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[j][0], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][0], acc[i][j], 0, 0, 0);
+                }
+        }
+    };
     if (nk > 0) {
-        gload(z.kbeg, ra0, rb0);
-        lstore(0, ra0, rb0);
+        gload(z.kbeg, ra0, rb0, sa0);
+        lstore(0, ra0, rb0, sa0);
     }
     long long tr1 = 0, tr2 = 0;
+    if constexpr (SPLIT) {
+        // One LDS buffer (the bf16 image of a tile is 1.5x the f32 one); registers hold the next k-tile meanwhile.  (A second register
+        // set with tiles kt+1 and kt+2 both in flight measured the same to slower: the loop is bound by the operand split's VALU
+        // work and the barriers, not by load latency, and the extra 24-32 VGPRs cost the 256x32 tile an occupancy step.)
+        __syncthreads();
+        for (int kt = 0; kt < nk; kt++) {
+            if (kt + 1 < nk) gload(z.kbeg + (kt + 1) * BKT, ra0, rb0, sa0);
+            compute_split();
+            __syncthreads();
+            if (kt + 1 < nk) { lstore(0, ra0, rb0, sa0); __syncthreads(); }
+        }
+    } else
     {
         __syncthreads();
         if (LDETR_TILE_TRACE && p.trace) tr1 = wall_clock64();
         if (!LDETR_TILE_TRACE) __builtin_amdgcn_sched_barrier(0);   // (the stamp sites double as scheduling fences: without either, hipcc's schedule of this kernel is 7 % slower end to end)
         for (int kt = 0; kt < nk; kt++) {
             const int buf = kt & 1;
-            if (kt + 1 < nk) gload(z.kbeg + (kt + 1) * BKT, ra0, rb0);
+            if (kt + 1 < nk) gload(z.kbeg + (kt + 1) * BKT, ra0, rb0, sa0);
             compute(buf);
-            if (kt + 1 < nk) lstore(buf ^ 1, ra0, rb0);   // (writing these between the MFMAs of the last k-pairs measured slower:
+            if (kt + 1 < nk) lstore(buf ^ 1, ra0, rb0, sa0);   // (writing these between the MFMAs of the last k-pairs measured slower:
             __syncthreads();                               //  the vmcnt wait then sits in the middle of the MFMA stream)
         }
     }
@@ -1454,6 +1601,7 @@ static int zero_fill(float* dst, long pitch, long width, long rows, hipStream_t 
 }
 
 static long long* g_trace_buffer = nullptr;   // ldetr_debug_trace_tiles
+static int g_split_bf16_override = -1;         // ldetr_set_split_bf16: -1 = environment / default, else the tile mask
 
 // Host-side conditions of the kernel's scalar-addressed loads (FAST instantiation): every operand whose view supports them must
 // qualify, otherwise the generic instantiation runs.  BKT is 32 for every tile shape.
@@ -1514,11 +1662,13 @@ static bool fast_operands_ok(const GemmParams& p, int Mmax) {
     return true;
 }
 
-template <int BM, int BN, int BKT, int AMODE, int BMODE, int NWV, bool FAST>
+template <int BM, int BN, int BKT, int AMODE, int BMODE, int NWV, bool FAST, bool SPLIT = false>
 static int launch_tile_impl(GemmParams& p, dim3 grid, hipStream_t st) {
     p.trace = g_trace_buffer;
-    constexpr size_t lds = (size_t)2 * BKT * ((BM + 2) + (BN + 2)) * sizeof(float);
-    auto kern = gemm_f32_kernel<BM, BN, BKT, AMODE, BMODE, NWV, FAST>;
+    constexpr bool a_kc = AMODE <= OP_KC_WTAP, b_kc = BMODE <= OP_KC_WTAP;
+    constexpr size_t lds = SPLIT ? (size_t)3 * (BKT / 8) * ((BM * 16 + (a_kc ? 128 : 0)) + (BN * 16 + (b_kc ? 128 : 0)))
+                                 : (size_t)2 * BKT * ((BM + 2) + (BN + 2)) * sizeof(float);
+    auto kern = gemm_f32_kernel<BM, BN, BKT, AMODE, BMODE, NWV, FAST, SPLIT>;
     if (lds > 64 * 1024) {
         static bool raised = false;   // one-time opt-in to > 64 KiB of dynamic LDS for this instantiation
         if (!raised) {
@@ -1620,10 +1770,31 @@ static int launch_gemm(GemmParams& p, int Mmax, long out_rows, int zbase, bool a
     }
     dim3 grid(cdiv(p.N, use128 ? 128 : 64), cdiv(Mmax, (use128 || use12864) ? 128 : 64), zbase * (split ? p.splitk : 1));
     int rc;
+    // bf16 split path (see gemm_f32_kernel): the 128-row tiles and the narrow tile, scalar-addressed operands only; four waves per
+    // block so that every wave owns >= two 32x32 accumulators (LDS operand bytes per MFMA halve with each doubling of the wave tile)
+    constexpr bool split_cap = (AMODE == OP_KC_CONV || AMODE == OP_KC_CONVT || AMODE == OP_KC_DENSE || AMODE == OP_RC_DENSE || AMODE == OP_RC_PIX || BMODE == OP_KC_DENSE || BMODE == OP_RC_WT || BMODE == OP_RC_DENSE || BMODE == OP_RC_PIX || BMODE == OP_KC_WTAP);
+    static const int split_tiles_env = getenv("LDETR_SPLIT_BF16") ? atoi(getenv("LDETR_SPLIT_BF16")) : 7;   // bit 0: 128x128, bit 1: 128x64, bit 2: 256x32
+    static const int split_kinds = getenv("LDETR_SPLIT_BF16_KINDS") ? atoi(getenv("LDETR_SPLIT_BF16_KINDS")) : 7;   // bit 0: both operands k-contiguous, bit 1: one, bit 2: none (weight gradients)
+    static const int split_min_kk = getenv("LDETR_SPLIT_BF16_MIN_K") ? atoi(getenv("LDETR_SPLIT_BF16_MIN_K")) : 128;
+    constexpr int split_kind = ((AMODE <= OP_KC_WTAP) && (BMODE <= OP_KC_WTAP)) ? 1 : (((AMODE <= OP_KC_WTAP) || (BMODE <= OP_KC_WTAP)) ? 2 : 4);
+    const int split_tiles = g_split_bf16_override >= 0 ? g_split_bf16_override : split_tiles_env;
+    const int split_on = (split_kinds & split_kind) ? split_tiles : 0;
+    bool sp = false;
+    if constexpr (split_cap) sp = split_on && (p.K / (split ? p.splitk : 1)) >= split_min_kk && fast_operands_ok<AMODE, BMODE>(p, Mmax);
     if constexpr (narrow_cap) {
-        if (use_narrow) return launch_tile<256, 32, 32, AMODE, BMODE, 4>(p, dim3(1, cdiv(Mmax, 256), zbase), Mmax, st);
+        if (use_narrow) {
+            if constexpr (split_cap) { if (sp && (split_on & 4)) return launch_tile_impl<256, 32, 32, AMODE, BMODE, 4, true, true>(p, dim3(1, cdiv(Mmax, 256), zbase), st); }
+            return launch_tile<256, 32, 32, AMODE, BMODE, 4>(p, dim3(1, cdiv(Mmax, 256), zbase), Mmax, st);
+        }
     }
-    if (use128) rc = launch_tile<128, 128, T128_BK, AMODE, BMODE, T128_WAVES>(p, grid, Mmax, st);
+    bool sp_done = false;
+    rc = 0;
+    if constexpr (split_cap) {
+        if (sp && use128 && (split_on & 1)) { rc = launch_tile_impl<128, 128, 32, AMODE, BMODE, 4, true, true>(p, grid, st); sp_done = true; }
+        else if (sp && use12864 && (split_on & 2)) { rc = launch_tile_impl<128, 64, 32, AMODE, BMODE, 4, true, true>(p, grid, st); sp_done = true; }
+    }
+    if (sp_done) {}
+    else if (use128) rc = launch_tile<128, 128, T128_BK, AMODE, BMODE, T128_WAVES>(p, grid, Mmax, st);
     else if (use12864) rc = launch_tile<128, 64, T12864_BK, AMODE, BMODE, T12864_WAVES>(p, grid, Mmax, st);
     else rc = launch_tile<64, 64, 32, AMODE, BMODE>(p, grid, Mmax, st);
     if (rc) return rc;
@@ -1700,6 +1871,12 @@ using namespace ldetr;
 extern "C" int ldetr_debug_trace_tiles(int64_t* buffer) {
     g_trace_buffer = reinterpret_cast<long long*>(buffer);
     return LDETR_OK;
+}
+
+extern "C" int ldetr_set_split_bf16(int tiles) {
+    const int prev = g_split_bf16_override;
+    g_split_bf16_override = tiles;
+    return prev;
 }
 
 extern "C" int ldetr_set_workspace(void* ptr, int64_t bytes) {

@@ -917,3 +917,65 @@ np.savez(sys.argv[1], **out)
         c = res['skinny'][key]
         err = np.abs(a.astype(np.float64) - c).max() / (np.abs(c).max() + 1e-12)
         assert err <= 2e-6, f'{key}: skinny-K routing differs, rel err {err:.2e}'
+
+
+# ------------------------------------------------------------------------------------------ bf16 split pipe vs f32 MFMA pipe
+def _both_pipes(fn):
+    """fn() on the f32 MFMA pipe and on the bf16 pipe with the exact three-way operand split (ldetr_set_split_bf16)."""
+    from layoutdetr_amd.hip import core
+    L = core.lib()
+    prev = L.ldetr_set_split_bf16(0)
+    try:
+        f32 = fn()
+        L.ldetr_set_split_bf16(7)
+        sp = fn()
+    finally:
+        L.ldetr_set_split_bf16(prev)
+    return f32, sp
+
+
+def _err(x, ref):
+    d = (x.double().cpu() - ref).abs()
+    return d.max().item() / ref.abs().max().item(), (d.pow(2).mean().sqrt() / ref.pow(2).mean().sqrt()).item()
+
+
+@pytest.mark.parametrize('ta,tb,M,N,K', [(0, 0, 4096, 512, 1152), (0, 1, 16384, 256, 512), (1, 1, 1024, 1024, 8192), (0, 0, 4096, 2048, 256)])
+def test_split_bf16_gemm_is_fp32_equivalent(dev, ta, tb, M, N, K):
+    """The split path (6 bf16 MFMAs per k16 on hi/mid/lo parts of the fp32 operands) against an fp64 contraction: at least as
+    accurate as the f32 MFMA path on operands with mixed exponents, for every operand view (k-contiguous / row-contiguous)."""
+    from layoutdetr_amd.hip import core
+    torch.manual_seed(40)
+    A = torch.randn((K, M) if ta else (M, K)) * torch.exp(torch.randn(K, 1) if ta else torch.randn(1, K))
+    B = torch.randn((K, N) if tb else (N, K)) * torch.exp(0.5 * (torch.randn(K, 1) if tb else torch.randn(1, K)))
+    ref = (A.double().t() if ta else A.double()) @ (B.double() if tb else B.double().t())
+    Ad, Bd = A.to(dev), B.to(dev)
+    f32, sp = _both_pipes(lambda: core.gemm(Ad, Bd, ta, tb, M, N, K).clone())
+    (m0, r0), (m1, r1) = _err(f32, ref), _err(sp, ref)
+    print(f'gemm ta={ta} tb={tb} {M}x{N}x{K}: f32 pipe max {m0:.2e} rms {r0:.2e} | bf16 split max {m1:.2e} rms {r1:.2e}')
+    assert not torch.equal(f32, sp), 'both runs took the same path: the split tiles were not exercised'
+    assert r1 <= 1.25 * r0 + 1e-9 and m1 <= 2.0 * m0 + 1e-9 and m1 < 5e-6
+
+
+def test_split_bf16_conv_fwd_bwd_is_fp32_equivalent(dev):
+    """3x3 conv forward, data gradient and weight gradient (tap-addressed, transposed-tap and pixel-major operand views) on both
+    pipes against fp64."""
+    from layoutdetr_amd.hip import conv
+    torch.manual_seed(41)
+    N, H, C, O = 16, 64, 128, 128
+    x = torch.randn(N, C, H, H) * torch.exp(torch.randn(1, C, 1, 1)); w = torch.randn(O, C, 3, 3) * (0.05 * torch.exp(0.5 * torch.randn(O, 1, 1, 1)))
+    g = torch.randn(N, O, H, H)
+    xr, wr = x.double().requires_grad_(True), w.double().requires_grad_(True)
+    yr = F.conv2d(xr, wr, padding=1); yr.backward(g.double())
+
+    def run():
+        xg = x.permute(0, 2, 3, 1).contiguous().to(dev).requires_grad_(True)
+        wg = w.to(dev).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+        y = conv.conv2d_nhwc(xg, wg, None, None, None, stride=1, pad=1, relu=False)
+        y.backward(g.permute(0, 2, 3, 1).contiguous().to(dev))
+        return y.detach().permute(0, 3, 1, 2), xg.grad.permute(0, 3, 1, 2), wg.grad.clone()
+    f32, sp = _both_pipes(run)
+    for name, a, b, ref in zip(('y', 'dx', 'dw'), f32, sp, (yr.detach(), xr.grad, wr.grad)):
+        (m0, r0), (m1, r1) = _err(a, ref), _err(b, ref)
+        print(f'conv {name}: f32 pipe max {m0:.2e} rms {r0:.2e} | bf16 split max {m1:.2e} rms {r1:.2e}')
+        assert name == 'dw' or not torch.equal(a, b), name + ': the split tiles were not exercised'
+        assert r1 <= 1.25 * r0 + 1e-9 and m1 <= 2.0 * m0 + 1e-9 and m1 < 5e-6, name
