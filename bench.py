@@ -250,6 +250,14 @@ def run(args, rank, local_rank, world):
                 if share is True:      # and the other side of the headline: D's trunk evaluated once per ITERATION (opt-in `--share-trunk iteration`;
                     r = measure(16, 'iteration')   # D's weights do not change between Gmain and Dmain, so Gmain's D(fake) can read Dmain's evaluation)
                     extra['value_iteration_trunk_sharing'] = r['value']
+                # the same step with every contraction on the f32 MFMA pipe (the default runs the 128-row / narrow tiles of the engine on the
+                # bf16 pipe with the exact three-way operand split: fp32 operands and results, csrc/gemm_conv.hip gemm_f32_kernel<.., SPLIT>)
+                prev = core.lib().ldetr_set_split_bf16(0)
+                try:
+                    r = measure(16, share)
+                finally:
+                    core.lib().ldetr_set_split_bf16(prev)
+                extra['value_f32_mfma_only'] = r['value']
     eager_step = primary.pop('eager_step')
     args.batch, b_local = primary['global_batch'], primary['per_gpu_batch']
     value, ms_per_step = primary['value'], primary['ms_per_step']
@@ -314,7 +322,11 @@ def run(args, rank, local_rank, world):
                         achieved=round(ach, 3), peak=F32_MFMA_PEAK_TFLOPS, unit='TFLOP/s', frac=round(ach / F32_MFMA_PEAK_TFLOPS, 4),
                         traffic=None, launches_per_step=launches // 2, algorithmic_gflop_per_step=round(fl / 2 / 1e9, 2),
                         engine_ms_per_step=round(sec / 2 * 1e3, 3), engine_ms_per_step_uncorrected=round(sec_raw / 2 * 1e3, 3),
-                        event_pair_overhead_us=round(ev_over_ms * 1e3, 2), by_entry=by_entry)
+                        event_pair_overhead_us=round(ev_over_ms * 1e3, 2), by_entry=by_entry,
+                        matrix_pipe='fp32 operands, fp32 accumulators and results throughout; the 128x128 / 128x64 / 256x32 tiles of gemm_f32_kernel multiply on the bf16 pipe '
+                                    'with an exact 3-way operand split (6 x v_mfma_f32_32x32x16_bf16 per k16, error <= the f32 MFMA path: tests/test_kernels_gpu.py '
+                                    'test_split_bf16_*), every other launch on v_mfma_f32_32x32x2_f32 / 16x16x4_f32; `peak` stays the f32 MFMA peak, `achieved` counts '
+                                    'algorithmic fp32 FLOPs (a split launch can exceed it: 6/16 of the bf16 pipe time per fp32 FLOP); value_f32_mfma_only = same step with the split off')
         # HBM traffic of the engine from the PMC counters (FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 passes over the same step, eager):
         # measured offline with tools/pmc_step.py (rocprofv3 cannot wrap this process from inside) and committed; per launch, like `achieved`
         pmc_path = os.path.join(ROOT, 'profiles', 'r02_pmc_traffic.json')

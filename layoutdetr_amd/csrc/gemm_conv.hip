@@ -376,12 +376,23 @@ __device__ __forceinline__ unsigned pk_bf16(float a, float b) {
     bf16x2_t r = {(__bf16)a, (__bf16)b};
     return *reinterpret_cast<unsigned*>(&r);
 }
+// 9 VALU instructions per pair: 3 packed conversions (round to nearest even), 2 x (shift, mask) to widen a part back to fp32, 2 packed
+// subtractions (exact: a part is the leading bits of what it is subtracted from).  The shift is inline asm because hipcc otherwise
+// re-converts the low element on its own instead of shifting the packed word (one more instruction per part).
 __device__ __forceinline__ void split2_bf16(float x0, float x1, unsigned& h, unsigned& m, unsigned& l) {
-    h = pk_bf16(x0, x1);
-    const float r0 = x0 - __uint_as_float(h << 16), r1 = x1 - __uint_as_float(h & 0xffff0000u);
-    m = pk_bf16(r0, r1);
-    const float s0 = r0 - __uint_as_float(m << 16), s1 = r1 - __uint_as_float(m & 0xffff0000u);
-    l = pk_bf16(s0, s1);
+    typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+    auto widen = [](unsigned w) {
+        unsigned lo16;
+        asm("v_lshlrev_b32 %0, 16, %1" : "=v"(lo16) : "v"(w));
+        f32x2_t r = {__uint_as_float(lo16), __uint_as_float(w & 0xffff0000u)};
+        return r;
+    };
+    const f32x2_t x = {x0, x1};
+    h = pk_bf16(x.x, x.y);
+    const f32x2_t r = x - widen(h);
+    m = pk_bf16(r.x, r.y);
+    const f32x2_t t = r - widen(m);
+    l = pk_bf16(t.x, t.y);
 }
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
 
@@ -964,6 +975,7 @@ __global__ __launch_bounds__(NWV * 64) void gemm_f32_kernel(GemmParams p) {
         constexpr int LDSF = 2 * BKT * (LDA + LDB);                                   // floats available
         constexpr int PASSES = (BM * CP + LDSF - 1) / LDSF, RP = BM / PASSES;         // rows staged per pass
         static_assert(BM % PASSES == 0 && RP * CP <= LDSF && (RP % 32) == 0, "epilogue staging does not fit");
+        static_assert(!SPLIT || RP * CP * 4 <= 3 * (BKT / 8) * (PLA + PLB), "epilogue staging does not fit the split path's LDS image");
         float* Cs = ldetr_smem;
 #pragma unroll
         for (int ps = 0; ps < PASSES; ps++) {
