@@ -261,7 +261,7 @@ int ldetr_demod_bwd_f32(const float* weight, int64_t so, int64_t si, int64_t sh,
 
 /* The generator phase's four layout losses on one set of generated boxes, fused with their gradients (training/loss.py:94,
  * metrics/metric_layoutnet.py:153-201,245-275): bbox, bbox_ref [B][N][4] (xc, yc, w, h), valid [B][N] (non-zero = real element),
- * N <= 16.  losses [4][B]: per-sample shares of (0) mse_loss(bbox[valid], bbox_ref[valid]), (1) generalized_iou_loss(same),
+ * N <= 64.  losses [4][B]: per-sample shares of (0) mse_loss(bbox[valid], bbox_ref[valid]), (1) generalized_iou_loss(same),
  * (2) compute_overlap(bbox, valid)[b], (3) compute_alignment(bbox, valid)[b] -- rows 0 and 1 sum to the reference's scalars.
  * grads [4][B][N][4] = d losses[t][b] / d bbox[b] (autograd's subgradient conventions).  bbox_ref may be NULL (rows 0, 1 = 0).
  * bwd: dbbox[b] = sum_t grad_losses[t][b] * grads[t][b]. */
@@ -271,7 +271,7 @@ int ldetr_layout_losses_bwd_f32(const float* grads, const float* grad_losses, in
 
 /* Batched linear-sum-assignment (Hungarian / shortest augmenting path) on device.
  * cost: [batch][n][n] float64 row-major; maximize != 0 negates the costs first;
- * row_ind / col_ind: [batch][n] int32 outputs with scipy's ordering (row_ind sorted ascending). n <= 16. */
+ * row_ind / col_ind: [batch][n] int32 outputs with scipy's ordering (row_ind sorted ascending). n <= 64. */
 int ldetr_lsap_f64(const double* cost, int batch, int n, int maximize, int* row_ind, int* col_ind, void* stream);
 
 #ifdef __cplusplus

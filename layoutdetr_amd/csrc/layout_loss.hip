@@ -4,8 +4,8 @@
 //     generalized_iou_loss(bbox_fake[valid], bbox_real[valid])             metrics/metric_layoutnet.py:245-275
 //     compute_overlap(bbox_fake, valid)                                    metrics/metric_layoutnet.py:153-179
 //     compute_alignment(bbox_fake, valid)                                  metrics/metric_layoutnet.py:182-201
-// Here one wave per sample computes the four values AND their gradients with respect to bbox_fake in the same pass (N <= 16
-// boxes: everything lives in registers / 1 KiB of LDS); the backward is a 4-term weighted sum of the saved gradients.
+// Here one wave per sample computes the four values AND their gradients with respect to bbox_fake in the same pass (N <= 64
+// boxes, one lane each: everything lives in registers / 2 KiB of LDS); the backward is a 4-term weighted sum of the saved gradients.
 // Subgradient conventions are autograd's: maximum / minimum split a tie half-half, where() passes the gradient of the taken
 // branch only, abs' = sign, min(dim) routes to the first arg-min, nan_to_num blocks the gradient of the entries it replaced, and
 // compute_alignment keeps its quirk of comparing valid boxes against padded ones too (the mask is applied to rows only).
@@ -34,10 +34,10 @@ __device__ __forceinline__ void ltrb_to_xywh(float dl, float dt, float dr, float
 }
 
 __global__ __launch_bounds__(64) void layout_losses_kernel(LayoutLossParams p) {
-    __shared__ float sb[16][4];
-    __shared__ int sv[16];
-    __shared__ int aj[16], ac[16];
-    __shared__ float as_[16];
+    __shared__ float sb[64][4];
+    __shared__ int sv[64];
+    __shared__ int aj[64], ac[64];
+    __shared__ float as_[64];
     const int b = blockIdx.x, k = threadIdx.x, N = p.N;
     // number of valid boxes in the whole batch (mse / gIoU are means over all valid boxes) and in this sample
     int tot = 0;
@@ -187,7 +187,7 @@ using namespace ldetr;
 extern "C" int ldetr_layout_losses_f32(const float* bbox, const float* bbox_ref, const uint8_t* valid, int B, int N, float* losses,
                                        float* grads, void* stream) {
     LDETR_CHECK(bbox && valid && losses && grads, "layout_losses: null pointer");
-    LDETR_CHECK(B > 0 && N > 0 && N <= 16, "layout_losses: needs 1 <= N <= 16 boxes per sample (got %d)", N);
+    LDETR_CHECK(B > 0 && N > 0 && N <= 64, "layout_losses: needs 1 <= N <= 64 boxes per sample (got %d)", N);
     LayoutLossParams p; memset(&p, 0, sizeof(p));
     p.box = bbox; p.ref = bbox_ref; p.valid = valid; p.losses = losses; p.grads = grads; p.B = B; p.N = N;
     hipLaunchKernelGGL(layout_losses_kernel, dim3(B), 64, 0, (hipStream_t)stream, p);
@@ -196,7 +196,7 @@ extern "C" int ldetr_layout_losses_f32(const float* bbox, const float* bbox_ref,
 
 extern "C" int ldetr_layout_losses_bwd_f32(const float* grads, const float* grad_losses, int B, int N, float* dbbox, void* stream) {
     LDETR_CHECK(grads && grad_losses && dbbox, "layout_losses_bwd: null pointer");
-    LDETR_CHECK(B > 0 && N > 0 && N <= 16, "layout_losses_bwd: needs 1 <= N <= 16 boxes per sample (got %d)", N);
+    LDETR_CHECK(B > 0 && N > 0 && N <= 64, "layout_losses_bwd: needs 1 <= N <= 64 boxes per sample (got %d)", N);
     LayoutLossParams p; memset(&p, 0, sizeof(p));
     p.grads = const_cast<float*>(grads); p.gout = grad_losses; p.dbox = dbbox; p.B = B; p.N = N;
     const long per = (long)B * N * 4;

@@ -91,7 +91,7 @@ class _LayoutLossesFn(torch.autograd.Function):
 
 def layout_losses_fused(bbox_fake, bbox_real, valid):
     """(mse_loss(fake[valid], real[valid]), generalized_iou_loss(fake[valid], real[valid]), compute_overlap(fake, valid) [B],
-    compute_alignment(fake, valid) [B]) with gradients to bbox_fake only; N <= 16 boxes per sample, GPU tensors."""
+    compute_alignment(fake, valid) [B]) with gradients to bbox_fake only; N <= 64 boxes per sample, GPU tensors."""
     if bbox_real.requires_grad:
         raise NotImplementedError('layout_losses_fused: the reference boxes are data (no gradient is produced for them)')
     out = _LayoutLossesFn.apply(bbox_fake, bbox_real, valid)
@@ -115,7 +115,7 @@ def linear_sum_assignment_batched(cost, maximize=False):
 # Evaluation metrics (reference metrics/metric_layoutnet.py:66-150, 204-242).  Same names and arguments as the
 # reference.  The reference scores one pair of layouts at a time on the host (numpy + scipy, a process pool over conditions);
 # here every same-condition pair of a corpus is scored in ONE batched device pass: pairwise IoU / DocSim weights as [P, n, n]
-# tensors, cross-label entries excluded by a large cost, one device Hungarian solve per pair (csrc/lsap.hip, n <= 16).
+# tensors, cross-label entries excluded by a large cost, one device Hungarian solve per pair (csrc/lsap.hip, n <= 64).
 # Since both layouts of a pair carry the same multiset of labels, the optimum of the single n x n problem is the sum of the
 # reference's per-label optima.  Only the final N x M matching per condition (rectangular, N and M unbounded) stays on scipy.
 _CROSS_LABEL = -1.0e6
@@ -161,7 +161,7 @@ def compute_docsim_for_layout(layout_1, layout_2):
 
 def maximum_scores_batched(b1, l1, b2, l2, kind='iou'):
     """Scores of P layout pairs at once.  b1, b2: [P, n, 4] float32 device tensors (xywh); l1, l2: [P, n] integer labels with
-    equal label multisets per pair; n <= 16.  -> [P] float64: per pair, the maximum over label-preserving matchings of the
+    equal label multisets per pair; n <= 64.  -> [P] float64: per pair, the maximum over label-preserving matchings of the
     summed IoU (kind='iou', reference :100-113) or DocSim weight (kind='docsim', :229-242), divided by n."""
     P, n, _ = b1.shape
     fn = compute_iou if kind == 'iou' else compute_docsim_weight
