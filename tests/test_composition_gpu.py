@@ -14,6 +14,7 @@ import os
 import numpy as np
 import pytest
 import torch
+import torch.nn.functional as F
 
 pytestmark = pytest.mark.gpu
 
@@ -197,22 +198,41 @@ def cast_sd(sd, dt):
     return {k: (v.to(dt) if v.dtype.is_floating_point else v.clone()) for k, v in sd.items()}
 
 
-def test_full_iteration_configs1_b2_256_vs_oracle_fp64_adjudicated(dev):
-    """BASELINE configs[1] size (B=2, 256x256, S=64 image tokens): one Gmain + Dmain iteration through the flat-parameter step.
-    Every loss term and bbox_fake within 1e-3 (north_star) of the CPU oracle; every gradient tensor judged against an fp64 run
-    of the oracle, with the oracle's own fp32 run as yardstick — the step is piecewise linear (ReLU, max-pool, min/max in the
-    layout losses), so a pre-activation within rounding distance of 0 flips a mask in ANY fp32 evaluation, CPU or GPU."""
+def _full_iteration_vs_oracle(dev, bg, B, seed, tag, text_on=False, flip_tolerant=False):
+    """One Gmain + Dmain iteration through the flat-parameter step against the CPU oracle in fp32 and fp64 (see the callers)."""
     from layoutdetr_amd.training import training_loop as tl
     from layoutdetr_amd.training.loss import StyleGAN2Loss
-    from oracle import step_ref
+    from layoutdetr_amd.training.networks_detr import TextTokens
+    from oracle import bert_ref, step_ref
     torch.set_num_threads(min(16, os.cpu_count() or 1))
-    bg, B = 256, 2
-    G, D = make_modules(bg, seed=21)
-    bt, zg, zd = make_batch(B, bg, seed=22)
+    if text_on:
+        G, D = make_modules(bg, seed=seed, text_mode='encoder', bert_num_encoder_layers=12, bert_num_heads=4)
+        for n, p in G.text_encoder.named_parameters():
+            p.data.normal_(0, 0.03)
+            if 'LayerNorm.weight' in n:
+                p.data.add_(1.0)
+        D.text_encoder.load_state_dict(G.text_encoder.state_dict())     # one frozen encoder: the oracle takes its features as an input
+    else:
+        G, D = make_modules(bg, seed=seed)
+    bt, zg, zd = make_batch(B, bg, seed=seed + 1)
     Gsd = {k: v.clone() for k, v in G.state_dict().items()}; Dsd = {k: v.clone() for k, v in D.state_dict().items()}
-    names = dict(G_param_names={n for n, _ in G.named_parameters()}, D_param_names={n for n, _ in D.named_parameters()})
+    toks = None
+    if text_on:
+        T = 40
+        g = torch.Generator().manual_seed(seed + 2)
+        ids = torch.randint(1000, 30000, (B, 9, T), generator=g); lens = torch.randint(3, T + 1, (B, 9), generator=g)
+        am = (torch.arange(T)[None, None, :] < lens[..., None]).long(); ids = ids * am
+        enc = {k[len('text_encoder.'):]: v for k, v in Gsd.items() if k.startswith('text_encoder.')}
+        with torch.no_grad():     # the frozen encoder's features: fp32 for the fp32 oracle run, fp64 for the yardstick run
+            bt['text_feat'] = bert_ref.bert_text_forward(enc, 4, ids.reshape(B * 9, T), am.reshape(B * 9, T))[:, 0].reshape(B, 9, -1)
+            feat64 = bert_ref.bert_text_forward(cast_sd(enc, torch.float64), 4, ids.reshape(B * 9, T), am.reshape(B * 9, T))[:, 0].reshape(B, 9, -1)
+        toks = TextTokens(ids.to(dev), am.to(dev), bt['text_len'].to(dev))
+    trainable = lambda m: {n for n, _ in m.named_parameters() if not n.startswith('text_encoder.')}      # noqa: E731  (the text encoder is frozen)
+    names = dict(G_param_names=trainable(G), D_param_names=trainable(D))
     o32 = step_ref.training_iteration(Gsd, Dsd, bt, zg, zd, bg_size=bg, apply_adam=False, **names)
     bt64 = {k: (v.double() if v.dtype.is_floating_point else v) for k, v in bt.items()}
+    if text_on:
+        bt64['text_feat'] = feat64
     o64 = step_ref.training_iteration(cast_sd(Gsd, torch.float64), cast_sd(Dsd, torch.float64), bt64, zg.double(), zd.double(), bg_size=bg,
                                       apply_adam=False, **names)
     G.eval().requires_grad_(False).to(dev); D.eval().requires_grad_(False).to(dev)
@@ -224,19 +244,21 @@ def test_full_iteration_configs1_b2_256_vs_oracle_fp64_adjudicated(dev):
     orig = dp.apply
 
     def spy(phase):
-        grads[phase.name] = {n: p.grad.detach().clone() for n, p in phase.module.named_parameters()}
+        grads[phase.name] = {n: p.grad.detach().clone() for n, p in phase.module.named_parameters() if p.grad is not None}
         terms[phase.name] = {k + (f'#{i}' if len(vs) > 1 else ''): v for k, vs in reports.items() for i, v in enumerate(vs)}
         reports.clear()
         orig(phase)
     dp.apply = spy
-    tl.training_iteration(loss, [pG, pD], dp, device_batch(bt, dev), B, [zg.to(dev), zd.to(dev)])
+    batch = device_batch(bt, dev)
+    if toks is not None:
+        batch['bbox_text'] = toks
+    tl.training_iteration(loss, [pG, pD], dp, batch, B, [zg.to(dev), zd.to(dev)])
     valid = ~bt['padding_mask']
     check(loss.last['bbox_fake'][valid.to(dev)], o64[0]['bbox_fake'][valid], 1e-3, 'bbox_fake')
     worst_term = 0.0
     for phase, key in (('Gmain', 'terms_G'), ('Dmain', 'terms_D')):
         ref = o64[0][key]
         got = terms[phase]
-        # the reference reports 'Loss/scores/fake' + 'Loss/signs/fake' twice in Dmain?  no: once per phase (Dgen); '#i' only if repeated
         assert set(ref) == set(got), sorted(set(ref) ^ set(got))
         for k, v in ref.items():
             e, e_cpu32 = rel(got[k], v), rel(o32[0][key][k], v)
@@ -250,17 +272,49 @@ def test_full_iteration_configs1_b2_256_vs_oracle_fp64_adjudicated(dev):
             if a > max(3 * b, 1e-4):
                 bad.append((a, b, phase, k))
     e_gpu, e_cpu = np.array(e_gpu), np.array(e_cpu)
-    print(f'[configs1 B=2 256] worst loss-term err {worst_term:.2e}; gradient error vs fp64 oracle: HIP median {np.median(e_gpu):.2e} p90 {np.quantile(e_gpu, .9):.2e} '
+    print(f'[{tag}] worst loss-term err {worst_term:.2e}; gradient error vs fp64 oracle: HIP median {np.median(e_gpu):.2e} p90 {np.quantile(e_gpu, .9):.2e} '
           f'max {e_gpu.max():.2e} | CPU fp32 median {np.median(e_cpu):.2e} p90 {np.quantile(e_cpu, .9):.2e} max {e_cpu.max():.2e}; '
           f'{len(bad)} of {len(e_gpu)} tensors beyond 3x the CPU-fp32 error: {sorted(bad, reverse=True)[:3]}')
     # As close to fp64 as the CPU fp32 evaluation is, IN DISTRIBUTION.  Not tensor by tensor: one flipped ReLU in layer2 perturbs the
     # gradient of every tensor upstream of it (all of layer1 + the stem move together by the same ~2e-2), and the CPU and the GPU
-    # run flip different units (CPU fp32's own worst tensor here is 1.4e-1 off its fp64 value).  The flip-free parts of the step
+    # run flip different units (CPU fp32's own worst tensor at B=2 / 256 is 1.4e-1 off its fp64 value).  The flip-free parts of the step
     # are held tensor by tensor at 1e-4 by test_loss_phases_vs_reference_fixture, the trunk's kernels by tests/test_kernels_gpu.py.
+    if flip_tolerant:
+        # 512 x 512: four times the activations of configs[1], and across seeds / pipes either side draws the unlucky flip (measured over
+        # six runs: CPU fp32 median 2.5e-6 .. 1.6e-4 and max 4e-2 .. 5.5e-1, HIP 1.2e-6 .. 2.7e-4 and 1e-1 .. 4.8e-1; a flipped FFN
+        # unit in one of G's decoder layers alone moves > half of the tensors by 1e-4).  What a wrong kernel would do — O(1) errors
+        # in many tensors, a rotated gradient — is still caught: few tensors far off, and each phase's whole gradient parallel to fp64's.
+        assert np.median(e_gpu) <= max(20 * np.median(e_cpu), 5e-4)
+        assert (e_gpu > 0.1).mean() <= max(2 * (e_cpu > 0.1).mean(), 0.10), (e_gpu > 0.1).mean()
+        for phase, i in (('Gmain', 1), ('Dmain', 2)):
+            a = torch.cat([grads[phase][k].double().cpu().flatten() for k in o64[i]]); b = torch.cat([o64[i][k].flatten() for k in o64[i]])
+            c32 = torch.cat([o32[i][k].double().flatten() for k in o64[i]])
+            cos, cos_cpu = F.cosine_similarity(a, b, dim=0).item(), F.cosine_similarity(c32, b, dim=0).item()
+            print(f'   {phase}: cosine(HIP, fp64) {cos:.6f}, cosine(CPU fp32, fp64) {cos_cpu:.6f}, norm ratio {(a.norm() / b.norm()).item():.5f}')
+            # (eight runs, four seeds x text on / off: HIP 0.9719 .. 1.0000 with the norm 0.66 .. 1.03 of fp64's, CPU fp32 0.9785 .. 1.0000 —
+            #  one unlucky unit in a layer with a dominant gradient moves the whole phase that far in either evaluation)
+            assert cos >= 0.95 and 0.6 <= (a.norm() / b.norm()).item() <= 1.5
+        return
     assert np.median(e_gpu) <= max(2 * np.median(e_cpu), 2e-5)
     assert np.quantile(e_gpu, 0.9) <= max(3 * np.quantile(e_cpu, 0.9), 1e-4)
     assert e_gpu.max() <= max(2 * e_cpu.max(), 1e-3)
     assert len(bad) <= 0.15 * len(e_gpu), bad[:5]
+
+
+def test_full_iteration_configs1_b2_256_vs_oracle_fp64_adjudicated(dev):
+    """BASELINE configs[1] size (B=2, 256x256, S=64 image tokens): one Gmain + Dmain iteration through the flat-parameter step.
+    Every loss term and bbox_fake within 1e-3 (north_star) of the CPU oracle; every gradient tensor judged against an fp64 run
+    of the oracle, with the oracle's own fp32 run as yardstick — the step is piecewise linear (ReLU, max-pool, min/max in the
+    layout losses), so a pre-activation within rounding distance of 0 flips a mask in ANY fp32 evaluation, CPU or GPU."""
+    _full_iteration_vs_oracle(dev, 256, 2, 21, 'configs1 B=2 256')
+
+
+def test_full_iteration_configs4_share_b2_512_text_encoder_on_vs_oracle_fp64_adjudicated(dev):
+    """BASELINE configs[4]'s shape (512x512 backgrounds -> S=256 image tokens, text path ON: token ids in, the frozen 12-layer BERT
+    text encoder runs inside G / D on the HIP kernels) for the full Gmain + Dmain iteration at 2 samples: every loss term, bbox_fake
+    and every trainable gradient against the oracle (bert_ref features in) in fp32 and fp64; the gradient gates are the flip-tolerant
+    ones (see the helper)."""
+    _full_iteration_vs_oracle(dev, 512, 2, 61, 'configs4 share B=2 512 text on', text_on=True, flip_tolerant=True)
 
 
 def test_forward_and_losses_configs2_b16_256_vs_oracle(dev):
