@@ -204,8 +204,9 @@ class Transformer(nn.Module):
         self._reset_parameters()
         self.d_model = d_model
         self.nhead = nhead
-        if d_model // nhead != 32:
-            raise NotImplementedError('the fused attention kernel is specialised for head_dim 32 (d_model 256, 8 heads)')
+        if d_model % nhead != 0 or (d_model // nhead) % 32 != 0 or d_model // nhead > 192:
+            raise NotImplementedError('the fused attention kernels take head widths that are multiples of 32 up to 192 '
+                                      f'(d_model {d_model} / {nhead} heads = {d_model / nhead:g})')
 
     def _reset_parameters(self):
         for p in self.parameters():

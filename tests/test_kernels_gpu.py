@@ -411,13 +411,15 @@ def test_maxpool(dev):
 
 
 # ------------------------------------------------------------------------------------------ attention
-@pytest.mark.parametrize('B,H,Lq,Lk', [(2, 8, 9, 9), (2, 8, 10, 64), (3, 2, 64, 64), (1, 4, 16, 256), (2, 8, 33, 100),
-                                       (2, 8, 9, 257), (2, 2, 300, 400), (1, 4, 16, 1024), (1, 2, 1024, 1024), (2, 1, 40, 2100)])
-def test_attention(dev, B, H, Lq, Lk):
-    """Lk <= 256: scores in registers; above: 256-key chunks with an online softmax (background_size 1024 -> 1024 memory tokens)."""
+@pytest.mark.parametrize('B,H,Lq,Lk,dh', [(2, 8, 9, 9, 32), (2, 8, 10, 64, 32), (3, 2, 64, 64, 32), (1, 4, 16, 256, 32), (2, 8, 33, 100, 32),
+                                          (2, 8, 9, 257, 32), (2, 2, 300, 400, 32), (1, 4, 16, 1024, 32), (1, 2, 1024, 1024, 32), (2, 1, 40, 2100, 32),
+                                          (2, 4, 9, 64, 64), (2, 2, 10, 256, 128), (2, 4, 70, 300, 64), (2, 3, 9, 9, 96)])
+def test_attention(dev, B, H, Lq, Lk, dh):
+    """Lk <= 256: scores in registers; above: 256-key chunks with an online softmax (background_size 1024 -> 1024 memory tokens).
+    Head widths 32 (the DETR blocks at 8 heads) .. 128 (hidden 256 at 4 / 2 heads), cross-attention shapes (Lq != Lk)."""
     from layoutdetr_amd.hip import attention
     torch.manual_seed(9)
-    d = H * 32
+    d = H * dh
     q = torch.randn(B * Lq, d); k = torch.randn(B * Lk, d); v = torch.randn(B * Lk, d)
     kpm = torch.zeros(B, Lk, dtype=torch.bool)
     kpm[0, Lk - Lk // 3:] = True
@@ -426,8 +428,8 @@ def test_attention(dev, B, H, Lq, Lk):
     qr, kr, vr = [t.clone().requires_grad_(True) for t in (q, k, v)]
 
     def heads(t, L):
-        return t.view(B, L, H, 32).permute(0, 2, 1, 3)
-    s = heads(qr, Lq) @ heads(kr, Lk).transpose(-1, -2) / math.sqrt(32)
+        return t.view(B, L, H, dh).permute(0, 2, 1, 3)
+    s = heads(qr, Lq) @ heads(kr, Lk).transpose(-1, -2) / math.sqrt(dh)
     s = s.masked_fill(kpm[:, None, None, :], float('-inf'))
     o = (s.softmax(-1) @ heads(vr, Lk)).permute(0, 2, 1, 3).reshape(B * Lq, d)
     g = torch.randn_like(o); o.backward(g)

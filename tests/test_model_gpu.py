@@ -50,6 +50,41 @@ def test_detr_transformer_matches_reference_golden(dev, name):
             check(p.grad, grads[k], 2e-4, 'grad ' + k)
 
 
+@pytest.mark.parametrize('cls_name,d_model,nhead', [('Transformer', 256, 4), ('TransformerWithToken', 256, 2), ('Transformer', 192, 2)])
+def test_detr_transformer_wider_heads_vs_oracle(dev, cls_name, d_model, nhead):
+    """Head widths 64 / 128 / 96 (the reference's constructors take any hidden_dim / nhead; its own default is 256 / 8 = 32): DETR
+    encoder-decoder forward and every gradient against the golden-pinned oracle (oracle/detr_ref.transformer) on ragged masks."""
+    from layoutdetr_amd.training import detr_transformer as T
+    from oracle import detr_ref
+    torch.manual_seed(71)
+    B, Hh, Ww, N = 3, 4, 5, 9
+    m = getattr(T, cls_name)(d_model=d_model, nhead=nhead, num_encoder_layers=2, num_decoder_layers=2, dim_feedforward=256, dropout=0.1).eval()
+    for p in m.parameters():
+        if p.dim() == 1:
+            p.data.uniform_(-0.2, 0.2).add_(1.0 if p.numel() == d_model and p.data.mean() > 0.5 else 0.0)
+    src = torch.randn(B, d_model, Hh, Ww); pos = torch.randn(B, d_model, Hh, Ww) * 0.5
+    mask = torch.zeros(B, Hh, Ww, dtype=torch.bool); mask[1, :, 3:] = True; mask[2, 2:, :] = True
+    tgt = torch.randn(N, B, d_model); kpm = torch.zeros(B, N, dtype=torch.bool); kpm[0, 6:] = True; kpm[2, 1:] = True
+    with_token = cls_name.endswith('Token')
+    valid = torch.cat([torch.ones(B, 1, dtype=torch.bool), ~kpm], 1) if with_token else ~kpm          # [B, Lq(+1)]
+    g_hs = torch.randn(B, valid.shape[1], d_model) * valid[..., None]
+    sd = {k: v.clone().requires_grad_(v.dtype.is_floating_point) for k, v in m.state_dict().items()}
+    sr, tr = src.clone().requires_grad_(True), tgt.clone().requires_grad_(True)
+    hs_r, mem_r = detr_ref.transformer(sd, sr, mask, pos, tr, kpm, nhead, with_token=with_token)
+    (hs_r * g_hs).sum().backward()
+    m.to(dev)
+    sg, tg = src.to(dev).requires_grad_(True), tgt.to(dev).requires_grad_(True)
+    hs, mem = m(sg, mask.to(dev), pos.to(dev), tg, kpm.to(dev))
+    check(hs.reshape(hs_r.shape)[valid.to(dev)], hs_r[valid], 3e-5, 'hs')
+    (hs.reshape(hs_r.shape) * g_hs.to(dev)).sum().backward()
+    check(sg.grad, sr.grad, 2e-4, 'd_src'); check(tg.grad.transpose(0, 1)[(~kpm).to(dev)], tr.grad.transpose(0, 1)[~kpm], 2e-4, 'd_tgt')
+    n = 0
+    for k, p in m.named_parameters():
+        if sd[k].grad is not None and sd[k].grad.abs().max() > 0:
+            check(p.grad, sd[k].grad, 3e-4, 'grad ' + k); n += 1
+    assert n >= 40
+
+
 def test_layoutganpp_encoder_matches_reference_golden(dev):
     from layoutdetr_amd.training.util import TransformerWithToken_layoutganpp
     d = load('transformer_layoutganpp')
