@@ -182,7 +182,7 @@ class StyleGAN2Loss(Loss):
         bbox_fake, loss_z, cls_logits, loss_lm, loss_text_len = self.run_G(gen_z, bbox_class, bbox_real, bbox_text, bbox_patch, padding_mask, background, gen_c, reconst=True)
         gen_logits, gen_logits_uncond = self.run_D(bbox_fake, bbox_class, bbox_text, bbox_patch, padding_mask, background, gen_c,
                                                    trunk_out=cached if cached is not None else (fork.join() if fork is not None else None))
-        if static and self.fused_layout_losses and bbox_fake.is_cuda and bbox_fake.shape[1] <= 16:
+        if static and self.fused_layout_losses and bbox_fake.is_cuda and bbox_fake.shape[1] <= 64:
             # one launch for the four layout terms and their gradients (csrc/layout_loss.hip) instead of ~280 elementwise ones
             l_rec, l_giou, l_ovl, l_aln = layout_losses_fused(bbox_fake, bbox_real, valid)
         elif static:
