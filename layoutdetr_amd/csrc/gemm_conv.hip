@@ -395,6 +395,9 @@ __device__ __forceinline__ void split2_bf16(float x0, float x1, unsigned& h, uns
     l = pk_bf16(t.x, t.y);
 }
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+#ifndef LDETR_KC_PAD
+#define LDETR_KC_PAD 64   // bytes between the (part, k-block) planes of a k-contiguous operand's LDS image (see gemm_f32_kernel)
+#endif
 
 template <int BM, int BN, int BKT, int AMODE, int BMODE, int NWV, bool FAST, bool SPLIT = false>
 __global__ __launch_bounds__(NWV * 64) void gemm_f32_kernel(GemmParams p) {
@@ -418,7 +421,7 @@ __global__ __launch_bounds__(NWV * 64) void gemm_f32_kernel(GemmParams p) {
     // mod rows/4: the lanes of a store hit consecutive slots, and the 32 rows of an operand read fall two per 16-byte bank group
     // (the minimum); with slot = row those stores were 16-way bank conflicts.
     char* const sbase = reinterpret_cast<char*>(ldetr_smem);
-    constexpr int PLA = A_KC ? BM * 16 + 128 : BM * 16, PLB = B_KC ? BN * 16 + 128 : BN * 16;   // bytes per (part, k-block) plane
+    constexpr int PLA = A_KC ? BM * 16 + LDETR_KC_PAD : BM * 16, PLB = B_KC ? BN * 16 + LDETR_KC_PAD : BN * 16;   // bytes per (part, k-block) plane
     constexpr int SB_OFF = 3 * (BKT / 8) * PLA;
     auto slotA = [](int row) { return A_KC ? row : ((row & 3) * (BM / 4) + (((row >> 2) + 8 * (row & 1)) & (BM / 4 - 1))); };
     auto slotB = [](int row) { return B_KC ? row : ((row & 3) * (BN / 4) + (((row >> 2) + 8 * (row & 1)) & (BN / 4 - 1))); };
@@ -1678,7 +1681,7 @@ template <int BM, int BN, int BKT, int AMODE, int BMODE, int NWV, bool FAST, boo
 static int launch_tile_impl(GemmParams& p, dim3 grid, hipStream_t st) {
     p.trace = g_trace_buffer;
     constexpr bool a_kc = AMODE <= OP_KC_WTAP, b_kc = BMODE <= OP_KC_WTAP;
-    constexpr size_t lds = SPLIT ? (size_t)3 * (BKT / 8) * ((BM * 16 + (a_kc ? 128 : 0)) + (BN * 16 + (b_kc ? 128 : 0)))
+    constexpr size_t lds = SPLIT ? (size_t)3 * (BKT / 8) * ((BM * 16 + (a_kc ? LDETR_KC_PAD : 0)) + (BN * 16 + (b_kc ? LDETR_KC_PAD : 0)))
                                  : (size_t)2 * BKT * ((BM + 2) + (BN + 2)) * sizeof(float);
     auto kern = gemm_f32_kernel<BM, BN, BKT, AMODE, BMODE, NWV, FAST, SPLIT>;
     if (lds > 64 * 1024) {
