@@ -416,15 +416,17 @@ __global__ __launch_bounds__(NWV * 64) void gemm_f32_kernel(GemmParams p) {
     float (*Bs)[BKT][LDB] = reinterpret_cast<float (*)[BKT][LDB]>(ldetr_smem + 2 * BKT * LDA);
     // SPLIT: one buffer of [part][k-block of 8][slot][8 bf16]: a lane's MFMA operand (8 consecutive k of one row) is one 16-byte
     // read.  k-contiguous operands keep slot = row (the 32 lanes of a k-block read 512 contiguous bytes; writes are 8 bytes per
-    // (row, half k-block), and 128 bytes of padding per plane keep the four k-blocks a wave writes for one row off each other's
-    // banks).  Row-contiguous operands (a lane loads 4 adjacent rows of one k) use slot = (row % 4) * rows/4 + (row / 4 + 8 * (row & 1))
-    // mod rows/4: the lanes of a store hit consecutive slots, and the 32 rows of an operand read fall two per 16-byte bank group
-    // (the minimum); with slot = row those stores were 16-way bank conflicts.
+    // (row, half k-block), and 64 bytes of padding per plane keep the four k-blocks a wave writes for one row off each other's
+    // banks).  Row-contiguous operands (a lane loads 4 adjacent rows of one k) use slot = (row % 4) * rows/4 + (row / 4 + rotation(row % 4))
+    // mod rows/4: the lanes of a store hit consecutive slots and a pass of an operand read hits every bank group once; with
+    // slot = row those stores were 16-way bank conflicts.
     char* const sbase = reinterpret_cast<char*>(ldetr_smem);
     constexpr int PLA = A_KC ? BM * 16 + LDETR_KC_PAD : BM * 16, PLB = B_KC ? BN * 16 + LDETR_KC_PAD : BN * 16;   // bytes per (part, k-block) plane
     constexpr int SB_OFF = 3 * (BKT / 8) * PLA;
-    auto slotA = [](int row) { return A_KC ? row : ((row & 3) * (BM / 4) + (((row >> 2) + 8 * (row & 1)) & (BM / 4 - 1))); };
-    auto slotB = [](int row) { return B_KC ? row : ((row & 3) * (BN / 4) + (((row >> 2) + 8 * (row & 1)) & (BN / 4 - 1))); };
+    // (rotation 0 / 8 / 4 / 12 slots for rows 4q, 4q+1, 4q+2, 4q+3: the 16 lanes of one pass of an operand read then hit 16 different
+    //  16-byte bank groups; with 0 / 8 / 0 / 8 they hit 8, two lanes each)
+    auto slotA = [](int row) { return A_KC ? row : ((row & 3) * (BM / 4) + (((row >> 2) + 8 * (row & 1) + 4 * ((row >> 1) & 1)) & (BM / 4 - 1))); };
+    auto slotB = [](int row) { return B_KC ? row : ((row & 3) * (BN / 4) + (((row >> 2) + 8 * (row & 1) + 4 * ((row >> 1) & 1)) & (BN / 4 - 1))); };
     auto adrA = [&](int part, int kb, int row, int koff) { return sbase + (part * (BKT / 8) + kb) * PLA + slotA(row) * 16 + koff * 2; };
     auto adrB = [&](int part, int kb, int row, int koff) { return sbase + SB_OFF + (part * (BKT / 8) + kb) * PLB + slotB(row) * 16 + koff * 2; };
     // row-contiguous operands under SPLIT: a thread's units are grouped G consecutive k for the same four rows, so the bf16 values
@@ -455,8 +457,12 @@ __global__ __launch_bounds__(NWV * 64) void gemm_f32_kernel(GemmParams p) {
             if constexpr (AMODE != OP_KC_DENSE) kdec_init_tap(a_d[i], z.tm, z.kbeg + a_k[i], p.A.C);
         } else {
             {
-                const int slot = tid + (i / GA) * NT, kg = slot / (BM / 4);
-                a_k[i] = kg * GA + (i % GA); a_r[i] = (slot - kg * (BM / 4)) << 2;
+                // SPLIT: adjacent lanes take the two k-groups that share a 16-byte LDS slot (its low / high 8 bytes), so the 32 lanes of a
+                // store pass fill 256 contiguous bytes; lanes 2q and 2q+1 then load from two rows of the operand (two coalesced runs)
+                const int slot = tid + (i / GA) * NT;
+                const int kg = SPLIT ? 2 * ((slot >> 1) / (BM / 4)) + (slot & 1) : slot / (BM / 4);
+                const int rq = SPLIT ? (slot >> 1) % (BM / 4) : slot - kg * (BM / 4);
+                a_k[i] = kg * GA + (i % GA); a_r[i] = rq << 2;
             }
             if constexpr (AMODE == OP_RC_WT) kdec_init_tap(a_d[i], z.tm, z.kbeg + a_k[i], p.A.C);
             if constexpr (AMODE == OP_RC_PIX || AMODE == OP_RC_CONVK) kdec_init_pix(a_d[i], z.kbeg + a_k[i], p.A.DH, p.A.DW);
@@ -471,8 +477,10 @@ __global__ __launch_bounds__(NWV * 64) void gemm_f32_kernel(GemmParams p) {
             if constexpr (BMODE != OP_KC_DENSE) kdec_init_tap(b_d[i], z.tm, z.kbeg + b_k[i], p.B.C);
         } else {
             {
-                const int slot = tid + (i / GB) * NT, kg = slot / (BN / 4);
-                b_k[i] = kg * GB + (i % GB); b_r[i] = (slot - kg * (BN / 4)) << 2;
+                const int slot = tid + (i / GB) * NT;
+                const int kg = SPLIT ? 2 * ((slot >> 1) / (BN / 4)) + (slot & 1) : slot / (BN / 4);
+                const int rq = SPLIT ? (slot >> 1) % (BN / 4) : slot - kg * (BN / 4);
+                b_k[i] = kg * GB + (i % GB); b_r[i] = rq << 2;
             }
             if constexpr (BMODE == OP_RC_WT) kdec_init_tap(b_d[i], z.tm, z.kbeg + b_k[i], p.B.C);
             if constexpr (BMODE == OP_RC_PIX || BMODE == OP_RC_CONVK) kdec_init_pix(b_d[i], z.kbeg + b_k[i], p.B.DH, p.B.DW);
