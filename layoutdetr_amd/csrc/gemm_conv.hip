@@ -1796,7 +1796,7 @@ static int launch_gemm(GemmParams& p, int Mmax, long out_rows, int zbase, bool a
     // bf16 split path (see gemm_f32_kernel): the 128-row tiles and the narrow tile, scalar-addressed operands only; four waves per
     // block so that every wave owns >= two 32x32 accumulators (LDS operand bytes per MFMA halve with each doubling of the wave tile)
     constexpr bool split_cap = (AMODE == OP_KC_CONV || AMODE == OP_KC_CONVT || AMODE == OP_KC_DENSE || AMODE == OP_RC_DENSE || AMODE == OP_RC_PIX || BMODE == OP_KC_DENSE || BMODE == OP_RC_WT || BMODE == OP_RC_DENSE || BMODE == OP_RC_PIX || BMODE == OP_KC_WTAP);
-    static const int split_tiles_env = getenv("LDETR_SPLIT_BF16") ? atoi(getenv("LDETR_SPLIT_BF16")) : 7;   // bit 0: 128x128, bit 1: 128x64, bit 2: 256x32
+    static const int split_tiles_env = getenv("LDETR_SPLIT_BF16") ? atoi(getenv("LDETR_SPLIT_BF16")) : 15;   // bit 0: 128x128, bit 1: 128x64, bit 2: 256x32, bit 3: 64x64
     static const int split_kinds = getenv("LDETR_SPLIT_BF16_KINDS") ? atoi(getenv("LDETR_SPLIT_BF16_KINDS")) : 7;   // bit 0: both operands k-contiguous, bit 1: one, bit 2: none (weight gradients)
     static const int split_min_kk = getenv("LDETR_SPLIT_BF16_MIN_K") ? atoi(getenv("LDETR_SPLIT_BF16_MIN_K")) : 128;
     constexpr int split_kind = ((AMODE <= OP_KC_WTAP) && (BMODE <= OP_KC_WTAP)) ? 1 : (((AMODE <= OP_KC_WTAP) || (BMODE <= OP_KC_WTAP)) ? 2 : 4);
@@ -1815,6 +1815,7 @@ static int launch_gemm(GemmParams& p, int Mmax, long out_rows, int zbase, bool a
     if constexpr (split_cap) {
         if (sp && use128 && (split_on & 1)) { rc = launch_tile_impl<128, 128, 32, AMODE, BMODE, 4, true, true>(p, grid, st); sp_done = true; }
         else if (sp && use12864 && (split_on & 2)) { rc = launch_tile_impl<128, 64, 32, AMODE, BMODE, 4, true, true>(p, grid, st); sp_done = true; }
+        else if (sp && !use128 && !use12864 && (split_on & 8)) { rc = launch_tile_impl<64, 64, 32, AMODE, BMODE, 4, true, true>(p, grid, st); sp_done = true; }
     }
     if (sp_done) {}
     else if (use128) rc = launch_tile<128, 128, T128_BK, AMODE, BMODE, T128_WAVES>(p, grid, Mmax, st);

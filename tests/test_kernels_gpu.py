@@ -907,6 +907,7 @@ np.savez(sys.argv[1], **out)
                      ('skinny', {'LDETR_SKINNY_MAXK': '256'})):   # the register-stationary 1x1 kernel (off by default since the FAST loads)
         path = str(tmp_path / f'{tag}.npz')
         e = dict(os.environ); e.update(env); e['PYTHONPATH'] = root + os.pathsep + e.get('PYTHONPATH', '')
+        e['LDETR_SPLIT_BF16'] = '0'      # the bf16 split path exists for FAST operands only: compare the f32 MFMA pipe with itself
         subprocess.run([sys.executable, '-c', script, path], check=True, env=e, cwd=root, timeout=300, stdin=subprocess.DEVNULL)
         res[tag] = np.load(path)
     for key in res['fast'].files:
@@ -929,7 +930,7 @@ def _both_pipes(fn):
     prev = L.ldetr_set_split_bf16(0)
     try:
         f32 = fn()
-        L.ldetr_set_split_bf16(7)
+        L.ldetr_set_split_bf16(15)
         sp = fn()
     finally:
         L.ldetr_set_split_bf16(prev)
