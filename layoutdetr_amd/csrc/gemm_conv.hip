@@ -19,6 +19,8 @@
 #include "../../include/ldetr_hip.h"
 
 namespace ldetr {
+int try_launch_stem_conv(const float* x, const ldetr_tensor4* xt, const float* w, int Cout, int KH, int KW, int stride, int pad,
+                         float* y, long ldy, int OH, int OW, const float* in_scale, const ldetr_epilogue* ep, hipStream_t st);
 int try_launch_wgrad_smallc(const float* x, const ldetr_tensor4* xt, const float* dy, const ldetr_tensor4* dyt, float* dw, int KH, int KW, int stride, int pad,
                             const float* x_scale, int64_t x_scale_ld, const float* dy_scale, int64_t dy_scale_ld, hipStream_t st);
 
@@ -2037,6 +2039,10 @@ extern "C" int ldetr_conv2d_fwd_f32(const float* x, const ldetr_tensor4* xt, con
     LDETR_CHECK(x && w && y && xt, "conv2d_fwd: null pointer");
     int eOH = (xt->H + 2 * pad - KH) / stride + 1, eOW = (xt->W + 2 * pad - KW) / stride + 1;
     LDETR_CHECK(eOH == OH && eOW == OW, "conv2d_fwd: output size mismatch (expected %dx%d)", eOH, eOW);
+    {   // the ResNet stem (3 -> 64 channels, 7x7 / 2) has its own LDS-resident kernel (csrc/stem_conv.hip)
+        const int took = try_launch_stem_conv(x, xt, w, Cout, KH, KW, stride, pad, y, ldy, OH, OW, in_scale, ep, (hipStream_t)stream);
+        if (took >= 0) return took;
+    }
     GemmParams p; memset(&p, 0, sizeof(p));
     init_operand(p.A); init_operand(p.B);
     set_conv_src(p.A, x, xt);

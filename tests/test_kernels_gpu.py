@@ -384,18 +384,27 @@ def test_conv_relu_gradient_handoff(dev, case):
     assert_close(xg.grad.permute(0, 3, 1, 2), xr.grad, 5e-6, 'dx')
 
 
-def test_conv2d_stem_nchw(dev):
+@pytest.mark.parametrize('N,H,W', [(2, 32, 32), (3, 50, 76), (1, 37, 131), (2, 256, 256)])
+def test_conv2d_stem_nchw(dev, N, H, W):
+    """ResNet stem 7x7 / 2 on an NCHW image (csrc/stem_conv.hip: LDS-resident patch + weights) with FrozenBN + ReLU fused; sizes that do
+    not fill the 8 x 32 output tiles, odd sizes; the weight gradient (engine, scalar-gather operand view) alongside."""
     from layoutdetr_amd.hip import conv
     torch.manual_seed(7)
-    x = torch.randn(2, 3, 32, 32); w = torch.randn(64, 3, 7, 7) * 0.1
+    x = torch.randn(N, 3, H, W); w = torch.randn(64, 3, 7, 7) * 0.1
     scale = torch.rand(64) + 0.5; shift = torch.randn(64)
-    wr = w.clone().requires_grad_(True)
-    yr = F.relu(F.conv2d(x, wr, stride=2, padding=3) * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1))
-    g = torch.randn_like(yr); yr.backward(g)
     wg = w.to(dev).contiguous(memory_format=torch.channels_last).requires_grad_(True)
     y = conv.conv2d_nhwc(x.to(dev), wg, scale.to(dev), shift.to(dev), None, stride=2, pad=3, relu=True, x_is_nchw=True)
+    wr = w.clone().requires_grad_(True)
+    pre = F.conv2d(x, wr, stride=2, padding=3) * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)
+    # the ReLU mask of the reference backward is the device's: among 10^5..10^6 outputs a few pre-activations lie within rounding
+    # distance of zero, and one flipped unit moves dw by ~1e-3 of its maximum (checked below: disagreements only there)
+    mask = (y.permute(0, 3, 1, 2) > 0).cpu()
+    flips = mask != (pre.detach() > 0)
+    assert flips.sum().item() <= 8 and (pre.detach()[flips].abs() < 1e-5).all()
+    yr = pre * mask
+    g = torch.randn_like(yr); yr.backward(g)
     y.backward(g.permute(0, 2, 3, 1).contiguous().to(dev))
-    assert_close(y.permute(0, 3, 1, 2), yr, 3e-6, 'stem y'); assert_close(wg.grad, wr.grad, 1e-5, 'stem dw')
+    assert_close(y.permute(0, 3, 1, 2), yr.detach(), 3e-6, 'stem y'); assert_close(wg.grad, wr.grad, 1e-5, 'stem dw')
 
 
 def test_maxpool(dev):
