@@ -30,6 +30,9 @@ if ROOT not in sys.path:
 import torch  # noqa: E402
 
 F32_MFMA_PEAK_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense, 256 CUs @ 2.4 GHz
+BF16_MFMA_PEAK_TFLOPS = 2500.0  # same guide: dense bf16 (v_mfma_f32_32x32x16_bf16); the exact 3-way split spends 6 bf16 products per fp32 product
+SPLIT_PIPE_PEAK_TFLOPS = BF16_MFMA_PEAK_TFLOPS / 6.0   # fp32-equivalent ceiling of a launch that runs on the bf16 pipe with the split
+METRIC = 'images/sec G+D fwd-bwd, 256x256 bg x9 elems'
 
 
 def make_batch(b, bg, device, seed):
@@ -128,7 +131,11 @@ def main():
         run(args, int(os.environ['RANK']), int(os.environ.get('LOCAL_RANK', '0')), env_world)
     elif args.gpus > 1:                                      # plain `python bench.py --gpus N`: spawn the ranks (train.py:27-47 does the same)
         import torch.multiprocessing as mp
-        assert torch.cuda.is_available() and (torch.cuda.device_count() >= args.gpus or os.environ.get('LDETR_BENCH_SHARE_GPU')), f'--gpus {args.gpus} but {torch.cuda.device_count()} visible'
+        if not torch.cuda.is_available() or not (torch.cuda.device_count() >= args.gpus or os.environ.get('LDETR_BENCH_SHARE_GPU')):
+            # one parsable line instead of a traceback: the driver's scaling sweep asks for N = 1, 2, 4, 8 on whatever node it got
+            print(json.dumps(dict(metric=METRIC, value=None, unit='images/s', n_gpus=args.gpus, steps=args.steps, warmup=args.warmup,
+                                  error=f'--gpus {args.gpus} requested but {torch.cuda.device_count() if torch.cuda.is_available() else 0} GPU(s) visible on this node')), flush=True)
+            raise SystemExit(2)
         mp.spawn(_spawned, args=(args, _free_port()), nprocs=args.gpus, join=True)
     else:
         run(args, 0, 0, 1)
@@ -178,7 +185,7 @@ def run(args, rank, local_rank, world):
     pG = tl.Phase('Gmain', G, lr=1e-5, betas=(0.0, 0.99), eps=1e-8, reg_interval=4)     # train.py:204,281; training_loop.py:191-194
     pD = tl.Phase('Dmain', D, lr=1e-5, betas=(0.0, 0.99), eps=1e-8, reg_interval=16)
     ema = tl.EmaTracker(pG, G_ema)
-    dp = tl.DataParallelStep(world_size=world)
+    dp_world = tl.DataParallelStep(world_size=world)
     n_params = (pG.fm.total, pD.fm.total)
     torch.manual_seed(0 * world + rank)   # training_loop.py:101-102 seed rule
     side = torch.cuda.Stream()
@@ -188,9 +195,12 @@ def run(args, rank, local_rank, world):
             dist.barrier()
         torch.cuda.synchronize()
 
-    def measure(b_local, share, want_eager=False):
-        """W warm-up + K timed iterations at `b_local` samples per GPU; -> dict(value, ms_per_step, global_batch[, eager_step])."""
+    def measure(b_local, share, want_eager=False, local_only=False):
+        """W warm-up + K timed iterations at `b_local` samples per GPU; -> dict(value, ms_per_step, global_batch[, eager_step]).
+        local_only (N > 1 diagnostics): the same step WITHOUT the gradient exchange (every rank steps on its own, as at N = 1): what the
+        driver's N = 1 bench line measures, re-measured on this node's GPUs."""
         gb = b_local * world
+        dp = dp_world if not local_only else tl.DataParallelStep(world_size=1)
         loss = StyleGAN2Loss(device, G, D, share_D_trunk=share)
         batch = to_device_batch(make_batch(b_local, bg, device, 1000 + rank), device, args.text_mode, args.text_tokens)
         cur_nimg = [0]
@@ -211,22 +221,46 @@ def run(args, rank, local_rank, world):
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
             graphed = tl.GraphedIteration(loss, [pG, pD], dp, batch, b_local, 4, ema=ema, batch_size=gb, ema_kimg=gb * 10 / 32,
-                                          capture_stream=side, overlap=not args.no_overlap)
+                                          capture_stream=side, overlap=(dp.world > 1 and not args.no_overlap))
             graphed.cur_nimg = cur_nimg[0]
             step = graphed.run
         for _ in range(args.warmup):
             step()
+        dp.exposed.clear()
+        dp.record_exposed = world > 1 and not local_only
         barrier()
         t0 = time.perf_counter()
         for _ in range(args.steps):
             step()
+        torch.cuda.synchronize()
+        mine = time.perf_counter() - t0          # this rank's own clock, before the closing barrier
         barrier()
         elapsed = time.perf_counter() - t0
+        dp.record_exposed = False
+        diag = None
         if world > 1:
             t = torch.tensor([elapsed], device=device, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = t.item()
+            # self-diagnosis of a multi-GPU run: per-rank step time (a straggler shows as spread) and, per phase, how long the compute stream
+            # stood still waiting for the all-reduce (event pair around DataParallelStep's join): the part of the exchange NOT hidden behind backward
+            exp = {}
+            for name, e0, e1 in dp.exposed:
+                exp[name] = exp.get(name, 0.0) + e0.elapsed_time(e1)
+            names = sorted({p.name for p in (pG, pD)})
+            vec = torch.tensor([mine / args.steps * 1e3] + [exp.get(n, 0.0) / args.steps for n in names], device=device, dtype=torch.float64)
+            allv = [torch.zeros_like(vec) for _ in range(world)]
+            dist.all_gather(allv, vec)
+            allv = torch.stack(allv).cpu()
+            diag = dict(rank_ms_per_step=dict(min=round(allv[:, 0].min().item(), 3), max=round(allv[:, 0].max().item(), 3), mean=round(allv[:, 0].mean().item(), 3),
+                                              per_rank=[round(v, 3) for v in allv[:, 0].tolist()]))
+            if not local_only:
+                diag['comm_exposed_ms'] = {n: dict(mean=round(allv[:, 1 + i].mean().item(), 3), max=round(allv[:, 1 + i].max().item(), 3)) for i, n in enumerate(names)}
+                diag['comm_exposed_ms']['per_step_total_max'] = round(allv[:, 1:].sum(1).max().item(), 3)
+                diag['allreduce_mb_per_step'] = round(4e-6 * (pG.fm.total + pD.fm.total), 1)
         out = dict(value=round(gb * args.steps / elapsed, 3), ms_per_step=round(elapsed / args.steps * 1e3, 3), global_batch=gb, per_gpu_batch=b_local)
+        if diag is not None:
+            out['diagnostics'] = diag
         if want_eager:
             out['eager_step'] = eager_step
         return out
@@ -242,7 +276,15 @@ def run(args, rank, local_rank, world):
         if not args.no_extra and not args.global_batch:
             if world > 1:      # the same ranks at 16 samples per GPU (weak scaling: global batch 16 x N)
                 w = measure(16, share)
-                extra['weak_scaling'] = dict(value=w['value'], ms_per_step=w['ms_per_step'], global_batch=w['global_batch'], per_gpu_batch=16, unit='images/s')
+                extra['weak_scaling'] = dict(value=w['value'], ms_per_step=w['ms_per_step'], global_batch=w['global_batch'], per_gpu_batch=16, unit='images/s',
+                                             diagnostics=w.get('diagnostics'))
+                # ... and WITHOUT the exchange: every rank runs the N = 1 bench workload on its own GPU.  `value_per_gpu` is what BENCH (N = 1)
+                # reports, re-measured here: it must agree with the driver's N = 1 line (else this node / these GPUs differ), and
+                # weak_scaling.ms_per_step - this ms_per_step is the whole cost of data parallelism (exposed exchange + stragglers).
+                l = measure(16, share, local_only=True)
+                extra['single_gpu_reference'] = dict(value_per_gpu=round(l['value'] / world, 3), ms_per_step=l['ms_per_step'], per_gpu_batch=16, unit='images/s',
+                                                     note='same processes, 16 samples per GPU, no gradient exchange (= the N=1 bench workload on each GPU); compare with BENCH at N=1',
+                                                     rank_ms_per_step=(l.get('diagnostics') or {}).get('rank_ms_per_step'))
             elif share is not False:   # N = 1: the reference's call pattern (one D-trunk evaluation per D pass: 25 % more conv FLOPs per step)
                 r = measure(16, False)
                 extra['value_reference_call_pattern'] = r['value']
@@ -259,6 +301,8 @@ def run(args, rank, local_rank, world):
                     core.lib().ldetr_set_split_bf16(prev)
                 extra['value_f32_mfma_only'] = r['value']
     eager_step = primary.pop('eager_step')
+    if primary.get('diagnostics') is not None:
+        extra['diagnostics'] = primary.pop('diagnostics')
     args.batch, b_local = primary['global_batch'], primary['per_gpu_batch']
     value, ms_per_step = primary['value'], primary['ms_per_step']
 
@@ -306,21 +350,41 @@ def run(args, rank, local_rank, world):
         sec = max(sec_raw - ev_over_ms * 1e-3 * launches, 1e-9)
         if os.environ.get('LDETR_ENGINE_SHAPES'):   # development aid: per-(entry point, flop count) table
             agg = {}
-            for tag, f, s_, e_ in core.PROF.records:
+            for tag, f, s_, e_, _nb, _pp in core.PROF.records:
                 a = agg.setdefault((tag, f), [0, 0.0]); a[0] += 1; a[1] += s_.elapsed_time(e_)
             with open(os.environ['LDETR_ENGINE_SHAPES'], 'w') as fh:
                 for (tag, f), (n, ms) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
                     fh.write(f'{tag:42s} gflop={f / 1e9:9.3f} calls/step={n // 2:4d} ms/step={ms / 2:8.3f} TF={f * n / ms / 1e9 if ms else 0:7.2f}\n')
         ach = fl / sec / 1e12 if sec > 0 else 0.0
         by = {}
-        for tag, f, s_, e_ in core.PROF.records:   # the same records, split by C-ABI entry point
+        t_pipe = [0.0, 0.0]          # engine time on the f32 MFMA pipe / on the bf16 pipe (exact operand split), event overhead removed
+        n_pipe = [0, 0]
+        alg_bytes = 0.0
+        for tag, f, s_, e_, nb, pipes in core.PROF.records:   # the same records, split by C-ABI entry point
             key = 'dense_gemm' if tag == 'gemm' else tag.replace('ldetr_', '').replace('_f32', '')
-            a = by.setdefault(key, [0.0, 0.0, 0]); a[0] += f; a[1] += max(s_.elapsed_time(e_) - ev_over_ms, 0.0); a[2] += 1
+            ms = max(s_.elapsed_time(e_) - ev_over_ms, 0.0)
+            a = by.setdefault(key, [0.0, 0.0, 0, 0.0, 0.0]); a[0] += f; a[1] += ms; a[2] += 1; a[3] += nb
+            alg_bytes += nb
+            tot = max(pipes[0] + pipes[1], 1)
+            t_pipe[0] += ms * pipes[0] / tot; t_pipe[1] += ms * pipes[1] / tot      # (a call that issued launches on both pipes: split by launch count)
+            n_pipe[0] += pipes[0]; n_pipe[1] += pipes[1]
+            a[4] += ms * pipes[1] / tot
         by_entry = {k: dict(gflop_per_step=round(v[0] / 2 / 1e9, 1), ms_per_step=round(v[1] / 2, 2), launches_per_step=v[2] // 2,
-                            tflops=round(v[0] / v[1] / 1e9, 2) if v[1] > 0 else 0.0) for k, v in sorted(by.items())}
+                            tflops=round(v[0] / v[1] / 1e9, 2) if v[1] > 0 else 0.0, algorithmic_gb_per_step=round(v[3] / 2 / 1e9, 2),
+                            frac_time_on_bf16_pipe=round(v[4] / v[1], 3) if v[1] > 0 else 0.0) for k, v in sorted(by.items())}
+        # the ceiling in use: a launch on the bf16 pipe with the exact 3-way split can reach 2500 / 6 = 416.7 fp32-equivalent TFLOP/s, a
+        # launch on the f32 MFMA pipe 157.3 -- time-weighted over the step's engine launches
+        tsum = max(t_pipe[0] + t_pipe[1], 1e-9)
+        peak_eff = (t_pipe[0] * F32_MFMA_PEAK_TFLOPS + t_pipe[1] * SPLIT_PIPE_PEAK_TFLOPS) / tsum
         roofline = dict(bound='mfma', kernel='f32 MFMA contraction engine: ldetr::gemm_f32_kernel<*> (LDS-tiled GEMM / implicit conv) + gemm_skinny_kernel<*> + gemm_small_kernel<*>, every launch',
                         achieved=round(ach, 3), peak=F32_MFMA_PEAK_TFLOPS, unit='TFLOP/s', frac=round(ach / F32_MFMA_PEAK_TFLOPS, 4),
+                        peak_effective=round(peak_eff, 1), frac_effective=round(ach / peak_eff, 4),
+                        peak_effective_note=f'time-weighted over the engine launches of the step: {t_pipe[1] / tsum:.3f} of the engine time runs on the bf16 matrix pipe with the '
+                                            f'exact 3-way operand split (fp32-equivalent ceiling {SPLIT_PIPE_PEAK_TFLOPS:.1f} = 2500 / 6 TFLOP/s; {n_pipe[1] // 2} kernel launches per step), '
+                                            f'{t_pipe[0] / tsum:.3f} on the f32 MFMA pipe ({F32_MFMA_PEAK_TFLOPS}; {n_pipe[0] // 2} launches)',
+                        engine_ms_on_bf16_pipe=round(t_pipe[1] / 2, 3), engine_ms_on_f32_pipe=round(t_pipe[0] / 2, 3),
                         traffic=None, launches_per_step=launches // 2, algorithmic_gflop_per_step=round(fl / 2 / 1e9, 2),
+                        algorithmic_gb_per_step=round(alg_bytes / 2 / 1e9, 2),
                         engine_ms_per_step=round(sec / 2 * 1e3, 3), engine_ms_per_step_uncorrected=round(sec_raw / 2 * 1e3, 3),
                         event_pair_overhead_us=round(ev_over_ms * 1e3, 2), by_entry=by_entry,
                         matrix_pipe='fp32 operands, fp32 accumulators and results throughout; the 128x128 / 128x64 / 256x32 tiles of gemm_f32_kernel multiply on the bf16 pipe '
@@ -329,13 +393,20 @@ def run(args, rank, local_rank, world):
                                     'algorithmic fp32 FLOPs (a split launch can exceed it: 6/16 of the bf16 pipe time per fp32 FLOP); value_f32_mfma_only = same step with the split off')
         # HBM traffic of the engine from the PMC counters (FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 passes over the same step, eager):
         # measured offline with tools/pmc_step.py (rocprofv3 cannot wrap this process from inside) and committed; per launch, like `achieved`
-        pmc_path = os.path.join(ROOT, 'profiles', 'r02_pmc_traffic.json')
+        pmc_path = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
         if os.path.exists(pmc_path) and args.bg == 256 and b_local == 16 and args.text_mode == 'features':
+            from layoutdetr_amd import build as kbuild
             pmc = json.load(open(pmc_path))
-            roofline['traffic'] = round(pmc['engine_bytes_per_launch'])
-            roofline['traffic_unit'] = 'HBM bytes per engine launch (mean over the step)'
-            roofline['traffic_gb_per_step'] = round((pmc['engine_total']['fetch'] + pmc['engine_total']['write']) / 1e9, 2)
-            roofline['traffic_source'] = 'profiles/r02_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, tools/pmc_step.py)'
+            if pmc.get('csrc_digest') != kbuild.source_digest():
+                # counters of another build of the kernels are not this build's traffic: say so instead of quoting them
+                roofline['traffic_note'] = (f"profiles/pmc_traffic.json was measured on kernel sources {str(pmc.get('csrc_digest'))[:12]}, this build is "
+                                            f"{kbuild.source_digest()[:12]}: re-run tools/pmc_step.py (two rocprofv3 --pmc passes) to refresh it")
+            else:
+                roofline['traffic'] = round(pmc['engine_bytes_per_launch'])
+                roofline['traffic_unit'] = 'HBM bytes per engine launch (mean over the step)'
+                roofline['traffic_gb_per_step'] = round((pmc['engine_total']['fetch'] + pmc['engine_total']['write']) / 1e9, 2)
+                roofline['traffic_over_algorithmic'] = round(roofline['traffic_gb_per_step'] / max(roofline['algorithmic_gb_per_step'], 1e-9), 2)
+                roofline['traffic_source'] = f"profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, two passes over tools/pmc_step.py; kernel sources {pmc['csrc_digest'][:12]} = this build)"
         try:    # the fractions north_star names, each as its own entry (HBM-bound kernels, modulated-conv layer at 256x256, DETR cross-attention)
             sys.path.insert(0, os.path.join(ROOT, 'tools'))
             import bench_hbm_kernels
@@ -347,7 +418,7 @@ def run(args, rank, local_rank, world):
         cpu = None
         if G_sd_cpu is not None:
             cpu = cpu_baseline(G_sd_cpu, D_sd_cpu, G_names, D_names, bg)
-        out = dict(metric='images/sec G+D fwd-bwd, 256x256 bg x9 elems', value=round(value, 3), unit='images/s', n_gpus=world, rccl_ranks=(dist.get_world_size() if world > 1 else 1), **({'shared_single_gpu_gloo': True} if share_gpu else {}),
+        out = dict(metric=METRIC, value=round(value, 3), unit='images/s', n_gpus=world, rccl_ranks=(dist.get_world_size() if world > 1 else 1), **({'shared_single_gpu_gloo': True} if share_gpu else {}),
                    steps=args.steps, warmup=args.warmup, ms_per_step=round(ms_per_step, 3), higher_is_better=True,
                    scaling=scaling, vs_baseline=None, dtype='f32', data='synthetic',
                    config=dict(workload=f'BASELINE configs[{2 if world == 1 else 3}]: global batch {args.batch} ({b_local} per GPU), {bg}x{bg} backgrounds x 9 elements, full G+D adversarial '

@@ -29,6 +29,7 @@
  *   ldetr_resample_coeffs, ldetr_resize_normalize_u8
  *                                 PIL resize + normalise of the page background: training/dataset_layoutganpp.py:330-338
  *   ldetr_lsap_f64                scipy.optimize.linear_sum_assignment as used at metrics/metric_layoutnet.py:111,125,240
+ *   ldetr_box_giou_pairwise_f32   box_cxcywh_to_xyxy + box_iou + generalized_box_iou: detr_util/box_ops.py:19-71
  */
 #ifndef LDETR_HIP_H
 #define LDETR_HIP_H
@@ -52,8 +53,14 @@ int ldetr_debug_trace_tiles(int64_t* buffer);
 /* Which tiles of the contraction engine run on the bf16 matrix pipe with the exact three-way operand split (fp32 operands and
  * results, fp32-equivalent accuracy: csrc/gemm_conv.hip, gemm_f32_kernel<..., SPLIT>).  Bit 0: 128x128, bit 1: 128x64, bit 2:
  * 256x32, bit 3: 64x64; 0 = f32 MFMA everywhere; -1 = back to the default / LDETR_SPLIT_BF16.  Process-wide; returns the previous override.
- * Used by the parity tests to run the same contraction on both pipes. */
+ * Used by the parity tests to run the same contraction on both pipes.  Non-finite values: the split of +-Inf is Inf + NaN + NaN, so a
+ * tile whose accumulators come out non-finite is recomputed on the f32 pipe inside the same launch -- both settings return the same
+ * Inf / NaN classes as an fp32 matmul (what training_loop.py:306-309's nan_to_num(0, 1e5, -1e5) then sees is therefore the same). */
 int ldetr_set_split_bf16(int tiles);
+
+/* Measurement aid (bench.py's roofline leg): how many contraction kernels the calling thread has launched so far on the f32 MFMA pipe
+ * and on the bf16 pipe with the exact operand split; the difference across one C-ABI call tells which ceiling that call is priced against. */
+int ldetr_engine_launch_counts(int64_t* f32_pipe, int64_t* bf16_split_pipe);
 
 /* Scratch memory for the contraction engine's in-kernel split-K reduction on the calling thread's current device.
  * `ptr`: zero-filled, 16-byte aligned device memory the caller keeps alive and uses from one stream at a time
@@ -273,6 +280,15 @@ int ldetr_layout_losses_bwd_f32(const float* grads, const float* grad_losses, in
  * cost: [batch][n][n] float64 row-major; maximize != 0 negates the costs first;
  * row_ind / col_ind: [batch][n] int32 outputs with scipy's ordering (row_ind sorted ascending). n <= 64. */
 int ldetr_lsap_f64(const double* cost, int batch, int n, int maximize, int* row_ind, int* col_ind, void* stream);
+
+/* Pairwise box IoU / union / generalised IoU of detr_util/box_ops.py (box_iou :35-48, generalized_box_iou :51-71; with cxcywh != 0
+ * the boxes go through box_cxcywh_to_xyxy :19-23 first), batched: boxes1 [B][N][4], boxes2 [B][M][4] fp32 (16-byte aligned rows)
+ * -> iou / uni / giou [B][N][M] fp32 (any may be NULL) and, if `cost` is not NULL, cost[b][i][j] = cost_sign * giou as float64: the
+ * matrix ldetr_lsap_f64 takes (the DETR matcher's cost_giou = -generalized_box_iou).  fp32 arithmetic in the reference's operation
+ * order without fma contraction: bit-identical to the reference's CPU values.  Degenerate pairs (union or enclosing area 0) give
+ * the reference's Inf / NaN; the reference's `assert x1 >= x0` is the caller's (layoutdetr_amd/detr_util/box_ops.py). */
+int ldetr_box_giou_pairwise_f32(const float* boxes1, const float* boxes2, int B, int N, int M, int cxcywh, float* iou, float* uni,
+                                float* giou, double* cost, double cost_sign, void* stream);
 
 #ifdef __cplusplus
 }

@@ -9,7 +9,8 @@ import os
 from ctypes import (POINTER, Structure, c_char_p, c_double, c_float, c_int, c_int64, c_ubyte, c_uint64, c_void_p)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'lib', 'libldetr_hip.so')
+# LDETR_LIB: development aid (tools/build_variant.sh) -- an alternative build of the same library, e.g. to A/B a kernel change on one box
+LIB_PATH = os.environ.get('LDETR_LIB') or os.path.join(_HERE, 'lib', 'libldetr_hip.so')
 
 
 class Tensor4(Structure):
@@ -68,12 +69,14 @@ SIGNATURES = {
     'ldetr_adam_step_f32': [_P, _P, _P, _P, _L, _L, _F, _F, _F, _F, _I, _F, _F, _F, _F, _P],
     'ldetr_ema_lerp_f32': [_P, _P, _L, _F, _P],
     'ldetr_lsap_f64': [_P, _I, _I, _I, _P, _P, _P],
+    'ldetr_box_giou_pairwise_f32': [_P, _P, _I, _I, _I, _I, _P, _P, _P, _P, c_double, _P],
     'ldetr_softmax_xent_fwd_f32': [_P, _L, _P, _P, _P, _P, _L, _I, _L, _F, _P],
     'ldetr_softmax_xent_bwd_f32': [_P, _L, _P, _P, _P, _P, _P, _L, _L, _I, _L, _F, _P],
     'ldetr_embedding_fwd_f32': [_P, _P, _P, _P, _L, _I, _I, _I, _P],
     'ldetr_embedding_bwd_f32': [_P, _P, _P, _L, _I, _I, _L, _P],
     'ldetr_debug_trace_tiles': [_P],
     'ldetr_set_split_bf16': [c_int],
+    'ldetr_engine_launch_counts': [POINTER(c_int64), POINTER(c_int64)],
     'ldetr_gemm_pair_f32': [_P, _P, _P],
     'ldetr_gemm_pair_is_single_launch': [_P, _P],
     'ldetr_demod_fwd_f32': [_P, _L, _L, _L, _L, _P, _P, _P, _I, _I, _I, _I, _I, _F, _P],
@@ -108,7 +111,7 @@ def load():
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported
         fn.restype = c_int
         fn.argtypes = argtypes
-    if lib.ldetr_abi_version() != 16:
+    if lib.ldetr_abi_version() != 17:
         raise RuntimeError('libldetr_hip.so ABI version mismatch; rebuild it')
     _lib = lib
     return lib

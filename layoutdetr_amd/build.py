@@ -20,7 +20,7 @@ LIBNAME = 'libldetr_hip.so'
 ARCH = 'gfx950'
 
 SOURCES = ['ldetr_core.cpp', 'bias_act.hip', 'upfirdn2d.hip', 'gemm_conv.hip', 'attention.hip', 'layernorm.hip',
-           'misc_ops.hip', 'optim.hip', 'lsap.hip', 'xent.hip', 'resample.hip', 'layout_loss.hip', 'demod.hip', 'wgrad_smallc.hip', 'stem_conv.hip']
+           'misc_ops.hip', 'optim.hip', 'lsap.hip', 'xent.hip', 'resample.hip', 'layout_loss.hip', 'demod.hip', 'wgrad_smallc.hip', 'stem_conv.hip', 'box_ops.hip']
 HEADERS = ['ldetr_common.hpp', os.path.join('..', '..', 'include', 'ldetr_hip.h')]
 
 # the per-block tracer of the tiled kernel (tools/trace_tiles.py) is a development build: LDETR_TILE_TRACE=1 python -m layoutdetr_amd.build --force
@@ -62,6 +62,12 @@ def _kernel_resources(remarks):
             k, v = body.rsplit(':', 1)
             out[cur][k.strip()] = v.strip()
     return out
+
+
+def source_digest():
+    """sha256 over the kernel sources and headers: identifies the build a measurement (profiles/pmc_traffic.json) belongs to."""
+    return _digest(sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(('.hip', '.cpp', '.hpp')) and not f.startswith('.'))
+                   + [os.path.normpath(os.path.join(CSRC, HEADERS[1]))])
 
 
 def lib_path():

@@ -1,0 +1,321 @@
+// Position-wise feed-forward block of the DETR layers as ONE launch per direction.
+// Reference: training/detr_transformer.py:212-214 / 283-285 -- src2 = linear2(dropout(relu(linear1(src)))) with d_model 256 and
+// dim_feedforward 2048 (networks_detr.py:101-103, 243, 269, 275), followed by src = norm(src + dropout(src2)).
+//
+// On the decoder-side stacks the block sees 144..320 tokens: linear1 and linear2 are two latency-bound launches (14 us each for
+// 0.15 GFLOP) and their backward is two paired launches plus an activation-gradient pass.  Here a block owns a 32-token row tile and a
+// 64-wide slice of the hidden layer:
+//   forward   H = dropout(relu(X W1_s^T + b1_s)) (kept in LDS, written once for the backward), then the slice's contribution
+//             Y_s = H W2_s^T to all 256 outputs -> ypart[s][M][256].  The 32 partial sums (+ b2) are added where they are consumed: in
+//             the residual + LayerNorm launch (ldetr_layernorm_fwd_parts_f32), in slice order, so the forward stays deterministic.
+//   backward  dH = (dY W2_s) * [H > 0] / keep, then dX += dH W1_s (fp32 atomics onto the buffer that already holds the residual-path
+//             gradient written by the LayerNorm backward), dW2[:, s] += dY^T H, dW1[s, :] += dH^T X, db1[s] += colsum dH,
+//             db2 += colsum dY (slice 0 only) -- fp32 atomics straight into the flat .grad buffers.
+// Operands stream global -> registers in MFMA operand order (v_mfma_f32_32x32x2_f32, exact fp32) like gemm_small_kernel; the only
+// LDS traffic is the hidden tile.  D must be 256 (8 column tiles = 2 per wave), the hidden width a multiple of 64.
+#include "ldetr_common.hpp"
+#include "../../include/ldetr_hip.h"
+
+namespace ldetr {
+
+struct FfnParams {
+    const float* x; long ldx;                 // [M, 256]
+    const float* w1; const float* b1;         // [F, 256], [F]
+    const float* w2;                          // [256, F]
+    float* h;                                 // [M, F] hidden after relu (+ dropout): saved for / read by the backward
+    float* ypart;                             // [F / 64][M][256]
+    int M, F;
+    float p_drop; unsigned long long seed; const unsigned long long* seed_ptr;
+    const float* dy;                          // [M, 256] gradient of the block's output
+    float* dx; long lddx;                     // [M, 256] accumulated (atomics)
+    float* dw1; float* db1; float* dw2; float* db2;
+};
+
+constexpr int FD = 256, FHS = 64, FHP = 68;   // model width, hidden slice, LDS pitch of the hidden tile
+
+typedef __attribute__((__vector_size__(16 * sizeof(float)))) float ffn_acc_t;
+
+__device__ __forceinline__ void ld_k16(const __amdgpu_buffer_rsrc_t& rs, int voff, int soff, float (&f)[16]) {   // 16 consecutive k of one row
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const auto v = __builtin_amdgcn_raw_buffer_load_b128(rs, voff + 16 * j, soff, 0);
+        f[4 * j] = __int_as_float(v[0]); f[4 * j + 1] = __int_as_float(v[1]); f[4 * j + 2] = __int_as_float(v[2]); f[4 * j + 3] = __int_as_float(v[3]);
+    }
+}
+__device__ __forceinline__ void ld_r16(const __amdgpu_buffer_rsrc_t& rs, int voff, int soff, int ld4, float (&f)[16]) {   // 16 consecutive k of one column (pitch ld4 bytes)
+#pragma unroll
+    for (int t = 0; t < 16; t++) f[t] = __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, voff, soff + t * ld4, 0));
+}
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t rsrc(const float* p) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p), 0, 0x7fffffff, 0x00020000);
+}
+#define FFN_MFMA16(A, B, ACC) _Pragma("unroll") for (int t_ = 0; t_ < 16; t_++) ACC = __builtin_amdgcn_mfma_f32_32x32x2f32(A[t_], B[t_], ACC, 0, 0, 0)
+
+__global__ __launch_bounds__(256) void ffn_fwd_kernel(FfnParams p) {
+    __shared__ float red[2][32][33];
+    __shared__ float Hs[32][FHP];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, cl = lane & 31, kl = lane >> 5;
+    const int m0 = blockIdx.x * 32, s = blockIdx.y, j0 = s * FHS;
+    const int OOB = (int)0x80000000;
+    // ---- phase 1: wave (ct, kh) = 32 hidden units x half of the 256-long reduction
+    const int ct = wave & 1, kh = wave >> 1;
+    {
+        const __amdgpu_buffer_rsrc_t rsX = rsrc(p.x), rsW = rsrc(p.w1);
+        const int vA = (m0 + cl < p.M) ? (int)(((long)(m0 + cl) * p.ldx + kh * 128 + 16 * kl) * 4) : OOB;
+        const int vB = ((j0 + ct * 32 + cl) * FD + kh * 128 + 16 * kl) * 4;
+        ffn_acc_t acc;
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[r] = 0.f;
+        float a0[16], b0[16], a1[16], b1[16];
+        ld_k16(rsX, vA, 0, a0); ld_k16(rsW, vB, 0, b0);
+        ld_k16(rsX, vA, 128, a1); ld_k16(rsW, vB, 128, b1);
+        FFN_MFMA16(a0, b0, acc);
+        ld_k16(rsX, vA, 256, a0); ld_k16(rsW, vB, 256, b0);
+        FFN_MFMA16(a1, b1, acc);
+        ld_k16(rsX, vA, 384, a1); ld_k16(rsW, vB, 384, b1);
+        FFN_MFMA16(a0, b0, acc);
+        FFN_MFMA16(a1, b1, acc);
+        if (kh == 1) {
+#pragma unroll
+            for (int r = 0; r < 16; r++) red[ct][(r & 3) + 8 * (r >> 2) + 4 * kl][cl] = acc[r];
+        }
+        __syncthreads();
+        if (kh == 0) {
+            const float bias = p.b1[j0 + ct * 32 + cl];
+            const float inv_keep = p.p_drop > 0.f ? 1.f / (1.f - p.p_drop) : 1.f;
+            const unsigned long long seed = p.seed + (p.seed_ptr ? *p.seed_ptr : 0ull);
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * kl;
+                float v = acc[r] + red[ct][row][cl] + bias;
+                v = v > 0.f ? v : 0.f;
+                const long m = m0 + row;
+                if (p.p_drop > 0.f) v *= drop_scale(seed, (uint64_t)(m * p.F + j0 + ct * 32 + cl), p.p_drop, inv_keep);
+                Hs[row][ct * 32 + cl] = v;
+                if (m < p.M) p.h[m * p.F + j0 + ct * 32 + cl] = v;
+            }
+        }
+        __syncthreads();
+    }
+    // ---- phase 2: wave w -> output column tiles 2w, 2w+1 of Y_s = H (32 x 64) W2[:, slice]^T
+    {
+        const __amdgpu_buffer_rsrc_t rsW = rsrc(p.w2);
+        ffn_acc_t acc[2];
+#pragma unroll
+        for (int q = 0; q < 2; q++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[q][r] = 0.f;
+        float b[2][2][16];
+#pragma unroll
+        for (int q = 0; q < 2; q++)
+#pragma unroll
+            for (int c = 0; c < 2; c++) ld_k16(rsW, (((wave * 2 + q) * 32 + cl) * p.F + j0 + 16 * kl) * 4, c * 128, b[q][c]);
+#pragma unroll
+        for (int c = 0; c < 2; c++) {
+            float a[16];
+#pragma unroll
+            for (int t = 0; t < 16; t++) a[t] = Hs[cl][c * 32 + 16 * kl + t];
+            FFN_MFMA16(a, b[0][c], acc[0]);
+            FFN_MFMA16(a, b[1][c], acc[1]);
+        }
+        float* dst = p.ypart + ((long)s * p.M) * FD;
+#pragma unroll
+        for (int q = 0; q < 2; q++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const long m = m0 + (r & 3) + 8 * (r >> 2) + 4 * kl;
+                if (m < p.M) dst[m * FD + (wave * 2 + q) * 32 + cl] = acc[q][r];
+            }
+    }
+}
+
+template <bool WGRAD>
+__global__ __launch_bounds__(256) void ffn_bwd_kernel(FfnParams p) {
+    __shared__ float red[2][32][33];
+    __shared__ float dHs[32][FHP];
+    __shared__ float Hs[32][FHP];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, cl = lane & 31, kl = lane >> 5;
+    const int m0 = blockIdx.x * 32, s = blockIdx.y, j0 = s * FHS;
+    const int OOB = (int)0x80000000;
+    const __amdgpu_buffer_rsrc_t rsDY = rsrc(p.dy), rsW1 = rsrc(p.w1), rsW2 = rsrc(p.w2), rsX = rsrc(p.x);
+    const float inv_keep = p.p_drop > 0.f ? 1.f / (1.f - p.p_drop) : 1.f;
+    // ---- phase 1: dH (32 tokens x 64 hidden) = dY (32 x 256) W2[:, slice]; wave (ct, kh) as in the forward
+    {
+        const int ct = wave & 1, kh = wave >> 1;
+        const int vA = (m0 + cl < p.M) ? ((m0 + cl) * FD + kh * 128 + 16 * kl) * 4 : OOB;
+        const int vB = (j0 + ct * 32 + cl + (kh * 128 + 16 * kl) * p.F) * 4;       // element (k = n, row = j): w2[n * F + j]
+        const int ld4 = p.F * 4;
+        ffn_acc_t acc;
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[r] = 0.f;
+        float a0[16], b0[16], a1[16], b1[16];
+        ld_k16(rsDY, vA, 0, a0); ld_r16(rsW2, vB, 0, ld4, b0);
+        ld_k16(rsDY, vA, 128, a1); ld_r16(rsW2, vB, 32 * ld4, ld4, b1);
+        FFN_MFMA16(a0, b0, acc);
+        ld_k16(rsDY, vA, 256, a0); ld_r16(rsW2, vB, 64 * ld4, ld4, b0);
+        FFN_MFMA16(a1, b1, acc);
+        ld_k16(rsDY, vA, 384, a1); ld_r16(rsW2, vB, 96 * ld4, ld4, b1);
+        FFN_MFMA16(a0, b0, acc);
+        FFN_MFMA16(a1, b1, acc);
+        if (kh == 1) {
+#pragma unroll
+            for (int r = 0; r < 16; r++) red[ct][(r & 3) + 8 * (r >> 2) + 4 * kl][cl] = acc[r];
+        }
+        __syncthreads();
+        if (kh == 0) {
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * kl;
+                const long m = m0 + row;
+                const float hv = m < p.M ? p.h[m * p.F + j0 + ct * 32 + cl] : 0.f;
+                // relu'(pre) and the dropout mask in one test: the saved hidden value is positive exactly where both let the gradient through
+                dHs[row][ct * 32 + cl] = hv > 0.f ? (acc[r] + red[ct][row][cl]) * inv_keep : 0.f;
+                if (WGRAD) Hs[row][ct * 32 + cl] = hv;
+            }
+        }
+        __syncthreads();
+    }
+    // ---- phase 2: dX (32 x 256) += dH (32 x 64) W1[slice, :]; wave w -> input-feature tiles 2w, 2w+1
+    {
+        ffn_acc_t acc[2];
+#pragma unroll
+        for (int q = 0; q < 2; q++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[q][r] = 0.f;
+        const int ld4 = FD * 4;
+        float b[2][2][16];
+#pragma unroll
+        for (int q = 0; q < 2; q++)
+#pragma unroll
+            for (int c = 0; c < 2; c++)      // element (k = j, row = c): w1[(j0 + j) * 256 + c]
+                ld_r16(rsW1, ((wave * 2 + q) * 32 + cl + (j0 + c * 32 + 16 * kl) * FD) * 4, 0, ld4, b[q][c]);
+#pragma unroll
+        for (int c = 0; c < 2; c++) {
+            float a[16];
+#pragma unroll
+            for (int t = 0; t < 16; t++) a[t] = dHs[cl][c * 32 + 16 * kl + t];
+            FFN_MFMA16(a, b[0][c], acc[0]);
+            FFN_MFMA16(a, b[1][c], acc[1]);
+        }
+#pragma unroll
+        for (int q = 0; q < 2; q++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const long m = m0 + (r & 3) + 8 * (r >> 2) + 4 * kl;
+                if (m < p.M) atomicAdd(p.dx + m * p.lddx + (wave * 2 + q) * 32 + cl, acc[q][r]);
+            }
+    }
+    if constexpr (WGRAD) {
+        // ---- phase 3: dW2[n][slice] (256 x 64) += dY^T (256 x 32 tokens) H (32 x 64); wave w -> n tiles 2w, 2w+1, both j tiles
+        {
+            float bj[2][16];
+#pragma unroll
+            for (int jt = 0; jt < 2; jt++)
+#pragma unroll
+                for (int t = 0; t < 16; t++) bj[jt][t] = Hs[16 * kl + t][jt * 32 + cl];
+#pragma unroll
+            for (int q = 0; q < 2; q++) {
+                const int nt = wave * 2 + q;
+                float a[16];      // element (m' = n, k' = token): dy[(m0 + token) * 256 + n]
+#pragma unroll
+                for (int t = 0; t < 16; t++) {
+                    const int m = m0 + 16 * kl + t;
+                    a[t] = __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsDY, m < p.M ? (m * FD + nt * 32 + cl) * 4 : OOB, 0, 0));
+                }
+#pragma unroll
+                for (int jt = 0; jt < 2; jt++) {
+                    ffn_acc_t acc;
+#pragma unroll
+                    for (int r = 0; r < 16; r++) acc[r] = 0.f;
+                    FFN_MFMA16(a, bj[jt], acc);
+#pragma unroll
+                    for (int r = 0; r < 16; r++)
+                        atomicAdd(p.dw2 + (long)(nt * 32 + (r & 3) + 8 * (r >> 2) + 4 * kl) * p.F + j0 + jt * 32 + cl, acc[r]);
+                }
+            }
+        }
+        // ---- phase 4: dW1[slice][c] (64 x 256) += dH^T (64 x 32 tokens) X (32 x 256); wave w -> c tiles 2w, 2w+1, both j tiles
+        {
+            float aj[2][16];
+#pragma unroll
+            for (int jt = 0; jt < 2; jt++)
+#pragma unroll
+                for (int t = 0; t < 16; t++) aj[jt][t] = dHs[16 * kl + t][jt * 32 + cl];
+#pragma unroll
+            for (int q = 0; q < 2; q++) {
+                const int ctile = wave * 2 + q;
+                float b[16];      // element (n' = c, k' = token): x[(m0 + token) * ldx + c]
+#pragma unroll
+                for (int t = 0; t < 16; t++) {
+                    const int m = m0 + 16 * kl + t;
+                    b[t] = __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsX, m < p.M ? (int)(((long)m * p.ldx + ctile * 32 + cl) * 4) : OOB, 0, 0));
+                }
+#pragma unroll
+                for (int jt = 0; jt < 2; jt++) {
+                    ffn_acc_t acc;
+#pragma unroll
+                    for (int r = 0; r < 16; r++) acc[r] = 0.f;
+                    FFN_MFMA16(aj[jt], b, acc);
+#pragma unroll
+                    for (int r = 0; r < 16; r++)
+                        atomicAdd(p.dw1 + (long)(j0 + jt * 32 + (r & 3) + 8 * (r >> 2) + 4 * kl) * FD + ctile * 32 + cl, acc[r]);
+                }
+            }
+        }
+        // ---- phase 5: bias gradients
+        if (tid < FHS && p.db1) {
+            float sum = 0.f;
+#pragma unroll 8
+            for (int r = 0; r < 32; r++) sum += dHs[r][tid];
+            atomicAdd(p.db1 + j0 + tid, sum);
+        }
+        if (s == 0 && p.db2) {
+            float sum = 0.f;
+            for (int r = 0; r < 32 && m0 + r < p.M; r++) sum += p.dy[(long)(m0 + r) * FD + tid];
+            atomicAdd(p.db2 + tid, sum);
+        }
+    }
+}
+
+}  // namespace ldetr
+
+using namespace ldetr;
+
+static int ffn_check(const char* what, int64_t M, int D, int F, const void* x, int64_t ldx) {
+    LDETR_CHECK(D == FD, "%s: the fused feed-forward block is built for d_model = 256 (got %d)", what, D);
+    LDETR_CHECK(F >= FHS && F % FHS == 0, "%s: hidden width must be a multiple of 64 (got %d)", what, F);
+    LDETR_CHECK(M >= 0 && M <= (1 << 20), "%s: bad row count", what);
+    LDETR_CHECK(x && ldx >= D && ldx % 4 == 0 && (((uintptr_t)x) & 15) == 0, "%s: x must be 16-byte aligned rows with a pitch that is a multiple of 4", what);
+    LDETR_CHECK((long)M * ldx * 4 < 0x7fffffffL && (long)M * F * 4 < 0x7fffffffL && (long)(F / FHS) * M * D * 4 < 0x7fffffffL, "%s: operand above 2 GiB", what);
+    return LDETR_OK;
+}
+
+extern "C" int ldetr_ffn_fwd_f32(const float* x, int64_t ldx, const float* w1, const float* b1, const float* w2, float* h, float* ypart,
+                                 int64_t M, int D, int F, float p_drop, uint64_t seed, const uint64_t* seed_ptr, void* stream) {
+    if (int rc = ffn_check("ffn_fwd", M, D, F, x, ldx)) return rc;
+    LDETR_CHECK(w1 && b1 && w2 && h && ypart, "ffn_fwd: null pointer");
+    LDETR_CHECK(p_drop >= 0.f && p_drop < 1.f, "ffn_fwd: p_drop out of range");
+    if (M == 0) return LDETR_OK;
+    FfnParams p; memset(&p, 0, sizeof(p));
+    p.x = x; p.ldx = ldx; p.w1 = w1; p.b1 = b1; p.w2 = w2; p.h = h; p.ypart = ypart; p.M = (int)M; p.F = F;
+    p.p_drop = p_drop; p.seed = seed; p.seed_ptr = (const unsigned long long*)seed_ptr;
+    hipLaunchKernelGGL(ffn_fwd_kernel, dim3(cdiv(M, 32), F / FHS), dim3(256), 0, (hipStream_t)stream, p);
+    return check_launch("ffn_fwd");
+}
+
+extern "C" int ldetr_ffn_bwd_f32(const float* dy, const float* x, int64_t ldx, const float* h, const float* w1, const float* w2,
+                                 float* dx, int64_t lddx, float* dw1, float* db1, float* dw2, float* db2,
+                                 int64_t M, int D, int F, float p_drop, void* stream) {
+    if (int rc = ffn_check("ffn_bwd", M, D, F, x, ldx)) return rc;
+    LDETR_CHECK(dy && h && w1 && w2 && dx && lddx >= D, "ffn_bwd: null pointer");
+    LDETR_CHECK((dw1 == nullptr) == (dw2 == nullptr), "ffn_bwd: dw1 and dw2 go together");
+    LDETR_CHECK((((uintptr_t)dy) & 15) == 0, "ffn_bwd: dy must be 16-byte aligned");
+    if (M == 0) return LDETR_OK;
+    FfnParams p; memset(&p, 0, sizeof(p));
+    p.x = x; p.ldx = ldx; p.w1 = w1; p.w2 = w2; p.h = const_cast<float*>(h); p.M = (int)M; p.F = F; p.p_drop = p_drop;
+    p.dy = dy; p.dx = dx; p.lddx = lddx; p.dw1 = dw1; p.db1 = db1; p.dw2 = dw2; p.db2 = db2;
+    const dim3 grid(cdiv(M, 32), F / FHS);
+    if (dw1) hipLaunchKernelGGL(ffn_bwd_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL(ffn_bwd_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, p);
+    return check_launch("ffn_bwd");
+}

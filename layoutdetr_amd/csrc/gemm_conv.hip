@@ -15,12 +15,15 @@
 // double-buffered with register staging (global loads for tile t+1 are in flight during the
 // MFMAs of tile t; one barrier per k-tile).
 #include <cstdlib>
+#include <type_traits>
+#include <atomic>
 #include "ldetr_common.hpp"
 #include "../../include/ldetr_hip.h"
 
 namespace ldetr {
 int try_launch_stem_conv(const float* x, const ldetr_tensor4* xt, const float* w, int Cout, int KH, int KW, int stride, int pad,
                          float* y, long ldy, int OH, int OW, const float* in_scale, const ldetr_epilogue* ep, hipStream_t st);
+static thread_local int64_t t_launches_f32 = 0, t_launches_split = 0;   // ldetr_engine_launch_counts: contraction kernels issued by this thread, by matrix pipe
 int try_launch_wgrad_smallc(const float* x, const ldetr_tensor4* xt, const float* dy, const ldetr_tensor4* dyt, float* dw, int KH, int KW, int stride, int pad,
                             const float* x_scale, int64_t x_scale_ld, const float* dy_scale, int64_t dy_scale_ld, hipStream_t st);
 
@@ -371,8 +374,9 @@ __device__ __forceinline__ float apply_epilogue(const GemmEpilogue& ep, float v,
 // accumulators.  bf16 x bf16 products are exact in fp32, the dropped terms are <= 2^-26 relative: the result is at least as close
 // to the exact contraction as the f32 MFMA path (tools/proto_bf16x6: rms error 1.6e-7 vs 2.0e-7 against fp64 at K = 4096), while
 // the matrix pipe spends 6 x 8 passes (v_mfma_f32_32x32x16_bf16) where the f32 path spends 8 x 16 (v_mfma_f32_32x32x2_f32).
-// Same 32x32 accumulator layout, so loaders, split-K fix-up and epilogues are shared with the f32 path.  Not equivalent for
-// non-finite inputs (Inf splits into Inf + NaN) and for |x| within one bf16 ulp of FLT_MAX.
+// Same 32x32 accumulator layout, so loaders, split-K fix-up and epilogues are shared with the f32 path.  Non-finite inputs
+// (Inf splits into Inf + NaN; so does |x| within one bf16 ulp of FLT_MAX) are handled after the loop: a tile with a non-finite
+// accumulator is recomputed on the f32 pipe inside the same launch, so such launches return what the f32 instantiation returns.
 __device__ __forceinline__ unsigned pk_bf16(float a, float b) {
     typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
     bf16x2_t r = {(__bf16)a, (__bf16)b};
@@ -446,44 +450,51 @@ __global__ __launch_bounds__(NWV * 64) void gemm_f32_kernel(GemmParams p) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WGN, wn = wave % WGN;
 
+    // unit i of thread t -> (first row, first k) of the float4 it stages (shared by the assignment below and the split path's f32 redo)
+    auto unitA = [](int t, int i, int& r, int& k) {
+        if constexpr (A_KC) { const int u = t + i * NT; r = u / QK; k = (u - r * QK) << 2; }
+        else {
+            // SPLIT: adjacent lanes take the two k-groups that share a 16-byte LDS slot (its low / high 8 bytes), so the 32 lanes of a
+            // store pass fill 256 contiguous bytes; lanes 2q and 2q+1 then load from two rows of the operand (two coalesced runs)
+            const int slot = t + (i / GA) * NT;
+            const int kg = SPLIT ? 2 * ((slot >> 1) / (BM / 4)) + (slot & 1) : slot / (BM / 4);
+            const int rq = SPLIT ? (slot >> 1) % (BM / 4) : slot - kg * (BM / 4);
+            k = kg * GA + (i % GA); r = rq << 2;
+        }
+    };
+    auto unitB = [](int t, int i, int& r, int& k) {
+        if constexpr (B_KC) { const int u = t + i * NT; r = u / QK; k = (u - r * QK) << 2; }
+        else {
+            const int slot = t + (i / GB) * NT;
+            const int kg = SPLIT ? 2 * ((slot >> 1) / (BN / 4)) + (slot & 1) : slot / (BN / 4);
+            const int rq = SPLIT ? (slot >> 1) % (BN / 4) : slot - kg * (BN / 4);
+            k = kg * GB + (i % GB); r = rq << 2;
+        }
+    };
     // Per-thread unit assignment + incremental k decode state.
     int a_r[NUA], a_k[NUA], b_r[NUB], b_k[NUB];
     RowCtx a_rc[NUA], b_rc[NUB];
     KDec a_d[NUA], b_d[NUB];
 #pragma unroll
     for (int i = 0; i < NUA; i++) {
-        int u = tid + i * NT;
         a_d[i].c = a_d[i].ty = a_d[i].tx = a_d[i].n = a_d[i].y = a_d[i].x = 0;
+        unitA(tid, i, a_r[i], a_k[i]);
         if constexpr (A_KC) {
-            a_r[i] = u / QK; a_k[i] = (u - a_r[i] * QK) << 2; a_rc[i] = make_row<AMODE>(p.A, p, z, m0 + a_r[i], z.M);
+            a_rc[i] = make_row<AMODE>(p.A, p, z, m0 + a_r[i], z.M);
             if constexpr (AMODE != OP_KC_DENSE) kdec_init_tap(a_d[i], z.tm, z.kbeg + a_k[i], p.A.C);
         } else {
-            {
-                // SPLIT: adjacent lanes take the two k-groups that share a 16-byte LDS slot (its low / high 8 bytes), so the 32 lanes of a
-                // store pass fill 256 contiguous bytes; lanes 2q and 2q+1 then load from two rows of the operand (two coalesced runs)
-                const int slot = tid + (i / GA) * NT;
-                const int kg = SPLIT ? 2 * ((slot >> 1) / (BM / 4)) + (slot & 1) : slot / (BM / 4);
-                const int rq = SPLIT ? (slot >> 1) % (BM / 4) : slot - kg * (BM / 4);
-                a_k[i] = kg * GA + (i % GA); a_r[i] = rq << 2;
-            }
             if constexpr (AMODE == OP_RC_WT) kdec_init_tap(a_d[i], z.tm, z.kbeg + a_k[i], p.A.C);
             if constexpr (AMODE == OP_RC_PIX || AMODE == OP_RC_CONVK) kdec_init_pix(a_d[i], z.kbeg + a_k[i], p.A.DH, p.A.DW);
         }
     }
 #pragma unroll
     for (int i = 0; i < NUB; i++) {
-        int u = tid + i * NT;
         b_d[i].c = b_d[i].ty = b_d[i].tx = b_d[i].n = b_d[i].y = b_d[i].x = 0;
+        unitB(tid, i, b_r[i], b_k[i]);
         if constexpr (B_KC) {
-            b_r[i] = u / QK; b_k[i] = (u - b_r[i] * QK) << 2; b_rc[i] = make_row<BMODE>(p.B, p, z, n0 + b_r[i], p.N);
+            b_rc[i] = make_row<BMODE>(p.B, p, z, n0 + b_r[i], p.N);
             if constexpr (BMODE != OP_KC_DENSE) kdec_init_tap(b_d[i], z.tm, z.kbeg + b_k[i], p.B.C);
         } else {
-            {
-                const int slot = tid + (i / GB) * NT;
-                const int kg = SPLIT ? 2 * ((slot >> 1) / (BN / 4)) + (slot & 1) : slot / (BN / 4);
-                const int rq = SPLIT ? (slot >> 1) % (BN / 4) : slot - kg * (BN / 4);
-                b_k[i] = kg * GB + (i % GB); b_r[i] = rq << 2;
-            }
             if constexpr (BMODE == OP_RC_WT) kdec_init_tap(b_d[i], z.tm, z.kbeg + b_k[i], p.B.C);
             if constexpr (BMODE == OP_RC_PIX || BMODE == OP_RC_CONVK) kdec_init_pix(b_d[i], z.kbeg + b_k[i], p.B.DH, p.B.DW);
         }
@@ -594,11 +605,14 @@ __global__ __launch_bounds__(NWV * 64) void gemm_f32_kernel(GemmParams p) {
             a_voff[i] = (m0 + a_r[i] < z.M) ? (int)(((long)uy * apix_st * p.A.sh + (long)ux * apix_st * p.A.sw + m0 + a_r[i]) * 4) : (int)0x80000000;
         }
     }
-    if constexpr (PIX_STATE) {
-        const int per = pixDH * pixDW;
-        g_n = z.kbeg / per; const int rem = z.kbeg - g_n * per;
-        g_y0 = rem / pixDW; g_x0 = rem - g_y0 * pixDW;
-    }
+    auto reset_pix = [&]() {
+        if constexpr (PIX_STATE) {
+            const int per = pixDH * pixDW;
+            g_n = z.kbeg / per; const int rem = z.kbeg - g_n * per;
+            g_y0 = rem / pixDW; g_x0 = rem - g_y0 * pixDW;
+        }
+    };
+    reset_pix();
     if constexpr (FAST && BMODE == OP_RC_PIX) {
         const long padoff = (long)pix_pad * p.B.sh + (long)pix_pad * p.B.sw;
         rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.B.p) - padoff, 0, 0x7fffffff, 0x00020000);
@@ -630,12 +644,16 @@ __global__ __launch_bounds__(NWV * 64) void gemm_f32_kernel(GemmParams p) {
             for (int i = 0; i < NUB; i++) b_voff[i] = (n0 + b_r[i] < p.N) ? (int)(((long)b_k[i] * p.B.ld + n0 + b_r[i]) * 4) : (int)0x80000000;
         }
     }
-    if constexpr (TAP_STATE) {
-        if (k_tiles_in_taps) {
-            f_tap = z.kbeg / f_C; f_c0 = z.kbeg - f_tap * f_C;
-            f_ty = f_tap / z.tm.ntx; f_tx = f_tap - f_ty * z.tm.ntx;
+    auto reset_kstate = [&]() {   // block-uniform position of the first k-tile (the loaders advance it tile by tile)
+        reset_pix();
+        if constexpr (TAP_STATE) {
+            if (k_tiles_in_taps) {
+                f_tap = z.kbeg / f_C; f_c0 = z.kbeg - f_tap * f_C;
+                f_ty = f_tap / z.tm.ntx; f_tx = f_tap - f_ty * z.tm.ntx;
+            }
         }
-    }
+    };
+    reset_kstate();
     auto as_float4 = [](auto v) { return make_float4(__int_as_float(v[0]), __int_as_float(v[1]), __int_as_float(v[2]), __int_as_float(v[3])); };
 
     f32x16 acc[TM][TN];
@@ -746,14 +764,15 @@ __global__ __launch_bounds__(NWV * 64) void gemm_f32_kernel(GemmParams p) {
         }
     };
     auto comp = [](const float4& v, int e) { return e == 0 ? v.x : (e == 1 ? v.y : (e == 2 ? v.z : v.w)); };
-    auto lstore = [&](int buf, float4 (&ra)[NUA], const float4 (&rb)[NUB], const float4 (&sa)[NSA]) {
+    auto lstore = [&](auto split_tag, int buf, float4 (&ra)[NUA], const float4 (&rb)[NUB], const float4 (&sa)[NSA]) {
+        constexpr bool SPL = decltype(split_tag)::value;   // the bf16 image, or (SPLIT kernels' non-finite fallback) the f32 one
         if constexpr (A_DEFER) {
             if (a_defer) {
 #pragma unroll
                 for (int i = 0; i < NUA; i++) { ra[i].x *= sa[i].x; ra[i].y *= sa[i].y; ra[i].z *= sa[i].z; ra[i].w *= sa[i].w; }
             }
         }
-        if constexpr (SPLIT) {
+        if constexpr (SPL) {
             unsigned h0, m0_, l0, h1, m1, l1;
             if constexpr (A_KC) {
 #pragma unroll
@@ -891,7 +910,7 @@ __global__ __launch_bounds__(NWV * 64) void gemm_f32_kernel(GemmParams p) {
     };
     if (nk > 0) {
         gload(z.kbeg, ra0, rb0, sa0);
-        lstore(0, ra0, rb0, sa0);
+        lstore(std::bool_constant<SPLIT>{}, 0, ra0, rb0, sa0);
     }
     long long tr1 = 0, tr2 = 0;
     if constexpr (SPLIT) {
@@ -903,7 +922,66 @@ __global__ __launch_bounds__(NWV * 64) void gemm_f32_kernel(GemmParams p) {
             if (kt + 1 < nk) gload(z.kbeg + (kt + 1) * BKT, ra0, rb0, sa0);
             compute_split();
             __syncthreads();
-            if (kt + 1 < nk) { lstore(0, ra0, rb0, sa0); __syncthreads(); }
+            if (kt + 1 < nk) { lstore(std::bool_constant<SPLIT>{}, 0, ra0, rb0, sa0); __syncthreads(); }
+        }
+        // Non-finite operands.  The three-way split of +-Inf (and of a finite value within one bf16 ulp of FLT_MAX) is Inf + NaN + NaN, so
+        // where the f32 pipe would produce +-Inf this loop produces NaN -- and the step's gradient sanitiser (training_loop.py:308:
+        // nan -> 0, +-inf -> +-1e5) tells the two apart.  A tile that comes out of the loop with any non-finite accumulator is therefore
+        // recomputed on the f32 MFMA pipe, here, before the epilogue (block-uniform branch; one LDS buffer of the f32 image fits inside
+        // the bf16 image; never taken on finite data: the check is one fma per accumulator register).
+        float chk = 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; i++)
+#pragma unroll
+            for (int j = 0; j < TN; j++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) chk = __builtin_fmaf(acc[i][j][r], 0.f, chk);   // NaN iff some accumulator is NaN / Inf
+        if (__builtin_expect(__syncthreads_or(chk != chk), 0)) {
+            // cold path: everything it needs beyond the loaders' state is recomputed from an opaque copy of the thread index, so that
+            // none of its addressing is hoisted above the hot loop (it cost the 128x64 instantiations an occupancy step otherwise)
+            int t2 = tid;
+            asm volatile("" : "+v"(t2));
+#pragma unroll
+            for (int i = 0; i < TM; i++)
+#pragma unroll
+                for (int j = 0; j < TN; j++)
+#pragma unroll
+                    for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+            reset_kstate();
+            const int kl2 = (t2 & 63) >> 5, cl2 = t2 & 31, w2 = t2 >> 6, wm2 = w2 / WGN, wn2 = w2 % WGN;
+            for (int kt = 0; kt < nk; kt++) {
+                gload(z.kbeg + kt * BKT, ra0, rb0, sa0);
+                if constexpr (A_DEFER) {
+                    if (a_defer) {
+#pragma unroll
+                        for (int i = 0; i < NUA; i++) { ra0[i].x *= sa0[i].x; ra0[i].y *= sa0[i].y; ra0[i].z *= sa0[i].z; ra0[i].w *= sa0[i].w; }
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < NUA; i++) {
+                    int r, k; unitA(t2, i, r, k);
+                    if constexpr (A_KC) { As[0][k + 0][r] = ra0[i].x; As[0][k + 1][r] = ra0[i].y; As[0][k + 2][r] = ra0[i].z; As[0][k + 3][r] = ra0[i].w; }
+                    else { As[0][k][r + 0] = ra0[i].x; As[0][k][r + 1] = ra0[i].y; As[0][k][r + 2] = ra0[i].z; As[0][k][r + 3] = ra0[i].w; }
+                }
+#pragma unroll
+                for (int i = 0; i < NUB; i++) {
+                    int r, k; unitB(t2, i, r, k);
+                    if constexpr (B_KC) { Bs[0][k + 0][r] = rb0[i].x; Bs[0][k + 1][r] = rb0[i].y; Bs[0][k + 2][r] = rb0[i].z; Bs[0][k + 3][r] = rb0[i].w; }
+                    else { Bs[0][k][r + 0] = rb0[i].x; Bs[0][k][r + 1] = rb0[i].y; Bs[0][k][r + 2] = rb0[i].z; Bs[0][k][r + 3] = rb0[i].w; }
+                }
+                __syncthreads();
+#pragma unroll 1
+                for (int kk = 0; kk < BKT / 2; kk++) {
+#pragma unroll
+                    for (int i = 0; i < TM; i++) {
+                        const float a = As[0][kk * 2 + kl2][wm2 * WM + i * 32 + cl2];
+#pragma unroll
+                        for (int j = 0; j < TN; j++)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, Bs[0][kk * 2 + kl2][wn2 * WN + j * 32 + cl2], acc[i][j], 0, 0, 0);
+                    }
+                }
+                __syncthreads();
+            }
         }
     } else
     {
@@ -914,7 +992,7 @@ __global__ __launch_bounds__(NWV * 64) void gemm_f32_kernel(GemmParams p) {
             const int buf = kt & 1;
             if (kt + 1 < nk) gload(z.kbeg + (kt + 1) * BKT, ra0, rb0, sa0);
             compute(buf);
-            if (kt + 1 < nk) lstore(buf ^ 1, ra0, rb0, sa0);   // (writing these between the MFMAs of the last k-pairs measured slower:
+            if (kt + 1 < nk) lstore(std::false_type{}, buf ^ 1, ra0, rb0, sa0);   // (writing these between the MFMAs of the last k-pairs measured slower:
             __syncthreads();                               //  the vmcnt wait then sits in the middle of the MFMA stream)
         }
     }
@@ -1466,6 +1544,7 @@ static int try_launch_skinny(const GemmParams& p, hipStream_t st) {
             raised = true;
         }
         hipLaunchKernelGGL(kern, grid, 256, lds, st, p, cpb, NC);
+        t_launches_f32++;
         return check_launch("gemm_skinny");
     };
     static bool r2 = false, r4 = false, r8 = false;
@@ -1537,6 +1616,7 @@ static int launch_small(GemmParams& p, hipStream_t st) {
         if (w8) hipLaunchKernelGGL((gemm_small_kernel<TA, TB, 8>), grid, 512, 0, st, p);
         else hipLaunchKernelGGL((gemm_small_kernel<TA, TB, 4>), grid, 256, 0, st, p);
     }
+    t_launches_f32++;
     return check_launch("gemm_small");
 }
 
@@ -1626,7 +1706,7 @@ static int zero_fill(float* dst, long pitch, long width, long rows, hipStream_t 
 }
 
 static long long* g_trace_buffer = nullptr;   // ldetr_debug_trace_tiles
-static int g_split_bf16_override = -1;         // ldetr_set_split_bf16: -1 = environment / default, else the tile mask
+static std::atomic<int> g_split_bf16_override{-1};   // ldetr_set_split_bf16: -1 = environment / default, else the tile mask (process-wide; atomic: tests toggle it while other host threads may launch)
 
 // Host-side conditions of the kernel's scalar-addressed loads (FAST instantiation): every operand whose view supports them must
 // qualify, otherwise the generic instantiation runs.  BKT is 32 for every tile shape.
@@ -1705,6 +1785,7 @@ static int launch_tile_impl(GemmParams& p, dim3 grid, hipStream_t st) {
         }
     }
     hipLaunchKernelGGL(kern, grid, NWV * 64, lds, st, p);
+    (SPLIT ? t_launches_split : t_launches_f32)++;
     return check_launch("gemm_f32");
 }
 
@@ -1802,7 +1883,8 @@ static int launch_gemm(GemmParams& p, int Mmax, long out_rows, int zbase, bool a
     static const int split_kinds = getenv("LDETR_SPLIT_BF16_KINDS") ? atoi(getenv("LDETR_SPLIT_BF16_KINDS")) : 7;   // bit 0: both operands k-contiguous, bit 1: one, bit 2: none (weight gradients)
     static const int split_min_kk = getenv("LDETR_SPLIT_BF16_MIN_K") ? atoi(getenv("LDETR_SPLIT_BF16_MIN_K")) : 128;
     constexpr int split_kind = ((AMODE <= OP_KC_WTAP) && (BMODE <= OP_KC_WTAP)) ? 1 : (((AMODE <= OP_KC_WTAP) || (BMODE <= OP_KC_WTAP)) ? 2 : 4);
-    const int split_tiles = g_split_bf16_override >= 0 ? g_split_bf16_override : split_tiles_env;
+    const int split_ovr = g_split_bf16_override.load(std::memory_order_relaxed);
+    const int split_tiles = split_ovr >= 0 ? split_ovr : split_tiles_env;
     const int split_on = (split_kinds & split_kind) ? split_tiles : 0;
     bool sp = false;
     if constexpr (split_cap) sp = split_on && (p.K / (split ? p.splitk : 1)) >= split_min_kk && fast_operands_ok<AMODE, BMODE>(p, Mmax);
@@ -1899,9 +1981,14 @@ extern "C" int ldetr_debug_trace_tiles(int64_t* buffer) {
     return LDETR_OK;
 }
 
+extern "C" int ldetr_engine_launch_counts(int64_t* f32_pipe, int64_t* bf16_split_pipe) {
+    if (f32_pipe) *f32_pipe = t_launches_f32;
+    if (bf16_split_pipe) *bf16_split_pipe = t_launches_split;
+    return LDETR_OK;
+}
+
 extern "C" int ldetr_set_split_bf16(int tiles) {
-    const int prev = g_split_bf16_override;
-    g_split_bf16_override = tiles;
+    const int prev = g_split_bf16_override.exchange(tiles);
     return prev;
 }
 
@@ -2016,6 +2103,7 @@ extern "C" int ldetr_gemm_pair_f32(const ldetr_gemm_desc* g0, const ldetr_gemm_d
                 else hipLaunchKernelGGL((gemm_small_pair_kernel<0, 1, 1, 1, 4, true>), grid, 256, 0, st, p0, p1, gx0, nt0, sk0, gx1, nt1, sk1);
             } else if (w8) hipLaunchKernelGGL((gemm_small_pair_kernel<0, 1, 1, 1, 8>), grid, 512, 0, st, p0, p1, gx0, nt0, sk0, gx1, nt1, sk1);
             else hipLaunchKernelGGL((gemm_small_pair_kernel<0, 1, 1, 1, 4>), grid, 256, 0, st, p0, p1, gx0, nt0, sk0, gx1, nt1, sk1);
+            t_launches_f32++;
             return check_launch("gemm_small_pair");
         }
     }
@@ -2122,6 +2210,7 @@ extern "C" int ldetr_conv2d_bwd_weight_f32(const float* x, const ldetr_tensor4* 
     if (!accumulate) { if (int zrc = zero_fill(dw, wsz, wsz, 1, st)) return zrc; }
     if (!gather) {   // 32 -> 32 channels on a large grid: the LDS-free operand-streaming kernel (wgrad_smallc.hip)
         const int took = try_launch_wgrad_smallc(x, xt, dy, dyt, dw, KH, KW, stride, pad, x_scale, x_scale_ld, dy_scale, dy_scale_ld, st);
+        if (took > 0) t_launches_f32++;
         if (took != 0) return took > 0 ? LDETR_OK : LDETR_ERR_LAUNCH;
     }
     if (splitk == 1 && accumulate) p.ep.accumulate = 1;

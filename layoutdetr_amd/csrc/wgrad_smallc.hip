@@ -134,7 +134,10 @@ int try_launch_wgrad_smallc(const float* x, const ldetr_tensor4* xt, const float
     if (!on || KH != 3 || KW != 3 || stride != 1 || pad != 1 || xt->C != 32 || dyt->C != 32 || dyt->H != H || dyt->W != W || (W & 1)) return 0;
     if (xt->sc != 1 || xt->sw != 32 || xt->sh != (long)W * 32 || xt->sn != (long)H * W * 32) return 0;
     if (dyt->sc != 1 || dyt->sw != 32 || dyt->sh != (long)W * 32 || dyt->sn != (long)H * W * 32) return 0;
-    if ((long)H * W * 32 * 4 >= 0x7fffffffL || (long)N * H * W < (1L << 18)) return 0;      // 32-bit offsets inside a sample; small grids stay on the GEMM path
+    // The kernel's border handling needs a first AND a distinct last column pair (W >= 4); its vector offsets reach (W + 1) pixels past either
+    // end of a sample's rows, so (H*W + 2*(W+1)) * 128 bytes must stay below 2^31; small grids stay on the GEMM path.  (fp32 atomics merge the
+    // blocks' partial sums: the result is summation-order dependent from run to run, like the engine's atomic split-K path.)
+    if (W < 4 || ((long)H * W + 2L * (W + 1)) * 128 >= 0x7fffffffL || (long)N * H * W < (1L << 18)) return 0;
     // strips of whole rows, never crossing a sample; about 4 waves per SIMD-pair of the chip
     static const int target = getenv("LDETR_WGRAD_SMALLC_WAVES") ? atoi(getenv("LDETR_WGRAD_SMALLC_WAVES")) : 2048;   // strips: 2 waves per SIMD
     int rpw = (int)(((long)N * H + target - 1) / target);

@@ -136,7 +136,24 @@ def install(modules=None):
         if parent in sys.modules:                  # `from training import training_loop` looks the attribute up on the package
             setattr(sys.modules[parent], leaf, mod)
         out[ref_name] = mod
+    if 'training.networks_detr' in out:
+        # under the reference's driver an unspecified text_mode means what the reference always builds: tokenizer + text encoder + LM decoder
+        out['training.networks_detr'].REFERENCE_DEFAULTS = True
     return out
+
+
+def uninstall():
+    """Undo install(): drop the aliases this module registered and restore the stand-alone constructor defaults (tests)."""
+    for ref_name, here in _ALIASES.items():
+        mod = sys.modules.get(ref_name)
+        if mod is not None and mod.__name__ == here:
+            del sys.modules[ref_name]
+            parent, _, leaf = ref_name.rpartition('.')
+            if parent in sys.modules and getattr(sys.modules[parent], leaf, None) is mod:
+                delattr(sys.modules[parent], leaf)
+    nd = sys.modules.get('layoutdetr_amd.training.networks_detr')
+    if nd is not None:
+        nd.REFERENCE_DEFAULTS = False
 
 
 def install_plugins():

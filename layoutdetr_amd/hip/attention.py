@@ -18,8 +18,9 @@ class _AttnFn(torch.autograd.Function):
     """q: [B*Lq, >=d] view, k/v: [B*Lk, >=d] views (unit inner stride, arbitrary row stride)."""
 
     @staticmethod
-    def forward(ctx, q, k, v, kpm, B, H, Lq, Lk, p_drop):
+    def forward(ctx, q, k, v, kpm, B, H, Lq, Lk, p_drop, kv_grad_dst=None):
         core.require_gpu(q, k, v, kpm)
+        ctx.kv_grad_dst = kv_grad_dst      # callable -> (dk view, dv view) inside a grouped projection's gradient buffer (grouped_kv below)
         dh = q.shape[1] // H
         assert q.stride(1) == 1 and k.stride(1) == 1 and v.stride(1) == 1
         d = H * dh
@@ -42,13 +43,16 @@ class _AttnFn(torch.autograd.Function):
         d = H * dh
         dout = core.f32c(dout)
         dq = torch.empty((B * Lq, d), device=q.device, dtype=torch.float32)
-        dk = torch.empty((B * Lk, d), device=q.device, dtype=torch.float32)
-        dv = torch.empty((B * Lk, d), device=q.device, dtype=torch.float32)
+        if ctx.kv_grad_dst is not None:
+            dk, dv = ctx.kv_grad_dst()       # written in place: the grouped projection's backward reads the whole buffer
+        else:
+            dk = torch.empty((B * Lk, d), device=q.device, dtype=torch.float32)
+            dv = torch.empty((B * Lk, d), device=q.device, dtype=torch.float32)
         core.check(core.lib().ldetr_attention_bwd_f32(
             core.ptr(q), q.stride(0), core.ptr(k), k.stride(0), core.ptr(v), v.stride(0), core.ptr(kpm),
-            core.ptr(out), d, core.ptr(lse), core.ptr(dout), d, core.ptr(dq), d, core.ptr(dk), d, core.ptr(dv), d,
+            core.ptr(out), d, core.ptr(lse), core.ptr(dout), d, core.ptr(dq), d, core.ptr(dk), dk.stride(0), core.ptr(dv), dv.stride(0),
             B, H, Lq, Lk, dh, scale, p_drop, seed, core.seed_ptr() if p_drop > 0 else None, 0, core.stream()), 'attention_bwd')
-        return dq, dk, dv, None, None, None, None, None, None
+        return dq, dk, dv, None, None, None, None, None, None, None
 
 
 class _AttnPackedFn(torch.autograd.Function):
@@ -100,11 +104,121 @@ def _kpm_u8(key_padding_mask):
     return None if key_padding_mask is None else key_padding_mask.to(torch.uint8).contiguous()
 
 
-def attention(q, k, v, key_padding_mask, B, H, Lq, Lk, p_drop=0.0):
+def attention(q, k, v, key_padding_mask, B, H, Lq, Lk, p_drop=0.0, kv_grad_dst=None):
     kpm = None
     if key_padding_mask is not None:
         kpm = key_padding_mask.to(torch.uint8).contiguous()
-    return _AttnFn.apply(q, k, v, kpm, B, H, Lq, Lk, p_drop)
+    return _AttnFn.apply(q, k, v, kpm, B, H, Lq, Lk, p_drop, kv_grad_dst)
+
+
+class _GroupedKVFn(torch.autograd.Function):
+    """The memory K / V projections of ALL decoder layers as two GEMMs.  The reference projects the (layer-invariant) encoder memory
+    inside every decoder layer (detr_transformer.py:277-280: `multihead_attn(query, key=memory + pos, value=memory)`, each layer with
+    its own in_proj_weight rows d:2d / 2d:3d): 2 x layers projections of M = S*B rows with N = d.  Here: K_all = (memory + pos) Wk_all^T
+    and V_all = memory Wv_all^T with N = layers * d (one large-tile launch each instead of `layers` latency-bound ones), the layers
+    read their [M, d] column blocks in place, their attention backward writes dK / dV into the matching blocks of ONE gradient
+    buffer, and the backward is two data-gradient GEMMs (K = layers * d) + two weight-gradient GEMMs whose [layers, d, d] results are
+    added into the layers' flat .grad rows with one strided launch.  The memory and memory + pos tensors are consumed once each,
+    so autograd has no gradient fan-in to sum.
+    forward(mem_pos, mem, n, W_0, b_0, ..., W_{n-1}, b_{n-1}) -> (K_0, ..., K_{n-1}, V_0, ..., V_{n-1}) and the gradient-buffer views via
+    ctx (see grouped_kv)."""
+
+    @staticmethod
+    def forward(ctx, mem_pos, mem, holder, *params):
+        core.require_gpu(mem_pos, mem)
+        ctx.set_materialize_grads(False)
+        Ws, bs = params[0::2], params[1::2]
+        n, d = len(Ws), mem.shape[1]
+        M = mem.shape[0]
+        mp, mm = core.f32c(mem_pos), core.f32c(mem)
+        with torch.no_grad():
+            Wk = torch.cat([w.detach()[d:2 * d] for w in Ws] + [w.detach()[2 * d:] for w in Ws])        # [2 n d, d]: K rows of every layer, then V rows
+            bk = torch.cat([b.detach()[d:2 * d] for b in bs] + [b.detach()[2 * d:] for b in bs])        # [2 n d]
+        nd = n * d
+        KV = torch.empty((M, 2 * nd), device=mem.device, dtype=torch.float32)
+        core.gemm(mp, Wk[:nd], 0, 0, M, nd, d, out=KV[:, :nd], ep=core.epilogue(col_bias=bk[:nd]))
+        core.gemm(mm, Wk[nd:], 0, 0, M, nd, d, out=KV[:, nd:], ep=core.epilogue(col_bias=bk[nd:]))
+        ctx.save_for_backward(mp, mm, Wk)
+        ctx.params = (Ws, bs)
+        ctx.cfg = (n, d, M)
+        ctx.holder = holder
+        holder.dKV = None
+        return tuple(KV[:, i * d:(i + 1) * d] for i in range(2 * n))
+
+    @staticmethod
+    def backward(ctx, *grads):
+        mp, mm, Wk = ctx.saved_tensors
+        n, d, M = ctx.cfg
+        Ws, bs = ctx.params
+        nd = n * d
+        dKV = ctx.holder.dKV
+        if dKV is None:
+            dKV = torch.zeros((M, 2 * nd), device=mp.device, dtype=torch.float32)
+        for i, g in enumerate(grads):      # blocks the attention backward wrote in place arrive as views of dKV: nothing to do for them
+            dst = dKV[:, i * d:(i + 1) * d]
+            if g is None:
+                if ctx.holder.dKV is not None:
+                    dst.zero_()
+            elif g.data_ptr() != dst.data_ptr() or g.stride() != dst.stride():
+                dst.copy_(g)
+        ctx.holder.dKV = None
+        dmp = core.gemm(dKV[:, :nd], Wk[:nd], 0, 1, M, d, nd) if ctx.needs_input_grad[0] else None
+        dmm = core.gemm(dKV[:, nd:], Wk[nd:], 0, 1, M, d, nd) if ctx.needs_input_grad[1] else None
+        need_w = any(ctx.needs_input_grad[3 + 2 * i] for i in range(n)) and not core.WEIGHT_GRADIENTS_DISABLED[0]
+        out = [None] * (2 * n)
+        if need_w:
+            T = torch.empty((2, nd, d), device=mp.device, dtype=torch.float32)
+            tb = torch.zeros((2, nd), device=mp.device, dtype=torch.float32)
+            core.gemm(dKV[:, :nd], mp, 1, 1, nd, d, M, out=T[0], ep=core.epilogue(a_rowsum=tb[0]))
+            core.gemm(dKV[:, nd:], mm, 1, 1, nd, d, M, out=T[1], ep=core.epilogue(a_rowsum=tb[1]))
+            gws, gbs = [core.flat_grad(w) for w in Ws], [core.flat_grad(b) for b in bs]
+            strided = all(g is not None for g in gws + gbs) and n > 1
+            if strided:       # the layers' parameters sit at a constant pitch in the flat gradient buffer: one strided add for all of them
+                sw = gws[1].storage_offset() - gws[0].storage_offset(); sb = gbs[1].storage_offset() - gbs[0].storage_offset()
+                strided = (all(g.is_contiguous() and g.untyped_storage().data_ptr() == gws[0].untyped_storage().data_ptr() for g in gws + gbs)
+                           and all(gws[i].storage_offset() - gws[0].storage_offset() == i * sw and gbs[i].storage_offset() - gbs[0].storage_offset() == i * sb for i in range(n)))
+            if strided:
+                gw = torch.as_strided(gws[0], (n, 2, d, d), (sw, d * d, d, 1), gws[0].storage_offset() + d * d)
+                gw += T.view(2, n, d, d).permute(1, 0, 2, 3)
+                gb = torch.as_strided(gbs[0], (n, 2, d), (sb, d, 1), gbs[0].storage_offset() + d)
+                gb += tb.view(2, n, d).permute(1, 0, 2)
+            else:
+                for i in range(n):
+                    if gws[i] is not None:
+                        gws[i][d:2 * d] += T[0, i * d:(i + 1) * d]; gws[i][2 * d:] += T[1, i * d:(i + 1) * d]
+                    else:
+                        g = torch.zeros_like(Ws[i]); g[d:2 * d] = T[0, i * d:(i + 1) * d]; g[2 * d:] = T[1, i * d:(i + 1) * d]
+                        out[2 * i] = g
+                    if gbs[i] is not None:
+                        gbs[i][d:2 * d] += tb[0, i * d:(i + 1) * d]; gbs[i][2 * d:] += tb[1, i * d:(i + 1) * d]
+                    else:
+                        g = torch.zeros_like(bs[i]); g[d:2 * d] = tb[0, i * d:(i + 1) * d]; g[2 * d:] = tb[1, i * d:(i + 1) * d]
+                        out[2 * i + 1] = g
+        return (dmp, dmm, None) + tuple(out)
+
+
+class _KVHolder(object):
+    """Shared between a grouped projection and the attention calls that read it: the [M, 2 n d] gradient buffer (allocated by the first
+    attention backward that needs it)."""
+    dKV = None
+
+
+def grouped_kv(mem_pos, mem, mhas):
+    """mhas: the layers' nn.MultiheadAttention parameter containers -> [(K_i, V_i, grad_dst_i)] per layer; grad_dst_i() yields the (dK, dV)
+    views the layer's attention backward writes into (pass it to mha_cross_kv)."""
+    n, d, M = len(mhas), mem.shape[1], mem.shape[0]
+    holder = _KVHolder()
+    outs = _GroupedKVFn.apply(mem_pos, mem, holder, *[t for m in mhas for t in (m.in_proj_weight, m.in_proj_bias)])
+
+    def dst(i):
+        def views():
+            if holder.dKV is None:
+                holder.dKV = torch.empty((M, 2 * n * d), device=mem.device, dtype=torch.float32)
+                holder.written = set()
+            holder.written.add(i)
+            return holder.dKV[:, i * d:(i + 1) * d], holder.dKV[:, (n + i) * d:(n + i + 1) * d]
+        return views
+    return [(outs[i], outs[n + i], dst(i)) for i in range(n)]
 
 
 def mha_forward(query, key, value, in_proj_weight, in_proj_bias, out_w, out_b, nhead, B, Lq, Lk,
@@ -155,3 +269,13 @@ def mha_forward(query, key, value, in_proj_weight, in_proj_bias, out_w, out_b, n
     if kv_alias:
         return out, alias, key, value
     return (out, alias) if passthru else out
+
+
+def mha_cross_kv(query, K, V, grad_dst, in_proj_weight, in_proj_bias, out_w, out_b, nhead, B, Lq, Lk, key_padding_mask=None, p_drop=0.0):
+    """Cross-attention block whose key / value projections were made by grouped_kv(): q projection (rows 0:d of the packed weight),
+    fused attention on the layer's [M, d] blocks of the grouped buffer, output projection.  -> (block output, alias of `query` for the
+    residual branch, see hip/linear.py passthru)."""
+    d = query.shape[1]
+    q, alias = linear(query, in_proj_weight, in_proj_bias, rows=(0, d), passthru=True)
+    o = attention(q, K, V, key_padding_mask, B, nhead, Lq, Lk, p_drop, kv_grad_dst=grad_dst)
+    return linear(o, out_w, out_b), alias

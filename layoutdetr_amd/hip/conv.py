@@ -48,7 +48,7 @@ class _ConvFn(torch.autograd.Function):
         ep = core.epilogue(col_scale=sc, col_bias=sh, residual=res, act=ACT_RELU if relu else ACT_NONE)
         core.engine_call('ldetr_conv2d_fwd_f32', 2.0 * N * OH * OW * O * KH * KW * I, lambda: core.check(core.lib().ldetr_conv2d_fwd_f32(
             core.ptr(x), ctypes.byref(xt), core.ptr(w), O, KH, KW, stride, pad, core.ptr(y), O, OH, OW, None, 0,
-            ctypes.byref(ep), core.stream()), 'conv2d_fwd'))
+            ctypes.byref(ep), core.stream()), 'conv2d_fwd'), operands=(x, y, w, res))
         ctx.save_for_backward(x, w, sc, y if relu else None)
         ctx.cfg = (stride, pad, relu, x_is_nchw, residual is not None, shift is not None, (N, H, W, I), premasked, mask_input)
         ctx.params = (weight, shift)
@@ -100,7 +100,7 @@ class _ConvFn(torch.autograd.Function):
                 epb = core.epilogue(residual=res2, mask_src=x.reshape(-1, I) if mask_input else None, mask_mode=1 if mask_input else 0)
             core.engine_call('ldetr_conv2d_bwd_data_f32', 2.0 * N * OH * OW * O * KH * KW * I, lambda: core.check(core.lib().ldetr_conv2d_bwd_data_f32(
                 core.ptr(dpre), ctypes.byref(dyt), core.ptr(w), I, KH, KW, stride, pad, core.ptr(dx), I, H, W,
-                core.ptr(sc), 0, ctypes.byref(epb) if epb is not None else None, core.stream()), 'conv2d_bwd_data'))
+                core.ptr(sc), 0, ctypes.byref(epb) if epb is not None else None, core.stream()), 'conv2d_bwd_data'), operands=(dpre, dx, w))
         if need_w:
             gw = core.flat_grad(wparam)
             acc = 0
@@ -118,12 +118,12 @@ class _ConvFn(torch.autograd.Function):
                 dyt_s = core.tensor4_nhwc(dpre_s)
                 core.engine_call('ldetr_conv2d_bwd_weight_f32', 2.0 * N * OH * OW * O * KH * KW * I, lambda: core.check(core.lib().ldetr_conv2d_bwd_weight_f32(
                     core.ptr(x), ctypes.byref(xt), core.ptr(dpre_s), ctypes.byref(dyt_s), core.ptr(dw_ohwi), KH, KW,
-                    stride, pad, sk, None, 0, None, 0, acc, core.stream()), 'conv2d_bwd_weight'))
+                    stride, pad, sk, None, 0, None, 0, acc, core.stream()), 'conv2d_bwd_weight'), operands=(x, dpre_s, dw_ohwi))
             else:
                 def wgrad():
                     core.engine_call('ldetr_conv2d_bwd_weight_f32', 2.0 * N * OH * OW * O * KH * KW * I, lambda: core.check(core.lib().ldetr_conv2d_bwd_weight_f32(
                         core.ptr(x), ctypes.byref(xt), core.ptr(dpre), ctypes.byref(dyt), core.ptr(dw_ohwi), KH, KW, stride,
-                        pad, sk, None, 0, core.ptr(sc), 0, acc, core.stream()), 'conv2d_bwd_weight'))
+                        pad, sk, None, 0, core.ptr(sc), 0, acc, core.stream()), 'conv2d_bwd_weight'), operands=(x, dpre, dw_ohwi))
                 if acc:
                     core.run_on_side(wgrad, keep=(x, dpre, sc))
                 else:
@@ -189,7 +189,7 @@ class _ConvTransposeFn(torch.autograd.Function):
         y = torch.empty((N, OH, OW, O), device=x.device, dtype=torch.float32)
         xt = core.tensor4_nhwc(x)
         core.engine_call('ldetr_conv_transpose2d_fwd_f32', 2.0 * N * H * W * O * KH * KW * I, lambda: core.check(core.lib().ldetr_conv_transpose2d_fwd_f32(
-            core.ptr(x), ctypes.byref(xt), core.ptr(w), O, KH, KW, stride, pad, core.ptr(y), O, OH, OW, None, 0, None, core.stream()), 'conv_transpose2d_fwd'))
+            core.ptr(x), ctypes.byref(xt), core.ptr(w), O, KH, KW, stride, pad, core.ptr(y), O, OH, OW, None, 0, None, core.stream()), 'conv_transpose2d_fwd'), operands=(x, y, w))
         ctx.save_for_backward(x, w)
         ctx.cfg = (stride, pad)
         return y
@@ -206,12 +206,12 @@ class _ConvTransposeFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
             core.engine_call('ldetr_conv_transpose2d_bwd_data_f32', 2.0 * N * H * W * O * KH * KW * I, lambda: core.check(core.lib().ldetr_conv_transpose2d_bwd_data_f32(
-                core.ptr(dy), ctypes.byref(dyt), core.ptr(w), I, KH, KW, stride, pad, core.ptr(dx), I, H, W, None, 0, None, core.stream()), 'conv_transpose2d_bwd_data'))
+                core.ptr(dy), ctypes.byref(dyt), core.ptr(w), I, KH, KW, stride, pad, core.ptr(dx), I, H, W, None, 0, None, core.stream()), 'conv_transpose2d_bwd_data'), operands=(dy, dx, w))
         if ctx.needs_input_grad[1] and not core.WEIGHT_GRADIENTS_DISABLED[0]:
             dw = torch.empty_like(w)
             xt = core.tensor4_nhwc(x)
             core.engine_call('ldetr_conv_transpose2d_bwd_weight_f32', 2.0 * N * H * W * O * KH * KW * I, lambda: core.check(core.lib().ldetr_conv_transpose2d_bwd_weight_f32(
-                core.ptr(x), ctypes.byref(xt), core.ptr(dy), ctypes.byref(dyt), core.ptr(dw), KH, KW, stride, pad, 0, None, 0, None, 0, 0, core.stream()), 'conv_transpose2d_bwd_weight'))
+                core.ptr(x), ctypes.byref(xt), core.ptr(dy), ctypes.byref(dyt), core.ptr(dw), KH, KW, stride, pad, 0, None, 0, None, 0, 0, core.stream()), 'conv_transpose2d_bwd_weight'), operands=(x, dy, dw))
         return dx, dw, None, None
 
 

@@ -36,16 +36,28 @@ class _EngineProfile(object):
 PROF = _EngineProfile()
 
 
-def engine_call(tag, flops, thunk):
+def engine_call(tag, flops, thunk, operands=(), nbytes=None):
+    """operands: the tensors the launch must read or write at least once (its algorithmic HBM bytes = 4 x their element counts; or `nbytes`)."""
     if not PROF.enabled:
         return thunk()
     s = torch.cuda.Event(enable_timing=True)
     e = torch.cuda.Event(enable_timing=True)
+    c0 = engine_launch_counts()
     s.record()
     r = thunk()
     e.record()
-    PROF.records.append((tag, float(flops), s, e))
+    c1 = engine_launch_counts()
+    if nbytes is None:
+        nbytes = 4.0 * sum(t.numel() for t in operands if t is not None)
+    PROF.records.append((tag, float(flops), s, e, nbytes, (c1[0] - c0[0], c1[1] - c0[1])))
     return r
+
+
+def engine_launch_counts():
+    """(launches on the f32 MFMA pipe, launches on the bf16 pipe with the exact operand split) issued by this thread so far."""
+    a, b = ctypes.c_int64(0), ctypes.c_int64(0)
+    lib().ldetr_engine_launch_counts(ctypes.byref(a), ctypes.byref(b))
+    return a.value, b.value
 
 
 
@@ -247,7 +259,7 @@ def gemm(A, B, ta, tb, M, N, K, out=None, ep=None, splitk=0, pix_per_sample=0, l
     ldb = B.stride(0) if ldb is None else ldb
     engine_call('gemm', 2.0 * M * N * K, lambda: check(lib().ldetr_gemm_f32(
         ptr(A), lda, int(ta), ptr(B), ldb, int(tb), ptr(out), out.stride(0), M, N, K, splitk,
-        ctypes.byref(ep) if ep is not None else None, pix_per_sample, stream()), 'gemm'))
+        ctypes.byref(ep) if ep is not None else None, pix_per_sample, stream()), 'gemm'), nbytes=4.0 * (M * K + N * K + M * N))
     return out
 
 
@@ -282,7 +294,8 @@ def gemm_pair(g0, g1):
     The data and the weight gradient of a linear layer run as ONE kernel launch when both are small-tile problems; otherwise as
     two, in order.  a_mask (laid out like A) folds a ReLU gradient into the loads of A: single-launch path only."""
     descs, flops = _pair_descs(g0, g1)
-    engine_call('gemm', flops, lambda: check(lib().ldetr_gemm_pair_f32(ctypes.byref(descs[0]), ctypes.byref(descs[1]), stream()), 'gemm_pair'))
+    engine_call('gemm', flops, lambda: check(lib().ldetr_gemm_pair_f32(ctypes.byref(descs[0]), ctypes.byref(descs[1]), stream()), 'gemm_pair'),
+                nbytes=4.0 * sum(d.M * d.K + d.N * d.K + d.M * d.N for d in descs))
 
 
 def colsum(a2d, B=1):

@@ -43,7 +43,7 @@ class _ModConvFn(torch.autograd.Function):
         xt = core.tensor4_nhwc(x)
         ep = core.epilogue(samp_scale=d, col_bias=b, act=ACT_LRELU, act_alpha=act_alpha, act_gain=act_gain)
         core.engine_call('ldetr_conv2d_fwd_f32', 2.0 * B * OH * OW * O * KH * KW * I, lambda: core.check(core.lib().ldetr_conv2d_fwd_f32(core.ptr(x), ctypes.byref(xt), core.ptr(w), O, KH, KW, 1, pad, core.ptr(y), O,
-                                                   OH, OW, core.ptr(s), s.stride(0), ctypes.byref(ep), core.stream()), 'modconv_fwd'))
+                                                   OH, OW, core.ptr(s), s.stride(0), ctypes.byref(ep), core.stream()), 'modconv_fwd'), operands=(x, y, w))
         ctx.save_for_backward(x, w, s, d, b, y)
         ctx.cfg = (pad, act_alpha, act_gain)
         ctx.params = (weight, bias)
@@ -67,7 +67,7 @@ class _ModConvFn(torch.autograd.Function):
             dxs = torch.empty((B, H, W, I), device=dy.device, dtype=torch.float32)
             core.engine_call('ldetr_conv2d_bwd_data_f32', 2.0 * B * OH * OW * O * KH * KW * I, lambda: core.check(core.lib().ldetr_conv2d_bwd_data_f32(core.ptr(dv), ctypes.byref(dvt), core.ptr(w), I, KH, KW, 1, pad,
                                                             core.ptr(dxs), I, H, W, core.ptr(d), d.stride(0), None, core.stream()),
-                       'modconv_bwd_data'))
+                       'modconv_bwd_data'), operands=(dv, dxs, w))
             dx, ds = _mul_reduce(dxs, x, s, B, H * W, I)
         if ctx.needs_input_grad[1]:
             gw = core.flat_grad(wparam)
@@ -80,7 +80,7 @@ class _ModConvFn(torch.autograd.Function):
             sk = 0   # the library picks tile and split-K factor together
             core.engine_call('ldetr_conv2d_bwd_weight_f32', 2.0 * B * OH * OW * O * KH * KW * I, lambda: core.check(core.lib().ldetr_conv2d_bwd_weight_f32(core.ptr(x), ctypes.byref(xt), core.ptr(dv), ctypes.byref(dvt),
                                                               core.ptr(dw_ohwi), KH, KW, 1, pad, sk, core.ptr(s), s.stride(0),
-                                                              core.ptr(d), d.stride(0), acc, core.stream()), 'modconv_bwd_weight'))
+                                                              core.ptr(d), d.stride(0), acc, core.stream()), 'modconv_bwd_weight'), operands=(x, dv, dw_ohwi))
             dw = None if acc else _grad_to_oihw(dw_ohwi)
         return dx, dw, ds, ddemod, dbias, None, None, None
 
@@ -100,7 +100,7 @@ class _ModConvUpFn(torch.autograd.Function):
         ep = core.epilogue(samp_scale=d)
         core.engine_call('ldetr_conv_transpose2d_fwd_f32', 2.0 * B * H * W * O * KH * KW * I, lambda: core.check(core.lib().ldetr_conv_transpose2d_fwd_f32(core.ptr(x), ctypes.byref(xt), core.ptr(w), O, KH, KW, 2, 0, core.ptr(ud),
                                                              O, UH, UW, core.ptr(s), s.stride(0), ctypes.byref(ep), core.stream()),
-                   'modconv_up_fwd'))
+                   'modconv_up_fwd'), operands=(x, ud, w))
         # conv2d_resample.py:113-130 with padding=1, 4-tap filter, up=2 -> transposed-conv pad 0, FIR pad [1,1,1,1], gain 4
         y = _up._kernel_call(ud.permute(0, 3, 1, 2), f, 1, 1, 1, 1, 1, 1, 1, 1, False, 4.0, act_bias=b,
                              act=(act_alpha, act_gain)).permute(0, 2, 3, 1)
@@ -131,7 +131,7 @@ class _ModConvUpFn(torch.autograd.Function):
             dxs = torch.empty((B, H, W, I), device=dy.device, dtype=torch.float32)
             core.engine_call('ldetr_conv_transpose2d_bwd_data_f32', 2.0 * B * H * W * O * KH * KW * I, lambda: core.check(core.lib().ldetr_conv_transpose2d_bwd_data_f32(core.ptr(dud), ctypes.byref(dudt), core.ptr(w), I, KH, KW, 2, 0,
                                                                       core.ptr(dxs), I, H, W, core.ptr(d), d.stride(0), None,
-                                                                      core.stream()), 'modconv_up_bwd_data'))
+                                                                      core.stream()), 'modconv_up_bwd_data'), operands=(dud, dxs, w))
             dx, ds = _mul_reduce(dxs, x, s, B, H * W, I)
         if ctx.needs_input_grad[1]:
             gw = core.flat_grad(wparam)
@@ -144,7 +144,7 @@ class _ModConvUpFn(torch.autograd.Function):
             sk = 0   # the library picks tile and split-K factor together
             core.engine_call('ldetr_conv_transpose2d_bwd_weight_f32', 2.0 * B * H * W * O * KH * KW * I, lambda: core.check(core.lib().ldetr_conv_transpose2d_bwd_weight_f32(core.ptr(x), ctypes.byref(xt), core.ptr(dud), ctypes.byref(dudt),
                                                                         core.ptr(dw_ohwi), KH, KW, 2, 0, sk, core.ptr(s), s.stride(0),
-                                                                        core.ptr(d), d.stride(0), acc, core.stream()), 'modconv_up_bwd_weight'))
+                                                                        core.ptr(d), d.stride(0), acc, core.stream()), 'modconv_up_bwd_weight'), operands=(x, dud, dw_ohwi))
             dw = None if acc else _grad_to_oihw(dw_ohwi)
         return dx, dw, ds, ddemod, dbias, None, None, None
 
@@ -163,7 +163,7 @@ class _ToRGBFn(torch.autograd.Function):
         xt = core.tensor4_nhwc(x)
         ep = core.epilogue(col_bias=b)
         core.engine_call('ldetr_conv2d_fwd_f32', 2.0 * B * H * W * O * C, lambda: core.check(core.lib().ldetr_conv2d_fwd_f32(core.ptr(x), ctypes.byref(xt), core.ptr(w), O, 1, 1, 1, 0, core.ptr(y), O, H, W,
-                                                   core.ptr(s), s.stride(0), ctypes.byref(ep), core.stream()), 'torgb_fwd'))
+                                                   core.ptr(s), s.stride(0), ctypes.byref(ep), core.stream()), 'torgb_fwd'), operands=(x, y, w))
         ctx.save_for_backward(x, w, s)
         ctx.wshape = weight.shape
         return y

@@ -8,13 +8,14 @@ every projection / FFN is one f32-MFMA GEMM with fused bias/relu/dropout, attent
 kernel per call, and each `x = norm(x + dropout(sub(x)))` is one kernel.
 """
 import copy
+import os
 from typing import Optional
 
 import torch
 from torch import Tensor, nn
 
 from ..hip import core
-from ..hip.attention import mha_forward
+from ..hip.attention import grouped_kv, mha_cross_kv, mha_forward
 from ..hip.layernorm import add_layernorm
 from ..hip.linear import linear
 
@@ -33,6 +34,8 @@ def _mha(m: nn.MultiheadAttention, q2, k2, v2, B, Lq, Lk, kpm, training, same_qk
                        B, Lq, Lk, key_padding_mask=kpm, p_drop=p, same_qk=same_qk, same_qkv=same_qkv, qk_pos=qk_pos, passthru=True,
                        qk_in=qk_in, kv_alias=kv_alias)
 
+
+_GROUP_KV = os.environ.get('LDETR_GROUP_KV', '1') != '0'
 
 _mask_scope = [None]     # dict while a Generator / Discriminator forward is running (mask_scope()), else None
 
@@ -116,11 +119,18 @@ class TransformerDecoderLayer(nn.Module):
         self.dropout3 = nn.Dropout(dropout)
         self.normalize_before = normalize_before
 
-    def forward2d(self, t2, mem2, mem_pos2, B, Lq, S, tgt_kpm, mem_kpm):
-        """-> (t2, alias of mem2, alias of mem_pos2): the next layer reads the memory through the aliases (mha_forward kv_alias)."""
+    def forward2d(self, t2, mem2, mem_pos2, B, Lq, S, tgt_kpm, mem_kpm, kv=None):
+        """-> (t2, alias of mem2, alias of mem_pos2): the next layer reads the memory through the aliases (mha_forward kv_alias).
+        kv = (K, V, grad_dst) from hip.attention.grouped_kv: the memory projections of this layer were made by the stack (one GEMM for
+        all layers); mem2 / mem_pos2 are then not touched here."""
         a, t2 = _mha(self.self_attn, t2, t2, t2, B, Lq, Lq, tgt_kpm, self.training, same_qkv=True)
         t2 = _add_ln(self.norm1, t2, a, self.dropout1, self.training)
-        a, t2, mem_pos2, mem2 = _mha(self.multihead_attn, t2, mem_pos2, mem2, B, Lq, S, mem_kpm, self.training, kv_alias=True)
+        if kv is not None:
+            m = self.multihead_attn
+            a, t2 = mha_cross_kv(t2, kv[0], kv[1], kv[2], m.in_proj_weight, m.in_proj_bias, m.out_proj.weight, m.out_proj.bias, m.num_heads, B, Lq, S,
+                                 key_padding_mask=mem_kpm, p_drop=m.dropout if self.training else 0.0)
+        else:
+            a, t2, mem_pos2, mem2 = _mha(self.multihead_attn, t2, mem_pos2, mem2, B, Lq, S, mem_kpm, self.training, kv_alias=True)
         t2 = _add_ln(self.norm2, t2, a, self.dropout2, self.training)
         f, t2 = _ffn(self, t2)
         return _add_ln(self.norm3, t2, f, self.dropout3, self.training), mem2, mem_pos2
@@ -172,8 +182,11 @@ class TransformerDecoder(nn.Module):
         tgt_kpm, mem_kpm = _mask_u8(tgt_kpm), _mask_u8(mem_kpm)
         if mem_pos2 is None:
             mem_pos2 = mem2 + pos2
-        for layer in self.layers:
-            t2, mem2, mem_pos2 = layer.forward2d(t2, mem2, mem_pos2, B, Lq, S, tgt_kpm, mem_kpm)
+        # the memory is the same for every layer (detr_transformer.py:277-280 projects it per layer): all layers' K / V projections as two
+        # GEMMs with N = layers * d, their backward as four (hip.attention._GroupedKVFn); LDETR_GROUP_KV=0 restores the per-layer launches
+        kvs = grouped_kv(mem_pos2, mem2, [l.multihead_attn for l in self.layers]) if (_GROUP_KV and len(self.layers) > 1) else None
+        for i, layer in enumerate(self.layers):
+            t2, mem2, mem_pos2 = layer.forward2d(t2, mem2, mem_pos2, B, Lq, S, tgt_kpm, mem_kpm, kv=None if kvs is None else kvs[i])
         if self.norm is not None:
             t2 = add_layernorm(t2, None, self.norm.weight, self.norm.bias, self.norm.eps)
         return t2

@@ -53,6 +53,26 @@ def normalize_2nd_moment(x, eps=1e-8):
     return x * (x.square().mean(dim=1, keepdim=True) + eps).rsqrt()
 
 
+# Set by layoutdetr_amd.dropin.install(): the modules are being driven by the reference's own train.py / training_loop, which builds G / D
+# from (class_name, z_dim, f_dim, ..., bert_* , im_f_dim) only (train.py:201-203,250-261) and hands them strings.  The reference ALWAYS
+# builds the BERT tokenizer, the frozen text encoder and the LM text decoder (networks_detr.py:84-131), so under that driver an
+# unspecified `text_mode` means 'encoder+lm' with the vocabulary taken from LDETR_BERT_VOCAB; stand-alone the default stays 'features'
+# (text features are the hot path's boundary input).
+REFERENCE_DEFAULTS = False
+
+
+def _resolve_text_mode(text_mode, tokenizer):
+    if text_mode is not None:
+        return text_mode
+    if not REFERENCE_DEFAULTS:
+        return 'features'
+    if tokenizer is None:
+        raise RuntimeError("Generator / Discriminator built through the reference's module names (layoutdetr_amd.dropin) take strings as bbox_text "
+                           "and therefore need the BERT vocabulary: set LDETR_BERT_VOCAB=<path to bert-base-uncased vocab.txt> (or pass "
+                           "tokenizer_vocab=...), or pass text_mode='features' and feed TextFeatures")
+    return 'encoder+lm'
+
+
 def build_backbone():
     backbone = Backbone(name='resnet50', train_backbone=True, return_interm_layers=None, dilation=False)
     position_embedding = PositionEmbeddingSine(num_pos_feats=128, normalize=True)
@@ -233,14 +253,14 @@ class Generator(nn.Module):
     def __init__(self, z_dim, num_bbox_labels, img_channels, img_height, img_width, c_dim,
                  f_dim=256, num_heads=4, num_layers=8, hidden_dim=256,
                  med_config='configs/med_config.json', bert_f_dim=768, bert_num_encoder_layers=12, bert_num_decoder_layers=12,
-                 bert_num_heads=12, background_size=1024, im_f_dim=512, max_text_length=256, text_mode='features', tokenizer_vocab=None):
+                 bert_num_heads=12, background_size=1024, im_f_dim=512, max_text_length=256, text_mode=None, tokenizer_vocab=None):
         super().__init__()
         self.z_dim = z_dim
         self.tokenizer = _build_tokenizer(tokenizer_vocab)
         self.num_bbox_labels = num_bbox_labels
         self.c_dim = c_dim
         self.max_text_length = max_text_length
-        self.text_mode = text_mode
+        self.text_mode = text_mode = _resolve_text_mode(text_mode, self.tokenizer)
         self.static_shapes = False   # see module docstring: True = sync-free full-slot outputs (hipGraph-capturable)
         _check_background_size(background_size)
 
@@ -311,13 +331,13 @@ class Discriminator(nn.Module):
     def __init__(self, num_bbox_labels, img_channels, img_height, img_width, c_dim,
                  f_dim=256, num_heads=4, num_layers=8, max_bbox=50, hidden_dim=256,
                  med_config='configs/med_config.json', bert_f_dim=768, bert_num_encoder_layers=12, bert_num_decoder_layers=12,
-                 bert_num_heads=12, background_size=1024, im_f_dim=512, max_text_length=256, text_mode='features', tokenizer_vocab=None):
+                 bert_num_heads=12, background_size=1024, im_f_dim=512, max_text_length=256, text_mode=None, tokenizer_vocab=None):
         super().__init__()
         self.tokenizer = _build_tokenizer(tokenizer_vocab)
         self.num_bbox_labels = num_bbox_labels
         self.c_dim = c_dim
         self.max_text_length = max_text_length
-        self.text_mode = text_mode
+        self.text_mode = text_mode = _resolve_text_mode(text_mode, self.tokenizer)
         self.static_shapes = False
         _check_background_size(background_size)
 

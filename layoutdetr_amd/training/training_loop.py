@@ -116,6 +116,10 @@ class DataParallelStep(object):
         self.bucket = bucket_bytes // 4
         self.fuse = fuse_sanitize
         self.comm_stream = torch.cuda.Stream() if (world_size > 1 and torch.cuda.is_available()) else None
+        # diagnostics (bench.py at N > 1): with `record_exposed` set, every apply() brackets its wait for the communication stream with an
+        # event pair on the compute stream -> `exposed` holds (phase name, start, end): the time the compute stream stood still for RCCL
+        self.record_exposed = False
+        self.exposed = []
 
     def exchange(self, gflat):
         """In-place SUM all-reduce of the flat gradient in large buckets on a side stream (xGMI is point-to-point:
@@ -159,10 +163,17 @@ class DataParallelStep(object):
         """exchanged=True: the caller already reduced the gradient segment by segment (exchange_async); only join here."""
         fm = phase.fm
         core.join_side()   # weight-gradient launches of a backward that was not run through Loss.accumulate_gradients
+        ev = None
+        if self.record_exposed and self.world > 1 and self.comm_stream is not None:
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record()
         if exchanged:
             self.finish()
         else:
             self.exchange(fm.gflat)
+        if ev is not None:
+            ev[1].record()
+            self.exposed.append((phase.name, ev[0], ev[1]))
         phase.step += 1
         scale = 1.0 / self.world
         if fm.flat.device.type != 'cuda':
@@ -202,11 +213,204 @@ class EmaTracker(object):
                 self._buf_versions[i] = ver
 
 
+def _named_params_and_buffers(module):
+    return list(module.named_parameters()) + list(module.named_buffers())     # torch_utils/misc.py:154-156
+
+
+def _packed_by_dtype(tensors):
+    """{dtype: [tensor, ...]} in order of appearance (one collective per dtype instead of one per tensor: a Generator has ~640 tensors)."""
+    groups = {}
+    for t in tensors:
+        groups.setdefault(t.dtype, []).append(t)
+    return groups
+
+
 def broadcast_module(module, src=0):
-    """Initial parameter/buffer broadcast (training_loop.py:176-179) — one collective per flat buffer when available."""
+    """Initial parameter / buffer broadcast (training_loop.py:176-179: one `torch.distributed.broadcast` per tensor there).  Here the
+    tensors of one dtype travel as ONE flat buffer: pack -> broadcast -> unpack (xGMI is point-to-point: a 180 MB transfer beats 640
+    launches of a few KB).  Same result: every rank ends with rank `src`'s values, layouts untouched."""
     import torch.distributed as dist
-    for t in list(module.parameters()) + list(module.buffers()):
-        dist.broadcast(t.data, src=src)
+    tensors = [t.data for _, t in _named_params_and_buffers(module)]
+    for dtype, ts in _packed_by_dtype(tensors).items():
+        wire = torch.uint8 if dtype == torch.bool else dtype
+        flat = torch.cat([t.reshape(-1).to(wire) for t in ts]) if len(ts) > 1 else ts[0].reshape(-1).to(wire).clone()
+        dist.broadcast(flat, src=src)
+        off = 0
+        for t in ts:
+            n = t.numel()
+            t.copy_(flat[off:off + n].view(t.shape).to(dtype))
+            off += n
+
+
+def check_ddp_consistency(module, ignore_regex=None):
+    """torch_utils/misc.py:183-194 (called at snapshot time, training_loop.py:402-405): every parameter / buffer must equal rank 0's
+    (floats after nan_to_num).  One broadcast per dtype group instead of one per tensor; the failing tensor is named like the
+    reference's assert message (`ClassName.parameter.name`)."""
+    import re
+
+    import torch.distributed as dist
+    named = [(type(module).__name__ + '.' + n, t.detach()) for n, t in _named_params_and_buffers(module)]
+    named = [(n, t) for n, t in named if not (ignore_regex is not None and re.fullmatch(ignore_regex, n))]
+    by = {}
+    for n, t in named:
+        by.setdefault(t.dtype, []).append((n, t))
+    pairs = []
+    for dtype, items in by.items():        # every collective first: a rank that differs must not leave the others waiting in the next one
+        wire = torch.uint8 if dtype == torch.bool else dtype
+        mine = torch.cat([(torch.nan_to_num(t) if t.is_floating_point() else t).reshape(-1).to(wire) for _, t in items])
+        other = mine.clone()
+        dist.broadcast(other, src=0)
+        pairs.append((items, mine, other))
+    for items, mine, other in pairs:
+        if not torch.equal(mine, other):
+            off = 0
+            for n, t in items:
+                k = t.numel()
+                assert torch.equal(mine[off:off + k], other[off:off + k]), n
+                off += k
+
+
+class StatsCollector(object):
+    """The slice of torch_utils/training_stats.py the training loop uses: `report(name, value)` accumulates [count, sum, sum of
+    squares] per name on the device (float32 reduction of the reported elements into float64 counters, :91-107) and `update()` sums
+    the deltas ACROSS RANKS with one float64 all-reduce of the stacked [names, 3] matrix (:232-254), then exposes mean / std / num of
+    the interval since the previous update (`Collector.update`, :158-176).  Names must be reported in the same order on every rank
+    (same contract as the reference, :60-64)."""
+
+    def __init__(self, device=None, world=1):
+        self.device, self.world = device, world
+        self._counters = {}        # name -> float64 [3] on the device
+        self._cumulative = {}      # name -> float64 [3] on the host
+        self._moments = {}
+
+    def report(self, name, value):
+        elems = torch.as_tensor(value)
+        if elems.numel() == 0:
+            self._counters.setdefault(name, None)
+            return value
+        elems = elems.detach().flatten().to(torch.float32)
+        m = torch.stack([torch.ones_like(elems).sum(), elems.sum(), elems.square().sum()]).to(torch.float64)
+        c = self._counters.get(name)
+        self._counters[name] = m if c is None else c + m
+        return value
+
+    def update(self):
+        names = list(self._counters)
+        if not names:
+            return {}
+        dev = self.device if self.device is not None else torch.device('cpu')
+        deltas = torch.stack([(self._counters[n] if self._counters[n] is not None else torch.zeros(3, dtype=torch.float64)).to(dev) for n in names])
+        for n in names:
+            self._counters[n] = None
+        if self.world > 1:
+            import torch.distributed as dist
+            dist.all_reduce(deltas)
+        deltas = deltas.cpu()
+        self._moments = {}
+        for i, n in enumerate(names):
+            self._cumulative[n] = self._cumulative.get(n, torch.zeros(3, dtype=torch.float64)) + deltas[i]
+            self._moments[n] = deltas[i]
+        return self.as_dict()
+
+    def num(self, name):
+        return int(self._moments[name][0]) if name in self._moments else 0
+
+    def mean(self, name):
+        d = self._moments.get(name)
+        return float(d[1] / d[0]) if d is not None and int(d[0]) != 0 else float('nan')
+
+    def std(self, name):
+        d = self._moments.get(name)
+        if d is None or int(d[0]) == 0 or not np.isfinite(float(d[1])):
+            return float('nan')
+        if int(d[0]) == 1:
+            return 0.0
+        mean = float(d[1] / d[0])
+        return float(np.sqrt(max(float(d[2] / d[0]) - mean * mean, 0)))
+
+    def as_dict(self):
+        return {n: dict(num=self.num(n), mean=self.mean(n), std=self.std(n)) for n in self._moments}
+
+
+def copy_params_and_buffers(src_module, dst_module, require_all=False):
+    """torch_utils/misc.py:158-165 (resume path, training_loop.py:145-146): by NAME, layouts of the destination kept."""
+    src = dict(_named_params_and_buffers(src_module)) if isinstance(src_module, torch.nn.Module) else dict(src_module)
+    with torch.no_grad():
+        for name, tensor in _named_params_and_buffers(dst_module):
+            assert (name in src) or (not require_all), name
+            if name in src and tuple(src[name].shape) == tuple(tensor.shape):
+                tensor.copy_(src[name].detach().to(tensor.device))
+
+
+def load_pretrained_detr(modules, path='pretrained/up-detr-pre-training-60ep-imagenet.pth', verbose=True):
+    """training_loop.py:137-139: `module.load_state_dict(torch.load(path)['model'], strict=False)` for G, D and G_ema — the UP-DETR
+    checkpoint initialises the ResNet-50 trunk, `input_proj` and the DETR transformer (same key names here).  The reference
+    fails without the file; this path trains from the constructors' initialisation instead and says so (no network to fetch it here)."""
+    import os
+    path = os.environ.get('LDETR_PRETRAINED', path)
+    if not os.path.exists(path):
+        if verbose:
+            print(f'[layoutdetr_amd] {path} not found: G / D / G_ema keep their random initialisation (the reference loads it with strict=False)')
+        return False
+    sd = torch.load(path, map_location='cpu')
+    sd = sd['model'] if isinstance(sd, dict) and 'model' in sd else sd
+    for m in modules:
+        own = m.state_dict()
+        m.load_state_dict({k: v for k, v in sd.items() if k in own and tuple(own[k].shape) == tuple(v.shape)}, strict=False)
+    return True
+
+
+def save_snapshot(path, G, D, G_ema, training_set_kwargs, num_gpus=1, rank=0):
+    """training_loop.py:395-412: deep copies in eval mode without gradients, cross-rank consistency check (G_ema-style running
+    averages excepted) + broadcast from rank 0, moved to the host, pickled by rank 0 as dict(G, D, G_ema, augment_pipe, training_set_kwargs)."""
+    import pickle
+    data = dict(G=G, D=D, G_ema=G_ema, augment_pipe=None, training_set_kwargs=dict(training_set_kwargs))
+    for key in ('G', 'D', 'G_ema'):
+        value = _plain_copy(data[key])
+        if num_gpus > 1:
+            check_ddp_consistency(value, ignore_regex=r'.*\.[^.]+_(avg|ema)')
+            broadcast_module(value, src=0)
+        data[key] = value.cpu()
+    if rank == 0:
+        with open(path, 'wb') as f:
+            pickle.dump(data, f)
+    return data
+
+
+def _plain_copy(module):
+    """copy.deepcopy(module).eval().requires_grad_(False) whose parameters own their memory (the live module's are views into the flat
+    step buffers and carry flat .grad views: neither belongs in a snapshot)."""
+    grads = [(p, p.grad) for p in module.parameters()]
+    for p, _ in grads:
+        p.grad = None
+    try:
+        m = copy.deepcopy(module)
+    finally:
+        for p, g in grads:
+            p.grad = g
+    for p in m.parameters():
+        p.data = p.data.clone(memory_format=torch.preserve_format)
+        if hasattr(p, '_ldetr_flat'):
+            p._ldetr_flat = False
+    return m.eval().requires_grad_(False)
+
+
+def load_resume(resume_pkl, G, D, G_ema):
+    """training_loop.py:141-146: G / D / G_ema from a snapshot written by save_snapshot() (a pickle of dict(G=, D=, G_ema=) modules) or a
+    torch file holding state dicts under the same keys; parameters and buffers are copied by name (require_all=False)."""
+    import pickle
+    try:
+        with open(resume_pkl, 'rb') as f:
+            data = pickle.load(f)
+    except (pickle.UnpicklingError, ModuleNotFoundError, AttributeError) as e:
+        try:
+            data = torch.load(resume_pkl, map_location='cpu')
+        except Exception:
+            raise RuntimeError(f'resume_pkl={resume_pkl!r}: neither a snapshot of this package (save_snapshot) nor a torch file of state dicts; '
+                               f'pickles of the reference\'s own classes need the reference tree + its legacy loader ({e})')
+    for name, module in (('G', G), ('D', D), ('G_ema', G_ema)):
+        if name in data and data[name] is not None:
+            copy_params_and_buffers(data[name], module, require_all=False)
 
 
 def _trunk_body(module):
@@ -248,11 +452,13 @@ def staged_backward(loss, phase, dp, run_stage1, between=None, exchange=None, st
     return True
 
 
-def training_iteration(loss, phases, dp, batch, batch_gpu, gen_z_per_phase, ema=None, batch_size=None, ema_kimg=None, cur_nimg=0, overlap=None):
+def training_iteration(loss, phases, dp, batch, batch_gpu, gen_z_per_phase, ema=None, batch_size=None, ema_kimg=None, cur_nimg=0, overlap=None,
+                       gen_c_per_phase=None, ema_rampup=0.05):
     """One iteration = all phases (Gmain, Dmain) over the rank-local batch, as training_loop.py:274-328.
 
     batch: dict with bbox_real [b,9,4], bbox_class [b,9], bbox_text (TextFeatures), bbox_patch, padding_mask [b,9] bool,
-           background [b,3,R,R], real_c, gen_c.  gen_z_per_phase: list of [b,9,z_dim] tensors, one per phase.
+           background [b,3,R,R], real_c, gen_c.  gen_z_per_phase: list of [b,9,z_dim] tensors, one per phase; gen_c_per_phase: the same for the
+           generator's conditioning labels (training_loop.py:257-263 draws one set per phase); None = batch['gen_c'] for every phase.
     """
     b = batch['bbox_real'].shape[0]
     core.reseed(batch['bbox_real'].device)   # fresh device-side dropout seed word for this iteration
@@ -261,29 +467,33 @@ def training_iteration(loss, phases, dp, batch, batch_gpu, gen_z_per_phase, ema=
         overlap = dp.world > 1
     d_stages = None
     if iter_share:
-        if overlap and b <= batch_gpu:
+        # the trunk is cut into backward stages only if the Dmain phase will run them (a recorded cut that is never run() would leave D's
+        # trunk without gradient while its flat segment is still reduced and applied)
+        d_phase = next(p for p in phases if p.name == 'Dmain')
+        if overlap and b <= batch_gpu and d_phase.fm.stage_segments() is not None and hasattr(_trunk_body(d_phase.module), 'stages'):
             from .detr_backbone import BackwardStages
             d_stages = BackwardStages()
         for s in range(0, b, batch_gpu):
             loss.precompute_D_trunk(batch['background'][s:s + batch_gpu], stages=d_stages)
-    for phase, gen_z in zip(phases, gen_z_per_phase):
+    for pi, (phase, gen_z) in enumerate(zip(phases, gen_z_per_phase)):
         phase.fm.zero_grad()
         phase.module.requires_grad_(True)
         phase.module.text_encoder.requires_grad_(False)
+        gen_c = batch['gen_c'] if gen_c_per_phase is None else gen_c_per_phase[pi]
 
-        def accumulate(phase=phase, gen_z=gen_z):
+        def accumulate(phase=phase, gen_z=gen_z, gen_c=gen_c):
             for s in range(0, b, batch_gpu):
                 sl = slice(s, s + batch_gpu)
                 loss.accumulate_gradients(phase=phase.name, bbox_real=batch['bbox_real'][sl], bbox_class=batch['bbox_class'][sl],
                                           bbox_text=batch['bbox_text'][sl], bbox_patch=batch['bbox_patch'][sl],
                                           padding_mask=batch['padding_mask'][sl], background=batch['background'][sl],
-                                          real_c=batch['real_c'][sl], gen_z=gen_z[sl], gen_c=batch['gen_c'][sl], gain=1, cur_nimg=cur_nimg)
+                                          real_c=batch['real_c'][sl], gen_z=gen_z[sl], gen_c=gen_c[sl], gain=1, cur_nimg=cur_nimg)
         staged = overlap and b <= batch_gpu
         exchanged = staged_backward(loss, phase, dp, accumulate, stages=(d_stages if (iter_share and phase.name == 'Dmain') else None)) if staged else (accumulate() or False)
         phase.module.requires_grad_(False)
         dp.apply(phase, exchanged=True) if exchanged else dp.apply(phase)
     if ema is not None:
-        ema.update(batch_size, ema_kimg, cur_nimg)
+        ema.update(batch_size, ema_kimg, cur_nimg, ema_rampup=ema_rampup)
 
 
 class GraphedIteration(object):
@@ -318,7 +528,8 @@ class GraphedIteration(object):
         if iter_share:
             # D's trunk forward gets its own graph, replayed before the phases; its activations stay alive in the shared pool until
             # the Dmain graph (captured below, replayed after it) runs the trunk's backward
-            if overlap and b <= batch_gpu:
+            d_phase = next(p for p in phases if p.name == 'Dmain')
+            if overlap and b <= batch_gpu and d_phase.fm.stage_segments() is not None and hasattr(_trunk_body(d_phase.module), 'stages'):
                 from .detr_backbone import BackwardStages
                 d_stages = BackwardStages()
             self.pre_graph = torch.cuda.CUDAGraph()
@@ -436,10 +647,16 @@ def training_loop(run_dir='.', training_set_kwargs={}, validation_set_kwargs={},
     unchanged (through layoutdetr_amd.dropin.install() or by importing it).  What it runs: dataset + DataLoader + InfiniteSampler
     exactly as :112-118, networks / loss by class name (:127-135,158), then per iteration the flat-parameter step of this module
     (phases Gmain / Dmain; the reg phases are no-ops at r1_gamma = pl_weight = 0, which is all `train.py` configures: :135-136).
-    Out of this path's scope and therefore NOT done here (a note is printed): augment pipe, ADA, image / network snapshots, metric
-    evaluation, tensorboard — SURVEY §8 marks them outside the hot path.  Returns dict(stats of the last tick, G, D, G_ema)."""
+    Also as the reference: the UP-DETR checkpoint into G / D / G_ema when `pretrained/up-detr-pre-training-60ep-imagenet.pth` exists
+    (:137-139), `resume_pkl` (:140-146), one flat broadcast per module (:176-179), per-phase latents AND conditioning labels (:257-263),
+    `ema_rampup` (:321-323), per-tick statistics summed over ranks in float64 + `stats.jsonl` (:428-447), network snapshots with the
+    cross-rank consistency check (:395-412).  NOT done here (a note is printed): augment pipe, ADA, image snapshots, metric evaluation,
+    tensorboard — SURVEY §8 marks them outside the hot path.  Returns dict(stats of the last tick, G, D, G_ema, snapshot_pkl)."""
+    import json
+    import os
     import time
     assert augment_kwargs is None and ada_target is None, 'the augment pipe / ADA are not part of the hot path'
+    start_time = time.time()
     device = torch.device('cuda', rank)
     torch.cuda.set_device(device)
     np.random.seed(random_seed * num_gpus + rank)
@@ -455,16 +672,19 @@ def training_loop(run_dir='.', training_set_kwargs={}, validation_set_kwargs={},
         print('Constructing networks...')
     G = construct_class_by_name(**G_kwargs, **common).train().requires_grad_(False).to(device)
     D = construct_class_by_name(**D_kwargs, **common).train().requires_grad_(False).to(device)
-    if num_gpus > 1:
-        for module in (G, D):
-            broadcast_module(module, src=0)          # :176-179
     G_ema = copy.deepcopy(G).eval()
-    stats = {}
-
-    def report(name, value):
-        stats.setdefault(name, []).append(value.detach().float().mean())
+    load_pretrained_detr((G, D, G_ema), verbose=(rank == 0))          # :137-139
+    if resume_pkl is not None and rank == 0:                          # :140-146 (rank 0 loads; the broadcast below distributes)
+        print(f'Resuming from "{resume_pkl}"')
+        load_resume(resume_pkl, G, D, G_ema)
+    if num_gpus > 1:
+        if rank == 0:
+            print(f'Distributing across {num_gpus} GPUs...')
+        for module in (G, D, G_ema):
+            broadcast_module(module, src=0)          # :176-179
+    collector = StatsCollector(device=device, world=num_gpus)         # training_stats.init_multiprocessing + Collector (:111, :204-206)
     lk = dict(loss_kwargs)
-    loss = construct_class_by_name(device=device, G=G, D=D, augment_pipe=None, report_fn=report, **lk)
+    loss = construct_class_by_name(device=device, G=G, D=D, augment_pipe=None, report_fn=collector.report, **lk)
     phases = []
     for name, module, opt, reg in (('G', G, G_opt_kwargs, G_reg_interval), ('D', D, D_opt_kwargs, D_reg_interval)):
         opt = dict(opt)
@@ -474,12 +694,15 @@ def training_loop(run_dir='.', training_set_kwargs={}, validation_set_kwargs={},
     dp = DataParallelStep(world_size=num_gpus)
     ema = EmaTracker(phases[0], G_ema)
     if rank == 0:
-        print('Not run on this path: augment pipe, ADA, image/network snapshots, metrics (outside the hot path)')
+        print('Not run on this path: augment pipe, ADA, image snapshots, metrics (outside the hot path)')
         print(f'Training for {total_kimg} kimg...')
     cur_nimg, cur_tick, tick_start_nimg, tick_start = resume_kimg * 1000, 0, resume_kimg * 1000, time.time()
     if progress_fn is not None:
         progress_fn(0, total_kimg)
     last = {}
+    stats_jsonl = open(os.path.join(run_dir, 'stats.jsonl'), 'wt') if (rank == 0 and run_dir and os.path.isdir(run_dir)) else None     # :200-202
+    snapshot_pkl = None
+    labelled = training_set.label_dim > 0 and hasattr(training_set, 'get_label')
     while True:
         samples, real_c = next(it)
         texts = list(map(list, zip(*samples['texts']))) if isinstance(samples.get('texts'), (list, tuple)) else samples['texts']   # :246
@@ -490,31 +713,44 @@ def training_loop(run_dir='.', training_set_kwargs={}, validation_set_kwargs={},
         batch = dict(bbox_real=samples['bboxes'].to(device).float(), bbox_class=samples['labels'].to(device).long(), bbox_text=texts,
                      bbox_patch=samples['patches'].to(device), padding_mask=~samples['mask'].to(device).bool(),
                      background=samples['background'].to(device).float(), real_c=real_c.to(device))
-        if batch['real_c'].shape[1] > 0 and hasattr(training_set, 'get_label'):      # training_loop.py:257-259: labels of random dataset items
-            gen_c = np.stack([training_set.get_label(np.random.randint(len(training_set))) for _ in range(b)])
-            batch['gen_c'] = torch.from_numpy(gen_c).to(device)
-        else:
-            batch['gen_c'] = torch.zeros_like(batch['real_c'])
+        # :257-263: one set of latents AND one set of conditioning labels (labels of random dataset items) PER PHASE
         gen_z = [torch.randn(b, batch['bbox_class'].shape[1], G.z_dim, device=device) for _ in phases]
-        training_iteration(loss, phases, dp, batch, batch_gpu, gen_z, ema=ema, batch_size=batch_size, ema_kimg=ema_kimg, cur_nimg=cur_nimg)
+        if labelled:
+            gen_c = [torch.from_numpy(np.stack([training_set.get_label(np.random.randint(len(training_set))) for _ in range(b)])).to(device) for _ in phases]
+        else:
+            gen_c = [torch.zeros_like(batch['real_c']) for _ in phases]
+        batch['gen_c'] = gen_c[0]
+        training_iteration(loss, phases, dp, batch, batch_gpu, gen_z, ema=ema, batch_size=batch_size, ema_kimg=ema_kimg, cur_nimg=cur_nimg,
+                           gen_c_per_phase=gen_c, ema_rampup=ema_rampup)
         cur_nimg += batch_size
         done = cur_nimg >= total_kimg * 1000
         if not done and cur_tick != 0 and cur_nimg < tick_start_nimg + kimg_per_tick * 1000:
             continue
         torch.cuda.synchronize()
         now = time.time()
-        last = {k: torch.stack(v).mean().item() for k, v in stats.items()}
-        stats.clear()
+        # :428-447: per-tick statistics, summed over ranks in float64 (one all-reduce), jsonl line by rank 0
+        tick_stats = collector.update()
+        last = {k: v['mean'] for k, v in tick_stats.items()}
         if rank == 0:
             print(f'tick {cur_tick:<5d} kimg {cur_nimg / 1e3:<8.1f} sec/kimg {(now - tick_start) / max(cur_nimg - tick_start_nimg, 1) * 1e3:<7.2f} ' +
                   ' '.join(f'{k.split("/")[-1]} {v:.3f}' for k, v in sorted(last.items()) if k.startswith('Loss/scores')))
+            if stats_jsonl is not None:
+                stats_jsonl.write(json.dumps(dict(tick_stats, timestamp=time.time(), **{'Progress/kimg': dict(num=1, mean=cur_nimg / 1e3, std=0.0)})) + '\n')
+                stats_jsonl.flush()
         if abort_fn is not None and abort_fn():
             done = True
+        # :395-412: network snapshot (every `network_snapshot_ticks` ticks and at the end), consistency-checked across ranks
+        if network_snapshot_ticks is not None and (done or cur_tick % network_snapshot_ticks == 0) and run_dir and os.path.isdir(run_dir):
+            snapshot_pkl = os.path.join(run_dir, f'network-snapshot-{cur_nimg // 1000:06d}.pkl')
+            save_snapshot(snapshot_pkl, G, D, G_ema, training_set_kwargs, num_gpus=num_gpus, rank=rank)
         cur_tick += 1
         tick_start_nimg, tick_start = cur_nimg, time.time()
         if progress_fn is not None:
             progress_fn(cur_nimg // 1000, total_kimg)
         if done:
             break
+    if stats_jsonl is not None:
+        stats_jsonl.close()
     last['cur_nimg'] = cur_nimg
-    return dict(stats=last, G=G, D=D, G_ema=G_ema)
+    last['total_sec'] = time.time() - start_time
+    return dict(stats=last, G=G, D=D, G_ema=G_ema, snapshot_pkl=snapshot_pkl, stats_detail=tick_stats)

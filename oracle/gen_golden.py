@@ -618,13 +618,86 @@ def gen_composition():
     save('composition', d)
 
 
+def gen_config0():
+    """BASELINE.json configs[0]: ONE sample, 128x128 background (stride 32 -> 4x4 = 16 memory tokens), 3 text boxes valid of the 9 slots,
+    the reference's own `Generator.forward` (networks_detr.py:133-187) on CPU, reconst off and on.  Same stand-ins as gen_composition
+    (ResNet body = the seeded feature map, tokenizer / text encoder table, LM decoder zero loss); weights and inputs from oracle/seeded.py."""
+    from oracle import seeded
+    nd = _import_ref_networks()
+    B, bg, seed, nvalid = 1, 128, 23, 3
+    inp = seeded.comp_inputs(B, bg, seed)
+    pm = torch.ones(B, 9, dtype=torch.bool); pm[:, :nvalid] = False
+    G, _ = _ref_G_D(nd, bg, inp['feats_g'], inp['feats_d'])
+    skip = ('backbone.0.body.', 'text_encoder.', 'text_decoder.')
+    G.load_state_dict(seeded.seeded_state_dict(G, 1, skip))
+    d = {'B': np.asarray(B), 'bg': np.asarray(bg), 'seed': np.asarray(seed), 'nvalid': np.asarray(nvalid)}
+    patch = torch.zeros(B, 9, 1, 1, 1); c = torch.zeros(B, 0)
+    tok = G.tokenizer(sum(inp['texts'], []))
+    d['text_feat'] = G.text_encoder(tok.input_ids, tok.attention_mask).last_hidden_state[:, 0, :].view(B, 9, -1)
+    d['text_len'] = torch.tensor([len(t) for t in sum(inp['texts'], [])]).view(B, 9)
+    with torch.no_grad():
+        d['G/bbox_fake_noreconst'] = G(inp['z_g'], inp['bbox_class'], inp['bbox_real'], inp['texts'], patch, pm, inp['background'], c)
+        out = G(inp['z_g'], inp['bbox_class'], inp['bbox_real'], inp['texts'], patch, pm, inp['background'], c, True)
+        for k, v in zip(('bbox_fake', 'loss_z', 'logit_cls', 'loss_lm', 'loss_text_len'), out):
+            d['G/' + k] = v
+    assert d['G/logit_cls'].shape[0] == nvalid
+    save('config0', d)
+
+
+def gen_box_ops():
+    """north_star row ns-1: the reference's own detr_util/box_ops.py (box_cxcywh_to_xyxy :19-23, box_iou :35-48, generalized_box_iou
+    :51-71; torchvision.ops.boxes.box_area is the two-line area formula, stubbed above) on batches of layouts, and the Hungarian
+    assignment the DETR matcher derives from it: scipy.optimize.linear_sum_assignment on cost = -GIoU (ties: duplicated boxes,
+    prediction == target, quantised coordinates; a zero-area target)."""
+    from scipy.optimize import linear_sum_assignment
+    from detr_util import box_ops
+    g = torch.Generator().manual_seed(77)
+    d = {}
+    idx = 0
+    for n in (9, 9, 9, 9, 9, 9, 16, 3, 1):
+        pred = torch.cat([torch.rand(n, 2, generator=g) * 0.6 + 0.2, torch.rand(n, 2, generator=g) * 0.35 + 0.05], -1)
+        tgt = torch.cat([torch.rand(n, 2, generator=g) * 0.6 + 0.2, torch.rand(n, 2, generator=g) * 0.35 + 0.05], -1)
+        if idx == 1:
+            tgt = pred.clone()                               # identical layouts
+        if idx == 2 and n > 4:
+            tgt[3] = tgt[1]; pred[5] = pred[2]; pred[6] = pred[2]    # duplicated boxes -> tied rows / columns
+        if idx == 3:
+            pred = (pred * 8).round() / 8; tgt = (tgt * 8).round() / 8; pred[:, 2:].clamp_(min=0.125); tgt[:, 2:].clamp_(min=0.125)   # quantised
+        if idx == 4:
+            tgt[2, 2:] = 0.0                                 # zero-area target box (union > 0 against every prediction)
+        if idx == 5:
+            pred[:] = pred[0]                                # constant rows
+        p_xyxy, t_xyxy = box_ops.box_cxcywh_to_xyxy(pred), box_ops.box_cxcywh_to_xyxy(tgt)
+        iou, union = box_ops.box_iou(p_xyxy, t_xyxy)
+        giou = box_ops.generalized_box_iou(p_xyxy, t_xyxy)
+        cost = (-giou).double().numpy()
+        r, c = linear_sum_assignment(cost)
+        for k, v in (('pred', pred), ('tgt', tgt), ('p_xyxy', p_xyxy), ('iou', iou), ('union', union), ('giou', giou)):
+            d[f'{k}{idx}'] = v
+        d[f'back{idx}'] = box_ops.box_xyxy_to_cxcywh(p_xyxy)
+        d[f'row{idx}'] = r; d[f'col{idx}'] = c
+        idx += 1
+    # rectangular pairwise matrices (N != M)
+    a = torch.cat([torch.rand(5, 2, generator=g) * 0.5, torch.rand(5, 2, generator=g) * 0.4 + 0.5], -1)
+    b = torch.cat([torch.rand(9, 2, generator=g) * 0.5, torch.rand(9, 2, generator=g) * 0.4 + 0.5], -1)
+    d['rect_a'] = a; d['rect_b'] = b
+    d['rect_iou'], d['rect_union'] = box_ops.box_iou(a, b)
+    d['rect_giou'] = box_ops.generalized_box_iou(a, b)
+    d['count'] = np.asarray(idx)
+    save('box_ops', d)
+
+
 if __name__ == '__main__':
     sys.path.insert(0, REF)
     sys.path.insert(1, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))   # `oracle.seeded` (the reference has no `oracle` package)
     _stub_modules()
     torch.set_num_threads(8)
     if '--only-composition' in sys.argv:
-        gen_composition(); sys.exit(0)
+        gen_composition(); gen_config0(); sys.exit(0)
+    if '--only-config0' in sys.argv:
+        gen_config0(); sys.exit(0)
+    if '--only-box-ops' in sys.argv:
+        gen_box_ops(); sys.exit(0)
     if '--only-metrics' in sys.argv:
         gen_metrics(); sys.exit(0)
     if '--only-resample' in sys.argv:
@@ -633,4 +706,4 @@ if __name__ == '__main__':
         gen_bert(); gen_bert_lm(); sys.exit(0)
     if '--skip-done' not in sys.argv:
         gen_ops(); gen_transformer()
-    gen_losses(); gen_decoder(); gen_frozen_bn(); gen_lsap(); gen_dp_step(); gen_metrics(); gen_bert(); gen_bert_lm(); gen_resample(); gen_composition()
+    gen_losses(); gen_decoder(); gen_frozen_bn(); gen_lsap(); gen_dp_step(); gen_metrics(); gen_bert(); gen_bert_lm(); gen_resample(); gen_composition(); gen_config0(); gen_box_ops()

@@ -120,16 +120,81 @@ class SyntheticLayouts(torch.utils.data.Dataset):
                     background=torch.randn(3, 64, 64, generator=g).numpy()), np.zeros((0,), np.float32)
 
 
-def test_training_loop_entry_runs_like_train_py_drives_it(dev, tmp_path):
-    """training_loop(**c) with the reference's keyword arguments (train.py:47,197-283): networks and loss by class name THROUGH THE
-    REFERENCE'S MODULE NAMES (dropin.install()), a dataset object, strings as bbox_text (host WordPiece tokenizer from a local vocab)."""
+@pytest.fixture
+def reference_names():
+    """dropin.install() for the duration of one test (it also switches the constructors to the reference's defaults: process-wide)."""
     from layoutdetr_amd import dropin
     dropin.install()
-    import importlib
-    tl = importlib.import_module('training.training_loop')
+    try:
+        yield dropin
+    finally:
+        dropin.uninstall()
+
+
+def _write_vocab(tmp_path):
     vocab = ['[PAD]', '[unused0]', '[UNK]', '[CLS]', '[SEP]', '[MASK]'] + sorted({w for s in SyntheticLayouts().words for w in s.replace('%', ' % ').replace('!', ' !').split()})
     vf = tmp_path / 'vocab.txt'
     vf.write_text('\n'.join(vocab) + '\n')
+    return vf
+
+
+def test_training_loop_with_train_py_own_kwargs(dev, tmp_path, reference_names, monkeypatch):
+    """What `python -m layoutdetr_amd.dropin train.py ...` does: G_kwargs / D_kwargs EXACTLY as train.py builds them (class_name + the
+    option-derived fields of train.py:250-261 — no text_mode, no tokenizer_vocab), strings from the loader.  Through the reference's
+    module names the constructors default to what the reference always builds (tokenizer from LDETR_BERT_VOCAB, frozen text encoder, LM
+    text decoder); a missing vocabulary fails at construction with a message, not at the first iteration.  Also exercised: resume_pkl
+    (a snapshot of a previous run), ema_rampup=None, the final network snapshot, stats.jsonl."""
+    import importlib
+    import json
+    import pickle
+    tl = importlib.import_module('training.training_loop')
+    nd = importlib.import_module('training.networks_detr')
+    common = dict(num_bbox_labels=8, img_channels=3, img_height=64, img_width=64, background_size=64, c_dim=0)
+    train_py = dict(f_dim=256, num_heads=4, num_layers=8, bert_f_dim=768, bert_num_heads=4, bert_num_encoder_layers=2, bert_num_decoder_layers=2, im_f_dim=512)
+    monkeypatch.delenv('LDETR_BERT_VOCAB', raising=False)
+    with pytest.raises(RuntimeError, match='LDETR_BERT_VOCAB'):
+        nd.Generator(z_dim=4, **train_py, **common)
+    monkeypatch.setenv('LDETR_BERT_VOCAB', str(_write_vocab(tmp_path)))
+    G = nd.Generator(z_dim=4, **train_py, **common)
+    assert G.text_mode == 'encoder+lm' and G.text_decoder is not None and G.tokenizer is not None
+    del G
+    run1, run2 = tmp_path / 'run1', tmp_path / 'run2'
+    run1.mkdir(); run2.mkdir()
+    kw = dict(training_set_kwargs=dict(class_name='test_boundary_gpu.SyntheticLayouts', n=8), data_loader_kwargs=dict(num_workers=0), random_seed=0,
+              num_gpus=1, rank=0, batch_size=4, batch_gpu=4,
+              G_kwargs=dict(class_name='training.networks_detr.Generator', z_dim=4, **train_py), D_kwargs=dict(class_name='training.networks_detr.Discriminator', **train_py),
+              G_opt_kwargs=dict(class_name='torch.optim.Adam', betas=[0, 0.99], eps=1e-8, lr=1e-5), D_opt_kwargs=dict(class_name='torch.optim.Adam', betas=[0, 0.99], eps=1e-8, lr=1e-5),
+              loss_kwargs=dict(class_name='training.loss.StyleGAN2Loss', r1_gamma=0.0, pl_weight=0.0), G_reg_interval=4, D_reg_interval=16,
+              ema_kimg=4 * 10 / 32, total_kimg=0.008, kimg_per_tick=0.004, network_snapshot_ticks=50)
+    out = tl.training_loop(run_dir=str(run1), **kw)
+    assert out['stats']['cur_nimg'] == 8 and out['snapshot_pkl'] and os.path.exists(out['snapshot_pkl'])
+    assert np.isfinite(out['stats']['Loss/G/loss_Ggen_text_rec']) and out['stats']['Loss/G/loss_Ggen_text_rec'] > 0, 'the LM text decoder did not run'
+    lines = [json.loads(l) for l in open(run1 / 'stats.jsonl')]
+    assert len(lines) >= 2 and lines[-1]['Loss/scores/fake']['num'] > 0 and 'std' in lines[-1]['Loss/scores/real']
+    with open(out['snapshot_pkl'], 'rb') as f:
+        snap = pickle.load(f)
+    assert set(snap) >= {'G', 'D', 'G_ema', 'training_set_kwargs'} and not any(p.requires_grad for p in snap['G_ema'].parameters())
+    assert all(p.device.type == 'cpu' for p in snap['D'].parameters())
+    for (n, a), (_, b) in zip(snap['G'].named_parameters(), out['G'].named_parameters()):
+        assert torch.equal(a, b.detach().cpu()), n
+    # resume: the second run starts from the first run's weights (rank 0 loads, parameters and buffers copied by name)
+    out2 = tl.training_loop(run_dir=str(run2), resume_pkl=out['snapshot_pkl'], resume_kimg=0, ema_rampup=None, **dict(kw, total_kimg=0.004))
+    w1 = dict(snap['D'].named_parameters())['enc_fc_in.layers.0.weight']
+    w2 = dict(out2['D'].named_parameters())['enc_fc_in.layers.0.weight'].detach().cpu()
+    assert (w1 - w2).abs().max() < 1e-3 and not torch.equal(w1, w2), 'run 2 did not start from the snapshot (or did not train)'
+    # ema_rampup=None: beta = 0.5 ** (batch / (ema_kimg * 1000)) = 0.5 ** (4 / 1250), so G_ema stays within (1 - beta) of the snapshot's G_ema
+    e1 = dict(snap['G_ema'].named_parameters())['fc_in.layers.0.weight']; e2 = dict(out2['G_ema'].named_parameters())['fc_in.layers.0.weight'].detach().cpu()
+    g2 = dict(out2['G'].named_parameters())['fc_in.layers.0.weight'].detach().cpu()
+    beta = 0.5 ** (4 / 1250.0)
+    assert torch.allclose(e2, g2.lerp(e1, beta), atol=1e-6), 'ema_rampup=None was not honoured'
+
+
+def test_training_loop_entry_runs_like_train_py_drives_it(dev, tmp_path, reference_names):
+    """training_loop(**c) with the reference's keyword arguments (train.py:47,197-283): networks and loss by class name THROUGH THE
+    REFERENCE'S MODULE NAMES (dropin.install()), a dataset object, strings as bbox_text (host WordPiece tokenizer from a local vocab)."""
+    import importlib
+    tl = importlib.import_module('training.training_loop')
+    vf = _write_vocab(tmp_path)
     net = dict(bert_f_dim=768, bert_num_heads=4, bert_num_encoder_layers=2, bert_num_decoder_layers=2, im_f_dim=512, text_mode='encoder', tokenizer_vocab=str(vf))
     seen = []
     out = tl.training_loop(

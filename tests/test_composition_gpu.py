@@ -94,6 +94,51 @@ def test_forward_tuples_vs_reference_fixture(dev):
         check(out[7][(~pm).to(dev)], d['D/bbox_pred_uncond'], 5e-5, 'static bbox_pred_uncond')
 
 
+def test_configs0_generator_forward_b1_128_3boxes(dev):
+    """BASELINE.json configs[0]: ONE sample, 128x128 background (4x4 = 16 memory tokens), 3 valid text boxes of the 9 slots.
+    (a) the HIP Generator against the reference's own Generator.forward (tests/golden/config0.npz, oracle/gen_golden.py:gen_config0; the
+    ResNet body is the fixture's feature map), reconst off / on, gather-shaped and static-shape heads; (b) the same workload with the
+    real ResNet-50 trunk on the HIP kernels against the CPU oracle (which test_oracle_golden pins to the same fixture)."""
+    from layoutdetr_amd.training.networks_detr import TextFeatures
+    from oracle import networks_ref, seeded
+    d = load('config0')
+    B, bg, seed, nv = int(d['B']), int(d['bg']), int(d['seed']), int(d['nvalid'])
+    assert (B, bg, nv) == (1, 128, 3)
+    inp = seeded.comp_inputs(B, bg, seed)
+    pm = torch.ones(B, 9, dtype=torch.bool); pm[:, :nv] = False
+    G, _ = build(dev, bg, inp)
+    t = {k: v.to(dev) for k, v in inp.items() if isinstance(v, torch.Tensor)}
+    tf = TextFeatures(d['text_feat'].to(dev), d['text_len'].to(dev))
+    patch = torch.zeros(B, 9, 1, 1, 1, device=dev)
+    pmd = pm.to(dev)
+    with torch.no_grad():
+        worst = check(G(t['z_g'], t['bbox_class'], t['bbox_real'], tf, patch, pmd, t['background'], None), d['G/bbox_fake_noreconst'], 2e-5, 'bbox_fake')
+        out = G(t['z_g'], t['bbox_class'], t['bbox_real'], tf, patch, pmd, t['background'], None, True)
+        for k, v in zip(('bbox_fake', 'loss_z', 'logit_cls', 'loss_lm', 'loss_text_len'), out):
+            worst = max(worst, check(v, d['G/' + k], 2e-5, 'G ' + k))
+        assert out[2].shape[0] == nv
+        G.static_shapes = True
+        out = G(t['z_g'], t['bbox_class'], t['bbox_real'], tf, patch, pmd, t['background'], None, True)
+        worst = max(worst, check(out[1], d['G/loss_z'], 2e-5, 'static loss_z'), check(out[4], d['G/loss_text_len'], 2e-5, 'static loss_text_len'),
+                    check(out[2][(~pm).to(dev)], d['G/logit_cls'], 2e-5, 'static logit_cls'), check(out[0], d['G/bbox_fake'], 2e-5, 'static bbox_fake'))
+    # (b) real trunk
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    G2, _ = make_modules(bg, seed=71)
+    bt, zg, _ = make_batch(B, bg, seed=72, ragged=False)
+    bt['padding_mask'] = pm.clone()
+    Gsd = {k: v.clone() for k, v in G2.state_dict().items()}
+    with torch.no_grad():
+        ref = networks_ref.generator(Gsd, zg, bt['bbox_class'], bt['text_feat'], bt['text_len'], pm, bt['background'], reconst=True)
+    G2.eval().requires_grad_(False).to(dev)
+    tf2 = TextFeatures(bt['text_feat'].to(dev), bt['text_len'].to(dev))
+    with torch.no_grad():
+        out = G2(zg.to(dev), bt['bbox_class'].to(dev), bt['bbox_real'].to(dev), tf2, patch, pmd, bt['background'].to(dev), None, True)
+    w2 = check(out[0][(~pm).to(dev)], ref[0][~pm], 1e-3, 'bbox_fake (ResNet trunk)')
+    for i, nm in [(1, 'loss_z'), (2, 'logit_cls'), (4, 'loss_text_len')]:
+        w2 = max(w2, check(out[i], ref[i], 1e-3, 'G ' + nm))
+    print(f'[configs0 B=1 128 3 boxes] vs reference fixture {worst:.2e}; with the ResNet trunk vs oracle {w2:.2e}')
+
+
 def digest_errors(g, d, phase, name):
     from oracle import seeded
     st, sb = seeded.grad_digest(g.detach().cpu())
@@ -198,7 +243,38 @@ def cast_sd(sd, dt):
     return {k: (v.to(dt) if v.dtype.is_floating_point else v.clone()) for k, v in sd.items()}
 
 
-def _full_iteration_vs_oracle(dev, bg, B, seed, tag, text_on=False, flip_tolerant=False):
+def _kernel_family(name, shape):
+    """Which kernel path produces this parameter's gradient (the grouping of the flip-free gate in _full_iteration_vs_oracle)."""
+    leaf = name.rsplit('.', 1)[-1]
+    if 'text_decoder' in name:
+        return 'lm:' + ('ln' if 'LayerNorm' in name else ('emb' if 'embeddings' in name else leaf + str(len(shape))))
+    if 'bg_decoder' in name:
+        if 'affine' in name:
+            return 'sg:affine.' + leaf
+        if 'torgb' in name:
+            return 'sg:torgb.' + leaf
+        if leaf == 'weight' and len(shape) == 4:
+            return 'sg:modconv_up' if '.conv0.' in name else 'sg:modconv'
+        return 'sg:' + leaf + str(len(shape))
+    if 'backbone' in name:
+        if len(shape) == 4:
+            tag = f'{shape[2]}x{shape[3]}'
+            return 'resnet:conv' + tag + ('_ds' if 'downsample' in name else '')
+        return 'resnet:' + leaf
+    if 'in_proj_weight' in name:
+        return 'attn:in_proj_weight'
+    if 'in_proj_bias' in name:
+        return 'attn:in_proj_bias'
+    if 'norm' in name.lower():
+        return 'ln:' + leaf
+    if len(shape) == 2:
+        return 'linear:weight' + ('_ffn' if 'linear1' in name or 'linear2' in name else '')
+    if len(shape) == 1:
+        return 'linear:bias'
+    return 'other'
+
+
+def _full_iteration_vs_oracle(dev, bg, B, seed, tag, text_on=False, flip_tolerant=False, lm_on=False):
     """One Gmain + Dmain iteration through the flat-parameter step against the CPU oracle in fp32 and fp64 (see the callers)."""
     from layoutdetr_amd.training import training_loop as tl
     from layoutdetr_amd.training.loss import StyleGAN2Loss
@@ -206,7 +282,8 @@ def _full_iteration_vs_oracle(dev, bg, B, seed, tag, text_on=False, flip_toleran
     from oracle import bert_ref, step_ref
     torch.set_num_threads(min(16, os.cpu_count() or 1))
     if text_on:
-        G, D = make_modules(bg, seed=seed, text_mode='encoder', bert_num_encoder_layers=12, bert_num_heads=4)
+        G, D = make_modules(bg, seed=seed, text_mode='encoder+lm' if lm_on else 'encoder', bert_num_encoder_layers=12, bert_num_heads=4,
+                            **(dict(bert_num_decoder_layers=2) if lm_on else {}))
         for n, p in G.text_encoder.named_parameters():
             p.data.normal_(0, 0.03)
             if 'LayerNorm.weight' in n:
@@ -227,7 +304,8 @@ def _full_iteration_vs_oracle(dev, bg, B, seed, tag, text_on=False, flip_toleran
             bt['text_feat'] = bert_ref.bert_text_forward(enc, 4, ids.reshape(B * 9, T), am.reshape(B * 9, T))[:, 0].reshape(B, 9, -1)
             feat64 = bert_ref.bert_text_forward(cast_sd(enc, torch.float64), 4, ids.reshape(B * 9, T), am.reshape(B * 9, T))[:, 0].reshape(B, 9, -1)
         toks = TextTokens(ids.to(dev), am.to(dev), bt['text_len'].to(dev))
-    trainable = lambda m: {n for n, _ in m.named_parameters() if not n.startswith('text_encoder.')}      # noqa: E731  (the text encoder is frozen)
+    # (the text encoder is frozen; the LM text decoder is trainable but outside the oracle's G / D: its loss and gradients are added below)
+    trainable = lambda m: {n for n, _ in m.named_parameters() if not n.startswith(('text_encoder.', 'text_decoder.'))}      # noqa: E731
     names = dict(G_param_names=trainable(G), D_param_names=trainable(D))
     o32 = step_ref.training_iteration(Gsd, Dsd, bt, zg, zd, bg_size=bg, apply_adam=False, **names)
     bt64 = {k: (v.double() if v.dtype.is_floating_point else v) for k, v in bt.items()}
@@ -235,6 +313,22 @@ def _full_iteration_vs_oracle(dev, bg, B, seed, tag, text_on=False, flip_toleran
         bt64['text_feat'] = feat64
     o64 = step_ref.training_iteration(cast_sd(Gsd, torch.float64), cast_sd(Dsd, torch.float64), bt64, zg.double(), zd.double(), bg_size=bg,
                                       apply_adam=False, **names)
+    if lm_on:
+        # The LM text decoder runs in mode='text' (no cross-attention, networks_detr.py:169-181 / 328-340): its loss depends on the token
+        # ids and its own weights only, so the oracle's term is bert_ref.bert_lm_loss on the valid slots ([DEC] as first token, pad ->
+        # ignored label) and its gradient the autograd of that, scaled by the phase's weight (Ggen_text_rec 1.0, Dreal_text_rec 0.1).
+        keep = ~bt['padding_mask'].reshape(-1)
+        dec_ids = ids.reshape(B * 9, T).clone(); dec_ids[:, 0] = toks.bos_token_id
+        labels = dec_ids.masked_fill(dec_ids == toks.pad_token_id, -100)
+        for sd_, o_list, key, term, wgt in ((Gsd, (o32, o64), 'terms_G', 'Loss/G/loss_Ggen_text_rec', step_ref.WEIGHTS['Ggen_text_rec']),
+                                            (Dsd, (o32, o64), 'terms_D', 'Loss/D/loss_Dreal_text_rec', step_ref.WEIGHTS['Dreal_text_rec'])):
+            for o, dt in zip(o_list, (torch.float32, torch.float64)):
+                dec = {k[len('text_decoder.'):]: v.to(dt).clone().requires_grad_(True) for k, v in sd_.items()
+                       if k.startswith('text_decoder.') and v.dtype.is_floating_point and 'crossattention' not in k and 'cls.predictions.decoder.weight' not in k}
+                lm, _ = bert_ref.bert_lm_loss(dec, 4, dec_ids[keep], am.reshape(B * 9, T)[keep], labels[keep])
+                (lm * wgt).backward()
+                o[0][key][term] = (lm * wgt).detach()
+                o[1 if key == 'terms_G' else 2].update({'text_decoder.' + k: v.grad for k, v in dec.items() if v.grad is not None})
     G.eval().requires_grad_(False).to(dev); D.eval().requires_grad_(False).to(dev)
     pG = tl.Phase('Gmain', G, lr=0.0); pD = tl.Phase('Dmain', D, lr=0.0)     # lr 0: Dmain sees the same G as the oracle's apply_adam=False
     reports = {}
@@ -272,6 +366,25 @@ def _full_iteration_vs_oracle(dev, bg, B, seed, tag, text_on=False, flip_toleran
             if a > max(3 * b, 1e-4):
                 bad.append((a, b, phase, k))
     e_gpu, e_cpu = np.array(e_gpu), np.array(e_cpu)
+    # Flip-free discriminator.  A tensor the CPU fp32 run gets within 1e-4 of fp64 is one no flipped unit reached in THAT evaluation; on
+    # those tensors, grouped by the kernel that produces them (3x3 / 1x1 / strided conv weight gradients, linear weights, packed
+    # attention projections, biases, LayerNorm, modulated-conv weights, ...), the MEDIAN HIP error of a family must be <= 1e-4 too.  A flip
+    # on the GPU side moves the tensors upstream of one unit, never a whole family's median; a systematic error in one kernel (say 5 % in
+    # a weight-gradient path) moves every member of its family and fails here even where the distributional gates below are loose.
+    fams = {}
+    idx = 0
+    for phase, i in (('Gmain', 1), ('Dmain', 2)):
+        for k in o64[i]:
+            if e_cpu[idx] < 1e-4:
+                fams.setdefault(_kernel_family(k, tuple(o64[i][k].shape)), []).append(e_gpu[idx])
+            idx += 1
+    fam_med = {f: float(np.median(v)) for f, v in fams.items() if len(v) >= 4}
+    print(f'[{tag}] flip-free families (median HIP error vs fp64 over tensors CPU fp32 gets < 1e-4; members): '
+          + ', '.join(f'{f} {m:.1e} ({len(fams[f])})' for f, m in sorted(fam_med.items(), key=lambda t: -t[1])))
+    assert sum(len(v) for v in fams.values()) >= 0.2 * len(e_gpu), 'too few flip-free tensors to judge'
+    fam_tol = 5e-4 if flip_tolerant else 1e-4    # (512 x 512: a GPU-side flip in a decoder layer moves more than half of a phase's tensors by ~1e-4)
+    for f, m in fam_med.items():
+        assert m <= fam_tol, f'{tag}: kernel family {f}: median error {m:.2e} on {len(fams[f])} flip-free tensors'
     print(f'[{tag}] worst loss-term err {worst_term:.2e}; gradient error vs fp64 oracle: HIP median {np.median(e_gpu):.2e} p90 {np.quantile(e_gpu, .9):.2e} '
           f'max {e_gpu.max():.2e} | CPU fp32 median {np.median(e_cpu):.2e} p90 {np.quantile(e_cpu, .9):.2e} max {e_cpu.max():.2e}; '
           f'{len(bad)} of {len(e_gpu)} tensors beyond 3x the CPU-fp32 error: {sorted(bad, reverse=True)[:3]}')
@@ -315,6 +428,60 @@ def test_full_iteration_configs4_share_b2_512_text_encoder_on_vs_oracle_fp64_adj
     and every trainable gradient against the oracle (bert_ref features in) in fp32 and fp64; the gradient gates are the flip-tolerant
     ones (see the helper)."""
     _full_iteration_vs_oracle(dev, 512, 2, 61, 'configs4 share B=2 512 text on', text_on=True, flip_tolerant=True)
+
+
+def test_full_iteration_b2_512_text_encoder_and_lm_decoder_on_vs_oracle_fp64_adjudicated(dev):
+    """text_mode='encoder+lm' (what the reference always builds: frozen 12-layer text encoder AND the trainable 2-layer LM text decoder
+    with its 30524-entry tied vocabulary head) for the full Gmain + Dmain iteration at 512x512 / 2 samples: every loss term incl. the two
+    text-reconstruction terms, bbox_fake, and every trainable gradient incl. the decoder's, fp64-adjudicated."""
+    _full_iteration_vs_oracle(dev, 512, 2, 63, 'B=2 512 encoder+lm', text_on=True, flip_tolerant=True, lm_on=True)
+
+
+def test_text_path_at_max_length_256_mostly_padding_vs_bert_ref(dev):
+    """The reference tokenises every element text with padding='max_length', max_length=256 (networks_detr.py:71,145): T = 256 with a few
+    real tokens per row and the rest padding.  Frozen text encoder forward (CLS features) and the LM decoder's loss + gradients on the
+    HIP kernels at that length — rows of 3..40 valid tokens, one row with [CLS] only — against bert_ref."""
+    from layoutdetr_amd.training import med
+    from oracle import bert_ref
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    torch.manual_seed(81)
+    R, T, H = 18, 256, 4
+    cfg = med.BertConfig(); cfg.num_hidden_layers, cfg.num_attention_heads = 12, H
+    enc = med.BertModel(cfg, add_pooling_layer=False)
+    for n, p in enc.named_parameters():
+        p.data.normal_(0, 0.03)
+        if 'LayerNorm.weight' in n:
+            p.data.add_(1.0)
+    g = torch.Generator().manual_seed(82)
+    lens = torch.randint(3, 41, (R,), generator=g); lens[4] = 1
+    ids = torch.randint(1000, 30000, (R, T), generator=g); am = (torch.arange(T)[None] < lens[:, None]).long(); ids = ids * am
+    esd = {k: v.clone() for k, v in enc.state_dict().items()}
+    with torch.no_grad():
+        ref = bert_ref.bert_text_forward(esd, H, ids, am)[:, 0]
+        out = enc.eval().to(dev)(ids.to(dev), attention_mask=am.to(dev), return_dict=True, mode='text').last_hidden_state[:, 0]
+    e_enc = check(out, ref, 1e-4, 'CLS features at T=256')
+    dcfg = med.BertConfig(); dcfg.num_hidden_layers, dcfg.num_attention_heads, dcfg.encoder_width, dcfg.vocab_size = 2, H, 512, 30524
+    dec = med.BertLMHeadModel(dcfg)
+    for n, p in dec.named_parameters():
+        p.data.normal_(0, 0.03)
+        if 'LayerNorm.weight' in n:
+            p.data.add_(1.0)
+    dsd = {k: v.clone() for k, v in dec.state_dict().items()}
+    dec_ids = ids.clone(); dec_ids[:, 0] = 30522
+    labels = dec_ids.masked_fill(dec_ids == 0, -100)
+    leaf = {k: v.clone().requires_grad_(True) for k, v in dsd.items() if v.dtype.is_floating_point and 'crossattention' not in k and 'cls.predictions.decoder.weight' not in k}
+    lm_ref, _ = bert_ref.bert_lm_loss(leaf, H, dec_ids, am, labels); lm_ref.backward()
+    dec.eval().to(dev)      # eval: dropout off (numeric parity runs without dropout), gradients still flow
+    lm = dec(dec_ids.to(dev), attention_mask=am.to(dev), labels=labels.to(dev), return_dict=True, mode='text').loss
+    lm.backward()
+    e_lm = check(lm, lm_ref.detach(), 2e-4, 'LM loss at T=256')
+    named = dict(dec.named_parameters())
+    worst = 0.0
+    for k, v in leaf.items():
+        if v.grad is None or k not in named or named[k].grad is None:
+            continue
+        worst = max(worst, check(named[k].grad, v.grad, 2e-3, 'LM decoder grad ' + k))
+    print(f'[T=256 mostly padding] CLS {e_enc:.2e}, LM loss {e_lm:.2e}, worst decoder gradient {worst:.2e}')
 
 
 def test_forward_and_losses_configs2_b16_256_vs_oracle(dev):

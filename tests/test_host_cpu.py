@@ -4,6 +4,7 @@ and position encoding against reference golden vectors), and that the product pa
 import os
 import re
 import socket
+import sys
 
 import numpy as np
 import pytest
@@ -28,7 +29,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), f'{name} declared in include/ldetr_hip.h but not exported'
     assert declared - {'ldetr_last_error', 'ldetr_abi_version'} == set(_lib.SIGNATURES), 'ctypes table out of sync with the header'
-    assert lib.ldetr_abi_version() == 16
+    assert lib.ldetr_abi_version() == 17
 
 
 def test_no_cpu_fallback():
@@ -256,6 +257,16 @@ def test_dropin_aliases_and_training_loop_signature():
     import inspect
     from layoutdetr_amd import dropin
     dropin.install()
+    try:
+        _dropin_checks(importlib, inspect)
+    finally:
+        dropin.uninstall()          # (install() also switches the constructors to the reference's defaults, process-wide)
+    assert 'training.networks_detr' not in sys.modules
+    from layoutdetr_amd.training import networks_detr
+    assert networks_detr.REFERENCE_DEFAULTS is False
+
+
+def _dropin_checks(importlib, inspect):
     nd = importlib.import_module('training.networks_detr')
     assert nd.Generator.__module__ == 'layoutdetr_amd.training.networks_detr' and hasattr(nd, 'split_list')
     assert importlib.import_module('training.loss').StyleGAN2Loss.__module__ == 'layoutdetr_amd.training.loss'
@@ -274,3 +285,80 @@ def test_dropin_aliases_and_training_loop_signature():
     kw.pop('z_dim'); inspect.signature(nd.Discriminator.__init__).bind(None, **kw)
     sampler = tl.InfiniteSampler(list(range(10)), rank=1, num_replicas=2, shuffle=False)
     it = iter(sampler); assert [next(it) for _ in range(6)] == [1, 3, 5, 7, 9, 1]
+    # under the reference's driver an unspecified text_mode is what the reference always builds; without the vocabulary that fails HERE
+    assert nd.REFERENCE_DEFAULTS is True
+    saved = os.environ.pop('LDETR_BERT_VOCAB', None)
+    try:
+        with pytest.raises(RuntimeError, match='LDETR_BERT_VOCAB'):
+            nd._resolve_text_mode(None, nd._build_tokenizer(None))
+        assert nd._resolve_text_mode('features', None) == 'features'
+    finally:
+        if saved is not None:
+            os.environ['LDETR_BERT_VOCAB'] = saved
+
+
+def _stats_worker(rank, world, port, q):
+    import torch.distributed as dist
+    from layoutdetr_amd.training import training_loop as tl
+    dist.init_process_group('gloo', init_method=f'tcp://127.0.0.1:{port}', rank=rank, world_size=world)
+    try:
+        # (1) per-tick statistics: float64 [count, sum, sum of squares] per name, ONE all-reduce of the stacked matrix (training_stats.py:232-254)
+        c = tl.StatsCollector(device=torch.device('cpu'), world=world)
+        vals = {0: [1.0, 2.0, 3.0], 1: [10.0]}[rank]
+        c.report('Loss/scores/fake', torch.tensor(vals)); c.report('Loss/scores/fake', torch.tensor([4.0 + rank]))
+        c.report('Loss/G/loss', torch.tensor(2.0 * (rank + 1))); c.report('Loss/empty', [])
+        d = c.update()
+        allv = np.array([1.0, 2.0, 3.0, 4.0, 10.0, 5.0])
+        ok_stats = (d['Loss/scores/fake']['num'] == 6 and abs(d['Loss/scores/fake']['mean'] - allv.mean()) < 1e-12
+                    and abs(d['Loss/scores/fake']['std'] - allv.std()) < 1e-9 and abs(d['Loss/G/loss']['mean'] - 3.0) < 1e-12 and d['Loss/empty']['num'] == 0)
+        c.report('Loss/scores/fake', torch.tensor([7.0]))
+        d2 = c.update()      # the next interval holds only what was reported since
+        ok_stats = ok_stats and d2['Loss/scores/fake']['num'] == 2 and d2['Loss/scores/fake']['mean'] == 7.0 and d2['Loss/G/loss']['num'] == 0
+        # (2) one flat broadcast per dtype group (training_loop.py:176-179), incl. bool / int64 buffers and a channels_last parameter
+        torch.manual_seed(rank)
+        m = torch.nn.Sequential(torch.nn.Conv2d(3, 4, 3), torch.nn.BatchNorm2d(4), torch.nn.Linear(5, 2))
+        m[0].weight.data = m[0].weight.data.contiguous(memory_format=torch.channels_last)
+        m.register_buffer('flag', torch.tensor([rank == 0, True]))
+        before = [t.detach().clone() for t in m.state_dict().values()]
+        consistent_before = True
+        try:
+            tl.check_ddp_consistency(m)
+        except AssertionError as e:
+            consistent_before = False
+            named = str(e)
+        tl.broadcast_module(m, src=0)
+        torch.manual_seed(0)
+        ref = torch.nn.Sequential(torch.nn.Conv2d(3, 4, 3), torch.nn.BatchNorm2d(4), torch.nn.Linear(5, 2))
+        want = dict(ref.state_dict(), flag=torch.tensor([True, True]))
+        same = all(torch.equal(v, want[k]) for k, v in m.state_dict().items())
+        layout_kept = m[0].weight.is_contiguous(memory_format=torch.channels_last)
+        tl.check_ddp_consistency(m)          # passes on every rank now
+        # (3) a divergence is reported with the reference's naming (ClassName.tensor name), on the rank that differs; ignore_regex skips it
+        if rank == 1:
+            m[2].bias.data[0] += 1.0
+        caught = ''
+        try:
+            tl.check_ddp_consistency(m)
+        except AssertionError as e:
+            caught = str(e)
+        tl.check_ddp_consistency(m, ignore_regex=r'.*\.2\.bias')
+        q.put((rank, bool(ok_stats), bool(same and layout_kept), consistent_before if rank == 0 else (not consistent_before and 'Sequential.' in named),
+               caught == ('' if rank == 0 else 'Sequential.2.bias')))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_stats_allreduce_flat_broadcast_and_consistency_check_gloo_world2():
+    """SURVEY 8e "also needed": the float64 statistics all-reduce (training_stats.py:232-254), the initial broadcast (one collective per
+    dtype group instead of one per tensor) and check_ddp_consistency (misc.py:183-194), two ranks over gloo."""
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_stats_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(all(r[1:]) for r in res), res

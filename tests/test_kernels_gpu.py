@@ -14,6 +14,8 @@ pytestmark = pytest.mark.gpu
 
 from oracle import ops_ref  # noqa: E402
 
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+
 
 def rel_err(a, b):
     a, b = a.detach().double().cpu(), b.detach().double().cpu()
@@ -499,6 +501,46 @@ def test_linear_autograd(dev):
     assert_close(wg.grad, wr.grad, 5e-6, 'dw'); assert_close(bg.grad, br.grad, 5e-6, 'db')
 
 
+def test_split_bf16_non_finite_operands_match_f32_pipe_and_reference_sanitiser(dev):
+    """The exact three-way split of +-Inf (and of a finite value within one bf16 ulp of FLT_MAX) is Inf + NaN + NaN: without care the bf16
+    pipe would return NaN where the f32 pipe (and the reference's fp32 GEMM) returns +-Inf, and the step's gradient sanitiser
+    (training_loop.py:306-309: nan -> 0, +inf -> 1e5, -inf -> -1e5) maps the two differently.  A tile whose accumulators come out
+    non-finite is recomputed on the f32 pipe inside the launch: (a) Inf / NaN / finite CLASSES of every output equal the f32 pipe's and
+    torch's fp32 matmul's, finite values agree; (b) fed through the fused sanitise + Adam kernel the parameters equal the reference
+    post-processing (oracle losses_ref.dp_postprocess, golden-pinned) + torch Adam."""
+    from layoutdetr_amd.hip import core
+    from oracle import losses_ref
+    torch.manual_seed(44)
+    for ta, tb, M, N, K in [(0, 0, 1024, 512, 1152), (1, 1, 512, 512, 4096), (0, 1, 2048, 256, 512)]:
+        A = torch.randn((K, M) if ta else (M, K)); B = torch.randn((K, N) if tb else (N, K)).abs() + 0.1      # B > 0: no Inf - Inf in a row
+        Av = A.t() if ta else A                                      # logical [M, K] view of the storage
+        Av[3, 5] = float('inf'); Av[70, 9] = -float('inf'); Av[200, 1] = float('nan'); Av[333, 7] = 3.4e38   # 3.4e38: bf16(hi) rounds to Inf
+        Av[400, 2] = float('inf'); Av[400, 3] = -float('inf')                                            # Inf - Inf -> NaN on every pipe
+        ref = Av @ (B if tb else B.t())                              # torch fp32 on the host
+        Ad, Bd = A.to(dev), B.to(dev)
+        f32, sp = _both_pipes(lambda: core.gemm(Ad, Bd, ta, tb, M, N, K).clone())
+        for name, out in (('f32 pipe', f32.cpu()), ('bf16 split', sp.cpu())):
+            assert torch.equal(torch.isnan(out), torch.isnan(ref)), f'{name} ta={ta} tb={tb}: NaN positions differ from the fp32 matmul'
+            assert torch.equal(torch.isposinf(out), torch.isposinf(ref)) and torch.equal(torch.isneginf(out), torch.isneginf(ref)), f'{name}: Inf positions differ'
+            fin = torch.isfinite(ref)
+            assert (out[fin] - ref[fin]).abs().max() <= 2e-5 * ref[fin].abs().max(), name
+        assert torch.isposinf(sp[3]).all() and torch.isneginf(sp[70]).all() and torch.isnan(sp[200]).all() and torch.isnan(sp[400]).all()
+        assert not torch.equal(f32[500:], sp[500:]), 'both runs took the same path: the split tiles were not exercised'
+        # (b) such a product as a weight gradient through `/world` + nan_to_num + Adam (fuse_sanitize = 1)
+        n = sp.numel(); world = 2
+        g_ref = losses_ref.dp_postprocess(ref.flatten().clone() * 1.0, world)
+        p0 = torch.randn(n)
+        pr = p0.clone().requires_grad_(True); opt = torch.optim.Adam([pr], lr=1e-3, betas=(0.0, 0.99), eps=1e-8)
+        pr.grad = g_ref.clone(); opt.step()
+        pg = p0.to(dev); m = torch.zeros(n, device=dev); v = torch.zeros(n, device=dev); gd = sp.flatten().contiguous()
+        core.check(core.lib().ldetr_adam_step_f32(core.ptr(pg), core.ptr(gd), core.ptr(m), core.ptr(v), n, 1, 1e-3, 0.0, 0.99, 1e-8,
+                                                  1, 1.0 / world, 0.0, 1e5, -1e5, core.stream()))
+        mc = m.cpu()
+        assert torch.equal(mc == 1e5, g_ref == 1e5) and torch.equal(mc == -1e5, g_ref == -1e5) and (mc == 1e5).any() and (mc == -1e5).any()
+        assert torch.equal((mc == 0) & ~torch.isfinite(ref.flatten()), torch.isnan(ref.flatten()))
+        assert_close(pg, pr, 1e-5, 'adam after sanitising a split-pipe gradient')
+
+
 # ------------------------------------------------------------------------------------------ optimiser / DP step kernels
 def test_adam_sanitize_ema(dev):
     from layoutdetr_amd.hip import core
@@ -554,6 +596,46 @@ def test_lsap_matches_scipy_bit_exact(dev):
             for b in range(batch):
                 r, cc = linear_sum_assignment(cost[b], maximize=bool(maximize))
                 assert ri[b].cpu().tolist() == r.tolist() and ci[b].cpu().tolist() == cc.tolist()
+
+
+# ------------------------------------------------------------------------------------------ detr_util/box_ops.py (north_star row ns-1)
+def test_box_ops_bit_exact_vs_reference_golden_and_hungarian_indices_vs_scipy(dev):
+    """box_cxcywh_to_xyxy / box_iou / generalized_box_iou on the GPU against vectors captured from the reference's own functions
+    (tests/golden/box_ops.npz): every matrix BIT-exact in fp32 (the reference's operation order, no fma contraction, correctly rounded
+    division); the Hungarian assignment on cost = -GIoU (one launch for the cost matrices of the whole batch + the device LSAP solve)
+    index-exact against the fixture's scipy result and against live scipy on fresh layouts incl. duplicated boxes (ties)."""
+    from scipy.optimize import linear_sum_assignment
+    from layoutdetr_amd.detr_util import box_ops
+    d = np.load(os.path.join(G, 'box_ops.npz'))
+    for i in range(int(d['count'])):
+        pred, tgt = torch.from_numpy(d[f'pred{i}']).to(dev), torch.from_numpy(d[f'tgt{i}']).to(dev)
+        p_xyxy, t_xyxy = box_ops.box_cxcywh_to_xyxy(pred), box_ops.box_cxcywh_to_xyxy(tgt)
+        assert np.array_equal(p_xyxy.cpu().numpy(), d[f'p_xyxy{i}']) and np.array_equal(box_ops.box_xyxy_to_cxcywh(p_xyxy).cpu().numpy(), d[f'back{i}'])
+        iou, union = box_ops.box_iou(p_xyxy, t_xyxy)
+        assert np.array_equal(iou.cpu().numpy(), d[f'iou{i}'], equal_nan=True), f'case {i}: iou not bit-exact'
+        assert np.array_equal(union.cpu().numpy(), d[f'union{i}']), f'case {i}: union'
+        assert np.array_equal(box_ops.generalized_box_iou(p_xyxy, t_xyxy).cpu().numpy(), d[f'giou{i}'], equal_nan=True), f'case {i}: giou not bit-exact'
+        ri, ci, giou = box_ops.hungarian_match_giou(pred[None], tgt[None])
+        assert np.array_equal(giou[0].cpu().numpy(), d[f'giou{i}'], equal_nan=True)
+        assert ri[0].cpu().tolist() == d[f'row{i}'].tolist() and ci[0].cpu().tolist() == d[f'col{i}'].tolist(), f'case {i}: assignment'
+    a, b = torch.from_numpy(d['rect_a']).to(dev), torch.from_numpy(d['rect_b']).to(dev)
+    iou, union = box_ops.box_iou(a, b)
+    assert np.array_equal(iou.cpu().numpy(), d['rect_iou']) and np.array_equal(union.cpu().numpy(), d['rect_union'])
+    assert np.array_equal(box_ops.generalized_box_iou(a, b).cpu().numpy(), d['rect_giou'])
+    with pytest.raises(AssertionError):
+        box_ops.generalized_box_iou(torch.tensor([[0.5, 0.5, 0.4, 0.6]], device=dev), b)      # x1 < x0: rejected like the reference
+    # a batch of layouts in one call against live scipy
+    g = torch.Generator().manual_seed(5)
+    for n in (9, 16, 33):
+        B = 64
+        pred = torch.cat([torch.rand(B, n, 2, generator=g) * 0.6 + 0.2, torch.rand(B, n, 2, generator=g) * 0.35 + 0.05], -1)
+        tgt = torch.cat([torch.rand(B, n, 2, generator=g) * 0.6 + 0.2, torch.rand(B, n, 2, generator=g) * 0.35 + 0.05], -1)
+        tgt[::4, 1] = tgt[::4, 0]; pred[1::4, 2] = pred[1::4, 0]; tgt[2::8] = pred[2::8]
+        ri, ci, giou = box_ops.hungarian_match_giou(pred.to(dev), tgt.to(dev))
+        cost = (-giou.cpu()).double().numpy()
+        for bb in range(B):
+            r, c = linear_sum_assignment(cost[bb])
+            assert ri[bb].cpu().tolist() == r.tolist() and ci[bb].cpu().tolist() == c.tolist(), (n, bb)
 
 
 # ------------------------------------------------------------------------------------------ layout metrics (SURVEY 8f-4)

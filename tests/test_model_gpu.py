@@ -50,6 +50,50 @@ def test_detr_transformer_matches_reference_golden(dev, name):
             check(p.grad, grads[k], 2e-4, 'grad ' + k)
 
 
+@pytest.mark.parametrize('flat', [False, True])
+def test_grouped_memory_kv_projection_equals_per_layer_projections(dev, flat):
+    """The six decoder layers' memory K / V projections as two grouped GEMMs (hip.attention._GroupedKVFn; backward: the layers' attention
+    kernels write dK / dV into one buffer, two data-gradient + two weight-gradient GEMMs, one strided add into the flat .grad) against the
+    per-layer launches the reference's call structure maps to (detr_transformer.py:277-280), at the real sizes (d 256, 8 heads, 6 + 6
+    layers, 16 samples x 64 memory tokens): outputs, input gradients and every parameter gradient, with autograd-returned gradients
+    (flat=False) and with gradients accumulated into a FlatModule buffer on top of a non-zero previous content (flat=True)."""
+    from layoutdetr_amd.training import detr_transformer as T
+    from layoutdetr_amd.training.training_loop import FlatModule
+    torch.manual_seed(91)
+    B, S, N, d = 16, 64, 9, 256
+    m = T.TransformerWithToken(d_model=d, nhead=8, num_encoder_layers=6, num_decoder_layers=6, dim_feedforward=2048, dropout=0.1).eval().to(dev)
+    src0 = torch.randn(B, d, 8, 8, device=dev); pos = torch.randn(B, d, 8, 8, device=dev) * 0.3
+    mask = torch.zeros(B, 8, 8, dtype=torch.bool, device=dev); mask[1, :, 6:] = True; mask[5, 5:, :] = True
+    tgt0 = torch.randn(N, B, d, device=dev); kpm = torch.zeros(B, N, dtype=torch.bool, device=dev); kpm[2, 4:] = True; kpm[7, 1:] = True
+    g_hs = torch.randn(B, N + 1, d, device=dev); g_mem = torch.randn(B, d, 8, 8, device=dev) * 0.1
+    fm = FlatModule(m) if flat else None
+    res = {}
+    prev = T._GROUP_KV
+    try:
+        for grouped in (False, True):
+            T._GROUP_KV = grouped
+            if flat:
+                fm.zero_grad(); fm.gflat.fill_(0.25)          # accumulate on top of existing content
+            else:
+                for p_ in m.parameters():
+                    p_.grad = None
+            src = src0.clone().requires_grad_(True); tgt = tgt0.clone().requires_grad_(True)
+            hs, mem = m(src, mask, pos, tgt, kpm)
+            ((hs * g_hs).sum() + (mem * g_mem).sum()).backward()
+            res[grouped] = dict(hs=hs.detach().clone(), mem=mem.detach().clone(), d_src=src.grad.clone(), d_tgt=tgt.grad.clone(),
+                                **{'g/' + k: p_.grad.detach().clone() for k, p_ in m.named_parameters() if p_.grad is not None})
+    finally:
+        T._GROUP_KV = prev
+    assert set(res[True]) == set(res[False])
+    worst = 0.0
+    for k, v in res[False].items():
+        e = rel(res[True][k], v)
+        worst = max(worst, e)
+        assert e <= (2e-5 if k in ('hs', 'mem') else 1e-4), f'{k}: {e:.3e}'
+    assert any('multihead_attn.in_proj_weight' in k for k in res[True])
+    print(f'[grouped K/V flat={flat}] worst deviation from the per-layer path {worst:.2e}')
+
+
 @pytest.mark.parametrize('cls_name,d_model,nhead', [('Transformer', 256, 4), ('TransformerWithToken', 256, 2), ('Transformer', 192, 2)])
 def test_detr_transformer_wider_heads_vs_oracle(dev, cls_name, d_model, nhead):
     """Head widths 64 / 128 / 96 (the reference's constructors take any hidden_dim / nhead; its own default is 256 / 8 = 32): DETR

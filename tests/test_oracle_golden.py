@@ -239,6 +239,28 @@ def test_background_resample_oracle_bit_exact():
         assert np.array_equal(out, d[f'out{i}']), f'case {i}: normalised tensor differs'
 
 
+def test_box_ops_oracle_matches_reference_golden_bit_exact():
+    """north_star row ns-1 (detr_util/box_ops.py): the numpy restatement against the reference's own functions — xyxy conversion, IoU,
+    union, GIoU bit-exact in fp32; the Hungarian assignment on cost = -GIoU index-exact through the C restatement of scipy's solver."""
+    from oracle import box_ops_ref
+    d = np.load(os.path.join(G, 'box_ops.npz'))
+    lib = _lsap_lib()
+    lsap = lambda cost: _lsap(lib, cost, False)
+    for i in range(int(d['count'])):
+        p_xyxy = box_ops_ref.box_cxcywh_to_xyxy(d[f'pred{i}'])
+        assert np.array_equal(p_xyxy, d[f'p_xyxy{i}'])
+        assert np.array_equal(box_ops_ref.box_xyxy_to_cxcywh(p_xyxy), d[f'back{i}'])
+        t_xyxy = box_ops_ref.box_cxcywh_to_xyxy(d[f'tgt{i}'])
+        iou, union = box_ops_ref.box_iou(p_xyxy, t_xyxy)
+        assert np.array_equal(iou, d[f'iou{i}'], equal_nan=True) and np.array_equal(union, d[f'union{i}'])
+        assert np.array_equal(box_ops_ref.generalized_box_iou(p_xyxy, t_xyxy), d[f'giou{i}'], equal_nan=True)
+        (r, c), _ = box_ops_ref.hungarian_match_giou(d[f'pred{i}'], d[f'tgt{i}'], lsap)
+        assert r.tolist() == d[f'row{i}'].tolist() and c.tolist() == d[f'col{i}'].tolist(), i
+    iou, union = box_ops_ref.box_iou(d['rect_a'], d['rect_b'])
+    assert np.array_equal(iou, d['rect_iou']) and np.array_equal(union, d['rect_union'])
+    assert np.array_equal(box_ops_ref.generalized_box_iou(d['rect_a'], d['rect_b']), d['rect_giou'])
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 # Rows a13 / a14: the composition.  tests/golden/composition.npz = outputs of the reference's own Generator.forward,
 # Discriminator.forward and StyleGAN2Loss.accumulate_gradients (oracle/gen_golden.py:gen_composition); weights and inputs
@@ -301,6 +323,25 @@ def test_composition_forward_tuples_vs_reference():
         lo = networks_ref.discriminator(Dsd, inp['bbox_real'], inp['bbox_class'], tf, tl, pm, bgl, feats=inp['feats_d'])
         close(lo[0], d['D/logit_ragged'], 1e-5); close(lo[1], d['D/logit_uncond_ragged'], 1e-5)
         assert not torch.equal(d['D/logit_ragged'], d['D/logit']), 'the ragged case must exercise the mask'
+
+
+def test_config0_generator_forward_vs_reference():
+    """BASELINE.json configs[0]: one sample, 128x128 background (16 memory tokens), 3 valid text boxes of 9 slots — the reference's own
+    Generator.forward (oracle/gen_golden.py:gen_config0) against the oracle."""
+    from oracle import networks_ref, seeded
+    d = load('config0')
+    B, bg, seed, nv = int(d['B']), int(d['bg']), int(d['seed']), int(d['nvalid'])
+    assert (B, bg, nv) == (1, 128, 3)
+    inp = seeded.comp_inputs(B, bg, seed)
+    pm = torch.ones(B, 9, dtype=torch.bool); pm[:, :nv] = False
+    _, _, Gsd, _ = comp_modules(bg)
+    with torch.no_grad():
+        close(networks_ref.generator(Gsd, inp['z_g'], inp['bbox_class'], d['text_feat'], d['text_len'], pm, inp['background'], feats=inp['feats_g']),
+              d['G/bbox_fake_noreconst'], 1e-5)
+        out = networks_ref.generator(Gsd, inp['z_g'], inp['bbox_class'], d['text_feat'], d['text_len'], pm, inp['background'], reconst=True, feats=inp['feats_g'])
+        for k, v in zip(('bbox_fake', 'loss_z', 'logit_cls', 'loss_lm', 'loss_text_len'), out):
+            close(v, d['G/' + k], 1e-5)
+        assert out[2].shape[0] == nv
 
 
 def test_composition_loss_phases_vs_reference():

@@ -2,7 +2,7 @@
 traffic counters for every kernel of the step (profiles/r02_pmc_traffic.*).
   rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d out_f -- python tools/pmc_step.py
   rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d out_w -- python tools/pmc_step.py      (separate passes)
-then  python tools/pmc_step.py --aggregate out_f out_w 2 > profiles/r02_pmc_traffic.json"""
+then  python tools/pmc_step.py --aggregate out_f out_w 2 > profiles/pmc_traffic.json   (stamped with the kernel sources' digest; bench.py quotes it only for the same build)"""
 import csv
 import glob
 import json
@@ -35,7 +35,8 @@ def aggregate(dir_f, dir_w, iters):
                         e['launches'] += 1.0 / iters
     eng = [k for k in out if k.startswith('gemm_')]
     tot = dict(fetch=sum(out[k]['fetch'] for k in eng), write=sum(out[k]['write'] for k in eng), launches=sum(out[k]['launches'] for k in eng))
-    return dict(note='rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes over tools/pmc_step.py (2 eager iterations, B=16, 256x256); bytes per ITERATION; '
+    from layoutdetr_amd import build as kbuild
+    return dict(csrc_digest=kbuild.source_digest(), note='rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes over tools/pmc_step.py (2 eager iterations, B=16, 256x256); bytes per ITERATION; '
                      'FETCH_SIZE doubled (gfx950 128-B requests tallied at 64 B), WRITE_SIZE as reported', engine_total=tot,
                 engine_bytes_per_launch=(tot['fetch'] + tot['write']) / max(tot['launches'], 1), by_kernel={k: out[k] for k in sorted(out, key=lambda k: -(out[k]['fetch'] + out[k]['write']))})
 
