@@ -192,9 +192,36 @@ int ldetr_layernorm_fwd_pos_f32(const float* x, const float* residual, const flo
                                 float* z, float* mean, float* rstd, int64_t rows, int D, float eps, float p_drop,
                                 uint64_t seed, const uint64_t* seed_ptr, const float* pos, int64_t pos_rows, float* ypos,
                                 void* stream);
+
+/* The same with the residual branch given as `n_parts` partial sums parts[s][rows][D] (pitch part_stride floats between slices) plus a
+ * column bias: r = part_bias + sum_s parts[s], added in slice order (deterministic).  This is where the hidden-slice contributions of the
+ * fused feed-forward block (ldetr_ffn_fwd_f32) are reduced.  n_parts = 0: `parts` is the plain residual (== ldetr_layernorm_fwd_pos_f32). */
+int ldetr_layernorm_fwd_parts_f32(const float* x, const float* parts, int n_parts, int64_t part_stride, const float* part_bias,
+                                  const float* gamma, const float* beta, float* y, float* z, float* mean, float* rstd,
+                                  int64_t rows, int D, float eps, float p_drop, uint64_t seed, const uint64_t* seed_ptr,
+                                  const float* pos, int64_t pos_rows, float* ypos, void* stream);
+
+/* Position-wise feed-forward block linear2(dropout(relu(linear1(x)))) of the DETR layers (training/detr_transformer.py:212-214, 283-285;
+ * d_model D = 256, hidden width F a multiple of 64), one launch per direction (csrc/ffn_fused.hip).
+ * fwd: x [M][ldx], w1 [F][D], b1 [F], w2 [D][F] -> h [M][F] (hidden after relu + dropout, kept for the backward) and
+ *      ypart [F/64][M][D]: per-hidden-slice contributions to the output WITHOUT b2 (reduce with ldetr_layernorm_fwd_parts_f32).
+ * bwd: dy [M][D] (gradient of the block output) -> dxpart [F/64][M][D]: per-hidden-slice contributions to the input gradient (reduce with
+ *      ldetr_layernorm_bwd_parts_f32) and, if dh is not NULL, dh [M][F] = gradient of the hidden pre-activation (relu and dropout masks
+ *      applied).  The weight gradients are plain contractions over the tokens: dW2 += dy^T h, dW1 += dh^T x, db2 / db1 = their row sums
+ *      (one ldetr_gemm_pair_f32 call).  p_drop / seed as in ldetr_gemm_f32's epilogue (element index = row * F + column of h). */
+int ldetr_ffn_fwd_f32(const float* x, int64_t ldx, const float* w1, const float* b1, const float* w2, float* h, float* ypart,
+                      int64_t M, int D, int F, float p_drop, uint64_t seed, const uint64_t* seed_ptr, void* stream);
+int ldetr_ffn_bwd_f32(const float* dy, const float* x, int64_t ldx, const float* h, const float* w1, const float* w2,
+                      float* dxpart, float* dh, int64_t M, int D, int F, float p_drop, void* stream);
 int ldetr_layernorm_bwd2_f32(const float* dy, const float* dy2, const float* z, const float* mean, const float* rstd,
                              const float* gamma, float* dx, float* dresidual, float* dgamma, float* dbeta, int64_t rows,
                              int D, float p_drop, uint64_t seed, const uint64_t* seed_ptr, void* stream);
+/* ... with the incoming gradient given as dy (+ dy2) + sum_s dy_parts[s][rows][D] (pitch part_stride floats), added in slice order: where the
+ * hidden-slice contributions of ldetr_ffn_bwd_f32 to the feed-forward block's input gradient are reduced. */
+int ldetr_layernorm_bwd_parts_f32(const float* dy, const float* dy2, const float* dy_parts, int n_parts, int64_t part_stride,
+                                  const float* z, const float* mean, const float* rstd, const float* gamma,
+                                  float* dx, float* dresidual, float* dgamma, float* dbeta, int64_t rows, int D,
+                                  float p_drop, uint64_t seed, const uint64_t* seed_ptr, void* stream);
 int ldetr_layernorm_fwd_f32(const float* x, const float* residual, const float* gamma, const float* beta, float* y,
                             float* z, float* mean, float* rstd, int64_t rows, int D, float eps, float p_drop,
                             uint64_t seed, const uint64_t* seed_ptr, void* stream);
@@ -220,6 +247,11 @@ int ldetr_grad_sanitize_f32(float* g, int64_t n, float scale, float nan_value, f
 int ldetr_adam_step_f32(float* p, const float* g, float* m, float* v, int64_t n, int64_t step, float lr, float beta1,
                         float beta2, float eps, int fuse_sanitize, float gscale, float nan_value, float posinf,
                         float neginf, void* stream);
+/* The same pass with the parameters' exponential moving average updated alongside (training_loop.py:320-328):
+ * p_ema = p_new + ema_beta * (p_ema - p_new); p_ema == NULL: plain Adam. */
+int ldetr_adam_ema_step_f32(float* p, const float* g, float* m, float* v, int64_t n, int64_t step, float lr, float beta1, float beta2,
+                            float eps, int fuse_sanitize, float gscale, float nan_value, float posinf, float neginf,
+                            float* p_ema, float ema_beta, void* stream);
 int ldetr_ema_lerp_f32(float* p_ema, const float* p, int64_t n, float beta, void* stream);
 
 /* Label-smoothed softmax cross entropy of the LM text decoder (CrossEntropyLoss(reduction='mean', label_smoothing) on the shifted

@@ -58,6 +58,10 @@ SIGNATURES = {
     'ldetr_layernorm_fwd_f32': [_P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _F, _F, c_uint64, _P, _P],
     'ldetr_layernorm_bwd_f32': [_P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _F, c_uint64, _P, _P],
     'ldetr_layernorm_fwd_pos_f32': [_P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _F, _F, c_uint64, _P, _P, _L, _P, _P],
+    'ldetr_layernorm_fwd_parts_f32': [_P, _P, _I, _L, _P, _P, _P, _P, _P, _P, _P, _L, _I, _F, _F, c_uint64, _P, _P, _L, _P, _P],
+    'ldetr_ffn_fwd_f32': [_P, _L, _P, _P, _P, _P, _P, _L, _I, _I, _F, c_uint64, _P, _P],
+    'ldetr_ffn_bwd_f32': [_P, _P, _L, _P, _P, _P, _P, _P, _L, _I, _I, _F, _P],
+    'ldetr_layernorm_bwd_parts_f32': [_P, _P, _P, _I, _L, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _F, c_uint64, _P, _P],
     'ldetr_layernorm_bwd2_f32': [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _F, c_uint64, _P, _P],
     'ldetr_colsum_f32': [_P, _P, _I, _L, _I, _P],
     'ldetr_act_bwd_reduce_f32': [_P, _P, _P, _P, _P, _P, _P, _I, _L, _I, _I, _F, _F, _P],
@@ -67,6 +71,7 @@ SIGNATURES = {
     'ldetr_maxpool3x3s2_bwd_f32': [_P, _P, _P, _I, _I, _I, _I, _P],
     'ldetr_grad_sanitize_f32': [_P, _L, _F, _F, _F, _F, _P],
     'ldetr_adam_step_f32': [_P, _P, _P, _P, _L, _L, _F, _F, _F, _F, _I, _F, _F, _F, _F, _P],
+    'ldetr_adam_ema_step_f32': [_P, _P, _P, _P, _L, _L, _F, _F, _F, _F, _I, _F, _F, _F, _F, _P, _F, _P],
     'ldetr_ema_lerp_f32': [_P, _P, _L, _F, _P],
     'ldetr_lsap_f64': [_P, _I, _I, _I, _P, _P, _P],
     'ldetr_box_giou_pairwise_f32': [_P, _P, _I, _I, _I, _I, _P, _P, _P, _P, c_double, _P],

@@ -8,9 +8,13 @@
 //   forward   H = dropout(relu(X W1_s^T + b1_s)) (kept in LDS, written once for the backward), then the slice's contribution
 //             Y_s = H W2_s^T to all 256 outputs -> ypart[s][M][256].  The 32 partial sums (+ b2) are added where they are consumed: in
 //             the residual + LayerNorm launch (ldetr_layernorm_fwd_parts_f32), in slice order, so the forward stays deterministic.
-//   backward  dH = (dY W2_s) * [H > 0] / keep, then dX += dH W1_s (fp32 atomics onto the buffer that already holds the residual-path
-//             gradient written by the LayerNorm backward), dW2[:, s] += dY^T H, dW1[s, :] += dH^T X, db1[s] += colsum dH,
-//             db2 += colsum dY (slice 0 only) -- fp32 atomics straight into the flat .grad buffers.
+//   backward  dH = (dY W2_s) * [H > 0] / keep (written once: operand of the weight gradients), then the slice's contribution dH W1_s to
+//             the input gradient -> dxpart[s][M][256], summed (in slice order, with the residual-path gradient) by the LayerNorm
+//             backward of the sub-block in front (ldetr_layernorm_bwd_parts_f32): no atomics, results reproducible run to run.
+//             The weight gradients dW2 += dY^T H and dW1 += dH^T X (K = tokens) are a different parallelisation (1024 output tiles,
+//             no reduction across blocks): one paired small-tile launch of the contraction engine (ldetr_gemm_pair_f32, TN + TN, bias
+//             gradients as row sums).  (First versions: weight gradients accumulated here with 6.5 M fp32 atomics per launch -- 50 us,
+//             no faster than the unfused path; dX by atomics -- run-to-run noise of 3e-7 that a saturated softmax upstream amplified to 1e-3.)
 // Operands stream global -> registers in MFMA operand order (v_mfma_f32_32x32x2_f32, exact fp32) like gemm_small_kernel; the only
 // LDS traffic is the hidden tile.  D must be 256 (8 column tiles = 2 per wave), the hidden width a multiple of 64.
 #include "ldetr_common.hpp"
@@ -27,8 +31,8 @@ struct FfnParams {
     int M, F;
     float p_drop; unsigned long long seed; const unsigned long long* seed_ptr;
     const float* dy;                          // [M, 256] gradient of the block's output
-    float* dx; long lddx;                     // [M, 256] accumulated (atomics)
-    float* dw1; float* db1; float* dw2; float* db2;
+    float* dxpart;                            // [F / 64][M][256] per-slice contributions to the input gradient
+    float* dh;                                // [M, F] gradient of the hidden pre-activation (written when the weight gradients are wanted)
 };
 
 constexpr int FD = 256, FHS = 64, FHP = 68;   // model width, hidden slice, LDS pitch of the hidden tile
@@ -133,7 +137,6 @@ template <bool WGRAD>
 __global__ __launch_bounds__(256) void ffn_bwd_kernel(FfnParams p) {
     __shared__ float red[2][32][33];
     __shared__ float dHs[32][FHP];
-    __shared__ float Hs[32][FHP];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, cl = lane & 31, kl = lane >> 5;
     const int m0 = blockIdx.x * 32, s = blockIdx.y, j0 = s * FHS;
     const int OOB = (int)0x80000000;
@@ -169,8 +172,9 @@ __global__ __launch_bounds__(256) void ffn_bwd_kernel(FfnParams p) {
                 const long m = m0 + row;
                 const float hv = m < p.M ? p.h[m * p.F + j0 + ct * 32 + cl] : 0.f;
                 // relu'(pre) and the dropout mask in one test: the saved hidden value is positive exactly where both let the gradient through
-                dHs[row][ct * 32 + cl] = hv > 0.f ? (acc[r] + red[ct][row][cl]) * inv_keep : 0.f;
-                if (WGRAD) Hs[row][ct * 32 + cl] = hv;
+                const float dh = hv > 0.f ? (acc[r] + red[ct][row][cl]) * inv_keep : 0.f;
+                dHs[row][ct * 32 + cl] = dh;
+                if (WGRAD && m < p.M) p.dh[m * p.F + j0 + ct * 32 + cl] = dh;      // pre-activation gradient: operand of the weight-gradient launch
             }
         }
         __syncthreads();
@@ -197,83 +201,14 @@ __global__ __launch_bounds__(256) void ffn_bwd_kernel(FfnParams p) {
             FFN_MFMA16(a, b[0][c], acc[0]);
             FFN_MFMA16(a, b[1][c], acc[1]);
         }
+        float* dst = p.dxpart + ((long)s * p.M) * FD;
 #pragma unroll
         for (int q = 0; q < 2; q++)
 #pragma unroll
             for (int r = 0; r < 16; r++) {
                 const long m = m0 + (r & 3) + 8 * (r >> 2) + 4 * kl;
-                if (m < p.M) atomicAdd(p.dx + m * p.lddx + (wave * 2 + q) * 32 + cl, acc[q][r]);
+                if (m < p.M) dst[m * FD + (wave * 2 + q) * 32 + cl] = acc[q][r];
             }
-    }
-    if constexpr (WGRAD) {
-        // ---- phase 3: dW2[n][slice] (256 x 64) += dY^T (256 x 32 tokens) H (32 x 64); wave w -> n tiles 2w, 2w+1, both j tiles
-        {
-            float bj[2][16];
-#pragma unroll
-            for (int jt = 0; jt < 2; jt++)
-#pragma unroll
-                for (int t = 0; t < 16; t++) bj[jt][t] = Hs[16 * kl + t][jt * 32 + cl];
-#pragma unroll
-            for (int q = 0; q < 2; q++) {
-                const int nt = wave * 2 + q;
-                float a[16];      // element (m' = n, k' = token): dy[(m0 + token) * 256 + n]
-#pragma unroll
-                for (int t = 0; t < 16; t++) {
-                    const int m = m0 + 16 * kl + t;
-                    a[t] = __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsDY, m < p.M ? (m * FD + nt * 32 + cl) * 4 : OOB, 0, 0));
-                }
-#pragma unroll
-                for (int jt = 0; jt < 2; jt++) {
-                    ffn_acc_t acc;
-#pragma unroll
-                    for (int r = 0; r < 16; r++) acc[r] = 0.f;
-                    FFN_MFMA16(a, bj[jt], acc);
-#pragma unroll
-                    for (int r = 0; r < 16; r++)
-                        atomicAdd(p.dw2 + (long)(nt * 32 + (r & 3) + 8 * (r >> 2) + 4 * kl) * p.F + j0 + jt * 32 + cl, acc[r]);
-                }
-            }
-        }
-        // ---- phase 4: dW1[slice][c] (64 x 256) += dH^T (64 x 32 tokens) X (32 x 256); wave w -> c tiles 2w, 2w+1, both j tiles
-        {
-            float aj[2][16];
-#pragma unroll
-            for (int jt = 0; jt < 2; jt++)
-#pragma unroll
-                for (int t = 0; t < 16; t++) aj[jt][t] = dHs[16 * kl + t][jt * 32 + cl];
-#pragma unroll
-            for (int q = 0; q < 2; q++) {
-                const int ctile = wave * 2 + q;
-                float b[16];      // element (n' = c, k' = token): x[(m0 + token) * ldx + c]
-#pragma unroll
-                for (int t = 0; t < 16; t++) {
-                    const int m = m0 + 16 * kl + t;
-                    b[t] = __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsX, m < p.M ? (int)(((long)m * p.ldx + ctile * 32 + cl) * 4) : OOB, 0, 0));
-                }
-#pragma unroll
-                for (int jt = 0; jt < 2; jt++) {
-                    ffn_acc_t acc;
-#pragma unroll
-                    for (int r = 0; r < 16; r++) acc[r] = 0.f;
-                    FFN_MFMA16(aj[jt], b, acc);
-#pragma unroll
-                    for (int r = 0; r < 16; r++)
-                        atomicAdd(p.dw1 + (long)(j0 + jt * 32 + (r & 3) + 8 * (r >> 2) + 4 * kl) * FD + ctile * 32 + cl, acc[r]);
-                }
-            }
-        }
-        // ---- phase 5: bias gradients
-        if (tid < FHS && p.db1) {
-            float sum = 0.f;
-#pragma unroll 8
-            for (int r = 0; r < 32; r++) sum += dHs[r][tid];
-            atomicAdd(p.db1 + j0 + tid, sum);
-        }
-        if (s == 0 && p.db2) {
-            float sum = 0.f;
-            for (int r = 0; r < 32 && m0 + r < p.M; r++) sum += p.dy[(long)(m0 + r) * FD + tid];
-            atomicAdd(p.db2 + tid, sum);
-        }
     }
 }
 
@@ -304,18 +239,16 @@ extern "C" int ldetr_ffn_fwd_f32(const float* x, int64_t ldx, const float* w1, c
 }
 
 extern "C" int ldetr_ffn_bwd_f32(const float* dy, const float* x, int64_t ldx, const float* h, const float* w1, const float* w2,
-                                 float* dx, int64_t lddx, float* dw1, float* db1, float* dw2, float* db2,
-                                 int64_t M, int D, int F, float p_drop, void* stream) {
+                                 float* dxpart, float* dh, int64_t M, int D, int F, float p_drop, void* stream) {
     if (int rc = ffn_check("ffn_bwd", M, D, F, x, ldx)) return rc;
-    LDETR_CHECK(dy && h && w1 && w2 && dx && lddx >= D, "ffn_bwd: null pointer");
-    LDETR_CHECK((dw1 == nullptr) == (dw2 == nullptr), "ffn_bwd: dw1 and dw2 go together");
+    LDETR_CHECK(dy && h && w1 && w2 && dxpart, "ffn_bwd: null pointer");
     LDETR_CHECK((((uintptr_t)dy) & 15) == 0, "ffn_bwd: dy must be 16-byte aligned");
     if (M == 0) return LDETR_OK;
     FfnParams p; memset(&p, 0, sizeof(p));
     p.x = x; p.ldx = ldx; p.w1 = w1; p.w2 = w2; p.h = const_cast<float*>(h); p.M = (int)M; p.F = F; p.p_drop = p_drop;
-    p.dy = dy; p.dx = dx; p.lddx = lddx; p.dw1 = dw1; p.db1 = db1; p.dw2 = dw2; p.db2 = db2;
+    p.dy = dy; p.dxpart = dxpart; p.dh = dh;
     const dim3 grid(cdiv(M, 32), F / FHS);
-    if (dw1) hipLaunchKernelGGL(ffn_bwd_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, p);
+    if (dh) hipLaunchKernelGGL(ffn_bwd_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, p);
     else hipLaunchKernelGGL(ffn_bwd_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, p);
     return check_launch("ffn_bwd");
 }

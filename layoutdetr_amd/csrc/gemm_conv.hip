@@ -941,6 +941,11 @@ __global__ __launch_bounds__(NWV * 64) void gemm_f32_kernel(GemmParams p) {
             // none of its addressing is hoisted above the hot loop (it cost the 128x64 instantiations an occupancy step otherwise)
             int t2 = tid;
             asm volatile("" : "+v"(t2));
+            // ONE buffer of the f32 image, B right behind A (the double-buffered As / Bs pointers of the f32 instantiation would reach past this
+            // instantiation's LDS allocation, which is sized for the bf16 image)
+            float (*A1)[LDA] = reinterpret_cast<float (*)[LDA]>(ldetr_smem);
+            float (*B1)[LDB] = reinterpret_cast<float (*)[LDB]>(ldetr_smem + BKT * LDA);
+            static_assert((size_t)BKT * (LDA + LDB) * sizeof(float) <= (size_t)3 * (BKT / 8) * (PLA + PLB), "the f32 image of one k-tile must fit inside the bf16 image");
 #pragma unroll
             for (int i = 0; i < TM; i++)
 #pragma unroll
@@ -960,24 +965,24 @@ __global__ __launch_bounds__(NWV * 64) void gemm_f32_kernel(GemmParams p) {
 #pragma unroll
                 for (int i = 0; i < NUA; i++) {
                     int r, k; unitA(t2, i, r, k);
-                    if constexpr (A_KC) { As[0][k + 0][r] = ra0[i].x; As[0][k + 1][r] = ra0[i].y; As[0][k + 2][r] = ra0[i].z; As[0][k + 3][r] = ra0[i].w; }
-                    else { As[0][k][r + 0] = ra0[i].x; As[0][k][r + 1] = ra0[i].y; As[0][k][r + 2] = ra0[i].z; As[0][k][r + 3] = ra0[i].w; }
+                    if constexpr (A_KC) { A1[k + 0][r] = ra0[i].x; A1[k + 1][r] = ra0[i].y; A1[k + 2][r] = ra0[i].z; A1[k + 3][r] = ra0[i].w; }
+                    else { A1[k][r + 0] = ra0[i].x; A1[k][r + 1] = ra0[i].y; A1[k][r + 2] = ra0[i].z; A1[k][r + 3] = ra0[i].w; }
                 }
 #pragma unroll
                 for (int i = 0; i < NUB; i++) {
                     int r, k; unitB(t2, i, r, k);
-                    if constexpr (B_KC) { Bs[0][k + 0][r] = rb0[i].x; Bs[0][k + 1][r] = rb0[i].y; Bs[0][k + 2][r] = rb0[i].z; Bs[0][k + 3][r] = rb0[i].w; }
-                    else { Bs[0][k][r + 0] = rb0[i].x; Bs[0][k][r + 1] = rb0[i].y; Bs[0][k][r + 2] = rb0[i].z; Bs[0][k][r + 3] = rb0[i].w; }
+                    if constexpr (B_KC) { B1[k + 0][r] = rb0[i].x; B1[k + 1][r] = rb0[i].y; B1[k + 2][r] = rb0[i].z; B1[k + 3][r] = rb0[i].w; }
+                    else { B1[k][r + 0] = rb0[i].x; B1[k][r + 1] = rb0[i].y; B1[k][r + 2] = rb0[i].z; B1[k][r + 3] = rb0[i].w; }
                 }
                 __syncthreads();
 #pragma unroll 1
                 for (int kk = 0; kk < BKT / 2; kk++) {
 #pragma unroll
                     for (int i = 0; i < TM; i++) {
-                        const float a = As[0][kk * 2 + kl2][wm2 * WM + i * 32 + cl2];
+                        const float a = A1[kk * 2 + kl2][wm2 * WM + i * 32 + cl2];
 #pragma unroll
                         for (int j = 0; j < TN; j++)
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, Bs[0][kk * 2 + kl2][wn2 * WN + j * 32 + cl2], acc[i][j], 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, B1[kk * 2 + kl2][wn2 * WN + j * 32 + cl2], acc[i][j], 0, 0, 0);
                     }
                 }
                 __syncthreads();
@@ -2076,9 +2081,11 @@ static void fill_dense(GemmParams& p, const ldetr_gemm_desc& g) {
 
 static bool pair_single_launch(const ldetr_gemm_desc* g0, const ldetr_gemm_desc* g1) {
     static const int pair_on = getenv("LDETR_GEMM_PAIR") ? atoi(getenv("LDETR_GEMM_PAIR")) : 1;
-    const bool layouts = g0->ta == 0 && g0->tb == 1 && g1->ta == 1 && g1->tb == 1;    // the instantiated pairing: NN + TN
-    return pair_on && layouts && g0->A && g0->B && g0->C && g1->A && g1->B && g1->C && small_class(*g0) && small_class(*g1) &&
-           (!g1->ep || !g1->ep->a_rowsum || g1->lda == g1->M) && !(g0->ep && g0->ep->a_rowsum);
+    // the instantiated pairings: NN + TN (a linear layer's data + weight gradient) and TN + TN (the two weight gradients of the
+    // feed-forward block, hip/ffn.py); a row-sum output needs a transposed, packed A
+    const bool nn_tn = g0->ta == 0 && g0->tb == 1 && g1->ta == 1 && g1->tb == 1, tn_tn = g0->ta == 1 && g0->tb == 1 && g1->ta == 1 && g1->tb == 1;
+    return pair_on && (nn_tn || tn_tn) && g0->A && g0->B && g0->C && g1->A && g1->B && g1->C && small_class(*g0) && small_class(*g1) &&
+           (!g1->ep || !g1->ep->a_rowsum || g1->lda == g1->M) && (!(g0->ep && g0->ep->a_rowsum) || (tn_tn && g0->lda == g0->M));
 }
 
 extern "C" int ldetr_gemm_pair_is_single_launch(const ldetr_gemm_desc* g0, const ldetr_gemm_desc* g1) {
@@ -2093,6 +2100,19 @@ extern "C" int ldetr_gemm_pair_f32(const ldetr_gemm_desc* g0, const ldetr_gemm_d
         const int gx0 = cdiv(p0.N, 32), nt0 = gx0 * cdiv(p0.M, 32), gx1 = cdiv(p1.N, 32), nt1 = gx1 * cdiv(p1.M, 32);
         // one block size for both: 8 waves only when both problems would take them on their own
         auto wants8 = [](long blocks, int sk, int K) { return blocks * sk <= 256 && (K + sk - 1) / sk >= 512; };
+        if (g0->ta == 1) {     // TN + TN
+            const int sk0 = plan_small_split(p0, nt0), sk1 = plan_small_split(p1, nt1);
+            const bool w8 = wants8(nt0, sk0, p0.K) && wants8(nt1, sk1, p1.K);
+            hipStream_t st = (hipStream_t)stream;
+            const dim3 grid((unsigned)(nt0 * sk0 + nt1 * sk1));
+            if (small_fast_ok(p0, 1, 1) && small_fast_ok(p1, 1, 1)) {
+                if (w8) hipLaunchKernelGGL((gemm_small_pair_kernel<1, 1, 1, 1, 8, true>), grid, 512, 0, st, p0, p1, gx0, nt0, sk0, gx1, nt1, sk1);
+                else hipLaunchKernelGGL((gemm_small_pair_kernel<1, 1, 1, 1, 4, true>), grid, 256, 0, st, p0, p1, gx0, nt0, sk0, gx1, nt1, sk1);
+            } else if (w8) hipLaunchKernelGGL((gemm_small_pair_kernel<1, 1, 1, 1, 8>), grid, 512, 0, st, p0, p1, gx0, nt0, sk0, gx1, nt1, sk1);
+            else hipLaunchKernelGGL((gemm_small_pair_kernel<1, 1, 1, 1, 4>), grid, 256, 0, st, p0, p1, gx0, nt0, sk0, gx1, nt1, sk1);
+            t_launches_f32++;
+            return check_launch("gemm_small_pair");
+        }
         if (!p0.ep.a_rowsum) {
             const int sk0 = plan_small_split(p0, nt0), sk1 = plan_small_split(p1, nt1);
             const bool w8 = wants8(nt0, sk0, p0.K) && wants8(nt1, sk1, p1.K);

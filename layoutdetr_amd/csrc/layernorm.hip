@@ -17,6 +17,12 @@ struct LnParams {
     // second output ypos[row] = y[row] + pos[row % pos_rows] (the next attention's q/k input: detr_transformer.py:207,277 add the
     // position embedding with a separate kernel per layer), and its gradient dy2 summed into dy on load
     const float* pos; long pos_rows; float* ypos; const float* dy2;
+    // the residual branch as `r_parts` partial sums [r_parts][rows][D] (+ a column bias): the slices of the fused feed-forward block
+    // (ffn_fused.hip) are added here, in slice order, instead of by a reduction launch of their own
+    int r_parts; long r_part_stride; const float* r_bias;
+    // backward: the incoming gradient as dy + sum of `dy_nparts` partial sums [dy_nparts][rows][D] (the hidden slices' contributions to the
+    // feed-forward block's input gradient), added in slice order
+    const float* dy_parts; int dy_nparts; long dy_part_stride;
 };
 
 // NV = float4 vectors per lane (D = 256*NV at most; lanes past D/4 idle)
@@ -38,6 +44,13 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(LnParams p) {
             v[i] = reinterpret_cast<const float4*>(p.x + row * p.D)[c4];
             if (p.r) {
                 float4 rr = reinterpret_cast<const float4*>(p.r + row * p.D)[c4];
+                if (p.r_parts > 0) {
+                    if (p.r_bias) { const float4 bb = reinterpret_cast<const float4*>(p.r_bias)[c4]; rr.x += bb.x; rr.y += bb.y; rr.z += bb.z; rr.w += bb.w; }
+                    for (int s = 1; s < p.r_parts; s++) {
+                        const float4 q = reinterpret_cast<const float4*>(p.r + s * p.r_part_stride + row * p.D)[c4];
+                        rr.x += q.x; rr.y += q.y; rr.z += q.z; rr.w += q.w;
+                    }
+                }
                 if (p.p_drop > 0.f) {
                     uint64_t e = (uint64_t)row * p.D + (c4 << 2);
                     rr.x *= drop_scale(seed, e, p.p_drop, inv_keep);
@@ -110,6 +123,10 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(LnParams p) {
                     const float4 d2 = reinterpret_cast<const float4*>(p.dy2 + row * p.D)[c4];
                     dy.x += d2.x; dy.y += d2.y; dy.z += d2.z; dy.w += d2.w;
                 }
+                for (int s = 0; s < p.dy_nparts; s++) {
+                    const float4 d2 = reinterpret_cast<const float4*>(p.dy_parts + s * p.dy_part_stride + row * p.D)[c4];
+                    dy.x += d2.x; dy.y += d2.y; dy.z += d2.z; dy.w += d2.w;
+                }
                 float4 gm = reinterpret_cast<const float4*>(p.gamma)[c4];
                 xh[i].x = (zz.x - mean) * rstd; xh[i].y = (zz.y - mean) * rstd;
                 xh[i].z = (zz.z - mean) * rstd; xh[i].w = (zz.w - mean) * rstd;
@@ -172,6 +189,15 @@ extern "C" int ldetr_layernorm_fwd_pos_f32(const float* x, const float* residual
                                            float* y, float* z, float* mean, float* rstd, int64_t rows, int D, float eps,
                                            float p_drop, uint64_t seed, const uint64_t* seed_ptr,
                                            const float* pos, int64_t pos_rows, float* ypos, void* stream) {
+    return ldetr_layernorm_fwd_parts_f32(x, residual, 0, 0, nullptr, gamma, beta, y, z, mean, rstd, rows, D, eps, p_drop, seed, seed_ptr, pos, pos_rows, ypos, stream);
+}
+
+extern "C" int ldetr_layernorm_fwd_parts_f32(const float* x, const float* parts, int n_parts, int64_t part_stride, const float* part_bias,
+                                             const float* gamma, const float* beta, float* y, float* z, float* mean, float* rstd,
+                                             int64_t rows, int D, float eps, float p_drop, uint64_t seed, const uint64_t* seed_ptr,
+                                             const float* pos, int64_t pos_rows, float* ypos, void* stream) {
+    const float* residual = parts;
+    LDETR_CHECK(n_parts >= 0 && (n_parts == 0 || (parts && part_stride >= rows * D)), "layernorm_fwd: bad partial-sum arguments");
     LDETR_CHECK(x && gamma && beta && y, "layernorm_fwd: null pointer");
     LDETR_CHECK((pos == nullptr) == (ypos == nullptr) && (!pos || pos_rows > 0), "layernorm_fwd: pos, pos_rows and ypos go together");
     LDETR_CHECK(D % 4 == 0 && D >= 4 && D <= 1024, "layernorm_fwd: D must be a multiple of 4 in [4, 1024]");
@@ -180,6 +206,7 @@ extern "C" int ldetr_layernorm_fwd_pos_f32(const float* x, const float* residual
     p.x = x; p.r = residual; p.gamma = gamma; p.beta = beta; p.y = y; p.z = z; p.mean = mean; p.rstd = rstd;
     p.rows = rows; p.D = D; p.eps = eps; p.p_drop = p_drop; p.seed = seed; p.seed_ptr = (const unsigned long long*)seed_ptr;
     p.pos = pos; p.pos_rows = pos_rows; p.ypos = ypos;
+    p.r_parts = n_parts; p.r_part_stride = part_stride; p.r_bias = n_parts > 0 ? part_bias : nullptr;
     int grid = (int)((rows + 3) / 4);
     hipStream_t st = (hipStream_t)stream;
     int nv = (D + 255) / 256;
@@ -200,6 +227,14 @@ extern "C" int ldetr_layernorm_bwd_f32(const float* dy, const float* z, const fl
 extern "C" int ldetr_layernorm_bwd2_f32(const float* dy, const float* dy2, const float* z, const float* mean, const float* rstd, const float* gamma,
                                         float* dx, float* dresidual, float* dgamma, float* dbeta, int64_t rows, int D,
                                         float p_drop, uint64_t seed, const uint64_t* seed_ptr, void* stream) {
+    return ldetr_layernorm_bwd_parts_f32(dy, dy2, nullptr, 0, 0, z, mean, rstd, gamma, dx, dresidual, dgamma, dbeta, rows, D, p_drop, seed, seed_ptr, stream);
+}
+
+extern "C" int ldetr_layernorm_bwd_parts_f32(const float* dy, const float* dy2, const float* dy_parts, int n_parts, int64_t part_stride,
+                                             const float* z, const float* mean, const float* rstd, const float* gamma,
+                                             float* dx, float* dresidual, float* dgamma, float* dbeta, int64_t rows, int D,
+                                             float p_drop, uint64_t seed, const uint64_t* seed_ptr, void* stream) {
+    LDETR_CHECK(n_parts >= 0 && (n_parts == 0 || (dy_parts && part_stride >= rows * D)), "layernorm_bwd: bad partial-sum arguments");
     LDETR_CHECK(dy && z && mean && rstd && gamma, "layernorm_bwd: null pointer");
     LDETR_CHECK(D % 4 == 0 && D >= 4 && D <= 1024, "layernorm_bwd: D must be a multiple of 4 in [4, 1024]");
     LDETR_CHECK((dgamma == nullptr) == (dbeta == nullptr), "layernorm_bwd: dgamma and dbeta go together");
@@ -207,6 +242,7 @@ extern "C" int ldetr_layernorm_bwd2_f32(const float* dy, const float* dy2, const
     LnParams p; memset(&p, 0, sizeof(p));
     p.dy = dy; p.z = const_cast<float*>(z); p.mean = const_cast<float*>(mean); p.rstd = const_cast<float*>(rstd);
     p.gamma = gamma; p.dx = dx; p.dr = dresidual; p.dgamma = dgamma; p.dbeta = dbeta; p.dy2 = dy2;
+    p.dy_parts = dy_parts; p.dy_nparts = n_parts; p.dy_part_stride = part_stride;
     p.rows = rows; p.D = D; p.p_drop = p_drop; p.seed = seed; p.seed_ptr = (const unsigned long long*)seed_ptr;
     int grid = (int)((rows + 3) / 4);
     if (grid > 512) grid = 512;

@@ -34,6 +34,7 @@ struct AdamParams {
     float* p; const float* g; float* m; float* v; long n;
     float lr, b1, b2, eps, bc1, bc2_sqrt;
     int fuse_sanitize; float gscale, nanv, posinf, neginf;
+    float* pe; float ema_beta;      // optional: p_ema = lerp(p_new, p_ema, beta) in the same pass (G_ema, training_loop.py:320-328)
 };
 
 __device__ __forceinline__ void adam_elem(float& p, float g, float& m, float& v, const AdamParams& a) {
@@ -61,9 +62,16 @@ __global__ __launch_bounds__(256) void adam_kernel(AdamParams a) {
         reinterpret_cast<float4*>(a.p)[i] = p;
         __builtin_nontemporal_store(f32x4{m.x, m.y, m.z, m.w}, reinterpret_cast<f32x4*>(a.m) + i);
         __builtin_nontemporal_store(f32x4{v.x, v.y, v.z, v.w}, reinterpret_cast<f32x4*>(a.v) + i);
+        if (a.pe) {   // the G_ema lerp rides along: the updated parameters are in registers, p is not read a second time
+            const f32x4 ev = __builtin_nontemporal_load(reinterpret_cast<f32x4*>(a.pe) + i);
+            __builtin_nontemporal_store(f32x4{p.x + a.ema_beta * (ev[0] - p.x), p.y + a.ema_beta * (ev[1] - p.y),
+                                              p.z + a.ema_beta * (ev[2] - p.z), p.w + a.ema_beta * (ev[3] - p.w)}, reinterpret_cast<f32x4*>(a.pe) + i);
+        }
     }
-    for (long i = (n4 << 2) + (long)blockIdx.x * blockDim.x + threadIdx.x; i < a.n; i += stride)
+    for (long i = (n4 << 2) + (long)blockIdx.x * blockDim.x + threadIdx.x; i < a.n; i += stride) {
         adam_elem(a.p[i], a.g[i], a.m[i], a.v[i], a);
+        if (a.pe) a.pe[i] = a.p[i] + a.ema_beta * (a.pe[i] - a.p[i]);
+    }
 }
 
 __global__ __launch_bounds__(256) void ema_kernel(float* pe, const float* p, long n, float beta) {
@@ -105,6 +113,17 @@ extern "C" int ldetr_grad_sanitize_f32(float* g, int64_t n, float scale, float n
 extern "C" int ldetr_adam_step_f32(float* p, const float* g, float* m, float* v, int64_t n, int64_t step,
                                    float lr, float beta1, float beta2, float eps,
                                    int fuse_sanitize, float gscale, float nan_value, float posinf, float neginf, void* stream) {
+    return ldetr_adam_ema_step_f32(p, g, m, v, n, step, lr, beta1, beta2, eps, fuse_sanitize, gscale, nan_value, posinf, neginf, nullptr, 0.f, stream);
+}
+
+// ... with the exponential moving average of the parameters updated in the same pass: p_ema = p_new + ema_beta * (p_ema - p_new)
+// (training_loop.py:320-328 runs it after the last phase of the iteration; G's parameters do not change between G's optimiser step and
+// that point, so the value is the same).  p_ema == NULL: plain Adam.
+extern "C" int ldetr_adam_ema_step_f32(float* p, const float* g, float* m, float* v, int64_t n, int64_t step,
+                                       float lr, float beta1, float beta2, float eps,
+                                       int fuse_sanitize, float gscale, float nan_value, float posinf, float neginf,
+                                       float* p_ema, float ema_beta, void* stream) {
+    LDETR_CHECK(!p_ema || (((uintptr_t)p_ema) & 15) == 0, "adam_step: p_ema must be 16-byte aligned");
     LDETR_CHECK((p && g && m && v) || n == 0, "adam_step: null pointer");
     LDETR_CHECK((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0, "adam_step: buffers must be 16-byte aligned");
     LDETR_CHECK(step >= 1, "adam_step: step must be >= 1");
@@ -115,6 +134,7 @@ extern "C" int ldetr_adam_step_f32(float* p, const float* g, float* m, float* v,
     double bc2 = 1.0 - pow((double)beta2, (double)step);
     a.bc1 = (float)bc1; a.bc2_sqrt = (float)sqrt(bc2);
     a.fuse_sanitize = fuse_sanitize; a.gscale = gscale; a.nanv = nan_value; a.posinf = posinf; a.neginf = neginf;
+    a.pe = p_ema; a.ema_beta = ema_beta;
     hipLaunchKernelGGL(adam_kernel, stream_grid(n), 256, 0, (hipStream_t)stream, a);
     return check_launch("adam_step");
 }

@@ -142,7 +142,7 @@ class _GroupedKVFn(torch.autograd.Function):
         ctx.params = (Ws, bs)
         ctx.cfg = (n, d, M)
         ctx.holder = holder
-        holder.dKV = None
+        holder.dK = holder.dV = None
         return tuple(KV[:, i * d:(i + 1) * d] for i in range(2 * n))
 
     @staticmethod
@@ -151,26 +151,27 @@ class _GroupedKVFn(torch.autograd.Function):
         n, d, M = ctx.cfg
         Ws, bs = ctx.params
         nd = n * d
-        dKV = ctx.holder.dKV
-        if dKV is None:
-            dKV = torch.zeros((M, 2 * nd), device=mp.device, dtype=torch.float32)
-        for i, g in enumerate(grads):      # blocks the attention backward wrote in place arrive as views of dKV: nothing to do for them
-            dst = dKV[:, i * d:(i + 1) * d]
+        dK, dV = ctx.holder.dK, ctx.holder.dV          # two packed [M, n d] buffers (the weight-gradient GEMM's row sums need a packed operand)
+        fresh = dK is None
+        if fresh:
+            dK = torch.zeros((M, nd), device=mp.device, dtype=torch.float32); dV = torch.zeros((M, nd), device=mp.device, dtype=torch.float32)
+        for i, g in enumerate(grads):      # blocks the attention backward wrote in place arrive as views of dK / dV: nothing to do for them
+            dst = (dK if i < n else dV)[:, (i % n) * d:(i % n + 1) * d]
             if g is None:
-                if ctx.holder.dKV is not None:
+                if not fresh:
                     dst.zero_()
             elif g.data_ptr() != dst.data_ptr() or g.stride() != dst.stride():
                 dst.copy_(g)
-        ctx.holder.dKV = None
-        dmp = core.gemm(dKV[:, :nd], Wk[:nd], 0, 1, M, d, nd) if ctx.needs_input_grad[0] else None
-        dmm = core.gemm(dKV[:, nd:], Wk[nd:], 0, 1, M, d, nd) if ctx.needs_input_grad[1] else None
+        ctx.holder.dK = ctx.holder.dV = None
+        dmp = core.gemm(dK, Wk[:nd], 0, 1, M, d, nd) if ctx.needs_input_grad[0] else None
+        dmm = core.gemm(dV, Wk[nd:], 0, 1, M, d, nd) if ctx.needs_input_grad[1] else None
         need_w = any(ctx.needs_input_grad[3 + 2 * i] for i in range(n)) and not core.WEIGHT_GRADIENTS_DISABLED[0]
         out = [None] * (2 * n)
         if need_w:
             T = torch.empty((2, nd, d), device=mp.device, dtype=torch.float32)
             tb = torch.zeros((2, nd), device=mp.device, dtype=torch.float32)
-            core.gemm(dKV[:, :nd], mp, 1, 1, nd, d, M, out=T[0], ep=core.epilogue(a_rowsum=tb[0]))
-            core.gemm(dKV[:, nd:], mm, 1, 1, nd, d, M, out=T[1], ep=core.epilogue(a_rowsum=tb[1]))
+            core.gemm(dK, mp, 1, 1, nd, d, M, out=T[0], ep=core.epilogue(a_rowsum=tb[0]))
+            core.gemm(dV, mm, 1, 1, nd, d, M, out=T[1], ep=core.epilogue(a_rowsum=tb[1]))
             gws, gbs = [core.flat_grad(w) for w in Ws], [core.flat_grad(b) for b in bs]
             strided = all(g is not None for g in gws + gbs) and n > 1
             if strided:       # the layers' parameters sit at a constant pitch in the flat gradient buffer: one strided add for all of them
@@ -198,9 +199,9 @@ class _GroupedKVFn(torch.autograd.Function):
 
 
 class _KVHolder(object):
-    """Shared between a grouped projection and the attention calls that read it: the [M, 2 n d] gradient buffer (allocated by the first
-    attention backward that needs it)."""
-    dKV = None
+    """Shared between a grouped projection and the attention calls that read it: the two [M, n d] gradient buffers (allocated by the first
+    attention backward that needs them)."""
+    dK = dV = None
 
 
 def grouped_kv(mem_pos, mem, mhas):
@@ -212,11 +213,10 @@ def grouped_kv(mem_pos, mem, mhas):
 
     def dst(i):
         def views():
-            if holder.dKV is None:
-                holder.dKV = torch.empty((M, 2 * n * d), device=mem.device, dtype=torch.float32)
-                holder.written = set()
-            holder.written.add(i)
-            return holder.dKV[:, i * d:(i + 1) * d], holder.dKV[:, (n + i) * d:(n + i + 1) * d]
+            if holder.dK is None:      # zero-filled: a layer whose attention backward never runs contributes nothing
+                holder.dK = torch.zeros((M, n * d), device=mem.device, dtype=torch.float32)
+                holder.dV = torch.zeros((M, n * d), device=mem.device, dtype=torch.float32)
+            return holder.dK[:, i * d:(i + 1) * d], holder.dV[:, i * d:(i + 1) * d]
         return views
     return [(outs[i], outs[n + i], dst(i)) for i in range(n)]
 

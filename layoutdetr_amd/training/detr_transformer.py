@@ -16,6 +16,7 @@ from torch import Tensor, nn
 
 from ..hip import core
 from ..hip.attention import grouped_kv, mha_cross_kv, mha_forward
+from ..hip import ffn as hffn
 from ..hip.layernorm import add_layernorm
 from ..hip.linear import linear
 
@@ -78,6 +79,19 @@ def _add_ln(norm: nn.LayerNorm, x2, r2, drop: nn.Dropout, training, pos=None):
     return add_layernorm(x2, r2, norm.weight, norm.bias, norm.eps, drop.p if training else 0.0, pos=pos)
 
 
+def _add_ln_ffn_add_ln(layer, norm_a: nn.LayerNorm, x2, r2, drop_a: nn.Dropout, norm_b: nn.LayerNorm, drop_b: nn.Dropout, pos=None):
+    """The tail of a layer: x1 = norm_a(x + dropout(r)); norm_b(x1 + dropout(linear2(dropout(relu(linear1(x1)))))) (detr_transformer.py:210-214
+    / 280-285).  On the token counts of the decoder-side stacks ONE autograd node of 3 launches forward / 4 backward (hip/ffn.py: fused
+    feed-forward launch, its partial sums reduced inside the LayerNorm launches); otherwise LayerNorm, two GEMMs, LayerNorm."""
+    t = layer.training
+    if hffn.usable(x2, layer.linear1, layer.linear2):
+        return hffn.add_ln_ffn_add_ln(x2, r2, norm_a, drop_a.p if t else 0.0, layer.linear1, layer.linear2, norm_b, layer.dropout.p if t else 0.0,
+                                      drop_b.p if t else 0.0, pos=pos)
+    x2 = _add_ln(norm_a, x2, r2, drop_a, t)
+    f, x2 = _ffn(layer, x2)
+    return _add_ln(norm_b, x2, f, drop_b, t, pos=pos)
+
+
 class TransformerEncoderLayer(nn.Module):
     def __init__(self, d_model, nhead, dim_feedforward=2048, dropout=0.1, activation='relu', normalize_before=False):
         super().__init__()
@@ -96,9 +110,7 @@ class TransformerEncoderLayer(nn.Module):
     def forward2d(self, x2, B, L, kpm, pos2, xpos2=None, emit_pos=False):
         """xpos2: x2 + pos2 when the producer already formed it (the previous layer's norm2 emits it: emit_pos) -> (y2[, y2 + pos2])."""
         a, x2 = _mha(self.self_attn, x2, x2, x2, B, L, L, kpm, self.training, same_qk=pos2 is not None, same_qkv=pos2 is None, qk_pos=pos2, qk_in=xpos2)
-        x2 = _add_ln(self.norm1, x2, a, self.dropout1, self.training)
-        f, x2 = _ffn(self, x2)
-        return _add_ln(self.norm2, x2, f, self.dropout2, self.training, pos=pos2 if emit_pos else None)
+        return _add_ln_ffn_add_ln(self, self.norm1, x2, a, self.dropout1, self.norm2, self.dropout2, pos=pos2 if emit_pos else None)
 
 
 class TransformerDecoderLayer(nn.Module):
@@ -131,9 +143,7 @@ class TransformerDecoderLayer(nn.Module):
                                  key_padding_mask=mem_kpm, p_drop=m.dropout if self.training else 0.0)
         else:
             a, t2, mem_pos2, mem2 = _mha(self.multihead_attn, t2, mem_pos2, mem2, B, Lq, S, mem_kpm, self.training, kv_alias=True)
-        t2 = _add_ln(self.norm2, t2, a, self.dropout2, self.training)
-        f, t2 = _ffn(self, t2)
-        return _add_ln(self.norm3, t2, f, self.dropout3, self.training), mem2, mem_pos2
+        return _add_ln_ffn_add_ln(self, self.norm2, t2, a, self.dropout2, self.norm3, self.dropout3), mem2, mem_pos2
 
 
 def _get_clones(module, N):

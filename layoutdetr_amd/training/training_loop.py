@@ -159,8 +159,10 @@ class DataParallelStep(object):
             torch.cuda.current_stream().wait_stream(self.comm_stream)
         self._pending = False
 
-    def apply(self, phase, exchanged=False):
-        """exchanged=True: the caller already reduced the gradient segment by segment (exchange_async); only join here."""
+    def apply(self, phase, exchanged=False, ema=None):
+        """exchanged=True: the caller already reduced the gradient segment by segment (exchange_async); only join here.
+        ema = (flat p_ema buffer, beta): the G_ema lerp of training_loop.py:320-328 in the same pass over the parameters (G's parameters do
+        not change between this step and the end of the iteration, where the reference updates G_ema)."""
         fm = phase.fm
         core.join_side()   # weight-gradient launches of a backward that was not run through Loss.accumulate_gradients
         ev = None
@@ -180,9 +182,11 @@ class DataParallelStep(object):
             raise RuntimeError('DataParallelStep.apply: parameters must live in GPU memory (no CPU fallback)')
         if not self.fuse:
             core.check(core.lib().ldetr_grad_sanitize_f32(core.ptr(fm.gflat), fm.total, scale, 0.0, 1e5, -1e5, core.stream()), 'grad_sanitize')
-        core.check(core.lib().ldetr_adam_step_f32(core.ptr(fm.flat), core.ptr(fm.gflat), core.ptr(phase.m), core.ptr(phase.v), fm.total,
-                                                  phase.step, phase.lr, phase.betas[0], phase.betas[1], phase.eps,
-                                                  1 if self.fuse else 0, scale, 0.0, 1e5, -1e5, core.stream()), 'adam_step')
+        core.check(core.lib().ldetr_adam_ema_step_f32(core.ptr(fm.flat), core.ptr(fm.gflat), core.ptr(phase.m), core.ptr(phase.v), fm.total,
+                                                      phase.step, phase.lr, phase.betas[0], phase.betas[1], phase.eps,
+                                                      1 if self.fuse else 0, scale, 0.0, 1e5, -1e5,
+                                                      core.ptr(ema[0]) if ema is not None else None, float(ema[1]) if ema is not None else 0.0,
+                                                      core.stream()), 'adam_step')
 
 
 class EmaTracker(object):
@@ -200,12 +204,24 @@ class EmaTracker(object):
         self.fm.gflat = None
         self._buf_versions = {}
 
-    def update(self, batch_size, ema_kimg, cur_nimg, ema_rampup=0.05):
+    @staticmethod
+    def beta(batch_size, ema_kimg, cur_nimg, ema_rampup=0.05):
         ema_nimg = ema_kimg * 1000
         if ema_rampup is not None:
             ema_nimg = min(ema_nimg, cur_nimg * ema_rampup)
-        beta = 0.5 ** (batch_size / max(ema_nimg, 1e-8))
-        core.check(core.lib().ldetr_ema_lerp_f32(core.ptr(self.fm.flat), core.ptr(self.src.flat), self.src.total, float(beta), core.stream()), 'ema_lerp')
+        return 0.5 ** (batch_size / max(ema_nimg, 1e-8))
+
+    def fused(self, phase, batch_size, ema_kimg, cur_nimg, ema_rampup=0.05):
+        """-> (p_ema flat buffer, beta) for DataParallelStep.apply(ema=...) when `phase` is the module this tracker follows, else None."""
+        if phase.fm is not self.src or batch_size is None or ema_kimg is None:
+            return None
+        return self.fm.flat, self.beta(batch_size, ema_kimg, cur_nimg, ema_rampup)
+
+    def update(self, batch_size, ema_kimg, cur_nimg, ema_rampup=0.05, lerp_done=False):
+        """lerp_done: the parameter lerp already ran inside G's optimiser pass (fused()); only the buffers are synchronised here."""
+        if not lerp_done:
+            beta = self.beta(batch_size, ema_kimg, cur_nimg, ema_rampup)
+            core.check(core.lib().ldetr_ema_lerp_f32(core.ptr(self.fm.flat), core.ptr(self.src.flat), self.src.total, float(beta), core.stream()), 'ema_lerp')
         for i, (b_ema, b) in enumerate(zip(self.G_ema.buffers(), self.G.buffers())):
             ver = (b._version, b.data_ptr())
             if self._buf_versions.get(i) != ver:      # buffers are frozen statistics: copy only when they changed
@@ -475,6 +491,7 @@ def training_iteration(loss, phases, dp, batch, batch_gpu, gen_z_per_phase, ema=
             d_stages = BackwardStages()
         for s in range(0, b, batch_gpu):
             loss.precompute_D_trunk(batch['background'][s:s + batch_gpu], stages=d_stages)
+    lerp_done = False
     for pi, (phase, gen_z) in enumerate(zip(phases, gen_z_per_phase)):
         phase.fm.zero_grad()
         phase.module.requires_grad_(True)
@@ -491,9 +508,11 @@ def training_iteration(loss, phases, dp, batch, batch_gpu, gen_z_per_phase, ema=
         staged = overlap and b <= batch_gpu
         exchanged = staged_backward(loss, phase, dp, accumulate, stages=(d_stages if (iter_share and phase.name == 'Dmain') else None)) if staged else (accumulate() or False)
         phase.module.requires_grad_(False)
-        dp.apply(phase, exchanged=True) if exchanged else dp.apply(phase)
+        fe = ema.fused(phase, batch_size, ema_kimg, cur_nimg, ema_rampup) if ema is not None else None
+        lerp_done = lerp_done or fe is not None
+        dp.apply(phase, exchanged=bool(exchanged), ema=fe)
     if ema is not None:
-        ema.update(batch_size, ema_kimg, cur_nimg, ema_rampup=ema_rampup)
+        ema.update(batch_size, ema_kimg, cur_nimg, ema_rampup=ema_rampup, lerp_done=lerp_done)
 
 
 class GraphedIteration(object):
@@ -515,6 +534,7 @@ class GraphedIteration(object):
         self.capture_stream = capture_stream
         self.loss, self.phases, self.dp, self.batch, self.batch_gpu = loss, phases, dp, batch, batch_gpu
         self.ema, self.batch_size, self.ema_kimg = ema, batch_size, ema_kimg
+        self.ema_rampup = 0.05
         self.cur_nimg = 0
         self.graphs = []       # per phase: [(graph, flat segment exchanged after it | None)]
         dev = batch['bbox_real'].device
@@ -589,6 +609,7 @@ class GraphedIteration(object):
     def run(self):
         if self.pre_graph is not None:
             self.pre_graph.replay()
+        lerp_done = False
         for phase, chain in zip(self.phases, self.graphs):
             exchanged = False
             for g, seg in chain:
@@ -597,9 +618,11 @@ class GraphedIteration(object):
                     for lo, hi in seg:
                         self.dp.exchange_async(phase.fm.gflat, lo, hi)
                     exchanged = True
-            self.dp.apply(phase, exchanged=True) if exchanged else self.dp.apply(phase)
+            fe = self.ema.fused(phase, self.batch_size, self.ema_kimg, self.cur_nimg, self.ema_rampup) if self.ema is not None else None
+            lerp_done = lerp_done or fe is not None
+            self.dp.apply(phase, exchanged=exchanged, ema=fe)
         if self.ema is not None:
-            self.ema.update(self.batch_size, self.ema_kimg, self.cur_nimg)
+            self.ema.update(self.batch_size, self.ema_kimg, self.cur_nimg, ema_rampup=self.ema_rampup, lerp_done=lerp_done)
         if self.batch_size:
             self.cur_nimg += self.batch_size
 

@@ -337,11 +337,11 @@ def _full_iteration_vs_oracle(dev, bg, B, seed, tag, text_on=False, flip_toleran
     grads, terms = {}, {}
     orig = dp.apply
 
-    def spy(phase):
+    def spy(phase, **kw):
         grads[phase.name] = {n: p.grad.detach().clone() for n, p in phase.module.named_parameters() if p.grad is not None}
         terms[phase.name] = {k + (f'#{i}' if len(vs) > 1 else ''): v for k, vs in reports.items() for i, v in enumerate(vs)}
         reports.clear()
-        orig(phase)
+        orig(phase, **kw)
     dp.apply = spy
     batch = device_batch(bt, dev)
     if toks is not None:
@@ -366,25 +366,24 @@ def _full_iteration_vs_oracle(dev, bg, B, seed, tag, text_on=False, flip_toleran
             if a > max(3 * b, 1e-4):
                 bad.append((a, b, phase, k))
     e_gpu, e_cpu = np.array(e_gpu), np.array(e_cpu)
-    # Flip-free discriminator.  A tensor the CPU fp32 run gets within 1e-4 of fp64 is one no flipped unit reached in THAT evaluation; on
-    # those tensors, grouped by the kernel that produces them (3x3 / 1x1 / strided conv weight gradients, linear weights, packed
-    # attention projections, biases, LayerNorm, modulated-conv weights, ...), the MEDIAN HIP error of a family must be <= 1e-4 too.  A flip
-    # on the GPU side moves the tensors upstream of one unit, never a whole family's median; a systematic error in one kernel (say 5 % in
-    # a weight-gradient path) moves every member of its family and fails here even where the distributional gates below are loose.
+    # Per-kernel-family discriminator.  Gradient tensors grouped by the kernel path that produces them (3x3 / 1x1 / strided conv weight
+    # gradients, linear weights, packed attention projections, biases, LayerNorm, modulated-conv weights, ...): the MEDIAN HIP error of
+    # a family (vs fp64) must be <= 1e-4, or -- where flipped ReLU units reach most of a family in ANY fp32 evaluation (the ResNet trunk:
+    # every tensor upstream of a flipped unit moves together) -- within 3x of the CPU fp32 run's own median for that family.  A flip
+    # on the GPU side moves some tensors, never the median of a family the CPU run gets right; a systematic error in one kernel (say
+    # 5 % in a weight-gradient path) moves every member of its family and fails here even where the distributional gates below are loose.
     fams = {}
     idx = 0
     for phase, i in (('Gmain', 1), ('Dmain', 2)):
         for k in o64[i]:
-            if e_cpu[idx] < 1e-4:
-                fams.setdefault(_kernel_family(k, tuple(o64[i][k].shape)), []).append(e_gpu[idx])
+            fams.setdefault(_kernel_family(k, tuple(o64[i][k].shape)), []).append((e_gpu[idx], e_cpu[idx]))
             idx += 1
-    fam_med = {f: float(np.median(v)) for f, v in fams.items() if len(v) >= 4}
-    print(f'[{tag}] flip-free families (median HIP error vs fp64 over tensors CPU fp32 gets < 1e-4; members): '
-          + ', '.join(f'{f} {m:.1e} ({len(fams[f])})' for f, m in sorted(fam_med.items(), key=lambda t: -t[1])))
-    assert sum(len(v) for v in fams.values()) >= 0.2 * len(e_gpu), 'too few flip-free tensors to judge'
     fam_tol = 5e-4 if flip_tolerant else 1e-4    # (512 x 512: a GPU-side flip in a decoder layer moves more than half of a phase's tensors by ~1e-4)
-    for f, m in fam_med.items():
-        assert m <= fam_tol, f'{tag}: kernel family {f}: median error {m:.2e} on {len(fams[f])} flip-free tensors'
+    fam_med = {f: (float(np.median([a for a, _ in v])), float(np.median([b for _, b in v])), len(v)) for f, v in fams.items() if len(v) >= 4}
+    print(f'[{tag}] kernel families, median error vs fp64 HIP / CPU fp32 (members): '
+          + ', '.join(f'{f} {g:.1e} / {c:.1e} ({n})' for f, (g, c, n) in sorted(fam_med.items(), key=lambda t: -t[1][0])))
+    for f, (g, c, n) in fam_med.items():
+        assert g <= max(fam_tol, 3 * c), f'{tag}: kernel family {f}: median error {g:.2e} over {n} tensors (CPU fp32: {c:.2e})'
     print(f'[{tag}] worst loss-term err {worst_term:.2e}; gradient error vs fp64 oracle: HIP median {np.median(e_gpu):.2e} p90 {np.quantile(e_gpu, .9):.2e} '
           f'max {e_gpu.max():.2e} | CPU fp32 median {np.median(e_cpu):.2e} p90 {np.quantile(e_cpu, .9):.2e} max {e_cpu.max():.2e}; '
           f'{len(bad)} of {len(e_gpu)} tensors beyond 3x the CPU-fp32 error: {sorted(bad, reverse=True)[:3]}')
@@ -478,7 +477,7 @@ def test_text_path_at_max_length_256_mostly_padding_vs_bert_ref(dev):
     named = dict(dec.named_parameters())
     worst = 0.0
     for k, v in leaf.items():
-        if v.grad is None or k not in named or named[k].grad is None:
+        if v.grad is None or k not in named or named[k].grad is None or k.endswith('key.bias'):     # (d/d key-bias of a softmax is exactly 0: rounding noise on both sides)
             continue
         worst = max(worst, check(named[k].grad, v.grad, 2e-3, 'LM decoder grad ' + k))
     print(f'[T=256 mostly padding] CLS {e_enc:.2e}, LM loss {e_lm:.2e}, worst decoder gradient {worst:.2e}')
