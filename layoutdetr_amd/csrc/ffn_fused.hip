@@ -63,22 +63,26 @@ __global__ __launch_bounds__(256) void ffn_fwd_kernel(FfnParams p) {
     const int OOB = (int)0x80000000;
     // ---- phase 1: wave (ct, kh) = 32 hidden units x half of the 256-long reduction
     const int ct = wave & 1, kh = wave >> 1;
+    float b2[2][2][16];      // phase 2's weights: W2[(2 wave + q) * 32 + cl][j0 + 32 c + 16 kl ..]
     {
-        const __amdgpu_buffer_rsrc_t rsX = rsrc(p.x), rsW = rsrc(p.w1);
+        const __amdgpu_buffer_rsrc_t rsX = rsrc(p.x), rsW = rsrc(p.w1), rsW2 = rsrc(p.w2);
         const int vA = (m0 + cl < p.M) ? (int)(((long)(m0 + cl) * p.ldx + kh * 128 + 16 * kl) * 4) : OOB;
         const int vB = ((j0 + ct * 32 + cl) * FD + kh * 128 + 16 * kl) * 4;
         ffn_acc_t acc;
 #pragma unroll
         for (int r = 0; r < 16; r++) acc[r] = 0.f;
-        float a0[16], b0[16], a1[16], b1[16];
-        ld_k16(rsX, vA, 0, a0); ld_k16(rsW, vB, 0, b0);
-        ld_k16(rsX, vA, 128, a1); ld_k16(rsW, vB, 128, b1);
-        FFN_MFMA16(a0, b0, acc);
-        ld_k16(rsX, vA, 256, a0); ld_k16(rsW, vB, 256, b0);
-        FFN_MFMA16(a1, b1, acc);
-        ld_k16(rsX, vA, 384, a1); ld_k16(rsW, vB, 384, b1);
-        FFN_MFMA16(a0, b0, acc);
-        FFN_MFMA16(a1, b1, acc);
+        // every operand of the block is requested before the first MFMA (the whole reduction of a wave is 4 chunks: ONE memory round
+        // trip instead of three -- at 18..320 tokens the launch is that round trip), the second GEMM's weights included
+        float a[4][16], b[4][16];
+#pragma unroll
+        for (int c = 0; c < 4; c++) { ld_k16(rsX, vA, c * 128, a[c]); ld_k16(rsW, vB, c * 128, b[c]); }
+#pragma unroll
+        for (int q = 0; q < 2; q++)
+#pragma unroll
+            for (int c = 0; c < 2; c++) ld_k16(rsW2, (((wave * 2 + q) * 32 + cl) * p.F + j0 + 16 * kl) * 4, c * 128, b2[q][c]);
+        __builtin_amdgcn_sched_barrier(0);      // keep every request ahead of the first MFMA (the scheduler otherwise sinks them next to their use)
+#pragma unroll
+        for (int c = 0; c < 4; c++) FFN_MFMA16(a[c], b[c], acc);
         if (kh == 1) {
 #pragma unroll
             for (int r = 0; r < 16; r++) red[ct][(r & 3) + 8 * (r >> 2) + 4 * kl][cl] = acc[r];
@@ -103,24 +107,18 @@ __global__ __launch_bounds__(256) void ffn_fwd_kernel(FfnParams p) {
     }
     // ---- phase 2: wave w -> output column tiles 2w, 2w+1 of Y_s = H (32 x 64) W2[:, slice]^T
     {
-        const __amdgpu_buffer_rsrc_t rsW = rsrc(p.w2);
         ffn_acc_t acc[2];
 #pragma unroll
         for (int q = 0; q < 2; q++)
 #pragma unroll
             for (int r = 0; r < 16; r++) acc[q][r] = 0.f;
-        float b[2][2][16];
-#pragma unroll
-        for (int q = 0; q < 2; q++)
-#pragma unroll
-            for (int c = 0; c < 2; c++) ld_k16(rsW, (((wave * 2 + q) * 32 + cl) * p.F + j0 + 16 * kl) * 4, c * 128, b[q][c]);
 #pragma unroll
         for (int c = 0; c < 2; c++) {
             float a[16];
 #pragma unroll
             for (int t = 0; t < 16; t++) a[t] = Hs[cl][c * 32 + 16 * kl + t];
-            FFN_MFMA16(a, b[0][c], acc[0]);
-            FFN_MFMA16(a, b[1][c], acc[1]);
+            FFN_MFMA16(a, b2[0][c], acc[0]);
+            FFN_MFMA16(a, b2[1][c], acc[1]);
         }
         float* dst = p.ypart + ((long)s * p.M) * FD;
 #pragma unroll
@@ -142,6 +140,7 @@ __global__ __launch_bounds__(256) void ffn_bwd_kernel(FfnParams p) {
     const int OOB = (int)0x80000000;
     const __amdgpu_buffer_rsrc_t rsDY = rsrc(p.dy), rsW1 = rsrc(p.w1), rsW2 = rsrc(p.w2), rsX = rsrc(p.x);
     const float inv_keep = p.p_drop > 0.f ? 1.f / (1.f - p.p_drop) : 1.f;
+    float b2[2][2][16];
     // ---- phase 1: dH (32 tokens x 64 hidden) = dY (32 x 256) W2[:, slice]; wave (ct, kh) as in the forward
     {
         const int ct = wave & 1, kh = wave >> 1;
@@ -151,15 +150,23 @@ __global__ __launch_bounds__(256) void ffn_bwd_kernel(FfnParams p) {
         ffn_acc_t acc;
 #pragma unroll
         for (int r = 0; r < 16; r++) acc[r] = 0.f;
-        float a0[16], b0[16], a1[16], b1[16];
-        ld_k16(rsDY, vA, 0, a0); ld_r16(rsW2, vB, 0, ld4, b0);
-        ld_k16(rsDY, vA, 128, a1); ld_r16(rsW2, vB, 32 * ld4, ld4, b1);
-        FFN_MFMA16(a0, b0, acc);
-        ld_k16(rsDY, vA, 256, a0); ld_r16(rsW2, vB, 64 * ld4, ld4, b0);
-        FFN_MFMA16(a1, b1, acc);
-        ld_k16(rsDY, vA, 384, a1); ld_r16(rsW2, vB, 96 * ld4, ld4, b1);
-        FFN_MFMA16(a0, b0, acc);
-        FFN_MFMA16(a1, b1, acc);
+        float a[4][16], b[4][16];
+#pragma unroll
+        for (int c = 0; c < 4; c++) { ld_k16(rsDY, vA, c * 128, a[c]); ld_r16(rsW2, vB, c * 32 * ld4, ld4, b[c]); }
+#pragma unroll
+        for (int q = 0; q < 2; q++)
+#pragma unroll
+            for (int c = 0; c < 2; c++)      // phase 2's weights, element (k = j, row = c): w1[(j0 + j) * 256 + c]
+                ld_r16(rsW1, ((wave * 2 + q) * 32 + cl + (j0 + c * 32 + 16 * kl) * FD) * 4, 0, FD * 4, b2[q][c]);
+        float hvs[16];      // the saved hidden values of this wave's output tile (relu / dropout mask), requested with everything else
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const long m = m0 + (r & 3) + 8 * (r >> 2) + 4 * kl;
+            hvs[r] = (kh == 0 && m < p.M) ? p.h[m * p.F + j0 + ct * 32 + cl] : 0.f;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int c = 0; c < 4; c++) FFN_MFMA16(a[c], b[c], acc);
         if (kh == 1) {
 #pragma unroll
             for (int r = 0; r < 16; r++) red[ct][(r & 3) + 8 * (r >> 2) + 4 * kl][cl] = acc[r];
@@ -170,7 +177,7 @@ __global__ __launch_bounds__(256) void ffn_bwd_kernel(FfnParams p) {
             for (int r = 0; r < 16; r++) {
                 const int row = (r & 3) + 8 * (r >> 2) + 4 * kl;
                 const long m = m0 + row;
-                const float hv = m < p.M ? p.h[m * p.F + j0 + ct * 32 + cl] : 0.f;
+                const float hv = hvs[r];
                 // relu'(pre) and the dropout mask in one test: the saved hidden value is positive exactly where both let the gradient through
                 const float dh = hv > 0.f ? (acc[r] + red[ct][row][cl]) * inv_keep : 0.f;
                 dHs[row][ct * 32 + cl] = dh;
@@ -186,20 +193,13 @@ __global__ __launch_bounds__(256) void ffn_bwd_kernel(FfnParams p) {
         for (int q = 0; q < 2; q++)
 #pragma unroll
             for (int r = 0; r < 16; r++) acc[q][r] = 0.f;
-        const int ld4 = FD * 4;
-        float b[2][2][16];
-#pragma unroll
-        for (int q = 0; q < 2; q++)
-#pragma unroll
-            for (int c = 0; c < 2; c++)      // element (k = j, row = c): w1[(j0 + j) * 256 + c]
-                ld_r16(rsW1, ((wave * 2 + q) * 32 + cl + (j0 + c * 32 + 16 * kl) * FD) * 4, 0, ld4, b[q][c]);
 #pragma unroll
         for (int c = 0; c < 2; c++) {
             float a[16];
 #pragma unroll
             for (int t = 0; t < 16; t++) a[t] = dHs[cl][c * 32 + 16 * kl + t];
-            FFN_MFMA16(a, b[0][c], acc[0]);
-            FFN_MFMA16(a, b[1][c], acc[1]);
+            FFN_MFMA16(a, b2[0][c], acc[0]);
+            FFN_MFMA16(a, b2[1][c], acc[1]);
         }
         float* dst = p.dxpart + ((long)s * p.M) * FD;
 #pragma unroll

@@ -262,6 +262,9 @@ class StyleGAN2Loss(Loss):
             phase = {'Greg': 'none', 'Gboth': 'Gmain'}.get(phase, phase)
         if self.r1_gamma == 0:
             phase = {'Dreg': 'none', 'Dboth': 'Dmain'}.get(phase, phase)
+        n_dbg = int(os.environ.get('LDETR_DBG_EXTRA_LAUNCHES', '0'))     # development aid: what does a leaf launch cost inside the captured phase?
+        if n_dbg:
+            self._dbg_extra = [torch.full((64,), 1.0, device=bbox_real.device) for _ in range(n_dbg)]
         if phase == 'Gmain':
             self.g_main_loss(bbox_real, bbox_class, bbox_text, bbox_patch, padding_mask, background, gen_z, gen_c).mul(gain).backward()
             core.join_side()

@@ -11,7 +11,7 @@ fi
 if [ -n "$PROF" ]; then
   cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
   rm -rf gpurun_out/$tag/prof
-  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/$tag/prof -- python bench.py --no-cpu-baseline --no-extra --no-roofline --steps 16 --warmup 4 > $out/prof_bench.log 2>&1
+  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/$tag/prof -- python bench.py --no-cpu-baseline --no-extra --no-roofline --steps 16 --warmup 4 $BENCH_ARGS > $out/prof_bench.log 2>&1
   f=$(find gpurun_out/$tag/prof -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $out/kernel_stats.csv
   find gpurun_out/$tag/prof -type f ! -name "*kernel_stats.csv" -delete
   tail -2 $out/prof_bench.log | cut -c1-300
@@ -25,7 +25,7 @@ for v in "$@"; do
     *) export LDETR_LIB=$PWD/layoutdetr_amd/lib/variants/libldetr_hip_$v.so ;;
   esac
   for rep in 1 2; do
-    timeout 300 python bench.py --no-cpu-baseline --no-extra --no-roofline --steps 20 --warmup 5 > $out/bench_${vv}_$rep.json 2> $out/bench_${vv}_$rep.err
+    timeout 300 python bench.py --no-cpu-baseline --no-extra --no-roofline --steps 20 --warmup 5 $BENCH_ARGS > $out/bench_${vv}_$rep.json 2> $out/bench_${vv}_$rep.err
     python - <<PY
 import json
 try:
