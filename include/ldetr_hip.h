@@ -130,8 +130,9 @@ int ldetr_gemm_f32(const float* A, int64_t lda, int ta, const float* B, int64_t 
                    int M, int N, int K, int splitk, const ldetr_epilogue* ep, int pix_per_sample, void* stream);
 
 /* Two ldetr_gemm_f32 problems in one call, executed in order g0 then g1 (they may read the same operands; their outputs must not
- * overlap each other's inputs).  With g0 = (ta 0, tb 1) and g1 = (ta 1, tb 1) -- the data and the weight gradient of a linear layer --
- * and both in the small-tile class, they run as ONE kernel launch; otherwise as two.  Same results either way. */
+ * overlap each other's inputs).  With g0 = (ta 0, tb 1), g1 = (ta 1, tb 1) -- the data and the weight gradient of a linear layer -- or
+ * both (ta 1, tb 1) -- the two weight gradients of the fused feed-forward block -- and both in the small-tile class, they run as ONE
+ * kernel launch; otherwise as two.  Same results either way. */
 typedef struct ldetr_gemm_desc {
     const float* A; int64_t lda; int ta;
     const float* B; int64_t ldb; int tb;
@@ -139,13 +140,9 @@ typedef struct ldetr_gemm_desc {
     int M, N, K, splitk;
     const ldetr_epilogue* ep;
     int pix_per_sample;
-    /* single-launch path only: every element of op(A) is replaced by (a_mask > 0 ? A * a_mask_gain : 0), a_mask laid out like A --
-     * the gradient of a ReLU (+ dropout) layer folded into the dY loads of both problems; NULL = off */
-    const float* a_mask;
-    float a_mask_gain;
 } ldetr_gemm_desc;
 int ldetr_gemm_pair_f32(const ldetr_gemm_desc* g0, const ldetr_gemm_desc* g1, void* stream);
-/* 1 if the pair would run as one launch (then a_mask may be used), else 0. */
+/* 1 if the pair would run as one launch, else 0. */
 int ldetr_gemm_pair_is_single_launch(const ldetr_gemm_desc* g0, const ldetr_gemm_desc* g1);
 
 int ldetr_conv2d_fwd_f32(const float* x, const ldetr_tensor4* xt, const float* w, int Cout, int KH, int KW, int stride,

@@ -21,7 +21,7 @@ class Tensor4(Structure):
 class GemmDesc(Structure):
     _fields_ = [('A', c_void_p), ('lda', c_int64), ('ta', c_int), ('B', c_void_p), ('ldb', c_int64), ('tb', c_int),
                 ('C', c_void_p), ('ldc', c_int64), ('M', c_int), ('N', c_int), ('K', c_int), ('splitk', c_int),
-                ('ep', c_void_p), ('pix_per_sample', c_int), ('a_mask', c_void_p), ('a_mask_gain', c_float)]
+                ('ep', c_void_p), ('pix_per_sample', c_int)]
 
 
 class Epilogue(Structure):
@@ -116,7 +116,7 @@ def load():
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported
         fn.restype = c_int
         fn.argtypes = argtypes
-    if lib.ldetr_abi_version() != 17:
+    if lib.ldetr_abi_version() != 18:
         raise RuntimeError('libldetr_hip.so ABI version mismatch; rebuild it')
     _lib = lib
     return lib

@@ -97,7 +97,6 @@ struct GemmParams {
     int ep_vec;          // host-checked: every epilogue operand is float4-addressable -> LDS-staged row-major epilogue
     float* ws;           // split-K fix-up: per-(tile, slice) partial tiles; null = fp32 atomics into C
     int* ws_count;       //   per-tile arrival counters (zero between launches)
-    const float* a_mask; float a_mask_gain;   // small-tile kernels: A element := mask > 0 ? A * gain : 0 (ReLU gradient folded into the dY loads)
     long long* trace;    // development aid (tools/trace_tiles.py): 4 wall-clock stamps per block, or null
     int narrow;          // host: the 256x32 tile was chosen (lets one-k-tile-per-tap channel counts take the scalar-addressed loads)
     GemmEpilogue ep;
@@ -1228,16 +1227,8 @@ __device__ __forceinline__ void gemm_small_body(const GemmParams& p, const int b
     __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.B.p), 0, FAST ? 0x7fffffff : 0, 0x00020000);
     const int voffA = (m0 + cl < p.M) ? (TA == 0 ? ((m0 + cl) * (int)p.A.ld + 16 * kl) * 4 : (16 * kl * (int)p.A.ld + m0 + cl) * 4) : (int)0x80000000;
     const int voffB = (n0 + cl < p.N) ? (TB == 0 ? ((n0 + cl) * (int)p.B.ld + 16 * kl) * 4 : (16 * kl * (int)p.B.ld + n0 + cl) * 4) : (int)0x80000000;
-    __amdgpu_buffer_rsrc_t rsM = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.a_mask ? p.a_mask : p.A.p), 0, FAST ? 0x7fffffff : 0, 0x00020000);
     auto loadA = [&](int k0, float (&f)[16]) {
         if constexpr (FAST) small_load_fast<TA>(rsA, voffA, k0, (int)p.A.ld, f); else small_load<TA>(p.A, m0 + cl, p.M, k0, kl, kend, f);
-        if (p.a_mask) {   // dY of a ReLU (+ dropout) layer: the saved output decides which elements carry gradient
-            float mk[16];
-            if constexpr (FAST) small_load_fast<TA>(rsM, voffA, k0, (int)p.A.ld, mk);
-            else { Operand om = p.A; om.p = p.a_mask; small_load<TA>(om, m0 + cl, p.M, k0, kl, kend, mk); }
-#pragma unroll
-            for (int t = 0; t < 16; t++) f[t] = mk[t] > 0.f ? f[t] * p.a_mask_gain : 0.f;
-        }
     };
     auto loadB = [&](int k0, float (&f)[16]) {
         if constexpr (FAST) small_load_fast<TB>(rsB, voffB, k0, (int)p.B.ld, f); else small_load<TB>(p.B, n0 + cl, p.N, k0, kl, kend, f);
@@ -1382,181 +1373,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_small_pair_kernel(GemmParams p0,
 }
 
 static inline bool al16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
-#ifndef SKINNY_MIN_M
-#define SKINNY_MIN_M 4096
-#endif
 
-// ---------------------------------------------------------------------------------------------
-// Skinny-K dense contractions (the trunk's 1x1 convs and their data gradients with K = channels <= 256 on up to 2^20 pixels):
-// ~100 FLOP per byte of activation traffic at best, i.e. HBM-bound, and the LDS-tiled kernel above keeps too few bytes in
-// flight for that (load -> barrier -> 2 k-tiles -> store per block).  Here every wave keeps its 32 rows of A in registers as
-// MFMA operands for the whole launch (A is read exactly once, all of it in flight at once), B streams through LDS in
-// column chunks shared by the block's 4 waves, and each 32x32 product goes straight through the fused epilogue.
-//   TB: 0 = B stored [N, K] (conv weight OHWI / nn.Linear), 1 = B stored [K, N].   KS = ceil(K / 32) rounded up to 2, 4 or 8.
-template <int TB, int KS>
-__global__ __launch_bounds__(256, (KS == 2 ? 4 : (KS == 4 ? 3 : 2))) void gemm_skinny_kernel(GemmParams p, int cols_per_block, int NC) {
-    using f32x16 = __attribute__((__vector_size__(16 * sizeof(float)))) float;
-    extern __shared__ __attribute__((aligned(16))) float Wsm[];   // [KS*32][NC + 4]
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int cl = lane & 31, kl = lane >> 5;
-    const int pitch = NC + 4;
-    const int mb = blockIdx.x * 128 + wave * 32;   // first of this wave's 32 rows
-    const int mrow = mb + cl;
-    float a[KS][16];
-#pragma unroll
-    for (int s = 0; s < KS; s++) {
-        const int kb = s * 32 + kl * 16;
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (mrow < p.M && kb + 4 * j < p.K) {
-                v = *reinterpret_cast<const float4*>(p.A.p + (long)mrow * p.A.ld + kb + 4 * j);
-                if (p.A.scale) {   // one factor per k for all rows (FrozenBN scale of the incoming gradient)
-                    float4 f = *reinterpret_cast<const float4*>(p.A.scale + kb + 4 * j);
-                    v.x *= f.x; v.y *= f.y; v.z *= f.z; v.w *= f.w;
-                }
-            }
-            a[s][4 * j] = v.x; a[s][4 * j + 1] = v.y; a[s][4 * j + 2] = v.z; a[s][4 * j + 3] = v.w;
-        }
-    }
-    const GemmEpilogue& ep = p.ep;
-    const int nbeg = blockIdx.y * cols_per_block, nend = min(p.N, nbeg + cols_per_block);
-    // C and the residual go through buffer descriptors: one VGPR byte offset per lane + a scalar row offset per element
-    // (the host guarantees both extents fit 31 bits), instead of a 64-bit address pair per element.
-    const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc(p.C, 0, (int)((long)p.M * p.ldc * 4), 0x00020000);
-    // one prefetched side operand per output element: the residual (forward) or the ReLU-mask source (data gradient); when a
-    // data gradient has both (block input: identity-path gradient + the previous block's ReLU mask) the mask is read at use
-    const bool is_mask = !ep.residual && ep.mask_mode == 1;
-    const bool late_mask = ep.residual && ep.mask_mode == 1;
-    const __amdgpu_buffer_rsrc_t rm = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(late_mask ? ep.mask_src : p.C), 0,
-                                                                          late_mask ? (int)((long)p.M * ep.ldm * 4) : 0, 0x00020000);
-    const int vom = ((blockIdx.x * 128 + wave * 32 + 4 * kl) * (int)ep.ldm + cl) * 4, ldm4 = (int)ep.ldm * 4;
-    const float* auxp = ep.residual ? ep.residual : (is_mask ? ep.mask_src : nullptr);
-    const long auxld = ep.residual ? ep.ldr : ep.ldm;
-    const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(auxp ? auxp : p.C), 0,
-                                                                          auxp ? (int)((long)p.M * auxld * 4) : 0, 0x00020000);
-    const int mlane = mb + 4 * kl;                       // row of element r: mlane + (r & 3) + 8 * (r >> 2)
-    const int voc = (mlane * (int)p.ldc + cl) * 4, vor = (mlane * (int)auxld + cl) * 4;
-    const int ldc4 = (int)p.ldc * 4, ldr4 = (int)auxld * 4;
-    const bool full_rows = mb + 32 <= p.M;
-    const int spc = NC / 32;                             // 32-column steps per LDS chunk
-    const int nsteps = (nend - nbeg + 31) / 32;
-    float res[16], resn[16];
-    auto load_res = [&](int step, float (&dstv)[16]) {
-        const int n = nbeg + step * 32 + cl;
-#pragma unroll
-        for (int r = 0; r < 16; r++) {
-            const int ro = (r & 3) + 8 * (r >> 2);
-            float v = 0.f;
-            if (n < nend && (full_rows || mlane + ro < p.M)) v = __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(rr, vor + (nbeg + step * 32) * 4, ro * ldr4, 0));   // b32 = raw bits
-            dstv[r] = v;
-        }
-    };
-#pragma unroll
-    for (int r = 0; r < 16; r++) { res[r] = 0.f; resn[r] = 0.f; }
-    if (auxp && nsteps > 0) load_res(0, res);
-    for (int step = 0; step < nsteps; step++) {
-        const int nc0 = nbeg + (step / spc) * NC;
-        if (step % spc == 0) {
-            __syncthreads();
-            if (TB == 0) {
-                for (int u = tid; u < NC * KS * 8; u += 256) {   // consecutive threads = consecutive columns: conflict-free transposing store
-                    const int n = u % NC, k4 = (u / NC) * 4;
-                    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (nc0 + n < nend && k4 < p.K) v = *reinterpret_cast<const float4*>(p.B.p + (long)(nc0 + n) * p.B.ld + k4);
-                    Wsm[(k4 + 0) * pitch + n] = v.x; Wsm[(k4 + 1) * pitch + n] = v.y;
-                    Wsm[(k4 + 2) * pitch + n] = v.z; Wsm[(k4 + 3) * pitch + n] = v.w;
-                }
-            } else {
-                const int q = NC / 4;
-                for (int u = tid; u < KS * 32 * q; u += 256) {
-                    const int n4 = (u % q) * 4, k = u / q;
-                    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (k < p.K && nc0 + n4 < nend) v = *reinterpret_cast<const float4*>(p.B.p + (long)k * p.B.ld + nc0 + n4);
-                    *reinterpret_cast<float4*>(Wsm + k * pitch + n4) = v;
-                }
-            }
-            __syncthreads();
-        }
-        if (auxp && step + 1 < nsteps) load_res(step + 1, resn);   // one step ahead: its latency hides under this step's MFMA chain
-        const int n32 = (step % spc) * 32;
-        const int n = nc0 + n32 + cl;
-        const bool nok = n < nend;
-        const float cs = (ep.col_scale && nok) ? ep.col_scale[n] : 1.f;
-        const float cb = (ep.col_bias && nok) ? ep.col_bias[n] : 0.f;
-        f32x16 acc;
-#pragma unroll
-        for (int r = 0; r < 16; r++) acc[r] = 0.f;
-        const float* wcol = Wsm + (kl * 16) * pitch + n32 + cl;
-#pragma unroll
-        for (int s = 0; s < KS; s++) {
-#pragma unroll
-            for (int t = 0; t < 16; t++)
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s][t], wcol[(s * 32 + t) * pitch], acc, 0, 0, 0);
-        }
-        if (nok) {
-            const int vo = voc + (nc0 + n32) * 4;
-#pragma unroll
-            for (int r = 0; r < 16; r++) {
-                const int ro = (r & 3) + 8 * (r >> 2);
-                const int m = mlane + ro;
-                if (!full_rows && m >= p.M) continue;
-                // lean epilogue (the launcher rejects per-sample scales, backward masks and dropout: their per-row index
-                // arithmetic gets hoisted out of the step loop and spills this kernel's A-stationary register budget)
-                float v = acc[r] * ep.alpha * cs + cb + (is_mask ? 0.f : res[r]);
-                if (ep.act == 1) v = fmaxf(v, 0.f);
-                else if (ep.act == 2) v = (v > 0.f ? v : v * ep.act_alpha) * ep.act_gain;
-                if (is_mask) v = res[r] > 0.f ? v : 0.f;
-                if (late_mask) v = __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(rm, vom + (nc0 + n32) * 4, ro * ldm4, 0)) > 0.f ? v : 0.f;
-                v *= ep.out_scale;
-                if (ep.accumulate) v += __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(rc, vo, ro * ldc4, 0));
-                __builtin_amdgcn_raw_buffer_store_b32(__float_as_int(v), rc, vo, ro * ldc4, 0);
-            }
-        }
-#pragma unroll
-        for (int r = 0; r < 16; r++) res[r] = resn[r];
-    }
-}
-
-// Eligibility + launch of the skinny-K kernel; returns -1 when the problem does not qualify (caller falls through).
-template <int TB>
-static int try_launch_skinny(const GemmParams& p, hipStream_t st) {
-    // With the scalar-addressed loads the LDS-tiled kernel overtook this register-stationary one on almost every 1x1 shape (e.g.
-    // 65536 x 128 x 256: 47.6 vs 89.4 us, 65536 x 64 x 256: 27.2 vs 47.7 us, 4096 x 1024 x 256: 26.8 vs 43.4 us); it stays available
-    // (LDETR_SKINNY_MAXK=256 restores the old routing) but is off by default.
-    static const int skinny_maxk = getenv("LDETR_SKINNY_MAXK") ? atoi(getenv("LDETR_SKINNY_MAXK")) : 0;
-    if (p.K > skinny_maxk || p.M < SKINNY_MIN_M || !p.A.vec || !p.B.vec || (p.K & 3) || p.zmode != 0 || p.splitk > 1) return -1;
-    if (p.A.scale && (p.A.scale_ld != 0 || !al16(p.A.scale))) return -1;
-    if (TB == 1 && (p.N & 3)) return -1;
-    if (p.ep.samp_scale || p.ep.p_drop > 0.f || p.ep.row_scale) return -1;   // lean epilogue only
-    if (p.ep.mask_mode && p.ep.mask_mode != 1) return -1;
-    if ((long)p.M * p.ldc * 4 >= (1l << 31) || (p.ep.residual && (long)p.M * p.ep.ldr * 4 >= (1l << 31)) ||
-        (p.ep.mask_mode && (long)p.M * p.ep.ldm * 4 >= (1l << 31))) return -1;   // 32-bit buffer offsets
-    const int KS = p.K <= 64 ? 2 : (p.K <= 128 ? 4 : 8);
-    int NC = KS == 2 ? 128 : 64;   // columns per LDS chunk: ~34 KiB (K <= 128: 4 resp. 3 blocks per CU) or ~68 KiB (K <= 256: 2 per CU)
-    if (const char* e = getenv("LDETR_SKINNY_NC")) { int v = atoi(e); if (v >= 32 && v % 32 == 0 && v < NC) NC = v; }   // tuning aid
-    const int bx = cdiv(p.M, 128), chunks = cdiv(p.N, NC);
-    int ny = cdiv(768, bx); if (ny > chunks) ny = chunks; if (ny < 1) ny = 1;
-    const int cpb = cdiv(chunks, ny) * NC;
-    dim3 grid(bx, cdiv(p.N, cpb), 1);
-    const size_t lds = (size_t)KS * 32 * (NC + 4) * sizeof(float);
-    auto go = [&](auto kern, bool& raised) {
-        if (!raised) {
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
-                set_error("gemm_skinny: cannot raise the dynamic LDS limit to %zu bytes", lds);
-                return (int)LDETR_ERR_LAUNCH;
-            }
-            raised = true;
-        }
-        hipLaunchKernelGGL(kern, grid, 256, lds, st, p, cpb, NC);
-        t_launches_f32++;
-        return check_launch("gemm_skinny");
-    };
-    static bool r2 = false, r4 = false, r8 = false;
-    if (KS == 2) return go(gemm_skinny_kernel<TB, 2>, r2);
-    if (KS == 4) return go(gemm_skinny_kernel<TB, 4>, r4);
-    return go(gemm_skinny_kernel<TB, 8>, r8);
-}
 
 // Caller-provided scratch for the split-K fix-up (ldetr_set_workspace): WS_COUNTERS ints of arrival counters, then partial tiles.
 // Both areas are handed out as RINGS, one fresh slice per launch: launches of one stream are ordered anyway, but a captured
@@ -2046,10 +1863,6 @@ extern "C" int ldetr_gemm_f32(const float* A, int64_t lda, int ta, const float* 
         if (!ta && tb) return launch_small<0, 1>(p, st);
         if (ta && tb) return launch_small<1, 1>(p, st);
     }
-    if (auto_split && !ta) {
-        int rc = tb ? try_launch_skinny<1>(p, st) : try_launch_skinny<0>(p, st);
-        if (rc >= 0) return rc;
-    }
     if (!ta && !tb) return launch_gemm<OP_KC_DENSE, OP_KC_DENSE>(p, M, M, 1, auto_split, false, st);
     if (!ta && tb) return launch_gemm<OP_KC_DENSE, OP_RC_DENSE>(p, M, M, 1, auto_split, false, st);
     if (ta && tb) return launch_gemm<OP_RC_DENSE, OP_RC_DENSE>(p, M, M, 1, auto_split, false, st);
@@ -2075,7 +1888,6 @@ static void fill_dense(GemmParams& p, const ldetr_gemm_desc& g) {
     p.B.vec = al16(g.B) && (g.ldb % 4 == 0) && (g.tb ? (g.N % 4 == 0) : (g.K % 4 == 0));
     p.M = g.M; p.N = g.N; p.K = g.K; p.C = g.C; p.ldc = g.ldc;
     p.zmode = 0; p.splitk = 1; p.pstep = 1; p.nsamp = 1; p.pix_per_sample = g.pix_per_sample;
-    p.a_mask = g.a_mask; p.a_mask_gain = g.a_mask_gain;
     fill_epilogue(p.ep, g.ep);
 }
 
@@ -2127,7 +1939,6 @@ extern "C" int ldetr_gemm_pair_f32(const ldetr_gemm_desc* g0, const ldetr_gemm_d
             return check_launch("gemm_small_pair");
         }
     }
-    LDETR_CHECK(!g0->a_mask && !g1->a_mask, "gemm_pair: a_mask is only available on the single-launch path (ask ldetr_gemm_pair_is_single_launch first)");
     int rc = ldetr_gemm_f32(g0->A, g0->lda, g0->ta, g0->B, g0->ldb, g0->tb, g0->C, g0->ldc, g0->M, g0->N, g0->K, g0->splitk, g0->ep, g0->pix_per_sample, stream);
     if (rc) return rc;
     return ldetr_gemm_f32(g1->A, g1->lda, g1->ta, g1->B, g1->ldb, g1->tb, g1->C, g1->ldc, g1->M, g1->N, g1->K, g1->splitk, g1->ep, g1->pix_per_sample, stream);
@@ -2167,8 +1978,6 @@ extern "C" int ldetr_conv2d_fwd_f32(const float* x, const ldetr_tensor4* xt, con
     if (KH == 1 && KW == 1 && stride == 1 && pad == 0 && p.A.vec && !in_scale && xt->sw == xt->C && xt->sh == (long)xt->W * xt->C &&
         xt->sn == (long)xt->H * xt->W * xt->C) {
         p.A.ld = xt->C;  // pure GEMM view of a packed NHWC tensor
-        int rc = try_launch_skinny<0>(p, st);
-        if (rc >= 0) return rc;
         return launch_gemm<OP_KC_DENSE, OP_KC_DENSE>(p, p.M, p.M, 1, true, false, st);
     }
     return launch_gemm<OP_KC_CONV, OP_KC_DENSE>(p, p.M, p.M, 1, true, false, st);
@@ -2196,14 +2005,6 @@ extern "C" int ldetr_conv2d_bwd_data_f32(const float* dy, const ldetr_tensor4* d
     p.zmode = 1; p.splitk = 1; p.pstep = stride; p.nsamp = dyt->N; p.pix_per_sample = IH * IW;
     p.M = dyt->N * IH * IW; p.K = KH * KW * dyt->C;
     fill_epilogue(p.ep, ep);
-    if (KH == 1 && KW == 1 && stride == 1 && pad == 0 && dyt->sw == dyt->C && dyt->sh == (long)dyt->W * dyt->C &&
-        dyt->sn == (long)dyt->H * dyt->W * dyt->C && (!dy_scale || dy_scale_ld == 0)) {
-        // 1x1 / stride 1: dx[M, Cin] = (dy * scale)[M, Cout] . w[Cout, Cin], a dense contraction over Cout
-        GemmParams g = p;
-        g.zmode = 0; g.A.ld = dyt->C; g.B.ld = Cin; g.B.vec = al16(w) && (Cin % 4 == 0);
-        int rc = try_launch_skinny<1>(g, (hipStream_t)stream);
-        if (rc >= 0) return rc;
-    }
     int Mmax = dyt->N * cdiv(IH, stride) * cdiv(IW, stride);
     return launch_gemm<OP_KC_CONVT, OP_RC_WT>(p, Mmax, (long)p.M, stride * stride, true, false, (hipStream_t)stream);
 }

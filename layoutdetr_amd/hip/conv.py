@@ -124,10 +124,7 @@ class _ConvFn(torch.autograd.Function):
                     core.engine_call('ldetr_conv2d_bwd_weight_f32', 2.0 * N * OH * OW * O * KH * KW * I, lambda: core.check(core.lib().ldetr_conv2d_bwd_weight_f32(
                         core.ptr(x), ctypes.byref(xt), core.ptr(dpre), ctypes.byref(dyt), core.ptr(dw_ohwi), KH, KW, stride,
                         pad, sk, None, 0, core.ptr(sc), 0, acc, core.stream()), 'conv2d_bwd_weight'), operands=(x, dpre, dw_ohwi))
-                if acc:
-                    core.run_on_side(wgrad, keep=(x, dpre, sc))
-                else:
-                    wgrad()
+                wgrad()
             dw = None if acc else _grad_to_oihw(dw_ohwi)
         dres = dpre if need_res else None
         if dx is None and dx_pass is not None:

@@ -100,58 +100,6 @@ def check(rc, what=''):
     _lib.check(rc, what)
 
 
-# Weight-gradient side stream.  The data-gradient chain (dX of layer n feeds layer n-1) is the critical path of a backward pass;
-# the weight/bias gradients only feed the optimizer.  They are launched on a second HIP stream (forked after their inputs are
-# ready, joined once after backward), so the hundreds of latency-bound dW launches of the transformer blocks overlap the dX
-# chain instead of sitting in it; inside a captured phase the fork/join become parallel branches of the hipGraph.
-SIDE_WGRAD = os.environ.get('LDETR_SIDE_WGRAD', '0') != '0'
-SIDE_BATCH = int(os.environ.get('LDETR_SIDE_BATCH', '32'))   # launches queued per fork (every fork is a cross-stream edge in the graph)
-_side_streams = {}
-_side_keep = []
-_side_queue = []
-_side_busy = [False]
-
-
-def _side_flush():
-    if not _side_queue:
-        return
-    main = torch.cuda.current_stream()
-    key = main.device.index
-    side = _side_streams.get(key)
-    if side is None:
-        side = _side_streams[key] = torch.cuda.Stream(device=main.device)
-    side.wait_stream(main)
-    with torch.cuda.stream(side):
-        for fn in _side_queue:
-            fn()
-    del _side_queue[:]
-    _side_busy[0] = True
-
-
-def run_on_side(fn, keep=()):
-    """Run fn() (kernel launches that only write flat .grad buffers) on the side stream, ordered after everything queued so far
-    on the current stream.  `keep`: tensors fn reads; held until join_side() so the allocator cannot recycle them early."""
-    if not SIDE_WGRAD:
-        return fn()
-    _side_queue.append(fn)
-    _side_keep.append(keep)
-    if len(_side_queue) >= SIDE_BATCH:
-        _side_flush()
-
-
-def join_side():
-    """Make the current stream wait for the side-stream gradient launches (call after backward, before the gradients are read)."""
-    _side_flush()
-    if not _side_busy[0]:
-        return
-    main = torch.cuda.current_stream()
-    side = _side_streams.get(main.device.index)
-    if side is not None:
-        main.wait_stream(side)
-    del _side_keep[:]
-    _side_busy[0] = False
-
-
 def require_gpu(*tensors):
     for t in tensors:
         if t is not None and t.device.type != 'cuda':
@@ -275,24 +223,21 @@ def _pair_descs(g0, g1):
         d.M, d.N, d.K, d.splitk = int(g['M']), int(g['N']), int(g['K']), 0
         d.ep = ctypes.addressof(g['ep']) if g.get('ep') is not None else None
         d.pix_per_sample = 0
-        m = g.get('a_mask')
-        d.a_mask = m.data_ptr() if m is not None else None
-        d.a_mask_gain = float(g.get('a_mask_gain', 1.0))
         descs.append(d)
         flops += 2.0 * d.M * d.N * d.K
     return descs, flops
 
 
 def gemm_pair_is_single_launch(g0, g1):
-    """True if gemm_pair(g0, g1) runs as one kernel launch (only then may the descriptors carry `a_mask`)."""
+    """True if gemm_pair(g0, g1) runs as one kernel launch."""
     descs, _ = _pair_descs(g0, g1)
     return lib().ldetr_gemm_pair_is_single_launch(ctypes.byref(descs[0]), ctypes.byref(descs[1])) == 1
 
 
 def gemm_pair(g0, g1):
-    """Two gemm() calls as one C-ABI call (ldetr_gemm_pair_f32): g = dict(A, B, ta, tb, M, N, K, out, ep[, a_mask, a_mask_gain]).
-    The data and the weight gradient of a linear layer run as ONE kernel launch when both are small-tile problems; otherwise as
-    two, in order.  a_mask (laid out like A) folds a ReLU gradient into the loads of A: single-launch path only."""
+    """Two gemm() calls as one C-ABI call (ldetr_gemm_pair_f32): g = dict(A, B, ta, tb, M, N, K, out, ep).
+    The data and the weight gradient of a linear layer (or the two weight gradients of the fused feed-forward block) run as ONE kernel
+    launch when both are small-tile problems; otherwise as two, in order."""
     descs, flops = _pair_descs(g0, g1)
     engine_call('gemm', flops, lambda: check(lib().ldetr_gemm_pair_f32(ctypes.byref(descs[0]), ctypes.byref(descs[1]), stream()), 'gemm_pair'),
                 nbytes=4.0 * sum(d.M * d.K + d.N * d.K + d.M * d.N for d in descs))

@@ -39,11 +39,6 @@ def act_backward(dy2, y2, act, act_alpha, act_gain, want_dbias, bias=None, demod
     return dv, (None if dbias_out is not None else dbias), ddemod
 
 
-# ReLU gradient folded into the paired kernel's dY loads (ldetr_gemm_desc.a_mask): measured neutral (293.1 vs 292.7 images/s: the
-# second read of the hidden activations costs what the two saved launches gain), so it stays opt-in
-_FUSED_RELU = os.environ.get('LDETR_FUSED_RELU', '0') != '0'
-
-
 class _LinearFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, act, act_alpha, act_gain, p_drop, wscale, rows, add_input, passthru):
@@ -94,25 +89,9 @@ class _LinearFn(torch.autograd.Function):
             gw = gw[r0:r1]
         if gb is not None:
             gb = gb[r0:r1] if (N % 4 == 0 and r0 % 4 == 0) else None
-        pairable = need_x and need_w and gw is not None and gw.is_contiguous() and not core.SIDE_WGRAD
+        pairable = need_x and need_w and gw is not None and gw.is_contiguous()
         dx = dw = db = None
-        fused_relu = False
-        if _FUSED_RELU and act == ACT_RELU and pairable and (gb is not None or not need_b) and y.is_contiguous() and dy2.is_contiguous():
-            # ReLU (+ dropout) gradient folded into the paired kernel's dY loads: no activation-gradient pass, no bias column sums
-            gain = act_gain / (1.0 - p_drop) if p_drop > 0 else act_gain
-            res = core.f32c(dx_pass.reshape(-1, K)) if dx_pass is not None else None
-            dx2 = torch.empty((M, K), device=dy2.device, dtype=torch.float32)
-            g0 = dict(A=dy2, B=w, ta=0, tb=1, M=M, N=K, K=N, out=dx2, ep=core.epilogue(alpha=wscale, residual=res), a_mask=y, a_mask_gain=gain)
-            g1 = dict(A=dy2, B=x2, ta=1, tb=1, M=N, N=K, K=M, out=gw, ep=core.epilogue(alpha=wscale, accumulate=True, a_rowsum=gb if need_b else None),
-                      a_mask=y, a_mask_gain=gain)
-            if core.gemm_pair_is_single_launch(g0, g1):
-                core.gemm_pair(g0, g1)
-                dx = dx2.reshape(xshape)
-                fused_relu = True
-        if fused_relu:
-            need_x = need_w = False
-            dpre = None
-        elif act != ACT_NONE:
+        if act != ACT_NONE:
             gain = act_gain / (1.0 - p_drop) if p_drop > 0 else act_gain
             dpre, db, _ = act_backward(dy2, y, act, act_alpha, gain, need_b, dbias_out=gb)
         else:
@@ -121,8 +100,7 @@ class _LinearFn(torch.autograd.Function):
             fold_db = need_b and gb is not None and need_w and gw is not None and gw.is_contiguous() and dpre.is_contiguous()
             if need_b and not fold_db:
                 if gb is not None:
-                    core.run_on_side(lambda: core.check(core.lib().ldetr_colsum_f32(core.ptr(dpre), core.ptr(gb), 1, M, N, core.stream()), 'colsum'),
-                                     keep=(dpre,))
+                    core.check(core.lib().ldetr_colsum_f32(core.ptr(dpre), core.ptr(gb), 1, M, N, core.stream()), 'colsum')
                 else:
                     db = core.colsum(dpre).reshape(-1)
         if need_x and need_w and pairable:
@@ -141,8 +119,7 @@ class _LinearFn(torch.autograd.Function):
             if gw is not None and gw.is_contiguous():
                 # dW = dY^T X accumulated into the flat .grad; the bias gradient (column sums of dY) rides along (a_rowsum)
                 rsum = gb if (act == ACT_NONE and fold_db) else None
-                core.run_on_side(lambda: core.gemm(dpre, x2, 1, 1, N, K, M, out=gw,
-                                                   ep=core.epilogue(alpha=wscale, accumulate=True, a_rowsum=rsum)), keep=(dpre, x2))
+                core.gemm(dpre, x2, 1, 1, N, K, M, out=gw, ep=core.epilogue(alpha=wscale, accumulate=True, a_rowsum=rsum))
             else:
                 dw = core.gemm(dpre, x2, 1, 1, N, K, M, ep=core.epilogue(alpha=wscale))
         full = wparam.shape[0]

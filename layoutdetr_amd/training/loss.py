@@ -55,39 +55,6 @@ class Loss:
         raise NotImplementedError()
 
 
-class _TrunkFork(object):
-    """D's ResNet trunk launched on a second HIP stream while the current stream runs G (the trunk only reads the backgrounds,
-    G's many latency-bound transformer launches leave most CUs idle): join() orders the current stream after it."""
-
-    def __init__(self, D, background, enabled):
-        self.out = None
-        self.side = None
-        if enabled and background.is_cuda:
-            main = torch.cuda.current_stream()
-            if main.device.index not in _TrunkFork.streams:      # (setdefault would build a new stream on every call)
-                _TrunkFork.streams[main.device.index] = torch.cuda.Stream(device=main.device)
-            self.side = _TrunkFork.streams[main.device.index]
-            self.side.wait_stream(main)
-            with torch.cuda.stream(self.side):
-                self.out = D.trunk(background)
-        else:
-            self.out = D.trunk(background)
-
-    def join(self):
-        if self.side is not None:
-            main = torch.cuda.current_stream()
-            main.wait_stream(self.side)
-            for f in self.out[0]:                 # allocated on the side stream, consumed on the main one: tell the allocator
-                f.tensors.record_stream(main)
-            for q in self.out[1]:
-                q.record_stream(main)
-            self.side = None
-        return self.out
-
-
-_TrunkFork.streams = {}
-
-
 class StyleGAN2Loss(Loss):
     def __init__(self, device, G, D, augment_pipe=None, r1_gamma=0.0, style_mixing_prob=0, pl_weight=0.0, pl_batch_shrink=2,
                  pl_decay=0.01, pl_no_weight_grad=False, blur_init_sigma=0, blur_fade_kimg=0,
@@ -122,7 +89,6 @@ class StyleGAN2Loss(Loss):
         # (values only: D is frozen there) and both D passes of Dmain (with its autograd graph).  The iteration driver calls
         # precompute_D_trunk() before the phases; without that call the per-phase behaviour above applies.
         self._trunk_cache = {}
-        self.fork_D_trunk = os.environ.get('LDETR_FORK_TRUNK', '0') != '0'   # measured: no gain inside hipGraphs (negative results)
         self._reporting = report_fn is not None   # the sign() statistics cost a launch each: only formed when someone listens
         self.report = report_fn if report_fn is not None else (lambda name, value: None)
         self.last = {}
@@ -178,10 +144,9 @@ class StyleGAN2Loss(Loss):
         valid = ~padding_mask
         static = bool(getattr(self.G, 'static_shapes', False))
         cached = self._cached_trunk(background, detach=True, pop=False)
-        fork = _TrunkFork(self.D, background, self.fork_D_trunk) if (cached is None and hasattr(self.D, 'trunk')) else None
         bbox_fake, loss_z, cls_logits, loss_lm, loss_text_len = self.run_G(gen_z, bbox_class, bbox_real, bbox_text, bbox_patch, padding_mask, background, gen_c, reconst=True)
         gen_logits, gen_logits_uncond = self.run_D(bbox_fake, bbox_class, bbox_text, bbox_patch, padding_mask, background, gen_c,
-                                                   trunk_out=cached if cached is not None else (fork.join() if fork is not None else None))
+                                                   trunk_out=cached)
         if static and self.fused_layout_losses and bbox_fake.is_cuda and bbox_fake.shape[1] <= 64:
             # one launch for the four layout terms and their gradients (csrc/layout_loss.hip) instead of ~280 elementwise ones
             l_rec, l_giou, l_ovl, l_aln = layout_losses_fused(bbox_fake, bbox_real, valid)
@@ -215,8 +180,6 @@ class StyleGAN2Loss(Loss):
     def d_gen_loss(self, bbox_real, bbox_class, bbox_text, bbox_patch, padding_mask, background, gen_z, gen_c, trunk_out=None, gen_out=None):
         if gen_out is None:
             bbox_fake = self.run_G(gen_z, bbox_class, bbox_real, bbox_text, bbox_patch, padding_mask, background, gen_c, update_emas=True)
-            if isinstance(trunk_out, _TrunkFork):
-                trunk_out = trunk_out.join()
             gen_out = self.run_D(bbox_fake, bbox_class, bbox_text, bbox_patch, padding_mask, background, gen_c, update_emas=True, trunk_out=trunk_out)
         gen_logits, gen_logits_uncond = gen_out
         loss_Dgen = F.softplus(gen_logits)
@@ -262,12 +225,8 @@ class StyleGAN2Loss(Loss):
             phase = {'Greg': 'none', 'Gboth': 'Gmain'}.get(phase, phase)
         if self.r1_gamma == 0:
             phase = {'Dreg': 'none', 'Dboth': 'Dmain'}.get(phase, phase)
-        n_dbg = int(os.environ.get('LDETR_DBG_EXTRA_LAUNCHES', '0'))     # development aid: what does a leaf launch cost inside the captured phase?
-        if n_dbg:
-            self._dbg_extra = [torch.full((64,), 1.0, device=bbox_real.device) for _ in range(n_dbg)]
         if phase == 'Gmain':
             self.g_main_loss(bbox_real, bbox_class, bbox_text, bbox_patch, padding_mask, background, gen_z, gen_c).mul(gain).backward()
-            core.join_side()
         if phase == 'Dmain':
             if self.share_D_trunk and hasattr(self.D, 'trunk'):   # True / 'phase' / 'iteration'
                 cached = self._cached_trunk(background, detach=False, pop=True)
@@ -282,12 +241,10 @@ class StyleGAN2Loss(Loss):
                     l_gen = self.d_gen_loss(bbox_real, bbox_class, bbox_text, bbox_patch, padding_mask, background, gen_z, gen_c, trunk_out=cached)
                     l_real = self.d_real_loss(bbox_real, bbox_class, bbox_text, bbox_patch, padding_mask, background, real_c, trunk_out=cached)
                 else:
-                    fork = _TrunkFork(self.D, background, self.fork_D_trunk)   # overlaps G's no-grad forward inside d_gen_loss
-                    l_gen = self.d_gen_loss(bbox_real, bbox_class, bbox_text, bbox_patch, padding_mask, background, gen_z, gen_c, trunk_out=fork)
-                    l_real = self.d_real_loss(bbox_real, bbox_class, bbox_text, bbox_patch, padding_mask, background, real_c, trunk_out=fork.join())
+                    trunk = self.D.trunk(background)
+                    l_gen = self.d_gen_loss(bbox_real, bbox_class, bbox_text, bbox_patch, padding_mask, background, gen_z, gen_c, trunk_out=trunk)
+                    l_real = self.d_real_loss(bbox_real, bbox_class, bbox_text, bbox_patch, padding_mask, background, real_c, trunk_out=trunk)
                 (l_gen + l_real).mul(gain).backward()   # one backward: the trunk sees the summed gradient of both passes
-                core.join_side()
             else:
                 self.d_gen_loss(bbox_real, bbox_class, bbox_text, bbox_patch, padding_mask, background, gen_z, gen_c).mul(gain).backward()
                 self.d_real_loss(bbox_real, bbox_class, bbox_text, bbox_patch, padding_mask, background, real_c).mul(gain).backward()
-                core.join_side()

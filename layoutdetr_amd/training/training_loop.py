@@ -164,7 +164,6 @@ class DataParallelStep(object):
         ema = (flat p_ema buffer, beta): the G_ema lerp of training_loop.py:320-328 in the same pass over the parameters (G's parameters do
         not change between this step and the end of the iteration, where the reference updates G_ema)."""
         fm = phase.fm
-        core.join_side()   # weight-gradient launches of a backward that was not run through Loss.accumulate_gradients
         ev = None
         if self.record_exposed and self.world > 1 and self.comm_stream is not None:
             ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
@@ -453,13 +452,11 @@ def staged_backward(loss, phase, dp, run_stage1, between=None, exchange=None, st
         exchange = lambda ranges: [dp.exchange_async(phase.fm.gflat, lo, hi) for lo, hi in ranges]
     try:
         run_stage1()
-        core.join_side()
         if between is not None:
             between(1)
         exchange(segs[0])
         for i in (2, 3):
             st.run(i)
-            core.join_side()
             if between is not None:
                 between(i)
             exchange(segs[i - 1])

@@ -196,8 +196,8 @@ def test_gemm_small_tiles_long_reduction(dev, M, N, K):
 
 
 @pytest.mark.parametrize('M,N,K', [(20000, 77, 100), (4096, 256, 64), (33000, 36, 256), (8192, 300, 132), (16384, 512, 128), (4100, 1000, 32)])
-def test_gemm_skinny_k(dev, M, N, K):
-    """Dense GEMMs with M >= 4096 and K <= 256 take the register-stationary kernel: both B layouts, full epilogue."""
+def test_gemm_tall_and_thin(dev, M, N, K):
+    """Dense GEMMs with M >= 4096 and K <= 256 (the trunk's 1x1 convolutions as plain matrices): both B layouts, full epilogue."""
     from layoutdetr_amd.hip import core
     torch.manual_seed(44)
     A = torch.randn(M, K); W = torch.randn(N, K); b = torch.randn(N); s = torch.rand(N) + 0.5; R = torch.randn(M, N)
@@ -205,14 +205,14 @@ def test_gemm_skinny_k(dev, M, N, K):
     ep = core.epilogue(alpha=0.5, col_scale=sd, col_bias=bd, residual=Rd, act=core.ACT_RELU)
     ref = F.relu(0.5 * (A.double() @ W.double().t()).float() * s + b + R)
     c = core.gemm(Ad, Wd, 0, 0, M, N, K, ep=ep)
-    assert_close(c, ref, 3e-6, 'skinny NT')
+    assert_close(c, ref, 3e-6, 'tall NT')
     N4 = (N + 3) // 4 * 4
     Bt = torch.randn(K, N4); Btd = Bt.to(dev)
     c = core.gemm(Ad, Btd, 0, 1, M, N4, K)
-    assert_close(c, (A.double() @ Bt.double()).float(), 3e-6, 'skinny NN')
+    assert_close(c, (A.double() @ Bt.double()).float(), 3e-6, 'tall NN')
     base = torch.randn(M, N4); out = base.to(dev).clone()
     core.gemm(Ad, Btd, 0, 1, M, N4, K, out=out, ep=core.epilogue(accumulate=True))
-    assert_close(out, base + (A.double() @ Bt.double()).float(), 3e-6, 'skinny NN accumulate')
+    assert_close(out, base + (A.double() @ Bt.double()).float(), 3e-6, 'tall NN accumulate')
 
 
 @pytest.mark.parametrize('tokens,N,K', [(144, 256, 256), (1024, 256, 2048), (1000, 2048, 256), (4096, 1024, 512)])
@@ -306,7 +306,7 @@ CONV_CASES = [
     (2, 8, 8, 512, 256, 1, 1, 0),
     (2, 4, 4, 256, 1024, 1, 1, 0),
     (2, 32, 32, 256, 128, 1, 1, 0),
-    # 1x1 / stride 1 with >= 4096 pixels and K <= 256: the register-stationary skinny-K kernel (fwd and data gradient),
+    # 1x1 / stride 1 with >= 4096 pixels and K <= 256 (plain tall-and-thin matrices for the engine), fwd and data gradient,
     # incl. ragged pixel counts, channel counts that are not multiples of 32 and every K bucket (<=64, <=128, <=256)
     (4, 32, 32, 64, 256, 1, 1, 0),
     (4, 32, 32, 256, 64, 1, 1, 0),
@@ -1054,28 +1054,6 @@ def test_gemm_pair_data_and_weight_gradient(dev, tokens, N, K):
     assert_close(dx, dx2, 1e-6, 'pair vs single dX')
 
 
-def test_gemm_pair_relu_mask_fold(dev):
-    """ldetr_gemm_desc.a_mask: the ReLU (+ dropout scale) gradient applied to dY inside the paired launch equals masking dY first;
-    the bias row sums see the masked values; the query tells when the single-launch path (and with it a_mask) is available."""
-    from layoutdetr_amd.hip import core
-    torch.manual_seed(91)
-    tokens, N, K = 1024, 2048, 256
-    dy = torch.randn(tokens, N); y = torch.relu(torch.randn(tokens, N)); w = torch.randn(N, K) / 16; x = torch.randn(tokens, K)
-    gain = 1.0 / 0.9
-    dpre = torch.where(y > 0, dy * gain, torch.zeros_like(dy))
-    dyd, yd, wd, xd = [t.to(dev) for t in (dy, y, w, x)]
-    gw = torch.zeros(N, K, device=dev); gb = torch.zeros(N, device=dev); dx = torch.empty(tokens, K, device=dev)
-    g0 = dict(A=dyd, B=wd, ta=0, tb=1, M=tokens, N=K, K=N, out=dx, ep=core.epilogue(), a_mask=yd, a_mask_gain=gain)
-    g1 = dict(A=dyd, B=xd, ta=1, tb=1, M=N, N=K, K=tokens, out=gw, ep=core.epilogue(accumulate=True, a_rowsum=gb), a_mask=yd, a_mask_gain=gain)
-    assert core.gemm_pair_is_single_launch(g0, g1)
-    core.gemm_pair(g0, g1)
-    assert_close(dx, (dpre.double() @ w.double()).float(), 3e-6, 'dX')
-    assert_close(gw, (dpre.double().t() @ x.double()).float(), 3e-6, 'dW')
-    assert_close(gb, dpre.double().sum(0).float(), 3e-6, 'dbias')
-    big = dict(A=torch.zeros(40000, 256, device=dev), B=wd[:256], ta=0, tb=1, M=40000, N=K, K=256, out=torch.empty(40000, K, device=dev), ep=core.epilogue())
-    assert not core.gemm_pair_is_single_launch(big, g1)
-
-
 def test_fast_and_generic_instantiations_agree(dev, tmp_path):
     """The scalar-addressed (FAST) kernels and the paired launch only change how addresses are formed and how work is batched:
     a subprocess with them switched off (LDETR_FAST_LOADS=0, LDETR_SMALL_FAST=0, LDETR_GEMM_PAIR=0) must produce the same
@@ -1101,8 +1079,7 @@ np.savez(sys.argv[1], **out)
 '''
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     res = {}
-    for tag, env in (('fast', {}), ('generic', {'LDETR_FAST_LOADS': '0', 'LDETR_SMALL_FAST': '0', 'LDETR_GEMM_PAIR': '0'}),
-                     ('skinny', {'LDETR_SKINNY_MAXK': '256'})):   # the register-stationary 1x1 kernel (off by default since the FAST loads)
+    for tag, env in (('fast', {}), ('generic', {'LDETR_FAST_LOADS': '0', 'LDETR_SMALL_FAST': '0', 'LDETR_GEMM_PAIR': '0'})):
         path = str(tmp_path / f'{tag}.npz')
         e = dict(os.environ); e.update(env); e['PYTHONPATH'] = root + os.pathsep + e.get('PYTHONPATH', '')
         e['LDETR_SPLIT_BF16'] = '0'      # the bf16 split path exists for FAST operands only: compare the f32 MFMA pipe with itself
@@ -1115,9 +1092,6 @@ np.savez(sys.argv[1], **out)
         else:
             err = np.abs(a.astype(np.float64) - b).max() / (np.abs(b).max() + 1e-12)
             assert err <= 1e-6, f'{key}: rel err {err:.2e}'
-        c = res['skinny'][key]
-        err = np.abs(a.astype(np.float64) - c).max() / (np.abs(c).max() + 1e-12)
-        assert err <= 2e-6, f'{key}: skinny-K routing differs, rel err {err:.2e}'
 
 
 # ------------------------------------------------------------------------------------------ bf16 split pipe vs f32 MFMA pipe
