@@ -1229,6 +1229,18 @@ __device__ __forceinline__ void gemm_small_body(const GemmParams& p, const int b
     const int voffB = (n0 + cl < p.N) ? (TB == 0 ? ((n0 + cl) * (int)p.B.ld + 16 * kl) * 4 : (16 * kl * (int)p.B.ld + n0 + cl) * 4) : (int)0x80000000;
     auto loadA = [&](int k0, float (&f)[16]) {
         if constexpr (FAST) small_load_fast<TA>(rsA, voffA, k0, (int)p.A.ld, f); else small_load<TA>(p.A, m0 + cl, p.M, k0, kl, kend, f);
+        if constexpr (TA == 0) {
+            if (p.A.scale) {   // one factor per k for all rows (FrozenBN scale of the incoming gradient: the 1x1 data gradients routed here)
+                const int kb = k0 + 16 * kl;
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    if (kb + 4 * j < kend) {
+                        const float4 s4 = *reinterpret_cast<const float4*>(p.A.scale + kb + 4 * j);
+                        f[4 * j] *= s4.x; f[4 * j + 1] *= s4.y; f[4 * j + 2] *= s4.z; f[4 * j + 3] *= s4.w;
+                    }
+                }
+            }
+        }
     };
     auto loadB = [&](int k0, float (&f)[16]) {
         if constexpr (FAST) small_load_fast<TB>(rsB, voffB, k0, (int)p.B.ld, f); else small_load<TB>(p.B, n0 + cl, p.N, k0, kl, kend, f);
@@ -1978,6 +1990,11 @@ extern "C" int ldetr_conv2d_fwd_f32(const float* x, const ldetr_tensor4* xt, con
     if (KH == 1 && KW == 1 && stride == 1 && pad == 0 && p.A.vec && !in_scale && xt->sw == xt->C && xt->sh == (long)xt->W * xt->C &&
         xt->sn == (long)xt->H * xt->W * xt->C) {
         p.A.ld = xt->C;  // pure GEMM view of a packed NHWC tensor
+        // few output tiles (the trunk's 1x1 convolutions at 2-4 samples per GPU: 32..128 tiles of 64x64 on 256 CUs): the latency-bound
+        // small-tile kernel, like every other dense contraction of that class (ldetr_gemm_f32); same epilogue
+        static const int conv_small = getenv("LDETR_CONV1X1_SMALL") ? atoi(getenv("LDETR_CONV1X1_SMALL")) : 1;
+        if (conv_small && !p.ep.samp_scale && (long)cdiv(p.M, 64) * cdiv(p.N, 64) < SMALL_GEMM_TILES && (long)p.M * p.N * p.K <= SMALL_GEMM_MNK)
+            return launch_small<0, 0>(p, st);
         return launch_gemm<OP_KC_DENSE, OP_KC_DENSE>(p, p.M, p.M, 1, true, false, st);
     }
     return launch_gemm<OP_KC_CONV, OP_KC_DENSE>(p, p.M, p.M, 1, true, false, st);
@@ -2005,6 +2022,17 @@ extern "C" int ldetr_conv2d_bwd_data_f32(const float* dy, const ldetr_tensor4* d
     p.zmode = 1; p.splitk = 1; p.pstep = stride; p.nsamp = dyt->N; p.pix_per_sample = IH * IW;
     p.M = dyt->N * IH * IW; p.K = KH * KW * dyt->C;
     fill_epilogue(p.ep, ep);
+    {   // 1x1 / stride 1 on few output tiles (the trunk at 2-4 samples per GPU): dx[M, Cin] = (dy * scale)[M, Cout] . w[Cout, Cin] as a
+        // dense small-tile contraction over Cout, like the forward (ldetr_conv2d_fwd_f32)
+        static const int conv_small = getenv("LDETR_CONV1X1_SMALL") ? atoi(getenv("LDETR_CONV1X1_SMALL")) : 1;
+        if (conv_small && KH == 1 && KW == 1 && stride == 1 && pad == 0 && dyt->sw == dyt->C && dyt->sh == (long)dyt->W * dyt->C &&
+            dyt->sn == (long)dyt->H * dyt->W * dyt->C && (!dy_scale || dy_scale_ld == 0) && dyt->C % 4 == 0 && !p.ep.samp_scale &&
+            (long)cdiv(p.M, 64) * cdiv(p.N, 64) < SMALL_GEMM_TILES && (long)p.M * p.N * p.K <= SMALL_GEMM_MNK) {
+            GemmParams g = p;
+            g.zmode = 0; g.pstep = 1; g.A.ld = dyt->C; g.B.ld = Cin; g.B.vec = al16(w) && (Cin % 4 == 0);
+            return launch_small<0, 1>(g, (hipStream_t)stream);
+        }
+    }
     int Mmax = dyt->N * cdiv(IH, stride) * cdiv(IW, stride);
     return launch_gemm<OP_KC_CONVT, OP_RC_WT>(p, Mmax, (long)p.M, stride * stride, true, false, (hipStream_t)stream);
 }
@@ -2065,6 +2093,13 @@ extern "C" int ldetr_conv2d_bwd_weight_f32(const float* x, const ldetr_tensor4* 
                               xt->sn == (long)xt->H * xt->W * Cin;
         if (x_packed) {
             p.B.p = x; p.B.ld = Cin; p.B.vec = al16(x);
+            // few output tiles and a short reduction (the trunk's 1x1 weight gradients at 2-4 samples per GPU): the small-tile kernel
+            // (dw is zero or holds the running gradient at this point: accumulate; its own in-kernel split-K when the reduction is long)
+            static const int conv_small = getenv("LDETR_CONV1X1_SMALL") ? atoi(getenv("LDETR_CONV1X1_SMALL")) : 1;
+            if (conv_small && (long)cdiv(p.M, 64) * cdiv(p.N, 64) < SMALL_GEMM_TILES && (long)p.M * p.N * p.K <= SMALL_GEMM_MNK && Kpix <= 8192) {
+                p.zmode = 0; p.ntaps = 1; p.c_tap_stride = 0; p.splitk = 1; p.ep.accumulate = 1;
+                return launch_small<1, 1>(p, st);
+            }
             return launch_gemm<OP_RC_DENSE, OP_RC_DENSE>(p, p.M, p.M, 1, false, true, st);
         }
         set_conv_src(p.B, x, xt);
