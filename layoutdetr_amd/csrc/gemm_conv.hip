@@ -23,6 +23,9 @@
 namespace ldetr {
 int try_launch_stem_conv(const float* x, const ldetr_tensor4* xt, const float* w, int Cout, int KH, int KW, int stride, int pad,
                          float* y, long ldy, int OH, int OW, const float* in_scale, const ldetr_epilogue* ep, hipStream_t st);
+int try_launch_conv_c32(const float* x, const ldetr_tensor4* xt, const float* w, int Cout, int KH, int KW, int stride, int pad,
+                        float* y, long ldy, int OH, int OW, const float* k_scale, long k_scale_ld, const ldetr_epilogue* ep,
+                        int transposed, hipStream_t st);
 static thread_local int64_t t_launches_f32 = 0, t_launches_split = 0;   // ldetr_engine_launch_counts: contraction kernels issued by this thread, by matrix pipe
 int try_launch_wgrad_smallc(const float* x, const ldetr_tensor4* xt, const float* dy, const ldetr_tensor4* dyt, float* dw, int KH, int KW, int stride, int pad,
                             const float* x_scale, int64_t x_scale_ld, const float* dy_scale, int64_t dy_scale_ld, hipStream_t st);
@@ -1974,6 +1977,11 @@ extern "C" int ldetr_conv2d_fwd_f32(const float* x, const ldetr_tensor4* xt, con
         const int took = try_launch_stem_conv(x, xt, w, Cout, KH, KW, stride, pad, y, ldy, OH, OW, in_scale, ep, (hipStream_t)stream);
         if (took >= 0) return took;
     }
+    {   // 32 -> 32 channels, 3x3, on a large grid (the 256x256 StyleGAN2 layers): filter bank in registers, no LDS (csrc/conv_c32.hip)
+        const int took = try_launch_conv_c32(x, xt, w, Cout, KH, KW, stride, pad, y, ldy, OH, OW, in_scale, in_scale_ld, ep, 0, (hipStream_t)stream);
+        if (took > 0) t_launches_f32++;
+        if (took != 0) return took > 0 ? LDETR_OK : LDETR_ERR_LAUNCH;
+    }
     GemmParams p; memset(&p, 0, sizeof(p));
     init_operand(p.A); init_operand(p.B);
     set_conv_src(p.A, x, xt);
@@ -2008,6 +2016,11 @@ extern "C" int ldetr_conv2d_bwd_data_f32(const float* dy, const ldetr_tensor4* d
                                          const ldetr_epilogue* ep, void* stream) {
     LDETR_CHECK(dy && w && dx && dyt, "conv2d_bwd_data: null pointer");
     LDETR_CHECK(dyt->sc == 1 && dyt->C % 4 == 0 && Cin % 4 == 0, "conv2d_bwd_data: channels must be NHWC-contiguous multiples of 4");
+    {   // the same register-resident kernel with the filter bank read transposed and flipped
+        const int took = try_launch_conv_c32(dy, dyt, w, Cin, KH, KW, stride, pad, dx, lddx, IH, IW, dy_scale, dy_scale_ld, ep, 1, (hipStream_t)stream);
+        if (took > 0) t_launches_f32++;
+        if (took != 0) return took > 0 ? LDETR_OK : LDETR_ERR_LAUNCH;
+    }
     GemmParams p; memset(&p, 0, sizeof(p));
     init_operand(p.A); init_operand(p.B);
     set_conv_src(p.A, dy, dyt);

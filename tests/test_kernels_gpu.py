@@ -1003,7 +1003,7 @@ def test_demod_coefficients_fwd_bwd(dev, B, O, I, K, cl):
 
 
 @pytest.mark.parametrize('B,R,Ci,Co,up', [(2, 16, 64, 64, 1), (2, 8, 128, 64, 2), (3, 16, 64, 128, 2), (2, 32, 96, 64, 1), (2, 4, 512, 512, 2),
-                                          (4, 256, 32, 32, 1)])   # the 256x256 32-channel layer: narrow 256x32 tile (fwd, dX) + operand-streaming weight gradient
+                                          (4, 256, 32, 32, 1)])   # the 256x256 32-channel layer: register-resident filter bank (csrc/conv_c32.hip: fwd, dX) + operand-streaming weight gradient
 def test_modulated_conv_layers_vs_oracle(dev, B, R, Ci, Co, up):
     """One StyleGAN2 synthesis layer (modulate -> 3x3 conv or transposed conv + 4x4 FIR -> demodulate -> bias -> lrelu * sqrt 2,
     networks_stylegan2.py:30-75,307-326) against the oracle's non-fused formulation, forward and all gradients, at channel counts
