@@ -11,7 +11,9 @@ N > 1: one process per GPU.  `python bench.py --gpus N` spawns the N ranks itsel
 train.py:27-47 does); under torch.distributed.run it reads RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment instead.
 The headline `value` at N > 1 is BASELINE configs[3]: GLOBAL batch 16 sharded over the ranks ("scaling": "strong"); the same
 process then also times 16 samples PER GPU and reports it as `weak_scaling` (global batch 16 x N).  At N = 1 both coincide
-(configs[2]) and the line also carries `value_reference_call_pattern` (D's trunk evaluated per pass, as the reference does).
+(configs[2]) and the line also carries `value_reference_call_pattern` (D's trunk evaluated per D pass, as the reference does) and
+`value_phase_trunk_sharing` (once per phase); the headline evaluates it once per iteration (same values: D's weights do not change
+between Gmain and Dmain).
 Gradients are exchanged with RCCL all-reduce over xGMI, bucketed and overlapped with the backward graphs.
 
 Prints ONE JSON line on rank 0.
@@ -104,7 +106,10 @@ def parse_args():
                          "inside every G/D forward; 'encoder+lm': plus the trainable LM text decoder and its loss (SURVEY 8f-1)")
     ap.add_argument('--text-tokens', type=int, default=40, help='tokens per element text (reference: padding to max_text_length)')
     ap.add_argument('--no-share-trunk', action='store_true', help="evaluate D's ResNet trunk separately for the fake and the real pass of Dmain, as the reference does")
-    ap.add_argument('--share-trunk', default='phase', choices=['phase', 'iteration'], help="'iteration': one D-trunk evaluation also serves Gmain's D(fake) (D's weights do not change between the two phases)")
+    ap.add_argument('--share-trunk', default='iteration', choices=['phase', 'iteration'],
+                    help="how often D's ResNet trunk runs on the iteration's backgrounds: 'iteration' (default) once -- D's weights do not change between Gmain and Dmain "
+                         "(training_loop.py:281-313: Gmain steps G only), so Gmain's D(fake) reads the evaluation Dmain differentiates; 'phase': once per phase; "
+                         "--no-share-trunk: once per D pass, the reference's call pattern.  Same values in all three (parity-tested); the line reports all three rates")
     ap.add_argument('--no-overlap', action='store_true', help='N>1: exchange gradients after each backward graph instead of overlapping the all-reduce with it')
     return ap.parse_args()
 
@@ -289,9 +294,11 @@ def run(args, rank, local_rank, world):
                 r = measure(16, False)
                 extra['value_reference_call_pattern'] = r['value']
                 extra['ms_per_step_reference_call_pattern'] = r['ms_per_step']
-                if share is True:      # and the other side of the headline: D's trunk evaluated once per ITERATION (opt-in `--share-trunk iteration`;
-                    r = measure(16, 'iteration')   # D's weights do not change between Gmain and Dmain, so Gmain's D(fake) can read Dmain's evaluation)
-                    extra['value_iteration_trunk_sharing'] = r['value']
+                # ... and the setting in between / beyond the headline's: D's trunk once per phase, once per iteration
+                if share == 'iteration':
+                    extra['value_phase_trunk_sharing'] = measure(16, True)['value']
+                else:
+                    extra['value_iteration_trunk_sharing'] = measure(16, 'iteration')['value']
                 # the same step with every contraction on the f32 MFMA pipe (the default runs the 128-row / narrow tiles of the engine on the
                 # bf16 pipe with the exact three-way operand split: fp32 operands and results, csrc/gemm_conv.hip gemm_f32_kernel<.., SPLIT>)
                 prev = core.lib().ldetr_set_split_bf16(0)
