@@ -87,12 +87,19 @@ template <int A, int G, int BM>
 __global__ __launch_bounds__(256) void bias_act_vec4_kernel(BiasActParams p) {
     const long n4 = p.sizeX >> 2;
     const long stride = (long)gridDim.x * blockDim.x;
+    // operands beyond the Infinity Cache (>= 128 MB per tensor: the 256 x 256 StyleGAN2 layers) are streamed: every element is touched
+    // once, non-temporal requests keep them from evicting what the neighbouring kernels still need (5.2 -> TB/s class of the Adam pass)
+    const bool nt = G > 0 && p.sizeX >= (1L << 25);      // (the forward's output is read back by the next layer: streaming it measured slower, 6.6 -> 6.0 TB/s)
+    auto ld4 = [&](const float* q, long i) {
+        if (nt) { const f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(q) + i); return make_float4(v[0], v[1], v[2], v[3]); }
+        return reinterpret_cast<const float4*>(q)[i];
+    };
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
-        float4 x = reinterpret_cast<const float4*>(p.x)[i];
+        float4 x = ld4(p.x, i);
         float4 xr = make_float4(0, 0, 0, 0), yr = xr, dy = make_float4(1, 1, 1, 1), b = xr;
-        if (p.xref) xr = reinterpret_cast<const float4*>(p.xref)[i];
-        if (p.yref) yr = reinterpret_cast<const float4*>(p.yref)[i];
-        if (p.dy) dy = reinterpret_cast<const float4*>(p.dy)[i];
+        if (p.xref) xr = ld4(p.xref, i);
+        if (p.yref) yr = ld4(p.yref, i);
+        if (p.dy) dy = ld4(p.dy, i);
         if (BM == 1) { float v = p.b[((i << 2) / p.stepB) % p.sizeB]; b = make_float4(v, v, v, v); }
         if (BM == 2) { b = *reinterpret_cast<const float4*>(p.b + ((i << 2) % p.sizeB)); }
         float4 y;
@@ -100,7 +107,8 @@ __global__ __launch_bounds__(256) void bias_act_vec4_kernel(BiasActParams p) {
         y.y = bias_act_elem<A, G>(x.y, b.y, xr.y, yr.y, dy.y, p.alpha, p.gain, p.clamp);
         y.z = bias_act_elem<A, G>(x.z, b.z, xr.z, yr.z, dy.z, p.alpha, p.gain, p.clamp);
         y.w = bias_act_elem<A, G>(x.w, b.w, xr.w, yr.w, dy.w, p.alpha, p.gain, p.clamp);
-        reinterpret_cast<float4*>(p.y)[i] = y;
+        if (nt) __builtin_nontemporal_store(f32x4{y.x, y.y, y.z, y.w}, reinterpret_cast<f32x4*>(p.y) + i);
+        else reinterpret_cast<float4*>(p.y)[i] = y;
     }
 }
 

@@ -255,12 +255,17 @@ extern "C" int ldetr_upfirdn2d_f32(const float* x, const float* f, float* y,
     if (grid > 256 * 32) grid = 256 * 32;
     static const int fir_mode = getenv("LDETR_FIR_TILED") ? atoi(getenv("LDETR_FIR_TILED")) : 1;   // 0: generic kernel everywhere (development switch)
     if (nhwc4 && fir_mode && upx == 1 && upy == 1 && downx == 1 && downy == 1 && fw == 4 && fh == 4 && (long)outH * outW >= 64) {
-        // register-tiled sliding-window form: 4 columns x 16 rows per thread on the large layers, 2 x 4 where threads are scarce
+        // register-tiled sliding-window form: 4 columns x TR rows per thread; TR = 8 (a strip re-reads 3 rows of its neighbour), 4 when
+        // 8-row strips would leave the chip under two waves per SIMD -- at 16 x 128 channels x 64 x 64 the first version's 16-row strips
+        // were 128 blocks on 256 CUs (2.97 TB/s; 4.03 with 4-row strips); 2 x 4 where threads are scarce
         const bool big = (long)N * outH * outW * (C / 4) >= (1L << 20);
-        const int TC = big ? 4 : 2, TR = big ? 16 : 4;
+        const long cols4 = (long)N * ((outW + 3) / 4) * (C / 4);
+        int TC = big ? 4 : 2, TR = big ? 8 : 4;
+        if (big && cols4 * ((outH + 7) / 8) < (1L << 17)) TR = 4;
         long threads = (long)N * ((outH + TR - 1) / TR) * ((outW + TC - 1) / TC) * (C / 4);
         int g = (int)((threads + 255) / 256);
-        if (big) hipLaunchKernelGGL((fir4x4_nhwc4_kernel<4, 16>), g, 256, 0, st, p);
+        if (big && TR == 8) hipLaunchKernelGGL((fir4x4_nhwc4_kernel<4, 8>), g, 256, 0, st, p);
+        else if (big) hipLaunchKernelGGL((fir4x4_nhwc4_kernel<4, 4>), g, 256, 0, st, p);
         else hipLaunchKernelGGL((fir4x4_nhwc4_kernel<2, 4>), g, 256, 0, st, p);
     } else if (nhwc4) hipLaunchKernelGGL(upfirdn2d_nhwc4_kernel, grid, 256, 0, st, p);
     else hipLaunchKernelGGL(upfirdn2d_planar_kernel, grid, 256, 0, st, p);
