@@ -383,7 +383,7 @@ def run(args, rank, local_rank, world):
         # launch on the f32 MFMA pipe 157.3 -- time-weighted over the step's engine launches
         tsum = max(t_pipe[0] + t_pipe[1], 1e-9)
         peak_eff = (t_pipe[0] * F32_MFMA_PEAK_TFLOPS + t_pipe[1] * SPLIT_PIPE_PEAK_TFLOPS) / tsum
-        roofline = dict(bound='mfma', kernel='f32 MFMA contraction engine: ldetr::gemm_f32_kernel<*> (LDS-tiled GEMM / implicit conv) + gemm_skinny_kernel<*> + gemm_small_kernel<*>, every launch',
+        roofline = dict(bound='mfma', kernel='f32 MFMA contraction engine: ldetr::gemm_f32_kernel<*> (LDS-tiled GEMM / implicit conv) + gemm_small_kernel<*> / gemm_small_pair_kernel<*> (+ conv3x3_c32 / wgrad_c32 / ffn kernels where they replace engine launches), every launch',
                         achieved=round(ach, 3), peak=F32_MFMA_PEAK_TFLOPS, unit='TFLOP/s', frac=round(ach / F32_MFMA_PEAK_TFLOPS, 4),
                         peak_effective=round(peak_eff, 1), frac_effective=round(ach / peak_eff, 4),
                         peak_effective_note=f'time-weighted over the engine launches of the step: {t_pipe[1] / tsum:.3f} of the engine time runs on the bf16 matrix pipe with the '

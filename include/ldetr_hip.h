@@ -198,6 +198,19 @@ int ldetr_layernorm_fwd_parts_f32(const float* x, const float* parts, int n_part
                                   int64_t rows, int D, float eps, float p_drop, uint64_t seed, const uint64_t* seed_ptr,
                                   const float* pos, int64_t pos_rows, float* ypos, void* stream);
 
+/* Self-attention sub-block of the short-sequence stacks (nn.MultiheadAttention(256, 8) with q = k = v = x, L <= 16 tokens per sample:
+ * training/detr_transformer.py:273-274; nn.TransformerEncoderLayer at training/util.py:21-26, networks_detr.py:243,269,275) as ONE
+ * forward launch (csrc/mha_small.hip): packed projection, masked softmax attention with dropout on the probabilities, and the output
+ * projection's per-head contributions.
+ *   x [B*L][ldx], w_in [768][256], b_in [768], w_out [256][256], kpm [B][L] (nonzero = masked key) or NULL
+ *   -> qkv [B*L][768] (projection incl. bias, q unscaled), o [B*L][256] (attention output), lse [B][8][L]: what
+ *      ldetr_attention_bwd_f32 reads (same dropout element index, same seed);
+ *   -> ypart [8][B*L][256]: out_proj contributions per head WITHOUT its bias (reduce with ldetr_layernorm_fwd_parts_f32). */
+int ldetr_mha_small_fwd_f32(const float* x, int64_t ldx, const float* w_in, const float* b_in, const float* w_out,
+                            const uint8_t* kpm, float* qkv, float* o, float* lse, float* ypart,
+                            int B, int L, int D, int H, float scale, float p_drop, uint64_t seed, const uint64_t* seed_ptr,
+                            void* stream);
+
 /* Position-wise feed-forward block linear2(dropout(relu(linear1(x)))) of the DETR layers (training/detr_transformer.py:212-214, 283-285;
  * d_model D = 256, hidden width F a multiple of 64), one launch per direction (csrc/ffn_fused.hip).
  * fwd: x [M][ldx], w1 [F][D], b1 [F], w2 [D][F] -> h [M][F] (hidden after relu + dropout, kept for the backward) and

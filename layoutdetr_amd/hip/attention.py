@@ -7,6 +7,7 @@ head-averaged attention weights the reference discards (`[0]`) are never formed.
 Layout is batch-first: activations are [B*L, d] row-major (row = b*L + position).
 """
 import math
+import os
 
 import torch
 
@@ -219,6 +220,102 @@ def grouped_kv(mem_pos, mem, mhas):
             return holder.dK[:, i * d:(i + 1) * d], holder.dV[:, i * d:(i + 1) * d]
         return views
     return [(outs[i], outs[n + i], dst(i)) for i in range(n)]
+
+
+SMALL_FUSED = os.environ.get('LDETR_MHA_SMALL', '1') != '0'
+
+
+def small_usable(x2, in_proj_weight, nhead, L):
+    """The one-launch self-attention forward (csrc/mha_small.hip): d_model 256, 8 heads, at most 16 tokens per sample."""
+    return (SMALL_FUSED and x2.is_cuda and x2.dtype == torch.float32 and in_proj_weight.shape[1] == 256 and nhead == 8 and 1 <= L <= 16
+            and x2.dim() == 2 and x2.stride(1) == 1 and x2.stride(0) % 4 == 0 and x2.data_ptr() % 16 == 0)
+
+
+class _SelfAttnPartsFn(torch.autograd.Function):
+    """Self-attention sub-block with q = k = v = x on <= 16 tokens per sample: ONE forward launch (packed projection, attention, the
+    output projection's per-head contributions).  -> (ypart [H, B*L, d], alias of x): the consumer -- the residual + LayerNorm launch
+    (hip.layernorm.add_layernorm / hip.ffn.add_ln_ffn_add_ln with a 3-D residual and `r_bias` = out_proj.bias) -- sums the H
+    contributions; its gradient arrives as one [B*L, d] matrix broadcast over H.  Backward = the unfused path's three launches on the
+    saved projection (out_proj dX + dW pair, ldetr_attention_bwd_f32, in_proj dX + dW pair); the residual-path gradient that arrives
+    through the alias is added in the last dX GEMM's epilogue."""
+
+    @staticmethod
+    def forward(ctx, x, w_in, b_in, w_out, b_out, kpm, B, H, L, p_drop):
+        core.require_gpu(x, w_in, b_in, w_out, b_out, kpm)
+        ctx.set_materialize_grads(False)
+        d = x.shape[1]
+        M = B * L
+        assert x.shape[0] == M
+        Wi, Bi, Wo = core.f32c(w_in.detach()), core.f32c(b_in.detach()), core.f32c(w_out.detach())
+        new = lambda *shape: torch.empty(shape, device=x.device, dtype=torch.float32)
+        qkv, o, lse, ypart = new(M, 3 * d), new(M, d), new(B * H * L), new(H, M, d)
+        seed = core.next_seed() if p_drop > 0 else 0
+        scale = 1.0 / math.sqrt(d // H)
+        core.check(core.lib().ldetr_mha_small_fwd_f32(
+            core.ptr(x), x.stride(0), core.ptr(Wi), core.ptr(Bi), core.ptr(Wo), core.ptr(kpm), core.ptr(qkv), core.ptr(o), core.ptr(lse),
+            core.ptr(ypart), B, L, d, H, scale, p_drop, seed, core.seed_ptr() if p_drop > 0 else None, core.stream()), 'mha_small_fwd')
+        ctx.save_for_backward(x, Wi, Wo, kpm, qkv, o, lse)
+        ctx.cfg = (B, H, L, d, scale, p_drop, seed)
+        ctx.params = (w_in, b_in, w_out, b_out)
+        return ypart, x
+
+    @staticmethod
+    def backward(ctx, dypart, dx_pass=None):
+        x, Wi, Wo, kpm, qkv, o, lse = ctx.saved_tensors
+        B, H, L, d, scale, p_drop, seed = ctx.cfg
+        w_in, b_in, w_out, b_out = ctx.params
+        if dypart is None:
+            return (dx_pass,) + (None,) * 9
+        M = B * L
+        dev = x.device
+        # every head's contribution receives the same gradient (the consumer returns it broadcast: stride 0 over H)
+        dr = core.f32c(dypart[0] if dypart.stride(0) == 0 else dypart.sum(0))
+        need_x = ctx.needs_input_grad[0]
+        need_w = any(ctx.needs_input_grad[1:5]) and not core.WEIGHT_GRADIENTS_DISABLED[0]
+        ret = [None] * 4
+        if need_w:
+            flat = [core.flat_grad(t) for t in (w_in, b_in, w_out, b_out)]
+            if all(f is not None and f.is_contiguous() for f in flat):
+                tgt = flat
+            else:
+                tgt = [torch.zeros_like(t, memory_format=torch.contiguous_format) for t in (w_in, b_in, w_out, b_out)]
+                ret = tgt
+        # out_proj: d_o = dr W_out, dW_out += dr^T o, db_out = column sums of dr
+        d_o = torch.empty((M, d), device=dev, dtype=torch.float32)
+        if need_w:
+            core.gemm_pair(dict(A=dr, B=Wo, ta=0, tb=1, M=M, N=d, K=d, out=d_o, ep=core.epilogue()),
+                           dict(A=dr, B=o, ta=1, tb=1, M=d, N=d, K=M, out=tgt[2], ep=core.epilogue(accumulate=True, a_rowsum=tgt[3])))
+        else:
+            core.gemm(dr, Wo, 0, 1, M, d, d, out=d_o)
+        # attention backward on the saved projection
+        dqkv = torch.empty_like(qkv)
+        q, k, v = qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:]
+        dq, dk, dv = dqkv[:, :d], dqkv[:, d:2 * d], dqkv[:, 2 * d:]
+        core.check(core.lib().ldetr_attention_bwd_f32(
+            core.ptr(q), 3 * d, core.ptr(k), 3 * d, core.ptr(v), 3 * d, core.ptr(kpm), core.ptr(o), d, core.ptr(lse), core.ptr(d_o), d,
+            core.ptr(dq), 3 * d, core.ptr(dk), 3 * d, core.ptr(dv), 3 * d, B, H, L, L, d // H, scale, p_drop, seed,
+            core.seed_ptr() if p_drop > 0 else None, 0, core.stream()), 'attention_bwd')
+        # in_proj: dx = dqkv W_in (+ the residual-path gradient), dW_in += dqkv^T x, db_in = column sums of dqkv
+        dx = None
+        res = core.f32c(dx_pass.reshape(M, d)) if dx_pass is not None else None
+        if need_x and need_w:
+            dx = torch.empty((M, d), device=dev, dtype=torch.float32)
+            core.gemm_pair(dict(A=dqkv, B=Wi, ta=0, tb=1, M=M, N=d, K=3 * d, out=dx, ep=core.epilogue(residual=res)),
+                           dict(A=dqkv, B=x, ta=1, tb=1, M=3 * d, N=d, K=M, out=tgt[0], ep=core.epilogue(accumulate=True, a_rowsum=tgt[1])))
+        else:
+            if need_x:
+                dx = core.gemm(dqkv, Wi, 0, 1, M, d, 3 * d, ep=core.epilogue(residual=res))
+            if need_w:
+                core.gemm(dqkv, x, 1, 1, 3 * d, d, M, out=tgt[0], ep=core.epilogue(accumulate=True, a_rowsum=tgt[1]))
+        if not need_x:
+            dx = dx_pass
+        return (dx, ret[0], ret[1], ret[2], ret[3], None, None, None, None, None)
+
+
+def self_attention_parts(x2, m_in_w, m_in_b, m_out_w, m_out_b, nhead, B, L, key_padding_mask=None, p_drop=0.0):
+    """-> (ypart [H, B*L, d], out_proj.bias (no gradient through this copy: it is formed in the node), alias of x2 for the residual branch)."""
+    ypart, alias = _SelfAttnPartsFn.apply(x2, m_in_w, m_in_b, m_out_w, m_out_b, _kpm_u8(key_padding_mask), B, nhead, L, p_drop)
+    return ypart, m_out_b.detach(), alias
 
 
 def mha_forward(query, key, value, in_proj_weight, in_proj_bias, out_w, out_b, nhead, B, Lq, Lk,

@@ -32,11 +32,15 @@ def usable(x2, linear1, linear2):
 
 class _LnFfnLnFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, r, ga, ba, eps_a, p_a, w1, b1, w2, b2, gb, bb, eps_b, p_hidden, p_b, pos):
-        core.require_gpu(x, r, ga, ba, w1, b1, w2, b2, gb, bb, pos)
+    def forward(ctx, x, r, ga, ba, eps_a, p_a, w1, b1, w2, b2, gb, bb, eps_b, p_hidden, p_b, pos, r_bias=None):
+        core.require_gpu(x, r, ga, ba, w1, b1, w2, b2, gb, bb, pos, r_bias)
         ctx.set_materialize_grads(False)
         D = x.shape[-1]
-        x2, r2 = core.f32c(x.reshape(-1, D)), core.f32c(r.reshape(-1, D))
+        # (a 3-D r with a 2-D x: per-head contributions of the fused self-attention block, summed with r_bias inside norm_a's launch)
+        n_rparts = r.shape[0] if (r.dim() == 3 and x.dim() == 2) else 0
+        x2 = core.f32c(x.reshape(-1, D))
+        r2 = core.f32c(r) if n_rparts else core.f32c(r.reshape(-1, D))
+        rb = core.f32c(r_bias) if (n_rparts and r_bias is not None) else None
         M, F = x2.shape[0], w1.shape[0]
         W1, B1, W2, B2 = core.f32c(w1.detach()), core.f32c(b1.detach()), core.f32c(w2.detach()), core.f32c(b2.detach())
         Ga, Ba, Gb, Bb = core.f32c(ga.detach()), core.f32c(ba.detach()), core.f32c(gb.detach()), core.f32c(bb.detach())
@@ -44,9 +48,14 @@ class _LnFfnLnFn(torch.autograd.Function):
         # norm_a(x + dropout(r))
         x1, za, mean_a, rstd_a = new(M, D), new(M, D), new(M), new(M)
         seed_a = core.next_seed() if p_a > 0 else 0
-        core.check(core.lib().ldetr_layernorm_fwd_pos_f32(
-            core.ptr(x2), core.ptr(r2), core.ptr(Ga), core.ptr(Ba), core.ptr(x1), core.ptr(za), core.ptr(mean_a), core.ptr(rstd_a), M, D, eps_a, p_a,
-            seed_a, core.seed_ptr() if p_a > 0 else None, None, 0, None, core.stream()), 'layernorm_fwd')
+        if n_rparts:
+            core.check(core.lib().ldetr_layernorm_fwd_parts_f32(
+                core.ptr(x2), core.ptr(r2), n_rparts, M * D, core.ptr(rb), core.ptr(Ga), core.ptr(Ba), core.ptr(x1), core.ptr(za), core.ptr(mean_a),
+                core.ptr(rstd_a), M, D, eps_a, p_a, seed_a, core.seed_ptr() if p_a > 0 else None, None, 0, None, core.stream()), 'layernorm_fwd_parts')
+        else:
+            core.check(core.lib().ldetr_layernorm_fwd_pos_f32(
+                core.ptr(x2), core.ptr(r2), core.ptr(Ga), core.ptr(Ba), core.ptr(x1), core.ptr(za), core.ptr(mean_a), core.ptr(rstd_a), M, D, eps_a, p_a,
+                seed_a, core.seed_ptr() if p_a > 0 else None, None, 0, None, core.stream()), 'layernorm_fwd')
         # feed-forward block on x1, hidden slices across blocks
         ns = F // 64
         h, parts = new(M, F), new(ns, M, D)
@@ -64,6 +73,7 @@ class _LnFfnLnFn(torch.autograd.Function):
             core.stream()), 'layernorm_fwd_parts')
         ctx.save_for_backward(x1, h, W1, W2, za, mean_a, rstd_a, Ga, zb, mean_b, rstd_b, Gb)
         ctx.cfg = (x.shape, D, F, M, p_a, seed_a, p_hidden, p_b, seed_b)
+        ctx.n_rparts = n_rparts
         ctx.params = (ga, ba, w1, b1, w2, b2, gb, bb)
         if pos is not None:
             return y.reshape(x.shape), ypos.reshape(x.shape)
@@ -74,7 +84,7 @@ class _LnFfnLnFn(torch.autograd.Function):
         x1, h, W1, W2, za, mean_a, rstd_a, Ga, zb, mean_b, rstd_b, Gb = ctx.saved_tensors
         xshape, D, F, M, p_a, seed_a, p_hidden, p_b, seed_b = ctx.cfg
         ga, ba, w1, b1, w2, b2, gb, bb = ctx.params
-        nin = 16
+        nin = 17
         if dy is None and dypos is None:
             return (None,) * nin
         if dy is None:
@@ -127,12 +137,15 @@ class _LnFfnLnFn(torch.autograd.Function):
             core.ptr(dz), None, core.ptr(dxpart), ns, M * D, core.ptr(za), core.ptr(mean_a), core.ptr(rstd_a), core.ptr(Ga), core.ptr(dx), core.ptr(drr),
             core.ptr(dga), core.ptr(dba), M, D, p_a, seed_a, core.seed_ptr() if p_a > 0 else None, core.stream()), 'layernorm_bwd')
         g_x = dx.reshape(xshape) if need_x else None
-        g_r = (drr if drr is not None else dx).reshape(xshape) if need_r else None
-        return (g_x, g_r, ret_a[0], ret_a[1], None, None, out_w[0], out_w[1], out_w[2], out_w[3], ret_b[0], ret_b[1], None, None, None, None)
+        g_r = None
+        if need_r:
+            g_r = drr if drr is not None else dx
+            g_r = g_r.unsqueeze(0).expand(ctx.n_rparts, M, D) if ctx.n_rparts else g_r.reshape(xshape)
+        return (g_x, g_r, ret_a[0], ret_a[1], None, None, out_w[0], out_w[1], out_w[2], out_w[3], ret_b[0], ret_b[1], None, None, None, None, None)
 
 
-def add_ln_ffn_add_ln(x, r, norm_a, p_a, linear1, linear2, norm_b, p_hidden=0.0, p_b=0.0, pos=None):
+def add_ln_ffn_add_ln(x, r, norm_a, p_a, linear1, linear2, norm_b, p_hidden=0.0, p_b=0.0, pos=None, r_bias=None):
     """norm_b(x1 + drop_b(linear2(drop_h(relu(linear1(x1)))))) with x1 = norm_a(x + drop_a(r)); pos as in hip.layernorm.add_layernorm
     (-> (y, y + pos))."""
     return _LnFfnLnFn.apply(x, r, norm_a.weight, norm_a.bias, norm_a.eps, p_a, linear1.weight, linear1.bias, linear2.weight, linear2.bias,
-                            norm_b.weight, norm_b.bias, norm_b.eps, p_hidden, p_b, pos)
+                            norm_b.weight, norm_b.bias, norm_b.eps, p_hidden, p_b, pos, r_bias)

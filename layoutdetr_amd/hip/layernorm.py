@@ -7,12 +7,16 @@ from . import core
 
 class _AddLnFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, r, gamma, beta, eps, p_drop, pos=None):
-        core.require_gpu(x, r, gamma, beta, pos)
+    def forward(ctx, x, r, gamma, beta, eps, p_drop, pos=None, r_bias=None):
+        core.require_gpu(x, r, gamma, beta, pos, r_bias)
         ctx.set_materialize_grads(False)
         D = x.shape[-1]
         x2 = core.f32c(x.reshape(-1, D))
-        r2 = core.f32c(r.reshape(-1, D)) if r is not None else None
+        # a 3-D residual [S, rows, D] is a sum still to be formed: r = r_bias + sum_s r[s] (the per-head contributions of the fused
+        # self-attention block, hip.attention.self_attention_parts), added in slice order inside this launch
+        n_parts = r.shape[0] if (r is not None and r.dim() == 3 and x.dim() == 2) else 0
+        r2 = (core.f32c(r) if n_parts else core.f32c(r.reshape(-1, D))) if r is not None else None
+        rb = core.f32c(r_bias) if (n_parts and r_bias is not None) else None
         g, b = core.f32c(gamma), core.f32c(beta)
         rows = x2.shape[0]
         y = torch.empty_like(x2)
@@ -22,12 +26,19 @@ class _AddLnFn(torch.autograd.Function):
         seed = core.next_seed() if (p_drop > 0 and r2 is not None) else 0
         pos2 = core.f32c(pos.reshape(-1, D)) if pos is not None else None
         ypos = torch.empty_like(x2) if pos2 is not None else None
-        core.check(core.lib().ldetr_layernorm_fwd_pos_f32(
-            core.ptr(x2), core.ptr(r2), core.ptr(g), core.ptr(b), core.ptr(y), core.ptr(z) if r2 is not None else None,
-            core.ptr(mean), core.ptr(rstd), rows, D, eps, p_drop if r2 is not None else 0.0, seed,
-            core.seed_ptr() if seed else None, core.ptr(pos2), pos2.shape[0] if pos2 is not None else 0, core.ptr(ypos), core.stream()),
-            'layernorm_fwd')
+        if n_parts:
+            core.check(core.lib().ldetr_layernorm_fwd_parts_f32(
+                core.ptr(x2), core.ptr(r2), n_parts, rows * D, core.ptr(rb), core.ptr(g), core.ptr(b), core.ptr(y), core.ptr(z),
+                core.ptr(mean), core.ptr(rstd), rows, D, eps, p_drop, seed, core.seed_ptr() if seed else None,
+                core.ptr(pos2), pos2.shape[0] if pos2 is not None else 0, core.ptr(ypos), core.stream()), 'layernorm_fwd_parts')
+        else:
+            core.check(core.lib().ldetr_layernorm_fwd_pos_f32(
+                core.ptr(x2), core.ptr(r2), core.ptr(g), core.ptr(b), core.ptr(y), core.ptr(z) if r2 is not None else None,
+                core.ptr(mean), core.ptr(rstd), rows, D, eps, p_drop if r2 is not None else 0.0, seed,
+                core.seed_ptr() if seed else None, core.ptr(pos2), pos2.shape[0] if pos2 is not None else 0, core.ptr(ypos), core.stream()),
+                'layernorm_fwd')
         ctx.save_for_backward(z, mean, rstd, g)
+        ctx.n_parts = n_parts
         ctx.cfg = (x.shape, r is not None, p_drop if r2 is not None else 0.0, seed, D)
         ctx.params = (gamma, beta)
         if pos is not None:
@@ -39,7 +50,7 @@ class _AddLnFn(torch.autograd.Function):
         z, mean, rstd, g = ctx.saved_tensors
         xshape, has_r, p_drop, seed, D = ctx.cfg
         if dy is None and dypos is None:
-            return (None,) * 7
+            return (None,) * 8
         if dy is None:
             dy, dypos = dypos, None
         dy2 = core.f32c(dy.reshape(-1, D))
@@ -64,11 +75,16 @@ class _AddLnFn(torch.autograd.Function):
             core.seed_ptr() if p_drop > 0 else None, core.stream()), 'layernorm_bwd')
         if fused:
             dgamma = dbeta = None
-        return (dx.reshape(xshape) if need_x else None, dr.reshape(xshape) if need_r else None, dgamma, dbeta, None, None, None)
+        if need_r:
+            g_r = dr.unsqueeze(0).expand(ctx.n_parts, rows, D) if ctx.n_parts else dr.reshape(xshape)     # (every slice of a partial-sum residual receives the same gradient)
+        else:
+            g_r = None
+        return (dx.reshape(xshape) if need_x else None, g_r, dgamma, dbeta, None, None, None, None)
 
 
-def add_layernorm(x, residual, gamma, beta, eps=1e-5, p_drop=0.0, pos=None):
+def add_layernorm(x, residual, gamma, beta, eps=1e-5, p_drop=0.0, pos=None, r_bias=None):
     """LayerNorm(x + dropout(residual)); residual may be None (plain LayerNorm).
+    residual [S, rows, D] with x [rows, D]: the residual is r_bias + the sum of the S slices (formed inside the launch, in slice order).
     pos ([S, D], rows broadcast over the batch): returns (y, y + pos) — the second tensor is what the next attention block projects
     q / k from, produced by the same launch instead of a separate add; its gradient is summed inside the backward launch."""
-    return _AddLnFn.apply(x, residual, gamma, beta, eps, p_drop, pos)
+    return _AddLnFn.apply(x, residual, gamma, beta, eps, p_drop, pos, r_bias)

@@ -15,7 +15,7 @@ import torch
 from torch import Tensor, nn
 
 from ..hip import core
-from ..hip.attention import grouped_kv, mha_cross_kv, mha_forward
+from ..hip.attention import grouped_kv, mha_cross_kv, mha_forward, self_attention_parts, small_usable
 from ..hip import ffn as hffn
 from ..hip.layernorm import add_layernorm
 from ..hip.linear import linear
@@ -75,19 +75,30 @@ def _ffn(layer, x2):
     return linear(h, layer.linear2.weight, layer.linear2.bias), x2
 
 
-def _add_ln(norm: nn.LayerNorm, x2, r2, drop: nn.Dropout, training, pos=None):
-    return add_layernorm(x2, r2, norm.weight, norm.bias, norm.eps, drop.p if training else 0.0, pos=pos)
+def _add_ln(norm: nn.LayerNorm, x2, r2, drop: nn.Dropout, training, pos=None, r_bias=None):
+    return add_layernorm(x2, r2, norm.weight, norm.bias, norm.eps, drop.p if training else 0.0, pos=pos, r_bias=r_bias)
 
 
-def _add_ln_ffn_add_ln(layer, norm_a: nn.LayerNorm, x2, r2, drop_a: nn.Dropout, norm_b: nn.LayerNorm, drop_b: nn.Dropout, pos=None):
+def _self_attn(m: nn.MultiheadAttention, x2, B, L, kpm, training):
+    """Self-attention sub-block with q = k = v = x2 -> (block output, out_proj bias still to be added or None, alias of x2 for the residual
+    branch).  Up to 16 tokens per sample: ONE launch (csrc/mha_small.hip) whose output is the per-head contributions [H, B*L, d]; the
+    residual + LayerNorm launch that follows sums them (r_bias).  Otherwise projection, attention, projection."""
+    if small_usable(x2, m.in_proj_weight, m.num_heads, L):
+        return self_attention_parts(x2, m.in_proj_weight, m.in_proj_bias, m.out_proj.weight, m.out_proj.bias, m.num_heads, B, L,
+                                    key_padding_mask=kpm, p_drop=m.dropout if training else 0.0)
+    a, x2 = _mha(m, x2, x2, x2, B, L, L, kpm, training, same_qkv=True)
+    return a, None, x2
+
+
+def _add_ln_ffn_add_ln(layer, norm_a: nn.LayerNorm, x2, r2, drop_a: nn.Dropout, norm_b: nn.LayerNorm, drop_b: nn.Dropout, pos=None, r_bias=None):
     """The tail of a layer: x1 = norm_a(x + dropout(r)); norm_b(x1 + dropout(linear2(dropout(relu(linear1(x1)))))) (detr_transformer.py:210-214
     / 280-285).  On the token counts of the decoder-side stacks ONE autograd node of 3 launches forward / 4 backward (hip/ffn.py: fused
     feed-forward launch, its partial sums reduced inside the LayerNorm launches); otherwise LayerNorm, two GEMMs, LayerNorm."""
     t = layer.training
     if hffn.usable(x2, layer.linear1, layer.linear2):
         return hffn.add_ln_ffn_add_ln(x2, r2, norm_a, drop_a.p if t else 0.0, layer.linear1, layer.linear2, norm_b, layer.dropout.p if t else 0.0,
-                                      drop_b.p if t else 0.0, pos=pos)
-    x2 = _add_ln(norm_a, x2, r2, drop_a, t)
+                                      drop_b.p if t else 0.0, pos=pos, r_bias=r_bias)
+    x2 = _add_ln(norm_a, x2, r2, drop_a, t, r_bias=r_bias)
     f, x2 = _ffn(layer, x2)
     return _add_ln(norm_b, x2, f, drop_b, t, pos=pos)
 
@@ -109,7 +120,10 @@ class TransformerEncoderLayer(nn.Module):
 
     def forward2d(self, x2, B, L, kpm, pos2, xpos2=None, emit_pos=False):
         """xpos2: x2 + pos2 when the producer already formed it (the previous layer's norm2 emits it: emit_pos) -> (y2[, y2 + pos2])."""
-        a, x2 = _mha(self.self_attn, x2, x2, x2, B, L, L, kpm, self.training, same_qk=pos2 is not None, same_qkv=pos2 is None, qk_pos=pos2, qk_in=xpos2)
+        if pos2 is None:
+            a, rb, x2 = _self_attn(self.self_attn, x2, B, L, kpm, self.training)
+            return _add_ln_ffn_add_ln(self, self.norm1, x2, a, self.dropout1, self.norm2, self.dropout2, r_bias=rb)
+        a, x2 = _mha(self.self_attn, x2, x2, x2, B, L, L, kpm, self.training, same_qk=True, qk_pos=pos2, qk_in=xpos2)
         return _add_ln_ffn_add_ln(self, self.norm1, x2, a, self.dropout1, self.norm2, self.dropout2, pos=pos2 if emit_pos else None)
 
 
@@ -135,8 +149,8 @@ class TransformerDecoderLayer(nn.Module):
         """-> (t2, alias of mem2, alias of mem_pos2): the next layer reads the memory through the aliases (mha_forward kv_alias).
         kv = (K, V, grad_dst) from hip.attention.grouped_kv: the memory projections of this layer were made by the stack (one GEMM for
         all layers); mem2 / mem_pos2 are then not touched here."""
-        a, t2 = _mha(self.self_attn, t2, t2, t2, B, Lq, Lq, tgt_kpm, self.training, same_qkv=True)
-        t2 = _add_ln(self.norm1, t2, a, self.dropout1, self.training)
+        a, rb, t2 = _self_attn(self.self_attn, t2, B, Lq, tgt_kpm, self.training)
+        t2 = _add_ln(self.norm1, t2, a, self.dropout1, self.training, r_bias=rb)
         if kv is not None:
             m = self.multihead_attn
             a, t2 = mha_cross_kv(t2, kv[0], kv[1], kv[2], m.in_proj_weight, m.in_proj_bias, m.out_proj.weight, m.out_proj.bias, m.num_heads, B, Lq, S,

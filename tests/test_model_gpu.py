@@ -163,6 +163,61 @@ def test_fused_ffn_stacks_equal_unfused_stacks(dev, flat):
     print(f'[fused FFN flat={flat}] worst deviation from the two-GEMM path {worst:.2e}')
 
 
+@pytest.mark.parametrize('flat,train', [(False, False), (True, False), (True, True)])
+def test_fused_self_attention_stacks_equal_unfused_stacks(dev, flat, train):
+    """The <= 16-token stacks with the one-launch self-attention forward (csrc/mha_small.hip: projection + attention + per-head output
+    projection, summed by the LayerNorm launch) against the three-launch path: TransformerWithToken's decoder (10 tokens x 16 samples) and
+    a 6-layer token encoder (9 x 16, ragged key-padding masks), outputs, input gradients and every parameter gradient.  train=True: both
+    paths draw their dropout seeds in the same order and index the attention mask identically, so they must still agree (the backward of
+    the fused block is ldetr_attention_bwd_f32 regenerating the fused forward's mask)."""
+    from layoutdetr_amd.hip import attention as A
+    from layoutdetr_amd.hip import core
+    from layoutdetr_amd.training import detr_transformer as T
+    from layoutdetr_amd.training.training_loop import FlatModule
+    torch.manual_seed(93)
+    B, N, d = 16, 9, 256
+    m = T.TransformerWithToken(d_model=d, nhead=8, num_encoder_layers=1, num_decoder_layers=6, dim_feedforward=2048, dropout=0.1).to(dev)
+    enc = T.TransformerEncoder(T.TransformerEncoderLayer(d_model=d, nhead=8, dim_feedforward=2048), num_layers=6).to(dev)
+    both = torch.nn.ModuleList([m, enc]).train(train)
+    src0 = torch.randn(B, d, 2, 2, device=dev); pos = torch.randn(B, d, 2, 2, device=dev) * 0.3
+    mask = torch.zeros(B, 2, 2, dtype=torch.bool, device=dev); mask[3, :, 1:] = True
+    tgt0 = torch.randn(N, B, d, device=dev); kpm = torch.zeros(B, N, dtype=torch.bool, device=dev); kpm[2, 4:] = True; kpm[7, 1:] = True
+    x0 = torch.randn(B * N, d, device=dev)
+    g_hs = torch.randn(B, N + 1, d, device=dev); g_enc = torch.randn(B * N, d, device=dev)
+    fm = FlatModule(both) if flat else None
+    res = {}
+    prev = A.SMALL_FUSED
+    try:
+        for fused in (False, True):
+            A.SMALL_FUSED = fused
+            core._seed_counter[0] = 1000
+            if flat:
+                fm.zero_grad(); fm.gflat.fill_(0.125)
+            else:
+                for p_ in both.parameters():
+                    p_.grad = None
+            src = src0.clone().requires_grad_(True); tgt = tgt0.clone().requires_grad_(True); x = x0.clone().requires_grad_(True)
+            n0 = core.engine_launch_counts() if hasattr(core, 'engine_launch_counts') else None
+            hs, _ = m(src, mask, pos, tgt, kpm)
+            y = enc.forward2d(x, B, N, kpm, None)
+            ((hs * g_hs).sum() + (y * g_enc).sum()).backward()
+            res[fused] = dict(hs=hs.detach().clone(), y=y.detach().clone(), d_src=src.grad.clone(), d_tgt=tgt.grad.clone(), d_x=x.grad.clone(),
+                              **{'g/' + k: p_.grad.detach().clone() for k, p_ in both.named_parameters() if p_.grad is not None})
+    finally:
+        A.SMALL_FUSED = prev
+    assert set(res[True]) == set(res[False])
+    assert any('self_attn.in_proj_weight' in k for k in res[True]) and any('self_attn.out_proj.bias' in k for k in res[True])
+    worst = 0.0
+    for k, v in res[False].items():
+        e = rel(res[True][k], v)
+        worst = max(worst, e)
+        if k in ('hs', 'y'):
+            assert e <= (2e-5 if not train else 1e-4), f'{k}: {e:.3e}'
+        else:
+            same_up_to_relu_flips(res[True][k], v, k)
+    print(f'[fused self-attention flat={flat} train={train}] worst deviation from the three-launch path {worst:.2e}')
+
+
 @pytest.mark.parametrize('cls_name,d_model,nhead', [('Transformer', 256, 4), ('TransformerWithToken', 256, 2), ('Transformer', 192, 2)])
 def test_detr_transformer_wider_heads_vs_oracle(dev, cls_name, d_model, nhead):
     """Head widths 64 / 128 / 96 (the reference's constructors take any hidden_dim / nhead; its own default is 256 / 8 = 32): DETR

@@ -50,7 +50,7 @@ def main():
     D = Discriminator(**kw).train().requires_grad_(False).to(dev)
     G.static_shapes = D.static_shapes = True
     pG, pD = tl.Phase('Gmain', G, lr=1e-5), tl.Phase('Dmain', D, lr=1e-5)
-    loss = StyleGAN2Loss(dev, G, D)
+    loss = StyleGAN2Loss(dev, G, D, share_D_trunk='iteration')
     dp = tl.DataParallelStep(1)
     batch = bench.to_device_batch(bench.make_batch(b, 256, dev, 1), dev)
     z = [torch.randn(b, 9, 4, device=dev) for _ in range(2)]
@@ -65,7 +65,7 @@ def main():
     agg = collections.Counter()
     for (name, where, shape), n in m.counts.items():
         agg[(name, where)] += n
-    for (name, where), n in agg.most_common(90):
+    for (name, where), n in agg.most_common(140):
         shapes = [f'{s}:{c}' for (nm, w, s), c in m.counts.items() if nm == name and w == where][:4]
         print(f'{n:5d}  {name:42s} {where:60s} {" ".join(shapes)}')
 

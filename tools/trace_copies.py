@@ -48,7 +48,7 @@ def main():
     D = Discriminator(**kw).train().requires_grad_(False).to(dev)
     G.static_shapes = D.static_shapes = True
     pG, pD = tl.Phase('Gmain', G, lr=1e-5), tl.Phase('Dmain', D, lr=1e-5)
-    loss = StyleGAN2Loss(dev, G, D)
+    loss = StyleGAN2Loss(dev, G, D, share_D_trunk='iteration')
     dp = tl.DataParallelStep(1)
     batch = bench.to_device_batch(bench.make_batch(b, 256, dev, 1), dev)
     z = [torch.randn(b, 9, 4, device=dev) for _ in range(2)]
