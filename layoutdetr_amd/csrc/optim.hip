@@ -45,6 +45,7 @@ __device__ __forceinline__ void adam_elem(float& p, float g, float& m, float& v,
     p -= (a.lr / a.bc1) * (m / denom);
 }
 
+template <bool EMA>      // (as a run-time branch on a.pe the plain step lost 7 % of its rate: 5.19 vs 5.58 TB/s)
 __global__ __launch_bounds__(256) void adam_kernel(AdamParams a) {
     const long n4 = a.n >> 2;
     const long stride = (long)gridDim.x * blockDim.x;
@@ -62,7 +63,7 @@ __global__ __launch_bounds__(256) void adam_kernel(AdamParams a) {
         reinterpret_cast<float4*>(a.p)[i] = p;
         __builtin_nontemporal_store(f32x4{m.x, m.y, m.z, m.w}, reinterpret_cast<f32x4*>(a.m) + i);
         __builtin_nontemporal_store(f32x4{v.x, v.y, v.z, v.w}, reinterpret_cast<f32x4*>(a.v) + i);
-        if (a.pe) {   // the G_ema lerp rides along: the updated parameters are in registers, p is not read a second time
+        if constexpr (EMA) {   // the G_ema lerp rides along: the updated parameters are in registers, p is not read a second time
             const f32x4 ev = __builtin_nontemporal_load(reinterpret_cast<f32x4*>(a.pe) + i);
             __builtin_nontemporal_store(f32x4{p.x + a.ema_beta * (ev[0] - p.x), p.y + a.ema_beta * (ev[1] - p.y),
                                               p.z + a.ema_beta * (ev[2] - p.z), p.w + a.ema_beta * (ev[3] - p.w)}, reinterpret_cast<f32x4*>(a.pe) + i);
@@ -70,7 +71,7 @@ __global__ __launch_bounds__(256) void adam_kernel(AdamParams a) {
     }
     for (long i = (n4 << 2) + (long)blockIdx.x * blockDim.x + threadIdx.x; i < a.n; i += stride) {
         adam_elem(a.p[i], a.g[i], a.m[i], a.v[i], a);
-        if (a.pe) a.pe[i] = a.p[i] + a.ema_beta * (a.pe[i] - a.p[i]);
+        if constexpr (EMA) a.pe[i] = a.p[i] + a.ema_beta * (a.pe[i] - a.p[i]);
     }
 }
 
@@ -135,7 +136,8 @@ extern "C" int ldetr_adam_ema_step_f32(float* p, const float* g, float* m, float
     a.bc1 = (float)bc1; a.bc2_sqrt = (float)sqrt(bc2);
     a.fuse_sanitize = fuse_sanitize; a.gscale = gscale; a.nanv = nan_value; a.posinf = posinf; a.neginf = neginf;
     a.pe = p_ema; a.ema_beta = ema_beta;
-    hipLaunchKernelGGL(adam_kernel, stream_grid(n), 256, 0, (hipStream_t)stream, a);
+    if (p_ema) hipLaunchKernelGGL(adam_kernel<true>, stream_grid(n), 256, 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(adam_kernel<false>, stream_grid(n), 256, 0, (hipStream_t)stream, a);
     return check_launch("adam_step");
 }
 

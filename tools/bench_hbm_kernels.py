@@ -111,5 +111,5 @@ if __name__ == '__main__':
     for r in measure():
         print(f"{r['kernel']:32s} {r['shape']:18s} {r['bytes'] / 1e6:8.1f} MB {r['us']:8.1f} us {r['tbps']:6.2f} TB/s ({r['tbps'] / 8.0:.2f} of 8 TB/s)")
     import json
-    for r in measure_named()[-2:]:
+    for r in measure_named()[-4:]:
         print(json.dumps(r))
