@@ -528,8 +528,10 @@ extern "C" int ldetr_attention_fwd_f32(const float* q, int64_t ldq, const float*
         return check_launch("attention_fwd_long");
     }
     // wide heads (the BERT text models): LDS-staged K / V shared by four query tiles per block
-    static const int wide_on = getenv("LDETR_ATTN_WIDE") ? atoi(getenv("LDETR_ATTN_WIDE")) : 1;
-    if (wide_on && head_dim >= 64 && (ldk % 4) == 0 && (ldv % 4) == 0 && ((((uintptr_t)k) | ((uintptr_t)v)) & 15) == 0) {
+    static const int wide_on = getenv("LDETR_ATTN_WIDE") ? atoi(getenv("LDETR_ATTN_WIDE")) : 3;
+    const bool wide_on_32 = (wide_on & 2) != 0;
+    // (32-wide heads too when a block's four query tiles are mostly real: the DETR encoder's 64 x 64 self-attention; bit 1 of the switch)
+    if ((wide_on & 1) && (head_dim >= 64 || ((wide_on_32) && Lq >= 48)) && (ldk % 4) == 0 && (ldv % 4) == 0 && ((((uintptr_t)k) | ((uintptr_t)v)) & 15) == 0) {
         const int nch = (Lk + 63) / 64, wgrid = B * H * ((Lq + 63) / 64);
 #define LDETR_ATTN_WIDE(NCH, DHC)                                                                                         \
     do {                                                                                                                   \
@@ -542,6 +544,7 @@ extern "C" int ldetr_attention_fwd_f32(const float* q, int64_t ldq, const float*
         else if (nch <= 3) LDETR_ATTN_WIDE(3, DHC); else LDETR_ATTN_WIDE(4, DHC);                                          \
     } while (0)
         switch (head_dim / 32) {
+            case 1: LDETR_ATTN_WIDE_D(1); break;
             case 2: LDETR_ATTN_WIDE_D(2); break;
             case 3: LDETR_ATTN_WIDE_D(3); break;
             case 4: LDETR_ATTN_WIDE_D(4); break;
