@@ -422,11 +422,12 @@ def test_maxpool(dev):
 
 
 # ------------------------------------------------------------------------------------------ attention
-@pytest.mark.parametrize('B,H,Lq,Lk,dh', [(2, 8, 9, 9, 32), (2, 8, 10, 64, 32), (3, 2, 64, 64, 32), (1, 4, 16, 256, 32), (2, 8, 33, 100, 32),
+@pytest.mark.parametrize('B,H,Lq,Lk,dh', [(2, 8, 9, 9, 32), (2, 8, 10, 64, 32), (3, 2, 64, 64, 32), (2, 8, 33, 40, 32), (2, 3, 64, 17, 32), (1, 4, 16, 256, 32), (2, 8, 33, 100, 32),
                                           (2, 8, 9, 257, 32), (2, 2, 300, 400, 32), (1, 4, 16, 1024, 32), (1, 2, 1024, 1024, 32), (2, 1, 40, 2100, 32),
                                           (2, 4, 9, 64, 64), (2, 2, 10, 256, 128), (2, 4, 70, 300, 64), (2, 3, 9, 9, 96)])
 def test_attention(dev, B, H, Lq, Lk, dh):
     """Lk <= 256: scores in registers; above: 256-key chunks with an online softmax (background_size 1024 -> 1024 memory tokens).
+    32-wide heads with 17..64 keys and <= 64 queries take the LDS-staged backward (attn_bwd_lds_kernel), 48+ queries the LDS-staged forward.
     Head widths 32 (the DETR blocks at 8 heads) .. 128 (hidden 256 at 4 / 2 heads), cross-attention shapes (Lq != Lk)."""
     from layoutdetr_amd.hip import attention
     torch.manual_seed(9)
@@ -845,7 +846,7 @@ def test_bottleneck_chain_fused_block_gradients(dev):
         assert_close(a, r, 3e-5, f'dw[{i}]')
 
 
-@pytest.mark.parametrize('B,H,L,dh,causal', [(2, 4, 40, 192, True), (3, 3, 21, 64, True), (2, 2, 70, 96, False), (2, 4, 40, 192, False), (2, 8, 19, 32, True),
+@pytest.mark.parametrize('B,H,L,dh,causal', [(2, 4, 40, 192, True), (3, 3, 21, 64, True), (2, 2, 70, 96, False), (2, 4, 40, 192, False), (2, 8, 19, 32, True), (2, 8, 64, 32, True), (3, 4, 37, 32, True),
                                              (2, 2, 256, 192, False), (2, 2, 200, 64, True), (1, 3, 130, 160, False), (2, 1, 64, 128, True),
                                              (2, 2, 300, 64, True), (1, 2, 520, 96, False)])
 def test_attention_wide_heads_and_causal(dev, B, H, L, dh, causal):
