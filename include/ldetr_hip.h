@@ -211,6 +211,17 @@ int ldetr_mha_small_fwd_f32(const float* x, int64_t ldx, const float* w_in, cons
                             int B, int L, int D, int H, float scale, float p_drop, uint64_t seed, const uint64_t* seed_ptr,
                             void* stream);
 
+/* Cross-attention sub-block of a decoder layer (training/detr_transformer.py:277-280) with <= 16 queries per sample onto <= 64 memory
+ * tokens whose K / V projections already exist (k, v: [B*Lk][ldk / ldv], head h in columns 32 h .. 32 h + 31): query projection
+ * (w_q, b_q = rows 0..255 of in_proj_weight / in_proj_bias), attention, per-head output projection in one launch.
+ *   -> q [B*Lq][256] (projected queries incl. bias, unscaled), o [B*Lq][256], lse [B][8][Lq]: what ldetr_attention_bwd_f32 reads;
+ *   -> ypart [8][B*Lq][256] as in ldetr_mha_small_fwd_f32. */
+int ldetr_mha_cross_fwd_f32(const float* x, int64_t ldx, const float* w_q, const float* b_q,
+                            const float* k, int64_t ldk, const float* v, int64_t ldv, const float* w_out,
+                            const uint8_t* kpm, float* q, float* o, float* lse, float* ypart,
+                            int B, int Lq, int Lk, int D, int H, float scale, float p_drop, uint64_t seed, const uint64_t* seed_ptr,
+                            void* stream);
+
 /* Position-wise feed-forward block linear2(dropout(relu(linear1(x)))) of the DETR layers (training/detr_transformer.py:212-214, 283-285;
  * d_model D = 256, hidden width F a multiple of 64), one launch per direction (csrc/ffn_fused.hip).
  * fwd: x [M][ldx], w1 [F][D], b1 [F], w2 [D][F] -> h [M][F] (hidden after relu + dropout, kept for the backward) and

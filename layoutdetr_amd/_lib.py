@@ -60,6 +60,7 @@ SIGNATURES = {
     'ldetr_layernorm_fwd_pos_f32': [_P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _F, _F, c_uint64, _P, _P, _L, _P, _P],
     'ldetr_layernorm_fwd_parts_f32': [_P, _P, _I, _L, _P, _P, _P, _P, _P, _P, _P, _L, _I, _F, _F, c_uint64, _P, _P, _L, _P, _P],
     'ldetr_mha_small_fwd_f32': [_P, _L, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _F, c_uint64, _P, _P],
+    'ldetr_mha_cross_fwd_f32': [_P, _L, _P, _P, _P, _L, _P, _L, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _F, c_uint64, _P, _P],
     'ldetr_ffn_fwd_f32': [_P, _L, _P, _P, _P, _P, _P, _L, _I, _I, _F, c_uint64, _P, _P],
     'ldetr_ffn_bwd_f32': [_P, _P, _L, _P, _P, _P, _P, _P, _L, _I, _I, _F, _P],
     'ldetr_layernorm_bwd_parts_f32': [_P, _P, _P, _I, _L, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _F, c_uint64, _P, _P],
@@ -117,7 +118,7 @@ def load():
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported
         fn.restype = c_int
         fn.argtypes = argtypes
-    if lib.ldetr_abi_version() != 19:
+    if lib.ldetr_abi_version() != 20:
         raise RuntimeError('libldetr_hip.so ABI version mismatch; rebuild it')
     _lib = lib
     return lib

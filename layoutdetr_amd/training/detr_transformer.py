@@ -153,11 +153,12 @@ class TransformerDecoderLayer(nn.Module):
         t2 = _add_ln(self.norm1, t2, a, self.dropout1, self.training, r_bias=rb)
         if kv is not None:
             m = self.multihead_attn
-            a, t2 = mha_cross_kv(t2, kv[0], kv[1], kv[2], m.in_proj_weight, m.in_proj_bias, m.out_proj.weight, m.out_proj.bias, m.num_heads, B, Lq, S,
-                                 key_padding_mask=mem_kpm, p_drop=m.dropout if self.training else 0.0)
+            a, rb, t2 = mha_cross_kv(t2, kv[0], kv[1], kv[2], m.in_proj_weight, m.in_proj_bias, m.out_proj.weight, m.out_proj.bias, m.num_heads, B, Lq, S,
+                                     key_padding_mask=mem_kpm, p_drop=m.dropout if self.training else 0.0)
         else:
+            rb = None
             a, t2, mem_pos2, mem2 = _mha(self.multihead_attn, t2, mem_pos2, mem2, B, Lq, S, mem_kpm, self.training, kv_alias=True)
-        return _add_ln_ffn_add_ln(self, self.norm2, t2, a, self.dropout2, self.norm3, self.dropout3), mem2, mem_pos2
+        return _add_ln_ffn_add_ln(self, self.norm2, t2, a, self.dropout2, self.norm3, self.dropout3, r_bias=rb), mem2, mem_pos2
 
 
 def _get_clones(module, N):

@@ -547,6 +547,76 @@ def test_split_bf16_non_finite_operands_match_f32_pipe_and_reference_sanitiser(d
         assert_close(pg.cpu()[big], pr.detach()[big], 1e-5, 'adam after sanitising a split-pipe gradient')
 
 
+# ------------------------------------------------------------------------------------------ fused attention sub-blocks
+@pytest.mark.parametrize('B,Lq,Lk,p_mask', [(16, 9, 0, True), (5, 10, 0, True), (3, 16, 0, False), (1, 1, 0, False),
+                                            (16, 10, 64, True), (4, 9, 4, True), (3, 16, 37, True), (2, 1, 64, False)])
+def test_fused_attention_subblocks_vs_fp64_reference(dev, B, Lq, Lk, p_mask):
+    """y = LayerNorm(x + MultiheadAttention(256, 8)(...)) through the one-launch forward kernels of csrc/mha_small.hip (Lk = 0: self-attention
+    q = k = v = x, mha_small_fwd_kernel; Lk > 0: cross-attention onto already projected memory K / V, mha_cross_fwd_kernel), their per-head
+    contributions summed by the partial-sum LayerNorm launch, backward through ldetr_attention_bwd_f32 + the paired projection gradients --
+    against an fp64 torch evaluation (no relu on this path: every value and gradient is held entry by entry), ragged key-padding masks."""
+    from layoutdetr_amd.hip import attention as A
+    from layoutdetr_amd.hip.layernorm import add_layernorm
+    torch.manual_seed(300 + 7 * B + Lq + Lk)
+    d, H = 256, 8
+    mha = torch.nn.MultiheadAttention(d, H, dropout=0.0)
+    mha.in_proj_bias.data.normal_(0, 0.2); mha.out_proj.bias.data.normal_(0, 0.2)
+    ln = torch.nn.LayerNorm(d); ln.weight.data.uniform_(0.5, 1.5); ln.bias.data.normal_(0, 0.1)
+    x = torch.randn(B * Lq, d); gy = torch.randn(B * Lq, d)
+    S = Lk if Lk else Lq
+    kpm = torch.zeros(B, S, dtype=torch.bool)
+    if p_mask:
+        kpm[0, S - S // 3:] = True
+        if B > 2:
+            kpm[2, 1:] = True
+    cross = Lk > 0
+    Kp = torch.randn(B * Lk, 2 * d)[:, :d] if cross else None      # views with a row pitch, as hip.attention.grouped_kv hands them out
+    Vp = torch.randn(B * Lk, 3 * d)[:, d:2 * d] if cross else None
+    # ---- fp64 reference
+    Wi, bi, Wo, bo = [t.detach().double() for t in (mha.in_proj_weight, mha.in_proj_bias, mha.out_proj.weight, mha.out_proj.bias)]
+    Wi.requires_grad_(True); bi.requires_grad_(True); Wo.requires_grad_(True); bo.requires_grad_(True)
+    lnr = torch.nn.LayerNorm(d).double(); lnr.load_state_dict({k: v.double() for k, v in ln.state_dict().items()})
+    xr = x.double().requires_grad_(True)
+    if cross:
+        Kr, Vr = Kp.double().clone().requires_grad_(True), Vp.double().clone().requires_grad_(True)
+        q = xr @ Wi[:d].t() + bi[:d]; k, v = Kr, Vr
+    else:
+        qkv = xr @ Wi.t() + bi
+        q, k, v = qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:]
+    heads = lambda t, L: t.reshape(B, L, H, d // H).permute(0, 2, 1, 3)
+    sc = heads(q, Lq) @ heads(k, S).transpose(-1, -2) / math.sqrt(d // H)
+    sc = sc.masked_fill(kpm[:, None, None, :], float('-inf'))
+    o = (sc.softmax(-1) @ heads(v, S)).permute(0, 2, 1, 3).reshape(B * Lq, d)
+    yr = lnr(xr + o @ Wo.t() + bo)
+    (yr * gy.double()).sum().backward()
+    # ---- HIP
+    mha.to(dev); ln.to(dev)
+    xg = x.to(dev).requires_grad_(True)
+    if cross:
+        Kg, Vg = Kp.to(dev).requires_grad_(True), Vp.to(dev).requires_grad_(True)
+        Kv, Vv = Kg.as_strided(Kg.shape, Kg.stride()), Vg.as_strided(Vg.shape, Vg.stride())
+        assert A.cross_usable(xg, Kg, Vg, mha.in_proj_weight, H, Lq, Lk)
+        part, rb, alias = A.mha_cross_kv(xg, Kg, Vg, None, mha.in_proj_weight, mha.in_proj_bias, mha.out_proj.weight, mha.out_proj.bias, H, B, Lq, Lk,
+                                         key_padding_mask=kpm.to(dev), p_drop=0.0)
+    else:
+        assert A.small_usable(xg, mha.in_proj_weight, H, Lq)
+        part, rb, alias = A.self_attention_parts(xg, mha.in_proj_weight, mha.in_proj_bias, mha.out_proj.weight, mha.out_proj.bias, H, B, Lq,
+                                                 key_padding_mask=kpm.to(dev), p_drop=0.0)
+    assert part.shape == (H, B * Lq, d)
+    y = add_layernorm(alias, part, ln.weight, ln.bias, ln.eps, 0.0, r_bias=rb)
+    (y * gy.to(dev)).sum().backward()
+    assert_close(y, yr, 1e-5, 'y')
+    assert_close(xg.grad, xr.grad, 2e-5, 'dx')
+    if cross:
+        assert_close(Kg.grad, Kr.grad, 2e-5, 'dK'); assert_close(Vg.grad, Vr.grad, 2e-5, 'dV')
+        assert_close(mha.in_proj_weight.grad[:d], Wi.grad[:d], 2e-5, 'dW_q'); assert_close(mha.in_proj_bias.grad[:d], bi.grad[:d], 2e-5, 'db_q')
+        assert float(mha.in_proj_weight.grad[d:].abs().max()) == 0.0        # (the K / V rows belong to the grouped projection's node)
+    else:
+        assert_close(mha.in_proj_weight.grad, Wi.grad, 2e-5, 'dW_in'); assert_close(mha.in_proj_bias.grad, bi.grad, 2e-5, 'db_in')
+    assert_close(mha.out_proj.weight.grad, Wo.grad, 2e-5, 'dW_out'); assert_close(mha.out_proj.bias.grad, bo.grad, 2e-5, 'db_out')
+    assert_close(ln.weight.grad, lnr.weight.grad, 2e-5, 'dgamma'); assert_close(ln.bias.grad, lnr.bias.grad, 2e-5, 'dbeta')
+
+
 # ------------------------------------------------------------------------------------------ fused feed-forward block
 @pytest.mark.parametrize('M,F,pos', [(144, 2048, False), (160, 2048, True), (9, 128, False), (320, 2048, False), (33, 64, True)])
 def test_ln_ffn_ln_fused_tail_vs_fp64_reference(dev, M, F, pos):
