@@ -23,6 +23,8 @@
 
 namespace ldetr {
 
+bool engine_split_enabled();      // gemm_conv.hip: ldetr_set_split_bf16 / LDETR_SPLIT_BF16 != 0
+
 struct ConvC32Params {
     const float* x; float* y; const float* w;                  // x, y: [N, H, W, 32] packed; w: [32 out][3][3][32 in] (OHWI)
     const float* k_scale; long k_scale_ld;                      // per sample, per input channel of THIS contraction (style / demod), or null
@@ -108,6 +110,129 @@ __global__ __launch_bounds__(256) void conv3x3_c32_kernel(ConvC32Params p) {
     }
 }
 
+// The same convolution on the bf16 matrix pipe with the exact three-way operand split (x = hi + mid + lo, six products per k16 slab:
+// fp32-equivalent results, see gemm_conv.hip "SPLIT").  The filter bank is split ONCE per block while it is folded into LDS -- the main
+// loop's B operand is three 16-byte LDS reads per k16 slab with no VALU -- and only the activations are split per tap (72 VALU per
+// lane against 16 v_mfma_f32_32x32x2_f32 = 1024 matrix-pipe cycles saved: 12 v_mfma_f32_32x32x16_bf16 = 384 cycles take their place).
+//   A (32 pixels x 16 k, bf16): lane (pixel cl, k-group kl) splits channels [16 m + 8 kl, + 8), m = 0, 1, of its pixel;
+//   B (16 k x 32 output channels): bank[tap][m][part][slot = 32 kl + o] = 8 consecutive reduction channels as one 16-byte slot,
+//                                  so lane l reads slot l: conflict-free ds_read_b128.
+// Non-finite values: Inf splits into Inf + NaN + NaN.  A segment whose accumulator comes out non-finite is recomputed on the f32 pipe
+// (v_mfma_f32_32x32x2_f32, operands straight from global memory: cold path), so the kernel returns what conv3x3_c32_kernel returns.
+__global__ __launch_bounds__(256) void conv3x3_c32_split_kernel(ConvC32Params p) {
+    __shared__ __attribute__((aligned(16))) unsigned wl[9 * 2 * 3 * 64 * 4];      // 55296 B
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, cl = lane & 31, kl = lane >> 5;
+    const long gw = (long)blockIdx.x * 4 + wave;
+    const int n = (int)(((long)blockIdx.x * 4) / p.waves_per_sample), wv = (int)(gw - (long)n * p.waves_per_sample);
+    if (n >= p.N) return;
+    const float* ks = p.k_scale ? p.k_scale + (long)n * p.k_scale_ld : nullptr;
+    // ---- the block's filter bank, factors folded in, split into its three bf16 parts: 1152 slots of 8 reduction channels
+    for (int sidx = tid; sidx < 1152; sidx += 256) {
+        const int o = sidx & 31, g = (sidx >> 5) & 1, m = (sidx >> 6) & 1, t = sidx >> 7;
+        const int k0 = 16 * m + 8 * g;
+        float v[8];
+        if (!p.transposed) {
+            const float4 w0 = *reinterpret_cast<const float4*>(p.w + (o * 9 + t) * 32 + k0), w1 = *reinterpret_cast<const float4*>(p.w + (o * 9 + t) * 32 + k0 + 4);
+            v[0] = w0.x; v[1] = w0.y; v[2] = w0.z; v[3] = w0.w; v[4] = w1.x; v[5] = w1.y; v[6] = w1.z; v[7] = w1.w;
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; j++) v[j] = p.w[((k0 + j) * 9 + (8 - t)) * 32 + o];      // reduce over the forward's output channels, taps flipped
+        }
+        if (ks) {
+#pragma unroll
+            for (int j = 0; j < 8; j++) v[j] *= ks[k0 + j];
+        }
+        unsigned h[4], md[4], lo[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) split2_bf16(v[2 * j], v[2 * j + 1], h[j], md[j], lo[j]);
+        unsigned* dst = wl + (((t * 2 + m) * 3) * 64 + g * 32 + o) * 4;
+        *reinterpret_cast<uint4*>(dst) = make_uint4(h[0], h[1], h[2], h[3]);
+        *reinterpret_cast<uint4*>(dst + 64 * 4) = make_uint4(md[0], md[1], md[2], md[3]);
+        *reinterpret_cast<uint4*>(dst + 2 * 64 * 4) = make_uint4(lo[0], lo[1], lo[2], lo[3]);
+    }
+    __syncthreads();
+    const int segs = p.W >> 5, tiles = p.H * segs;
+    const int t0 = wv * p.tiles_per_wave, t1 = min(tiles, t0 + p.tiles_per_wave);
+    if (t0 >= t1) return;
+    const float osc = p.o_scale ? p.o_scale[(long)n * p.o_scale_ld + cl] : 1.f;
+    const float bs = p.bias ? p.bias[cl] : 0.f;
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x) + (long)n * p.H * p.W * 32, 0, 0x7fffffff, 0x00020000);
+    float* const yb = p.y + (long)n * p.H * p.W * 32;
+    const int OOB = (int)0x80000000;
+    auto voff = [&](int tile, int g) {      // byte offset of channel 8 kl of this lane's pixel for tap g, or out of range
+        const int y = tile / segs, x0 = (tile - y * segs) << 5;
+        const int yy = y + g / 3 - 1, xx = x0 + cl + g % 3 - 1;
+        return (tile < t1 && (unsigned)yy < (unsigned)p.H && (unsigned)xx < (unsigned)p.W) ? ((yy * p.W + xx) * 32 + 8 * kl) * 4 : OOB;
+    };
+    auto loadA = [&](int vo, float (&a)[16]) {      // a[0..7] = channels 8 kl .. + 7, a[8..15] = channels 16 + 8 kl .. + 7
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const auto v = __builtin_amdgcn_raw_buffer_load_b128(rx, vo, (j >> 1) * 64 + (j & 1) * 16, 0);
+            a[4 * j] = __int_as_float(v[0]); a[4 * j + 1] = __int_as_float(v[1]); a[4 * j + 2] = __int_as_float(v[2]); a[4 * j + 3] = __int_as_float(v[3]);
+        }
+    };
+    int woff = lane * 4;
+    float a[3][16];
+    loadA(voff(t0, 0), a[0]);
+    loadA(voff(t0, 1), a[1]);
+    for (int tile = t0; tile < t1; tile++) {
+        c32_acc_t acc;
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[r] = 0.f;
+        asm volatile("" : "+v"(woff));      // keep the bank reads inside the loop (see conv3x3_c32_kernel)
+        const unsigned* const wrow = wl + woff;
+#pragma unroll
+        for (int g = 0; g < 9; g++) {
+            if (g < 7) loadA(voff(tile, g + 2), a[(g + 2) % 3]);
+            else loadA(voff(tile + 1, g - 7), a[(g + 2) % 3]);
+#pragma unroll
+            for (int m = 0; m < 2; m++) {
+                unsigned ah[4], am[4], al[4];
+#pragma unroll
+                for (int j = 0; j < 4; j++) split2_bf16(a[g % 3][8 * m + 2 * j], a[g % 3][8 * m + 2 * j + 1], ah[j], am[j], al[j]);
+                const uint4 A0 = make_uint4(ah[0], ah[1], ah[2], ah[3]), A1 = make_uint4(am[0], am[1], am[2], am[3]), A2 = make_uint4(al[0], al[1], al[2], al[3]);
+                const uint4 B0 = *reinterpret_cast<const uint4*>(wrow + ((g * 2 + m) * 3 + 0) * 256);
+                const uint4 B1 = *reinterpret_cast<const uint4*>(wrow + ((g * 2 + m) * 3 + 1) * 256);
+                const uint4 B2 = *reinterpret_cast<const uint4*>(wrow + ((g * 2 + m) * 3 + 2) * 256);
+#define C32_MF(X, Y) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8_t*>(&X), *reinterpret_cast<const bf16x8_t*>(&Y), acc, 0, 0, 0)
+                C32_MF(A1, B1); C32_MF(A0, B2); C32_MF(A2, B0); C32_MF(A0, B1); C32_MF(A1, B0); C32_MF(A0, B0);      // smallest terms first
+#undef C32_MF
+            }
+        }
+        float chk = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; r++) chk = __builtin_fmaf(acc[r], 0.f, chk);
+        if (__builtin_expect(__ballot(chk != chk) != 0ull, 0)) {
+            // cold path: this segment again on the f32 pipe, operands from global memory (step s of a tap: lane k-group kl takes reduction
+            // channel c = (s < 8 ? 8 kl + s : 16 + 8 kl + s - 8) on both sides)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[r] = 0.f;
+            for (int g = 0; g < 9; g++) {
+                float af[16];
+                loadA(voff(tile, g), af);
+#pragma unroll 1
+                for (int s2 = 0; s2 < 16; s2++) {
+                    const int c = (s2 < 8 ? 8 * kl + s2 : 16 + 8 * kl + s2 - 8);
+                    float wv_ = !p.transposed ? p.w[(cl * 9 + g) * 32 + c] : p.w[(c * 9 + (8 - g)) * 32 + cl];
+                    if (ks) wv_ *= ks[c];
+                    float av = 0.f;
+#pragma unroll
+                    for (int q = 0; q < 16; q++) av = (q == s2) ? af[q] : av;
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, wv_, acc, 0, 0, 0);
+                }
+            }
+        }
+        const int y = tile / segs, x0 = (tile - y * segs) << 5;
+        float* dst = yb + ((long)y * p.W + x0) * 32 + cl;
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            float v = acc[r] * osc + bs;
+            if (p.act == 2) v = (v > 0.f ? v : v * p.act_alpha) * p.act_gain;
+            dst[((r & 3) + 8 * (r >> 2) + 4 * kl) * 32] = v;
+        }
+    }
+}
+
 // -> 1 if the launch was taken, 0 if the shape / epilogue does not fit (the caller continues on the tiled engine), < 0 on error
 int try_launch_conv_c32(const float* x, const ldetr_tensor4* xt, const float* w, int Cout, int KH, int KW, int stride, int pad,
                         float* y, long ldy, int OH, int OW, const float* k_scale, long k_scale_ld, const ldetr_epilogue* ep,
@@ -135,7 +260,10 @@ int try_launch_conv_c32(const float* x, const ldetr_tensor4* xt, const float* w,
     if (wps > tiles) wps = (tiles + 3) & ~3;
     p.waves_per_sample = wps;
     p.tiles_per_wave = (tiles + wps - 1) / wps;
-    hipLaunchKernelGGL(conv3x3_c32_kernel, dim3((unsigned)((long)N * wps / 4)), dim3(256), 0, st, p);
+    // bf16 pipe with the exact operand split unless the engine's switch puts everything on the f32 MFMAs (LDETR_CONV_C32_SPLIT=0: f32 here only)
+    static const int split_on = getenv("LDETR_CONV_C32_SPLIT") ? atoi(getenv("LDETR_CONV_C32_SPLIT")) : 1;
+    if (split_on && engine_split_enabled()) hipLaunchKernelGGL(conv3x3_c32_split_kernel, dim3((unsigned)((long)N * wps / 4)), dim3(256), 0, st, p);
+    else hipLaunchKernelGGL(conv3x3_c32_kernel, dim3((unsigned)((long)N * wps / 4)), dim3(256), 0, st, p);
     return check_launch("conv3x3_c32") == 0 ? 1 : -1;
 }
 

@@ -379,30 +379,7 @@ __device__ __forceinline__ float apply_epilogue(const GemmEpilogue& ep, float v,
 // Same 32x32 accumulator layout, so loaders, split-K fix-up and epilogues are shared with the f32 path.  Non-finite inputs
 // (Inf splits into Inf + NaN; so does |x| within one bf16 ulp of FLT_MAX) are handled after the loop: a tile with a non-finite
 // accumulator is recomputed on the f32 pipe inside the same launch, so such launches return what the f32 instantiation returns.
-__device__ __forceinline__ unsigned pk_bf16(float a, float b) {
-    typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
-    bf16x2_t r = {(__bf16)a, (__bf16)b};
-    return *reinterpret_cast<unsigned*>(&r);
-}
-// 9 VALU instructions per pair: 3 packed conversions (round to nearest even), 2 x (shift, mask) to widen a part back to fp32, 2 packed
-// subtractions (exact: a part is the leading bits of what it is subtracted from).  The shift is inline asm because hipcc otherwise
-// re-converts the low element on its own instead of shifting the packed word (one more instruction per part).
-__device__ __forceinline__ void split2_bf16(float x0, float x1, unsigned& h, unsigned& m, unsigned& l) {
-    typedef __attribute__((ext_vector_type(2))) float f32x2_t;
-    auto widen = [](unsigned w) {
-        unsigned lo16;
-        asm("v_lshlrev_b32 %0, 16, %1" : "=v"(lo16) : "v"(w));
-        f32x2_t r = {__uint_as_float(lo16), __uint_as_float(w & 0xffff0000u)};
-        return r;
-    };
-    const f32x2_t x = {x0, x1};
-    h = pk_bf16(x.x, x.y);
-    const f32x2_t r = x - widen(h);
-    m = pk_bf16(r.x, r.y);
-    const f32x2_t t = r - widen(m);
-    l = pk_bf16(t.x, t.y);
-}
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+// (pk_bf16 / split2_bf16 / bf16x8_t: ldetr_common.hpp -- shared with conv_c32.hip)
 #ifndef LDETR_KC_PAD
 #define LDETR_KC_PAD 64   // bytes between the (part, k-block) planes of a k-contiguous operand's LDS image (see gemm_f32_kernel)
 #endif
@@ -1758,6 +1735,13 @@ static int launch_gemm(GemmParams& p, int Mmax, long out_rows, int zbase, bool a
 // Weight gradients reduce over pixels (K = N*OH*OW, up to 2^20) into a small [Cout, taps, Cin] output: pick the tile
 // first (128-wide tiles when the channel counts allow them: two accumulator chains per wave, fewer LDS reads per MFMA),
 // then split K until that tile's grid fills the chip.  Mirrors the tile thresholds of launch_gemm.
+// (conv_c32.hip follows the same switch: value_f32_mfma_only of the bench line and the f32-pipe halves of the parity tests cover it too)
+bool engine_split_enabled() {
+    static const int split_tiles_env = getenv("LDETR_SPLIT_BF16") ? atoi(getenv("LDETR_SPLIT_BF16")) : 15;
+    const int ovr = g_split_bf16_override.load(std::memory_order_relaxed);
+    return (ovr >= 0 ? ovr : split_tiles_env) != 0;
+}
+
 static int wgrad_auto_split(int M, int N, int K, int zbase) {
     // few pixels (small per-GPU batches): shorter slices keep the chip busy; the floor of a weight-gradient launch is its serial k-loop
     // (measured: 128-pixel slices help at 2 samples per GPU, 25.3 -> 24.8 ms per step, and cost 4 % at 16 per GPU: keyed on the launch's work)

@@ -59,6 +59,32 @@ __device__ __forceinline__ float drop_scale(uint64_t seed, uint64_t idx, float p
     return (u >= p_drop) ? inv_keep : 0.0f;
 }
 
+// ---- exact three-way bf16 split of fp32 operands (gemm_conv.hip's SPLIT path, conv_c32.hip): x = hi + mid + lo
+__device__ __forceinline__ unsigned pk_bf16(float a, float b) {
+    typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+    bf16x2_t r = {(__bf16)a, (__bf16)b};
+    return *reinterpret_cast<unsigned*>(&r);
+}
+// 9 VALU instructions per pair: 3 packed conversions (round to nearest even), 2 x (shift, mask) to widen a part back to fp32, 2 packed
+// subtractions (exact: a part is the leading bits of what it is subtracted from).  The shift is inline asm because hipcc otherwise
+// re-converts the low element on its own instead of shifting the packed word (one more instruction per part).
+__device__ __forceinline__ void split2_bf16(float x0, float x1, unsigned& h, unsigned& m, unsigned& l) {
+    typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+    auto widen = [](unsigned w) {
+        unsigned lo16;
+        asm("v_lshlrev_b32 %0, 16, %1" : "=v"(lo16) : "v"(w));
+        f32x2_t r = {__uint_as_float(lo16), __uint_as_float(w & 0xffff0000u)};
+        return r;
+    };
+    const f32x2_t x = {x0, x1};
+    h = pk_bf16(x.x, x.y);
+    const f32x2_t r = x - widen(h);
+    m = pk_bf16(r.x, r.y);
+    const f32x2_t t = r - widen(m);
+    l = pk_bf16(t.x, t.y);
+}
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -1202,6 +1202,59 @@ def test_split_bf16_gemm_is_fp32_equivalent(dev, ta, tb, M, N, K):
     assert r1 <= 1.25 * r0 + 1e-9 and m1 <= 2.0 * m0 + 1e-9 and m1 < 5e-6
 
 
+def test_conv_c32_split_pipe_is_fp32_equivalent_and_non_finite_safe(dev):
+    """csrc/conv_c32.hip (3x3, 32 -> 32 channels, 256x256: forward with per-sample input-channel factors + per-sample output factors + bias +
+    lrelu, and the data gradient = the transposed, tap-flipped bank) on the f32 MFMA pipe and on the bf16 pipe with the exact operand split:
+    both against fp64 (the split at least as close), and with +-Inf / NaN / FLT_MAX planted in the activations the split kernel must return
+    exactly the f32 kernel's non-finite pattern (a segment that meets one recomputes itself on the f32 pipe) and untouched values elsewhere."""
+    import ctypes
+    from layoutdetr_amd.hip import core
+    torch.manual_seed(43)
+    N, H, C = 4, 256, 32
+    x = torch.randn(N, H, H, C) * torch.exp(0.7 * torch.randn(1, 1, 1, C)); w = torch.randn(C, 3, 3, C) * 0.1          # NHWC, OHWI
+    st = torch.rand(N, C) + 0.5; dm = torch.rand(N, C) + 0.5; b = torch.randn(C) * 0.1
+    L = core.lib()
+
+    def run(xin, transposed):
+        xd, wd, sd, dd, bd = [t.to(dev).contiguous() for t in (xin, w, st, dm, b)]
+        y = torch.empty(N, H, H, C, device=dev)
+        xt = core.tensor4_nhwc(xd)
+        if not transposed:
+            ep = core.epilogue(col_bias=bd, samp_scale=dd, act=core.ACT_LRELU, act_alpha=0.2, act_gain=math.sqrt(2))
+            core.check(L.ldetr_conv2d_fwd_f32(core.ptr(xd), ctypes.byref(xt), core.ptr(wd), C, 3, 3, 1, 1, core.ptr(y), C, H, H, core.ptr(sd), C,
+                                              ctypes.byref(ep), core.stream()), 'conv fwd')
+        else:
+            core.check(L.ldetr_conv2d_bwd_data_f32(core.ptr(xd), ctypes.byref(xt), core.ptr(wd), C, 3, 3, 1, 1, core.ptr(y), C, H, H, core.ptr(dd), C,
+                                                   None, core.stream()), 'conv bwd data')
+        torch.cuda.synchronize()
+        return y.cpu()
+    for transposed in (False, True):
+        xr = x.double().permute(0, 3, 1, 2)
+        if not transposed:
+            ref = F.conv2d(xr * st.double()[:, :, None, None], w.double().permute(0, 3, 1, 2), padding=1) * dm.double()[:, :, None, None] + b.double()[None, :, None, None]
+            ref = F.leaky_relu(ref, 0.2) * math.sqrt(2)
+        else:
+            ref = F.conv_transpose2d(xr * dm.double()[:, :, None, None], w.double().permute(0, 3, 1, 2), padding=1)
+        ref = ref.permute(0, 2, 3, 1)
+        f32, sp = _both_pipes(lambda: run(x, transposed))
+        (m0, r0), (m1, r1) = _err(f32, ref), _err(sp, ref)
+        print(f'conv_c32 transposed={transposed}: f32 pipe max {m0:.2e} rms {r0:.2e} | bf16 split max {m1:.2e} rms {r1:.2e}')
+        assert not torch.equal(f32, sp), 'both runs took the same kernel'
+        assert r1 <= 1.25 * r0 + 1e-9 and m1 <= 2.0 * m0 + 1e-9 and m1 < 5e-6
+        xp = x.clone()
+        xp[0, 10, 40, 3] = float('inf'); xp[1, 200, 77, 9] = float('-inf'); xp[2, 0, 0, 31] = float('nan'); xp[3, 255, 255, 0] = 3.4e38; xp[3, 100, 31, 5] = float('inf')
+        f32p, spp = _both_pipes(lambda: run(xp, transposed))
+        bad = ~torch.isfinite(f32p)
+        assert bad.any() and torch.equal(bad, ~torch.isfinite(spp)), 'non-finite pattern differs between the pipes'
+        assert torch.equal(torch.isnan(f32p), torch.isnan(spp)) and torch.equal(f32p[bad & ~torch.isnan(f32p)], spp[bad & ~torch.isnan(spp)]), 'Inf / NaN classes differ'
+        touched = bad | (f32p != f32)                                   # outputs whose 3x3 window holds a planted value
+        seg = touched.reshape(N, H, H // 32, 32 * C).any(-1)             # their 32-pixel segments (the unit the f32 redo works on)
+        clean = ~seg[..., None].expand(N, H, H // 32, 32 * C).reshape(N, H, H, C)
+        assert torch.equal(spp[clean], sp[clean]), 'a segment without planted values changed'
+        fin = ~bad & ~clean
+        assert ((spp[fin].double() - f32p[fin].double()).abs() <= 2e-6 * f32p[fin].double().abs() + 1e-5).all(), 'finite values of a recomputed segment'
+
+
 def test_split_bf16_conv_fwd_bwd_is_fp32_equivalent(dev):
     """3x3 conv forward, data gradient and weight gradient (tap-addressed, transposed-tap and pixel-major operand views) on both
     pipes against fp64."""
