@@ -104,6 +104,27 @@ def measure_named(B=16):
                     frac=round(fl / t / 1e12 / MFMA, 6), us=round(t * 1e6, 2), mfma_util_device=round(fl / t / 1e12 / MFMA, 6),
                     mfma_util_in_kernel=round(mfma_cycles / (t * 2.4e9), 4),
                     note='1.2 MFLOP per sample and layer on 128 waves: launch / latency-bound at any utilisation (SURVEY 7); in-kernel = MFMA issue cycles of a wave / kernel duration at 2.4 GHz'))
+    # the same cross-attention as the training step runs it since round 3: query projection + attention + per-head output projection of the
+    # decoder layer's sub-block in ONE launch (csrc/mha_small.hip: mha_cross_fwd_kernel), and the self-attention sub-block likewise
+    d = H * dh
+    Wi = torch.randn(3 * d, d, device=dev) * 0.05; bi = torch.randn(3 * d, device=dev); Wo = torch.randn(d, d, device=dev) * 0.05
+    x = torch.randn(B * Lq, d, device=dev)
+    qb = torch.empty(B * Lq, d, device=dev); ob = torch.empty(B * Lq, d, device=dev); lse = torch.empty(B * H * Lq, device=dev); yp = torch.empty(H, B * Lq, d, device=dev)
+    qkv = torch.empty(B * Lq, 3 * d, device=dev)
+    L = core.lib()
+    t = timed(lambda: core.check(L.ldetr_mha_cross_fwd_f32(core.ptr(x), d, core.ptr(Wi), core.ptr(bi), core.ptr(k), d, core.ptr(v), d, core.ptr(Wo), None, core.ptr(qb), core.ptr(ob),
+                                                           core.ptr(lse), core.ptr(yp), B, Lq, S, d, H, 1.0 / dh ** 0.5, 0.0, 0, None, core.stream())))
+    fl2 = 2.0 * B * Lq * d * d * 2 + fl
+    cyc = (128 // 4 + 2 * (S // 16) * (dh // 4) + 128 // 4) * 32          # per-SIMD MFMA issue cycles of a (sample, head) block: projection, attention (one wave), output projection
+    out.append(dict(kernel='DETR cross-attention sub-block fwd (mha_cross_fwd_kernel: q projection + attention + out projection)', shape=f'(b*h={B * H}, Lq={Lq}, Lk={S}, dh={dh})', bound='latency',
+                    achieved=round(fl2 / t / 1e12, 4), peak=MFMA, unit='TFLOP/s', frac=round(fl2 / t / 1e12 / MFMA, 6), us=round(t * 1e6, 2), mfma_util_device=round(fl2 / t / 1e12 / MFMA, 6),
+                    mfma_util_in_kernel=round(cyc / (t * 2.4e9), 4), note='replaces three launches (5.5 + 8.9 + 5.5 us stand-alone); rows 10..15 of every 16-row MFMA tile are padding'))
+    t = timed(lambda: core.check(L.ldetr_mha_small_fwd_f32(core.ptr(x), d, core.ptr(Wi), core.ptr(bi), core.ptr(Wo), None, core.ptr(qkv), core.ptr(ob), core.ptr(lse), core.ptr(yp),
+                                                           B, Lq, d, H, 1.0 / dh ** 0.5, 0.0, 0, None, core.stream())))
+    fl3 = 2.0 * B * Lq * d * (3 * d) + 4.0 * Lq * Lq * dh * B * H + 2.0 * B * Lq * d * d
+    out.append(dict(kernel='self-attention sub-block fwd (mha_small_fwd_kernel: packed projection + attention + out projection)', shape=f'(b*h={B * H}, L={Lq}, dh={dh})', bound='latency',
+                    achieved=round(fl3 / t / 1e12, 4), peak=MFMA, unit='TFLOP/s', frac=round(fl3 / t / 1e12 / MFMA, 6), us=round(t * 1e6, 2),
+                    mfma_util_in_kernel=round((96 + 16 + 32) * 32 / (t * 2.4e9), 4), note='replaces three launches (8 + 6 + 6 us)'))
     return out
 
 
@@ -111,5 +132,5 @@ if __name__ == '__main__':
     for r in measure():
         print(f"{r['kernel']:32s} {r['shape']:18s} {r['bytes'] / 1e6:8.1f} MB {r['us']:8.1f} us {r['tbps']:6.2f} TB/s ({r['tbps'] / 8.0:.2f} of 8 TB/s)")
     import json
-    for r in measure_named()[-4:]:
+    for r in measure_named()[-6:]:
         print(json.dumps(r))
