@@ -256,6 +256,10 @@ int ldetr_act_bwd_reduce_f32(const float* dy, const float* y, float* dv, const f
                              void* stream);
 int ldetr_mul_reduce_f32(const float* a, const float* x, const float* scale, float* out, float* red, int B, int64_t P,
                          int C, void* stream);
+/* ToRGBLayer forward (training/networks_stylegan2.py:349-353): y[b][p][o] = bias[o] + sum_c x[b][p][c] w[o][c] styles[b][c], 3 colour channels;
+ * x [B][P][C] NHWC pixels, C = 4 x a power of two <= 512. */
+int ldetr_torgb_fwd_f32(const float* x, const float* w, const float* styles, const float* bias, float* y,
+                        int B, int64_t P, int C, void* stream);
 int ldetr_torgb_bwd_f32(const float* x, const float* dy, const float* w, const float* styles, float* dx, float* dws,
                         float* dbias, int B, int64_t P, int C, void* stream);
 

@@ -68,6 +68,7 @@ SIGNATURES = {
     'ldetr_colsum_f32': [_P, _P, _I, _L, _I, _P],
     'ldetr_act_bwd_reduce_f32': [_P, _P, _P, _P, _P, _P, _P, _I, _L, _I, _I, _F, _F, _P],
     'ldetr_mul_reduce_f32': [_P, _P, _P, _P, _P, _I, _L, _I, _P],
+    'ldetr_torgb_fwd_f32': [_P, _P, _P, _P, _P, _I, _L, _I, _P],
     'ldetr_torgb_bwd_f32': [_P, _P, _P, _P, _P, _P, _P, _I, _L, _I, _P],
     'ldetr_maxpool3x3s2_fwd_f32': [_P, _P, _P, _I, _I, _I, _I, _P],
     'ldetr_maxpool3x3s2_bwd_f32': [_P, _P, _P, _I, _I, _I, _I, _P],
@@ -118,7 +119,7 @@ def load():
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported
         fn.restype = c_int
         fn.argtypes = argtypes
-    if lib.ldetr_abi_version() != 20:
+    if lib.ldetr_abi_version() != 21:
         raise RuntimeError('libldetr_hip.so ABI version mismatch; rebuild it')
     _lib = lib
     return lib

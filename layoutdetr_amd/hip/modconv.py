@@ -160,10 +160,15 @@ class _ToRGBFn(torch.autograd.Function):
         B, H, W, C = x.shape
         O = w.shape[0]
         y = torch.empty((B, H, W, O), device=x.device, dtype=torch.float32)
-        xt = core.tensor4_nhwc(x)
-        ep = core.epilogue(col_bias=b)
-        core.engine_call('ldetr_conv2d_fwd_f32', 2.0 * B * H * W * O * C, lambda: core.check(core.lib().ldetr_conv2d_fwd_f32(core.ptr(x), ctypes.byref(xt), core.ptr(w), O, 1, 1, 1, 0, core.ptr(y), O, H, W,
-                                                   core.ptr(s), s.stride(0), ctypes.byref(ep), core.stream()), 'torgb_fwd'), operands=(x, y, w))
+        c4 = C // 4
+        if O == 3 and C % 4 == 0 and C <= 512 and (c4 & (c4 - 1)) == 0 and s.stride(0) == C:
+            # streaming kernel (csrc/misc_ops.hip): one read of x; on the engine the 3 output channels pad a 64-wide tile (144 us at 16 x 256^2 x 32)
+            core.check(core.lib().ldetr_torgb_fwd_f32(core.ptr(x), core.ptr(w), core.ptr(s), core.ptr(b), core.ptr(y), B, H * W, C, core.stream()), 'torgb_fwd')
+        else:
+            xt = core.tensor4_nhwc(x)
+            ep = core.epilogue(col_bias=b)
+            core.engine_call('ldetr_conv2d_fwd_f32', 2.0 * B * H * W * O * C, lambda: core.check(core.lib().ldetr_conv2d_fwd_f32(core.ptr(x), ctypes.byref(xt), core.ptr(w), O, 1, 1, 1, 0, core.ptr(y), O, H, W,
+                                                       core.ptr(s), s.stride(0), ctypes.byref(ep), core.stream()), 'torgb_fwd'), operands=(x, y, w))
         ctx.save_for_backward(x, w, s)
         ctx.wshape = weight.shape
         return y
