@@ -347,6 +347,35 @@ int ldetr_lsap_f64(const double* cost, int batch, int n, int maximize, int* row_
 int ldetr_box_giou_pairwise_f32(const float* boxes1, const float* boxes2, int B, int N, int M, int cxcywh, float* iou, float* uni,
                                 float* giou, double* cost, double cost_sign, void* stream);
 
+/* ---- Plane-format ("P3") convolutions of the ResNet-50 trunk (csrc/p3_engine.hip; ATen conv2d + its autograd behind
+ * torchvision's resnet50 at training/detr_backbone.py:98-114).
+ * P3 storage of an fp32 tensor [rows][C], C % 8 == 0: the exact three-way bf16 split x = hi + mid + lo in 48-byte groups of
+ * 8 channels, [rows][C/8][3][8 x bf16] (6 bytes per element; `void*` below).  The convolutions contract such operands on the bf16
+ * matrix pipe with fp32 accumulation: fp32-equivalent results (the same six-product scheme as ldetr_set_split_bf16's tiles).
+ * Finite values only: an Inf / NaN element stays non-finite but not in the same class (Inf = Inf + NaN + NaN). */
+int ldetr_p3_split_f32(const float* src, int64_t ld, void* dst, int64_t rows, int C, void* stream);
+int ldetr_p3_merge_f32(const void* src, float* dst, int64_t ld, int64_t rows, int C, void* stream);
+/* w [O][KH][KW][I] fp32 -> P3 [I][KH*KW][O] (taps in the original order): the B operand of the data gradient. */
+int ldetr_p3_weight_bwd(const float* w_ohwi, void* dst, int O, int KH, int KW, int I, void* stream);
+
+/* v = acc * alpha * col_scale[n] + col_bias[n] + residual[m][n];  relu;  v = relu_mask[m][n] > 0 ? v : 0;  store as P3 and / or fp32. */
+typedef struct ldetr_p3_epilogue {
+    float alpha;
+    const float* col_scale;
+    const float* col_bias;
+    const void* residual_p3;
+    const float* residual_f32;
+    const void* relu_mask_p3;
+    int relu;
+} ldetr_p3_epilogue;
+
+/* y[n][oy][ox][co] = sum x[n][oy*stride - pad + kh][ox*stride - pad + kw][ci] * w[co][kh][kw][ci]; x P3 [N][H][W][Cin] (Cin % 32 == 0),
+ * w P3 [Cout][KH][KW][Cin] (Cout % 8 == 0), KH*KW <= 32, stride 1 or 2. */
+int ldetr_p3_conv2d_fwd(const void* x, int N, int H, int W, int Cin, const void* w, int Cout, int KH, int KW, int stride, int pad,
+                        const ldetr_p3_epilogue* ep, void* out_p3, float* out_f32, void* stream);
+/* Development probe (tools/p3_dev.py): ds_read_b64_tr_b16 lane map and LDS-DMA range semantics. */
+int ldetr_p3_probe(const void* g, int gbytes, void* out_tr, void* out_dma, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

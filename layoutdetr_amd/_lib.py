@@ -24,6 +24,11 @@ class GemmDesc(Structure):
                 ('ep', c_void_p), ('pix_per_sample', c_int)]
 
 
+class P3Epilogue(Structure):
+    _fields_ = [('alpha', c_float), ('col_scale', c_void_p), ('col_bias', c_void_p), ('residual_p3', c_void_p),
+                ('residual_f32', c_void_p), ('relu_mask_p3', c_void_p), ('relu', c_int)]
+
+
 class Epilogue(Structure):
     _fields_ = [('alpha', c_float), ('col_scale', c_void_p), ('col_bias', c_void_p), ('samp_scale', c_void_p),
                 ('samp_ld', c_int64), ('residual', c_void_p), ('ldr', c_int64), ('act', c_int),
@@ -92,6 +97,11 @@ SIGNATURES = {
     'ldetr_layout_losses_f32': [_P, _P, _P, _I, _I, _P, _P, _P],
     'ldetr_layout_losses_bwd_f32': [_P, _P, _I, _I, _P, _P],
     'ldetr_resample_coeffs': [_I, _I, _P, _P, _L, _P],
+    'ldetr_p3_split_f32': [_P, _L, _P, _L, _I, _P],
+    'ldetr_p3_merge_f32': [_P, _P, _L, _L, _I, _P],
+    'ldetr_p3_weight_bwd': [_P, _P, _I, _I, _I, _I, _P],
+    'ldetr_p3_conv2d_fwd': [_P, _I, _I, _I, _I, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P],
+    'ldetr_p3_probe': [_P, _I, _P, _P, _P],
     'ldetr_resize_normalize_u8': [_P, _L, _I, _I, _I, _I, _P, _P, _I, _P, _P, _I, _P, _P, _P, _F, _F, _F, _F, _F, _F, _P],
 }
 

@@ -20,7 +20,7 @@ LIBNAME = 'libldetr_hip.so'
 ARCH = 'gfx950'
 
 SOURCES = ['ldetr_core.cpp', 'bias_act.hip', 'upfirdn2d.hip', 'gemm_conv.hip', 'attention.hip', 'layernorm.hip',
-           'misc_ops.hip', 'optim.hip', 'lsap.hip', 'xent.hip', 'resample.hip', 'layout_loss.hip', 'demod.hip', 'wgrad_smallc.hip', 'stem_conv.hip', 'box_ops.hip', 'ffn_fused.hip', 'conv_c32.hip', 'mha_small.hip']
+           'misc_ops.hip', 'optim.hip', 'lsap.hip', 'xent.hip', 'resample.hip', 'layout_loss.hip', 'demod.hip', 'wgrad_smallc.hip', 'stem_conv.hip', 'box_ops.hip', 'ffn_fused.hip', 'conv_c32.hip', 'mha_small.hip', 'p3_engine.hip']
 HEADERS = ['ldetr_common.hpp', os.path.join('..', '..', 'include', 'ldetr_hip.h')]
 
 # the per-block tracer of the tiled kernel (tools/trace_tiles.py) is a development build: LDETR_TILE_TRACE=1 python -m layoutdetr_amd.build --force
@@ -29,7 +29,7 @@ FLAGS = ([] if os.environ.get('LDETR_TILE_TRACE') else ['-DLDETR_TILE_TRACE=0'])
          '-Wno-unused-result', '-Rpass-analysis=kernel-resource-usage']
 # kernels whose register budget is the design: any scratch (spill / stack object) is a build error, not a silent 10x slowdown
 # (an erf in the engine's epilogue once cost 320 bytes of scratch per lane and every 128x128 GEMM ran 14x slower)
-NO_SCRATCH = ('wgrad_c32_3x3_kernel', 'gemm_f32_kernel', 'gemm_small_kernel', 'attn_fwd_kernel', 'attn_fwd_wide_kernel', 'attn_bwd_kernel', 'ffn_fwd_kernel', 'ffn_bwd_kernel', 'conv3x3_c32_kernel', 'mha_small_fwd_kernel', 'mha_cross_fwd_kernel')
+NO_SCRATCH = ('wgrad_c32_3x3_kernel', 'gemm_f32_kernel', 'gemm_small_kernel', 'attn_fwd_kernel', 'attn_fwd_wide_kernel', 'attn_bwd_kernel', 'ffn_fwd_kernel', 'ffn_bwd_kernel', 'conv3x3_c32_kernel', 'mha_small_fwd_kernel', 'mha_cross_fwd_kernel', 'p3_nt_kernel')
 
 
 def _hipcc():

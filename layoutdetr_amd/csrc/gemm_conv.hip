@@ -1490,6 +1490,21 @@ constexpr long SMALL_GEMM_MNK = 1l << 30;
 
 // Transient scratch for other kernels of the library (partial sums of the row reductions): a slice of the same ring, valid for
 // the launches the caller enqueues next on its stream.  nullptr when no workspace is registered or the request does not fit.
+// Split-K scratch for the other contraction kernels of the library (p3_engine.hip): `tiles` arrival counters + `partial_bytes` of partial tiles
+// from the same rings; false if no workspace is registered or it is too small.
+bool splitk_ws_alloc(long tiles, size_t partial_bytes, float** ws, int** counters) {
+    Workspace& w = workspace_for_current_device();
+    const size_t need = (partial_bytes + 255) & ~(size_t)255;
+    const size_t pbytes = w.bytes > WS_COUNTERS * sizeof(int) ? w.bytes - WS_COUNTERS * sizeof(int) : 0;
+    if (!w.ptr || need > pbytes || tiles > WS_COUNTERS) return false;
+    if (w.counter_cursor + tiles > (size_t)WS_COUNTERS) w.counter_cursor = 0;
+    if (w.partial_cursor + need > pbytes) w.partial_cursor = 0;
+    *counters = reinterpret_cast<int*>(w.ptr) + w.counter_cursor;
+    *ws = reinterpret_cast<float*>(reinterpret_cast<char*>(w.ptr) + WS_COUNTERS * sizeof(int) + w.partial_cursor);
+    w.counter_cursor += tiles; w.partial_cursor += need;
+    return true;
+}
+
 float* scratch_alloc(size_t bytes) {
     Workspace& w = workspace_for_current_device();
     const size_t pbytes = w.bytes > WS_COUNTERS * sizeof(int) ? w.bytes - WS_COUNTERS * sizeof(int) : 0;

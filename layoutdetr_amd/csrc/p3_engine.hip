@@ -1,0 +1,541 @@
+// Plane-format contraction engine for gfx950: the ResNet-50 trunk's convolutions on the bf16 matrix pipe with fp32-equivalent
+// results and NO operand conversion inside the k-loop (training/detr_backbone.py:98-114 via torchvision's resnet50; ATen conv2d +
+// its autograd in the reference).
+//
+// Activation / weight format "P3": an fp32 tensor [rows][C] (C % 8 == 0, channels contiguous = NHWC pixels or OHWI weights) is
+// stored as its exact three-way bf16 split x = hi + mid + lo (8 + 8 + 8 significant bits; ldetr_common.hpp::split2_bf16), in 48-byte
+// groups of 8 channels: [rows][C/8][3 planes][8 x bf16].  6 bytes per element; a row's k-range is one contiguous segment holding
+// all three planes.  Producers (this engine's epilogues, the max-pool, ldetr_p3_split_f32) write it once; consumers move it
+// global -> LDS with buffer_load ... lds (16 bytes per lane, no VGPR round trip, no VALU) and feed v_mfma_f32_32x32x16_bf16 with
+// ds_read_b128 fragments.  Per k16 slab the six products of weight >= 2^-18 (hi.hi, hi.mid, mid.hi, hi.lo, lo.hi, mid.mid) go
+// into the same fp32 accumulators: at least as close to the exact contraction as v_mfma_f32_32x32x2_f32 (gemm_conv.hip, SPLIT).
+//
+// p3_nt_kernel: C[m][n] = sum_k A(m, k) B[n][k]; A = implicit-GEMM gather of P3 pixels (k = (tap, channel), stride 1 or 2, zero
+// padding = out-of-range buffer offsets), B = P3 weights, k-contiguous.  Forward convs, and data gradients through transposed /
+// tap-flipped weight copies (ldetr_p3_weight_bwd).  3-stage LDS ring of BK = 32 tiles, one barrier per k-tile, counted vmcnt
+// (two tiles in flight across the barrier), XOR-swizzled 64-byte LDS rows (conflict-free ds_read_b128), XCD-aware tile order,
+// in-kernel split-K (partial tiles parked with agent-scope stores, last arriver reduces in slice order).
+// Epilogue through LDS in row-major 8-channel groups: FrozenBN scale/shift, residual (P3 or f32), ReLU, ReLU-gradient mask from a
+// P3 tensor's hi plane, outputs as P3 and / or f32.
+#include <cstdlib>
+#include "ldetr_common.hpp"
+#include "../../include/ldetr_hip.h"
+
+namespace ldetr {
+
+bool splitk_ws_alloc(long tiles, size_t partial_bytes, float** ws, int** counters);   // gemm_conv.hip (ring of ldetr_set_workspace)
+
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) void lds_void;
+
+struct P3Epi {
+    float alpha;
+    const float* col_scale;
+    const float* col_bias;
+    const char* res_p3;      // residual [M][N] P3
+    const float* res_f32;    // residual [M][N] f32
+    const char* mask_p3;     // backward: multiply by (mask > 0), mask [M][N] P3 (hi plane decides)
+    int relu;
+    char* out_p3;
+    float* out_f32;
+};
+
+struct P3NtParams {
+    const char* A;           // P3 pixels, shifted back by pad_off bytes (all tap offsets non-negative)
+    const char* B;           // P3 weights [N][taps * Cin]
+    unsigned a_bytes, b_bytes;   // descriptor ranges
+    int M, N, Cin;
+    int KH, KW, stride, pad; // taps = KH * KW <= 32
+    int H, W, OH, OW;        // source grid, destination grid (rows of C enumerate (n, oy, ox))
+    int out_H, out_W, out_step, out_py, out_px;   // output row -> pixel of the stored tensor: (oy*out_step + out_py, ox*out_step + out_px) in an out_H x out_W grid
+    int tap_mode;            // 0: src = dst*stride - pad + tap (forward);  1: src = (dst + pad - tap) / stride over the taps of one parity class (data gradient, stride 2)
+    int kh0, kw0, tstep, nty, ntx;   // tap walk: kh = kh0 + tstep*ty (ty < nty), kw likewise; weights' tap index = ty*ntx + tx in B's k order
+    int nkt;                 // k-tiles in total (taps * Cin / 32)
+    int splitk;
+    float* ws; int* ws_count;
+    int mtiles, ntiles;
+    P3Epi ep;
+};
+
+__device__ __forceinline__ float bf_lo(unsigned w) { return __uint_as_float(w << 16); }
+__device__ __forceinline__ float bf_hi(unsigned w) { return __uint_as_float(w & 0xffff0000u); }
+
+// XCD-aware tile order: block b runs on XCD b % 8; give each XCD a contiguous range of tiles so that the blocks sharing an
+// A row panel / B column panel share an L2 (bijective also when the tile count is not a multiple of 8).
+__device__ __forceinline__ int xcd_remap(int b, int n) {
+    const int q = n >> 3, r = n & 7, x = b & 7, i = b >> 3;
+    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
+}
+
+// One k-tile's LDS-DMA of this wave: its 16-row groups of A (gathered pixels) and B (weight rows), three 1-KiB instructions each.
+// (A free function, not a lambda: hipcc drops the host stub of a kernel template whose lambda captures mutable locals next to these builtins.)
+template <int BM, int BN, int NW>
+__device__ __forceinline__ void p3_issue_tile(const P3NtParams& p, const __amdgpu_buffer_rsrc_t rsA, const __amdgpu_buffer_rsrc_t rsB, char* sb, int w,
+                                              const unsigned* offA, const unsigned* vmA, const unsigned* offB,
+                                              int& tap, int& cc, int ktpt) {
+    constexpr int RGA = BM / 16 / NW, RGB = BN / 16 / NW, A_BYTES = BM * 192;
+    // tap offset relative to the row's reference pixel (p.A is shifted back so that it is never negative): uniform
+    const int ty = tap / p.ntx, tx = tap - ty * p.ntx;
+    int dpix;
+    if (p.tap_mode == 0) dpix = (p.kh0 + ty) * p.W + (p.kw0 + tx);             // reference = tap (pad, pad); p.A shifted by (pad*W + pad) pixels
+    else dpix = (p.nty - 1 - ty) * p.W + (p.ntx - 1 - tx);                      // reference = source of tap (kh0, kw0); p.A shifted by ((nty-1)*W + ntx-1) pixels
+    const int sA = dpix * p.Cin * 6 + cc * 192;
+    const int sB = ((p.kh0 + p.tstep * ty) * p.KW + p.kw0 + p.tstep * tx) * p.Cin * 6 + cc * 192;
+#pragma unroll
+    for (int i = 0; i < RGA; i++) {
+        const unsigned vo = ((vmA[i] >> tap) & 1u) ? offA[i] : 0x80000000u;
+#pragma unroll
+        for (int j = 0; j < 3; j++)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_void*)(sb + ((w * RGA + i) * 3 + j) * 1024), 16, vo, sA + j * 64, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < RGB; i++) {
+#pragma unroll
+        for (int j = 0; j < 3; j++)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_void*)(sb + A_BYTES + ((w * RGB + i) * 3 + j) * 1024), 16, offB[i], sB + j * 64, 0, 0);
+    }
+    if (++cc == ktpt) { cc = 0; ++tap; }
+}
+
+// BM x BN block tile, NW waves as a WGM x WGN grid (WGN = 4 for eight waves on a 128-wide tile), NST ring stages of BK = 32.
+template <int BM, int BN, int NW, int NST>
+__global__ __launch_bounds__(NW * 64) void p3_nt_kernel(P3NtParams p) {
+    constexpr int NT = NW * 64;
+    constexpr int WGN = (NW == 8 && BN >= 128) ? 4 : 2, WGM = NW / WGN;
+    constexpr int WM = BM / WGM, WN = BN / WGN, TM = WM / 32, TN = WN / 32;   // wave tile, 32x32 accumulators per wave
+    constexpr int A_BYTES = BM * 192, B_BYTES = BN * 192, ST_BYTES = A_BYTES + B_BYTES;
+    constexpr int RGA = BM / 16 / NW, RGB = BN / 16 / NW;   // 16-row groups per wave and operand
+    constexpr int LPT = (RGA + RGB) * 3;                     // LDS-DMA instructions per wave and k-tile
+    static_assert(TM >= 1 && TN >= 1 && RGA >= 1 && RGB >= 1 && BM % (16 * NW) == 0 && BN % (16 * NW) == 0, "tile / wave-count mismatch");
+    extern __shared__ __attribute__((aligned(1024))) char p3_smem[];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, wm = w / WGN, wn = w % WGN;
+    const int cl = lane & 31, kl = lane >> 5;
+
+    const int ntl = p.mtiles * p.ntiles;
+    const int t = xcd_remap(blockIdx.x, ntl);
+    const int tm = t / p.ntiles, tn = t - tm * p.ntiles;   // consecutive tiles share the A panel
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int ks = blockIdx.y;
+    const int per = (p.nkt + p.splitk - 1) / p.splitk;
+    const int kt0 = ks * per, kt1 = min(p.nkt, kt0 + per);
+
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.A), 0, p.a_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.B), 0, p.b_bytes, 0x00020000);
+
+    // ---- per-lane source rows for the LDS-DMA (row-in-group = lane / 4, 16-byte piece = (lane % 4) ^ swizzle)
+    const int rr = lane >> 2, pq = (lane & 3) ^ ((rr >> 2) & 3);
+    const int ktpt = p.Cin >> 5;                          // k-tiles per tap
+    unsigned offA[RGA], vmA[RGA], offB[RGB];
+#pragma unroll
+    for (int i = 0; i < RGA; i++) {
+        const int m = m0 + (w * RGA + i) * 16 + rr;
+        unsigned vm = 0, off = 0;
+        if (m < p.M) {
+            const int hw = p.OH * p.OW;
+            const int n = m / hw, rem = m - n * hw, oy = rem / p.OW, ox = rem - oy * p.OW;
+            if (p.tap_mode == 0) {
+                const int iy = oy * p.stride, ix = ox * p.stride;   // tap (pad, pad): in range for every stride / pad used
+                off = (unsigned)(((n * p.H + iy) * p.W + ix) * p.Cin) * 6u;
+                if (p.nty * p.ntx == 1) vm = 1u;                    // 1x1, pad 0
+                else
+                    for (int ty = 0; ty < p.nty; ty++)
+                        for (int tx = 0; tx < p.ntx; tx++) {
+                            const int sy = iy - p.pad + p.kh0 + ty, sx = ix - p.pad + p.kw0 + tx;
+                            if (sy >= 0 && sy < p.H && sx >= 0 && sx < p.W) vm |= 1u << (ty * p.ntx + tx);
+                        }
+            } else {
+                // destination (input-gradient) pixel of this parity class; source (output-gradient) pixel = (dst + pad - kh) / stride
+                const int dy = oy * p.out_step + p.out_py + p.pad, dx = ox * p.out_step + p.out_px + p.pad;
+                const int by = (dy - p.kh0) / p.stride, bx = (dx - p.kw0) / p.stride;   // tap (kh0, kw0): the largest source index
+                off = (unsigned)(((n * p.H + by) * p.W + bx) * p.Cin) * 6u;
+                for (int ty = 0; ty < p.nty; ty++)
+                    for (int tx = 0; tx < p.ntx; tx++) {
+                        const int sy = by - ty, sx = bx - tx;
+                        if (sy >= 0 && sy < p.H && sx >= 0 && sx < p.W) vm |= 1u << (ty * p.ntx + tx);
+                    }
+            }
+        }
+        offA[i] = off + pq * 16; vmA[i] = vm;
+    }
+#pragma unroll
+    for (int i = 0; i < RGB; i++) {
+        const int n = n0 + (w * RGB + i) * 16 + rr;
+        offB[i] = n < p.N ? (unsigned)n * (unsigned)(p.KH * p.KW * p.Cin) * 6u + pq * 16 : 0x80000000u;
+    }
+
+    // uniform walk over (tap, channel tile)
+    int tap = kt0 / ktpt, cc = kt0 - tap * ktpt;          // next k-tile to issue
+#define P3_ISSUE(st_) p3_issue_tile<BM, BN, NW>(p, rsA, rsB, p3_smem + (st_) * ST_BYTES, w, offA, vmA, offB, tap, cc, ktpt)
+
+    // ---- fragment read offsets: piece e = 3*(2s + kl) + plane -> DMA instruction e / 4, slot (e % 4) ^ swizzle(row)
+    const int frr = cl & 15, frg = cl >> 4;               // row within its 16-row group, group within the 32-row block
+    unsigned fo[2][3];
+#pragma unroll
+    for (int s = 0; s < 2; s++)
+#pragma unroll
+        for (int pl = 0; pl < 3; pl++) {
+            const int e = 3 * (2 * s + kl) + pl;
+            fo[s][pl] = (unsigned)((frg * 3 + (e >> 2)) * 1024 + frr * 64 + (((e & 3) ^ ((frr >> 2) & 3)) << 4));
+        }
+    const unsigned foA = (unsigned)(wm * (WM / 16) * 3 * 1024), foB = (unsigned)(A_BYTES + wn * (WN / 16) * 3 * 1024);
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; i++)
+#pragma unroll
+        for (int j = 0; j < TN; j++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+
+    const int nloc = kt1 - kt0;
+#pragma unroll
+    for (int q = 0; q < NST - 1; q++)
+        if (nloc > q) P3_ISSUE(q);
+    for (int it = 0; it < nloc; it++) {
+        // tile `it` must have landed; the NST - 2 tiles issued after it may stay in flight
+        if (NST >= 3 && it + NST - 2 < nloc) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPT * (NST - 2)) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (it + NST - 1 < nloc) P3_ISSUE((it + NST - 1) % NST);
+        const char* sb = p3_smem + (it % NST) * ST_BYTES;
+#pragma unroll
+        for (int s = 0; s < 2; s++) {
+            bf16x8_t a[TM][3], b[TN][3];
+#pragma unroll
+            for (int i = 0; i < TM; i++)
+#pragma unroll
+                for (int pl = 0; pl < 3; pl++)
+                    a[i][pl] = *reinterpret_cast<const bf16x8_t*>(sb + foA + i * (2 * 3 * 1024) + fo[s][pl]);
+#pragma unroll
+            for (int j = 0; j < TN; j++)
+#pragma unroll
+                for (int pl = 0; pl < 3; pl++)
+                    b[j][pl] = *reinterpret_cast<const bf16x8_t*>(sb + foB + j * (2 * 3 * 1024) + fo[s][pl]);
+#pragma unroll
+            for (int i = 0; i < TM; i++)
+#pragma unroll
+                for (int j = 0; j < TN; j++) {   // smallest terms first
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[j][1], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][2], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][2], b[j][0], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][1], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[j][0], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][0], acc[i][j], 0, 0, 0);
+                }
+        }
+    }
+#undef P3_ISSUE
+
+    // ---- split-K: park the raw tile (register order: coalesced), the last arriver sums the slices in slice order
+    if (p.splitk > 1) {
+        float* slot0 = p.ws + (long)t * p.splitk * (BM * BN);
+        float* mine = slot0 + (long)ks * (BM * BN);
+#pragma unroll
+        for (int i = 0; i < TM; i++)
+#pragma unroll
+            for (int j = 0; j < TN; j++)
+#pragma unroll
+                for (int r = 0; r < 16; r++)
+                    __hip_atomic_store(mine + ((i * TN + j) * 16 + r) * NT + tid, acc[i][j][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        int* flag = reinterpret_cast<int*>(p3_smem);
+        if (tid == 0) {
+            const int old = atomicAdd(p.ws_count + t, 1);
+            const int last = old == p.splitk - 1;
+            if (last) __hip_atomic_store(p.ws_count + t, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            *flag = last;
+        }
+        __syncthreads();
+        const int last = *flag;
+        if (!last) return;
+#pragma unroll
+        for (int i = 0; i < TM; i++)
+#pragma unroll
+            for (int j = 0; j < TN; j++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+        for (int sl = 0; sl < p.splitk; sl++) {
+            const float* src = slot0 + (long)sl * (BM * BN);
+#pragma unroll
+            for (int i = 0; i < TM; i++)
+#pragma unroll
+                for (int j = 0; j < TN; j++)
+#pragma unroll
+                    for (int r = 0; r < 16; r++)
+                        acc[i][j][r] += __hip_atomic_load(src + ((i * TN + j) * 16 + r) * NT + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+
+    // ---- epilogue: wave tile (WM x WN) through LDS, then 8-channel groups per lane
+    __syncthreads();
+    constexpr int CP = WN + 4;
+    static_assert(NW * WM * CP * 4 <= NST * ST_BYTES, "epilogue staging does not fit");
+    float* Cs = reinterpret_cast<float*>(p3_smem) + w * (WM * CP);
+#pragma unroll
+    for (int i = 0; i < TM; i++)
+#pragma unroll
+        for (int j = 0; j < TN; j++)
+#pragma unroll
+            for (int r = 0; r < 16; r++)
+                Cs[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kl) * CP + j * 32 + cl] = acc[i][j][r];
+    // (each wave reads back its own region only: LDS operations of one wave execute in order, no barrier)
+    const P3Epi& ep = p.ep;
+    constexpr int CH = WN / 8;                            // 8-channel groups per row of the wave tile
+    constexpr int RPI = 64 / CH;                          // rows per iteration
+    const int ch = lane % CH, rl0 = lane / CH;
+    const int n = n0 + wn * WN + ch * 8;
+    float cs[8], cb[8];
+#pragma unroll
+    for (int e = 0; e < 8; e++) { cs[e] = p.ep.alpha; cb[e] = 0.f; }
+    if (n < p.N) {
+        if (ep.col_scale) {
+            const float4 s0 = *reinterpret_cast<const float4*>(ep.col_scale + n), s1 = *reinterpret_cast<const float4*>(ep.col_scale + n + 4);
+            cs[0] *= s0.x; cs[1] *= s0.y; cs[2] *= s0.z; cs[3] *= s0.w; cs[4] *= s1.x; cs[5] *= s1.y; cs[6] *= s1.z; cs[7] *= s1.w;
+        }
+        if (ep.col_bias) {
+            const float4 s0 = *reinterpret_cast<const float4*>(ep.col_bias + n), s1 = *reinterpret_cast<const float4*>(ep.col_bias + n + 4);
+            cb[0] = s0.x; cb[1] = s0.y; cb[2] = s0.z; cb[3] = s0.w; cb[4] = s1.x; cb[5] = s1.y; cb[6] = s1.z; cb[7] = s1.w;
+        }
+    }
+    const int ohw = p.OH * p.OW;
+#pragma unroll 2
+    for (int it = 0; it < WM / RPI; it++) {
+        const int rl = it * RPI + rl0;
+        const int m = m0 + wm * WM + rl;
+        if (m >= p.M || n >= p.N) continue;
+        long orow = m;
+        if (p.out_step != 1 || p.out_H != p.OH || p.out_W != p.OW) {
+            const int nn = m / ohw, rem = m - nn * ohw, oy = rem / p.OW, ox = rem - oy * p.OW;
+            orow = ((long)nn * p.out_H + (oy * p.out_step + p.out_py)) * p.out_W + (ox * p.out_step + p.out_px);
+        }
+        const float4 v0 = *reinterpret_cast<const float4*>(Cs + rl * CP + ch * 8), v1 = *reinterpret_cast<const float4*>(Cs + rl * CP + ch * 8 + 4);
+        float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+#pragma unroll
+        for (int e = 0; e < 8; e++) v[e] = v[e] * cs[e] + cb[e];
+        const long goff = (orow * p.N + n) * 6;           // byte offset of this 8-channel group in a P3 [rows][N] tensor
+        if (ep.res_p3) {
+            const u32x4 h = *reinterpret_cast<const u32x4*>(ep.res_p3 + goff), md = *reinterpret_cast<const u32x4*>(ep.res_p3 + goff + 16),
+                        lo = *reinterpret_cast<const u32x4*>(ep.res_p3 + goff + 32);
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                v[2 * e] += (bf_lo(h[e]) + bf_lo(md[e])) + bf_lo(lo[e]);
+                v[2 * e + 1] += (bf_hi(h[e]) + bf_hi(md[e])) + bf_hi(lo[e]);
+            }
+        }
+        if (ep.res_f32) {
+            const float4 r0 = *reinterpret_cast<const float4*>(ep.res_f32 + orow * p.N + n), r1 = *reinterpret_cast<const float4*>(ep.res_f32 + orow * p.N + n + 4);
+            v[0] += r0.x; v[1] += r0.y; v[2] += r0.z; v[3] += r0.w; v[4] += r1.x; v[5] += r1.y; v[6] += r1.z; v[7] += r1.w;
+        }
+        if (ep.relu) {
+#pragma unroll
+            for (int e = 0; e < 8; e++) v[e] = fmaxf(v[e], 0.f);
+        }
+        if (ep.mask_p3) {
+            const u32x4 h = *reinterpret_cast<const u32x4*>(ep.mask_p3 + goff);
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                if ((int)(h[e] << 16) <= 0) v[2 * e] = 0.f;
+                if ((int)(h[e] & 0xffff0000u) <= 0) v[2 * e + 1] = 0.f;
+            }
+        }
+        if (ep.out_f32) {
+            *reinterpret_cast<float4*>(ep.out_f32 + orow * p.N + n) = make_float4(v[0], v[1], v[2], v[3]);
+            *reinterpret_cast<float4*>(ep.out_f32 + orow * p.N + n + 4) = make_float4(v[4], v[5], v[6], v[7]);
+        }
+        if (ep.out_p3) {
+            u32x4 h, md, lo;
+#pragma unroll
+            for (int e = 0; e < 4; e++) { unsigned a, b, c; split2_bf16(v[2 * e], v[2 * e + 1], a, b, c); h[e] = a; md[e] = b; lo[e] = c; }
+            *reinterpret_cast<u32x4*>(ep.out_p3 + goff) = h;
+            *reinterpret_cast<u32x4*>(ep.out_p3 + goff + 16) = md;
+            *reinterpret_cast<u32x4*>(ep.out_p3 + goff + 32) = lo;
+        }
+    }
+}
+
+// ---- fp32 <-> P3 streaming conversions.  One thread = one 8-channel group.
+__global__ __launch_bounds__(256) void p3_split_kernel(const float* __restrict__ src, long ld, char* __restrict__ dst, long rows, int C) {
+    const int cg = C >> 3;
+    const long total = rows * cg;
+    for (long u = (long)blockIdx.x * 256 + threadIdx.x; u < total; u += (long)gridDim.x * 256) {
+        const long r = u / cg; const int g = (int)(u - r * cg);
+        const float4 v0 = *reinterpret_cast<const float4*>(src + r * ld + g * 8), v1 = *reinterpret_cast<const float4*>(src + r * ld + g * 8 + 4);
+        const float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+        u32x4 h, md, lo;
+#pragma unroll
+        for (int e = 0; e < 4; e++) { unsigned a, b, c; split2_bf16(v[2 * e], v[2 * e + 1], a, b, c); h[e] = a; md[e] = b; lo[e] = c; }
+        char* d = dst + u * 48;
+        *reinterpret_cast<u32x4*>(d) = h; *reinterpret_cast<u32x4*>(d + 16) = md; *reinterpret_cast<u32x4*>(d + 32) = lo;
+    }
+}
+
+__global__ __launch_bounds__(256) void p3_merge_kernel(const char* __restrict__ src, float* __restrict__ dst, long ld, long rows, int C) {
+    const int cg = C >> 3;
+    const long total = rows * cg;
+    for (long u = (long)blockIdx.x * 256 + threadIdx.x; u < total; u += (long)gridDim.x * 256) {
+        const long r = u / cg; const int g = (int)(u - r * cg);
+        const char* s = src + u * 48;
+        const u32x4 h = *reinterpret_cast<const u32x4*>(s), md = *reinterpret_cast<const u32x4*>(s + 16), lo = *reinterpret_cast<const u32x4*>(s + 32);
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            v[2 * e] = (bf_lo(h[e]) + bf_lo(md[e])) + bf_lo(lo[e]);
+            v[2 * e + 1] = (bf_hi(h[e]) + bf_hi(md[e])) + bf_hi(lo[e]);
+        }
+        *reinterpret_cast<float4*>(dst + r * ld + g * 8) = make_float4(v[0], v[1], v[2], v[3]);
+        *reinterpret_cast<float4*>(dst + r * ld + g * 8 + 4) = make_float4(v[4], v[5], v[6], v[7]);
+    }
+}
+
+// Weights for the data gradient: w [O][KH][KW][I] fp32 -> P3 [I][KH*KW][O] (k = (tap, out channel) contiguous, taps in the
+// original order; the kernel's tap walk does the flipping).  One thread = 8 out channels of one (i, tap).
+__global__ __launch_bounds__(256) void p3_weight_bwd_kernel(const float* __restrict__ w, char* __restrict__ dst, int O, int T, int I) {
+    const int og = O >> 3;
+    const long total = (long)I * T * og;
+    for (long u = (long)blockIdx.x * 256 + threadIdx.x; u < total; u += (long)gridDim.x * 256) {
+        const int g = (int)(u % og); const long it = u / og; const int tp = (int)(it % T); const int i = (int)(it / T);
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; e++) v[e] = w[((long)(g * 8 + e) * T + tp) * I + i];
+        u32x4 h, md, lo;
+#pragma unroll
+        for (int e = 0; e < 4; e++) { unsigned a, b, c; split2_bf16(v[2 * e], v[2 * e + 1], a, b, c); h[e] = a; md[e] = b; lo[e] = c; }
+        char* d = dst + u * 48;
+        *reinterpret_cast<u32x4*>(d) = h; *reinterpret_cast<u32x4*>(d + 16) = md; *reinterpret_cast<u32x4*>(d + 32) = lo;
+    }
+}
+
+// ---- probes (development): semantics of ds_read_b64_tr_b16 and of out-of-range / immediate-offset LDS-DMA
+__global__ void p3_probe_kernel(const unsigned short* g, int gbytes, unsigned short* out_tr, unsigned short* out_dma) {
+    __shared__ __attribute__((aligned(1024))) unsigned short sm[4096];
+    const int l = threadIdx.x;
+    for (int i = l; i < 4096; i += 64) sm[i] = (unsigned short)i;
+    __syncthreads();
+    typedef short s16x4 __attribute__((ext_vector_type(4)));
+    const s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(sm + l * 4));
+    for (int e = 0; e < 4; e++) out_tr[l * 4 + e] = (unsigned short)v[e];
+    // second pattern: lanes i/4 -> row stride 64 B (k rows), i%4 -> 8-byte column quads
+    const s16x4 v2 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(sm + (l >> 2) * 32 + (l & 3) * 4));
+    for (int e = 0; e < 4; e++) out_tr[256 + l * 4 + e] = (unsigned short)v2[e];
+    __syncthreads();
+    for (int i = l; i < 4096; i += 64) sm[i] = 0xffff;
+    __syncthreads();
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(g), 0, gbytes, 0x00020000);
+    // (a) lanes >= 32 out of range; (b) immediate offset 64; (c) scalar offset 128
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void*)(sm), 16, l < 32 ? l * 16 : 0x80000000u, 0, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void*)(sm + 512), 16, l * 16, 0, 64, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void*)(sm + 1536), 16, l * 16, 128, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void*)(sm + 2560), 16, l * 16, gbytes - 512, 0, 0);   // (d) is the scalar offset part of the range check?
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int i = l; i < 3072; i += 64) out_dma[i] = sm[i];
+}
+
+template <int BM, int BN, int NW, int NST>
+static int launch_nt_cfg(P3NtParams& p, int sk, hipStream_t st) {
+    p.mtiles = cdiv(p.M, BM); p.ntiles = cdiv(p.N, BN);
+    const long nt = (long)p.mtiles * p.ntiles;
+    if (sk > p.nkt) sk = p.nkt;
+    if (sk < 1) sk = 1;
+    p.splitk = sk; p.ws = nullptr; p.ws_count = nullptr;
+    if (sk > 1 && !splitk_ws_alloc(nt, (size_t)nt * sk * BM * BN * sizeof(float), &p.ws, &p.ws_count)) p.splitk = sk = 1;
+    constexpr size_t lds = (size_t)NST * (BM + BN) * 192;
+    auto kern = p3_nt_kernel<BM, BN, NW, NST>;
+    static bool raised = false;
+    if (lds > 64 * 1024 && !raised) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+            set_error("p3_nt: cannot raise the dynamic LDS limit to %zu bytes", lds);
+            return LDETR_ERR_LAUNCH;
+        }
+        raised = true;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)nt, sk, 1), NW * 64, lds, st, p);
+    return check_launch("p3_nt");
+}
+
+static int launch_nt(P3NtParams& p, hipStream_t st) {
+    // tile configurations: 1 = 128x128, 8 waves, 3 stages (one block per CU); 2 = 128x64, 4 waves, 2 stages (two blocks per CU);
+    // 3 = 64x64, 4 waves, 3 stages (two blocks per CU); 4 = 128x128, 4 waves, 3 stages; 5 = 128x64, 4 waves, 3 stages
+    static const int force_tile = getenv("LDETR_P3_TILE") ? atoi(getenv("LDETR_P3_TILE")) : 0;
+    static const int force_sk = getenv("LDETR_P3_SK") ? atoi(getenv("LDETR_P3_SK")) : 0;
+    auto tiles = [&](int a, int b) { return (long)cdiv(p.M, a) * cdiv(p.N, b); };
+    int cfg = 1;
+    if (p.N <= 64 || tiles(128, 128) < 256) cfg = 2;
+    if (cfg == 2 && tiles(128, 64) < 192 && p.M <= 4096) cfg = 3;
+    if (force_tile) cfg = force_tile;
+    const int bm = cfg == 3 ? 64 : 128, bn = (cfg == 1 || cfg == 4) ? 128 : 64;
+    const long nt = tiles(bm, bn);
+    const long slots = (cfg == 2 || cfg == 3) ? 512 : 256;
+    int sk = 1;
+    if (nt < slots * 3 / 4) { sk = (int)(slots / nt); if (sk > p.nkt / 4) sk = p.nkt / 4; if (sk > 16) sk = 16; }
+    if (force_sk > 0) sk = force_sk;
+    switch (cfg) {
+        case 1: return launch_nt_cfg<128, 128, 8, 3>(p, sk, st);
+        case 2: return launch_nt_cfg<128, 64, 4, 2>(p, sk, st);
+        case 3: return launch_nt_cfg<64, 64, 4, 3>(p, sk, st);
+        case 4: return launch_nt_cfg<128, 128, 4, 3>(p, sk, st);
+        default: return launch_nt_cfg<128, 64, 4, 3>(p, sk, st);
+    }
+}
+
+static void fill_epi(P3Epi& e, const ldetr_p3_epilogue* s) {
+    memset(&e, 0, sizeof(e));
+    e.alpha = 1.f;
+    if (!s) return;
+    e.alpha = s->alpha; e.col_scale = s->col_scale; e.col_bias = s->col_bias;
+    e.res_p3 = (const char*)s->residual_p3; e.res_f32 = s->residual_f32; e.mask_p3 = (const char*)s->relu_mask_p3; e.relu = s->relu;
+}
+
+}  // namespace ldetr
+
+using namespace ldetr;
+
+extern "C" int ldetr_p3_split_f32(const float* src, int64_t ld, void* dst, int64_t rows, int C, void* stream) {
+    LDETR_CHECK(src && dst && rows >= 0 && C > 0 && C % 8 == 0 && ld % 4 == 0, "p3_split: C must be a multiple of 8 and rows 16-byte aligned (C=%d)", C);
+    if (rows == 0) return LDETR_OK;
+    const long units = rows * (C / 8);
+    const int blocks = (int)std::min<long>((units + 255) / 256, 256 * 16);
+    hipLaunchKernelGGL(p3_split_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, src, (long)ld, (char*)dst, (long)rows, C);
+    return check_launch("p3_split");
+}
+
+extern "C" int ldetr_p3_merge_f32(const void* src, float* dst, int64_t ld, int64_t rows, int C, void* stream) {
+    LDETR_CHECK(src && dst && rows >= 0 && C > 0 && C % 8 == 0 && ld % 4 == 0, "p3_merge: C must be a multiple of 8 (C=%d)", C);
+    if (rows == 0) return LDETR_OK;
+    const long units = rows * (C / 8);
+    const int blocks = (int)std::min<long>((units + 255) / 256, 256 * 16);
+    hipLaunchKernelGGL(p3_merge_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const char*)src, dst, (long)ld, (long)rows, C);
+    return check_launch("p3_merge");
+}
+
+extern "C" int ldetr_p3_weight_bwd(const float* w_ohwi, void* dst, int O, int KH, int KW, int I, void* stream) {
+    LDETR_CHECK(w_ohwi && dst && O % 8 == 0 && I > 0 && KH > 0 && KW > 0, "p3_weight_bwd: O must be a multiple of 8 (O=%d)", O);
+    const long units = (long)I * KH * KW * (O / 8);
+    const int blocks = (int)std::min<long>((units + 255) / 256, 256 * 16);
+    hipLaunchKernelGGL(p3_weight_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w_ohwi, (char*)dst, O, KH * KW, I);
+    return check_launch("p3_weight_bwd");
+}
+
+extern "C" int ldetr_p3_conv2d_fwd(const void* x, int N, int H, int W, int Cin, const void* w, int Cout, int KH, int KW, int stride, int pad,
+                                   const ldetr_p3_epilogue* ep, void* out_p3, float* out_f32, void* stream) {
+    const int OH = (H + 2 * pad - KH) / stride + 1, OW = (W + 2 * pad - KW) / stride + 1;
+    LDETR_CHECK(x && w && (out_p3 || out_f32), "p3_conv2d_fwd: null operand");
+    LDETR_CHECK(Cin % 32 == 0 && Cout % 8 == 0 && KH * KW <= 32 && pad < KH && pad < KW && (stride == 1 || stride == 2),
+                "p3_conv2d_fwd: unsupported geometry (Cin=%d Cout=%d k=%dx%d stride=%d pad=%d)", Cin, Cout, KH, KW, stride, pad);
+    const long xbytes = (long)N * H * W * Cin * 6, wbytes = (long)Cout * KH * KW * Cin * 6, pad_off = ((long)pad * W + pad) * Cin * 6;
+    LDETR_CHECK(xbytes + pad_off < 0x7fffffffL && wbytes < 0x7fffffffL && (long)N * OH * OW * Cout * 6 < (1L << 40), "p3_conv2d_fwd: tensor too large for 31-bit buffer offsets");
+    P3NtParams p; memset(&p, 0, sizeof(p));
+    p.A = (const char*)x - pad_off; p.a_bytes = (unsigned)(xbytes + pad_off); p.B = (const char*)w; p.b_bytes = (unsigned)wbytes;
+    p.M = N * OH * OW; p.N = Cout; p.Cin = Cin; p.KH = KH; p.KW = KW; p.stride = stride; p.pad = pad; p.H = H; p.W = W; p.OH = OH; p.OW = OW;
+    p.out_H = OH; p.out_W = OW; p.out_step = 1; p.tap_mode = 0; p.kh0 = 0; p.kw0 = 0; p.tstep = 1; p.nty = KH; p.ntx = KW;
+    p.nkt = KH * KW * Cin / 32;
+    fill_epi(p.ep, ep); p.ep.out_p3 = (char*)out_p3; p.ep.out_f32 = out_f32;
+    if (p.M == 0) return LDETR_OK;
+    return launch_nt(p, (hipStream_t)stream);
+}
+
+extern "C" int ldetr_p3_probe(const void* g, int gbytes, void* out_tr, void* out_dma, void* stream) {
+    hipLaunchKernelGGL(p3_probe_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (const unsigned short*)g, gbytes, (unsigned short*)out_tr, (unsigned short*)out_dma);
+    return check_launch("p3_probe");
+}

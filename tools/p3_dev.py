@@ -1,0 +1,125 @@
+"""Development driver of the plane-format engine (csrc/p3_engine.hip): probes, parity against fp64 torch, timings.
+Usage: python tools/p3_dev.py [probe] [check] [bench]"""
+import ctypes, sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import torch.nn.functional as F
+from layoutdetr_amd.hip import core
+from layoutdetr_amd import _lib
+dev = torch.device('cuda:0')
+L = core.lib()
+
+
+def p3_split(x2d):
+    rows, C = x2d.shape
+    out = torch.empty(rows * C * 6, dtype=torch.uint8, device=dev)
+    core.check(L.ldetr_p3_split_f32(core.ptr(x2d), x2d.stride(0), core.ptr(out), rows, C, core.stream()), 'split')
+    return out
+
+
+def p3_merge(p, rows, C):
+    out = torch.empty(rows, C, dtype=torch.float32, device=dev)
+    core.check(L.ldetr_p3_merge_f32(core.ptr(p), core.ptr(out), C, rows, C, core.stream()), 'merge')
+    return out
+
+
+def timeit(fn, n=20):
+    fn(); torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for _ in range(n): fn()
+    g.replay(); torch.cuda.synchronize()
+    s = torch.cuda.Event(enable_timing=True); e = torch.cuda.Event(enable_timing=True)
+    s.record(); g.replay(); g.replay(); e.record(); torch.cuda.synchronize()
+    return s.elapsed_time(e) / (2 * n) * 1e-3
+
+
+def probe():
+    g = torch.arange(8192, dtype=torch.int16, device=dev)
+    tr = torch.zeros(512, dtype=torch.int16, device=dev); dma = torch.zeros(3072, dtype=torch.int16, device=dev)
+    core.check(L.ldetr_p3_probe(core.ptr(g), 2048, core.ptr(tr), core.ptr(dma), core.stream()), 'probe')
+    torch.cuda.synchronize()
+    tr = tr.cpu().numpy().astype('int64') & 0xffff; dma = dma.cpu().numpy().astype('int64') & 0xffff
+    print('tr-read, lane l reads 4 x b16 at element 4*l: lane -> elements')
+    for l in range(64):
+        print(f'  lane {l:2d}: {list(tr[l*4:l*4+4])}', '| pattern2:', list(tr[256 + l*4:256 + l*4+4]))
+    print('dma (a) lanes>=32 out of range: first elems of lane 0, 31, 32, 63:', dma[0:2], dma[31*8:31*8+2], dma[32*8:32*8+2], dma[63*8:63*8+2])
+    print('dma (b) imm offset 64 B: lds elem 512.. :', dma[512:516], ' (global elem 32 expected if imm applies to global only; if also LDS, data lands 32 elems later:', dma[512+32:512+36], ')')
+    print('dma (c) soffset 128 B:', dma[1536:1540], '(expect 64..)')
+    print('dma (d) soffset = bytes-512, lanes >= 32 beyond the range if soffset is checked: lane 31', dma[2560+31*8:2560+31*8+2], 'lane 32', dma[2560+32*8:2560+32*8+2])
+
+
+def conv_ref(x, w, stride, pad):
+    return F.conv2d(x.permute(0, 3, 1, 2).double(), w.permute(0, 3, 1, 2).double(), stride=stride, padding=pad).permute(0, 2, 3, 1)
+
+
+def run_fwd(xp, N, H, Ci, wp, Co, k, s, pad, ep, yp, yf):
+    return L.ldetr_p3_conv2d_fwd(core.ptr(xp), N, H, H, Ci, core.ptr(wp), Co, k, k, s, pad, ctypes.byref(ep) if ep is not None else None,
+                                 core.ptr(yp), core.ptr(yf), core.stream())
+
+
+def check_case(N, H, Ci, Co, k, s, pad, full_ep=True):
+    torch.manual_seed(1)
+    x = torch.randn(N, H, H, Ci, device=dev) * torch.exp(torch.randn(N, H, H, Ci, device=dev))
+    w = torch.randn(Co, k, k, Ci, device=dev) / (k * Ci ** 0.5)
+    OH = (H + 2 * pad - k) // s + 1
+    xp = p3_split(x.reshape(-1, Ci)); wp = p3_split(w.reshape(Co, -1))
+    assert torch.equal(p3_merge(xp, N * H * H, Ci), x.reshape(-1, Ci)), 'split/merge is not exact'
+    yf = torch.empty(N, OH, OH, Co, device=dev); yp = torch.empty(N * OH * OH * Co * 6, dtype=torch.uint8, device=dev)
+    ep = None
+    ref = conv_ref(x, w, s, pad)
+    if full_ep:
+        sc = torch.rand(Co, device=dev) + 0.5; sh = torch.randn(Co, device=dev); res = torch.randn(N, OH, OH, Co, device=dev)
+        resp = p3_split(res.reshape(-1, Co))
+        ep = _lib.P3Epilogue(); ep.alpha = 1.0; ep.col_scale = sc.data_ptr(); ep.col_bias = sh.data_ptr(); ep.residual_p3 = resp.data_ptr(); ep.relu = 1
+        ref = torch.relu(ref * sc.double() + sh.double() + res.double())
+    core.check(run_fwd(xp, N, H, Ci, wp, Co, k, s, pad, ep, yp, yf), 'fwd')
+    torch.cuda.synchronize()
+    err = (yf.double() - ref).abs().max().item() / ref.abs().max().item()
+    rms = ((yf.double() - ref).pow(2).mean().sqrt() / ref.pow(2).mean().sqrt()).item()
+    same = torch.equal(p3_merge(yp, N * OH * OH, Co), yf.reshape(-1, Co))
+    print(f'check N={N} H={H} {Ci}->{Co} k{k} s{s} ep={full_ep}: max err/max {err:.2e} rms {rms:.2e} p3==f32 {same}', flush=True)
+    assert err < 2e-6 and same
+
+
+def bench_case(name, N, H, Ci, Co, k, s, pad):
+    x = torch.randn(N, H, H, Ci, device=dev); w = torch.randn(Co, k, k, Ci, device=dev) / (k * Ci ** 0.5)
+    OH = (H + 2 * pad - k) // s + 1
+    xp = p3_split(x.reshape(-1, Ci)); wp = p3_split(w.reshape(Co, -1))
+    yp = torch.empty(N * OH * OH * Co * 6, dtype=torch.uint8, device=dev)
+    sc = torch.rand(Co, device=dev) + 0.5; sh = torch.randn(Co, device=dev); res = torch.randn(N, OH, OH, Co, device=dev)
+    resp = p3_split(res.reshape(-1, Co))
+    ep = _lib.P3Epilogue(); ep.alpha = 1.0; ep.col_scale = sc.data_ptr(); ep.col_bias = sh.data_ptr(); ep.residual_p3 = resp.data_ptr(); ep.relu = 1
+    fl = 2.0 * N * OH * OH * Co * k * k * Ci
+    t = timeit(lambda: run_fwd(xp, N, H, Ci, wp, Co, k, s, pad, ep, yp, None))
+    # the f32 engine on the same problem
+    y = torch.empty(N, OH, OH, Co, device=dev); xt = core.tensor4_nhwc(x)
+    ep0 = core.epilogue(col_scale=sc, col_bias=sh, residual=res.reshape(-1, Co), act=core.ACT_RELU)
+    t0 = timeit(lambda: L.ldetr_conv2d_fwd_f32(core.ptr(x), ctypes.byref(xt), core.ptr(w), Co, k, k, s, pad, core.ptr(y), Co, OH, OH, None, 0, ctypes.byref(ep0), core.stream()))
+    print(f'{name:24s} M={N*OH*OH:6d} N={Co:4d} K={k*k*Ci:5d}  p3 {t*1e6:7.1f}us {fl/t/1e12:6.1f}TF | f32 engine {t0*1e6:7.1f}us {fl/t0/1e12:6.1f}TF', flush=True)
+
+
+CASES = [('l1 1x1 64->64', 64, 64, 64, 1, 1, 0), ('l1 3x3 64->64', 64, 64, 64, 3, 1, 1), ('l1 1x1 64->256', 64, 64, 256, 1, 1, 0), ('l1 1x1 256->64', 64, 256, 64, 1, 1, 0),
+         ('l2 1x1 256->128', 64, 256, 128, 1, 1, 0), ('l2 3x3 128->128 s2', 64, 128, 128, 3, 2, 1), ('l2 1x1 128->512', 32, 128, 512, 1, 1, 0), ('l2 1x1 256->512 s2', 64, 256, 512, 1, 2, 0),
+         ('l2 1x1 512->128', 32, 512, 128, 1, 1, 0), ('l2 3x3 128->128', 32, 128, 128, 3, 1, 1),
+         ('l3 3x3 256->256 s2', 32, 256, 256, 3, 2, 1), ('l3 1x1 256->1024', 16, 256, 1024, 1, 1, 0), ('l3 1x1 1024->256', 16, 1024, 256, 1, 1, 0), ('l3 3x3 256->256', 16, 256, 256, 3, 1, 1),
+         ('l4 3x3 512->512 s2', 16, 512, 512, 3, 2, 1), ('l4 1x1 512->2048', 8, 512, 2048, 1, 1, 0), ('l4 1x1 2048->512', 8, 2048, 512, 1, 1, 0), ('l4 3x3 512->512', 8, 512, 512, 3, 1, 1),
+         ('sg 3x3 512->512 @16', 16, 512, 512, 3, 1, 1), ('sg 3x3 128->128 @64', 64, 128, 128, 3, 1, 1)]
+
+if __name__ == '__main__':
+    what = sys.argv[1:] or ['probe', 'check', 'bench']
+    if 'probe' in what:
+        probe()
+    if 'check' in what:
+        check_case(1, 8, 32, 64, 1, 1, 0, False)
+        check_case(2, 8, 64, 64, 3, 1, 1, False)
+        check_case(2, 9, 64, 72, 3, 1, 1, True)
+        check_case(2, 16, 64, 128, 3, 2, 1, True)
+        check_case(3, 16, 128, 256, 1, 2, 0, True)
+        check_case(4, 32, 128, 128, 3, 1, 1, True)
+        check_case(16, 8, 512, 512, 3, 1, 1, True)     # split-K
+        check_case(16, 16, 1024, 256, 1, 1, 0, True)   # split-K
+    if 'bench' in what:
+        B = int(os.environ.get('B', '16'))
+        for c in CASES:
+            bench_case(c[0], B, *c[1:])
