@@ -355,8 +355,14 @@ int ldetr_box_giou_pairwise_f32(const float* boxes1, const float* boxes2, int B,
  * Finite values only: an Inf / NaN element stays non-finite but not in the same class (Inf = Inf + NaN + NaN). */
 int ldetr_p3_split_f32(const float* src, int64_t ld, void* dst, int64_t rows, int C, void* stream);
 int ldetr_p3_merge_f32(const void* src, float* dst, int64_t ld, int64_t rows, int C, void* stream);
-/* w [O][KH][KW][I] fp32 -> P3 [I][KH*KW][O] (taps in the original order): the B operand of the data gradient. */
-int ldetr_p3_weight_bwd(const float* w_ohwi, void* dst, int O, int KH, int KW, int I, void* stream);
+/* w [O][KH][KW][I] fp32 (times o_scale[o] when not NULL: FrozenBN's factor of the output gradient) -> P3 [I][KH*KW][O], taps in the
+ * original order: the B operand of ldetr_p3_conv2d_bwd_data. */
+int ldetr_p3_weight_bwd(const float* w_ohwi, const float* o_scale, void* dst, int O, int KH, int KW, int I, void* stream);
+
+/* Every conv weight of a module in one launch: table_dev (device memory) holds nconv rows of 8 int64 = {w fp32 [O][T][I] pointer,
+ * o_scale pointer or 0, dst_fwd pointer or 0 (P3 of w as stored), dst_bwd pointer or 0 (what ldetr_p3_weight_bwd writes), O, T, I,
+ * index of the row's first block}; a row owns ceil(O*T*I/8 / 256) consecutive blocks, total_blocks = their sum.  O % 8 == 0, I % 8 == 0. */
+int ldetr_p3_weight_prep(const int64_t* table_dev, int nconv, int total_blocks, void* stream);
 
 /* v = acc * alpha * col_scale[n] + col_bias[n] + residual[m][n];  relu;  v = relu_mask[m][n] > 0 ? v : 0;  store as P3 and / or fp32. */
 typedef struct ldetr_p3_epilogue {
@@ -373,6 +379,15 @@ typedef struct ldetr_p3_epilogue {
  * w P3 [Cout][KH][KW][Cin] (Cout % 8 == 0), KH*KW <= 32, stride 1 or 2. */
 int ldetr_p3_conv2d_fwd(const void* x, int N, int H, int W, int Cin, const void* w, int Cout, int KH, int KW, int stride, int pad,
                         const ldetr_p3_epilogue* ep, void* out_p3, float* out_f32, void* stream);
+/* dx[n][iy][ix][ci] = sum_{kh,kw,co} dy[n][(iy + pad - kh) / stride][(ix + pad - kw) / stride][co] * wb[ci][kh][kw][co] over the taps whose
+ * quotients are exact and in range; dy P3 [N][OH][OW][Cout] (Cout % 32 == 0), wb from ldetr_p3_weight_bwd, dx [N][IH][IW][Cin].  The epilogue's
+ * [m][n] operands (residual, mask) are indexed like dx. */
+int ldetr_p3_conv2d_bwd_data(const void* dy, int N, int OH, int OW, int Cout, const void* wb, int Cin, int KH, int KW, int stride, int pad,
+                             int IH, int IW, const ldetr_p3_epilogue* ep, void* out_p3, float* out_f32, void* stream);
+/* dw[co][kh][kw][ci] += dy_scale[co] * sum_pixels dy[n][oy][ox][co] * x[n][oy*stride - pad + kh][ox*stride - pad + kw][ci]  (fp32 atomics
+ * onto the existing buffer, e.g. a view of the flat .grad buffer); x P3 [N][H][W][Cin], dy P3 [N][OH][OW][Cout], both channel counts % 32 == 0. */
+int ldetr_p3_conv2d_bwd_weight(const void* x, int N, int H, int W, int Cin, const void* dy, int Cout, int KH, int KW, int stride, int pad,
+                               const float* dy_scale, float* dw, void* stream);
 /* Development probe (tools/p3_dev.py): ds_read_b64_tr_b16 lane map and LDS-DMA range semantics. */
 int ldetr_p3_probe(const void* g, int gbytes, void* out_tr, void* out_dma, void* stream);
 

@@ -354,6 +354,182 @@ __global__ __launch_bounds__(NW * 64) void p3_nt_kernel(P3NtParams p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// p3_tn_kernel: weight gradients.  dW[co][tap][ci] += row_scale[co] * sum_pix dY[pix][co] * X[src(pix, tap)][ci]: per tap a GEMM whose
+// reduction index is the output pixel, so BOTH operands are stored reduction-major (a pixel's channels are contiguous).  The LDS image
+// of a [32 pixels x 32 channels] P3 block is the same one the NT kernel builds (16-pixel groups x three 1-KiB DMA instructions, XOR
+// swizzle); the MFMA fragments (8 consecutive pixels of one channel per lane) come out of it with ds_read_b64_tr_b16, the gfx950
+// transposing LDS read: a 16-lane group reads a [4 pixels][16 channels] block, lane i supplying the address of (pixel i/4, channel
+// quad i%4) and receiving the 4 pixels of channel i.  Conflict-free for this image (32 distinct 8-byte units per 32-lane pass).
+// Grid: (co tiles x ci tiles x taps, pixel slices); fp32 atomics into dW (the flat .grad buffer), like gemm_conv.hip's weight gradients.
+struct P3TnParams {
+    const char* dY; const char* X;   // X shifted back by pad_off bytes
+    unsigned dy_bytes, x_bytes;
+    int Cout, Cin, KH, KW, stride, pad;
+    int H, W, OH, OW;                // X grid, dY grid
+    int npix;                        // N * OH * OW
+    float inv_ohw, inv_ow;
+    int mtiles, ntiles, splitk;
+    const float* row_scale;          // [Cout] or null
+    float alpha;
+    float* dW;                       // [Cout][KH*KW][Cin]
+    int debug;                       // development: 1 = skip the k-loop (epilogue cost alone), 2 = skip the epilogue
+};
+
+__device__ __forceinline__ void fastdivmod(int x, int d, float invd, int& q, int& r) {   // exact for 0 <= x < 2^24
+    q = (int)(__int2float_rz(x) * invd);
+    r = x - q * d;
+    if (r >= d) { ++q; r -= d; }
+    if (r < 0) { --q; r += d; }
+}
+
+typedef short s16x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ bf16x8_t tr_frag(const char* base, unsigned o0, unsigned o1) {
+    const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(base + o0));
+    const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(base + o1));
+    typedef short s16x8_t __attribute__((ext_vector_type(8)));
+    const s16x8_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8_t, v);
+}
+
+template <int BM, int BN>
+__device__ __forceinline__ void p3_tn_issue(const P3TnParams& p, const __amdgpu_buffer_rsrc_t rsA, const __amdgpu_buffer_rsrc_t rsB, char* sb, int w, int lane,
+                                            int k0, int kend, int m0, int n0, int kh, int kw) {
+    constexpr int UA = BM / 64, UB = BN / 64, A_BYTES = BM * 192;   // [16 pixels x 32 channels] units per wave and operand
+    const int rg = w & 1, rr = lane >> 2, pq = (lane & 3) ^ ((rr >> 2) & 3);
+    const int pix = k0 + rg * 16 + rr;
+    const bool inr = pix < kend;
+    // A = dY: dense pixel rows
+    const unsigned offA = inr ? (unsigned)pix * (unsigned)p.Cout * 6u + pq * 16 : 0x80000000u;
+#pragma unroll
+    for (int i = 0; i < UA; i++) {
+        const int cb = (w >> 1) * UA + i;
+        const int sA = (m0 + cb * 32) * 6;
+#pragma unroll
+        for (int j = 0; j < 3; j++)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_void*)(sb + ((cb * 2 + rg) * 3 + j) * 1024), 16, offA, sA + j * 64, 0, 0);
+    }
+    // B = X gathered at the tap
+    unsigned offB = 0x80000000u;
+    {
+        int n, rem, oy, ox;
+        fastdivmod(pix, p.OH * p.OW, p.inv_ohw, n, rem);
+        fastdivmod(rem, p.OW, p.inv_ow, oy, ox);
+        const int sy = oy * p.stride - p.pad + kh, sx = ox * p.stride - p.pad + kw;
+        if (inr && sy >= 0 && sy < p.H && sx >= 0 && sx < p.W)
+            offB = (unsigned)(((n * p.H + oy * p.stride) * p.W + ox * p.stride) * p.Cin) * 6u + pq * 16;   // reference = tap (pad, pad); the tap's shift is uniform
+    }
+    const int sBt = (kh * p.W + kw) * p.Cin * 6;
+#pragma unroll
+    for (int i = 0; i < UB; i++) {
+        const int cb = (w >> 1) * UB + i;
+        const int sB = sBt + (n0 + cb * 32) * 6;
+#pragma unroll
+        for (int j = 0; j < 3; j++)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_void*)(sb + A_BYTES + ((cb * 2 + rg) * 3 + j) * 1024), 16, offB, sB + j * 64, 0, 0);
+    }
+}
+
+template <int BM, int BN, int NST>
+__global__ __launch_bounds__(256) void p3_tn_kernel(P3TnParams p) {
+    constexpr int A_BYTES = BM * 192, B_BYTES = BN * 192, ST_BYTES = A_BYTES + B_BYTES;
+    constexpr int LPT = (BM / 64 + BN / 64) * 3;
+    constexpr int TM = BM / 64, TN = BN / 64;
+    extern __shared__ __attribute__((aligned(1024))) char p3_smem[];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, wm = w >> 1, wn = w & 1;
+    const int cl = lane & 31, kl = lane >> 5;
+    const int taps = p.KH * p.KW;
+    int b = blockIdx.x;
+    const int tap = b % taps; b /= taps;
+    const int tn = b % p.ntiles, tm = b / p.ntiles;
+    const int kh = tap / p.KW, kw = tap - kh * p.KW;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int nkt = (p.npix + 31) >> 5;
+    const int per = (nkt + p.splitk - 1) / p.splitk;
+    const int kt0 = blockIdx.y * per, kt1 = min(nkt, kt0 + per);
+    int nloc = kt1 - kt0;
+    if (nloc <= 0) return;
+    if (p.debug == 1) nloc = 0;
+    const int kend = p.npix;
+
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.dY), 0, p.dy_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.X), 0, p.x_bytes, 0x00020000);
+
+    // transposing fragment reads: lane -> (channel group g of 16, lane-in-group i16, pixel octet kl); read r covers pixels 8 kl + 4 r .. + 3
+    const int g = cl >> 4, i16 = cl & 15, chq = i16 & 3;
+    const int c = 2 * g + (chq >> 1), half = chq & 1;
+    unsigned fo[2][3];
+#pragma unroll
+    for (int r = 0; r < 2; r++)
+#pragma unroll
+        for (int pl = 0; pl < 3; pl++) {
+            const int rowin = 8 * kl + 4 * r + (i16 >> 2);
+            const int e = 3 * c + pl;
+            fo[r][pl] = (unsigned)((e >> 2) * 1024 + rowin * 64 + (((e & 3) ^ ((rowin >> 2) & 3)) << 4) + half * 8);
+        }
+    const unsigned foA = (unsigned)(wm * TM * 2 * 3072), foB = (unsigned)(A_BYTES + wn * TN * 2 * 3072);
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; i++)
+#pragma unroll
+        for (int j = 0; j < TN; j++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+
+#pragma unroll
+    for (int q = 0; q < NST - 1; q++)
+        if (nloc > q) p3_tn_issue<BM, BN>(p, rsA, rsB, p3_smem + q * ST_BYTES, w, lane, (kt0 + q) * 32, kend, m0, n0, kh, kw);
+    for (int it = 0; it < nloc; it++) {
+        if (NST >= 3 && it + NST - 2 < nloc) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPT * (NST - 2)) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (it + NST - 1 < nloc)
+            p3_tn_issue<BM, BN>(p, rsA, rsB, p3_smem + ((it + NST - 1) % NST) * ST_BYTES, w, lane, (kt0 + it + NST - 1) * 32, kend, m0, n0, kh, kw);
+        const char* sb = p3_smem + (it % NST) * ST_BYTES;
+#pragma unroll
+        for (int s = 0; s < 2; s++) {
+            bf16x8_t a[TM][3], bb[TN][3];
+#pragma unroll
+            for (int i = 0; i < TM; i++)
+#pragma unroll
+                for (int pl = 0; pl < 3; pl++)
+                    a[i][pl] = tr_frag(sb + foA + (i * 2 + s) * 3072, fo[0][pl], fo[1][pl]);
+#pragma unroll
+            for (int j = 0; j < TN; j++)
+#pragma unroll
+                for (int pl = 0; pl < 3; pl++)
+                    bb[j][pl] = tr_frag(sb + foB + (j * 2 + s) * 3072, fo[0][pl], fo[1][pl]);
+#pragma unroll
+            for (int i = 0; i < TM; i++)
+#pragma unroll
+                for (int j = 0; j < TN; j++) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], bb[j][1], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], bb[j][2], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][2], bb[j][0], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], bb[j][1], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], bb[j][0], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], bb[j][0], acc[i][j], 0, 0, 0);
+                }
+        }
+    }
+    // acc[i][j][r]: row (out channel) = (r&3) + 8*(r>>2) + 4*kl, col (in channel) = cl
+    if (p.debug == 2 && acc[0][0][0] != 12345.f) return;
+#pragma unroll
+    for (int i = 0; i < TM; i++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int m = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * kl;
+            if (m >= p.Cout) continue;
+            const float sc = p.row_scale ? p.alpha * p.row_scale[m] : p.alpha;
+#pragma unroll
+            for (int j = 0; j < TN; j++) {
+                const int n = n0 + (wn * TN + j) * 32 + cl;
+                if (n < p.Cin) atomicAdd(p.dW + ((long)m * taps + tap) * p.Cin + n, acc[i][j][r] * sc);
+            }
+        }
+}
+
 // ---- fp32 <-> P3 streaming conversions.  One thread = one 8-channel group.
 __global__ __launch_bounds__(256) void p3_split_kernel(const float* __restrict__ src, long ld, char* __restrict__ dst, long rows, int C) {
     const int cg = C >> 3;
@@ -390,18 +566,56 @@ __global__ __launch_bounds__(256) void p3_merge_kernel(const char* __restrict__ 
 
 // Weights for the data gradient: w [O][KH][KW][I] fp32 -> P3 [I][KH*KW][O] (k = (tap, out channel) contiguous, taps in the
 // original order; the kernel's tap walk does the flipping).  One thread = 8 out channels of one (i, tap).
-__global__ __launch_bounds__(256) void p3_weight_bwd_kernel(const float* __restrict__ w, char* __restrict__ dst, int O, int T, int I) {
+__global__ __launch_bounds__(256) void p3_weight_bwd_kernel(const float* __restrict__ w, const float* __restrict__ o_scale, char* __restrict__ dst, int O, int T, int I) {
     const int og = O >> 3;
     const long total = (long)I * T * og;
     for (long u = (long)blockIdx.x * 256 + threadIdx.x; u < total; u += (long)gridDim.x * 256) {
         const int g = (int)(u % og); const long it = u / og; const int tp = (int)(it % T); const int i = (int)(it / T);
         float v[8];
 #pragma unroll
-        for (int e = 0; e < 8; e++) v[e] = w[((long)(g * 8 + e) * T + tp) * I + i];
+        for (int e = 0; e < 8; e++) v[e] = w[((long)(g * 8 + e) * T + tp) * I + i] * (o_scale ? o_scale[g * 8 + e] : 1.f);
         u32x4 h, md, lo;
 #pragma unroll
         for (int e = 0; e < 4; e++) { unsigned a, b, c; split2_bf16(v[2 * e], v[2 * e + 1], a, b, c); h[e] = a; md[e] = b; lo[e] = c; }
         char* d = dst + u * 48;
+        *reinterpret_cast<u32x4*>(d) = h; *reinterpret_cast<u32x4*>(d + 16) = md; *reinterpret_cast<u32x4*>(d + 32) = lo;
+    }
+}
+
+// Both P3 images of every convolution weight of a module in ONE launch (after each optimiser step): table row c =
+// {w, o_scale or 0, dst_fwd or 0, dst_bwd or 0, O, T, I, first block}; a block covers 256 of the conv's O*T*I/8 groups.
+//   dst_fwd: the split of w as stored, [O][T][I]  (forward B operand);  dst_bwd: [I][T][O] of w * o_scale[o]  (data-gradient B operand).
+__global__ __launch_bounds__(256) void p3_weight_prep_kernel(const long long* __restrict__ table, int nconv) {
+    int c = 0;
+    while (c + 1 < nconv && (long long)blockIdx.x >= table[(c + 1) * 8 + 7]) ++c;
+    const long long* row = table + c * 8;
+    const float* w = reinterpret_cast<const float*>(row[0]);
+    const float* sc = reinterpret_cast<const float*>(row[1]);
+    char* df = reinterpret_cast<char*>(row[2]);
+    char* db = reinterpret_cast<char*>(row[3]);
+    const int O = (int)row[4], T = (int)row[5], I = (int)row[6];
+    const long u = ((long)blockIdx.x - row[7]) * 256 + threadIdx.x;
+    const long units = (long)O * T * I / 8;
+    if (u >= units) return;
+    if (df) {
+        const float4 v0 = *reinterpret_cast<const float4*>(w + u * 8), v1 = *reinterpret_cast<const float4*>(w + u * 8 + 4);
+        const float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+        u32x4 h, md, lo;
+#pragma unroll
+        for (int e = 0; e < 4; e++) { unsigned a, b, cc; split2_bf16(v[2 * e], v[2 * e + 1], a, b, cc); h[e] = a; md[e] = b; lo[e] = cc; }
+        char* d = df + u * 48;
+        *reinterpret_cast<u32x4*>(d) = h; *reinterpret_cast<u32x4*>(d + 16) = md; *reinterpret_cast<u32x4*>(d + 32) = lo;
+    }
+    if (db) {
+        // u -> (out-channel group g, tap tp, in channel i), i fastest: the eight reads of a wave are eight coalesced rows
+        const int i = (int)(u % I); const long r = u / I; const int tp = (int)(r % T); const int g = (int)(r / T);
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; e++) v[e] = w[((long)(g * 8 + e) * T + tp) * I + i] * (sc ? sc[g * 8 + e] : 1.f);
+        u32x4 h, md, lo;
+#pragma unroll
+        for (int e = 0; e < 4; e++) { unsigned a, b, cc; split2_bf16(v[2 * e], v[2 * e + 1], a, b, cc); h[e] = a; md[e] = b; lo[e] = cc; }
+        char* d = db + (((long)i * T + tp) * (O / 8) + g) * 48;
         *reinterpret_cast<u32x4*>(d) = h; *reinterpret_cast<u32x4*>(d + 16) = md; *reinterpret_cast<u32x4*>(d + 32) = lo;
     }
 }
@@ -509,12 +723,18 @@ extern "C" int ldetr_p3_merge_f32(const void* src, float* dst, int64_t ld, int64
     return check_launch("p3_merge");
 }
 
-extern "C" int ldetr_p3_weight_bwd(const float* w_ohwi, void* dst, int O, int KH, int KW, int I, void* stream) {
+extern "C" int ldetr_p3_weight_bwd(const float* w_ohwi, const float* o_scale, void* dst, int O, int KH, int KW, int I, void* stream) {
     LDETR_CHECK(w_ohwi && dst && O % 8 == 0 && I > 0 && KH > 0 && KW > 0, "p3_weight_bwd: O must be a multiple of 8 (O=%d)", O);
     const long units = (long)I * KH * KW * (O / 8);
     const int blocks = (int)std::min<long>((units + 255) / 256, 256 * 16);
-    hipLaunchKernelGGL(p3_weight_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w_ohwi, (char*)dst, O, KH * KW, I);
+    hipLaunchKernelGGL(p3_weight_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w_ohwi, o_scale, (char*)dst, O, KH * KW, I);
     return check_launch("p3_weight_bwd");
+}
+
+extern "C" int ldetr_p3_weight_prep(const int64_t* table_dev, int nconv, int total_blocks, void* stream) {
+    LDETR_CHECK(table_dev && nconv > 0 && total_blocks > 0, "p3_weight_prep: empty table");
+    hipLaunchKernelGGL(p3_weight_prep_kernel, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const long long*>(table_dev), nconv);
+    return check_launch("p3_weight_prep");
 }
 
 extern "C" int ldetr_p3_conv2d_fwd(const void* x, int N, int H, int W, int Cin, const void* w, int Cout, int KH, int KW, int stride, int pad,
@@ -533,6 +753,90 @@ extern "C" int ldetr_p3_conv2d_fwd(const void* x, int N, int H, int W, int Cin, 
     fill_epi(p.ep, ep); p.ep.out_p3 = (char*)out_p3; p.ep.out_f32 = out_f32;
     if (p.M == 0) return LDETR_OK;
     return launch_nt(p, (hipStream_t)stream);
+}
+
+// dx[n][iy][ix][ci] = sum dy[n][(iy + pad - kh) / stride][(ix + pad - kw) / stride][co] * wb[ci][kh][kw][co] over the taps that divide:
+// one launch per parity class of (iy, ix) (stride^2 classes; a class without taps still runs its epilogue, e.g. writes the residual).
+extern "C" int ldetr_p3_conv2d_bwd_data(const void* dy, int N, int OH, int OW, int Cout, const void* wb, int Cin, int KH, int KW, int stride, int pad,
+                                        int IH, int IW, const ldetr_p3_epilogue* ep, void* out_p3, float* out_f32, void* stream) {
+    LDETR_CHECK(dy && wb && (out_p3 || out_f32), "p3_conv2d_bwd_data: null operand");
+    LDETR_CHECK(Cout % 32 == 0 && Cin % 8 == 0 && KH * KW <= 32 && pad < KH && pad < KW && (stride == 1 || stride == 2),
+                "p3_conv2d_bwd_data: unsupported geometry (Cin=%d Cout=%d k=%dx%d stride=%d pad=%d)", Cin, Cout, KH, KW, stride, pad);
+    const long dybytes = (long)N * OH * OW * Cout * 6, wbytes = (long)Cin * KH * KW * Cout * 6;
+    for (int cls = stride * stride - 1; cls >= 0; cls--) {
+        const int py = cls / stride, px = cls - py * stride;
+        P3NtParams p; memset(&p, 0, sizeof(p));
+        p.kh0 = (py + pad) % stride; p.kw0 = (px + pad) % stride; p.tstep = stride;
+        p.nty = p.kh0 < KH ? (KH - p.kh0 + stride - 1) / stride : 0; p.ntx = p.kw0 < KW ? (KW - p.kw0 + stride - 1) / stride : 0;
+        const int ntaps = p.nty * p.ntx;
+        if (ntaps == 0) { p.nty = 0; p.ntx = 1; }
+        const long shift = ((long)(p.nty > 0 ? p.nty - 1 : 0) * OW + (p.ntx - 1)) * Cout * 6;
+        LDETR_CHECK(dybytes + shift < 0x7fffffffL && wbytes < 0x7fffffffL, "p3_conv2d_bwd_data: tensor too large for 31-bit buffer offsets");
+        p.A = (const char*)dy - shift; p.a_bytes = (unsigned)(dybytes + shift); p.B = (const char*)wb; p.b_bytes = (unsigned)wbytes;
+        p.OH = (IH - py + stride - 1) / stride; p.OW = (IW - px + stride - 1) / stride;   // this class's pixel grid
+        if (p.OH <= 0 || p.OW <= 0) continue;
+        p.M = N * p.OH * p.OW; p.N = Cin; p.Cin = Cout; p.KH = KH; p.KW = KW; p.stride = stride; p.pad = pad; p.H = OH; p.W = OW;
+        p.out_H = IH; p.out_W = IW; p.out_step = stride; p.out_py = py; p.out_px = px; p.tap_mode = 1;
+        p.nkt = ntaps * Cout / 32;
+        fill_epi(p.ep, ep); p.ep.out_p3 = (char*)out_p3; p.ep.out_f32 = out_f32;
+        if (p.M == 0) continue;
+        const int rc = launch_nt(p, (hipStream_t)stream);
+        if (rc != LDETR_OK) return rc;
+    }
+    return LDETR_OK;
+}
+
+template <int BM, int BN, int NST>
+static int launch_tn_cfg(P3TnParams& p, int target_blocks, hipStream_t st) {
+    p.mtiles = cdiv(p.Cout, BM); p.ntiles = cdiv(p.Cin, BN);
+    const long nt = (long)p.mtiles * p.ntiles * p.KH * p.KW;
+    const int nkt = (p.npix + 31) / 32;
+    int sk = (int)((target_blocks + nt - 1) / nt);
+    if (sk > nkt / 4) sk = nkt / 4;
+    if (sk < 1) sk = 1;
+    static const int force_sk = getenv("LDETR_P3_WSK") ? atoi(getenv("LDETR_P3_WSK")) : 0;
+    if (force_sk > 0) sk = std::min(force_sk, nkt);
+    p.splitk = sk;
+    constexpr size_t lds = (size_t)NST * (BM + BN) * 192;
+    auto kern = p3_tn_kernel<BM, BN, NST>;
+    static bool raised = false;
+    if (lds > 64 * 1024 && !raised) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+            set_error("p3_tn: cannot raise the dynamic LDS limit to %zu bytes", lds);
+            return LDETR_ERR_LAUNCH;
+        }
+        raised = true;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)nt, sk, 1), 256, lds, st, p);
+    return check_launch("p3_tn");
+}
+
+extern "C" int ldetr_p3_conv2d_bwd_weight(const void* x, int N, int H, int W, int Cin, const void* dy, int Cout, int KH, int KW, int stride, int pad,
+                                          const float* dy_scale, float* dw, void* stream) {
+    const int OH = (H + 2 * pad - KH) / stride + 1, OW = (W + 2 * pad - KW) / stride + 1;
+    LDETR_CHECK(x && dy && dw, "p3_conv2d_bwd_weight: null operand");
+    LDETR_CHECK(Cin % 32 == 0 && Cout % 32 == 0 && pad < KH && pad < KW && (stride == 1 || stride == 2),
+                "p3_conv2d_bwd_weight: unsupported geometry (Cin=%d Cout=%d k=%dx%d stride=%d pad=%d)", Cin, Cout, KH, KW, stride, pad);
+    const long xbytes = (long)N * H * W * Cin * 6, dybytes = (long)N * OH * OW * Cout * 6, pad_off = ((long)pad * W + pad) * Cin * 6;
+    LDETR_CHECK(xbytes + pad_off < 0x7fffffffL && dybytes < 0x7fffffffL && (long)N * OH * OW < (1L << 24), "p3_conv2d_bwd_weight: tensor too large for 31-bit buffer offsets");
+    P3TnParams p; memset(&p, 0, sizeof(p));
+    p.dY = (const char*)dy; p.dy_bytes = (unsigned)dybytes; p.X = (const char*)x - pad_off; p.x_bytes = (unsigned)(xbytes + pad_off);
+    p.Cout = Cout; p.Cin = Cin; p.KH = KH; p.KW = KW; p.stride = stride; p.pad = pad; p.H = H; p.W = W; p.OH = OH; p.OW = OW;
+    p.npix = N * OH * OW; p.inv_ohw = 1.0f / (float)(OH * OW); p.inv_ow = 1.0f / (float)OW;
+    p.row_scale = dy_scale; p.alpha = 1.f; p.dW = dw;
+    static const int dbg = getenv("LDETR_P3_WDEBUG") ? atoi(getenv("LDETR_P3_WDEBUG")) : 0;
+    p.debug = dbg;
+    if (p.npix == 0) return LDETR_OK;
+    static const int force_tile = getenv("LDETR_P3_WTILE") ? atoi(getenv("LDETR_P3_WTILE")) : 0;
+    int cfg = (Cout >= 128 && Cin >= 128 && (long)(Cout / 128) * (Cin / 128) * KH * KW >= 8) ? 1 : ((Cout >= 128 && Cin >= 64) ? 2 : 3);
+    if (Cout % 128 != 0 || Cin % 128 != 0) cfg = std::max(cfg, 2);
+    if (Cout % 128 != 0 || Cin % 64 != 0) cfg = 3;
+    if (force_tile) cfg = force_tile;
+    switch (cfg) {
+        case 1: return launch_tn_cfg<128, 128, 3>(p, 256, (hipStream_t)stream);
+        case 2: return launch_tn_cfg<128, 64, 3>(p, 256, (hipStream_t)stream);
+        default: return launch_tn_cfg<64, 64, 3>(p, 512, (hipStream_t)stream);
+    }
 }
 
 extern "C" int ldetr_p3_probe(const void* g, int gbytes, void* out_tr, void* out_dma, void* stream) {

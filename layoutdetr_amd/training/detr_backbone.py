@@ -16,6 +16,7 @@ from torch import nn
 
 from ..detr_util.misc import NestedTensor
 from ..hip import conv as hconv
+from ..hip import p3 as hp3
 
 
 class FrozenBatchNorm2d(nn.Module):
@@ -103,6 +104,22 @@ class Bottleneck(nn.Module):
             idt = hconv.conv2d_nhwc(x, self.downsample[0].weight, sd, bd, None, self.downsample[0].stride, 0, relu=False)
         return hconv.conv2d_nhwc(out, self.conv3.weight, s3, b3, idt, 1, 0, relu=True, mask_input=True, premasked=self.premask_out)
 
+    p3_index = None   # (conv1, conv2, conv3, downsample or None): this block's rows in ResNet50Body's hip.p3.WeightPlanes
+
+    def forward_p3(self, x, planes, out_f32=False):
+        """The same block on P3 activations (hip/p3.py): x and the result are plane-format tensors; out_f32: the block output leaves the
+        trunk as fp32 [N, H, W, C] (its ReLU mask is then applied by this block's own backward)."""
+        s1, b1 = self.bn1.folded(); s2, b2 = self.bn2.folded(); s3, b3 = self.bn3.folded()
+        i1, i2, i3, idn = self.p3_index
+        out, x = hp3.conv2d_p3(x, self.conv1.weight, planes.ptrs(i1), s1, b1, None, 1, 0, relu=True, premasked=True, mask_input=self.mask_in, passthru=True)
+        out = hp3.conv2d_p3(out, self.conv2.weight, planes.ptrs(i2), s2, b2, None, self.conv2.stride, 1, relu=True, premasked=True, mask_input=True)
+        idt = x
+        if self.downsample is not None:
+            sd, bd = self.downsample[1].folded()
+            idt = hp3.conv2d_p3(x, self.downsample[0].weight, planes.ptrs(idn), sd, bd, None, self.downsample[0].stride, 0, relu=False)
+        return hp3.conv2d_p3(out, self.conv3.weight, planes.ptrs(i3), s3, b3, idt, 1, 0, relu=True, mask_input=True,
+                             premasked=self.premask_out and not out_f32, out_f32=out_f32)
+
 
 class BackwardStages(object):
     """Cuts a phase's backward pass into stages so that the gradient exchange of the part that is already complete can run
@@ -133,6 +150,10 @@ class BackwardStages(object):
         return any(self.records.values())
 
 
+import weakref
+_P3_PLANES = weakref.WeakKeyDictionary()   # ResNet50Body -> hip.p3.WeightPlanes
+
+
 class ResNet50Body(nn.Module):
     """conv1/bn1/maxpool/layer1..4 of torchvision resnet50 (what IntermediateLayerGetter keeps, detr_backbone.py:78-79)."""
 
@@ -154,10 +175,37 @@ class ResNet50Body(nn.Module):
             prev.premask_out = True
             nxt.mask_in = True
 
+    def p3_planes(self):
+        """P3 images of the 52 conv weights behind the stem (hip.p3.WeightPlanes; built on first use and kept OUTSIDE the module's state,
+        so deepcopy / pickle / state_dict see the reference's module only)."""
+        planes = _P3_PLANES.get(self)
+        if planes is None:
+            convs = []
+            for li in range(1, 5):
+                for b in getattr(self, f'layer{li}'):
+                    i0 = len(convs)
+                    convs += [(b.conv1.weight, b.bn1), (b.conv2.weight, b.bn2), (b.conv3.weight, b.bn3)]
+                    idn = None
+                    if b.downsample is not None:
+                        idn = len(convs)
+                        convs.append((b.downsample[0].weight, b.downsample[1]))
+                    b.p3_index = (i0, i0 + 1, i0 + 2, idn)
+            planes = _P3_PLANES[self] = hp3.WeightPlanes(convs)
+        return planes
+
+    @staticmethod
+    def p3_enabled(x):
+        """Plane-format trunk (default) unless LDETR_TRUNK_P3=0 or the activation would not fit the engine's 31-bit buffer offsets."""
+        import os
+        N, H, W, C = x.shape
+        return os.environ.get('LDETR_TRUNK_P3', '1') != '0' and N * H * W * 256 * 6 < 0x7fffffff and N * H * W < (1 << 24)
+
     def forward(self, x_nchw):
         s, b = self.bn1.folded()
         x = hconv.conv2d_nhwc(x_nchw, self.conv1.weight, s, b, None, 2, 3, relu=True, x_is_nchw=True)
         x = hconv.maxpool3x3s2_nhwc(x)
+        if self.p3_enabled(x):
+            return self._forward_p3(x)
         x = self.layer1(x); x = self.layer2(x)
         st = self.stages if (self.stages is not None and x.requires_grad and torch.is_grad_enabled()) else None
         if st is not None:
@@ -166,6 +214,26 @@ class ResNet50Body(nn.Module):
         if st is not None:
             x = st.cut(x, 2)
         return x  # [N, H/32, W/32, 2048]
+
+    def _forward_p3(self, x):
+        planes = self.p3_planes()
+        planes.ensure()
+        x = hp3.split(x)
+        for b in self.layer1:
+            x = b.forward_p3(x, planes)
+        for b in self.layer2:
+            x = b.forward_p3(x, planes)
+        st = self.stages if (self.stages is not None and x.requires_grad and torch.is_grad_enabled()) else None
+        if st is not None:
+            x = st.cut(x, 3)
+        for b in self.layer3:
+            x = b.forward_p3(x, planes)
+        n4 = len(self.layer4)
+        for i, b in enumerate(self.layer4):
+            x = b.forward_p3(x, planes, out_f32=(i == n4 - 1))
+        if st is not None:
+            x = st.cut(x, 2)
+        return x  # fp32 [N, H/32, W/32, 2048]
 
 
 class BackboneBase(nn.Module):

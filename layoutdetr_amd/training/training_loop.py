@@ -36,6 +36,14 @@ def _phys_view(flat_slice, like):
     raise RuntimeError('FlatModule: parameter is neither contiguous nor channels_last')
 
 
+def _trunk_bodies(module):
+    from .detr_backbone import ResNet50Body
+    import os
+    if os.environ.get('LDETR_TRUNK_P3', '1') == '0':
+        return []
+    return [m for m in module.modules() if isinstance(m, ResNet50Body)]
+
+
 class FlatModule(object):
     """Re-homes all parameters of `module` into one flat fp32 buffer and their .grad into another."""
 
@@ -186,6 +194,12 @@ class DataParallelStep(object):
                                                       1 if self.fuse else 0, scale, 0.0, 1e5, -1e5,
                                                       core.ptr(ema[0]) if ema is not None else None, float(ema[1]) if ema is not None else 0.0,
                                                       core.stream()), 'adam_step')
+        # the trunk's plane-format weight images (hip/p3.py) follow the parameters: one launch per optimiser step instead of one per forward
+        for body in _trunk_bodies(phase.module):
+            planes = body.p3_planes()
+            planes.managed = True
+            planes.stale = True
+            planes.ensure()
 
 
 class EmaTracker(object):

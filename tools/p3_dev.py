@@ -82,6 +82,59 @@ def check_case(N, H, Ci, Co, k, s, pad, full_ep=True):
     assert err < 2e-6 and same
 
 
+def p3_weight_bwd(w, scale=None):
+    Co, k, _, Ci = w.shape
+    out = torch.empty(Ci * k * k * Co * 6, dtype=torch.uint8, device=dev)
+    core.check(L.ldetr_p3_weight_bwd(core.ptr(w), core.ptr(scale), core.ptr(out), Co, k, k, Ci, core.stream()), 'weight_bwd')
+    return out
+
+
+def check_bwd(N, H, Ci, Co, k, s, pad):
+    torch.manual_seed(2)
+    OH = (H + 2 * pad - k) // s + 1
+    x = torch.randn(N, H, H, Ci, device=dev)
+    w = torch.randn(Co, k, k, Ci, device=dev) / (k * Ci ** 0.5)
+    dy = torch.randn(N, OH, OH, Co, device=dev) * torch.exp(torch.randn(N, OH, OH, Co, device=dev))
+    sc = torch.rand(Co, device=dev) + 0.5
+    xd = x.double().permute(0, 3, 1, 2).requires_grad_(True); wd = w.double().permute(0, 3, 1, 2).requires_grad_(True)
+    y = F.conv2d(xd, wd, stride=s, padding=pad)
+    gx, gw = torch.autograd.grad(y, (xd, wd), (dy.double() * sc.double()).permute(0, 3, 1, 2))
+    gx = gx.permute(0, 2, 3, 1); gw = gw.permute(0, 2, 3, 1)
+    # data gradient with mask (x > 0) and a residual
+    res = torch.randn(N, H, H, Ci, device=dev)
+    dyp = p3_split(dy.reshape(-1, Co)); xp = p3_split(x.reshape(-1, Ci)); resp = p3_split(res.reshape(-1, Ci)); wb = p3_weight_bwd(w, sc)
+    ep = _lib.P3Epilogue(); ep.alpha = 1.0; ep.residual_p3 = resp.data_ptr(); ep.relu_mask_p3 = xp.data_ptr()
+    dxf = torch.empty(N, H, H, Ci, device=dev); dxp = torch.empty(N * H * H * Ci * 6, dtype=torch.uint8, device=dev)
+    core.check(L.ldetr_p3_conv2d_bwd_data(core.ptr(dyp), N, OH, OH, Co, core.ptr(wb), Ci, k, k, s, pad, H, H, ctypes.byref(ep), core.ptr(dxp), core.ptr(dxf), core.stream()), 'bwd_data')
+    ref = torch.where(x > 0, gx + res.double(), torch.zeros_like(gx))
+    e1 = (dxf.double() - ref).abs().max().item() / ref.abs().max().item()
+    same = torch.equal(p3_merge(dxp, N * H * H, Ci), dxf.reshape(-1, Ci))
+    # weight gradient (accumulating onto an existing buffer)
+    dw0 = torch.randn(Co, k, k, Ci, device=dev); dw = dw0.clone()
+    core.check(L.ldetr_p3_conv2d_bwd_weight(core.ptr(xp), N, H, H, Ci, core.ptr(dyp), Co, k, k, s, pad, core.ptr(sc), core.ptr(dw), core.stream()), 'bwd_weight')
+    torch.cuda.synchronize()
+    e2 = ((dw - dw0).double() - gw).abs().max().item() / gw.abs().max().item()
+    print(f'check bwd N={N} H={H} {Ci}->{Co} k{k} s{s}: dx err {e1:.2e} p3==f32 {same} | dw err {e2:.2e}', flush=True)
+    assert e1 < 3e-6 and same and e2 < 3e-6
+
+
+def bench_bwd(name, N, H, Ci, Co, k, s, pad):
+    OH = (H + 2 * pad - k) // s + 1
+    x = torch.randn(N, H, H, Ci, device=dev); w = torch.randn(Co, k, k, Ci, device=dev) / (k * Ci ** 0.5); dy = torch.randn(N, OH, OH, Co, device=dev)
+    sc = torch.rand(Co, device=dev) + 0.5
+    dyp = p3_split(dy.reshape(-1, Co)); xp = p3_split(x.reshape(-1, Ci)); wb = p3_weight_bwd(w, sc)
+    ep = _lib.P3Epilogue(); ep.alpha = 1.0; ep.relu_mask_p3 = xp.data_ptr()
+    dxp = torch.empty(N * H * H * Ci * 6, dtype=torch.uint8, device=dev); dw = torch.zeros(Co, k, k, Ci, device=dev)
+    fl = 2.0 * N * OH * OH * Co * k * k * Ci
+    t1 = timeit(lambda: L.ldetr_p3_conv2d_bwd_data(core.ptr(dyp), N, OH, OH, Co, core.ptr(wb), Ci, k, k, s, pad, H, H, ctypes.byref(ep), core.ptr(dxp), None, core.stream()))
+    t2 = timeit(lambda: L.ldetr_p3_conv2d_bwd_weight(core.ptr(xp), N, H, H, Ci, core.ptr(dyp), Co, k, k, s, pad, core.ptr(sc), core.ptr(dw), core.stream()))
+    dx = torch.empty_like(x); dyt = core.tensor4_nhwc(dy); xt = core.tensor4_nhwc(x)
+    epb = core.epilogue(mask_src=x.reshape(-1, Ci), mask_mode=1)
+    t3 = timeit(lambda: L.ldetr_conv2d_bwd_data_f32(core.ptr(dy), ctypes.byref(dyt), core.ptr(w), Ci, k, k, s, pad, core.ptr(dx), Ci, H, H, core.ptr(sc), 0, ctypes.byref(epb), core.stream()))
+    t4 = timeit(lambda: L.ldetr_conv2d_bwd_weight_f32(core.ptr(x), ctypes.byref(xt), core.ptr(dy), ctypes.byref(dyt), core.ptr(dw), k, k, s, pad, 0, None, 0, core.ptr(sc), 0, 1, core.stream()))
+    print(f'{name:24s} bwdD p3 {t1*1e6:7.1f}us {fl/t1/1e12:6.1f}TF (f32 eng {t3*1e6:7.1f}us {fl/t3/1e12:6.1f}) | bwdW p3 {t2*1e6:7.1f}us {fl/t2/1e12:6.1f}TF (f32 eng {t4*1e6:7.1f}us {fl/t4/1e12:6.1f})', flush=True)
+
+
 def bench_case(name, N, H, Ci, Co, k, s, pad):
     x = torch.randn(N, H, H, Ci, device=dev); w = torch.randn(Co, k, k, Ci, device=dev) / (k * Ci ** 0.5)
     OH = (H + 2 * pad - k) // s + 1
@@ -119,7 +172,19 @@ if __name__ == '__main__':
         check_case(4, 32, 128, 128, 3, 1, 1, True)
         check_case(16, 8, 512, 512, 3, 1, 1, True)     # split-K
         check_case(16, 16, 1024, 256, 1, 1, 0, True)   # split-K
+    if 'checkb' in what:
+        check_bwd(1, 8, 32, 32, 1, 1, 0)
+        check_bwd(2, 8, 64, 64, 3, 1, 1)
+        check_bwd(2, 9, 64, 96, 3, 1, 1)
+        check_bwd(2, 16, 64, 128, 3, 2, 1)
+        check_bwd(3, 16, 128, 256, 1, 2, 0)
+        check_bwd(4, 32, 128, 128, 3, 1, 1)
+        check_bwd(16, 8, 512, 512, 3, 1, 1)
+        check_bwd(16, 16, 1024, 256, 1, 1, 0)
+    B = int(os.environ.get('B', '16'))
     if 'bench' in what:
-        B = int(os.environ.get('B', '16'))
         for c in CASES:
             bench_case(c[0], B, *c[1:])
+    if 'benchb' in what:
+        for c in CASES:
+            bench_bwd(c[0], B, *c[1:])
