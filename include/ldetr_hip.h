@@ -390,6 +390,7 @@ int ldetr_p3_conv2d_bwd_weight(const void* x, int N, int H, int W, int Cin, cons
                                const float* dy_scale, float* dw, void* stream);
 /* Development probe (tools/p3_dev.py): ds_read_b64_tr_b16 lane map and LDS-DMA range semantics. */
 int ldetr_p3_probe(const void* g, int gbytes, void* out_tr, void* out_dma, void* stream);
+int ldetr_p3_dma_probe(const void* src, int64_t bytes, int seg, int pitch, int iters, int pieces, int blocks, void* stream);
 
 #ifdef __cplusplus
 }

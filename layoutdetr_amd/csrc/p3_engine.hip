@@ -54,6 +54,7 @@ struct P3NtParams {
     int splitk;
     float* ws; int* ws_count;
     int mtiles, ntiles;
+    int debug;               // development: 1 = no operand traffic in the k-loop, 2 = no MFMA work in the k-loop
     P3Epi ep;
 };
 
@@ -67,13 +68,19 @@ __device__ __forceinline__ int xcd_remap(int b, int n) {
     return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
 }
 
-// One k-tile's LDS-DMA of this wave: its 16-row groups of A (gathered pixels) and B (weight rows), three 1-KiB instructions each.
-// (A free function, not a lambda: hipcc drops the host stub of a kernel template whose lambda captures mutable locals next to these builtins.)
+// One k-tile of this wave's operand rows, global -> registers: its 16-row groups of A (gathered pixels) and B (weight rows), three
+// 16-byte pieces per lane and group (piece = (lane % 4) ^ swizzle of its 64-byte instruction slice).  Register staging, not LDS-DMA:
+// measured on MI355X (tools/p3_dev.py dma / reg, profiles/r04_p3_staging_probe.txt) `buffer_load ... lds` tops out at 42-55 GB/s per CU
+// from L2-resident operands whatever the access shape, plain buffer_load_dwordx4 + ds_write_b128 moves 105-220 GB/s per CU, and every
+// DMA-fed version of this kernel sat exactly on the first figure.  (Free functions: hipcc drops the host stub of a kernel template whose
+// lambda captures mutable locals next to buffer builtins.)
+typedef unsigned int ld128_t __attribute__((__vector_size__(16)));
+
 template <int BM, int BN, int NW>
-__device__ __forceinline__ void p3_issue_tile(const P3NtParams& p, const __amdgpu_buffer_rsrc_t rsA, const __amdgpu_buffer_rsrc_t rsB, char* sb, int w,
-                                              const unsigned* offA, const unsigned* vmA, const unsigned* offB,
-                                              int& tap, int& cc, int ktpt) {
-    constexpr int RGA = BM / 16 / NW, RGB = BN / 16 / NW, A_BYTES = BM * 192;
+__device__ __forceinline__ void p3_load_tile(const P3NtParams& p, const __amdgpu_buffer_rsrc_t rsA, const __amdgpu_buffer_rsrc_t rsB,
+                                             const unsigned* offA, const unsigned* vmA, const unsigned* offB, int& tap, int& cc, int ktpt,
+                                             ld128_t* ra, ld128_t* rb) {
+    constexpr int RGA = BM / 16 / NW, RGB = BN / 16 / NW;
     // tap offset relative to the row's reference pixel (p.A is shifted back so that it is never negative): uniform
     const int ty = tap / p.ntx, tx = tap - ty * p.ntx;
     int dpix;
@@ -83,32 +90,43 @@ __device__ __forceinline__ void p3_issue_tile(const P3NtParams& p, const __amdgp
     const int sB = ((p.kh0 + p.tstep * ty) * p.KW + p.kw0 + p.tstep * tx) * p.Cin * 6 + cc * 192;
 #pragma unroll
     for (int i = 0; i < RGA; i++) {
-        const unsigned vo = ((vmA[i] >> tap) & 1u) ? offA[i] : 0x80000000u;
+        const unsigned vo = ((vmA[i] >> tap) & 1u) ? offA[i] : 0x80000000u;   // out of the descriptor's range: the load returns zeros (padding)
 #pragma unroll
-        for (int j = 0; j < 3; j++)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_void*)(sb + ((w * RGA + i) * 3 + j) * 1024), 16, vo, sA + j * 64, 0, 0);
+        for (int j = 0; j < 3; j++) ra[i * 3 + j] = __builtin_amdgcn_raw_buffer_load_b128(rsA, vo, sA + j * 64, 0);
     }
 #pragma unroll
     for (int i = 0; i < RGB; i++) {
 #pragma unroll
-        for (int j = 0; j < 3; j++)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_void*)(sb + A_BYTES + ((w * RGB + i) * 3 + j) * 1024), 16, offB[i], sB + j * 64, 0, 0);
+        for (int j = 0; j < 3; j++) rb[i * 3 + j] = __builtin_amdgcn_raw_buffer_load_b128(rsB, offB[i], sB + j * 64, 0);
     }
     if (++cc == ktpt) { cc = 0; ++tap; }
 }
 
-// BM x BN block tile, NW waves as a WGM x WGN grid (WGN = 4 for eight waves on a 128-wide tile), NST ring stages of BK = 32.
-template <int BM, int BN, int NW, int NST>
+template <int BM, int BN, int NW>
+__device__ __forceinline__ void p3_store_tile(char* sb, int w, int lane, const ld128_t* ra, const ld128_t* rb) {
+    constexpr int RGA = BM / 16 / NW, RGB = BN / 16 / NW, A_BYTES = BM * 192;
+#pragma unroll
+    for (int i = 0; i < RGA; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) *reinterpret_cast<ld128_t*>(sb + ((w * RGA + i) * 3 + j) * 1024 + lane * 16) = ra[i * 3 + j];
+#pragma unroll
+    for (int i = 0; i < RGB; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) *reinterpret_cast<ld128_t*>(sb + A_BYTES + ((w * RGB + i) * 3 + j) * 1024 + lane * 16) = rb[i * 3 + j];
+}
+
+// BM x BN block tile, NW waves as a WGM x WGN grid (WGN = 4 for eight waves on a 128-wide tile), two LDS stages of BK = 32: the loads of
+// k-tile t+1 are in flight (in registers) during the MFMAs of k-tile t and are written to the other stage before the iteration's one barrier.
+template <int BM, int BN, int NW>
 __global__ __launch_bounds__(NW * 64) void p3_nt_kernel(P3NtParams p) {
-    constexpr int NT = NW * 64;
+    constexpr int NT = NW * 64, NST = 2;
     constexpr int WGN = (NW == 8 && BN >= 128) ? 4 : 2, WGM = NW / WGN;
     constexpr int WM = BM / WGM, WN = BN / WGN, TM = WM / 32, TN = WN / 32;   // wave tile, 32x32 accumulators per wave
     constexpr int A_BYTES = BM * 192, B_BYTES = BN * 192, ST_BYTES = A_BYTES + B_BYTES;
     constexpr int RGA = BM / 16 / NW, RGB = BN / 16 / NW;   // 16-row groups per wave and operand
-    constexpr int LPT = (RGA + RGB) * 3;                     // LDS-DMA instructions per wave and k-tile
     static_assert(TM >= 1 && TN >= 1 && RGA >= 1 && RGB >= 1 && BM % (16 * NW) == 0 && BN % (16 * NW) == 0, "tile / wave-count mismatch");
     extern __shared__ __attribute__((aligned(1024))) char p3_smem[];
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, wm = w / WGN, wn = w % WGN;
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), wm = w / WGN, wn = w % WGN;   // w in an SGPR: LDS-DMA bases and scalar offsets stay scalar
     const int cl = lane & 31, kl = lane >> 5;
 
     const int ntl = p.mtiles * p.ntiles;
@@ -122,7 +140,7 @@ __global__ __launch_bounds__(NW * 64) void p3_nt_kernel(P3NtParams p) {
     const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.A), 0, p.a_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.B), 0, p.b_bytes, 0x00020000);
 
-    // ---- per-lane source rows for the LDS-DMA (row-in-group = lane / 4, 16-byte piece = (lane % 4) ^ swizzle)
+    // ---- per-lane source rows (row-in-group = lane / 4, 16-byte piece = (lane % 4) ^ swizzle)
     const int rr = lane >> 2, pq = (lane & 3) ^ ((rr >> 2) & 3);
     const int ktpt = p.Cin >> 5;                          // k-tiles per tap
     unsigned offA[RGA], vmA[RGA], offB[RGB];
@@ -165,9 +183,8 @@ __global__ __launch_bounds__(NW * 64) void p3_nt_kernel(P3NtParams p) {
 
     // uniform walk over (tap, channel tile)
     int tap = kt0 / ktpt, cc = kt0 - tap * ktpt;          // next k-tile to issue
-#define P3_ISSUE(st_) p3_issue_tile<BM, BN, NW>(p, rsA, rsB, p3_smem + (st_) * ST_BYTES, w, offA, vmA, offB, tap, cc, ktpt)
 
-    // ---- fragment read offsets: piece e = 3*(2s + kl) + plane -> DMA instruction e / 4, slot (e % 4) ^ swizzle(row)
+    // ---- fragment read offsets: piece e = 3*(2s + kl) + plane -> 64-byte slice e / 4, slot (e % 4) ^ swizzle(row)
     const int frr = cl & 15, frg = cl >> 4;               // row within its 16-row group, group within the 32-row block
     unsigned fo[2][3];
 #pragma unroll
@@ -187,16 +204,16 @@ __global__ __launch_bounds__(NW * 64) void p3_nt_kernel(P3NtParams p) {
 #pragma unroll
             for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
 
-    const int nloc = kt1 - kt0;
-#pragma unroll
-    for (int q = 0; q < NST - 1; q++)
-        if (nloc > q) P3_ISSUE(q);
+    const int nloc = p.debug == 3 ? 0 : kt1 - kt0;
+    ld128_t ra[RGA * 3], rb[RGB * 3];
+    if (nloc > 0) {
+        p3_load_tile<BM, BN, NW>(p, rsA, rsB, offA, vmA, offB, tap, cc, ktpt, ra, rb);
+        p3_store_tile<BM, BN, NW>(p3_smem, w, lane, ra, rb);
+    }
+    __syncthreads();
     for (int it = 0; it < nloc; it++) {
-        // tile `it` must have landed; the NST - 2 tiles issued after it may stay in flight
-        if (NST >= 3 && it + NST - 2 < nloc) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPT * (NST - 2)) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        if (it + NST - 1 < nloc) P3_ISSUE((it + NST - 1) % NST);
+        if (it + 1 < nloc && p.debug != 1) p3_load_tile<BM, BN, NW>(p, rsA, rsB, offA, vmA, offB, tap, cc, ktpt, ra, rb);
+        if (p.debug != 2) {
         const char* sb = p3_smem + (it % NST) * ST_BYTES;
 #pragma unroll
         for (int s = 0; s < 2; s++) {
@@ -223,8 +240,10 @@ __global__ __launch_bounds__(NW * 64) void p3_nt_kernel(P3NtParams p) {
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][0], acc[i][j], 0, 0, 0);
                 }
         }
+        }
+        if (it + 1 < nloc && p.debug != 1) p3_store_tile<BM, BN, NW>(p3_smem + ((it + 1) % NST) * ST_BYTES, w, lane, ra, rb);
+        __syncthreads();
     }
-#undef P3_ISSUE
 
     // ---- split-K: park the raw tile (register order: coalesced), the last arriver sums the slices in slice order
     if (p.splitk > 1) {
@@ -248,6 +267,7 @@ __global__ __launch_bounds__(NW * 64) void p3_nt_kernel(P3NtParams p) {
         }
         __syncthreads();
         const int last = *flag;
+        __syncthreads();   // the flag word is part of the epilogue's staging area
         if (!last) return;
 #pragma unroll
         for (int i = 0; i < TM; i++)
@@ -267,8 +287,7 @@ __global__ __launch_bounds__(NW * 64) void p3_nt_kernel(P3NtParams p) {
         }
     }
 
-    // ---- epilogue: wave tile (WM x WN) through LDS, then 8-channel groups per lane
-    __syncthreads();
+    // ---- epilogue: wave tile (WM x WN) through LDS, then 8-channel groups per lane (the k-loop ended on a barrier)
     constexpr int CP = WN + 4;
     static_assert(NW * WM * CP * 4 <= NST * ST_BYTES, "epilogue staging does not fit");
     float* Cs = reinterpret_cast<float*>(p3_smem) + w * (WM * CP);
@@ -377,25 +396,32 @@ struct P3TnParams {
 };
 
 __device__ __forceinline__ void fastdivmod(int x, int d, float invd, int& q, int& r) {   // exact for 0 <= x < 2^24
-    q = (int)(__int2float_rz(x) * invd);
+    q = (int)((float)x * invd);
     r = x - q * d;
     if (r >= d) { ++q; r -= d; }
     if (r < 0) { --q; r += d; }
 }
 
-typedef short s16x4_t __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ bf16x8_t tr_frag(const char* base, unsigned o0, unsigned o1) {
-    const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(base + o0));
-    const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(base + o1));
-    typedef short s16x8_t __attribute__((ext_vector_type(8)));
-    const s16x8_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+// Transposing LDS reads as inline asm: hipcc's waitcnt pass cannot tell the builtin's LDS access from the LDS-DMA writes in flight and
+// drains the whole DMA queue (vmcnt(0)) before every one of them, i.e. it serialises the ring.  The asm is invisible to that pass, so the
+// lgkmcnt waits are written by hand (tr_wait) before the fragments are used.
+typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ u32x2_t tr_read(unsigned addr) {
+    u32x2_t v;
+    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(v) : "v"(addr) : "memory");
+    return v;
+}
+// (sched_barrier: the asm results look ready to the scheduler, which would otherwise hoist the consuming MFMAs above the wait)
+__device__ __forceinline__ void tr_wait() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_sched_barrier(0); }
+__device__ __forceinline__ bf16x8_t tr_join(u32x2_t lo, u32x2_t hi) {
+    const u32x4 v = {lo[0], lo[1], hi[0], hi[1]};
     return __builtin_bit_cast(bf16x8_t, v);
 }
 
 template <int BM, int BN>
-__device__ __forceinline__ void p3_tn_issue(const P3TnParams& p, const __amdgpu_buffer_rsrc_t rsA, const __amdgpu_buffer_rsrc_t rsB, char* sb, int w, int lane,
-                                            int k0, int kend, int m0, int n0, int kh, int kw) {
-    constexpr int UA = BM / 64, UB = BN / 64, A_BYTES = BM * 192;   // [16 pixels x 32 channels] units per wave and operand
+__device__ __forceinline__ void p3_tn_load(const P3TnParams& p, const __amdgpu_buffer_rsrc_t rsA, const __amdgpu_buffer_rsrc_t rsB, int w, int lane,
+                                           int k0, int kend, int m0, int n0, int kh, int kw, ld128_t* ra, ld128_t* rb) {
+    constexpr int UA = BM / 64, UB = BN / 64;   // [16 pixels x 32 channels] units per wave and operand
     const int rg = w & 1, rr = lane >> 2, pq = (lane & 3) ^ ((rr >> 2) & 3);
     const int pix = k0 + rg * 16 + rr;
     const bool inr = pix < kend;
@@ -406,8 +432,7 @@ __device__ __forceinline__ void p3_tn_issue(const P3TnParams& p, const __amdgpu_
         const int cb = (w >> 1) * UA + i;
         const int sA = (m0 + cb * 32) * 6;
 #pragma unroll
-        for (int j = 0; j < 3; j++)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_void*)(sb + ((cb * 2 + rg) * 3 + j) * 1024), 16, offA, sA + j * 64, 0, 0);
+        for (int j = 0; j < 3; j++) ra[i * 3 + j] = __builtin_amdgcn_raw_buffer_load_b128(rsA, offA, sA + j * 64, 0);
     }
     // B = X gathered at the tap
     unsigned offB = 0x80000000u;
@@ -425,18 +450,30 @@ __device__ __forceinline__ void p3_tn_issue(const P3TnParams& p, const __amdgpu_
         const int cb = (w >> 1) * UB + i;
         const int sB = sBt + (n0 + cb * 32) * 6;
 #pragma unroll
-        for (int j = 0; j < 3; j++)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_void*)(sb + A_BYTES + ((cb * 2 + rg) * 3 + j) * 1024), 16, offB, sB + j * 64, 0, 0);
+        for (int j = 0; j < 3; j++) rb[i * 3 + j] = __builtin_amdgcn_raw_buffer_load_b128(rsB, offB, sB + j * 64, 0);
     }
 }
 
-template <int BM, int BN, int NST>
+template <int BM, int BN>
+__device__ __forceinline__ void p3_tn_store(char* sb, int w, int lane, const ld128_t* ra, const ld128_t* rb) {
+    constexpr int UA = BM / 64, UB = BN / 64, A_BYTES = BM * 192;
+    const int rg = w & 1;
+#pragma unroll
+    for (int i = 0; i < UA; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) *reinterpret_cast<ld128_t*>(sb + ((((w >> 1) * UA + i) * 2 + rg) * 3 + j) * 1024 + lane * 16) = ra[i * 3 + j];
+#pragma unroll
+    for (int i = 0; i < UB; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) *reinterpret_cast<ld128_t*>(sb + A_BYTES + ((((w >> 1) * UB + i) * 2 + rg) * 3 + j) * 1024 + lane * 16) = rb[i * 3 + j];
+}
+
+template <int BM, int BN>
 __global__ __launch_bounds__(256) void p3_tn_kernel(P3TnParams p) {
-    constexpr int A_BYTES = BM * 192, B_BYTES = BN * 192, ST_BYTES = A_BYTES + B_BYTES;
-    constexpr int LPT = (BM / 64 + BN / 64) * 3;
+    constexpr int A_BYTES = BM * 192, B_BYTES = BN * 192, ST_BYTES = A_BYTES + B_BYTES, NST = 2;
     constexpr int TM = BM / 64, TN = BN / 64;
     extern __shared__ __attribute__((aligned(1024))) char p3_smem[];
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, wm = w >> 1, wn = w & 1;
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), wm = w >> 1, wn = w & 1;
     const int cl = lane & 31, kl = lane >> 5;
     const int taps = p.KH * p.KW;
     int b = blockIdx.x;
@@ -468,6 +505,7 @@ __global__ __launch_bounds__(256) void p3_tn_kernel(P3TnParams p) {
             fo[r][pl] = (unsigned)((e >> 2) * 1024 + rowin * 64 + (((e & 3) ^ ((rowin >> 2) & 3)) << 4) + half * 8);
         }
     const unsigned foA = (unsigned)(wm * TM * 2 * 3072), foB = (unsigned)(A_BYTES + wn * TN * 2 * 3072);
+    const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)p3_smem;
 
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -477,29 +515,46 @@ __global__ __launch_bounds__(256) void p3_tn_kernel(P3TnParams p) {
 #pragma unroll
             for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
 
-#pragma unroll
-    for (int q = 0; q < NST - 1; q++)
-        if (nloc > q) p3_tn_issue<BM, BN>(p, rsA, rsB, p3_smem + q * ST_BYTES, w, lane, (kt0 + q) * 32, kend, m0, n0, kh, kw);
+    ld128_t ga[(BM / 64) * 3], gb[(BN / 64) * 3];
+    if (nloc > 0) {
+        p3_tn_load<BM, BN>(p, rsA, rsB, w, lane, kt0 * 32, kend, m0, n0, kh, kw, ga, gb);
+        p3_tn_store<BM, BN>(p3_smem, w, lane, ga, gb);
+    }
+    __syncthreads();
     for (int it = 0; it < nloc; it++) {
-        if (NST >= 3 && it + NST - 2 < nloc) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPT * (NST - 2)) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        if (it + NST - 1 < nloc)
-            p3_tn_issue<BM, BN>(p, rsA, rsB, p3_smem + ((it + NST - 1) % NST) * ST_BYTES, w, lane, (kt0 + it + NST - 1) * 32, kend, m0, n0, kh, kw);
-        const char* sb = p3_smem + (it % NST) * ST_BYTES;
+        if (it + 1 < nloc) p3_tn_load<BM, BN>(p, rsA, rsB, w, lane, (kt0 + it + 1) * 32, kend, m0, n0, kh, kw, ga, gb);
+        const unsigned sbase = lds_base + (unsigned)((it % NST) * ST_BYTES);
+        u32x2_t ra[2][TM][3][2], rb[2][TN][3][2];   // [k16 step][block][plane][pixel half]
 #pragma unroll
         for (int s = 0; s < 2; s++) {
+#pragma unroll
+            for (int i = 0; i < TM; i++)
+#pragma unroll
+                for (int pl = 0; pl < 3; pl++) {
+                    ra[s][i][pl][0] = tr_read(sbase + foA + (i * 2 + s) * 3072 + fo[0][pl]);
+                    ra[s][i][pl][1] = tr_read(sbase + foA + (i * 2 + s) * 3072 + fo[1][pl]);
+                }
+#pragma unroll
+            for (int j = 0; j < TN; j++)
+#pragma unroll
+                for (int pl = 0; pl < 3; pl++) {
+                    rb[s][j][pl][0] = tr_read(sbase + foB + (j * 2 + s) * 3072 + fo[0][pl]);
+                    rb[s][j][pl][1] = tr_read(sbase + foB + (j * 2 + s) * 3072 + fo[1][pl]);
+                }
+            if (s == 0) tr_wait();   // step 1's reads stay in flight behind step 0's MFMAs
+        }
+#pragma unroll
+        for (int s = 0; s < 2; s++) {
+            if (s == 1) tr_wait();
             bf16x8_t a[TM][3], bb[TN][3];
 #pragma unroll
             for (int i = 0; i < TM; i++)
 #pragma unroll
-                for (int pl = 0; pl < 3; pl++)
-                    a[i][pl] = tr_frag(sb + foA + (i * 2 + s) * 3072, fo[0][pl], fo[1][pl]);
+                for (int pl = 0; pl < 3; pl++) a[i][pl] = tr_join(ra[s][i][pl][0], ra[s][i][pl][1]);
 #pragma unroll
             for (int j = 0; j < TN; j++)
 #pragma unroll
-                for (int pl = 0; pl < 3; pl++)
-                    bb[j][pl] = tr_frag(sb + foB + (j * 2 + s) * 3072, fo[0][pl], fo[1][pl]);
+                for (int pl = 0; pl < 3; pl++) bb[j][pl] = tr_join(rb[s][j][pl][0], rb[s][j][pl][1]);
 #pragma unroll
             for (int i = 0; i < TM; i++)
 #pragma unroll
@@ -512,6 +567,8 @@ __global__ __launch_bounds__(256) void p3_tn_kernel(P3TnParams p) {
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], bb[j][0], acc[i][j], 0, 0, 0);
                 }
         }
+        if (it + 1 < nloc) p3_tn_store<BM, BN>(p3_smem + ((it + 1) % NST) * ST_BYTES, w, lane, ga, gb);
+        __syncthreads();
     }
     // acc[i][j][r]: row (out channel) = (r&3) + 8*(r>>2) + 4*kl, col (in channel) = cl
     if (p.debug == 2 && acc[0][0][0] != 12345.f) return;
@@ -646,16 +703,18 @@ __global__ void p3_probe_kernel(const unsigned short* g, int gbytes, unsigned sh
     for (int i = l; i < 3072; i += 64) out_dma[i] = sm[i];
 }
 
-template <int BM, int BN, int NW, int NST>
+template <int BM, int BN, int NW>
 static int launch_nt_cfg(P3NtParams& p, int sk, hipStream_t st) {
     p.mtiles = cdiv(p.M, BM); p.ntiles = cdiv(p.N, BN);
     const long nt = (long)p.mtiles * p.ntiles;
     if (sk > p.nkt) sk = p.nkt;
     if (sk < 1) sk = 1;
+    static const int dbg = getenv("LDETR_P3_DEBUG") ? atoi(getenv("LDETR_P3_DEBUG")) : 0;
+    p.debug = dbg;
     p.splitk = sk; p.ws = nullptr; p.ws_count = nullptr;
     if (sk > 1 && !splitk_ws_alloc(nt, (size_t)nt * sk * BM * BN * sizeof(float), &p.ws, &p.ws_count)) p.splitk = sk = 1;
-    constexpr size_t lds = (size_t)NST * (BM + BN) * 192;
-    auto kern = p3_nt_kernel<BM, BN, NW, NST>;
+    constexpr size_t lds = (size_t)2 * (BM + BN) * 192;
+    auto kern = p3_nt_kernel<BM, BN, NW>;
     static bool raised = false;
     if (lds > 64 * 1024 && !raised) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
@@ -669,8 +728,8 @@ static int launch_nt_cfg(P3NtParams& p, int sk, hipStream_t st) {
 }
 
 static int launch_nt(P3NtParams& p, hipStream_t st) {
-    // tile configurations: 1 = 128x128, 8 waves, 3 stages (one block per CU); 2 = 128x64, 4 waves, 2 stages (two blocks per CU);
-    // 3 = 64x64, 4 waves, 3 stages (two blocks per CU); 4 = 128x128, 4 waves, 3 stages; 5 = 128x64, 4 waves, 3 stages
+    // tile configurations (LDS = 2 stages): 1 = 128x128, 8 waves (96 KiB: one block per CU); 2 = 128x64, 4 waves (72 KiB: two per CU);
+    // 3 = 64x64, 4 waves (48 KiB: three per CU); 4 = 128x128, 4 waves
     static const int force_tile = getenv("LDETR_P3_TILE") ? atoi(getenv("LDETR_P3_TILE")) : 0;
     static const int force_sk = getenv("LDETR_P3_SK") ? atoi(getenv("LDETR_P3_SK")) : 0;
     auto tiles = [&](int a, int b) { return (long)cdiv(p.M, a) * cdiv(p.N, b); };
@@ -685,12 +744,61 @@ static int launch_nt(P3NtParams& p, hipStream_t st) {
     if (nt < slots * 3 / 4) { sk = (int)(slots / nt); if (sk > p.nkt / 4) sk = p.nkt / 4; if (sk > 16) sk = 16; }
     if (force_sk > 0) sk = force_sk;
     switch (cfg) {
-        case 1: return launch_nt_cfg<128, 128, 8, 3>(p, sk, st);
-        case 2: return launch_nt_cfg<128, 64, 4, 2>(p, sk, st);
-        case 3: return launch_nt_cfg<64, 64, 4, 3>(p, sk, st);
-        case 4: return launch_nt_cfg<128, 128, 4, 3>(p, sk, st);
-        default: return launch_nt_cfg<128, 64, 4, 3>(p, sk, st);
+        case 1: return launch_nt_cfg<128, 128, 8>(p, sk, st);
+        case 2: return launch_nt_cfg<128, 64, 4>(p, sk, st);
+        case 3: return launch_nt_cfg<64, 64, 4>(p, sk, st);
+        default: return launch_nt_cfg<128, 128, 4>(p, sk, st);
     }
+}
+
+// Development probe: LDS-DMA throughput of one access shape.  Every wave of a 256-thread block walks `iters` k-steps along its own 64*16/SEG
+// rows (row pitch `pitch` bytes), fetching SEG contiguous bytes per row and step (SEG/16 lanes per row), PIECES instructions per step into a
+// 4-deep LDS ring (nothing reads the LDS: this measures the global -> LDS path alone).
+template <int SEG>
+__global__ __launch_bounds__(256) void p3_dma_probe_kernel(const char* src, unsigned bytes, int pitch, int iters, int pieces, int rows_total) {
+    extern __shared__ __attribute__((aligned(1024))) char p3_smem[];
+    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    constexpr int LPR = SEG / 16, RPI = 64 / LPR;   // lanes per row, rows per instruction
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(src), 0, bytes, 0x00020000);
+    const int row0 = (int)(((long)blockIdx.x * 4 + w) * RPI * pieces % rows_total);
+    for (int it = 0; it < iters; it++) {
+        const int koff = (it * SEG) % pitch;
+        for (int q = 0; q < pieces; q++) {
+            const int row = (row0 + q * RPI + lane / LPR) % rows_total;
+            const unsigned vo = (unsigned)row * (unsigned)pitch + (lane % LPR) * 16;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void*)(p3_smem + ((w * 4 + (it & 3)) * 8 + (q & 7)) * 1024), 16, vo, koff, 0, 0);
+        }
+        if (it >= 3) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");   // <= 3 steps x 8 pieces in flight (pieces <= 8)
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+// The same walk with register staging: buffer_load_dwordx4 into VGPRs, ds_write_b128 one step later (two register sets).
+template <int SEG, int PIECES>
+__global__ __launch_bounds__(256) void p3_reg_probe_kernel(const char* src, unsigned bytes, int pitch, int iters, int rows_total) {
+    extern __shared__ __attribute__((aligned(1024))) char p3_smem[];
+    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    constexpr int LPR = SEG / 16, RPI = 64 / LPR;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(src), 0, bytes, 0x00020000);
+    const int row0 = (int)(((long)blockIdx.x * 4 + w) * RPI * PIECES % rows_total);
+    unsigned vo[PIECES];
+#pragma unroll
+    for (int q = 0; q < PIECES; q++) vo[q] = (unsigned)((row0 + q * RPI + lane / LPR) % rows_total) * (unsigned)pitch + (lane % LPR) * 16;
+    u32x4 ra[PIECES], rb[PIECES];
+#pragma unroll
+    for (int q = 0; q < PIECES; q++) ra[q] = __builtin_amdgcn_raw_buffer_load_b128(rs, vo[q], 0, 0);
+    for (int it = 0; it < iters; it += 2) {
+        const int k1 = ((it + 1) * SEG) % pitch, k2 = ((it + 2) * SEG) % pitch;
+#pragma unroll
+        for (int q = 0; q < PIECES; q++) rb[q] = __builtin_amdgcn_raw_buffer_load_b128(rs, vo[q], k1, 0);
+#pragma unroll
+        for (int q = 0; q < PIECES; q++) *reinterpret_cast<u32x4*>(p3_smem + ((w * 2 + 0) * PIECES + q) * 1024 + lane * 16) = ra[q];
+#pragma unroll
+        for (int q = 0; q < PIECES; q++) ra[q] = __builtin_amdgcn_raw_buffer_load_b128(rs, vo[q], k2, 0);
+#pragma unroll
+        for (int q = 0; q < PIECES; q++) *reinterpret_cast<u32x4*>(p3_smem + ((w * 2 + 1) * PIECES + q) * 1024 + lane * 16) = rb[q];
+    }
+    if (ra[0][0] == 0x12345678u) p3_smem[0] = 1;
 }
 
 static void fill_epi(P3Epi& e, const ldetr_p3_epilogue* s) {
@@ -786,7 +894,7 @@ extern "C" int ldetr_p3_conv2d_bwd_data(const void* dy, int N, int OH, int OW, i
     return LDETR_OK;
 }
 
-template <int BM, int BN, int NST>
+template <int BM, int BN>
 static int launch_tn_cfg(P3TnParams& p, int target_blocks, hipStream_t st) {
     p.mtiles = cdiv(p.Cout, BM); p.ntiles = cdiv(p.Cin, BN);
     const long nt = (long)p.mtiles * p.ntiles * p.KH * p.KW;
@@ -797,8 +905,8 @@ static int launch_tn_cfg(P3TnParams& p, int target_blocks, hipStream_t st) {
     static const int force_sk = getenv("LDETR_P3_WSK") ? atoi(getenv("LDETR_P3_WSK")) : 0;
     if (force_sk > 0) sk = std::min(force_sk, nkt);
     p.splitk = sk;
-    constexpr size_t lds = (size_t)NST * (BM + BN) * 192;
-    auto kern = p3_tn_kernel<BM, BN, NST>;
+    constexpr size_t lds = (size_t)2 * (BM + BN) * 192;
+    auto kern = p3_tn_kernel<BM, BN>;
     static bool raised = false;
     if (lds > 64 * 1024 && !raised) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
@@ -833,10 +941,31 @@ extern "C" int ldetr_p3_conv2d_bwd_weight(const void* x, int N, int H, int W, in
     if (Cout % 128 != 0 || Cin % 64 != 0) cfg = 3;
     if (force_tile) cfg = force_tile;
     switch (cfg) {
-        case 1: return launch_tn_cfg<128, 128, 3>(p, 256, (hipStream_t)stream);
-        case 2: return launch_tn_cfg<128, 64, 3>(p, 256, (hipStream_t)stream);
-        default: return launch_tn_cfg<64, 64, 3>(p, 512, (hipStream_t)stream);
+        case 1: return launch_tn_cfg<128, 128>(p, 256, (hipStream_t)stream);
+        case 2: return launch_tn_cfg<128, 64>(p, 256, (hipStream_t)stream);
+        default: return launch_tn_cfg<64, 64>(p, 512, (hipStream_t)stream);
     }
+}
+
+extern "C" int ldetr_p3_dma_probe(const void* src, int64_t bytes, int seg, int pitch, int iters, int pieces, int blocks, void* stream) {
+    const int rows_total = (int)(bytes / pitch);
+    hipStream_t st = (hipStream_t)stream;
+    const size_t lds = 4 * 4 * 8 * 1024;
+#define P3_PROBE(S)                                                                                                           \
+    do {                                                                                                                      \
+        static bool raised = false;                                                                                           \
+        if (!raised) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&p3_dma_probe_kernel<S>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); raised = true; } \
+        hipLaunchKernelGGL((p3_dma_probe_kernel<S>), dim3(blocks), dim3(256), lds, st, (const char*)src, (unsigned)bytes, pitch, iters, pieces, rows_total); \
+    } while (0)
+    if (pieces < 0) {   // register-staged variant, 6 pieces
+        if (seg == 64) hipLaunchKernelGGL((p3_reg_probe_kernel<64, 6>), dim3(blocks), dim3(256), 64 * 1024, st, (const char*)src, (unsigned)bytes, pitch, iters, rows_total);
+        else hipLaunchKernelGGL((p3_reg_probe_kernel<256, 6>), dim3(blocks), dim3(256), 64 * 1024, st, (const char*)src, (unsigned)bytes, pitch, iters, rows_total);
+        return check_launch("p3_reg_probe");
+    }
+    if (seg == 64) P3_PROBE(64); else if (seg == 128) P3_PROBE(128); else if (seg == 256) P3_PROBE(256); else if (seg == 1024) P3_PROBE(1024);
+    else { set_error("p3_dma_probe: seg must be 64, 128, 256 or 1024"); return LDETR_ERR_ARG; }
+#undef P3_PROBE
+    return check_launch("p3_dma_probe");
 }
 
 extern "C" int ldetr_p3_probe(const void* g, int gbytes, void* out_tr, void* out_dma, void* stream) {

@@ -1,8 +1,13 @@
-import csv, glob, sys, collections
+"""Per-dispatch averages of rocprofv3 --pmc counters for kernels whose name contains a pattern: python tools/agg_pmc.py <dir or csv> [pattern]"""
+import csv, glob, os, sys, collections
 root = sys.argv[1]
+pat = sys.argv[2] if len(sys.argv) > 2 else 'gemm_f32_kernel'
+paths = [root] if os.path.isfile(root) else glob.glob(root + '/**/*counter_collection.csv', recursive=True)
 acc = collections.defaultdict(float); n = collections.Counter()
-for path in glob.glob(root + '/**/*counter_collection.csv', recursive=True):
+for path in paths:
     for r in csv.DictReader(open(path)):
-        if 'gemm_f32_kernel' not in r['Kernel_Name']: continue
-        acc[r['Counter_Name']] += float(r['Counter_Value']); n[r['Counter_Name']] += 1
-print(root, {k: round(v / n[k]) for k, v in sorted(acc.items())}, 'launches', max(n.values()) if n else 0)
+        if pat not in r['Kernel_Name']: continue
+        key = (r['Kernel_Name'].split('(')[0][-60:], r['Counter_Name'])
+        acc[key] += float(r['Counter_Value']); n[key] += 1
+for (kn, cn), v in sorted(acc.items()):
+    print(f'{kn:60s} {cn:28s} {v / n[(kn, cn)]:16.0f}  x{n[(kn, cn)]}')

@@ -49,6 +49,31 @@ def probe():
     print('dma (d) soffset = bytes-512, lanes >= 32 beyond the range if soffset is checked: lane 31', dma[2560+31*8:2560+31*8+2], 'lane 32', dma[2560+32*8:2560+32*8+2])
 
 
+def reg_probe():
+    for mb in (12, 96):
+        buf = torch.zeros(mb << 20, dtype=torch.uint8, device=dev)
+        for blocks in (256, 512, 1024):
+            for seg in (64, 256):
+                for pitch in (768, 3072):
+                    iters, pieces = 64, 6
+                    t = timeit(lambda: L.ldetr_p3_dma_probe(core.ptr(buf), buf.numel(), seg, pitch, iters, -1, blocks, core.stream()), n=5)
+                    byts = blocks * 4 * (iters + 1) * pieces * 1024
+                    print(f'reg probe buf {mb:3d} MiB blocks {blocks:4d} seg {seg:4d} pitch {pitch:5d}: {t*1e6:8.1f} us  {byts/t/1e12:6.2f} TB/s  {byts/t/256/1e9:6.1f} GB/s/CU', flush=True)
+
+
+def dma_probe():
+    for mb in (12, 96):
+        buf = torch.zeros(mb << 20, dtype=torch.uint8, device=dev)
+        for blocks in (256, 512, 1024):
+            for seg in (64, 128, 256, 1024):
+                for pitch in (768, 3072):
+                    if seg > pitch: continue
+                    iters, pieces = 64, 6
+                    t = timeit(lambda: L.ldetr_p3_dma_probe(core.ptr(buf), buf.numel(), seg, pitch, iters, pieces, blocks, core.stream()), n=5)
+                    byts = blocks * 4 * iters * pieces * 1024
+                    print(f'dma probe buf {mb:3d} MiB blocks {blocks:4d} seg {seg:4d} pitch {pitch:5d}: {t*1e6:8.1f} us  {byts/t/1e12:6.2f} TB/s  {byts/t/256/1e9:6.1f} GB/s/CU', flush=True)
+
+
 def conv_ref(x, w, stride, pad):
     return F.conv2d(x.permute(0, 3, 1, 2).double(), w.permute(0, 3, 1, 2).double(), stride=stride, padding=pad).permute(0, 2, 3, 1)
 
@@ -159,10 +184,14 @@ CASES = [('l1 1x1 64->64', 64, 64, 64, 1, 1, 0), ('l1 3x3 64->64', 64, 64, 64, 3
          ('l4 3x3 512->512 s2', 16, 512, 512, 3, 2, 1), ('l4 1x1 512->2048', 8, 512, 2048, 1, 1, 0), ('l4 1x1 2048->512', 8, 2048, 512, 1, 1, 0), ('l4 3x3 512->512', 8, 512, 512, 3, 1, 1),
          ('sg 3x3 512->512 @16', 16, 512, 512, 3, 1, 1), ('sg 3x3 128->128 @64', 64, 128, 128, 3, 1, 1)]
 
-if __name__ == '__main__':
+def main():
     what = sys.argv[1:] or ['probe', 'check', 'bench']
     if 'probe' in what:
         probe()
+    if 'dma' in what:
+        dma_probe()
+    if 'reg' in what:
+        reg_probe()
     if 'check' in what:
         check_case(1, 8, 32, 64, 1, 1, 0, False)
         check_case(2, 8, 64, 64, 3, 1, 1, False)
@@ -188,3 +217,7 @@ if __name__ == '__main__':
     if 'benchb' in what:
         for c in CASES:
             bench_bwd(c[0], B, *c[1:])
+
+
+if __name__ == '__main__':
+    main()
