@@ -25,11 +25,11 @@ HEADERS = ['ldetr_common.hpp', os.path.join('..', '..', 'include', 'ldetr_hip.h'
 
 # the per-block tracer of the tiled kernel (tools/trace_tiles.py) is a development build: LDETR_TILE_TRACE=1 python -m layoutdetr_amd.build --force
 # (the production kernel carries explicit sched_barrier(0) fences where the tracer's stamps used to sit)
-FLAGS = ([] if os.environ.get('LDETR_TILE_TRACE') else ['-DLDETR_TILE_TRACE=0']) + ['-O3', '-std=c++17', '-fPIC', f'--offload-arch={ARCH}', '-munsafe-fp-atomics', '-fno-gpu-rdc',
+FLAGS = ([] if os.environ.get('LDETR_TILE_TRACE') else ['-DLDETR_TILE_TRACE=0']) + (['-DP3_TRACE'] if os.environ.get('LDETR_P3_TRACE') else []) + ['-O3', '-std=c++17', '-fPIC', f'--offload-arch={ARCH}', '-munsafe-fp-atomics', '-fno-gpu-rdc',
          '-Wno-unused-result', '-Rpass-analysis=kernel-resource-usage']
 # kernels whose register budget is the design: any scratch (spill / stack object) is a build error, not a silent 10x slowdown
 # (an erf in the engine's epilogue once cost 320 bytes of scratch per lane and every 128x128 GEMM ran 14x slower)
-NO_SCRATCH = ('wgrad_c32_3x3_kernel', 'gemm_f32_kernel', 'gemm_small_kernel', 'attn_fwd_kernel', 'attn_fwd_wide_kernel', 'attn_bwd_kernel', 'ffn_fwd_kernel', 'ffn_bwd_kernel', 'conv3x3_c32_kernel', 'mha_small_fwd_kernel', 'mha_cross_fwd_kernel', 'p3_nt_kernel')
+NO_SCRATCH = ('wgrad_c32_3x3_kernel', 'gemm_f32_kernel', 'gemm_small_kernel', 'attn_fwd_kernel', 'attn_fwd_wide_kernel', 'attn_bwd_kernel', 'ffn_fwd_kernel', 'ffn_bwd_kernel', 'conv3x3_c32_kernel', 'mha_small_fwd_kernel', 'mha_cross_fwd_kernel', 'p3_nt_kernel', 'p3_tn_kernel', 'p3_c3_kernel')
 
 
 def _hipcc():

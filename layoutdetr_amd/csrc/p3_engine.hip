@@ -68,6 +68,132 @@ __device__ __forceinline__ int xcd_remap(int b, int n) {
     return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
 }
 
+// Epilogue of one wave: its WM x WN accumulator tile goes through the wave's own LDS region (Cs, row pitch WN + 4 floats) and comes back as
+// 8-channel groups per lane: scale / shift, residual (P3 or fp32), ReLU, ReLU-gradient mask from a P3 tensor's hi plane, P3 and / or fp32 stores.
+// rowmap(rl) -> output row (pixel index of the stored tensor) of local row rl of this wave's tile, or -1.
+template <int WM, int WN, int TM, int TN, typename RowMap>
+__device__ __forceinline__ void p3_wave_epilogue(const P3Epi& ep, float* Cs, const f32x16 (&acc)[TM][TN], int lane, int nbase, int N, RowMap rowmap) {
+    constexpr int CP = WN + 4;
+    const int cl = lane & 31, kl = lane >> 5;
+#pragma unroll
+    for (int i = 0; i < TM; i++)
+#pragma unroll
+        for (int j = 0; j < TN; j++)
+#pragma unroll
+            for (int r = 0; r < 16; r++)
+                Cs[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kl) * CP + j * 32 + cl] = acc[i][j][r];
+    // (each wave reads back its own region only: LDS operations of one wave execute in order, no barrier)
+    constexpr int CH = WN / 8;                            // 8-channel groups per row of the wave tile
+    constexpr int RPI = 64 / CH;                          // rows per iteration
+    const int ch = lane % CH, rl0 = lane / CH;
+    const int n = nbase + ch * 8;
+    float cs[8], cb[8];
+#pragma unroll
+    for (int e = 0; e < 8; e++) { cs[e] = ep.alpha; cb[e] = 0.f; }
+    if (n < N) {
+        if (ep.col_scale) {
+            const float4 s0 = *reinterpret_cast<const float4*>(ep.col_scale + n), s1 = *reinterpret_cast<const float4*>(ep.col_scale + n + 4);
+            cs[0] *= s0.x; cs[1] *= s0.y; cs[2] *= s0.z; cs[3] *= s0.w; cs[4] *= s1.x; cs[5] *= s1.y; cs[6] *= s1.z; cs[7] *= s1.w;
+        }
+        if (ep.col_bias) {
+            const float4 s0 = *reinterpret_cast<const float4*>(ep.col_bias + n), s1 = *reinterpret_cast<const float4*>(ep.col_bias + n + 4);
+            cb[0] = s0.x; cb[1] = s0.y; cb[2] = s0.z; cb[3] = s0.w; cb[4] = s1.x; cb[5] = s1.y; cb[6] = s1.z; cb[7] = s1.w;
+        }
+    }
+#pragma unroll 2
+    for (int it = 0; it < WM / RPI; it++) {
+        const int rl = it * RPI + rl0;
+        const long orow = rowmap(rl);
+        if (orow < 0 || n >= N) continue;
+        const float4 v0 = *reinterpret_cast<const float4*>(Cs + rl * CP + ch * 8), v1 = *reinterpret_cast<const float4*>(Cs + rl * CP + ch * 8 + 4);
+        float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+#pragma unroll
+        for (int e = 0; e < 8; e++) v[e] = v[e] * cs[e] + cb[e];
+        const long goff = (orow * N + n) * 6;             // byte offset of this 8-channel group in a P3 [rows][N] tensor
+        if (ep.res_p3) {
+            const u32x4 h = *reinterpret_cast<const u32x4*>(ep.res_p3 + goff), md = *reinterpret_cast<const u32x4*>(ep.res_p3 + goff + 16),
+                        lo = *reinterpret_cast<const u32x4*>(ep.res_p3 + goff + 32);
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                v[2 * e] += (bf_lo(h[e]) + bf_lo(md[e])) + bf_lo(lo[e]);
+                v[2 * e + 1] += (bf_hi(h[e]) + bf_hi(md[e])) + bf_hi(lo[e]);
+            }
+        }
+        if (ep.res_f32) {
+            const float4 r0 = *reinterpret_cast<const float4*>(ep.res_f32 + orow * N + n), r1 = *reinterpret_cast<const float4*>(ep.res_f32 + orow * N + n + 4);
+            v[0] += r0.x; v[1] += r0.y; v[2] += r0.z; v[3] += r0.w; v[4] += r1.x; v[5] += r1.y; v[6] += r1.z; v[7] += r1.w;
+        }
+        if (ep.relu) {
+#pragma unroll
+            for (int e = 0; e < 8; e++) v[e] = fmaxf(v[e], 0.f);
+        }
+        if (ep.mask_p3) {
+            const u32x4 h = *reinterpret_cast<const u32x4*>(ep.mask_p3 + goff);
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                if ((int)(h[e] << 16) <= 0) v[2 * e] = 0.f;
+                if ((int)(h[e] & 0xffff0000u) <= 0) v[2 * e + 1] = 0.f;
+            }
+        }
+        if (ep.out_f32) {
+            *reinterpret_cast<float4*>(ep.out_f32 + orow * N + n) = make_float4(v[0], v[1], v[2], v[3]);
+            *reinterpret_cast<float4*>(ep.out_f32 + orow * N + n + 4) = make_float4(v[4], v[5], v[6], v[7]);
+        }
+        if (ep.out_p3) {
+            u32x4 h, md, lo;
+#pragma unroll
+            for (int e = 0; e < 4; e++) { unsigned a, b, c; split2_bf16(v[2 * e], v[2 * e + 1], a, b, c); h[e] = a; md[e] = b; lo[e] = c; }
+            *reinterpret_cast<u32x4*>(ep.out_p3 + goff) = h;
+            *reinterpret_cast<u32x4*>(ep.out_p3 + goff + 16) = md;
+            *reinterpret_cast<u32x4*>(ep.out_p3 + goff + 32) = lo;
+        }
+    }
+}
+
+// Split-K hand-off shared by the contraction kernels: every slice parks its raw accumulators in the workspace (register order: coalesced,
+// agent-scope stores), the slice that arrives last at the tile's counter sums all slices in slice order (deterministic) and returns true.
+template <int TM, int TN, int NT>
+__device__ __forceinline__ bool p3_splitk_reduce(f32x16 (&acc)[TM][TN], float* ws, int* ws_count, long tile, int ks, int splitk, int tile_elems, int tid, int* flag) {
+    float* slot0 = ws + tile * splitk * (long)tile_elems;
+    float* mine = slot0 + (long)ks * tile_elems;
+#pragma unroll
+    for (int i = 0; i < TM; i++)
+#pragma unroll
+        for (int j = 0; j < TN; j++)
+#pragma unroll
+            for (int r = 0; r < 16; r++)
+                __hip_atomic_store(mine + ((i * TN + j) * 16 + r) * NT + tid, acc[i][j][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+        const int old = atomicAdd(ws_count + tile, 1);
+        const int last = old == splitk - 1;
+        if (last) __hip_atomic_store(ws_count + tile, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        *flag = last;
+    }
+    __syncthreads();
+    const int last = *flag;
+    __syncthreads();   // the flag word is part of the epilogue's staging area
+    if (!last) return false;
+#pragma unroll
+    for (int i = 0; i < TM; i++)
+#pragma unroll
+        for (int j = 0; j < TN; j++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+    for (int sl = 0; sl < splitk; sl++) {
+        const float* src = slot0 + (long)sl * tile_elems;
+#pragma unroll
+        for (int i = 0; i < TM; i++)
+#pragma unroll
+            for (int j = 0; j < TN; j++)
+#pragma unroll
+                for (int r = 0; r < 16; r++)
+                    acc[i][j][r] += __hip_atomic_load(src + ((i * TN + j) * 16 + r) * NT + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    return true;
+}
+
 // One k-tile of this wave's operand rows, global -> registers: its 16-row groups of A (gathered pixels) and B (weight rows), three
 // 16-byte pieces per lane and group (piece = (lane % 4) ^ swizzle of its 64-byte instruction slice).  Register staging, not LDS-DMA:
 // measured on MI355X (tools/p3_dev.py dma / reg, profiles/r04_p3_staging_probe.txt) `buffer_load ... lds` tops out at 42-55 GB/s per CU
@@ -245,132 +371,210 @@ __global__ __launch_bounds__(NW * 64) void p3_nt_kernel(P3NtParams p) {
         __syncthreads();
     }
 
-    // ---- split-K: park the raw tile (register order: coalesced), the last arriver sums the slices in slice order
-    if (p.splitk > 1) {
-        float* slot0 = p.ws + (long)t * p.splitk * (BM * BN);
-        float* mine = slot0 + (long)ks * (BM * BN);
+    // ---- split-K, then the epilogue (the k-loop ended on a barrier)
+    if (p.splitk > 1 && !p3_splitk_reduce<TM, TN, NT>(acc, p.ws, p.ws_count, t, ks, p.splitk, BM * BN, tid, reinterpret_cast<int*>(p3_smem))) return;
+    constexpr int CP = WN + 4;
+    static_assert(NW * WM * CP * 4 <= NST * ST_BYTES, "epilogue staging does not fit");
+    const int ohw = p.OH * p.OW;
+    p3_wave_epilogue<WM, WN, TM, TN>(p.ep, reinterpret_cast<float*>(p3_smem) + w * (WM * CP), acc, lane, n0 + wn * WN, p.N, [&](int rl) -> long {
+        const int m = m0 + wm * WM + rl;
+        if (m >= p.M) return -1;
+        if (p.out_step == 1 && p.out_H == p.OH && p.out_W == p.OW) return m;
+        const int nn = m / ohw, rem = m - nn * ohw, oy = rem / p.OW, ox = rem - oy * p.OW;
+        return ((long)nn * p.out_H + (oy * p.out_step + p.out_py)) * p.out_W + (ox * p.out_step + p.out_px);
+    });
+}
+
+// ---------------------------------------------------------------------------------------------
+// p3_c3_kernel: 3x3 / stride 1 / pad 1 convolutions (forward, and the data gradient as the same conv with mirrored taps) on 2-D pixel
+// patches.  What bounds the gather kernel above is the CU's global-load path (~50 GB/s per CU of L1 misses, whatever the access shape:
+// profiles/r04_p3_staging_probe.txt), and a per-tap gather fetches every input pixel nine times.  Here a block's 128 output pixels are
+// 8 x 16 patches (16 x 8 / two 8 x 8 images / ... for narrower images), the (PH+2) x (PW+2) halo of the current 32-channel slice is loaded
+// ONCE into LDS (out-of-image pixels = out-of-range offsets = zeros) and all nine taps read their A fragments from it at shifted
+// addresses; only the 64 x 32 weight tile of a tap streams per k-step.  Bytes per MFMA drop 2.3x (36 KiB + 9 x 12 KiB per channel slice
+// instead of 9 x 36 KiB).  The next slice's halo is prefetched into registers across the nine taps and written between two barriers.
+// 4 waves (2 x 2), wave tile 64 pixels x 32 channels; LDS: halo 39 KiB + 3 weight stages x 12 KiB = 75 KiB -> two blocks per CU.
+struct P3C3Params {
+    const char* X; const char* Wt;
+    unsigned x_bytes, w_bytes;
+    int N_img, H, W, Cin, Nout;
+    int lgPW, lgPH, NP;          // patch width / height (powers of two), patches per 128-row tile
+    int HWp, HPIX, NH, NG;       // halo row width, halo pixels per patch, halo pixels per tile, 16-pixel groups per tile (<= 13)
+    int ppr, ppi;                // patches per image row, per image
+    int flip;                    // data gradient: tap (ty, tx) reads the halo at (2 - ty, 2 - tx)
+    int ncc;                     // 32-channel slices
+    int splitk; float* ws; int* ws_count;
+    int mtiles, ntiles;
+    P3Epi ep;
+};
+
+constexpr int C3_NGMAX = 13, C3_A_BYTES = C3_NGMAX * 3072, C3_B_BYTES = 4 * 3072, C3_LDS = C3_A_BYTES + 3 * C3_B_BYTES;
+
+__device__ __forceinline__ void p3_c3_decode_tile_row(const P3C3Params& p, int tm, int r, int& n, int& y0, int& x0, int& py, int& px) {
+    const int lgpp = p.lgPW + p.lgPH;
+    const int sp = r >> lgpp, q = r & ((1 << lgpp) - 1);
+    py = q >> p.lgPW; px = q & ((1 << p.lgPW) - 1);
+    const int pid = tm * p.NP + sp;
+    n = pid / p.ppi; const int prem = pid - n * p.ppi;
+    const int pr = prem / p.ppr, pc = prem - pr * p.ppr;
+    y0 = pr << p.lgPH; x0 = pc << p.lgPW;
+}
+
+template <int TAP>
+__device__ __forceinline__ void p3_c3_tap(const P3C3Params& p, const __amdgpu_buffer_rsrc_t rsA, const __amdgpu_buffer_rsrc_t rsB, char* smem, int w, int lane,
+                                          const unsigned (&offA)[4], unsigned offB, int cc, bool more_cc, bool more_tile,
+                                          ld128_t (&ar)[12], ld128_t (&br)[3], const unsigned (&h0)[2], const unsigned (&ce)[2][3], const unsigned (&fo)[2][3],
+                                          unsigned foB, f32x16 (&acc)[2][1]) {
+    // ---- global loads first: the next weight tile (tap + 1, or tap 0 of the next slice), and this tap's share of the next halo
+    if (more_tile) {
+        const int ntap = TAP == 8 ? 0 : TAP + 1, ncc = TAP == 8 ? cc + 1 : cc;
+        const int sB = ntap * p.Cin * 6 + ncc * 192;
 #pragma unroll
-        for (int i = 0; i < TM; i++)
+        for (int j = 0; j < 3; j++) br[j] = __builtin_amdgcn_raw_buffer_load_b128(rsB, offB, sB + j * 64, 0);
+    }
+    if (more_cc) {
 #pragma unroll
-            for (int j = 0; j < TN; j++)
+        for (int q = TAP * 12 / 9; q < (TAP + 1) * 12 / 9; q++)
+            ar[q] = __builtin_amdgcn_raw_buffer_load_b128(rsA, offA[q / 3], (cc + 1) * 192 + (q % 3) * 64, 0);
+    }
+    // ---- this tap's MFMAs: A fragments from the halo at the tap's shift, B fragments from stage TAP % 3
+    constexpr int ty = TAP / 3, tx = TAP % 3;
+    const int dt = p.flip ? (2 - ty) * p.HWp + (2 - tx) : ty * p.HWp + tx;
+    unsigned hb[2], sw[2];
 #pragma unroll
-                for (int r = 0; r < 16; r++)
-                    __hip_atomic_store(mine + ((i * TN + j) * 16 + r) * NT + tid, acc[i][j][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        int* flag = reinterpret_cast<int*>(p3_smem);
-        if (tid == 0) {
-            const int old = atomicAdd(p.ws_count + t, 1);
-            const int last = old == p.splitk - 1;
-            if (last) __hip_atomic_store(p.ws_count + t, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            *flag = last;
+    for (int i = 0; i < 2; i++) {
+        const unsigned h = h0[i] + dt;
+        hb[i] = (h >> 4) * 3072 + ((h & 15) << 6);
+        sw[i] = ((h >> 2) & 3) << 4;
+    }
+    const char* sb = smem + C3_A_BYTES + (TAP % 3) * C3_B_BYTES + foB;
+#pragma unroll
+    for (int s2 = 0; s2 < 2; s2++) {
+        bf16x8_t a[2][3], b[3];
+#pragma unroll
+        for (int i = 0; i < 2; i++)
+#pragma unroll
+            for (int pl = 0; pl < 3; pl++) a[i][pl] = *reinterpret_cast<const bf16x8_t*>(smem + hb[i] + (ce[s2][pl] ^ sw[i]));
+#pragma unroll
+        for (int pl = 0; pl < 3; pl++) b[pl] = *reinterpret_cast<const bf16x8_t*>(sb + fo[s2][pl]);
+#pragma unroll
+        for (int i = 0; i < 2; i++) {   // smallest terms first
+            acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[1], acc[i][0], 0, 0, 0);
+            acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[2], acc[i][0], 0, 0, 0);
+            acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][2], b[0], acc[i][0], 0, 0, 0);
+            acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[1], acc[i][0], 0, 0, 0);
+            acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[0], acc[i][0], 0, 0, 0);
+            acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[0], acc[i][0], 0, 0, 0);
         }
-        __syncthreads();
-        const int last = *flag;
-        __syncthreads();   // the flag word is part of the epilogue's staging area
-        if (!last) return;
+    }
+    // ---- the next weight tile goes to its stage; one barrier per tap
+    if (more_tile) {
+        char* dst = smem + C3_A_BYTES + ((TAP + 1) % 3) * C3_B_BYTES + w * 3072 + lane * 16;
 #pragma unroll
-        for (int i = 0; i < TM; i++)
+        for (int j = 0; j < 3; j++) *reinterpret_cast<ld128_t*>(dst + j * 1024) = br[j];
+    }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(256, 2) void p3_c3_kernel(P3C3Params p) {
+    constexpr int BM = 128, BN = 64, NT = 256, WM = 64, WN = 32;
+    extern __shared__ __attribute__((aligned(1024))) char p3_smem[];
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), wm = w >> 1, wn = w & 1;
+    const int cl = lane & 31, kl = lane >> 5;
+    const int ntl = p.mtiles * p.ntiles;
+    const int t = xcd_remap(blockIdx.x, ntl);
+    const int tm = t / p.ntiles, tn = t - tm * p.ntiles;
+    const int n0 = tn * BN;
+    const int ks = blockIdx.y;
+    const int per = (p.ncc + p.splitk - 1) / p.splitk;
+    const int cc0 = ks * per, cc1 = min(p.ncc, cc0 + per);
+
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.X), 0, p.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.Wt), 0, p.w_bytes, 0x00020000);
+
+    // ---- loader rows: halo groups w, w + 4, w + 8, w + 12 (16 pixels each) and weight group w
+    const int rr = lane >> 2, pq = (lane & 3) ^ ((rr >> 2) & 3);
+    unsigned offA[4], offB;
 #pragma unroll
-            for (int j = 0; j < TN; j++)
+    for (int i = 0; i < 4; i++) {
+        const int h = (w + 4 * i) * 16 + rr;
+        unsigned off = 0x80000000u;
+        if (h < p.NH) {
+            const int sp = h / p.HPIX, rem = h - sp * p.HPIX, hy = rem / p.HWp, hx = rem - hy * p.HWp;
+            const int pid = tm * p.NP + sp;
+            const int n = pid / p.ppi, prem = pid - n * p.ppi, pr = prem / p.ppr, pc = prem - pr * p.ppr;
+            const int y = (pr << p.lgPH) + hy - 1, x = (pc << p.lgPW) + hx - 1;
+            if (n < p.N_img && y >= 0 && y < p.H && x >= 0 && x < p.W) off = (unsigned)(((n * p.H + y) * p.W + x) * p.Cin) * 6u + pq * 16;
+        }
+        offA[i] = off;
+    }
+    {
+        const int n = n0 + w * 16 + rr;
+        offB = n < p.Nout ? (unsigned)n * (unsigned)(9 * p.Cin) * 6u + pq * 16 : 0x80000000u;
+    }
+    // ---- fragment addressing
+    unsigned h0[2];
 #pragma unroll
-                for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
-        for (int sl = 0; sl < p.splitk; sl++) {
-            const float* src = slot0 + (long)sl * (BM * BN);
+    for (int i = 0; i < 2; i++) {
+        const int r = wm * WM + i * 32 + cl;
+        const int lgpp = p.lgPW + p.lgPH;
+        const int sp = r >> lgpp, q = r & ((1 << lgpp) - 1);
+        h0[i] = (unsigned)(sp * p.HPIX + (q >> p.lgPW) * p.HWp + (q & ((1 << p.lgPW) - 1)));
+    }
+    const int frr = cl & 15, frg = cl >> 4;
+    unsigned ce[2][3], fo[2][3];
 #pragma unroll
-            for (int i = 0; i < TM; i++)
+    for (int s2 = 0; s2 < 2; s2++)
 #pragma unroll
-                for (int j = 0; j < TN; j++)
+        for (int pl = 0; pl < 3; pl++) {
+            const int e = 3 * (2 * s2 + kl) + pl;
+            ce[s2][pl] = (unsigned)(((e >> 2) * 1024) | ((e & 3) << 4));
+            fo[s2][pl] = (unsigned)((frg * 3 + (e >> 2)) * 1024 + frr * 64 + (((e & 3) ^ ((frr >> 2) & 3)) << 4));
+        }
+    const unsigned foB = (unsigned)(wn * 2 * 3072);
+
+    f32x16 acc[2][1];
 #pragma unroll
-                    for (int r = 0; r < 16; r++)
-                        acc[i][j][r] += __hip_atomic_load(src + ((i * TN + j) * 16 + r) * NT + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[i][0][r] = 0.f;
+
+    ld128_t ar[12], br[3];
+    if (cc1 > cc0) {
+        // first halo and first weight tile
+#pragma unroll
+        for (int q = 0; q < 12; q++) ar[q] = __builtin_amdgcn_raw_buffer_load_b128(rsA, offA[q / 3], cc0 * 192 + (q % 3) * 64, 0);
+#pragma unroll
+        for (int j = 0; j < 3; j++) br[j] = __builtin_amdgcn_raw_buffer_load_b128(rsB, offB, cc0 * 192 + j * 64, 0);
+#pragma unroll
+        for (int q = 0; q < 12; q++)
+            if (w + 4 * (q / 3) < C3_NGMAX) *reinterpret_cast<ld128_t*>(p3_smem + ((w + 4 * (q / 3)) * 3 + (q % 3)) * 1024 + lane * 16) = ar[q];
+#pragma unroll
+        for (int j = 0; j < 3; j++) *reinterpret_cast<ld128_t*>(p3_smem + C3_A_BYTES + w * 3072 + j * 1024 + lane * 16) = br[j];
+    }
+    __syncthreads();
+    for (int cc = cc0; cc < cc1; cc++) {
+        const bool more_cc = cc + 1 < cc1;
+#define C3_TAP(T_) p3_c3_tap<T_>(p, rsA, rsB, p3_smem, w, lane, offA, offB, cc, more_cc, (T_) < 8 || more_cc, ar, br, h0, ce, fo, foB, acc)
+        C3_TAP(0); C3_TAP(1); C3_TAP(2); C3_TAP(3); C3_TAP(4); C3_TAP(5); C3_TAP(6); C3_TAP(7); C3_TAP(8);
+#undef C3_TAP
+        if (more_cc) {   // every wave passed tap 8's barrier: the halo can be replaced
+#pragma unroll
+            for (int q = 0; q < 12; q++)
+                if (w + 4 * (q / 3) < C3_NGMAX) *reinterpret_cast<ld128_t*>(p3_smem + ((w + 4 * (q / 3)) * 3 + (q % 3)) * 1024 + lane * 16) = ar[q];
+            __syncthreads();
         }
     }
 
-    // ---- epilogue: wave tile (WM x WN) through LDS, then 8-channel groups per lane (the k-loop ended on a barrier)
+    if (p.splitk > 1 && !p3_splitk_reduce<2, 1, NT>(acc, p.ws, p.ws_count, t, ks, p.splitk, BM * BN, tid, reinterpret_cast<int*>(p3_smem))) return;
     constexpr int CP = WN + 4;
-    static_assert(NW * WM * CP * 4 <= NST * ST_BYTES, "epilogue staging does not fit");
-    float* Cs = reinterpret_cast<float*>(p3_smem) + w * (WM * CP);
-#pragma unroll
-    for (int i = 0; i < TM; i++)
-#pragma unroll
-        for (int j = 0; j < TN; j++)
-#pragma unroll
-            for (int r = 0; r < 16; r++)
-                Cs[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kl) * CP + j * 32 + cl] = acc[i][j][r];
-    // (each wave reads back its own region only: LDS operations of one wave execute in order, no barrier)
-    const P3Epi& ep = p.ep;
-    constexpr int CH = WN / 8;                            // 8-channel groups per row of the wave tile
-    constexpr int RPI = 64 / CH;                          // rows per iteration
-    const int ch = lane % CH, rl0 = lane / CH;
-    const int n = n0 + wn * WN + ch * 8;
-    float cs[8], cb[8];
-#pragma unroll
-    for (int e = 0; e < 8; e++) { cs[e] = p.ep.alpha; cb[e] = 0.f; }
-    if (n < p.N) {
-        if (ep.col_scale) {
-            const float4 s0 = *reinterpret_cast<const float4*>(ep.col_scale + n), s1 = *reinterpret_cast<const float4*>(ep.col_scale + n + 4);
-            cs[0] *= s0.x; cs[1] *= s0.y; cs[2] *= s0.z; cs[3] *= s0.w; cs[4] *= s1.x; cs[5] *= s1.y; cs[6] *= s1.z; cs[7] *= s1.w;
-        }
-        if (ep.col_bias) {
-            const float4 s0 = *reinterpret_cast<const float4*>(ep.col_bias + n), s1 = *reinterpret_cast<const float4*>(ep.col_bias + n + 4);
-            cb[0] = s0.x; cb[1] = s0.y; cb[2] = s0.z; cb[3] = s0.w; cb[4] = s1.x; cb[5] = s1.y; cb[6] = s1.z; cb[7] = s1.w;
-        }
-    }
-    const int ohw = p.OH * p.OW;
-#pragma unroll 2
-    for (int it = 0; it < WM / RPI; it++) {
-        const int rl = it * RPI + rl0;
-        const int m = m0 + wm * WM + rl;
-        if (m >= p.M || n >= p.N) continue;
-        long orow = m;
-        if (p.out_step != 1 || p.out_H != p.OH || p.out_W != p.OW) {
-            const int nn = m / ohw, rem = m - nn * ohw, oy = rem / p.OW, ox = rem - oy * p.OW;
-            orow = ((long)nn * p.out_H + (oy * p.out_step + p.out_py)) * p.out_W + (ox * p.out_step + p.out_px);
-        }
-        const float4 v0 = *reinterpret_cast<const float4*>(Cs + rl * CP + ch * 8), v1 = *reinterpret_cast<const float4*>(Cs + rl * CP + ch * 8 + 4);
-        float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
-#pragma unroll
-        for (int e = 0; e < 8; e++) v[e] = v[e] * cs[e] + cb[e];
-        const long goff = (orow * p.N + n) * 6;           // byte offset of this 8-channel group in a P3 [rows][N] tensor
-        if (ep.res_p3) {
-            const u32x4 h = *reinterpret_cast<const u32x4*>(ep.res_p3 + goff), md = *reinterpret_cast<const u32x4*>(ep.res_p3 + goff + 16),
-                        lo = *reinterpret_cast<const u32x4*>(ep.res_p3 + goff + 32);
-#pragma unroll
-            for (int e = 0; e < 4; e++) {
-                v[2 * e] += (bf_lo(h[e]) + bf_lo(md[e])) + bf_lo(lo[e]);
-                v[2 * e + 1] += (bf_hi(h[e]) + bf_hi(md[e])) + bf_hi(lo[e]);
-            }
-        }
-        if (ep.res_f32) {
-            const float4 r0 = *reinterpret_cast<const float4*>(ep.res_f32 + orow * p.N + n), r1 = *reinterpret_cast<const float4*>(ep.res_f32 + orow * p.N + n + 4);
-            v[0] += r0.x; v[1] += r0.y; v[2] += r0.z; v[3] += r0.w; v[4] += r1.x; v[5] += r1.y; v[6] += r1.z; v[7] += r1.w;
-        }
-        if (ep.relu) {
-#pragma unroll
-            for (int e = 0; e < 8; e++) v[e] = fmaxf(v[e], 0.f);
-        }
-        if (ep.mask_p3) {
-            const u32x4 h = *reinterpret_cast<const u32x4*>(ep.mask_p3 + goff);
-#pragma unroll
-            for (int e = 0; e < 4; e++) {
-                if ((int)(h[e] << 16) <= 0) v[2 * e] = 0.f;
-                if ((int)(h[e] & 0xffff0000u) <= 0) v[2 * e + 1] = 0.f;
-            }
-        }
-        if (ep.out_f32) {
-            *reinterpret_cast<float4*>(ep.out_f32 + orow * p.N + n) = make_float4(v[0], v[1], v[2], v[3]);
-            *reinterpret_cast<float4*>(ep.out_f32 + orow * p.N + n + 4) = make_float4(v[4], v[5], v[6], v[7]);
-        }
-        if (ep.out_p3) {
-            u32x4 h, md, lo;
-#pragma unroll
-            for (int e = 0; e < 4; e++) { unsigned a, b, c; split2_bf16(v[2 * e], v[2 * e + 1], a, b, c); h[e] = a; md[e] = b; lo[e] = c; }
-            *reinterpret_cast<u32x4*>(ep.out_p3 + goff) = h;
-            *reinterpret_cast<u32x4*>(ep.out_p3 + goff + 16) = md;
-            *reinterpret_cast<u32x4*>(ep.out_p3 + goff + 32) = lo;
-        }
-    }
+    static_assert(4 * WM * CP * 4 <= C3_LDS, "epilogue staging does not fit");
+    p3_wave_epilogue<WM, WN, 2, 1>(p.ep, reinterpret_cast<float*>(p3_smem) + w * (WM * CP), acc, lane, n0 + wn * WN, p.Nout, [&](int rl) -> long {
+        int n, y0, x0, py, px;
+        p3_c3_decode_tile_row(p, tm, wm * WM + rl, n, y0, x0, py, px);
+        if (n >= p.N_img) return -1;
+        return ((long)n * p.H + (y0 + py)) * p.W + (x0 + px);
+    });
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -801,6 +1005,50 @@ __global__ __launch_bounds__(256) void p3_reg_probe_kernel(const char* src, unsi
     if (ra[0][0] == 0x12345678u) p3_smem[0] = 1;
 }
 
+// 3x3 / stride 1 / pad 1 on pixel patches: returns false when the geometry does not fit (the caller then takes the gather kernel).
+static bool c3_geometry(int N, int H, int W, P3C3Params& p) {
+    auto lg = [](int v) { int l = 0; while ((1 << l) < v) ++l; return (1 << l) == v ? l : -1; };
+    int PW = W < 16 ? W : 16;
+    if (lg(PW) < 0 || W % PW) return false;
+    int PH = 128 / PW; if (PH > H) PH = H;
+    while (PH > 1 && (H % PH || lg(PH) < 0)) PH >>= 1;
+    if (lg(PH) < 0 || H % PH || 128 % (PW * PH)) return false;
+    p.lgPW = lg(PW); p.lgPH = lg(PH); p.NP = 128 / (PW * PH);
+    p.HWp = PW + 2; p.HPIX = (PH + 2) * (PW + 2); p.NH = p.NP * p.HPIX; p.NG = (p.NH + 15) / 16;
+    if (p.NG > C3_NGMAX) return false;
+    p.ppr = W / PW; p.ppi = (H / PH) * (W / PW);
+    p.N_img = N; p.H = H; p.W = W;
+    p.mtiles = (int)(((long)N * p.ppi + p.NP - 1) / p.NP);
+    return true;
+}
+
+static int launch_c3(P3C3Params& p, hipStream_t st) {
+    p.ntiles = cdiv(p.Nout, 64);
+    const long nt = (long)p.mtiles * p.ntiles;
+    int sk = 1;
+    static const int force_sk = getenv("LDETR_P3_SK") ? atoi(getenv("LDETR_P3_SK")) : 0;
+    if (nt < 384) { sk = (int)(512 / nt); if (sk > p.ncc / 2) sk = p.ncc / 2; if (sk > 16) sk = 16; if (sk < 1) sk = 1; }
+    if (force_sk > 0) sk = force_sk;
+    if (sk > p.ncc) sk = p.ncc;
+    p.splitk = sk; p.ws = nullptr; p.ws_count = nullptr;
+    if (sk > 1 && !splitk_ws_alloc(nt, (size_t)nt * sk * 128 * 64 * sizeof(float), &p.ws, &p.ws_count)) p.splitk = sk = 1;
+    static bool raised = false;
+    if (!raised) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&p3_c3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, C3_LDS) != hipSuccess) {
+            set_error("p3_c3: cannot raise the dynamic LDS limit to %d bytes", C3_LDS);
+            return LDETR_ERR_LAUNCH;
+        }
+        raised = true;
+    }
+    hipLaunchKernelGGL(p3_c3_kernel, dim3((unsigned)nt, sk, 1), 256, C3_LDS, st, p);
+    return check_launch("p3_c3");
+}
+
+static bool c3_enabled() {
+    static const int on = getenv("LDETR_P3_PATCH") ? atoi(getenv("LDETR_P3_PATCH")) : 1;
+    return on != 0;
+}
+
 static void fill_epi(P3Epi& e, const ldetr_p3_epilogue* s) {
     memset(&e, 0, sizeof(e));
     e.alpha = 1.f;
@@ -853,6 +1101,15 @@ extern "C" int ldetr_p3_conv2d_fwd(const void* x, int N, int H, int W, int Cin, 
                 "p3_conv2d_fwd: unsupported geometry (Cin=%d Cout=%d k=%dx%d stride=%d pad=%d)", Cin, Cout, KH, KW, stride, pad);
     const long xbytes = (long)N * H * W * Cin * 6, wbytes = (long)Cout * KH * KW * Cin * 6, pad_off = ((long)pad * W + pad) * Cin * 6;
     LDETR_CHECK(xbytes + pad_off < 0x7fffffffL && wbytes < 0x7fffffffL && (long)N * OH * OW * Cout * 6 < (1L << 40), "p3_conv2d_fwd: tensor too large for 31-bit buffer offsets");
+    if (KH == 3 && KW == 3 && stride == 1 && pad == 1 && c3_enabled()) {
+        P3C3Params c; memset(&c, 0, sizeof(c));
+        if (c3_geometry(N, H, W, c)) {
+            c.X = (const char*)x; c.x_bytes = (unsigned)xbytes; c.Wt = (const char*)w; c.w_bytes = (unsigned)wbytes;
+            c.Cin = Cin; c.Nout = Cout; c.flip = 0; c.ncc = Cin / 32;
+            fill_epi(c.ep, ep); c.ep.out_p3 = (char*)out_p3; c.ep.out_f32 = out_f32;
+            return launch_c3(c, (hipStream_t)stream);
+        }
+    }
     P3NtParams p; memset(&p, 0, sizeof(p));
     p.A = (const char*)x - pad_off; p.a_bytes = (unsigned)(xbytes + pad_off); p.B = (const char*)w; p.b_bytes = (unsigned)wbytes;
     p.M = N * OH * OW; p.N = Cout; p.Cin = Cin; p.KH = KH; p.KW = KW; p.stride = stride; p.pad = pad; p.H = H; p.W = W; p.OH = OH; p.OW = OW;
@@ -871,6 +1128,15 @@ extern "C" int ldetr_p3_conv2d_bwd_data(const void* dy, int N, int OH, int OW, i
     LDETR_CHECK(Cout % 32 == 0 && Cin % 8 == 0 && KH * KW <= 32 && pad < KH && pad < KW && (stride == 1 || stride == 2),
                 "p3_conv2d_bwd_data: unsupported geometry (Cin=%d Cout=%d k=%dx%d stride=%d pad=%d)", Cin, Cout, KH, KW, stride, pad);
     const long dybytes = (long)N * OH * OW * Cout * 6, wbytes = (long)Cin * KH * KW * Cout * 6;
+    if (KH == 3 && KW == 3 && stride == 1 && pad == 1 && OH == IH && OW == IW && dybytes < 0x7fffffffL && wbytes < 0x7fffffffL && c3_enabled()) {
+        P3C3Params c; memset(&c, 0, sizeof(c));
+        if (c3_geometry(N, IH, IW, c)) {   // dx = conv(dy, wb) with mirrored taps: source pixel = dst + 1 - k
+            c.X = (const char*)dy; c.x_bytes = (unsigned)dybytes; c.Wt = (const char*)wb; c.w_bytes = (unsigned)wbytes;
+            c.Cin = Cout; c.Nout = Cin; c.flip = 1; c.ncc = Cout / 32;
+            fill_epi(c.ep, ep); c.ep.out_p3 = (char*)out_p3; c.ep.out_f32 = out_f32;
+            return launch_c3(c, (hipStream_t)stream);
+        }
+    }
     for (int cls = stride * stride - 1; cls >= 0; cls--) {
         const int py = cls / stride, px = cls - py * stride;
         P3NtParams p; memset(&p, 0, sizeof(p));

@@ -74,6 +74,29 @@ def dma_probe():
                     print(f'dma probe buf {mb:3d} MiB blocks {blocks:4d} seg {seg:4d} pitch {pitch:5d}: {t*1e6:8.1f} us  {byts/t/1e12:6.2f} TB/s  {byts/t/256/1e9:6.1f} GB/s/CU', flush=True)
 
 
+def trace_case(N, H, Ci, Co, k, s, pad):
+    """Needs a library built with LDETR_P3_TRACE=1: where the waves of the forward kernel spend their cycles."""
+    import numpy as np
+    x = torch.randn(N, H, H, Ci, device=dev); w = torch.randn(Co, k, k, Ci, device=dev) / (k * Ci ** 0.5)
+    OH = (H + 2 * pad - k) // s + 1
+    xp = p3_split(x.reshape(-1, Ci)); wp = p3_split(w.reshape(Co, -1))
+    yp = torch.empty(N * OH * OH * Co * 6, dtype=torch.uint8, device=dev)
+    buf = torch.zeros(8192 * 8 * 8, dtype=torch.int64, device=dev)
+    for _ in range(3):
+        run_fwd(xp, N, H, Ci, wp, Co, k, s, pad, None, yp, None)
+    torch.cuda.synchronize()
+    L.ldetr_p3_debug_trace(core.ptr(buf))
+    run_fwd(xp, N, H, Ci, wp, Co, k, s, pad, None, yp, None)
+    torch.cuda.synchronize()
+    L.ldetr_p3_debug_trace(None)
+    t = buf.cpu().numpy().reshape(-1, 8)
+    t = t[t[:, 4] > 0]
+    tot = t[:, 6] - t[:, 5]
+    print(f'trace N={N} H={H} {Ci}->{Co} k{k}: waves {len(t)}  k-tiles/wave {t[:,4].mean():.1f}  loop cycles/wave {tot.mean():.0f}  per k-tile: load-issue {np.mean(t[:,0]/t[:,4]):.0f}  mfma-phase {np.mean(t[:,1]/t[:,4]):.0f}  store {np.mean(t[:,2]/t[:,4]):.0f}  barrier {np.mean(t[:,3]/t[:,4]):.0f}  (cycle counter ticks)')
+    span = (t[:, 6].max() - t[:, 5].min())
+    print(f'   first loop start -> last loop end: {span} ticks; XCC ids seen: {sorted(set(t[:,7] & 0xf))}')
+
+
 def conv_ref(x, w, stride, pad):
     return F.conv2d(x.permute(0, 3, 1, 2).double(), w.permute(0, 3, 1, 2).double(), stride=stride, padding=pad).permute(0, 2, 3, 1)
 
@@ -188,6 +211,10 @@ def main():
     what = sys.argv[1:] or ['probe', 'check', 'bench']
     if 'probe' in what:
         probe()
+    if 'trace' in what:
+        trace_case(16, 16, 256, 256, 3, 1, 1)
+        trace_case(16, 32, 128, 128, 3, 1, 1)
+        trace_case(16, 16, 1024, 256, 1, 1, 0)
     if 'dma' in what:
         dma_probe()
     if 'reg' in what:
