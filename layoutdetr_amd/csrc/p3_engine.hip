@@ -54,6 +54,7 @@ struct P3NtParams {
     int splitk;
     float* ws; int* ws_count;
     int mtiles, ntiles;
+    int nclass, nimg;        // data gradient with stride > 1: blockIdx.z enumerates the stride^2 parity classes of the destination pixels (one launch)
     int debug;               // development: 1 = no operand traffic in the k-loop, 2 = no MFMA work in the k-loop
     P3Epi ep;
 };
@@ -255,6 +256,23 @@ __global__ __launch_bounds__(NW * 64) void p3_nt_kernel(P3NtParams p) {
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), wm = w / WGN, wn = w % WGN;   // w in an SGPR: LDS-DMA bases and scalar offsets stay scalar
     const int cl = lane & 31, kl = lane >> 5;
 
+    int ws_tile0 = 0;
+    if (p.nclass > 1) {
+        // this block's parity class (heaviest = most taps first: blocks are dispatched in z order, the light classes fill the tail)
+        const int sd = p.stride, cls = p.nclass - 1 - (int)blockIdx.z, py = cls / sd, px = cls - py * sd;
+        ws_tile0 = cls * p.mtiles * p.ntiles;
+        p.kh0 = (py + p.pad) % sd; p.kw0 = (px + p.pad) % sd;
+        p.nty = p.kh0 < p.KH ? (p.KH - p.kh0 + sd - 1) / sd : 0; p.ntx = p.kw0 < p.KW ? (p.KW - p.kw0 + sd - 1) / sd : 0;
+        const int ntaps = p.nty * p.ntx;
+        if (ntaps == 0) { p.nty = 0; p.ntx = 1; }
+        const unsigned shift = (unsigned)(((p.nty > 0 ? p.nty - 1 : 0) * p.W + (p.ntx - 1)) * p.Cin) * 6u;
+        p.A -= shift; p.a_bytes += shift;
+        p.OH = (p.out_H - py + sd - 1) / sd; p.OW = (p.out_W - px + sd - 1) / sd;
+        p.M = p.nimg * p.OH * p.OW; p.out_py = py; p.out_px = px;
+        p.nkt = ntaps * p.Cin / 32;
+        p.mtiles = (p.M + BM - 1) / BM;
+        if ((int)blockIdx.x >= p.mtiles * p.ntiles) return;
+    }
     const int ntl = p.mtiles * p.ntiles;
     const int t = xcd_remap(blockIdx.x, ntl);
     const int tm = t / p.ntiles, tn = t - tm * p.ntiles;   // consecutive tiles share the A panel
@@ -372,7 +390,7 @@ __global__ __launch_bounds__(NW * 64) void p3_nt_kernel(P3NtParams p) {
     }
 
     // ---- split-K, then the epilogue (the k-loop ended on a barrier)
-    if (p.splitk > 1 && !p3_splitk_reduce<TM, TN, NT>(acc, p.ws, p.ws_count, t, ks, p.splitk, BM * BN, tid, reinterpret_cast<int*>(p3_smem))) return;
+    if (p.splitk > 1 && !p3_splitk_reduce<TM, TN, NT>(acc, p.ws, p.ws_count, ws_tile0 + t, ks, p.splitk, BM * BN, tid, reinterpret_cast<int*>(p3_smem))) return;
     constexpr int CP = WN + 4;
     static_assert(NW * WM * CP * 4 <= NST * ST_BYTES, "epilogue staging does not fit");
     const int ohw = p.OH * p.OW;
@@ -910,13 +928,14 @@ __global__ void p3_probe_kernel(const unsigned short* g, int gbytes, unsigned sh
 template <int BM, int BN, int NW>
 static int launch_nt_cfg(P3NtParams& p, int sk, hipStream_t st) {
     p.mtiles = cdiv(p.M, BM); p.ntiles = cdiv(p.N, BN);
+    const int ncls = p.nclass > 1 ? p.nclass : 1;
     const long nt = (long)p.mtiles * p.ntiles;
     if (sk > p.nkt) sk = p.nkt;
     if (sk < 1) sk = 1;
     static const int dbg = getenv("LDETR_P3_DEBUG") ? atoi(getenv("LDETR_P3_DEBUG")) : 0;
     p.debug = dbg;
     p.splitk = sk; p.ws = nullptr; p.ws_count = nullptr;
-    if (sk > 1 && !splitk_ws_alloc(nt, (size_t)nt * sk * BM * BN * sizeof(float), &p.ws, &p.ws_count)) p.splitk = sk = 1;
+    if (sk > 1 && !splitk_ws_alloc(nt * ncls, (size_t)nt * ncls * sk * BM * BN * sizeof(float), &p.ws, &p.ws_count)) p.splitk = sk = 1;
     constexpr size_t lds = (size_t)2 * (BM + BN) * 192;
     auto kern = p3_nt_kernel<BM, BN, NW>;
     static bool raised = false;
@@ -927,7 +946,7 @@ static int launch_nt_cfg(P3NtParams& p, int sk, hipStream_t st) {
         }
         raised = true;
     }
-    hipLaunchKernelGGL(kern, dim3((unsigned)nt, sk, 1), NW * 64, lds, st, p);
+    hipLaunchKernelGGL(kern, dim3((unsigned)nt, sk, ncls), NW * 64, lds, st, p);
     return check_launch("p3_nt");
 }
 
@@ -937,9 +956,9 @@ static int launch_nt(P3NtParams& p, hipStream_t st) {
     static const int force_tile = getenv("LDETR_P3_TILE") ? atoi(getenv("LDETR_P3_TILE")) : 0;
     static const int force_sk = getenv("LDETR_P3_SK") ? atoi(getenv("LDETR_P3_SK")) : 0;
     auto tiles = [&](int a, int b) { return (long)cdiv(p.M, a) * cdiv(p.N, b); };
-    int cfg = 1;
-    if (p.N <= 64 || tiles(128, 128) < 256) cfg = 2;
-    if (cfg == 2 && tiles(128, 64) < 192 && p.M <= 4096) cfg = 3;
+    // (sweeps of the trunk shapes at 16 x 256^2, profiles/r04_p3_sweeps.txt: the global-load path of a CU, not the matrix pipe, bounds these
+    // launches, and small tiles keep more waves resident to cover it; 128-row tiles only pay when a 64 x 64 grid is many waves of blocks)
+    int cfg = p.M > 16384 ? 2 : 3;
     if (force_tile) cfg = force_tile;
     const int bm = cfg == 3 ? 64 : 128, bn = (cfg == 1 || cfg == 4) ? 128 : 64;
     const long nt = tiles(bm, bn);
@@ -1137,27 +1156,26 @@ extern "C" int ldetr_p3_conv2d_bwd_data(const void* dy, int N, int OH, int OW, i
             return launch_c3(c, (hipStream_t)stream);
         }
     }
-    for (int cls = stride * stride - 1; cls >= 0; cls--) {
-        const int py = cls / stride, px = cls - py * stride;
-        P3NtParams p; memset(&p, 0, sizeof(p));
-        p.kh0 = (py + pad) % stride; p.kw0 = (px + pad) % stride; p.tstep = stride;
-        p.nty = p.kh0 < KH ? (KH - p.kh0 + stride - 1) / stride : 0; p.ntx = p.kw0 < KW ? (KW - p.kw0 + stride - 1) / stride : 0;
-        const int ntaps = p.nty * p.ntx;
-        if (ntaps == 0) { p.nty = 0; p.ntx = 1; }
-        const long shift = ((long)(p.nty > 0 ? p.nty - 1 : 0) * OW + (p.ntx - 1)) * Cout * 6;
-        LDETR_CHECK(dybytes + shift < 0x7fffffffL && wbytes < 0x7fffffffL, "p3_conv2d_bwd_data: tensor too large for 31-bit buffer offsets");
-        p.A = (const char*)dy - shift; p.a_bytes = (unsigned)(dybytes + shift); p.B = (const char*)wb; p.b_bytes = (unsigned)wbytes;
-        p.OH = (IH - py + stride - 1) / stride; p.OW = (IW - px + stride - 1) / stride;   // this class's pixel grid
-        if (p.OH <= 0 || p.OW <= 0) continue;
-        p.M = N * p.OH * p.OW; p.N = Cin; p.Cin = Cout; p.KH = KH; p.KW = KW; p.stride = stride; p.pad = pad; p.H = OH; p.W = OW;
-        p.out_H = IH; p.out_W = IW; p.out_step = stride; p.out_py = py; p.out_px = px; p.tap_mode = 1;
-        p.nkt = ntaps * Cout / 32;
-        fill_epi(p.ep, ep); p.ep.out_p3 = (char*)out_p3; p.ep.out_f32 = out_f32;
-        if (p.M == 0) continue;
-        const int rc = launch_nt(p, (hipStream_t)stream);
-        if (rc != LDETR_OK) return rc;
+    P3NtParams p; memset(&p, 0, sizeof(p));
+    p.B = (const char*)wb; p.b_bytes = (unsigned)wbytes;
+    p.N = Cin; p.Cin = Cout; p.KH = KH; p.KW = KW; p.stride = stride; p.pad = pad; p.H = OH; p.W = OW;
+    p.out_H = IH; p.out_W = IW; p.out_step = stride; p.tap_mode = 1; p.tstep = stride; p.nimg = N;
+    fill_epi(p.ep, ep); p.ep.out_p3 = (char*)out_p3; p.ep.out_f32 = out_f32;
+    const long max_shift = ((long)(KH - 1) * OW + (KW - 1)) * Cout * 6;
+    LDETR_CHECK(dybytes + max_shift < 0x7fffffffL && wbytes < 0x7fffffffL, "p3_conv2d_bwd_data: tensor too large for 31-bit buffer offsets");
+    if (stride == 1) {
+        p.kh0 = 0; p.kw0 = 0; p.nty = KH; p.ntx = KW;
+        p.A = (const char*)dy - max_shift; p.a_bytes = (unsigned)(dybytes + max_shift);
+        p.OH = IH; p.OW = IW; p.M = N * IH * IW; p.nkt = KH * KW * Cout / 32; p.nclass = 1;
+    } else {
+        // sized for the heaviest class (py, px) = (stride - 1, ...): the kernel derives every class's own taps, grid and shift from blockIdx.z
+        p.A = (const char*)dy; p.a_bytes = (unsigned)dybytes;
+        p.OH = (IH + stride - 1) / stride; p.OW = (IW + stride - 1) / stride; p.M = N * p.OH * p.OW;
+        p.nkt = ((KH + stride - 1) / stride) * ((KW + stride - 1) / stride) * Cout / 32; p.nclass = stride * stride;
+        if (p.nkt == 0) p.nkt = 1;
     }
-    return LDETR_OK;
+    if (p.M == 0) return LDETR_OK;
+    return launch_nt(p, (hipStream_t)stream);
 }
 
 template <int BM, int BN>
@@ -1202,9 +1220,7 @@ extern "C" int ldetr_p3_conv2d_bwd_weight(const void* x, int N, int H, int W, in
     p.debug = dbg;
     if (p.npix == 0) return LDETR_OK;
     static const int force_tile = getenv("LDETR_P3_WTILE") ? atoi(getenv("LDETR_P3_WTILE")) : 0;
-    int cfg = (Cout >= 128 && Cin >= 128 && (long)(Cout / 128) * (Cin / 128) * KH * KW >= 8) ? 1 : ((Cout >= 128 && Cin >= 64) ? 2 : 3);
-    if (Cout % 128 != 0 || Cin % 128 != 0) cfg = std::max(cfg, 2);
-    if (Cout % 128 != 0 || Cin % 64 != 0) cfg = 3;
+    int cfg = 3;   // 64 x 64: the most resident waves per CU (sweep: 48-50 us against 58-84 for the wider tiles on the trunk's 3x3 shapes)
     if (force_tile) cfg = force_tile;
     switch (cfg) {
         case 1: return launch_tn_cfg<128, 128>(p, 256, (hipStream_t)stream);
