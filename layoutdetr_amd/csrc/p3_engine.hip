@@ -53,7 +53,7 @@ struct P3NtParams {
     int nkt;                 // k-tiles in total (taps * Cin / 32)
     int splitk;
     float* ws; int* ws_count;
-    int mtiles, ntiles;
+    int mtiles, ntiles, xm, xn;   // tile grid and the XCD array laid over it (xcd_tile)
     int nclass, nimg;        // data gradient with stride > 1: blockIdx.z enumerates the stride^2 parity classes of the destination pixels (one launch)
     int debug;               // development: 1 = no operand traffic in the k-loop, 2 = no MFMA work in the k-loop
     P3Epi ep;
@@ -62,11 +62,17 @@ struct P3NtParams {
 __device__ __forceinline__ float bf_lo(unsigned w) { return __uint_as_float(w << 16); }
 __device__ __forceinline__ float bf_hi(unsigned w) { return __uint_as_float(w & 0xffff0000u); }
 
-// XCD-aware tile order: block b runs on XCD b % 8; give each XCD a contiguous range of tiles so that the blocks sharing an
-// A row panel / B column panel share an L2 (bijective also when the tile count is not a multiple of 8).
-__device__ __forceinline__ int xcd_remap(int b, int n) {
-    const int q = n >> 3, r = n & 7, x = b & 7, i = b >> 3;
-    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
+// XCD-aware tile order.  Block b runs on XCD b % 8 and every XCD has its own 4 MiB L2, so the 8 XCDs are laid over the tile grid as an
+// xm x xn array (xm * xn = 8): XCD (xi, xj) owns the m-tiles of chunk xi and the n-tiles of chunk xj, n fastest.  Its L2 then holds 1/xm of the
+// A panel rows and 1/xn of the weights; through the fabric go A x xn + B x xm bytes per launch, which the host minimises (layer 4: the
+// 14 MB weight image used to be fetched by all eight L2s).  Returns false for the padding blocks of a ragged partition.
+__device__ __forceinline__ bool xcd_tile(int b, int mtiles, int ntiles, int xm, int xn, int& tm, int& tn) {
+    const int x = b & 7, i = b >> 3, xi = x / xn, xj = x - xi * xn;
+    const int mlo = xi * mtiles / xm, mhi = (xi + 1) * mtiles / xm, nlo = xj * ntiles / xn, nhi = (xj + 1) * ntiles / xn;
+    const int cn = nhi - nlo;
+    if (cn <= 0 || i >= (mhi - mlo) * cn) return false;
+    tm = mlo + i / cn; tn = nlo + i - (i / cn) * cn;
+    return true;
 }
 
 // Epilogue of one wave: its WM x WN accumulator tile goes through the wave's own LDS region (Cs, row pitch WN + 4 floats) and comes back as
@@ -271,11 +277,10 @@ __global__ __launch_bounds__(NW * 64) void p3_nt_kernel(P3NtParams p) {
         p.M = p.nimg * p.OH * p.OW; p.out_py = py; p.out_px = px;
         p.nkt = ntaps * p.Cin / 32;
         p.mtiles = (p.M + BM - 1) / BM;
-        if ((int)blockIdx.x >= p.mtiles * p.ntiles) return;
     }
-    const int ntl = p.mtiles * p.ntiles;
-    const int t = xcd_remap(blockIdx.x, ntl);
-    const int tm = t / p.ntiles, tn = t - tm * p.ntiles;   // consecutive tiles share the A panel
+    int tm, tn;
+    if (!xcd_tile(blockIdx.x, p.mtiles, p.ntiles, p.xm, p.xn, tm, tn)) return;
+    const int t = tm * p.ntiles + tn;
     const int m0 = tm * BM, n0 = tn * BN;
     const int ks = blockIdx.y;
     const int per = (p.nkt + p.splitk - 1) / p.splitk;
@@ -422,7 +427,7 @@ struct P3C3Params {
     int flip;                    // data gradient: tap (ty, tx) reads the halo at (2 - ty, 2 - tx)
     int ncc;                     // 32-channel slices
     int splitk; float* ws; int* ws_count;
-    int mtiles, ntiles;
+    int mtiles, ntiles, xm, xn;
     P3Epi ep;
 };
 
@@ -499,9 +504,9 @@ __global__ __launch_bounds__(256, 2) void p3_c3_kernel(P3C3Params p) {
     extern __shared__ __attribute__((aligned(1024))) char p3_smem[];
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), wm = w >> 1, wn = w & 1;
     const int cl = lane & 31, kl = lane >> 5;
-    const int ntl = p.mtiles * p.ntiles;
-    const int t = xcd_remap(blockIdx.x, ntl);
-    const int tm = t / p.ntiles, tn = t - tm * p.ntiles;
+    int tm, tn;
+    if (!xcd_tile(blockIdx.x, p.mtiles, p.ntiles, p.xm, p.xn, tm, tn)) return;
+    const int t = tm * p.ntiles + tn;
     const int n0 = tn * BN;
     const int ks = blockIdx.y;
     const int per = (p.ncc + p.splitk - 1) / p.splitk;
@@ -698,14 +703,17 @@ __global__ __launch_bounds__(256) void p3_tn_kernel(P3TnParams p) {
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), wm = w >> 1, wn = w & 1;
     const int cl = lane & 31, kl = lane >> 5;
     const int taps = p.KH * p.KW;
-    int b = blockIdx.x;
+    // grid = (pixel slices, tiles x taps): blocks are dispatched x-fastest and block i runs on XCD i % 8, so with a multiple of 8 slices every
+    // block that reads a given pixel slice of dY / X shares one XCD's L2 (the other order made all 8 L2s fetch every slice: 155 MB of fabric
+    // traffic per launch, profiles/r04a_pmc_traffic.json)
+    int b = blockIdx.y;
     const int tap = b % taps; b /= taps;
     const int tn = b % p.ntiles, tm = b / p.ntiles;
     const int kh = tap / p.KW, kw = tap - kh * p.KW;
     const int m0 = tm * BM, n0 = tn * BN;
     const int nkt = (p.npix + 31) >> 5;
     const int per = (nkt + p.splitk - 1) / p.splitk;
-    const int kt0 = blockIdx.y * per, kt1 = min(nkt, kt0 + per);
+    const int kt0 = blockIdx.x * per, kt1 = min(nkt, kt0 + per);
     int nloc = kt1 - kt0;
     if (nloc <= 0) return;
     if (p.debug == 1) nloc = 0;
@@ -925,11 +933,26 @@ __global__ void p3_probe_kernel(const unsigned short* g, int gbytes, unsigned sh
     for (int i = l; i < 3072; i += 64) out_dma[i] = sm[i];
 }
 
+// XCD array (xm x xn = 8) over an mtiles x ntiles grid minimising the bytes every L2 has to pull through the fabric: a_bytes * xn + b_bytes * xm.
+static void choose_xcd_array(int mtiles, int ntiles, double a_bytes, double b_bytes, int& xm, int& xn, long& grid_x) {
+    static const int force = getenv("LDETR_P3_XN") ? atoi(getenv("LDETR_P3_XN")) : 0;
+    double best = -1.0; xm = 8; xn = 1;
+    for (int n = 1; n <= 8; n *= 2) {
+        const int m = 8 / n;
+        if ((n > ntiles && n > 1) || (m > mtiles && m > 1)) continue;
+        const double cost = a_bytes * n + b_bytes * m;
+        if (best < 0 || cost < best || (force == n)) { best = force == n ? 0.0 : cost; xm = m; xn = n; }
+    }
+    grid_x = 8L * cdiv(mtiles, xm) * cdiv(ntiles, xn);
+}
+
 template <int BM, int BN, int NW>
 static int launch_nt_cfg(P3NtParams& p, int sk, hipStream_t st) {
     p.mtiles = cdiv(p.M, BM); p.ntiles = cdiv(p.N, BN);
     const int ncls = p.nclass > 1 ? p.nclass : 1;
     const long nt = (long)p.mtiles * p.ntiles;
+    long grid_x;
+    choose_xcd_array(p.mtiles, p.ntiles, (double)p.M * p.Cin * 6.0, (double)p.N * p.KH * p.KW * p.Cin * 6.0, p.xm, p.xn, grid_x);
     if (sk > p.nkt) sk = p.nkt;
     if (sk < 1) sk = 1;
     static const int dbg = getenv("LDETR_P3_DEBUG") ? atoi(getenv("LDETR_P3_DEBUG")) : 0;
@@ -946,7 +969,7 @@ static int launch_nt_cfg(P3NtParams& p, int sk, hipStream_t st) {
         }
         raised = true;
     }
-    hipLaunchKernelGGL(kern, dim3((unsigned)nt, sk, ncls), NW * 64, lds, st, p);
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid_x, sk, ncls), NW * 64, lds, st, p);
     return check_launch("p3_nt");
 }
 
@@ -1059,7 +1082,9 @@ static int launch_c3(P3C3Params& p, hipStream_t st) {
         }
         raised = true;
     }
-    hipLaunchKernelGGL(p3_c3_kernel, dim3((unsigned)nt, sk, 1), 256, C3_LDS, st, p);
+    long grid_x;
+    choose_xcd_array(p.mtiles, p.ntiles, (double)p.N_img * p.H * p.W * p.Cin * 6.0, (double)p.Nout * 9 * p.Cin * 6.0, p.xm, p.xn, grid_x);
+    hipLaunchKernelGGL(p3_c3_kernel, dim3((unsigned)grid_x, sk, 1), 256, C3_LDS, st, p);
     return check_launch("p3_c3");
 }
 
@@ -1185,6 +1210,7 @@ static int launch_tn_cfg(P3TnParams& p, int target_blocks, hipStream_t st) {
     const int nkt = (p.npix + 31) / 32;
     int sk = (int)((target_blocks + nt - 1) / nt);
     if (sk > nkt / 4) sk = nkt / 4;
+    if (sk >= 8) sk = (sk + 4) / 8 * 8;   // a multiple of the XCD count: slice s -> XCD s % 8
     if (sk < 1) sk = 1;
     static const int force_sk = getenv("LDETR_P3_WSK") ? atoi(getenv("LDETR_P3_WSK")) : 0;
     if (force_sk > 0) sk = std::min(force_sk, nkt);
@@ -1199,7 +1225,7 @@ static int launch_tn_cfg(P3TnParams& p, int target_blocks, hipStream_t st) {
         }
         raised = true;
     }
-    hipLaunchKernelGGL(kern, dim3((unsigned)nt, sk, 1), 256, lds, st, p);
+    hipLaunchKernelGGL(kern, dim3(sk, (unsigned)nt, 1), 256, lds, st, p);
     return check_launch("p3_tn");
 }
 
