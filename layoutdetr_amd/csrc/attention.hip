@@ -723,8 +723,8 @@ extern "C" int ldetr_attention_bwd_f32(const float* q, int64_t ldq, const float*
     hipStream_t st = (hipStream_t)stream;
     // 32-wide heads, 17..64 keys, <= 64 queries: one LDS-staged block per (batch, head) (attn_bwd_lds_kernel)
     static const int lds_on = getenv("LDETR_ATTN_BWD_LDS") ? atoi(getenv("LDETR_ATTN_BWD_LDS")) : 1;
-    if (lds_on && head_dim == 32 && Lq <= 64 && Lk <= 64 && nkt >= 2 && (ldq % 4) == 0 && (ldk % 4) == 0 && (ldv % 4) == 0 && (lddo % 4) == 0 &&
-        ((((uintptr_t)q) | ((uintptr_t)k) | ((uintptr_t)v) | ((uintptr_t)dout)) & 15) == 0) {
+    if (lds_on && head_dim == 32 && Lq <= 64 && Lk <= 64 && nkt >= 2 && (ldq % 4) == 0 && (ldk % 4) == 0 && (ldv % 4) == 0 && (lddo % 4) == 0 && (ldo % 4) == 0 &&
+        ((((uintptr_t)q) | ((uintptr_t)k) | ((uintptr_t)v) | ((uintptr_t)dout) | ((uintptr_t)out)) & 15) == 0) {   // (dq / dk / dv: checked above for every path)
         hipLaunchKernelGGL(attn_bwd_lds_kernel, B * H, 512, 0, st, p);
         return check_launch("attention_bwd_lds");
     }

@@ -27,6 +27,7 @@ int try_launch_conv_c32(const float* x, const ldetr_tensor4* xt, const float* w,
                         float* y, long ldy, int OH, int OW, const float* k_scale, long k_scale_ld, const ldetr_epilogue* ep,
                         int transposed, hipStream_t st);
 static thread_local int64_t t_launches_f32 = 0, t_launches_split = 0;   // ldetr_engine_launch_counts: contraction kernels issued by this thread, by matrix pipe
+void note_engine_launch(bool bf16_split_pipe) { (bf16_split_pipe ? t_launches_split : t_launches_f32)++; }   // contraction kernels of other translation units (p3_engine.hip)
 int try_launch_wgrad_smallc(const float* x, const ldetr_tensor4* xt, const float* dy, const ldetr_tensor4* dyt, float* dw, int KH, int KW, int stride, int pad,
                             const float* x_scale, int64_t x_scale_ld, const float* dy_scale, int64_t dy_scale_ld, hipStream_t st);
 

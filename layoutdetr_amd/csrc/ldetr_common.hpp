@@ -83,6 +83,33 @@ __device__ __forceinline__ void split2_bf16(float x0, float x1, unsigned& h, uns
     const f32x2_t t = r - widen(m);
     l = pk_bf16(t.x, t.y);
 }
+// The split of values that are STORED (plane-format producers, p3_engine.hip): exact for EVERY fp32 value, so that hi + mid + lo gives the
+// value back bit for bit.  split2_bf16 is exact for finite values whose leading part does not round up to Inf; the rest take the rare branch:
+// finite values within half a bf16 ulp of the overflow threshold get a truncated hi (the remainder then has <= 16 significant bits: still
+// exact in two more parts), and +-Inf / NaN are stored as (x, 0, 0) -- the plain split would store Inf - Inf = NaN in the lower planes and
+// turn every Inf into NaN, a different class for training_loop.py:308's nan_to_num(nan=0, posinf=1e5, neginf=-1e5).
+__device__ __forceinline__ void split2_bf16_exact(float x0, float x1, unsigned& h, unsigned& m, unsigned& l) {
+    split2_bf16(x0, x1, h, m, l);
+    if (__builtin_expect((((h & 0x7f80u) == 0x7f80u) | ((h & 0x7f800000u) == 0x7f800000u)), 0)) {
+        auto fix = [](float x, unsigned& he, unsigned& me, unsigned& le) {   // 16-bit parts of one element
+            if ((he & 0x7f80u) != 0x7f80u) return;
+            const unsigned xb = __float_as_uint(x);
+            if ((xb & 0x7f800000u) == 0x7f800000u) {
+                he = (xb & 0x007fffffu) ? ((xb >> 16) | 0x0040u) : (xb >> 16);   // a NaN stays a (quiet) NaN even if its payload sits in the low bits
+                me = le = 0u;
+                return;
+            }
+            he = xb >> 16;
+            const float r = x - __uint_as_float(he << 16);
+            me = pk_bf16(r, 0.f) & 0xffffu;
+            const float t = r - __uint_as_float(me << 16);
+            le = pk_bf16(t, 0.f) & 0xffffu;
+        };
+        unsigned h0 = h & 0xffffu, h1 = h >> 16, m0 = m & 0xffffu, m1 = m >> 16, l0 = l & 0xffffu, l1 = l >> 16;
+        fix(x0, h0, m0, l0); fix(x1, h1, m1, l1);
+        h = h0 | (h1 << 16); m = m0 | (m1 << 16); l = l0 | (l1 << 16);
+    }
+}
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
 
 __device__ __forceinline__ float wave_sum(float v) {

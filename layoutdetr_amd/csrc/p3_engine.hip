@@ -3,7 +3,8 @@
 // its autograd in the reference).
 //
 // Activation / weight format "P3": an fp32 tensor [rows][C] (C % 8 == 0, channels contiguous = NHWC pixels or OHWI weights) is
-// stored as its exact three-way bf16 split x = hi + mid + lo (8 + 8 + 8 significant bits; ldetr_common.hpp::split2_bf16), in 48-byte
+// stored as its exact three-way bf16 split x = hi + mid + lo (8 + 8 + 8 significant bits; ldetr_common.hpp::split2_bf16_exact: every normal
+// fp32 value, +-0, +-Inf and NaN come back bit for bit -- -0 as +0 -- and subnormals keep the bits bf16's subnormal range holds), in 48-byte
 // groups of 8 channels: [rows][C/8][3 planes][8 x bf16].  6 bytes per element; a row's k-range is one contiguous segment holding
 // all three planes.  Producers (this engine's epilogues, the max-pool, ldetr_p3_split_f32) write it once; consumers move it
 // global -> LDS with buffer_load ... lds (16 bytes per lane, no VGPR round trip, no VALU) and feed v_mfma_f32_32x32x16_bf16 with
@@ -24,6 +25,7 @@
 namespace ldetr {
 
 bool splitk_ws_alloc(long tiles, size_t partial_bytes, float** ws, int** counters);   // gemm_conv.hip (ring of ldetr_set_workspace)
+void note_engine_launch(bool bf16_split_pipe);                                          // gemm_conv.hip (ldetr_engine_launch_counts)
 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) void lds_void;
@@ -55,10 +57,11 @@ struct P3NtParams {
     float* ws; int* ws_count;
     int mtiles, ntiles, xm, xn;   // tile grid and the XCD array laid over it (xcd_tile)
     int nclass, nimg;        // data gradient with stride > 1: blockIdx.z enumerates the stride^2 parity classes of the destination pixels (one launch)
-    int debug;               // development: 1 = no operand traffic in the k-loop, 2 = no MFMA work in the k-loop
     P3Epi ep;
 };
 
+// (merging the planes: hi + (mid + lo).  mid + lo is the exact remainder (<= 16 significant bits), so the outer sum is the stored value exactly;
+// (hi + mid) + lo overflows for values within 2^-8 of FLT_MAX, whose hi + mid is 2^128)
 __device__ __forceinline__ float bf_lo(unsigned w) { return __uint_as_float(w << 16); }
 __device__ __forceinline__ float bf_hi(unsigned w) { return __uint_as_float(w & 0xffff0000u); }
 
@@ -122,24 +125,24 @@ __device__ __forceinline__ void p3_wave_epilogue(const P3Epi& ep, float* Cs, con
                         lo = *reinterpret_cast<const u32x4*>(ep.res_p3 + goff + 32);
 #pragma unroll
             for (int e = 0; e < 4; e++) {
-                v[2 * e] += (bf_lo(h[e]) + bf_lo(md[e])) + bf_lo(lo[e]);
-                v[2 * e + 1] += (bf_hi(h[e]) + bf_hi(md[e])) + bf_hi(lo[e]);
+                v[2 * e] += bf_lo(h[e]) + (bf_lo(md[e]) + bf_lo(lo[e]));
+                v[2 * e + 1] += bf_hi(h[e]) + (bf_hi(md[e]) + bf_hi(lo[e]));
             }
         }
         if (ep.res_f32) {
             const float4 r0 = *reinterpret_cast<const float4*>(ep.res_f32 + orow * N + n), r1 = *reinterpret_cast<const float4*>(ep.res_f32 + orow * N + n + 4);
             v[0] += r0.x; v[1] += r0.y; v[2] += r0.z; v[3] += r0.w; v[4] += r1.x; v[5] += r1.y; v[6] += r1.z; v[7] += r1.w;
         }
-        if (ep.relu) {
+        if (ep.relu) {   // ATen's threshold: relu(NaN) = NaN (fmaxf would return 0)
 #pragma unroll
-            for (int e = 0; e < 8; e++) v[e] = fmaxf(v[e], 0.f);
+            for (int e = 0; e < 8; e++) v[e] = v[e] < 0.f ? 0.f : v[e];
         }
-        if (ep.mask_p3) {
+        if (ep.mask_p3) {   // threshold_backward: the gradient passes where mask > 0, which is false for NaN (hi plane: +0 < bits <= +Inf)
             const u32x4 h = *reinterpret_cast<const u32x4*>(ep.mask_p3 + goff);
 #pragma unroll
             for (int e = 0; e < 4; e++) {
-                if ((int)(h[e] << 16) <= 0) v[2 * e] = 0.f;
-                if ((int)(h[e] & 0xffff0000u) <= 0) v[2 * e + 1] = 0.f;
+                if ((h[e] << 16) - 1u >= 0x7f800000u) v[2 * e] = 0.f;
+                if ((h[e] & 0xffff0000u) - 1u >= 0x7f800000u) v[2 * e + 1] = 0.f;
             }
         }
         if (ep.out_f32) {
@@ -149,7 +152,7 @@ __device__ __forceinline__ void p3_wave_epilogue(const P3Epi& ep, float* Cs, con
         if (ep.out_p3) {
             u32x4 h, md, lo;
 #pragma unroll
-            for (int e = 0; e < 4; e++) { unsigned a, b, c; split2_bf16(v[2 * e], v[2 * e + 1], a, b, c); h[e] = a; md[e] = b; lo[e] = c; }
+            for (int e = 0; e < 4; e++) { unsigned a, b, c; split2_bf16_exact(v[2 * e], v[2 * e + 1], a, b, c); h[e] = a; md[e] = b; lo[e] = c; }
             *reinterpret_cast<u32x4*>(ep.out_p3 + goff) = h;
             *reinterpret_cast<u32x4*>(ep.out_p3 + goff + 16) = md;
             *reinterpret_cast<u32x4*>(ep.out_p3 + goff + 32) = lo;
@@ -201,38 +204,133 @@ __device__ __forceinline__ bool p3_splitk_reduce(f32x16 (&acc)[TM][TN], float* w
     return true;
 }
 
+// ---- Non-finite operands.  The three-way split is exact for finite values only; +-Inf and NaN are stored as (x, 0, 0) (split2_bf16_exact), and a
+// product like Inf.hi x 1.0.mid = Inf x 0 then puts NaN where an fp32 convolution gives Inf -- a different class for the step's gradient
+// sanitiser (training_loop.py:308: NaN -> 0, +-Inf -> +-1e5).  Every contraction kernel therefore looks at its accumulators after the k-loop
+// (any non-finite operand or overflow leaves a non-finite sum: one fma per register, one ballot), and a wave that finds one recomputes its tile
+// of this block's reduction slice with fp32 FMAs on the merged planes: the result of an fp32 evaluation, whatever the operands.  Cold path:
+// plain loops over (row, column), results handed back to the accumulator registers through a wave-private LDS image; a clean launch pays the
+// check only.
+template <int TM, int TN>
+__device__ __forceinline__ bool p3_acc_non_finite(const f32x16 (&acc)[TM][TN]) {
+    float chk = 0.f;
+#pragma unroll
+    for (int i = 0; i < TM; i++)
+#pragma unroll
+        for (int j = 0; j < TN; j++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) chk = fmaf(acc[i][j][r], 0.f, chk);
+    return __builtin_amdgcn_ballot_w64(chk != chk) != 0ull;
+}
+
+typedef unsigned int ld128_t __attribute__((__vector_size__(16)));
+
+// the eight fp32 values of one 48-byte P3 group (out-of-range vector offset -> zeros)
+__device__ __forceinline__ void p3_load_group(const __amdgpu_buffer_rsrc_t rs, unsigned vo, int so, float (&v)[8]) {
+    const ld128_t h = __builtin_amdgcn_raw_buffer_load_b128(rs, vo, so, 0), md = __builtin_amdgcn_raw_buffer_load_b128(rs, vo, so + 16, 0),
+                  lo = __builtin_amdgcn_raw_buffer_load_b128(rs, vo, so + 32, 0);
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+        v[2 * e] = bf_lo(h[e]) + (bf_lo(md[e]) + bf_lo(lo[e]));
+        v[2 * e + 1] = bf_hi(h[e]) + (bf_hi(md[e]) + bf_hi(lo[e]));
+    }
+}
+
+// one element: channel c of the P3 row at byte offset `row` (out of range -> 0)
+__device__ __forceinline__ float p3_load_elem(const __amdgpu_buffer_rsrc_t rs, unsigned row, int c) {
+    const unsigned vo = row == 0x80000000u ? row : row + (unsigned)((c >> 3) * 48 + (c & 7) * 2);
+    const unsigned h = __builtin_amdgcn_raw_buffer_load_b16(rs, vo, 0, 0), md = __builtin_amdgcn_raw_buffer_load_b16(rs, vo, 16, 0),
+                   lo = __builtin_amdgcn_raw_buffer_load_b16(rs, vo, 32, 0);
+    return bf_lo(h) + (bf_lo(md) + bf_lo(lo));
+}
+
+// dot(row, col) for every element of the wave's WM x WN tile -> the wave's accumulator registers (img: wave-private LDS, WM * WN floats;
+// acc[i][j][r] of lane (kl, cl) is row i*32 + (r&3) + 8*(r>>2) + 4*kl, column j*32 + cl)
+template <int WM, int WN, int TM, int TN, typename Dot>
+__device__ __forceinline__ void p3_cold_tile(f32x16 (&acc)[TM][TN], float* img, int lane, Dot dot) {
+    for (int e = lane; e < WM * WN; e += 64) {
+        const int row = e / WN, col = e - row * WN;
+        const float v = dot(row, col);
+        const int i = row >> 5, rr = row & 31, j = col >> 5, cl = col & 31;
+        img[((i * TN + j) * 16 + (rr & 3) + 4 * (rr >> 3)) * 64 + ((rr >> 2) & 1) * 32 + cl] = v;
+    }
+    // (LDS operations of one wave execute in order: no barrier)
+#pragma unroll
+    for (int i = 0; i < TM; i++)
+#pragma unroll
+        for (int j = 0; j < TN; j++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[i][j][r] = img[((i * TN + j) * 16 + r) * 64 + lane];
+}
+
+// Output row m of the gather kernel: byte offset of its reference pixel and the taps that fall inside the image (see p3_load_tile).
+__device__ __forceinline__ void p3_nt_row(const P3NtParams& p, int m, unsigned& off, unsigned& vm) {
+    vm = 0; off = 0;
+    if (m >= p.M) return;
+    const int hw = p.OH * p.OW;
+    const int n = m / hw, rem = m - n * hw, oy = rem / p.OW, ox = rem - oy * p.OW;
+    if (p.tap_mode == 0) {
+        const int iy = oy * p.stride, ix = ox * p.stride;   // tap (pad, pad): in range for every stride / pad used
+        off = (unsigned)(((n * p.H + iy) * p.W + ix) * p.Cin) * 6u;
+        if (p.nty * p.ntx == 1) vm = 1u;                    // 1x1, pad 0
+        else
+            for (int ty = 0; ty < p.nty; ty++)
+                for (int tx = 0; tx < p.ntx; tx++) {
+                    const int sy = iy - p.pad + p.kh0 + ty, sx = ix - p.pad + p.kw0 + tx;
+                    if (sy >= 0 && sy < p.H && sx >= 0 && sx < p.W) vm |= 1u << (ty * p.ntx + tx);
+                }
+    } else {
+        // destination (input-gradient) pixel of this parity class; source (output-gradient) pixel = (dst + pad - kh) / stride
+        const int dy = oy * p.out_step + p.out_py + p.pad, dx = ox * p.out_step + p.out_px + p.pad;
+        const int by = (dy - p.kh0) / p.stride, bx = (dx - p.kw0) / p.stride;   // tap (kh0, kw0): the largest source index
+        off = (unsigned)(((n * p.H + by) * p.W + bx) * p.Cin) * 6u;
+        for (int ty = 0; ty < p.nty; ty++)
+            for (int tx = 0; tx < p.ntx; tx++) {
+                const int sy = by - ty, sx = bx - tx;
+                if (sy >= 0 && sy < p.H && sx >= 0 && sx < p.W) vm |= 1u << (ty * p.ntx + tx);
+            }
+    }
+}
+
+// Scalar offsets of k-tile (tap, cc) in A (relative to a row's reference pixel; p.A is shifted back so that they are never negative) and in B.
+__device__ __forceinline__ void p3_nt_koff(const P3NtParams& p, int tap, int cc, int& sA, int& sB) {
+    const int ty = tap / p.ntx, tx = tap - ty * p.ntx;
+    int dpix;
+    if (p.tap_mode == 0) dpix = (p.kh0 + ty) * p.W + (p.kw0 + tx);             // reference = tap (pad, pad); p.A shifted by (pad*W + pad) pixels
+    else dpix = (p.nty - 1 - ty) * p.W + (p.ntx - 1 - tx);                      // reference = source of tap (kh0, kw0); p.A shifted by ((nty-1)*W + ntx-1) pixels
+    sA = dpix * p.Cin * 6 + cc * 192;
+    sB = ((p.kh0 + p.tstep * ty) * p.KW + p.kw0 + p.tstep * tx) * p.Cin * 6 + cc * 192;
+}
+
 // One k-tile of this wave's operand rows, global -> registers: its 16-row groups of A (gathered pixels) and B (weight rows), three
 // 16-byte pieces per lane and group (piece = (lane % 4) ^ swizzle of its 64-byte instruction slice).  Register staging, not LDS-DMA:
 // measured on MI355X (tools/p3_dev.py dma / reg, profiles/r04_p3_staging_probe.txt) `buffer_load ... lds` tops out at 42-55 GB/s per CU
 // from L2-resident operands whatever the access shape, plain buffer_load_dwordx4 + ds_write_b128 moves 105-220 GB/s per CU, and every
 // DMA-fed version of this kernel sat exactly on the first figure.  (Free functions: hipcc drops the host stub of a kernel template whose
 // lambda captures mutable locals next to buffer builtins.)
-typedef unsigned int ld128_t __attribute__((__vector_size__(16)));
-
 template <int BM, int BN, int NW>
 __device__ __forceinline__ void p3_load_tile(const P3NtParams& p, const __amdgpu_buffer_rsrc_t rsA, const __amdgpu_buffer_rsrc_t rsB,
-                                             const unsigned* offA, const unsigned* vmA, const unsigned* offB, int& tap, int& cc, int ktpt,
+                                             const unsigned* offA, const unsigned* vmA, const unsigned* offB, int& tap, int& cc, int ktpt, bool live,
                                              ld128_t* ra, ld128_t* rb) {
     constexpr int RGA = BM / 16 / NW, RGB = BN / 16 / NW;
-    // tap offset relative to the row's reference pixel (p.A is shifted back so that it is never negative): uniform
-    const int ty = tap / p.ntx, tx = tap - ty * p.ntx;
-    int dpix;
-    if (p.tap_mode == 0) dpix = (p.kh0 + ty) * p.W + (p.kw0 + tx);             // reference = tap (pad, pad); p.A shifted by (pad*W + pad) pixels
-    else dpix = (p.nty - 1 - ty) * p.W + (p.ntx - 1 - tx);                      // reference = source of tap (kh0, kw0); p.A shifted by ((nty-1)*W + ntx-1) pixels
-    const int sA = dpix * p.Cin * 6 + cc * 192;
-    const int sB = ((p.kh0 + p.tstep * ty) * p.KW + p.kw0 + p.tstep * tx) * p.Cin * 6 + cc * 192;
+    // live = false: a k-tile past the end of the slice.  Its loads are still issued (out-of-range offsets: zeros, no memory traffic) so that every
+    // iteration of the k-loop issues the same number of loads and the compiler's vmcnt waits stay exact (a conditional load would make the
+    // wait before each LDS store cover the whole prefetch queue).
+    int sA, sB;   // uniform
+    p3_nt_koff(p, tap, cc, sA, sB);
 #pragma unroll
     for (int i = 0; i < RGA; i++) {
-        const unsigned vo = ((vmA[i] >> tap) & 1u) ? offA[i] : 0x80000000u;   // out of the descriptor's range: the load returns zeros (padding)
+        const unsigned vo = (live && ((vmA[i] >> tap) & 1u)) ? offA[i] : 0x80000000u;   // out of the descriptor's range: the load returns zeros (padding)
 #pragma unroll
         for (int j = 0; j < 3; j++) ra[i * 3 + j] = __builtin_amdgcn_raw_buffer_load_b128(rsA, vo, sA + j * 64, 0);
     }
 #pragma unroll
     for (int i = 0; i < RGB; i++) {
+        const unsigned vo = live ? offB[i] : 0x80000000u;
 #pragma unroll
-        for (int j = 0; j < 3; j++) rb[i * 3 + j] = __builtin_amdgcn_raw_buffer_load_b128(rsB, offB[i], sB + j * 64, 0);
+        for (int j = 0; j < 3; j++) rb[i * 3 + j] = __builtin_amdgcn_raw_buffer_load_b128(rsB, vo, sB + j * 64, 0);
     }
-    if (++cc == ktpt) { cc = 0; ++tap; }
+    if (live && ++cc == ktpt) { cc = 0; ++tap; }
 }
 
 template <int BM, int BN, int NW>
@@ -248,11 +346,14 @@ __device__ __forceinline__ void p3_store_tile(char* sb, int w, int lane, const l
         for (int j = 0; j < 3; j++) *reinterpret_cast<ld128_t*>(sb + A_BYTES + ((w * RGB + i) * 3 + j) * 1024 + lane * 16) = rb[i * 3 + j];
 }
 
-// BM x BN block tile, NW waves as a WGM x WGN grid (WGN = 4 for eight waves on a 128-wide tile), two LDS stages of BK = 32: the loads of
-// k-tile t+1 are in flight (in registers) during the MFMAs of k-tile t and are written to the other stage before the iteration's one barrier.
-template <int BM, int BN, int NW>
+// BM x BN block tile, NW waves as a WGM x WGN grid (WGN = 4 for eight waves on a 128-wide tile), two LDS stages of BK = 32, PF k-tiles in
+// flight in registers: during the MFMAs of k-tile t the loads of tiles t+1 .. t+PF are outstanding; tile t+1 is written to the other stage before
+// the iteration's one barrier and its registers take tile t+1+PF.  What bounds these launches is bytes in flight per CU over the load latency
+// (profiles/r04_pmc_sq.txt: matrix pipe 22-26 % busy on the 1x1 shapes with ONE tile in flight; 12 waves x 6 KiB / ~1.5 us = the ~50 GB/s per
+// CU every earlier variant sat on), so the depth is what the register file allows at the tile's occupancy.
+template <int BM, int BN, int NW, int PF, int NST>
 __global__ __launch_bounds__(NW * 64) void p3_nt_kernel(P3NtParams p) {
-    constexpr int NT = NW * 64, NST = 2;
+    constexpr int NT = NW * 64;   // NST = LDS stages: 2 = one barrier per k-tile; 1 = two barriers, half the LDS (more blocks per CU)
     constexpr int WGN = (NW == 8 && BN >= 128) ? 4 : 2, WGM = NW / WGN;
     constexpr int WM = BM / WGM, WN = BN / WGN, TM = WM / 32, TN = WN / 32;   // wave tile, 32x32 accumulators per wave
     constexpr int A_BYTES = BM * 192, B_BYTES = BN * 192, ST_BYTES = A_BYTES + B_BYTES;
@@ -295,33 +396,8 @@ __global__ __launch_bounds__(NW * 64) void p3_nt_kernel(P3NtParams p) {
     unsigned offA[RGA], vmA[RGA], offB[RGB];
 #pragma unroll
     for (int i = 0; i < RGA; i++) {
-        const int m = m0 + (w * RGA + i) * 16 + rr;
-        unsigned vm = 0, off = 0;
-        if (m < p.M) {
-            const int hw = p.OH * p.OW;
-            const int n = m / hw, rem = m - n * hw, oy = rem / p.OW, ox = rem - oy * p.OW;
-            if (p.tap_mode == 0) {
-                const int iy = oy * p.stride, ix = ox * p.stride;   // tap (pad, pad): in range for every stride / pad used
-                off = (unsigned)(((n * p.H + iy) * p.W + ix) * p.Cin) * 6u;
-                if (p.nty * p.ntx == 1) vm = 1u;                    // 1x1, pad 0
-                else
-                    for (int ty = 0; ty < p.nty; ty++)
-                        for (int tx = 0; tx < p.ntx; tx++) {
-                            const int sy = iy - p.pad + p.kh0 + ty, sx = ix - p.pad + p.kw0 + tx;
-                            if (sy >= 0 && sy < p.H && sx >= 0 && sx < p.W) vm |= 1u << (ty * p.ntx + tx);
-                        }
-            } else {
-                // destination (input-gradient) pixel of this parity class; source (output-gradient) pixel = (dst + pad - kh) / stride
-                const int dy = oy * p.out_step + p.out_py + p.pad, dx = ox * p.out_step + p.out_px + p.pad;
-                const int by = (dy - p.kh0) / p.stride, bx = (dx - p.kw0) / p.stride;   // tap (kh0, kw0): the largest source index
-                off = (unsigned)(((n * p.H + by) * p.W + bx) * p.Cin) * 6u;
-                for (int ty = 0; ty < p.nty; ty++)
-                    for (int tx = 0; tx < p.ntx; tx++) {
-                        const int sy = by - ty, sx = bx - tx;
-                        if (sy >= 0 && sy < p.H && sx >= 0 && sx < p.W) vm |= 1u << (ty * p.ntx + tx);
-                    }
-            }
-        }
+        unsigned vm, off;
+        p3_nt_row(p, m0 + (w * RGA + i) * 16 + rr, off, vm);
         offA[i] = off + pq * 16; vmA[i] = vm;
     }
 #pragma unroll
@@ -353,51 +429,80 @@ __global__ __launch_bounds__(NW * 64) void p3_nt_kernel(P3NtParams p) {
 #pragma unroll
             for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
 
-    const int nloc = p.debug == 3 ? 0 : kt1 - kt0;
-    ld128_t ra[RGA * 3], rb[RGB * 3];
-    if (nloc > 0) {
-        p3_load_tile<BM, BN, NW>(p, rsA, rsB, offA, vmA, offB, tap, cc, ktpt, ra, rb);
-        p3_store_tile<BM, BN, NW>(p3_smem, w, lane, ra, rb);
-    }
+    const int nloc = kt1 - kt0;
+    ld128_t ra[PF][RGA * 3], rb[PF][RGB * 3];
+#pragma unroll
+    for (int d = 0; d < PF; d++) p3_load_tile<BM, BN, NW>(p, rsA, rsB, offA, vmA, offB, tap, cc, ktpt, d < nloc, ra[d], rb[d]);
+    if (nloc > 0) p3_store_tile<BM, BN, NW>(p3_smem, w, lane, ra[0], rb[0]);
     __syncthreads();
-    for (int it = 0; it < nloc; it++) {
-        if (it + 1 < nloc && p.debug != 1) p3_load_tile<BM, BN, NW>(p, rsA, rsB, offA, vmA, offB, tap, cc, ktpt, ra, rb);
-        if (p.debug != 2) {
-        const char* sb = p3_smem + (it % NST) * ST_BYTES;
+    for (int it0 = 0; it0 < nloc; it0 += PF) {
 #pragma unroll
-        for (int s = 0; s < 2; s++) {
-            bf16x8_t a[TM][3], b[TN][3];
+        for (int d = 0; d < PF; d++) {
+            const int it = it0 + d;
+            // tile `it` went from ra[d] to LDS before the last barrier: its registers take tile it + PF
+            p3_load_tile<BM, BN, NW>(p, rsA, rsB, offA, vmA, offB, tap, cc, ktpt, it + PF < nloc, ra[d], rb[d]);
+            if (it < nloc) {
+                const char* sb = p3_smem + (it % NST) * ST_BYTES;
 #pragma unroll
-            for (int i = 0; i < TM; i++)
+                for (int s = 0; s < 2; s++) {
+                    bf16x8_t a[TM][3], b[TN][3];
 #pragma unroll
-                for (int pl = 0; pl < 3; pl++)
-                    a[i][pl] = *reinterpret_cast<const bf16x8_t*>(sb + foA + i * (2 * 3 * 1024) + fo[s][pl]);
+                    for (int i = 0; i < TM; i++)
 #pragma unroll
-            for (int j = 0; j < TN; j++)
+                        for (int pl = 0; pl < 3; pl++)
+                            a[i][pl] = *reinterpret_cast<const bf16x8_t*>(sb + foA + i * (2 * 3 * 1024) + fo[s][pl]);
 #pragma unroll
-                for (int pl = 0; pl < 3; pl++)
-                    b[j][pl] = *reinterpret_cast<const bf16x8_t*>(sb + foB + j * (2 * 3 * 1024) + fo[s][pl]);
+                    for (int j = 0; j < TN; j++)
 #pragma unroll
-            for (int i = 0; i < TM; i++)
+                        for (int pl = 0; pl < 3; pl++)
+                            b[j][pl] = *reinterpret_cast<const bf16x8_t*>(sb + foB + j * (2 * 3 * 1024) + fo[s][pl]);
 #pragma unroll
-                for (int j = 0; j < TN; j++) {   // smallest terms first
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[j][1], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][2], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][2], b[j][0], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][1], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[j][0], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][0], acc[i][j], 0, 0, 0);
+                    for (int i = 0; i < TM; i++)
+#pragma unroll
+                        for (int j = 0; j < TN; j++) {   // smallest terms first
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[j][1], acc[i][j], 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][2], acc[i][j], 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][2], b[j][0], acc[i][j], 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][1], acc[i][j], 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[j][0], acc[i][j], 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][0], acc[i][j], 0, 0, 0);
+                        }
                 }
+                if (NST == 1) __syncthreads();   // every wave is done reading the one stage
+                if (it + 1 < nloc) p3_store_tile<BM, BN, NW>(p3_smem + ((it + 1) % NST) * ST_BYTES, w, lane, ra[(d + 1) % PF], rb[(d + 1) % PF]);
+                __syncthreads();
+            }
         }
-        }
-        if (it + 1 < nloc && p.debug != 1) p3_store_tile<BM, BN, NW>(p3_smem + ((it + 1) % NST) * ST_BYTES, w, lane, ra, rb);
-        __syncthreads();
     }
 
-    // ---- split-K, then the epilogue (the k-loop ended on a barrier)
-    if (p.splitk > 1 && !p3_splitk_reduce<TM, TN, NT>(acc, p.ws, p.ws_count, ws_tile0 + t, ks, p.splitk, BM * BN, tid, reinterpret_cast<int*>(p3_smem))) return;
+    // ---- non-finite operands: this wave's tile of the slice again, in fp32 (the k-loop ended on a barrier: LDS is free; a wave's image
+    // lives in the region its epilogue stages through)
     constexpr int CP = WN + 4;
-    static_assert(NW * WM * CP * 4 <= NST * ST_BYTES, "epilogue staging does not fit");
+    // (the launch sizes the dynamic LDS as max(NST * ST_BYTES, NW * WM * CP * 4): the epilogue's staging area)
+    if (p3_acc_non_finite<TM, TN>(acc)) {
+        p3_cold_tile<WM, WN, TM, TN>(acc, reinterpret_cast<float*>(p3_smem) + w * (WM * CP), lane, [&](int row, int col) -> float {
+            unsigned off, vm;
+            p3_nt_row(p, m0 + wm * WM + row, off, vm);
+            const int n = n0 + wn * WN + col;
+            const unsigned ob = n < p.N ? (unsigned)n * (unsigned)(p.KH * p.KW * p.Cin) * 6u : 0x80000000u;
+            float s = 0.f;
+            for (int kt = kt0; kt < kt1; kt++) {
+                const int tp = kt / ktpt;
+                int sA, sB;
+                p3_nt_koff(p, tp, kt - tp * ktpt, sA, sB);
+                const unsigned vo = ((vm >> tp) & 1u) ? off : 0x80000000u;   // padding: zeros, multiplied like the matrix path's
+                for (int g = 0; g < 4; g++) {
+                    float a[8], b[8];
+                    p3_load_group(rsA, vo, sA + g * 48, a); p3_load_group(rsB, ob, sB + g * 48, b);
+#pragma unroll
+                    for (int e = 0; e < 8; e++) s = fmaf(a[e], b[e], s);
+                }
+            }
+            return s;
+        });
+    }
+    // ---- split-K, then the epilogue
+    if (p.splitk > 1 && !p3_splitk_reduce<TM, TN, NT>(acc, p.ws, p.ws_count, ws_tile0 + t, ks, p.splitk, BM * BN, tid, reinterpret_cast<int*>(p3_smem))) return;
     const int ohw = p.OH * p.OW;
     p3_wave_epilogue<WM, WN, TM, TN>(p.ep, reinterpret_cast<float*>(p3_smem) + w * (WM * CP), acc, lane, n0 + wn * WN, p.N, [&](int rl) -> long {
         const int m = m0 + wm * WM + rl;
@@ -589,9 +694,32 @@ __global__ __launch_bounds__(256, 2) void p3_c3_kernel(P3C3Params p) {
         }
     }
 
-    if (p.splitk > 1 && !p3_splitk_reduce<2, 1, NT>(acc, p.ws, p.ws_count, t, ks, p.splitk, BM * BN, tid, reinterpret_cast<int*>(p3_smem))) return;
     constexpr int CP = WN + 4;
     static_assert(4 * WM * CP * 4 <= C3_LDS, "epilogue staging does not fit");
+    if (p3_acc_non_finite<2, 1>(acc)) {   // non-finite operands: this wave's tile of the slice again, in fp32 (see p3_cold_tile)
+        p3_cold_tile<WM, WN, 2, 1>(acc, reinterpret_cast<float*>(p3_smem) + w * (WM * CP), lane, [&](int row, int col) -> float {
+            int n, y0, x0, py, px;
+            p3_c3_decode_tile_row(p, tm, wm * WM + row, n, y0, x0, py, px);
+            if (n >= p.N_img) return 0.f;
+            const int y = y0 + py, x = x0 + px, no = n0 + wn * WN + col;
+            const unsigned ob = no < p.Nout ? (unsigned)no * (unsigned)(9 * p.Cin) * 6u : 0x80000000u;
+            float s = 0.f;
+            for (int cc = cc0; cc < cc1; cc++)
+                for (int tap = 0; tap < 9; tap++) {
+                    const int ty = tap / 3, tx = tap - ty * 3;
+                    const int sy = y + (p.flip ? 1 - ty : ty - 1), sx = x + (p.flip ? 1 - tx : tx - 1);
+                    const unsigned vo = (sy >= 0 && sy < p.H && sx >= 0 && sx < p.W) ? (unsigned)(((n * p.H + sy) * p.W + sx) * p.Cin) * 6u : 0x80000000u;
+                    for (int g = 0; g < 4; g++) {
+                        float a[8], b[8];
+                        p3_load_group(rsA, vo, cc * 192 + g * 48, a); p3_load_group(rsB, ob, tap * p.Cin * 6 + cc * 192 + g * 48, b);
+#pragma unroll
+                        for (int e = 0; e < 8; e++) s = fmaf(a[e], b[e], s);
+                    }
+                }
+            return s;
+        });
+    }
+    if (p.splitk > 1 && !p3_splitk_reduce<2, 1, NT>(acc, p.ws, p.ws_count, t, ks, p.splitk, BM * BN, tid, reinterpret_cast<int*>(p3_smem))) return;
     p3_wave_epilogue<WM, WN, 2, 1>(p.ep, reinterpret_cast<float*>(p3_smem) + w * (WM * CP), acc, lane, n0 + wn * WN, p.Nout, [&](int rl) -> long {
         int n, y0, x0, py, px;
         p3_c3_decode_tile_row(p, tm, wm * WM + rl, n, y0, x0, py, px);
@@ -619,7 +747,6 @@ struct P3TnParams {
     const float* row_scale;          // [Cout] or null
     float alpha;
     float* dW;                       // [Cout][KH*KW][Cin]
-    int debug;                       // development: 1 = skip the k-loop (epilogue cost alone), 2 = skip the epilogue
 };
 
 __device__ __forceinline__ void fastdivmod(int x, int d, float invd, int& q, int& r) {   // exact for 0 <= x < 2^24
@@ -695,7 +822,7 @@ __device__ __forceinline__ void p3_tn_store(char* sb, int w, int lane, const ld1
         for (int j = 0; j < 3; j++) *reinterpret_cast<ld128_t*>(sb + A_BYTES + ((((w >> 1) * UB + i) * 2 + rg) * 3 + j) * 1024 + lane * 16) = rb[i * 3 + j];
 }
 
-template <int BM, int BN>
+template <int BM, int BN, int PF>
 __global__ __launch_bounds__(256) void p3_tn_kernel(P3TnParams p) {
     constexpr int A_BYTES = BM * 192, B_BYTES = BN * 192, ST_BYTES = A_BYTES + B_BYTES, NST = 2;
     constexpr int TM = BM / 64, TN = BN / 64;
@@ -714,10 +841,9 @@ __global__ __launch_bounds__(256) void p3_tn_kernel(P3TnParams p) {
     const int nkt = (p.npix + 31) >> 5;
     const int per = (nkt + p.splitk - 1) / p.splitk;
     const int kt0 = blockIdx.x * per, kt1 = min(nkt, kt0 + per);
-    int nloc = kt1 - kt0;
+    const int nloc = kt1 - kt0;
     if (nloc <= 0) return;
-    if (p.debug == 1) nloc = 0;
-    const int kend = p.npix;
+    const int kend = min(kt1 * 32, p.npix);   // pixels past the slice load as zeros (out-of-range offsets): the dead tiles of the prefetch queue
 
     const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.dY), 0, p.dy_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.X), 0, p.x_bytes, 0x00020000);
@@ -745,14 +871,18 @@ __global__ __launch_bounds__(256) void p3_tn_kernel(P3TnParams p) {
 #pragma unroll
             for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
 
-    ld128_t ga[(BM / 64) * 3], gb[(BN / 64) * 3];
-    if (nloc > 0) {
-        p3_tn_load<BM, BN>(p, rsA, rsB, w, lane, kt0 * 32, kend, m0, n0, kh, kw, ga, gb);
-        p3_tn_store<BM, BN>(p3_smem, w, lane, ga, gb);
-    }
+    // PF pixel tiles in flight in registers (see p3_nt_kernel); every iteration issues the same loads, dead tiles as out-of-range offsets
+    ld128_t ga[PF][(BM / 64) * 3], gb[PF][(BN / 64) * 3];
+#pragma unroll
+    for (int d = 0; d < PF; d++) p3_tn_load<BM, BN>(p, rsA, rsB, w, lane, (kt0 + d) * 32, kend, m0, n0, kh, kw, ga[d], gb[d]);
+    p3_tn_store<BM, BN>(p3_smem, w, lane, ga[0], gb[0]);
     __syncthreads();
-    for (int it = 0; it < nloc; it++) {
-        if (it + 1 < nloc) p3_tn_load<BM, BN>(p, rsA, rsB, w, lane, (kt0 + it + 1) * 32, kend, m0, n0, kh, kw, ga, gb);
+    for (int it0 = 0; it0 < nloc; it0 += PF) {
+#pragma unroll
+      for (int d = 0; d < PF; d++) {
+        const int it = it0 + d;
+        p3_tn_load<BM, BN>(p, rsA, rsB, w, lane, (kt0 + it + PF) * 32, kend, m0, n0, kh, kw, ga[d], gb[d]);
+        if (it < nloc) {
         const unsigned sbase = lds_base + (unsigned)((it % NST) * ST_BYTES);
         u32x2_t ra[2][TM][3][2], rb[2][TN][3][2];   // [k16 step][block][plane][pixel half]
 #pragma unroll
@@ -797,11 +927,30 @@ __global__ __launch_bounds__(256) void p3_tn_kernel(P3TnParams p) {
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], bb[j][0], acc[i][j], 0, 0, 0);
                 }
         }
-        if (it + 1 < nloc) p3_tn_store<BM, BN>(p3_smem + ((it + 1) % NST) * ST_BYTES, w, lane, ga, gb);
+        if (it + 1 < nloc) p3_tn_store<BM, BN>(p3_smem + ((it + 1) % NST) * ST_BYTES, w, lane, ga[(d + 1) % PF], gb[(d + 1) % PF]);
         __syncthreads();
+        }
+      }
     }
     // acc[i][j][r]: row (out channel) = (r&3) + 8*(r>>2) + 4*kl, col (in channel) = cl
-    if (p.debug == 2 && acc[0][0][0] != 12345.f) return;
+    if (p3_acc_non_finite<TM, TN>(acc)) {   // non-finite operands: this wave's tile of the pixel slice again, in fp32 (see p3_cold_tile)
+        p3_cold_tile<TM * 32, TN * 32, TM, TN>(acc, reinterpret_cast<float*>(p3_smem) + w * (TM * TN * 1024), lane, [&](int row, int col) -> float {
+            const int co = m0 + wm * TM * 32 + row, ci = n0 + wn * TN * 32 + col;
+            if (co >= p.Cout || ci >= p.Cin) return 0.f;
+            float s = 0.f;
+            const int pend = min(kt1 * 32, kend);
+            for (int pix = kt0 * 32; pix < pend; pix++) {
+                int n, rem, oy, ox;
+                fastdivmod(pix, p.OH * p.OW, p.inv_ohw, n, rem);
+                fastdivmod(rem, p.OW, p.inv_ow, oy, ox);
+                const int sy = oy * p.stride - p.pad + kh, sx = ox * p.stride - p.pad + kw;
+                const bool in = sy >= 0 && sy < p.H && sx >= 0 && sx < p.W;
+                const unsigned xo = in ? (unsigned)(((n * p.H + oy * p.stride) * p.W + ox * p.stride) * p.Cin) * 6u + (unsigned)((kh * p.W + kw) * p.Cin * 6) : 0x80000000u;
+                s = fmaf(p3_load_elem(rsA, (unsigned)pix * (unsigned)p.Cout * 6u, co), p3_load_elem(rsB, xo, ci), s);   // padding: zero, multiplied like the matrix path's
+            }
+            return s;
+        });
+    }
 #pragma unroll
     for (int i = 0; i < TM; i++)
 #pragma unroll
@@ -827,7 +976,7 @@ __global__ __launch_bounds__(256) void p3_split_kernel(const float* __restrict__
         const float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
         u32x4 h, md, lo;
 #pragma unroll
-        for (int e = 0; e < 4; e++) { unsigned a, b, c; split2_bf16(v[2 * e], v[2 * e + 1], a, b, c); h[e] = a; md[e] = b; lo[e] = c; }
+        for (int e = 0; e < 4; e++) { unsigned a, b, c; split2_bf16_exact(v[2 * e], v[2 * e + 1], a, b, c); h[e] = a; md[e] = b; lo[e] = c; }
         char* d = dst + u * 48;
         *reinterpret_cast<u32x4*>(d) = h; *reinterpret_cast<u32x4*>(d + 16) = md; *reinterpret_cast<u32x4*>(d + 32) = lo;
     }
@@ -843,8 +992,8 @@ __global__ __launch_bounds__(256) void p3_merge_kernel(const char* __restrict__ 
         float v[8];
 #pragma unroll
         for (int e = 0; e < 4; e++) {
-            v[2 * e] = (bf_lo(h[e]) + bf_lo(md[e])) + bf_lo(lo[e]);
-            v[2 * e + 1] = (bf_hi(h[e]) + bf_hi(md[e])) + bf_hi(lo[e]);
+            v[2 * e] = bf_lo(h[e]) + (bf_lo(md[e]) + bf_lo(lo[e]));
+            v[2 * e + 1] = bf_hi(h[e]) + (bf_hi(md[e]) + bf_hi(lo[e]));
         }
         *reinterpret_cast<float4*>(dst + r * ld + g * 8) = make_float4(v[0], v[1], v[2], v[3]);
         *reinterpret_cast<float4*>(dst + r * ld + g * 8 + 4) = make_float4(v[4], v[5], v[6], v[7]);
@@ -863,7 +1012,7 @@ __global__ __launch_bounds__(256) void p3_weight_bwd_kernel(const float* __restr
         for (int e = 0; e < 8; e++) v[e] = w[((long)(g * 8 + e) * T + tp) * I + i] * (o_scale ? o_scale[g * 8 + e] : 1.f);
         u32x4 h, md, lo;
 #pragma unroll
-        for (int e = 0; e < 4; e++) { unsigned a, b, c; split2_bf16(v[2 * e], v[2 * e + 1], a, b, c); h[e] = a; md[e] = b; lo[e] = c; }
+        for (int e = 0; e < 4; e++) { unsigned a, b, c; split2_bf16_exact(v[2 * e], v[2 * e + 1], a, b, c); h[e] = a; md[e] = b; lo[e] = c; }
         char* d = dst + u * 48;
         *reinterpret_cast<u32x4*>(d) = h; *reinterpret_cast<u32x4*>(d + 16) = md; *reinterpret_cast<u32x4*>(d + 32) = lo;
     }
@@ -889,7 +1038,7 @@ __global__ __launch_bounds__(256) void p3_weight_prep_kernel(const long long* __
         const float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
         u32x4 h, md, lo;
 #pragma unroll
-        for (int e = 0; e < 4; e++) { unsigned a, b, cc; split2_bf16(v[2 * e], v[2 * e + 1], a, b, cc); h[e] = a; md[e] = b; lo[e] = cc; }
+        for (int e = 0; e < 4; e++) { unsigned a, b, cc; split2_bf16_exact(v[2 * e], v[2 * e + 1], a, b, cc); h[e] = a; md[e] = b; lo[e] = cc; }
         char* d = df + u * 48;
         *reinterpret_cast<u32x4*>(d) = h; *reinterpret_cast<u32x4*>(d + 16) = md; *reinterpret_cast<u32x4*>(d + 32) = lo;
     }
@@ -901,7 +1050,7 @@ __global__ __launch_bounds__(256) void p3_weight_prep_kernel(const long long* __
         for (int e = 0; e < 8; e++) v[e] = w[((long)(g * 8 + e) * T + tp) * I + i] * (sc ? sc[g * 8 + e] : 1.f);
         u32x4 h, md, lo;
 #pragma unroll
-        for (int e = 0; e < 4; e++) { unsigned a, b, cc; split2_bf16(v[2 * e], v[2 * e + 1], a, b, cc); h[e] = a; md[e] = b; lo[e] = cc; }
+        for (int e = 0; e < 4; e++) { unsigned a, b, cc; split2_bf16_exact(v[2 * e], v[2 * e + 1], a, b, cc); h[e] = a; md[e] = b; lo[e] = cc; }
         char* d = db + (((long)i * T + tp) * (O / 8) + g) * 48;
         *reinterpret_cast<u32x4*>(d) = h; *reinterpret_cast<u32x4*>(d + 16) = md; *reinterpret_cast<u32x4*>(d + 32) = lo;
     }
@@ -946,7 +1095,7 @@ static void choose_xcd_array(int mtiles, int ntiles, double a_bytes, double b_by
     grid_x = 8L * cdiv(mtiles, xm) * cdiv(ntiles, xn);
 }
 
-template <int BM, int BN, int NW>
+template <int BM, int BN, int NW, int PF, int NST>
 static int launch_nt_cfg(P3NtParams& p, int sk, hipStream_t st) {
     p.mtiles = cdiv(p.M, BM); p.ntiles = cdiv(p.N, BN);
     const int ncls = p.nclass > 1 ? p.nclass : 1;
@@ -955,12 +1104,11 @@ static int launch_nt_cfg(P3NtParams& p, int sk, hipStream_t st) {
     choose_xcd_array(p.mtiles, p.ntiles, (double)p.M * p.Cin * 6.0, (double)p.N * p.KH * p.KW * p.Cin * 6.0, p.xm, p.xn, grid_x);
     if (sk > p.nkt) sk = p.nkt;
     if (sk < 1) sk = 1;
-    static const int dbg = getenv("LDETR_P3_DEBUG") ? atoi(getenv("LDETR_P3_DEBUG")) : 0;
-    p.debug = dbg;
     p.splitk = sk; p.ws = nullptr; p.ws_count = nullptr;
     if (sk > 1 && !splitk_ws_alloc(nt * ncls, (size_t)nt * ncls * sk * BM * BN * sizeof(float), &p.ws, &p.ws_count)) p.splitk = sk = 1;
-    constexpr size_t lds = (size_t)2 * (BM + BN) * 192;
-    auto kern = p3_nt_kernel<BM, BN, NW>;
+    constexpr int WGN_ = (NW == 8 && BN >= 128) ? 4 : 2, WM_ = BM / (NW / WGN_), WN_ = BN / WGN_;
+    constexpr size_t lds_loop = (size_t)NST * (BM + BN) * 192, lds_epi = (size_t)NW * WM_ * (WN_ + 4) * 4, lds = lds_loop > lds_epi ? lds_loop : lds_epi;
+    auto kern = p3_nt_kernel<BM, BN, NW, PF, NST>;
     static bool raised = false;
     if (lds > 64 * 1024 && !raised) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
@@ -970,6 +1118,7 @@ static int launch_nt_cfg(P3NtParams& p, int sk, hipStream_t st) {
         raised = true;
     }
     hipLaunchKernelGGL(kern, dim3((unsigned)grid_x, sk, ncls), NW * 64, lds, st, p);
+    note_engine_launch(true);
     return check_launch("p3_nt");
 }
 
@@ -985,16 +1134,31 @@ static int launch_nt(P3NtParams& p, hipStream_t st) {
     if (force_tile) cfg = force_tile;
     const int bm = cfg == 3 ? 64 : 128, bn = (cfg == 1 || cfg == 4) ? 128 : 64;
     const long nt = tiles(bm, bn);
-    const long slots = (cfg == 2 || cfg == 3) ? 512 : 256;
+    static const int force_slots = getenv("LDETR_P3_SLOTS") ? atoi(getenv("LDETR_P3_SLOTS")) : 0;
+    const long slots = force_slots ? force_slots : ((cfg == 2 || cfg == 3) ? 512 : 256);
     int sk = 1;
     if (nt < slots * 3 / 4) { sk = (int)(slots / nt); if (sk > p.nkt / 4) sk = p.nkt / 4; if (sk > 16) sk = 16; }
     if (force_sk > 0) sk = force_sk;
-    switch (cfg) {
-        case 1: return launch_nt_cfg<128, 128, 8>(p, sk, st);
-        case 2: return launch_nt_cfg<128, 64, 4>(p, sk, st);
-        case 3: return launch_nt_cfg<64, 64, 4>(p, sk, st);
-        default: return launch_nt_cfg<128, 128, 4>(p, sk, st);
+    static const int force_pf = getenv("LDETR_P3_PF") ? atoi(getenv("LDETR_P3_PF")) : 0;
+    const int pf = force_pf ? force_pf : 3;
+    static const int force_nst = getenv("LDETR_P3_NST") ? atoi(getenv("LDETR_P3_NST")) : 0;
+    const int nst = force_nst ? force_nst : 2;
+#define P3_NT_CASE(BM_, BN_, NW_)                                                                                   \
+    switch (pf * 2 + (nst == 1 ? 0 : 1)) {                                                                          \
+        case 2: return launch_nt_cfg<BM_, BN_, NW_, 1, 1>(p, sk, st);                                               \
+        case 3: return launch_nt_cfg<BM_, BN_, NW_, 1, 2>(p, sk, st);                                               \
+        case 4: return launch_nt_cfg<BM_, BN_, NW_, 2, 1>(p, sk, st);                                               \
+        case 5: return launch_nt_cfg<BM_, BN_, NW_, 2, 2>(p, sk, st);                                               \
+        case 6: return launch_nt_cfg<BM_, BN_, NW_, 3, 1>(p, sk, st);                                               \
+        default: return launch_nt_cfg<BM_, BN_, NW_, 3, 2>(p, sk, st);                                              \
     }
+    switch (cfg) {
+        case 1: P3_NT_CASE(128, 128, 8)
+        case 2: P3_NT_CASE(128, 64, 4)
+        case 3: P3_NT_CASE(64, 64, 4)
+        default: P3_NT_CASE(128, 128, 4)
+    }
+#undef P3_NT_CASE
 }
 
 // Development probe: LDS-DMA throughput of one access shape.  Every wave of a 256-thread block walks `iters` k-steps along its own 64*16/SEG
@@ -1085,6 +1249,7 @@ static int launch_c3(P3C3Params& p, hipStream_t st) {
     long grid_x;
     choose_xcd_array(p.mtiles, p.ntiles, (double)p.N_img * p.H * p.W * p.Cin * 6.0, (double)p.Nout * 9 * p.Cin * 6.0, p.xm, p.xn, grid_x);
     hipLaunchKernelGGL(p3_c3_kernel, dim3((unsigned)grid_x, sk, 1), 256, C3_LDS, st, p);
+    note_engine_launch(true);
     return check_launch("p3_c3");
 }
 
@@ -1203,7 +1368,7 @@ extern "C" int ldetr_p3_conv2d_bwd_data(const void* dy, int N, int OH, int OW, i
     return launch_nt(p, (hipStream_t)stream);
 }
 
-template <int BM, int BN>
+template <int BM, int BN, int PF>
 static int launch_tn_cfg(P3TnParams& p, int target_blocks, hipStream_t st) {
     p.mtiles = cdiv(p.Cout, BM); p.ntiles = cdiv(p.Cin, BN);
     const long nt = (long)p.mtiles * p.ntiles * p.KH * p.KW;
@@ -1216,7 +1381,7 @@ static int launch_tn_cfg(P3TnParams& p, int target_blocks, hipStream_t st) {
     if (force_sk > 0) sk = std::min(force_sk, nkt);
     p.splitk = sk;
     constexpr size_t lds = (size_t)2 * (BM + BN) * 192;
-    auto kern = p3_tn_kernel<BM, BN>;
+    auto kern = p3_tn_kernel<BM, BN, PF>;
     static bool raised = false;
     if (lds > 64 * 1024 && !raised) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
@@ -1226,6 +1391,7 @@ static int launch_tn_cfg(P3TnParams& p, int target_blocks, hipStream_t st) {
         raised = true;
     }
     hipLaunchKernelGGL(kern, dim3(sk, (unsigned)nt, 1), 256, lds, st, p);
+    note_engine_launch(true);
     return check_launch("p3_tn");
 }
 
@@ -1242,17 +1408,25 @@ extern "C" int ldetr_p3_conv2d_bwd_weight(const void* x, int N, int H, int W, in
     p.Cout = Cout; p.Cin = Cin; p.KH = KH; p.KW = KW; p.stride = stride; p.pad = pad; p.H = H; p.W = W; p.OH = OH; p.OW = OW;
     p.npix = N * OH * OW; p.inv_ohw = 1.0f / (float)(OH * OW); p.inv_ow = 1.0f / (float)OW;
     p.row_scale = dy_scale; p.alpha = 1.f; p.dW = dw;
-    static const int dbg = getenv("LDETR_P3_WDEBUG") ? atoi(getenv("LDETR_P3_WDEBUG")) : 0;
-    p.debug = dbg;
     if (p.npix == 0) return LDETR_OK;
     static const int force_tile = getenv("LDETR_P3_WTILE") ? atoi(getenv("LDETR_P3_WTILE")) : 0;
     int cfg = 3;   // 64 x 64: the most resident waves per CU (sweep: 48-50 us against 58-84 for the wider tiles on the trunk's 3x3 shapes)
     if (force_tile) cfg = force_tile;
-    switch (cfg) {
-        case 1: return launch_tn_cfg<128, 128>(p, 256, (hipStream_t)stream);
-        case 2: return launch_tn_cfg<128, 64>(p, 256, (hipStream_t)stream);
-        default: return launch_tn_cfg<64, 64>(p, 512, (hipStream_t)stream);
+    static const int force_pf = getenv("LDETR_P3_WPF") ? atoi(getenv("LDETR_P3_WPF")) : 0;
+    const int pf = force_pf ? force_pf : 3;
+#define P3_TN_CASE(BM_, BN_, TB_)                                                                \
+    switch (pf) {                                                                                \
+        case 1: return launch_tn_cfg<BM_, BN_, 1>(p, TB_, (hipStream_t)stream);                  \
+        case 2: return launch_tn_cfg<BM_, BN_, 2>(p, TB_, (hipStream_t)stream);                  \
+        case 3: return launch_tn_cfg<BM_, BN_, 3>(p, TB_, (hipStream_t)stream);                  \
+        default: return launch_tn_cfg<BM_, BN_, 4>(p, TB_, (hipStream_t)stream);                 \
     }
+    switch (cfg) {
+        case 1: P3_TN_CASE(128, 128, 256)
+        case 2: P3_TN_CASE(128, 64, 256)
+        default: P3_TN_CASE(64, 64, 512)
+    }
+#undef P3_TN_CASE
 }
 
 extern "C" int ldetr_p3_dma_probe(const void* src, int64_t bytes, int seg, int pitch, int iters, int pieces, int blocks, void* stream) {

@@ -132,10 +132,16 @@ class BackwardStages(object):
     `leaf.grad`; `run(stage)` then continues from it.  Parameter order in the flat gradient buffer is (stem, layer1..layer4, rest),
     so each stage completes one contiguous segment (`training_loop.FlatModule.stage_segments`)."""
 
-    def __init__(self):
+    def __init__(self, n_stages=3):
+        # n_stages = 2: trunk | rest only (no cut between layer2 and layer3).  At a few samples per GPU a stage is a few ms of kernels, and a
+        # host that issues the collective between two graph replays a little late leaves the GPU idle for a visible part of it; two longer
+        # stages hide that at the price of exchanging the whole trunk's gradient (94 MB) after the trunk's backward instead of in two pieces.
+        self.n_stages = n_stages
         self.records = {2: [], 3: []}
 
     def cut(self, x, stage):
+        if stage > self.n_stages:
+            return x
         leaf = x.detach().requires_grad_(True)
         self.records[stage].append((x, leaf))
         return leaf

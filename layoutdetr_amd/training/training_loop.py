@@ -44,6 +44,16 @@ def _trunk_bodies(module):
     return [m for m in module.modules() if isinstance(m, ResNet50Body)]
 
 
+def refresh_weight_planes(module):
+    """The trunk's plane-format weight images (hip/p3.py) follow the parameters: one launch per module after every optimiser step (or any other
+    in-place change of the weights) instead of one per forward."""
+    for body in _trunk_bodies(module):
+        planes = body.p3_planes()
+        planes.managed = True
+        planes.stale = True
+        planes.ensure()
+
+
 class FlatModule(object):
     """Re-homes all parameters of `module` into one flat fp32 buffer and their .grad into another."""
 
@@ -82,11 +92,11 @@ class FlatModule(object):
     def numel(self):
         return self.total
 
-    def stage_segments(self):
+    def stage_segments(self, n_stages=3):
         """Per backward stage (detr_backbone.BackwardStages) the list of (lo, hi) ranges of the flat buffer it completes: stage 1 =
         everything but the trunk (the module's own direct parameters, e.g. D.pos_token, precede `backbone` in parameter order: two
         ranges), stage 2 = trunk layer3 + layer4, stage 3 = stem + layer1 + layer2 — or None when the trunk is not one contiguous
-        run of parameters ending in layer3/layer4 (then the phase is exchanged in one piece)."""
+        run of parameters ending in layer3/layer4 (then the phase is exchanged in one piece).  n_stages = 2: stage 2 = the whole trunk."""
         pre = 'backbone.0.body.'
         trunk = [i for i, n in enumerate(self.names) if n.startswith(pre)]
         if not trunk or trunk != list(range(trunk[0], trunk[0] + len(trunk))):
@@ -96,7 +106,10 @@ class FlatModule(object):
             return None
         off = lambda i: self.offsets[i] if i < len(self.offsets) else self.total
         o0, o2, oT = off(trunk[0]), off(late[0]), off(trunk[-1] + 1)
-        return [[r for r in ((0, o0), (oT, self.total)) if r[1] > r[0]], [(o2, oT)], [(o0, o2)]]
+        rest = [r for r in ((0, o0), (oT, self.total)) if r[1] > r[0]]
+        if n_stages == 2:
+            return [rest, [(o0, oT)]]
+        return [rest, [(o2, oT)], [(o0, o2)]]
 
 
 class Phase(object):
@@ -194,12 +207,7 @@ class DataParallelStep(object):
                                                       1 if self.fuse else 0, scale, 0.0, 1e5, -1e5,
                                                       core.ptr(ema[0]) if ema is not None else None, float(ema[1]) if ema is not None else 0.0,
                                                       core.stream()), 'adam_step')
-        # the trunk's plane-format weight images (hip/p3.py) follow the parameters: one launch per optimiser step instead of one per forward
-        for body in _trunk_bodies(phase.module):
-            planes = body.p3_planes()
-            planes.managed = True
-            planes.stale = True
-            planes.ensure()
+        refresh_weight_planes(phase.module)
 
 
 class EmaTracker(object):
@@ -317,10 +325,15 @@ class StatsCollector(object):
         if elems.numel() == 0:
             self._counters.setdefault(name, None)
             return value
+        # count: known on the host (no launch); sum and sum of squares: one stacked fp32 reduction (the reference's three separate reductions,
+        # ones_like and stack were ~8 latency-bound launches per reported name and micro-batch)
         elems = elems.detach().flatten().to(torch.float32)
-        m = torch.stack([torch.ones_like(elems).sum(), elems.sum(), elems.square().sum()]).to(torch.float64)
+        m = torch.stack((elems, elems * elems)).sum(1).to(torch.float64)
         c = self._counters.get(name)
-        self._counters[name] = m if c is None else c + m
+        if c is None:
+            c = self._counters[name] = torch.zeros(3, dtype=torch.float64, device=elems.device)
+        c[0] += float(elems.numel())
+        c[1:] += m
         return value
 
     def update(self):
@@ -447,19 +460,32 @@ def _trunk_body(module):
     return bb[0].body if bb is not None and hasattr(bb[0], 'body') else None
 
 
-def staged_backward(loss, phase, dp, run_stage1, between=None, exchange=None, stages=None):
-    """One phase's forward + backward in three stages with the gradient exchange of each finished segment launched behind it
+def backward_stage_count(per_gpu_batch):
+    """Stages of a phase's backward when the gradient exchange is overlapped with it: trunk | rest (2) at <= 4 samples per GPU, where a third
+    boundary would make every stage graph only a few ms long and the host's issue latency between two replays shows in the exposed
+    communication time; layer1-2 | layer3-4 | rest (3) above.  LDETR_BACKWARD_STAGES = 2 | 3 overrides."""
+    import os
+    forced = os.environ.get('LDETR_BACKWARD_STAGES')
+    if forced in ('2', '3'):
+        return int(forced)
+    return 2 if per_gpu_batch <= 4 else 3
+
+
+def staged_backward(loss, phase, dp, run_stage1, between=None, exchange=None, stages=None, n_stages=3):
+    """One phase's forward + backward in n_stages (2 or 3) stages with the gradient exchange of each finished segment launched behind it
     (DataParallelStep.exchange_async) -> True if the gradients were exchanged here.  `run_stage1()` runs the forward passes and
     `loss.backward()`; `between(i)` (optional) is called after stage i's work has been queued (graph capture boundaries);
     `exchange(ranges)` replaces the RCCL launch (graph capture: the collectives stay outside the graphs); `stages`: the
     BackwardStages that already recorded this phase's trunk cuts (iteration-level D-trunk sharing evaluates D's trunk before the phases)."""
     from .detr_backbone import BackwardStages
-    segs = phase.fm.stage_segments()
+    if stages is not None:
+        n_stages = stages.n_stages
+    segs = phase.fm.stage_segments(n_stages)
     body = _trunk_body(phase.module)
     if segs is None or body is None or not hasattr(body, 'stages'):
         run_stage1()
         return False
-    st = stages if stages is not None else BackwardStages()
+    st = stages if stages is not None else BackwardStages(n_stages)
     if stages is None:
         body.stages = st
     if exchange is None:
@@ -469,7 +495,7 @@ def staged_backward(loss, phase, dp, run_stage1, between=None, exchange=None, st
         if between is not None:
             between(1)
         exchange(segs[0])
-        for i in (2, 3):
+        for i in range(2, n_stages + 1):
             st.run(i)
             if between is not None:
                 between(i)
@@ -499,7 +525,7 @@ def training_iteration(loss, phases, dp, batch, batch_gpu, gen_z_per_phase, ema=
         d_phase = next(p for p in phases if p.name == 'Dmain')
         if overlap and b <= batch_gpu and d_phase.fm.stage_segments() is not None and hasattr(_trunk_body(d_phase.module), 'stages'):
             from .detr_backbone import BackwardStages
-            d_stages = BackwardStages()
+            d_stages = BackwardStages(backward_stage_count(b))
         for s in range(0, b, batch_gpu):
             loss.precompute_D_trunk(batch['background'][s:s + batch_gpu], stages=d_stages)
     lerp_done = False
@@ -517,7 +543,8 @@ def training_iteration(loss, phases, dp, batch, batch_gpu, gen_z_per_phase, ema=
                                           padding_mask=batch['padding_mask'][sl], background=batch['background'][sl],
                                           real_c=batch['real_c'][sl], gen_z=gen_z[sl], gen_c=gen_c[sl], gain=1, cur_nimg=cur_nimg)
         staged = overlap and b <= batch_gpu
-        exchanged = staged_backward(loss, phase, dp, accumulate, stages=(d_stages if (iter_share and phase.name == 'Dmain') else None)) if staged else (accumulate() or False)
+        exchanged = staged_backward(loss, phase, dp, accumulate, stages=(d_stages if (iter_share and phase.name == 'Dmain') else None),
+                                    n_stages=backward_stage_count(b)) if staged else (accumulate() or False)
         phase.module.requires_grad_(False)
         fe = ema.fused(phase, batch_size, ema_kimg, cur_nimg, ema_rampup) if ema is not None else None
         lerp_done = lerp_done or fe is not None
@@ -540,7 +567,8 @@ class GraphedIteration(object):
         # capture_stream: the side stream the eager warm-up iterations ran on.  Autograd's AccumulateGrad nodes remember the stream of
         # their first use; capturing on that same stream keeps the whole backward on ONE stream (a mismatch makes the engine hop
         # streams inside the capture, and the private-pool allocator then recycles blocks across branches: corrupted replays)
-        # overlap (default: world > 1): each phase becomes THREE chained graphs (backward stages, detr_backbone.BackwardStages); between
+        # overlap (default: world > 1): each phase becomes THREE chained graphs (backward stages, detr_backbone.BackwardStages; two at <= 4 samples
+        # per GPU, backward_stage_count); between
         # their replays the finished gradient segment goes to RCCL on the communication stream while the next graph computes.
         self.capture_stream = capture_stream
         self.loss, self.phases, self.dp, self.batch, self.batch_gpu = loss, phases, dp, batch, batch_gpu
@@ -562,7 +590,7 @@ class GraphedIteration(object):
             d_phase = next(p for p in phases if p.name == 'Dmain')
             if overlap and b <= batch_gpu and d_phase.fm.stage_segments() is not None and hasattr(_trunk_body(d_phase.module), 'stages'):
                 from .detr_backbone import BackwardStages
-                d_stages = BackwardStages()
+                d_stages = BackwardStages(backward_stage_count(b))
             self.pre_graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.pre_graph, pool=pool, stream=self.capture_stream):
                 for s in range(0, b, batch_gpu):
@@ -599,14 +627,15 @@ class GraphedIteration(object):
             begin()
             try:
                 if staged:
-                    segs = phase.fm.stage_segments()
+                    nst = backward_stage_count(b)
+                    segs = phase.fm.stage_segments(nst)
 
                     def between(i):
                         end(segs[i - 1])
-                        if i < 3:
+                        if i < nst:
                             begin()
                     staged_backward(loss, phase, dp, stage1, between=between, exchange=lambda ranges: None,
-                                    stages=(d_stages if (iter_share and phase.name == 'Dmain') else None))
+                                    stages=(d_stages if (iter_share and phase.name == 'Dmain') else None), n_stages=nst)
                 else:
                     stage1()
                     end(None)

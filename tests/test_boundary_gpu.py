@@ -211,3 +211,34 @@ def test_training_loop_entry_runs_like_train_py_drives_it(dev, tmp_path, referen
     assert all(torch.isfinite(p).all() for p in out['G'].parameters())
     moved = sum(float((a - b).abs().max()) > 0 for a, b in zip(out['G'].parameters(), out['G_ema'].parameters()))
     assert moved > 100, 'G was not updated / EMA not tracking'
+
+
+def test_bench_two_ranks_on_one_gpu_prints_the_scaling_schema(dev):
+    """`python bench.py --gpus 2` with both ranks on cuda:0 over gloo (LDETR_BENCH_SHARE_GPU=1): the rank logic, the staged graphs, the
+    overlapped exchange plumbing and -- what this test is for -- the ONE JSON line the driver's scaling sweep parses, with every diagnostic
+    field the first real multi-GPU run is read through.  No xGMI is involved; values are not asserted, the schema is."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, LDETR_BENCH_SHARE_GPU='1', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '1', '--no-roofline'], env=env, cwd=root,
+                       capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, f'expected exactly one JSON line on stdout, got {len(lines)}'
+    d = json.loads(lines[0])
+    for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline', 'dtype', 'data', 'config',
+              'rccl_ranks', 'diagnostics', 'weak_scaling', 'single_gpu_reference', 'strong_scaling_ceiling'):
+        assert k in d, f'missing field {k}'
+    assert d['n_gpus'] == 2 and d['rccl_ranks'] == 2 and d['steps'] == 3 and d['warmup'] == 1 and d['scaling'] == 'strong' and d['higher_is_better'] is True
+    assert d['unit'] == 'images/s' and d['value'] > 0 and d['ms_per_step'] > 0 and d['shared_single_gpu_gloo'] is True
+    assert d['config']['global_batch'] == 16 and d['config']['per_gpu_batch'] == 8 and d['config']['parallelism'] == 'dp2' and 'workload' in d['config']
+    assert d['config']['allreduce_overlapped_with_backward'] is True
+    diag = d['diagnostics']
+    assert len(diag['rank_ms_per_step']['per_rank']) == 2 and set(diag['comm_exposed_ms']) >= {'Gmain', 'Dmain', 'per_step_total_max'} and diag['allreduce_mb_per_step'] > 0
+    w = d['weak_scaling']
+    assert w['global_batch'] == 32 and w['per_gpu_batch'] == 16 and w['value'] > 0 and 'comm_exposed_ms' in w['diagnostics']
+    assert d['single_gpu_reference']['per_gpu_batch'] == 16 and d['single_gpu_reference']['value_per_gpu'] > 0
+    c = d['strong_scaling_ceiling']
+    assert c['n_gpus'] == 2 and c['per_gpu_batch_share'] == 8 and 1.0 < c['value'] <= 2.05

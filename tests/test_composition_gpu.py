@@ -601,3 +601,54 @@ def test_forward_backward_background_1024_long_key_attention(dev):
             worst = max(worst, check(out_d[i], ref_d[i].detach(), 1e-3, 'D ' + nm))
     worst = max(worst, check(zd.grad[valid.to(dev)], zr.grad[valid], 2e-3, 'dz'), check(bd.grad[valid.to(dev)], br.grad[valid], 2e-3, 'dbbox'))
     print(f'[background 1024, 1024 memory tokens] worst err {worst:.2e}')
+
+
+def test_soak_graph_replayed_iterations_with_dropout_stay_finite(dev):
+    """60 hipGraph-replayed Gmain + Dmain iterations of the bench workload (16 samples, 256 x 256, dropout ON, lr 2e-4, iteration-level trunk
+    sharing, plane-format trunk, fused attention / feed-forward tails, sanitise + Adam + EMA): the one place where dropout, graph replay and
+    every fused tail run together at the headline batch.  Every parameter, gradient, Adam moment and G_ema value must stay finite, both
+    modules must move, and the plane-format weight images must follow the parameters."""
+    import copy
+    import bench
+    from layoutdetr_amd.hip import p3 as hp3
+    from layoutdetr_amd.training import training_loop as tl
+    from layoutdetr_amd.training.loss import StyleGAN2Loss
+    from layoutdetr_amd.training.networks_detr import Discriminator, Generator
+    n_it, b = 60, 16
+    torch.manual_seed(0)
+    kw = dict(num_bbox_labels=8, img_channels=3, img_height=256, img_width=256, c_dim=0, background_size=256, bert_f_dim=768, im_f_dim=512)
+    G = Generator(z_dim=4, **kw).train().requires_grad_(False).to(dev)
+    D = Discriminator(**kw).train().requires_grad_(False).to(dev)
+    G.static_shapes = D.static_shapes = True
+    G_ema = copy.deepcopy(G).eval()
+    pG, pD = tl.Phase('Gmain', G, lr=2e-4, betas=(0.0, 0.99), eps=1e-8), tl.Phase('Dmain', D, lr=2e-4, betas=(0.0, 0.99), eps=1e-8)
+    ema = tl.EmaTracker(pG, G_ema)
+    loss = StyleGAN2Loss(dev, G, D, share_D_trunk='iteration')
+    dp = tl.DataParallelStep(1)
+    batch = bench.to_device_batch(bench.make_batch(b, 256, dev, 1), dev)
+    p0 = [pG.fm.flat.clone(), pD.fm.flat.clone()]
+    side = torch.cuda.Stream(); side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(2):
+            tl.training_iteration(loss, [pG, pD], dp, batch, b, [torch.randn(b, 9, 4, device=dev) for _ in range(2)], ema=ema, batch_size=b, ema_kimg=b * 10 / 32, cur_nimg=0)
+    torch.cuda.current_stream().wait_stream(side); torch.cuda.synchronize()
+    g = tl.GraphedIteration(loss, [pG, pD], dp, batch, b, 4, ema=ema, batch_size=b, ema_kimg=b * 10 / 32, capture_stream=side)
+    for _ in range(n_it):
+        g.run()
+    torch.cuda.synchronize()
+    for name, ph, q0 in (('G', pG, p0[0]), ('D', pD, p0[1])):
+        assert bool(torch.isfinite(ph.fm.flat).all()), f'{name}: non-finite parameters after {n_it} replays'
+        assert bool(torch.isfinite(ph.fm.gflat).all()), f'{name}: non-finite gradients'
+        assert bool(torch.isfinite(ph.m).all()) and bool(torch.isfinite(ph.v).all()), f'{name}: non-finite Adam moments'
+        assert float((ph.fm.flat - q0).abs().max()) > 0, f'{name} did not move'
+    assert all(bool(torch.isfinite(p).all()) for p in G_ema.parameters())
+    # the trunk's plane-format weight images are the split of the CURRENT parameters (refreshed by one launch per optimiser step)
+    for mod in (G, D):
+        for body in tl._trunk_bodies(mod):
+            planes = body.p3_planes()
+            for idx in (0, 17, len(planes.convs) - 1):
+                w = planes.convs[idx][0]
+                O = w.shape[0]
+                img = planes.fwd[planes.offsets[idx]:planes.offsets[idx] + w.numel() * 6].view(torch.bfloat16)
+                want = hp3.split_raw(w.detach().permute(0, 2, 3, 1).reshape(1, 1, O, -1)).reshape(-1)
+                assert torch.equal(img.view(torch.int16), want.view(torch.int16)), 'stale plane-format weight image'

@@ -166,7 +166,10 @@ def check_bwd(N, H, Ci, Co, k, s, pad):
     assert e1 < 3e-6 and same and e2 < 3e-6
 
 
-def bench_bwd(name, N, H, Ci, Co, k, s, pad):
+P3_ONLY = bool(os.environ.get('P3_ONLY'))
+
+
+def bench_bwd(name, N, H, Ci, Co, k, s, pad, what='dw'):
     OH = (H + 2 * pad - k) // s + 1
     x = torch.randn(N, H, H, Ci, device=dev); w = torch.randn(Co, k, k, Ci, device=dev) / (k * Ci ** 0.5); dy = torch.randn(N, OH, OH, Co, device=dev)
     sc = torch.rand(Co, device=dev) + 0.5
@@ -174,8 +177,11 @@ def bench_bwd(name, N, H, Ci, Co, k, s, pad):
     ep = _lib.P3Epilogue(); ep.alpha = 1.0; ep.relu_mask_p3 = xp.data_ptr()
     dxp = torch.empty(N * H * H * Ci * 6, dtype=torch.uint8, device=dev); dw = torch.zeros(Co, k, k, Ci, device=dev)
     fl = 2.0 * N * OH * OH * Co * k * k * Ci
-    t1 = timeit(lambda: L.ldetr_p3_conv2d_bwd_data(core.ptr(dyp), N, OH, OH, Co, core.ptr(wb), Ci, k, k, s, pad, H, H, ctypes.byref(ep), core.ptr(dxp), None, core.stream()))
-    t2 = timeit(lambda: L.ldetr_p3_conv2d_bwd_weight(core.ptr(xp), N, H, H, Ci, core.ptr(dyp), Co, k, k, s, pad, core.ptr(sc), core.ptr(dw), core.stream()))
+    t1 = timeit(lambda: L.ldetr_p3_conv2d_bwd_data(core.ptr(dyp), N, OH, OH, Co, core.ptr(wb), Ci, k, k, s, pad, H, H, ctypes.byref(ep), core.ptr(dxp), None, core.stream())) if 'd' in what else 1.0
+    t2 = timeit(lambda: L.ldetr_p3_conv2d_bwd_weight(core.ptr(xp), N, H, H, Ci, core.ptr(dyp), Co, k, k, s, pad, core.ptr(sc), core.ptr(dw), core.stream())) if 'w' in what else 1.0
+    if P3_ONLY:
+        print(f'{name:24s} bwdD p3 {t1*1e6:7.1f}us {fl/t1/1e12:6.1f}TF | bwdW p3 {t2*1e6:7.1f}us {fl/t2/1e12:6.1f}TF', flush=True)
+        return
     dx = torch.empty_like(x); dyt = core.tensor4_nhwc(dy); xt = core.tensor4_nhwc(x)
     epb = core.epilogue(mask_src=x.reshape(-1, Ci), mask_mode=1)
     t3 = timeit(lambda: L.ldetr_conv2d_bwd_data_f32(core.ptr(dy), ctypes.byref(dyt), core.ptr(w), Ci, k, k, s, pad, core.ptr(dx), Ci, H, H, core.ptr(sc), 0, ctypes.byref(epb), core.stream()))
@@ -193,6 +199,9 @@ def bench_case(name, N, H, Ci, Co, k, s, pad):
     ep = _lib.P3Epilogue(); ep.alpha = 1.0; ep.col_scale = sc.data_ptr(); ep.col_bias = sh.data_ptr(); ep.residual_p3 = resp.data_ptr(); ep.relu = 1
     fl = 2.0 * N * OH * OH * Co * k * k * Ci
     t = timeit(lambda: run_fwd(xp, N, H, Ci, wp, Co, k, s, pad, ep, yp, None))
+    if P3_ONLY:
+        print(f'{name:24s} M={N*OH*OH:6d} N={Co:4d} K={k*k*Ci:5d}  p3 {t*1e6:7.1f}us {fl/t/1e12:6.1f}TF', flush=True)
+        return
     # the f32 engine on the same problem
     y = torch.empty(N, OH, OH, Co, device=dev); xt = core.tensor4_nhwc(x)
     ep0 = core.epilogue(col_scale=sc, col_bias=sh, residual=res.reshape(-1, Co), act=core.ACT_RELU)
@@ -205,6 +214,7 @@ CASES = [('l1 1x1 64->64', 64, 64, 64, 1, 1, 0), ('l1 3x3 64->64', 64, 64, 64, 3
          ('l2 1x1 512->128', 32, 512, 128, 1, 1, 0), ('l2 3x3 128->128', 32, 128, 128, 3, 1, 1),
          ('l3 3x3 256->256 s2', 32, 256, 256, 3, 2, 1), ('l3 1x1 256->1024', 16, 256, 1024, 1, 1, 0), ('l3 1x1 1024->256', 16, 1024, 256, 1, 1, 0), ('l3 3x3 256->256', 16, 256, 256, 3, 1, 1),
          ('l4 3x3 512->512 s2', 16, 512, 512, 3, 2, 1), ('l4 1x1 512->2048', 8, 512, 2048, 1, 1, 0), ('l4 1x1 2048->512', 8, 2048, 512, 1, 1, 0), ('l4 3x3 512->512', 8, 512, 512, 3, 1, 1),
+         ('l3 1x1 512->256', 32, 512, 256, 1, 1, 0), ('l3 1x1 512->1024 s2', 32, 512, 1024, 1, 2, 0), ('l4 1x1 1024->512', 16, 1024, 512, 1, 1, 0), ('l4 1x1 1024->2048 s2', 16, 1024, 2048, 1, 2, 0),
          ('sg 3x3 512->512 @16', 16, 512, 512, 3, 1, 1), ('sg 3x3 128->128 @64', 64, 128, 128, 3, 1, 1)]
 
 def main():
@@ -244,6 +254,12 @@ def main():
     if 'benchb' in what:
         for c in CASES:
             bench_bwd(c[0], B, *c[1:])
+    if 'benchd' in what:
+        for c in CASES:
+            bench_bwd(c[0], B, *c[1:], what='d')
+    if 'benchw' in what:
+        for c in CASES:
+            bench_bwd(c[0], B, *c[1:], what='w')
 
 
 if __name__ == '__main__':
