@@ -388,9 +388,13 @@ int ldetr_p3_conv2d_bwd_data(const void* dy, int N, int OH, int OW, int Cout, co
  * onto the existing buffer, e.g. a view of the flat .grad buffer); x P3 [N][H][W][Cin], dy P3 [N][OH][OW][Cout], both channel counts % 32 == 0. */
 int ldetr_p3_conv2d_bwd_weight(const void* x, int N, int H, int W, int Cin, const void* dy, int Cout, int KH, int KW, int stride, int pad,
                                const float* dy_scale, float* dw, void* stream);
-/* Development probe (tools/p3_dev.py): ds_read_b64_tr_b16 lane map and LDS-DMA range semantics. */
-int ldetr_p3_probe(const void* g, int gbytes, void* out_tr, void* out_dma, void* stream);
-int ldetr_p3_dma_probe(const void* src, int64_t bytes, int seg, int pitch, int iters, int pieces, int blocks, void* stream);
+/* Both gradients of one convolution -- ldetr_p3_conv2d_bwd_data(dy, ..., ep, dx_p3, dx_f32) and ldetr_p3_conv2d_bwd_weight(x, ..., dy_scale, dw),
+ * the two halves of ATen's convolution_backward for one layer -- as ONE kernel launch when the two grids can share a launch (the two are
+ * independent and each alone leaves the chip idle through its fill and its store burst; parallel branches of a captured hipGraph do not
+ * overlap, one grid does), else as the two launches.  x is the layer's input [N][IH][IW][Cin]; *launches (optional) receives 1 or 2. */
+int ldetr_p3_conv2d_bwd_pair(const void* dy, int N, int OH, int OW, int Cout, const void* wb, const void* x, int Cin, int KH, int KW, int stride, int pad,
+                             int IH, int IW, const ldetr_p3_epilogue* ep, void* dx_p3, float* dx_f32, const float* dy_scale, float* dw,
+                             int* launches, void* stream);
 
 #ifdef __cplusplus
 }

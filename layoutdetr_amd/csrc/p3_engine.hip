@@ -352,7 +352,7 @@ __device__ __forceinline__ void p3_store_tile(char* sb, int w, int lane, const l
 // (profiles/r04_pmc_sq.txt: matrix pipe 22-26 % busy on the 1x1 shapes with ONE tile in flight; 12 waves x 6 KiB / ~1.5 us = the ~50 GB/s per
 // CU every earlier variant sat on), so the depth is what the register file allows at the tile's occupancy.
 template <int BM, int BN, int NW, int PF, int NST>
-__global__ __launch_bounds__(NW * 64) void p3_nt_kernel(P3NtParams p) {
+__device__ __forceinline__ void p3_nt_body(P3NtParams p, const int bx, const int by, const int bz) {   // (bx, by, bz): the block's place in the (tiles, k-slices, parity classes) grid
     constexpr int NT = NW * 64;   // NST = LDS stages: 2 = one barrier per k-tile; 1 = two barriers, half the LDS (more blocks per CU)
     constexpr int WGN = (NW == 8 && BN >= 128) ? 4 : 2, WGM = NW / WGN;
     constexpr int WM = BM / WGM, WN = BN / WGN, TM = WM / 32, TN = WN / 32;   // wave tile, 32x32 accumulators per wave
@@ -366,7 +366,7 @@ __global__ __launch_bounds__(NW * 64) void p3_nt_kernel(P3NtParams p) {
     int ws_tile0 = 0;
     if (p.nclass > 1) {
         // this block's parity class (heaviest = most taps first: blocks are dispatched in z order, the light classes fill the tail)
-        const int sd = p.stride, cls = p.nclass - 1 - (int)blockIdx.z, py = cls / sd, px = cls - py * sd;
+        const int sd = p.stride, cls = p.nclass - 1 - bz, py = cls / sd, px = cls - py * sd;
         ws_tile0 = cls * p.mtiles * p.ntiles;
         p.kh0 = (py + p.pad) % sd; p.kw0 = (px + p.pad) % sd;
         p.nty = p.kh0 < p.KH ? (p.KH - p.kh0 + sd - 1) / sd : 0; p.ntx = p.kw0 < p.KW ? (p.KW - p.kw0 + sd - 1) / sd : 0;
@@ -380,10 +380,10 @@ __global__ __launch_bounds__(NW * 64) void p3_nt_kernel(P3NtParams p) {
         p.mtiles = (p.M + BM - 1) / BM;
     }
     int tm, tn;
-    if (!xcd_tile(blockIdx.x, p.mtiles, p.ntiles, p.xm, p.xn, tm, tn)) return;
+    if (!xcd_tile(bx, p.mtiles, p.ntiles, p.xm, p.xn, tm, tn)) return;
     const int t = tm * p.ntiles + tn;
     const int m0 = tm * BM, n0 = tn * BN;
-    const int ks = blockIdx.y;
+    const int ks = by;
     const int per = (p.nkt + p.splitk - 1) / p.splitk;
     const int kt0 = ks * per, kt1 = min(p.nkt, kt0 + per);
 
@@ -513,6 +513,9 @@ __global__ __launch_bounds__(NW * 64) void p3_nt_kernel(P3NtParams p) {
     });
 }
 
+template <int BM, int BN, int NW, int PF, int NST>
+__global__ __launch_bounds__(NW * 64) void p3_nt_kernel(P3NtParams p) { p3_nt_body<BM, BN, NW, PF, NST>(p, blockIdx.x, blockIdx.y, blockIdx.z); }
+
 // ---------------------------------------------------------------------------------------------
 // p3_c3_kernel: 3x3 / stride 1 / pad 1 convolutions (forward, and the data gradient as the same conv with mirrored taps) on 2-D pixel
 // patches.  What bounds the gather kernel above is the CU's global-load path (~50 GB/s per CU of L1 misses, whatever the access shape:
@@ -604,16 +607,16 @@ __device__ __forceinline__ void p3_c3_tap(const P3C3Params& p, const __amdgpu_bu
     __syncthreads();
 }
 
-__global__ __launch_bounds__(256, 2) void p3_c3_kernel(P3C3Params p) {
+__device__ __forceinline__ void p3_c3_body(const P3C3Params& p, const int bx, const int by) {
     constexpr int BM = 128, BN = 64, NT = 256, WM = 64, WN = 32;
     extern __shared__ __attribute__((aligned(1024))) char p3_smem[];
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), wm = w >> 1, wn = w & 1;
     const int cl = lane & 31, kl = lane >> 5;
     int tm, tn;
-    if (!xcd_tile(blockIdx.x, p.mtiles, p.ntiles, p.xm, p.xn, tm, tn)) return;
+    if (!xcd_tile(bx, p.mtiles, p.ntiles, p.xm, p.xn, tm, tn)) return;
     const int t = tm * p.ntiles + tn;
     const int n0 = tn * BN;
-    const int ks = blockIdx.y;
+    const int ks = by;
     const int per = (p.ncc + p.splitk - 1) / p.splitk;
     const int cc0 = ks * per, cc1 = min(p.ncc, cc0 + per);
 
@@ -728,6 +731,8 @@ __global__ __launch_bounds__(256, 2) void p3_c3_kernel(P3C3Params p) {
     });
 }
 
+__global__ __launch_bounds__(256, 2) void p3_c3_kernel(P3C3Params p) { p3_c3_body(p, blockIdx.x, blockIdx.y); }
+
 // ---------------------------------------------------------------------------------------------
 // p3_tn_kernel: weight gradients.  dW[co][tap][ci] += row_scale[co] * sum_pix dY[pix][co] * X[src(pix, tap)][ci]: per tap a GEMM whose
 // reduction index is the output pixel, so BOTH operands are stored reduction-major (a pixel's channels are contiguous).  The LDS image
@@ -822,9 +827,9 @@ __device__ __forceinline__ void p3_tn_store(char* sb, int w, int lane, const ld1
         for (int j = 0; j < 3; j++) *reinterpret_cast<ld128_t*>(sb + A_BYTES + ((((w >> 1) * UB + i) * 2 + rg) * 3 + j) * 1024 + lane * 16) = rb[i * 3 + j];
 }
 
-template <int BM, int BN, int PF>
-__global__ __launch_bounds__(256) void p3_tn_kernel(P3TnParams p) {
-    constexpr int A_BYTES = BM * 192, B_BYTES = BN * 192, ST_BYTES = A_BYTES + B_BYTES, NST = 2;
+template <int BM, int BN, int PF, int NST>
+__device__ __forceinline__ void p3_tn_body(const P3TnParams& p, const int bx, const int by) {   // bx: pixel slice, by: (tile, tap)
+    constexpr int A_BYTES = BM * 192, B_BYTES = BN * 192, ST_BYTES = A_BYTES + B_BYTES;   // NST LDS stages (see p3_nt_body)
     constexpr int TM = BM / 64, TN = BN / 64;
     extern __shared__ __attribute__((aligned(1024))) char p3_smem[];
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), wm = w >> 1, wn = w & 1;
@@ -833,14 +838,14 @@ __global__ __launch_bounds__(256) void p3_tn_kernel(P3TnParams p) {
     // grid = (pixel slices, tiles x taps): blocks are dispatched x-fastest and block i runs on XCD i % 8, so with a multiple of 8 slices every
     // block that reads a given pixel slice of dY / X shares one XCD's L2 (the other order made all 8 L2s fetch every slice: 155 MB of fabric
     // traffic per launch, profiles/r04a_pmc_traffic.json)
-    int b = blockIdx.y;
+    int b = by;
     const int tap = b % taps; b /= taps;
     const int tn = b % p.ntiles, tm = b / p.ntiles;
     const int kh = tap / p.KW, kw = tap - kh * p.KW;
     const int m0 = tm * BM, n0 = tn * BN;
     const int nkt = (p.npix + 31) >> 5;
     const int per = (nkt + p.splitk - 1) / p.splitk;
-    const int kt0 = blockIdx.x * per, kt1 = min(nkt, kt0 + per);
+    const int kt0 = bx * per, kt1 = min(nkt, kt0 + per);
     const int nloc = kt1 - kt0;
     if (nloc <= 0) return;
     const int kend = min(kt1 * 32, p.npix);   // pixels past the slice load as zeros (out-of-range offsets): the dead tiles of the prefetch queue
@@ -927,6 +932,7 @@ __global__ __launch_bounds__(256) void p3_tn_kernel(P3TnParams p) {
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], bb[j][0], acc[i][j], 0, 0, 0);
                 }
         }
+        if (NST == 1) __syncthreads();   // every wave is done reading the one stage
         if (it + 1 < nloc) p3_tn_store<BM, BN>(p3_smem + ((it + 1) % NST) * ST_BYTES, w, lane, ga[(d + 1) % PF], gb[(d + 1) % PF]);
         __syncthreads();
         }
@@ -964,6 +970,51 @@ __global__ __launch_bounds__(256) void p3_tn_kernel(P3TnParams p) {
                 if (n < p.Cin) atomicAdd(p.dW + ((long)m * taps + tap) * p.Cin + n, acc[i][j][r] * sc);
             }
         }
+}
+
+template <int BM, int BN, int PF, int NST>
+__global__ __launch_bounds__(256) void p3_tn_kernel(P3TnParams p) { p3_tn_body<BM, BN, PF, NST>(p, blockIdx.x, blockIdx.y); }
+
+// ---------------------------------------------------------------------------------------------
+// Data gradient + weight gradient of one convolution as ONE launch.  Each of the two kernels alone is a short launch whose blocks run in
+// lock-step (all load first, all store last: the matrix pipe idles through the fill and the chip-wide epilogue burst), and the two are
+// independent: on two streams they overlap to 0.65-0.85 of their serial time (tools/p3_dev.py pair), but parallel branches of a captured
+// hipGraph do not (0.92-1.0; `pair graph`), and the step is a graph.  So the pair is one grid holding both kernels' blocks; both read dY
+// (one L2 fill).
+// Which body a block of the paired grid runs, and its index in that body's own grid.  Default (n_tn8 < 0): the weight gradient's blocks first,
+// padded to a multiple of 8 so that both bodies keep their block -> XCD alignment (block b runs on XCD b % 8); the data gradient's blocks move
+// in as those retire.  The alternative (n_tn8 > 0) interleaves the two in chunks of 8 in proportion to their counts; measured slower
+// (profiles/r04_p3_sweeps.txt: 0.98 against 0.85 of the two separate launches): CUs that hold both kinds at once lose more than the overlap gains.
+__device__ __forceinline__ bool p3_pair_split(int b, int n_tn8, int n_other8, int& idx) {
+    if (n_tn8 < 0) {
+        n_tn8 = -n_tn8;
+        if (b < n_tn8 * 8) { idx = b; return true; }
+        idx = b - n_tn8 * 8; return false;
+    }
+    const int c = b >> 3, tot = n_tn8 + n_other8;
+    const int a = (int)(((long)c * n_tn8) / tot), a1 = (int)(((long)(c + 1) * n_tn8) / tot);
+    if (a1 > a) { idx = a * 8 + (b & 7); return true; }
+    idx = (c - a) * 8 + (b & 7);
+    return false;
+}
+
+template <int BM, int BN, int NST>
+__global__ __launch_bounds__(256) void p3_bwd_pair_nt_kernel(P3NtParams pn, P3TnParams pt, int n_tn, int n_tn8, int n_nt8, int tn_sk, int nt_gx, int nt_sk) {
+    int idx;
+    if (p3_pair_split(blockIdx.x, n_tn8, n_nt8, idx)) {
+        if (idx < n_tn) p3_tn_body<64, 64, 1, 1>(pt, idx % tn_sk, idx / tn_sk);
+        return;
+    }
+    p3_nt_body<BM, BN, 4, 1, NST>(pn, idx % nt_gx, (idx / nt_gx) % nt_sk, idx / (nt_gx * nt_sk));
+}
+
+__global__ __launch_bounds__(256, 2) void p3_bwd_pair_c3_kernel(P3C3Params pc, P3TnParams pt, int n_tn, int n_tn8, int n_c38, int tn_sk, int c3_gx) {
+    int idx;
+    if (p3_pair_split(blockIdx.x, n_tn8, n_c38, idx)) {
+        if (idx < n_tn) p3_tn_body<64, 64, 1, 1>(pt, idx % tn_sk, idx / tn_sk);
+        return;
+    }
+    p3_c3_body(pc, idx % c3_gx, idx / c3_gx);
 }
 
 // ---- fp32 <-> P3 streaming conversions.  One thread = one 8-channel group.
@@ -1056,32 +1107,6 @@ __global__ __launch_bounds__(256) void p3_weight_prep_kernel(const long long* __
     }
 }
 
-// ---- probes (development): semantics of ds_read_b64_tr_b16 and of out-of-range / immediate-offset LDS-DMA
-__global__ void p3_probe_kernel(const unsigned short* g, int gbytes, unsigned short* out_tr, unsigned short* out_dma) {
-    __shared__ __attribute__((aligned(1024))) unsigned short sm[4096];
-    const int l = threadIdx.x;
-    for (int i = l; i < 4096; i += 64) sm[i] = (unsigned short)i;
-    __syncthreads();
-    typedef short s16x4 __attribute__((ext_vector_type(4)));
-    const s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(sm + l * 4));
-    for (int e = 0; e < 4; e++) out_tr[l * 4 + e] = (unsigned short)v[e];
-    // second pattern: lanes i/4 -> row stride 64 B (k rows), i%4 -> 8-byte column quads
-    const s16x4 v2 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(sm + (l >> 2) * 32 + (l & 3) * 4));
-    for (int e = 0; e < 4; e++) out_tr[256 + l * 4 + e] = (unsigned short)v2[e];
-    __syncthreads();
-    for (int i = l; i < 4096; i += 64) sm[i] = 0xffff;
-    __syncthreads();
-    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(g), 0, gbytes, 0x00020000);
-    // (a) lanes >= 32 out of range; (b) immediate offset 64; (c) scalar offset 128
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void*)(sm), 16, l < 32 ? l * 16 : 0x80000000u, 0, 0, 0);
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void*)(sm + 512), 16, l * 16, 0, 64, 0);
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void*)(sm + 1536), 16, l * 16, 128, 0, 0);
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void*)(sm + 2560), 16, l * 16, gbytes - 512, 0, 0);   // (d) is the scalar offset part of the range check?
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    for (int i = l; i < 3072; i += 64) out_dma[i] = sm[i];
-}
-
 // XCD array (xm x xn = 8) over an mtiles x ntiles grid minimising the bytes every L2 has to pull through the fabric: a_bytes * xn + b_bytes * xm.
 static void choose_xcd_array(int mtiles, int ntiles, double a_bytes, double b_bytes, int& xm, int& xn, long& grid_x) {
     static const int force = getenv("LDETR_P3_XN") ? atoi(getenv("LDETR_P3_XN")) : 0;
@@ -1095,62 +1120,76 @@ static void choose_xcd_array(int mtiles, int ntiles, double a_bytes, double b_by
     grid_x = 8L * cdiv(mtiles, xm) * cdiv(ntiles, xn);
 }
 
-template <int BM, int BN, int NW, int PF, int NST>
-static int launch_nt_cfg(P3NtParams& p, int sk, hipStream_t st) {
+static int env_int(const char* name, int dflt) { const char* v = getenv(name); return v ? atoi(v) : dflt; }
+
+static bool raise_lds(const void* kern, size_t lds, const char* what) {
+    if (lds <= 64 * 1024) return true;
+    if (hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+        set_error("%s: cannot raise the dynamic LDS limit to %zu bytes", what, lds);
+        return false;
+    }
+    return true;
+}
+
+// ---- gather kernel: tile grid, XCD array, split-K scratch of one configuration -> grid dimensions
+struct NtGrid { long gx; int sk, ncls; size_t lds; };
+
+template <int BM, int BN, int NW, int NST>
+static NtGrid plan_nt(P3NtParams& p, int sk) {
     p.mtiles = cdiv(p.M, BM); p.ntiles = cdiv(p.N, BN);
-    const int ncls = p.nclass > 1 ? p.nclass : 1;
+    NtGrid g; g.ncls = p.nclass > 1 ? p.nclass : 1;
     const long nt = (long)p.mtiles * p.ntiles;
-    long grid_x;
-    choose_xcd_array(p.mtiles, p.ntiles, (double)p.M * p.Cin * 6.0, (double)p.N * p.KH * p.KW * p.Cin * 6.0, p.xm, p.xn, grid_x);
+    choose_xcd_array(p.mtiles, p.ntiles, (double)p.M * p.Cin * 6.0, (double)p.N * p.KH * p.KW * p.Cin * 6.0, p.xm, p.xn, g.gx);
     if (sk > p.nkt) sk = p.nkt;
     if (sk < 1) sk = 1;
     p.splitk = sk; p.ws = nullptr; p.ws_count = nullptr;
-    if (sk > 1 && !splitk_ws_alloc(nt * ncls, (size_t)nt * ncls * sk * BM * BN * sizeof(float), &p.ws, &p.ws_count)) p.splitk = sk = 1;
+    if (sk > 1 && !splitk_ws_alloc(nt * g.ncls, (size_t)nt * g.ncls * sk * BM * BN * sizeof(float), &p.ws, &p.ws_count)) p.splitk = sk = 1;
+    g.sk = sk;
     constexpr int WGN_ = (NW == 8 && BN >= 128) ? 4 : 2, WM_ = BM / (NW / WGN_), WN_ = BN / WGN_;
-    constexpr size_t lds_loop = (size_t)NST * (BM + BN) * 192, lds_epi = (size_t)NW * WM_ * (WN_ + 4) * 4, lds = lds_loop > lds_epi ? lds_loop : lds_epi;
+    constexpr size_t lds_loop = (size_t)NST * (BM + BN) * 192, lds_epi = (size_t)NW * WM_ * (WN_ + 4) * 4;   // the epilogue stages the tile through LDS
+    g.lds = lds_loop > lds_epi ? lds_loop : lds_epi;
+    return g;
+}
+
+// split-K factor of a tile configuration: fill `slots` block slots, at least four k-tiles per slice
+static int nt_splitk(const P3NtParams& p, int bm, int bn, long slots) {
+    const long nt = (long)cdiv(p.M, bm) * cdiv(p.N, bn);
+    int sk = 1;
+    if (nt < slots * 3 / 4) { sk = (int)(slots / nt); if (sk > p.nkt / 4) sk = p.nkt / 4; if (sk > 16) sk = 16; if (sk < 1) sk = 1; }
+    const int force_sk = env_int("LDETR_P3_SK", 0);
+    return force_sk > 0 ? force_sk : sk;
+}
+
+template <int BM, int BN, int NW, int PF, int NST>
+static int launch_nt_cfg(P3NtParams& p, int sk, hipStream_t st) {
+    const NtGrid g = plan_nt<BM, BN, NW, NST>(p, sk);
     auto kern = p3_nt_kernel<BM, BN, NW, PF, NST>;
     static bool raised = false;
-    if (lds > 64 * 1024 && !raised) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
-            set_error("p3_nt: cannot raise the dynamic LDS limit to %zu bytes", lds);
-            return LDETR_ERR_LAUNCH;
-        }
-        raised = true;
-    }
-    hipLaunchKernelGGL(kern, dim3((unsigned)grid_x, sk, ncls), NW * 64, lds, st, p);
+    if (!raised) { if (!raise_lds(reinterpret_cast<const void*>(kern), g.lds, "p3_nt")) return LDETR_ERR_LAUNCH; raised = true; }
+    hipLaunchKernelGGL(kern, dim3((unsigned)g.gx, g.sk, g.ncls), NW * 64, g.lds, st, p);
     note_engine_launch(true);
     return check_launch("p3_nt");
 }
 
-static int launch_nt(P3NtParams& p, hipStream_t st) {
-    // tile configurations (LDS = 2 stages): 1 = 128x128, 8 waves (96 KiB: one block per CU); 2 = 128x64, 4 waves (72 KiB: two per CU);
-    // 3 = 64x64, 4 waves (48 KiB: three per CU); 4 = 128x128, 4 waves
-    static const int force_tile = getenv("LDETR_P3_TILE") ? atoi(getenv("LDETR_P3_TILE")) : 0;
-    static const int force_sk = getenv("LDETR_P3_SK") ? atoi(getenv("LDETR_P3_SK")) : 0;
-    auto tiles = [&](int a, int b) { return (long)cdiv(p.M, a) * cdiv(p.N, b); };
-    // (sweeps of the trunk shapes at 16 x 256^2, profiles/r04_p3_sweeps.txt: the global-load path of a CU, not the matrix pipe, bounds these
-    // launches, and small tiles keep more waves resident to cover it; 128-row tiles only pay when a 64 x 64 grid is many waves of blocks)
-    int cfg = p.M > 16384 ? 2 : 3;
+static int launch_nt(P3NtParams& p, bool forward, hipStream_t st) {
+    // Tile configurations: 1 = 128x128, 8 waves; 2 = 128x64, 4 waves; 3 = 64x64, 4 waves; 4 = 128x128, 4 waves.  One LDS stage (two barriers
+    // per k-tile, half the LDS: more blocks per CU) and one k-tile of register prefetch are the defaults: the sweeps over the trunk shapes at
+    // 16 x 256^2 (profiles/r04_p3_sweeps.txt: tile x prefetch depth x stage count) put 64x64 / one stage first on all but the large-grid
+    // forward shapes, where the 128x128 tile's halved operand traffic wins; deeper prefetch never paid (the loads are not what these short
+    // launches wait for: blocks run in lock-step through fill, loop and a chip-wide epilogue burst).
+    static const int force_tile = env_int("LDETR_P3_TILE", 0), force_pf = env_int("LDETR_P3_PF", 0), force_nst = env_int("LDETR_P3_NST", 0), force_slots = env_int("LDETR_P3_SLOTS", 0);
+    int cfg = 3;
+    if (forward && p.nclass <= 1 && ((p.M >= 65536 && p.N >= 128) || (p.M >= 16384 && p.N >= 256 && p.nkt <= 16))) cfg = 1;
     if (force_tile) cfg = force_tile;
     const int bm = cfg == 3 ? 64 : 128, bn = (cfg == 1 || cfg == 4) ? 128 : 64;
-    const long nt = tiles(bm, bn);
-    static const int force_slots = getenv("LDETR_P3_SLOTS") ? atoi(getenv("LDETR_P3_SLOTS")) : 0;
-    const long slots = force_slots ? force_slots : ((cfg == 2 || cfg == 3) ? 512 : 256);
-    int sk = 1;
-    if (nt < slots * 3 / 4) { sk = (int)(slots / nt); if (sk > p.nkt / 4) sk = p.nkt / 4; if (sk > 16) sk = 16; }
-    if (force_sk > 0) sk = force_sk;
-    static const int force_pf = getenv("LDETR_P3_PF") ? atoi(getenv("LDETR_P3_PF")) : 0;
-    const int pf = force_pf ? force_pf : 3;
-    static const int force_nst = getenv("LDETR_P3_NST") ? atoi(getenv("LDETR_P3_NST")) : 0;
-    const int nst = force_nst ? force_nst : 2;
+    const int sk = nt_splitk(p, bm, bn, force_slots ? force_slots : ((cfg == 2 || cfg == 3) ? 512 : 256));
+    const int pf = force_pf ? force_pf : 1, nst = force_nst ? force_nst : 1;
 #define P3_NT_CASE(BM_, BN_, NW_)                                                                                   \
     switch (pf * 2 + (nst == 1 ? 0 : 1)) {                                                                          \
         case 2: return launch_nt_cfg<BM_, BN_, NW_, 1, 1>(p, sk, st);                                               \
         case 3: return launch_nt_cfg<BM_, BN_, NW_, 1, 2>(p, sk, st);                                               \
         case 4: return launch_nt_cfg<BM_, BN_, NW_, 2, 1>(p, sk, st);                                               \
-        case 5: return launch_nt_cfg<BM_, BN_, NW_, 2, 2>(p, sk, st);                                               \
-        case 6: return launch_nt_cfg<BM_, BN_, NW_, 3, 1>(p, sk, st);                                               \
-        default: return launch_nt_cfg<BM_, BN_, NW_, 3, 2>(p, sk, st);                                              \
+        default: return launch_nt_cfg<BM_, BN_, NW_, 2, 2>(p, sk, st);                                              \
     }
     switch (cfg) {
         case 1: P3_NT_CASE(128, 128, 8)
@@ -1159,56 +1198,6 @@ static int launch_nt(P3NtParams& p, hipStream_t st) {
         default: P3_NT_CASE(128, 128, 4)
     }
 #undef P3_NT_CASE
-}
-
-// Development probe: LDS-DMA throughput of one access shape.  Every wave of a 256-thread block walks `iters` k-steps along its own 64*16/SEG
-// rows (row pitch `pitch` bytes), fetching SEG contiguous bytes per row and step (SEG/16 lanes per row), PIECES instructions per step into a
-// 4-deep LDS ring (nothing reads the LDS: this measures the global -> LDS path alone).
-template <int SEG>
-__global__ __launch_bounds__(256) void p3_dma_probe_kernel(const char* src, unsigned bytes, int pitch, int iters, int pieces, int rows_total) {
-    extern __shared__ __attribute__((aligned(1024))) char p3_smem[];
-    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    constexpr int LPR = SEG / 16, RPI = 64 / LPR;   // lanes per row, rows per instruction
-    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(src), 0, bytes, 0x00020000);
-    const int row0 = (int)(((long)blockIdx.x * 4 + w) * RPI * pieces % rows_total);
-    for (int it = 0; it < iters; it++) {
-        const int koff = (it * SEG) % pitch;
-        for (int q = 0; q < pieces; q++) {
-            const int row = (row0 + q * RPI + lane / LPR) % rows_total;
-            const unsigned vo = (unsigned)row * (unsigned)pitch + (lane % LPR) * 16;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void*)(p3_smem + ((w * 4 + (it & 3)) * 8 + (q & 7)) * 1024), 16, vo, koff, 0, 0);
-        }
-        if (it >= 3) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");   // <= 3 steps x 8 pieces in flight (pieces <= 8)
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-}
-
-// The same walk with register staging: buffer_load_dwordx4 into VGPRs, ds_write_b128 one step later (two register sets).
-template <int SEG, int PIECES>
-__global__ __launch_bounds__(256) void p3_reg_probe_kernel(const char* src, unsigned bytes, int pitch, int iters, int rows_total) {
-    extern __shared__ __attribute__((aligned(1024))) char p3_smem[];
-    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    constexpr int LPR = SEG / 16, RPI = 64 / LPR;
-    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(src), 0, bytes, 0x00020000);
-    const int row0 = (int)(((long)blockIdx.x * 4 + w) * RPI * PIECES % rows_total);
-    unsigned vo[PIECES];
-#pragma unroll
-    for (int q = 0; q < PIECES; q++) vo[q] = (unsigned)((row0 + q * RPI + lane / LPR) % rows_total) * (unsigned)pitch + (lane % LPR) * 16;
-    u32x4 ra[PIECES], rb[PIECES];
-#pragma unroll
-    for (int q = 0; q < PIECES; q++) ra[q] = __builtin_amdgcn_raw_buffer_load_b128(rs, vo[q], 0, 0);
-    for (int it = 0; it < iters; it += 2) {
-        const int k1 = ((it + 1) * SEG) % pitch, k2 = ((it + 2) * SEG) % pitch;
-#pragma unroll
-        for (int q = 0; q < PIECES; q++) rb[q] = __builtin_amdgcn_raw_buffer_load_b128(rs, vo[q], k1, 0);
-#pragma unroll
-        for (int q = 0; q < PIECES; q++) *reinterpret_cast<u32x4*>(p3_smem + ((w * 2 + 0) * PIECES + q) * 1024 + lane * 16) = ra[q];
-#pragma unroll
-        for (int q = 0; q < PIECES; q++) ra[q] = __builtin_amdgcn_raw_buffer_load_b128(rs, vo[q], k2, 0);
-#pragma unroll
-        for (int q = 0; q < PIECES; q++) *reinterpret_cast<u32x4*>(p3_smem + ((w * 2 + 1) * PIECES + q) * 1024 + lane * 16) = rb[q];
-    }
-    if (ra[0][0] == 0x12345678u) p3_smem[0] = 1;
 }
 
 // 3x3 / stride 1 / pad 1 on pixel patches: returns false when the geometry does not fit (the caller then takes the gather kernel).
@@ -1228,33 +1217,33 @@ static bool c3_geometry(int N, int H, int W, P3C3Params& p) {
     return true;
 }
 
-static int launch_c3(P3C3Params& p, hipStream_t st) {
+// tile grid, split-K scratch, XCD array of the patch kernel -> grid_x (grid = (grid_x, splitk))
+static long plan_c3(P3C3Params& p) {
     p.ntiles = cdiv(p.Nout, 64);
     const long nt = (long)p.mtiles * p.ntiles;
     int sk = 1;
-    static const int force_sk = getenv("LDETR_P3_SK") ? atoi(getenv("LDETR_P3_SK")) : 0;
+    const int force_sk = env_int("LDETR_P3_SK", 0);
     if (nt < 384) { sk = (int)(512 / nt); if (sk > p.ncc / 2) sk = p.ncc / 2; if (sk > 16) sk = 16; if (sk < 1) sk = 1; }
     if (force_sk > 0) sk = force_sk;
     if (sk > p.ncc) sk = p.ncc;
     p.splitk = sk; p.ws = nullptr; p.ws_count = nullptr;
     if (sk > 1 && !splitk_ws_alloc(nt, (size_t)nt * sk * 128 * 64 * sizeof(float), &p.ws, &p.ws_count)) p.splitk = sk = 1;
-    static bool raised = false;
-    if (!raised) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&p3_c3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, C3_LDS) != hipSuccess) {
-            set_error("p3_c3: cannot raise the dynamic LDS limit to %d bytes", C3_LDS);
-            return LDETR_ERR_LAUNCH;
-        }
-        raised = true;
-    }
     long grid_x;
     choose_xcd_array(p.mtiles, p.ntiles, (double)p.N_img * p.H * p.W * p.Cin * 6.0, (double)p.Nout * 9 * p.Cin * 6.0, p.xm, p.xn, grid_x);
-    hipLaunchKernelGGL(p3_c3_kernel, dim3((unsigned)grid_x, sk, 1), 256, C3_LDS, st, p);
+    return grid_x;
+}
+
+static int launch_c3(P3C3Params& p, hipStream_t st) {
+    const long grid_x = plan_c3(p);
+    static bool raised = false;
+    if (!raised) { if (!raise_lds(reinterpret_cast<const void*>(&p3_c3_kernel), C3_LDS, "p3_c3")) return LDETR_ERR_LAUNCH; raised = true; }
+    hipLaunchKernelGGL(p3_c3_kernel, dim3((unsigned)grid_x, p.splitk, 1), 256, C3_LDS, st, p);
     note_engine_launch(true);
     return check_launch("p3_c3");
 }
 
 static bool c3_enabled() {
-    static const int on = getenv("LDETR_P3_PATCH") ? atoi(getenv("LDETR_P3_PATCH")) : 1;
+    static const int on = env_int("LDETR_P3_PATCH", 1);
     return on != 0;
 }
 
@@ -1264,6 +1253,109 @@ static void fill_epi(P3Epi& e, const ldetr_p3_epilogue* s) {
     if (!s) return;
     e.alpha = s->alpha; e.col_scale = s->col_scale; e.col_bias = s->col_bias;
     e.res_p3 = (const char*)s->residual_p3; e.res_f32 = s->residual_f32; e.mask_p3 = (const char*)s->relu_mask_p3; e.relu = s->relu;
+}
+
+// ---- weight gradient: pixel-slice count of a tile configuration
+template <int BM, int BN>
+static void plan_tn(P3TnParams& p, int target_blocks) {
+    p.mtiles = cdiv(p.Cout, BM); p.ntiles = cdiv(p.Cin, BN);
+    const long nt = (long)p.mtiles * p.ntiles * p.KH * p.KW;
+    const int nkt = (p.npix + 31) / 32;
+    int sk = (int)((target_blocks + nt - 1) / nt);
+    if (sk > nkt / 4) sk = nkt / 4;
+    if (sk >= 8) sk = (sk + 4) / 8 * 8;   // a multiple of the XCD count: slice s -> XCD s % 8
+    if (sk < 1) sk = 1;
+    const int force_sk = env_int("LDETR_P3_WSK", 0);
+    if (force_sk > 0) sk = std::min(force_sk, nkt);
+    p.splitk = sk;
+}
+
+template <int BM, int BN, int PF, int NST>
+static int launch_tn_cfg(P3TnParams& p, int target_blocks, hipStream_t st) {
+    plan_tn<BM, BN>(p, target_blocks);
+    const long nt = (long)p.mtiles * p.ntiles * p.KH * p.KW;
+    constexpr size_t lds_loop = (size_t)NST * (BM + BN) * 192, lds_cold = (size_t)(BM / 64) * (BN / 64) * 4096 * 4;   // (the cold path's accumulator image)
+    constexpr size_t lds = lds_loop > lds_cold ? lds_loop : lds_cold;
+    auto kern = p3_tn_kernel<BM, BN, PF, NST>;
+    static bool raised = false;
+    if (!raised) { if (!raise_lds(reinterpret_cast<const void*>(kern), lds, "p3_tn")) return LDETR_ERR_LAUNCH; raised = true; }
+    hipLaunchKernelGGL(kern, dim3(p.splitk, (unsigned)nt, 1), 256, lds, st, p);
+    note_engine_launch(true);
+    return check_launch("p3_tn");
+}
+
+static int launch_tn(P3TnParams& p, hipStream_t st) {
+    static const int force_tile = env_int("LDETR_P3_WTILE", 0), force_pf = env_int("LDETR_P3_WPF", 0), force_nst = env_int("LDETR_P3_WNST", 0), force_tb = env_int("LDETR_P3_WSLOTS", 0);
+    const int cfg = force_tile ? force_tile : 3;   // 64 x 64: the most resident waves per CU (sweep: 1179 us over the trunk shapes against 1580-1940 for the wider tiles)
+    const int pf = force_pf ? force_pf : 1, nst = force_nst ? force_nst : 1;   // one LDS stage, one pixel tile in flight: 1193 us; two stages / two tiles: 1222-1243 us
+#define P3_TN_CASE(BM_, BN_, TB_)                                                                            \
+    switch (pf * 2 + (nst == 1 ? 0 : 1)) {                                                                   \
+        case 2: return launch_tn_cfg<BM_, BN_, 1, 1>(p, force_tb ? force_tb : TB_, st);                      \
+        case 3: return launch_tn_cfg<BM_, BN_, 1, 2>(p, force_tb ? force_tb : TB_, st);                      \
+        case 4: return launch_tn_cfg<BM_, BN_, 2, 1>(p, force_tb ? force_tb : TB_, st);                      \
+        default: return launch_tn_cfg<BM_, BN_, 2, 2>(p, force_tb ? force_tb : TB_, st);                     \
+    }
+    switch (cfg) {
+        case 1: P3_TN_CASE(128, 128, 256)
+        case 2: P3_TN_CASE(128, 64, 256)
+        default: P3_TN_CASE(64, 64, 512)
+    }
+#undef P3_TN_CASE
+}
+
+// ---- operand set-up shared by the single and the paired entry points
+static int setup_bwd_data(const void* dy, int N, int OH, int OW, int Cout, const void* wb, int Cin, int KH, int KW, int stride, int pad, int IH, int IW,
+                          const ldetr_p3_epilogue* ep, void* out_p3, float* out_f32, bool& use_c3, P3C3Params& c, P3NtParams& p) {
+    LDETR_CHECK(dy && wb && (out_p3 || out_f32), "p3_conv2d_bwd_data: null operand");
+    LDETR_CHECK(Cout % 32 == 0 && Cin % 8 == 0 && KH * KW <= 32 && pad < KH && pad < KW && (stride == 1 || stride == 2),
+                "p3_conv2d_bwd_data: unsupported geometry (Cin=%d Cout=%d k=%dx%d stride=%d pad=%d)", Cin, Cout, KH, KW, stride, pad);
+    const long dybytes = (long)N * OH * OW * Cout * 6, wbytes = (long)Cin * KH * KW * Cout * 6;
+    use_c3 = false;
+    if (KH == 3 && KW == 3 && stride == 1 && pad == 1 && OH == IH && OW == IW && dybytes < 0x7fffffffL && wbytes < 0x7fffffffL && c3_enabled()) {
+        memset(&c, 0, sizeof(c));
+        if (c3_geometry(N, IH, IW, c)) {   // dx = conv(dy, wb) with mirrored taps: source pixel = dst + 1 - k
+            c.X = (const char*)dy; c.x_bytes = (unsigned)dybytes; c.Wt = (const char*)wb; c.w_bytes = (unsigned)wbytes;
+            c.Cin = Cout; c.Nout = Cin; c.flip = 1; c.ncc = Cout / 32;
+            fill_epi(c.ep, ep); c.ep.out_p3 = (char*)out_p3; c.ep.out_f32 = out_f32;
+            use_c3 = true;
+            return LDETR_OK;
+        }
+    }
+    memset(&p, 0, sizeof(p));
+    p.B = (const char*)wb; p.b_bytes = (unsigned)wbytes;
+    p.N = Cin; p.Cin = Cout; p.KH = KH; p.KW = KW; p.stride = stride; p.pad = pad; p.H = OH; p.W = OW;
+    p.out_H = IH; p.out_W = IW; p.out_step = stride; p.tap_mode = 1; p.tstep = stride; p.nimg = N;
+    fill_epi(p.ep, ep); p.ep.out_p3 = (char*)out_p3; p.ep.out_f32 = out_f32;
+    const long max_shift = ((long)(KH - 1) * OW + (KW - 1)) * Cout * 6;
+    LDETR_CHECK(dybytes + max_shift < 0x7fffffffL && wbytes < 0x7fffffffL, "p3_conv2d_bwd_data: tensor too large for 31-bit buffer offsets");
+    if (stride == 1) {
+        p.kh0 = 0; p.kw0 = 0; p.nty = KH; p.ntx = KW;
+        p.A = (const char*)dy - max_shift; p.a_bytes = (unsigned)(dybytes + max_shift);
+        p.OH = IH; p.OW = IW; p.M = N * IH * IW; p.nkt = KH * KW * Cout / 32; p.nclass = 1;
+    } else {
+        // sized for the heaviest class (py, px) = (stride - 1, ...): the kernel derives every class's own taps, grid and shift from its class index
+        p.A = (const char*)dy; p.a_bytes = (unsigned)dybytes;
+        p.OH = (IH + stride - 1) / stride; p.OW = (IW + stride - 1) / stride; p.M = N * p.OH * p.OW;
+        p.nkt = ((KH + stride - 1) / stride) * ((KW + stride - 1) / stride) * Cout / 32; p.nclass = stride * stride;
+        if (p.nkt == 0) p.nkt = 1;
+    }
+    return LDETR_OK;
+}
+
+static int setup_bwd_weight(const void* x, int N, int H, int W, int Cin, const void* dy, int Cout, int KH, int KW, int stride, int pad,
+                            const float* dy_scale, float* dw, P3TnParams& p) {
+    const int OH = (H + 2 * pad - KH) / stride + 1, OW = (W + 2 * pad - KW) / stride + 1;
+    LDETR_CHECK(x && dy && dw, "p3_conv2d_bwd_weight: null operand");
+    LDETR_CHECK(Cin % 32 == 0 && Cout % 32 == 0 && pad < KH && pad < KW && (stride == 1 || stride == 2),
+                "p3_conv2d_bwd_weight: unsupported geometry (Cin=%d Cout=%d k=%dx%d stride=%d pad=%d)", Cin, Cout, KH, KW, stride, pad);
+    const long xbytes = (long)N * H * W * Cin * 6, dybytes = (long)N * OH * OW * Cout * 6, pad_off = ((long)pad * W + pad) * Cin * 6;
+    LDETR_CHECK(xbytes + pad_off < 0x7fffffffL && dybytes < 0x7fffffffL && (long)N * OH * OW < (1L << 24), "p3_conv2d_bwd_weight: tensor too large for 31-bit buffer offsets");
+    memset(&p, 0, sizeof(p));
+    p.dY = (const char*)dy; p.dy_bytes = (unsigned)dybytes; p.X = (const char*)x - pad_off; p.x_bytes = (unsigned)(xbytes + pad_off);
+    p.Cout = Cout; p.Cin = Cin; p.KH = KH; p.KW = KW; p.stride = stride; p.pad = pad; p.H = H; p.W = W; p.OH = OH; p.OW = OW;
+    p.npix = N * OH * OW; p.inv_ohw = 1.0f / (float)(OH * OW); p.inv_ow = 1.0f / (float)OW;
+    p.row_scale = dy_scale; p.alpha = 1.f; p.dW = dw;
+    return LDETR_OK;
 }
 
 }  // namespace ldetr
@@ -1326,131 +1418,71 @@ extern "C" int ldetr_p3_conv2d_fwd(const void* x, int N, int H, int W, int Cin, 
     p.nkt = KH * KW * Cin / 32;
     fill_epi(p.ep, ep); p.ep.out_p3 = (char*)out_p3; p.ep.out_f32 = out_f32;
     if (p.M == 0) return LDETR_OK;
-    return launch_nt(p, (hipStream_t)stream);
+    return launch_nt(p, true, (hipStream_t)stream);
 }
 
 // dx[n][iy][ix][ci] = sum dy[n][(iy + pad - kh) / stride][(ix + pad - kw) / stride][co] * wb[ci][kh][kw][co] over the taps that divide:
-// one launch per parity class of (iy, ix) (stride^2 classes; a class without taps still runs its epilogue, e.g. writes the residual).
+// the stride^2 parity classes of (iy, ix) are one launch (a class without taps still runs its epilogue, e.g. writes the residual).
 extern "C" int ldetr_p3_conv2d_bwd_data(const void* dy, int N, int OH, int OW, int Cout, const void* wb, int Cin, int KH, int KW, int stride, int pad,
                                         int IH, int IW, const ldetr_p3_epilogue* ep, void* out_p3, float* out_f32, void* stream) {
-    LDETR_CHECK(dy && wb && (out_p3 || out_f32), "p3_conv2d_bwd_data: null operand");
-    LDETR_CHECK(Cout % 32 == 0 && Cin % 8 == 0 && KH * KW <= 32 && pad < KH && pad < KW && (stride == 1 || stride == 2),
-                "p3_conv2d_bwd_data: unsupported geometry (Cin=%d Cout=%d k=%dx%d stride=%d pad=%d)", Cin, Cout, KH, KW, stride, pad);
-    const long dybytes = (long)N * OH * OW * Cout * 6, wbytes = (long)Cin * KH * KW * Cout * 6;
-    if (KH == 3 && KW == 3 && stride == 1 && pad == 1 && OH == IH && OW == IW && dybytes < 0x7fffffffL && wbytes < 0x7fffffffL && c3_enabled()) {
-        P3C3Params c; memset(&c, 0, sizeof(c));
-        if (c3_geometry(N, IH, IW, c)) {   // dx = conv(dy, wb) with mirrored taps: source pixel = dst + 1 - k
-            c.X = (const char*)dy; c.x_bytes = (unsigned)dybytes; c.Wt = (const char*)wb; c.w_bytes = (unsigned)wbytes;
-            c.Cin = Cout; c.Nout = Cin; c.flip = 1; c.ncc = Cout / 32;
-            fill_epi(c.ep, ep); c.ep.out_p3 = (char*)out_p3; c.ep.out_f32 = out_f32;
-            return launch_c3(c, (hipStream_t)stream);
-        }
-    }
-    P3NtParams p; memset(&p, 0, sizeof(p));
-    p.B = (const char*)wb; p.b_bytes = (unsigned)wbytes;
-    p.N = Cin; p.Cin = Cout; p.KH = KH; p.KW = KW; p.stride = stride; p.pad = pad; p.H = OH; p.W = OW;
-    p.out_H = IH; p.out_W = IW; p.out_step = stride; p.tap_mode = 1; p.tstep = stride; p.nimg = N;
-    fill_epi(p.ep, ep); p.ep.out_p3 = (char*)out_p3; p.ep.out_f32 = out_f32;
-    const long max_shift = ((long)(KH - 1) * OW + (KW - 1)) * Cout * 6;
-    LDETR_CHECK(dybytes + max_shift < 0x7fffffffL && wbytes < 0x7fffffffL, "p3_conv2d_bwd_data: tensor too large for 31-bit buffer offsets");
-    if (stride == 1) {
-        p.kh0 = 0; p.kw0 = 0; p.nty = KH; p.ntx = KW;
-        p.A = (const char*)dy - max_shift; p.a_bytes = (unsigned)(dybytes + max_shift);
-        p.OH = IH; p.OW = IW; p.M = N * IH * IW; p.nkt = KH * KW * Cout / 32; p.nclass = 1;
-    } else {
-        // sized for the heaviest class (py, px) = (stride - 1, ...): the kernel derives every class's own taps, grid and shift from blockIdx.z
-        p.A = (const char*)dy; p.a_bytes = (unsigned)dybytes;
-        p.OH = (IH + stride - 1) / stride; p.OW = (IW + stride - 1) / stride; p.M = N * p.OH * p.OW;
-        p.nkt = ((KH + stride - 1) / stride) * ((KW + stride - 1) / stride) * Cout / 32; p.nclass = stride * stride;
-        if (p.nkt == 0) p.nkt = 1;
-    }
+    bool use_c3; P3C3Params c; P3NtParams p;
+    const int rc = setup_bwd_data(dy, N, OH, OW, Cout, wb, Cin, KH, KW, stride, pad, IH, IW, ep, out_p3, out_f32, use_c3, c, p);
+    if (rc != LDETR_OK) return rc;
+    if (use_c3) return launch_c3(c, (hipStream_t)stream);
     if (p.M == 0) return LDETR_OK;
-    return launch_nt(p, (hipStream_t)stream);
-}
-
-template <int BM, int BN, int PF>
-static int launch_tn_cfg(P3TnParams& p, int target_blocks, hipStream_t st) {
-    p.mtiles = cdiv(p.Cout, BM); p.ntiles = cdiv(p.Cin, BN);
-    const long nt = (long)p.mtiles * p.ntiles * p.KH * p.KW;
-    const int nkt = (p.npix + 31) / 32;
-    int sk = (int)((target_blocks + nt - 1) / nt);
-    if (sk > nkt / 4) sk = nkt / 4;
-    if (sk >= 8) sk = (sk + 4) / 8 * 8;   // a multiple of the XCD count: slice s -> XCD s % 8
-    if (sk < 1) sk = 1;
-    static const int force_sk = getenv("LDETR_P3_WSK") ? atoi(getenv("LDETR_P3_WSK")) : 0;
-    if (force_sk > 0) sk = std::min(force_sk, nkt);
-    p.splitk = sk;
-    constexpr size_t lds = (size_t)2 * (BM + BN) * 192;
-    auto kern = p3_tn_kernel<BM, BN, PF>;
-    static bool raised = false;
-    if (lds > 64 * 1024 && !raised) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
-            set_error("p3_tn: cannot raise the dynamic LDS limit to %zu bytes", lds);
-            return LDETR_ERR_LAUNCH;
-        }
-        raised = true;
-    }
-    hipLaunchKernelGGL(kern, dim3(sk, (unsigned)nt, 1), 256, lds, st, p);
-    note_engine_launch(true);
-    return check_launch("p3_tn");
+    return launch_nt(p, false, (hipStream_t)stream);
 }
 
 extern "C" int ldetr_p3_conv2d_bwd_weight(const void* x, int N, int H, int W, int Cin, const void* dy, int Cout, int KH, int KW, int stride, int pad,
                                           const float* dy_scale, float* dw, void* stream) {
-    const int OH = (H + 2 * pad - KH) / stride + 1, OW = (W + 2 * pad - KW) / stride + 1;
-    LDETR_CHECK(x && dy && dw, "p3_conv2d_bwd_weight: null operand");
-    LDETR_CHECK(Cin % 32 == 0 && Cout % 32 == 0 && pad < KH && pad < KW && (stride == 1 || stride == 2),
-                "p3_conv2d_bwd_weight: unsupported geometry (Cin=%d Cout=%d k=%dx%d stride=%d pad=%d)", Cin, Cout, KH, KW, stride, pad);
-    const long xbytes = (long)N * H * W * Cin * 6, dybytes = (long)N * OH * OW * Cout * 6, pad_off = ((long)pad * W + pad) * Cin * 6;
-    LDETR_CHECK(xbytes + pad_off < 0x7fffffffL && dybytes < 0x7fffffffL && (long)N * OH * OW < (1L << 24), "p3_conv2d_bwd_weight: tensor too large for 31-bit buffer offsets");
-    P3TnParams p; memset(&p, 0, sizeof(p));
-    p.dY = (const char*)dy; p.dy_bytes = (unsigned)dybytes; p.X = (const char*)x - pad_off; p.x_bytes = (unsigned)(xbytes + pad_off);
-    p.Cout = Cout; p.Cin = Cin; p.KH = KH; p.KW = KW; p.stride = stride; p.pad = pad; p.H = H; p.W = W; p.OH = OH; p.OW = OW;
-    p.npix = N * OH * OW; p.inv_ohw = 1.0f / (float)(OH * OW); p.inv_ow = 1.0f / (float)OW;
-    p.row_scale = dy_scale; p.alpha = 1.f; p.dW = dw;
+    P3TnParams p;
+    const int rc = setup_bwd_weight(x, N, H, W, Cin, dy, Cout, KH, KW, stride, pad, dy_scale, dw, p);
+    if (rc != LDETR_OK) return rc;
     if (p.npix == 0) return LDETR_OK;
-    static const int force_tile = getenv("LDETR_P3_WTILE") ? atoi(getenv("LDETR_P3_WTILE")) : 0;
-    int cfg = 3;   // 64 x 64: the most resident waves per CU (sweep: 48-50 us against 58-84 for the wider tiles on the trunk's 3x3 shapes)
-    if (force_tile) cfg = force_tile;
-    static const int force_pf = getenv("LDETR_P3_WPF") ? atoi(getenv("LDETR_P3_WPF")) : 0;
-    const int pf = force_pf ? force_pf : 3;
-#define P3_TN_CASE(BM_, BN_, TB_)                                                                \
-    switch (pf) {                                                                                \
-        case 1: return launch_tn_cfg<BM_, BN_, 1>(p, TB_, (hipStream_t)stream);                  \
-        case 2: return launch_tn_cfg<BM_, BN_, 2>(p, TB_, (hipStream_t)stream);                  \
-        case 3: return launch_tn_cfg<BM_, BN_, 3>(p, TB_, (hipStream_t)stream);                  \
-        default: return launch_tn_cfg<BM_, BN_, 4>(p, TB_, (hipStream_t)stream);                 \
-    }
-    switch (cfg) {
-        case 1: P3_TN_CASE(128, 128, 256)
-        case 2: P3_TN_CASE(128, 64, 256)
-        default: P3_TN_CASE(64, 64, 512)
-    }
-#undef P3_TN_CASE
+    return launch_tn(p, (hipStream_t)stream);
 }
 
-extern "C" int ldetr_p3_dma_probe(const void* src, int64_t bytes, int seg, int pitch, int iters, int pieces, int blocks, void* stream) {
-    const int rows_total = (int)(bytes / pitch);
+// Both gradients of one convolution (ldetr_p3_conv2d_bwd_data + ldetr_p3_conv2d_bwd_weight, same arguments) as ONE launch when the two
+// kernels can share a grid (p3_bwd_pair_*_kernel), else as the two launches.  *launches (optional) receives the number of launches made.
+extern "C" int ldetr_p3_conv2d_bwd_pair(const void* dy, int N, int OH, int OW, int Cout, const void* wb, const void* x, int Cin, int KH, int KW, int stride, int pad,
+                                        int IH, int IW, const ldetr_p3_epilogue* ep, void* dx_p3, float* dx_f32, const float* dy_scale, float* dw,
+                                        int* launches, void* stream) {
     hipStream_t st = (hipStream_t)stream;
-    const size_t lds = 4 * 4 * 8 * 1024;
-#define P3_PROBE(S)                                                                                                           \
-    do {                                                                                                                      \
-        static bool raised = false;                                                                                           \
-        if (!raised) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&p3_dma_probe_kernel<S>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); raised = true; } \
-        hipLaunchKernelGGL((p3_dma_probe_kernel<S>), dim3(blocks), dim3(256), lds, st, (const char*)src, (unsigned)bytes, pitch, iters, pieces, rows_total); \
-    } while (0)
-    if (pieces < 0) {   // register-staged variant, 6 pieces
-        if (seg == 64) hipLaunchKernelGGL((p3_reg_probe_kernel<64, 6>), dim3(blocks), dim3(256), 64 * 1024, st, (const char*)src, (unsigned)bytes, pitch, iters, rows_total);
-        else hipLaunchKernelGGL((p3_reg_probe_kernel<256, 6>), dim3(blocks), dim3(256), 64 * 1024, st, (const char*)src, (unsigned)bytes, pitch, iters, rows_total);
-        return check_launch("p3_reg_probe");
+    bool use_c3; P3C3Params c; P3NtParams pn; P3TnParams pt;
+    int rc = setup_bwd_data(dy, N, OH, OW, Cout, wb, Cin, KH, KW, stride, pad, IH, IW, ep, dx_p3, dx_f32, use_c3, c, pn);
+    if (rc != LDETR_OK) return rc;
+    rc = setup_bwd_weight(x, N, IH, IW, Cin, dy, Cout, KH, KW, stride, pad, dy_scale, dw, pt);
+    if (rc != LDETR_OK) return rc;
+    LDETR_CHECK(pt.OH == OH && pt.OW == OW, "p3_conv2d_bwd_pair: dy is %dx%d but the geometry gives %dx%d", OH, OW, pt.OH, pt.OW);
+    if (launches) *launches = 0;
+    if (pt.npix == 0) return LDETR_OK;
+    static const int pair_on = env_int("LDETR_P3_PAIR", 3);   // bit 0: gather kernel + weight gradient, bit 1: patch kernel + weight gradient
+    const bool forced = env_int("LDETR_P3_TILE", 0) || env_int("LDETR_P3_WTILE", 0) || env_int("LDETR_P3_PF", 0) || env_int("LDETR_P3_WPF", 0) || env_int("LDETR_P3_NST", 0);
+    if (!forced && ((use_c3 && (pair_on & 2)) || (!use_c3 && (pair_on & 1)))) {
+        static const int order = env_int("LDETR_P3_PAIR_ORDER", 0) ? 1 : -1;   // 0: the weight gradient's blocks first (0.85 of the two launches over the trunk shapes), 1: interleaved (0.98)
+        plan_tn<64, 64>(pt, env_int("LDETR_P3_WSLOTS", 512));
+        const long n_tn = (long)pt.splitk * pt.mtiles * pt.ntiles * pt.KH * pt.KW, n_tn_pad = (n_tn + 7) / 8 * 8;
+        constexpr size_t lds_tn = (size_t)1 * (64 + 64) * 192;   // one LDS stage for the weight gradient's blocks: more blocks of either kind per CU
+        if (use_c3) {
+            const long gx = plan_c3(c);
+            const size_t lds = C3_LDS > lds_tn ? (size_t)C3_LDS : lds_tn;
+            static bool raised = false;
+            if (!raised) { if (!raise_lds(reinterpret_cast<const void*>(&p3_bwd_pair_c3_kernel), lds, "p3_bwd_pair_c3")) return LDETR_ERR_LAUNCH; raised = true; }
+            hipLaunchKernelGGL(p3_bwd_pair_c3_kernel, dim3((unsigned)(n_tn_pad + gx * c.splitk)), 256, lds, st, c, pt, (int)n_tn, order * (int)(n_tn_pad / 8), (int)(gx * c.splitk / 8),
+                               pt.splitk, (int)gx);
+        } else {
+            const NtGrid g = plan_nt<64, 64, 4, 1>(pn, nt_splitk(pn, 64, 64, 512));
+            const size_t lds = g.lds > lds_tn ? g.lds : lds_tn;
+            hipLaunchKernelGGL((p3_bwd_pair_nt_kernel<64, 64, 1>), dim3((unsigned)(n_tn_pad + g.gx * g.sk * g.ncls)), 256, lds, st, pn, pt, (int)n_tn, order * (int)(n_tn_pad / 8),
+                               (int)(g.gx * g.sk * g.ncls / 8), pt.splitk, (int)g.gx, g.sk);
+        }
+        note_engine_launch(true);
+        if (launches) *launches = 1;
+        return check_launch("p3_bwd_pair");
     }
-    if (seg == 64) P3_PROBE(64); else if (seg == 128) P3_PROBE(128); else if (seg == 256) P3_PROBE(256); else if (seg == 1024) P3_PROBE(1024);
-    else { set_error("p3_dma_probe: seg must be 64, 128, 256 or 1024"); return LDETR_ERR_ARG; }
-#undef P3_PROBE
-    return check_launch("p3_dma_probe");
-}
-
-extern "C" int ldetr_p3_probe(const void* g, int gbytes, void* out_tr, void* out_dma, void* stream) {
-    hipLaunchKernelGGL(p3_probe_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (const unsigned short*)g, gbytes, (unsigned short*)out_tr, (unsigned short*)out_dma);
-    return check_launch("p3_probe");
+    rc = launch_tn(pt, st);
+    if (rc != LDETR_OK) return rc;
+    rc = use_c3 ? launch_c3(c, st) : (pn.M == 0 ? LDETR_OK : launch_nt(pn, false, st));
+    if (launches) *launches = 2;
+    return rc;
 }

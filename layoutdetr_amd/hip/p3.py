@@ -178,6 +178,23 @@ class _ConvP3Fn(torch.autograd.Function):
         need_res = has_res and ctx.needs_input_grad[6]
         dx = None
         flops = 2.0 * N * OH * OW * O * KH * KW * I
+        if need_x and need_w:
+            # both gradients in one launch (ldetr_p3_conv2d_bwd_pair): the weight gradient accumulates straight into the flat .grad when it can
+            wparam = ctx.wparam
+            gw = core.flat_grad(wparam)
+            if gw is not None and gw.permute(0, 2, 3, 1).is_contiguous():
+                dw_buf, dw = gw, None
+            else:
+                dw_buf = torch.zeros((O, I, KH, KW), device=x.device, dtype=torch.float32).contiguous(memory_format=torch.channels_last)
+                dw = dw_buf
+            dx = p3_empty(N, H, W, I, x.device)
+            dxp = dx_pass.contiguous() if dx_pass is not None else None
+            ep = _epi(residual_p3=dxp, mask_p3=x if mask_input else None)
+            core.engine_call('ldetr_p3_conv2d_bwd_pair', 2.0 * flops, lambda: core.check(core.lib().ldetr_p3_conv2d_bwd_pair(
+                core.ptr(dyp), N, OH, OW, O, ctypes.c_void_p(wbwd), core.ptr(x), I, KH, KW, stride, pad, H, W, ctypes.byref(ep), core.ptr(dx), None,
+                core.ptr(sc), core.ptr(dw_buf), None, core.stream()), 'p3_conv2d_bwd_pair'),
+                nbytes=6.0 * (dyp.numel() // 3 + wparam.numel() + 2 * N * H * W * I) + 6.0 * (x.numel() // 3) + 4.0 * wparam.numel())
+            return (dx, dw, None, None, None, None, dyp if need_res else None) + (None,) * 7
         if need_x:
             dx = p3_empty(N, H, W, I, x.device)
             dxp = dx_pass.contiguous() if dx_pass is not None else None

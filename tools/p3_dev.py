@@ -1,5 +1,5 @@
 """Development driver of the plane-format engine (csrc/p3_engine.hip): probes, parity against fp64 torch, timings.
-Usage: python tools/p3_dev.py [probe] [check] [bench]"""
+Usage: python tools/p3_dev.py [check] [checkb] [bench] [benchb | benchd | benchw] [pair [graph]]"""
 import ctypes, sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -32,69 +32,6 @@ def timeit(fn, n=20):
     s = torch.cuda.Event(enable_timing=True); e = torch.cuda.Event(enable_timing=True)
     s.record(); g.replay(); g.replay(); e.record(); torch.cuda.synchronize()
     return s.elapsed_time(e) / (2 * n) * 1e-3
-
-
-def probe():
-    g = torch.arange(8192, dtype=torch.int16, device=dev)
-    tr = torch.zeros(512, dtype=torch.int16, device=dev); dma = torch.zeros(3072, dtype=torch.int16, device=dev)
-    core.check(L.ldetr_p3_probe(core.ptr(g), 2048, core.ptr(tr), core.ptr(dma), core.stream()), 'probe')
-    torch.cuda.synchronize()
-    tr = tr.cpu().numpy().astype('int64') & 0xffff; dma = dma.cpu().numpy().astype('int64') & 0xffff
-    print('tr-read, lane l reads 4 x b16 at element 4*l: lane -> elements')
-    for l in range(64):
-        print(f'  lane {l:2d}: {list(tr[l*4:l*4+4])}', '| pattern2:', list(tr[256 + l*4:256 + l*4+4]))
-    print('dma (a) lanes>=32 out of range: first elems of lane 0, 31, 32, 63:', dma[0:2], dma[31*8:31*8+2], dma[32*8:32*8+2], dma[63*8:63*8+2])
-    print('dma (b) imm offset 64 B: lds elem 512.. :', dma[512:516], ' (global elem 32 expected if imm applies to global only; if also LDS, data lands 32 elems later:', dma[512+32:512+36], ')')
-    print('dma (c) soffset 128 B:', dma[1536:1540], '(expect 64..)')
-    print('dma (d) soffset = bytes-512, lanes >= 32 beyond the range if soffset is checked: lane 31', dma[2560+31*8:2560+31*8+2], 'lane 32', dma[2560+32*8:2560+32*8+2])
-
-
-def reg_probe():
-    for mb in (12, 96):
-        buf = torch.zeros(mb << 20, dtype=torch.uint8, device=dev)
-        for blocks in (256, 512, 1024):
-            for seg in (64, 256):
-                for pitch in (768, 3072):
-                    iters, pieces = 64, 6
-                    t = timeit(lambda: L.ldetr_p3_dma_probe(core.ptr(buf), buf.numel(), seg, pitch, iters, -1, blocks, core.stream()), n=5)
-                    byts = blocks * 4 * (iters + 1) * pieces * 1024
-                    print(f'reg probe buf {mb:3d} MiB blocks {blocks:4d} seg {seg:4d} pitch {pitch:5d}: {t*1e6:8.1f} us  {byts/t/1e12:6.2f} TB/s  {byts/t/256/1e9:6.1f} GB/s/CU', flush=True)
-
-
-def dma_probe():
-    for mb in (12, 96):
-        buf = torch.zeros(mb << 20, dtype=torch.uint8, device=dev)
-        for blocks in (256, 512, 1024):
-            for seg in (64, 128, 256, 1024):
-                for pitch in (768, 3072):
-                    if seg > pitch: continue
-                    iters, pieces = 64, 6
-                    t = timeit(lambda: L.ldetr_p3_dma_probe(core.ptr(buf), buf.numel(), seg, pitch, iters, pieces, blocks, core.stream()), n=5)
-                    byts = blocks * 4 * iters * pieces * 1024
-                    print(f'dma probe buf {mb:3d} MiB blocks {blocks:4d} seg {seg:4d} pitch {pitch:5d}: {t*1e6:8.1f} us  {byts/t/1e12:6.2f} TB/s  {byts/t/256/1e9:6.1f} GB/s/CU', flush=True)
-
-
-def trace_case(N, H, Ci, Co, k, s, pad):
-    """Needs a library built with LDETR_P3_TRACE=1: where the waves of the forward kernel spend their cycles."""
-    import numpy as np
-    x = torch.randn(N, H, H, Ci, device=dev); w = torch.randn(Co, k, k, Ci, device=dev) / (k * Ci ** 0.5)
-    OH = (H + 2 * pad - k) // s + 1
-    xp = p3_split(x.reshape(-1, Ci)); wp = p3_split(w.reshape(Co, -1))
-    yp = torch.empty(N * OH * OH * Co * 6, dtype=torch.uint8, device=dev)
-    buf = torch.zeros(8192 * 8 * 8, dtype=torch.int64, device=dev)
-    for _ in range(3):
-        run_fwd(xp, N, H, Ci, wp, Co, k, s, pad, None, yp, None)
-    torch.cuda.synchronize()
-    L.ldetr_p3_debug_trace(core.ptr(buf))
-    run_fwd(xp, N, H, Ci, wp, Co, k, s, pad, None, yp, None)
-    torch.cuda.synchronize()
-    L.ldetr_p3_debug_trace(None)
-    t = buf.cpu().numpy().reshape(-1, 8)
-    t = t[t[:, 4] > 0]
-    tot = t[:, 6] - t[:, 5]
-    print(f'trace N={N} H={H} {Ci}->{Co} k{k}: waves {len(t)}  k-tiles/wave {t[:,4].mean():.1f}  loop cycles/wave {tot.mean():.0f}  per k-tile: load-issue {np.mean(t[:,0]/t[:,4]):.0f}  mfma-phase {np.mean(t[:,1]/t[:,4]):.0f}  store {np.mean(t[:,2]/t[:,4]):.0f}  barrier {np.mean(t[:,3]/t[:,4]):.0f}  (cycle counter ticks)')
-    span = (t[:, 6].max() - t[:, 5].min())
-    print(f'   first loop start -> last loop end: {span} ticks; XCC ids seen: {sorted(set(t[:,7] & 0xf))}')
 
 
 def conv_ref(x, w, stride, pad):
@@ -189,6 +126,74 @@ def bench_bwd(name, N, H, Ci, Co, k, s, pad, what='dw'):
     print(f'{name:24s} bwdD p3 {t1*1e6:7.1f}us {fl/t1/1e12:6.1f}TF (f32 eng {t3*1e6:7.1f}us {fl/t3/1e12:6.1f}) | bwdW p3 {t2*1e6:7.1f}us {fl/t2/1e12:6.1f}TF (f32 eng {t4*1e6:7.1f}us {fl/t4/1e12:6.1f})', flush=True)
 
 
+def pair_test(name, N, H, Ci, Co, k, s, pad, reps=30):
+    """Do the data gradient and the weight gradient of one layer overlap when they may?  Serial on one stream vs the two on two streams."""
+    OH = (H + 2 * pad - k) // s + 1
+    x = torch.randn(N, H, H, Ci, device=dev); w = torch.randn(Co, k, k, Ci, device=dev) / (k * Ci ** 0.5); dy = torch.randn(N, OH, OH, Co, device=dev)
+    sc = torch.rand(Co, device=dev) + 0.5
+    dyp = p3_split(dy.reshape(-1, Co)); xp = p3_split(x.reshape(-1, Ci)); wb = p3_weight_bwd(w, sc)
+    ep = _lib.P3Epilogue(); ep.alpha = 1.0; ep.relu_mask_p3 = xp.data_ptr()
+    dxp = torch.empty(N * H * H * Ci * 6, dtype=torch.uint8, device=dev); dw = torch.zeros(Co, k, k, Ci, device=dev)
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    def dgrad(st): return L.ldetr_p3_conv2d_bwd_data(core.ptr(dyp), N, OH, OH, Co, core.ptr(wb), Ci, k, k, s, pad, H, H, ctypes.byref(ep), core.ptr(dxp), None, ctypes.c_void_p(st.cuda_stream))
+    def wgrad(st): return L.ldetr_p3_conv2d_bwd_weight(core.ptr(xp), N, H, H, Ci, core.ptr(dyp), Co, k, k, s, pad, core.ptr(sc), core.ptr(dw), ctypes.c_void_p(st.cuda_stream))
+    def run(mode):
+        torch.cuda.synchronize()
+        e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True); e2 = torch.cuda.Event(enable_timing=True)
+        torch.cuda._sleep(2_000_000)            # let the host run ahead
+        s1.wait_stream(torch.cuda.current_stream()); s2.wait_stream(torch.cuda.current_stream())
+        e0.record(s1)
+        s2.wait_event(e0)
+        for _ in range(reps):
+            if mode == 'serial':
+                dgrad(s1); wgrad(s1)
+            elif mode == 'd':
+                dgrad(s1)
+            elif mode == 'w':
+                wgrad(s1)
+            else:
+                dgrad(s1); wgrad(s2)
+        e2.record(s2); s1.wait_event(e2); e1.record(s1)
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps * 1e3
+    def graphed(par):
+        g = torch.cuda.CUDAGraph()
+        cs = torch.cuda.Stream()
+        with torch.cuda.graph(g, stream=cs):
+            for _ in range(reps):
+                if par:
+                    s2.wait_stream(cs)
+                    dgrad(cs); wgrad(s2)
+                    cs.wait_stream(s2)
+                else:
+                    dgrad(cs); wgrad(cs)
+        g.replay(); torch.cuda.synchronize()
+        a = torch.cuda.Event(enable_timing=True); b = torch.cuda.Event(enable_timing=True)
+        a.record(); g.replay(); b.record(); torch.cuda.synchronize()
+        return a.elapsed_time(b) / reps * 1e3
+    run('serial')
+    if 'graph' in sys.argv:
+        gs, gp = graphed(False), graphed(True)
+        print(f'{name:24s} graph serial {gs:6.1f}us  graph fork/join per layer {gp:6.1f}us ({gp / gs:.2f}x)', flush=True)
+        return
+    def fused(st): return L.ldetr_p3_conv2d_bwd_pair(core.ptr(dyp), N, OH, OH, Co, core.ptr(wb), core.ptr(xp), Ci, k, k, s, pad, H, H, ctypes.byref(ep), core.ptr(dxp), None,
+                                                     core.ptr(sc), core.ptr(dw), None, ctypes.c_void_p(st.cuda_stream))
+    def run_fused():
+        torch.cuda.synchronize()
+        e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+        torch.cuda._sleep(2_000_000)
+        s1.wait_stream(torch.cuda.current_stream())
+        e0.record(s1)
+        for _ in range(reps):
+            fused(s1)
+        e1.record(s1)
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps * 1e3
+    td, tw, ts, tp = run('d'), run('w'), run('serial'), run('par')
+    run_fused(); tf = run_fused()
+    print(f'{name:24s} dgrad {td:6.1f}us wgrad {tw:6.1f}us  serial {ts:6.1f}us  two streams {tp:6.1f}us ({tp / ts:.2f}x)  one launch {tf:6.1f}us ({tf / ts:.2f}x)', flush=True)
+
+
 def bench_case(name, N, H, Ci, Co, k, s, pad):
     x = torch.randn(N, H, H, Ci, device=dev); w = torch.randn(Co, k, k, Ci, device=dev) / (k * Ci ** 0.5)
     OH = (H + 2 * pad - k) // s + 1
@@ -218,17 +223,7 @@ CASES = [('l1 1x1 64->64', 64, 64, 64, 1, 1, 0), ('l1 3x3 64->64', 64, 64, 64, 3
          ('sg 3x3 512->512 @16', 16, 512, 512, 3, 1, 1), ('sg 3x3 128->128 @64', 64, 128, 128, 3, 1, 1)]
 
 def main():
-    what = sys.argv[1:] or ['probe', 'check', 'bench']
-    if 'probe' in what:
-        probe()
-    if 'trace' in what:
-        trace_case(16, 16, 256, 256, 3, 1, 1)
-        trace_case(16, 32, 128, 128, 3, 1, 1)
-        trace_case(16, 16, 1024, 256, 1, 1, 0)
-    if 'dma' in what:
-        dma_probe()
-    if 'reg' in what:
-        reg_probe()
+    what = sys.argv[1:] or ['check', 'checkb', 'bench', 'benchb']
     if 'check' in what:
         check_case(1, 8, 32, 64, 1, 1, 0, False)
         check_case(2, 8, 64, 64, 3, 1, 1, False)
@@ -254,6 +249,9 @@ def main():
     if 'benchb' in what:
         for c in CASES:
             bench_bwd(c[0], B, *c[1:])
+    if 'pair' in what:
+        for c in CASES:
+            pair_test(c[0], B, *c[1:])
     if 'benchd' in what:
         for c in CASES:
             bench_bwd(c[0], B, *c[1:], what='d')
