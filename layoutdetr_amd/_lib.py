@@ -132,7 +132,7 @@ def load():
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported
         fn.restype = c_int
         fn.argtypes = argtypes
-    if lib.ldetr_abi_version() != 21:
+    if lib.ldetr_abi_version() != 22:
         raise RuntimeError('libldetr_hip.so ABI version mismatch; rebuild it')
     _lib = lib
     return lib

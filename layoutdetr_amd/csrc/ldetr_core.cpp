@@ -14,4 +14,4 @@ void set_error(const char* fmt, ...) {
 }  // namespace ldetr
 
 extern "C" const char* ldetr_last_error(void) { return ldetr::g_err; }
-extern "C" int ldetr_abi_version(void) { return 21; }
+extern "C" int ldetr_abi_version(void) { return 22; }

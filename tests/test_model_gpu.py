@@ -41,14 +41,15 @@ def same_up_to_relu_flips(a, b, what):
     frac = (e > 2e-2).double().mean().item()
     assert e.max().item() <= 2e-2 or frac <= 0.01, f'{what}: max {e.max().item():.3e}, {frac:.4f} of the entries beyond 2e-2'
     # ... and a dense criterion beside the outlier allowance: a wiring error confined to a slice (one bias, one block of in_proj rows) or a
-    # ~1 % scale error moves the bulk of the entries; a flipped unit does not.  Median <= 1e-4, 90th percentile <= 2e-3 of the largest entry,
-    # and the same for each third of the leading dimension (the q / k / v row blocks of a packed projection).
-    def dense(ee, tag):
+    # ~1 % scale error moves the bulk of the entries (median ~3e-3 of the largest entry); a flipped unit does not, and fp32 summation-order noise of a
+    # bias gradient (a column sum over all tokens) measures 1.6e-4.  Median <= 5e-4, 90th percentile <= 5e-3 of the largest entry, for the tensor
+    # and for each third of its leading dimension (the q / k / v row blocks of a packed projection) on the block's own scale.
+    def dense(ee, tag, med_tol=5e-4, p90_tol=5e-3):
         v = ee.reshape(-1)
         if v.numel() == 0:
             return
         med, p90 = v.median().item(), v.kthvalue(max(1, int(0.9 * v.numel()))).values.item()
-        assert med <= 1e-4 and p90 <= 2e-3, f'{what}{tag}: median error {med:.3e}, p90 {p90:.3e} of the largest entry'
+        assert med <= med_tol and p90 <= p90_tol, f'{what}{tag}: median error {med:.3e}, p90 {p90:.3e} of the largest entry'
     dense(e, '')
     if e.dim() >= 1 and e.shape[0] >= 3 and e.shape[0] % 3 == 0:
         t = e.shape[0] // 3
