@@ -89,9 +89,6 @@ class StyleGAN2Loss(Loss):
         # (values only: D is frozen there) and both D passes of Dmain (with its autograd graph).  The iteration driver calls
         # precompute_D_trunk() before the phases; without that call the per-phase behaviour above applies.
         self._trunk_cache = {}
-        # called (if set) when Gmain's generator forward has been queued and D's trunk output is about to be read: GraphedIteration ends one
-        # graph and starts the next there, so that D's trunk evaluation (its own graph, on a second stream) runs BESIDE the generator's forward
-        self.on_G_forward_done = None
         self._reporting = report_fn is not None   # the sign() statistics cost a launch each: only formed when someone listens
         self.report = report_fn if report_fn is not None else (lambda name, value: None)
         self.last = {}
@@ -148,8 +145,6 @@ class StyleGAN2Loss(Loss):
         static = bool(getattr(self.G, 'static_shapes', False))
         cached = self._cached_trunk(background, detach=True, pop=False)
         bbox_fake, loss_z, cls_logits, loss_lm, loss_text_len = self.run_G(gen_z, bbox_class, bbox_real, bbox_text, bbox_patch, padding_mask, background, gen_c, reconst=True)
-        if self.on_G_forward_done is not None:
-            self.on_G_forward_done()
         gen_logits, gen_logits_uncond = self.run_D(bbox_fake, bbox_class, bbox_text, bbox_patch, padding_mask, background, gen_c,
                                                    trunk_out=cached)
         if static and self.fused_layout_losses and bbox_fake.is_cuda and bbox_fake.shape[1] <= 64:

@@ -18,7 +18,6 @@ Everything outside this step (dataset, snapshots, metrics, pickles: training_loo
 is out of scope; `training_iteration` is what `bench.py` times.
 """
 import copy
-import os
 
 import numpy as np
 import torch
@@ -585,42 +584,17 @@ class GraphedIteration(object):
             overlap = dp.world > 1
         pool = torch.cuda.graph_pool_handle() if (iter_share or overlap) else None
         d_stages = None
-        self.side_stream = None      # set when D's trunk work is replayed beside the generator's forward (see below)
-        pipelined, pool_side = False, None
         if iter_share:
-            # D's trunk forward gets its own graph, replayed before the phases; its activations stay alive (by reference) until
+            # D's trunk forward gets its own graph, replayed before the phases; its activations stay alive in the shared pool until
             # the Dmain graph (captured below, replayed after it) runs the trunk's backward
             d_phase = next(p for p in phases if p.name == 'Dmain')
-            stage_ok = b <= batch_gpu and d_phase.fm.stage_segments() is not None and hasattr(_trunk_body(d_phase.module), 'stages')
-            from .detr_backbone import BackwardStages
-            if overlap and stage_ok:
+            if overlap and b <= batch_gpu and d_phase.fm.stage_segments() is not None and hasattr(_trunk_body(d_phase.module), 'stages'):
+                from .detr_backbone import BackwardStages
                 d_stages = BackwardStages(backward_stage_count(b))
-            elif not overlap and stage_ok and os.environ.get('LDETR_PIPELINE_D_TRUNK', '1') != '0' and os.environ.get('LDETR_OVERLAP_D_TRUNK', '1') != '0':
-                # one GPU, no exchange to overlap: the trunk | rest cut of the staged backward is used to run D's trunk BACKWARD (+ D's optimiser
-                # step + the next iteration's trunk forward) on the side stream while the main stream already runs the next iteration's
-                # generator forward, which depends on none of them (see the comment at the trunk graph below)
-                pipelined = True
-                d_stages = BackwardStages(2)
-            # D's trunk evaluation and the generator's forward of Gmain are independent until D's heads read the trunk features, and short
-            # dependent launches leave the chip half idle: branches of ONE hipGraph do not overlap on this stack, but two graphs
-            # replayed on two streams do.  So the trunk graph gets a memory pool of its own (graphs that may run concurrently must not share
-            # recycled blocks; its outputs stay alive by reference until Dmain's backward, as before) and Gmain is cut into two graphs at the
-            # point where D's heads start: [trunk graph on the side stream ‖ G forward] -> join -> [D heads, losses, backward].
-            # Pipelined form (one GPU): Dmain's backward is cut at trunk | rest; the trunk's backward, D's Adam step, the refresh of D's weight
-            # images and the NEXT iteration's trunk forward all run on the side stream (same side pool: they are sequential there) while the main
-            # stream starts the next iteration with the generator's forward -- everything D's trunk needs or produces is joined at the same point,
-            # the graph that starts D's heads.  Same values: only independent work is reordered across two streams.
-            side_ok = (d_stages is None or pipelined) and b <= batch_gpu and os.environ.get('LDETR_OVERLAP_D_TRUNK', '1') != '0'
-            if side_ok:
-                self.side_stream = torch.cuda.Stream()
-                pool_side = torch.cuda.graph_pool_handle()
             self.pre_graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.pre_graph, pool=(pool_side if side_ok else pool), stream=self.capture_stream):
+            with torch.cuda.graph(self.pre_graph, pool=pool, stream=self.capture_stream):
                 for s in range(0, b, batch_gpu):
                     loss.precompute_D_trunk(batch['background'][s:s + batch_gpu], stages=d_stages)
-            # (pipelined) the gradient at the trunk | rest boundary is produced by Dmain's main-stream graph and read by the trunk's backward on the
-            # side stream while the main stream has moved on: it must not live in the main pool, whose blocks the next generator forward recycles
-            self._boundary = [torch.empty_like(x) for x, _ in d_stages.records[2]] if pipelined else None
         for phase in phases:
             for m in (loss.G, loss.D):
                 if not getattr(m, 'static_shapes', False):
@@ -628,19 +602,17 @@ class GraphedIteration(object):
             phase.fm.zero_grad()
             phase.module.requires_grad_(True)
             phase.module.text_encoder.requires_grad_(False)
-            pipe_here = pipelined and phase.name == 'Dmain'
-            staged = (overlap and b <= batch_gpu and phase.fm.stage_segments() is not None) or pipe_here
-            chain, cur = [], {}      # chain: (graph, flat segment exchanged after it | 'join' | None, replayed on the side stream?)
+            staged = overlap and b <= batch_gpu and phase.fm.stage_segments() is not None
+            chain, cur = [], {}
 
-            def begin(side=False):
+            def begin():
                 cur['g'] = torch.cuda.CUDAGraph()
-                cur['side'] = side
-                cur['ctx'] = torch.cuda.graph(cur['g'], pool=(pool_side if side else pool), stream=self.capture_stream)
+                cur['ctx'] = torch.cuda.graph(cur['g'], pool=pool, stream=self.capture_stream)
                 cur['ctx'].__enter__()
 
             def end(seg):
                 cur['ctx'].__exit__(None, None, None)
-                chain.append((cur['g'], seg, cur['side']))
+                chain.append((cur['g'], seg))
 
             def stage1(phase=phase):
                 core.reseed(dev)
@@ -655,30 +627,15 @@ class GraphedIteration(object):
             begin()
             try:
                 if staged:
-                    nst = 2 if pipe_here else backward_stage_count(b)
+                    nst = backward_stage_count(b)
                     segs = phase.fm.stage_segments(nst)
 
                     def between(i):
-                        if pipe_here and i == 1:
-                            for (_, leaf), buf in zip(d_stages.records[2], self._boundary):
-                                if leaf.grad is not None:
-                                    buf.copy_(leaf.grad)
-                                    leaf.grad = buf
-                        end(None if pipe_here else segs[i - 1])
+                        end(segs[i - 1])
                         if i < nst:
-                            begin(side=pipe_here)      # pipelined: the trunk's backward is the side stream's graph
+                            begin()
                     staged_backward(loss, phase, dp, stage1, between=between, exchange=lambda ranges: None,
                                     stages=(d_stages if (iter_share and phase.name == 'Dmain') else None), n_stages=nst)
-                elif self.side_stream is not None and phase.name == 'Gmain':
-                    def cut():
-                        end(None)
-                        begin()
-                    loss.on_G_forward_done = cut
-                    try:
-                        stage1()
-                    finally:
-                        loss.on_G_forward_done = None
-                    end('join')      # this graph starts where D's heads read the trunk features: it waits for the side stream
                 else:
                     stage1()
                     end(None)
@@ -689,46 +646,21 @@ class GraphedIteration(object):
             phase.module.requires_grad_(False)
             self.graphs.append(chain)
 
-    def join(self):
-        """Make the current stream wait for the side stream's work (pipelined form: D's trunk backward, optimiser step and weight images).
-        Call before reading D's parameters / gradients on the current stream between iterations; torch.cuda.synchronize() does as well."""
-        if self.side_stream is not None:
-            torch.cuda.current_stream().wait_stream(self.side_stream)
-
     def run(self):
         if self.pre_graph is not None:
-            if self.side_stream is not None:
-                cur = torch.cuda.current_stream()
-                self.side_stream.wait_stream(cur)          # the previous iteration's Dmain (trunk backward, Adam, weight images) is ahead of it
-                with torch.cuda.stream(self.side_stream):
-                    self.pre_graph.replay()
-            else:
-                self.pre_graph.replay()
+            self.pre_graph.replay()
         lerp_done = False
         for phase, chain in zip(self.phases, self.graphs):
-            exchanged, on_side = False, False
-            for g, seg, side in chain:
-                if seg == 'join':
-                    torch.cuda.current_stream().wait_stream(self.side_stream)
-                    seg = None
-                if side:                 # (pipelined) the trunk's backward: behind everything queued so far, on the side stream
-                    self.side_stream.wait_stream(torch.cuda.current_stream())
-                    with torch.cuda.stream(self.side_stream):
-                        g.replay()
-                    on_side = True
-                else:
-                    g.replay()
+            exchanged = False
+            for g, seg in chain:
+                g.replay()
                 if seg is not None:      # this stage's gradient segment is complete: reduce it while the next graph computes
                     for lo, hi in seg:
                         self.dp.exchange_async(phase.fm.gflat, lo, hi)
                     exchanged = True
             fe = self.ema.fused(phase, self.batch_size, self.ema_kimg, self.cur_nimg, self.ema_rampup) if self.ema is not None else None
             lerp_done = lerp_done or fe is not None
-            if on_side:                  # the optimiser step of a phase whose last graph ran on the side stream follows it there
-                with torch.cuda.stream(self.side_stream):
-                    self.dp.apply(phase, exchanged=exchanged, ema=fe)
-            else:
-                self.dp.apply(phase, exchanged=exchanged, ema=fe)
+            self.dp.apply(phase, exchanged=exchanged, ema=fe)
         if self.ema is not None:
             self.ema.update(self.batch_size, self.ema_kimg, self.cur_nimg, ema_rampup=self.ema_rampup, lerp_done=lerp_done)
         if self.batch_size:

@@ -172,6 +172,31 @@ def pair_test(name, N, H, Ci, Co, k, s, pad, reps=30):
         a.record(); g.replay(); b.record(); torch.cuda.synchronize()
         return a.elapsed_time(b) / reps * 1e3
     run('serial')
+    if 'graph2' in sys.argv:      # two GRAPHS (one per kernel kind) replayed on two streams: do whole graphs overlap?
+        def cap(fn):
+            g = torch.cuda.CUDAGraph(); cs = torch.cuda.Stream()
+            with torch.cuda.graph(g, stream=cs):
+                for _ in range(reps): fn(cs)
+            return g
+        gd, gw = cap(dgrad), cap(wgrad)
+        def rep2(par):
+            torch.cuda.synchronize()
+            a = torch.cuda.Event(enable_timing=True); b = torch.cuda.Event(enable_timing=True)
+            cur = torch.cuda.current_stream()
+            a.record()
+            if par:
+                s2.wait_stream(cur)
+                gd.replay()
+                with torch.cuda.stream(s2): gw.replay()
+                cur.wait_stream(s2)
+            else:
+                gd.replay(); gw.replay()
+            b.record(); torch.cuda.synchronize()
+            return a.elapsed_time(b) / reps * 1e3
+        rep2(False); rep2(True)
+        ts, tp = rep2(False), rep2(True)
+        print(f'{name:24s} two graphs back to back {ts:6.1f}us  on two streams {tp:6.1f}us ({tp / ts:.2f}x)', flush=True)
+        return
     if 'graph' in sys.argv:
         gs, gp = graphed(False), graphed(True)
         print(f'{name:24s} graph serial {gs:6.1f}us  graph fork/join per layer {gp:6.1f}us ({gp / gs:.2f}x)', flush=True)
