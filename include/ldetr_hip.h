@@ -379,6 +379,11 @@ typedef struct ldetr_p3_epilogue {
  * w P3 [Cout][KH][KW][Cin] (Cout % 8 == 0), KH*KW <= 32, stride 1 or 2. */
 int ldetr_p3_conv2d_fwd(const void* x, int N, int H, int W, int Cin, const void* w, int Cout, int KH, int KW, int stride, int pad,
                         const ldetr_p3_epilogue* ep, void* out_p3, float* out_f32, void* stream);
+/* ldetr_p3_conv2d_fwd on two (activations, weights, epilogue, output) sets of the same geometry as ONE launch (the second set is the z = 1 half of the
+ * grid): G's and D's trunks convolve the same backgrounds with different weights, ATen runs them as two convolutions. */
+int ldetr_p3_conv2d_fwd_dual(const void* x1, const void* x2, int N, int H, int W, int Cin, const void* w1, const void* w2, int Cout, int KH, int KW,
+                             int stride, int pad, const ldetr_p3_epilogue* ep1, const ldetr_p3_epilogue* ep2, void* out1_p3, float* out1_f32,
+                             void* out2_p3, float* out2_f32, void* stream);
 /* dx[n][iy][ix][ci] = sum_{kh,kw,co} dy[n][(iy + pad - kh) / stride][(ix + pad - kw) / stride][co] * wb[ci][kh][kw][co] over the taps whose
  * quotients are exact and in range; dy P3 [N][OH][OW][Cout] (Cout % 32 == 0), wb from ldetr_p3_weight_bwd, dx [N][IH][IW][Cin].  The epilogue's
  * [m][n] operands (residual, mask) are indexed like dx. */

@@ -58,6 +58,14 @@ struct P3NtParams {
     int mtiles, ntiles, xm, xn;   // tile grid and the XCD array laid over it (xcd_tile)
     int nclass, nimg;        // data gradient with stride > 1: blockIdx.z enumerates the stride^2 parity classes of the destination pixels (one launch)
     P3Epi ep;
+    int ngroups;             // grouped forward (2): the same geometry on a second operand set (P3Group2) as the z = 1 half of the grid
+};
+
+// Second (activations, weights, epilogue) set of a grouped forward launch: a kernel argument of its own, so that the kernels that never group
+// (the paired backward) do not carry it (their register budget is their occupancy)
+struct P3Group2 {
+    const char* A2; const char* B2;
+    P3Epi ep2;
 };
 
 // (merging the planes: hi + (mid + lo).  mid + lo is the exact remainder (<= 16 significant bits), so the outer sum is the stored value exactly;
@@ -351,8 +359,8 @@ __device__ __forceinline__ void p3_store_tile(char* sb, int w, int lane, const l
 // the iteration's one barrier and its registers take tile t+1+PF.  What bounds these launches is bytes in flight per CU over the load latency
 // (profiles/r04_pmc_sq.txt: matrix pipe 22-26 % busy on the 1x1 shapes with ONE tile in flight; 12 waves x 6 KiB / ~1.5 us = the ~50 GB/s per
 // CU every earlier variant sat on), so the depth is what the register file allows at the tile's occupancy.
-template <int BM, int BN, int NW, int PF, int NST>
-__device__ __forceinline__ void p3_nt_body(P3NtParams p, const int bx, const int by, const int bz) {   // (bx, by, bz): the block's place in the (tiles, k-slices, parity classes) grid
+template <int BM, int BN, int NW, int PF, int NST, bool GROUPS>
+__device__ __forceinline__ void p3_nt_body(P3NtParams p, const P3Group2& g2, const int bx, const int by, const int bz) {   // (bx, by, bz): the block's place in the (tiles, k-slices, parity classes) grid
     constexpr int NT = NW * 64;   // NST = LDS stages: 2 = one barrier per k-tile; 1 = two barriers, half the LDS (more blocks per CU)
     constexpr int WGN = (NW == 8 && BN >= 128) ? 4 : 2, WGM = NW / WGN;
     constexpr int WM = BM / WGM, WN = BN / WGN, TM = WM / 32, TN = WN / 32;   // wave tile, 32x32 accumulators per wave
@@ -378,6 +386,9 @@ __device__ __forceinline__ void p3_nt_body(P3NtParams p, const int bx, const int
         p.M = p.nimg * p.OH * p.OW; p.out_py = py; p.out_px = px;
         p.nkt = ntaps * p.Cin / 32;
         p.mtiles = (p.M + BM - 1) / BM;
+    } else if (GROUPS && p.ngroups > 1 && bz > 0) {
+        p.A = g2.A2; p.B = g2.B2; p.ep = g2.ep2;
+        ws_tile0 = p.mtiles * p.ntiles;
     }
     int tm, tn;
     if (!xcd_tile(bx, p.mtiles, p.ntiles, p.xm, p.xn, tm, tn)) return;
@@ -514,7 +525,7 @@ __device__ __forceinline__ void p3_nt_body(P3NtParams p, const int bx, const int
 }
 
 template <int BM, int BN, int NW, int PF, int NST>
-__global__ __launch_bounds__(NW * 64) void p3_nt_kernel(P3NtParams p) { p3_nt_body<BM, BN, NW, PF, NST>(p, blockIdx.x, blockIdx.y, blockIdx.z); }
+__global__ __launch_bounds__(NW * 64) void p3_nt_kernel(P3NtParams p, P3Group2 g2) { p3_nt_body<BM, BN, NW, PF, NST, true>(p, g2, blockIdx.x, blockIdx.y, blockIdx.z); }
 
 // ---------------------------------------------------------------------------------------------
 // p3_c3_kernel: 3x3 / stride 1 / pad 1 convolutions (forward, and the data gradient as the same conv with mirrored taps) on 2-D pixel
@@ -537,6 +548,7 @@ struct P3C3Params {
     int splitk; float* ws; int* ws_count;
     int mtiles, ntiles, xm, xn;
     P3Epi ep;
+    int ngroups;                 // grouped forward: see P3NtParams / P3Group2
 };
 
 constexpr int C3_NGMAX = 13, C3_A_BYTES = C3_NGMAX * 3072, C3_B_BYTES = 4 * 3072, C3_LDS = C3_A_BYTES + 3 * C3_B_BYTES;
@@ -607,8 +619,10 @@ __device__ __forceinline__ void p3_c3_tap(const P3C3Params& p, const __amdgpu_bu
     __syncthreads();
 }
 
-__device__ __forceinline__ void p3_c3_body(const P3C3Params& p, const int bx, const int by) {
+template <bool GROUPS>
+__device__ __forceinline__ void p3_c3_body(P3C3Params p, const P3Group2& g2, const int bx, const int by, const int bz) {
     constexpr int BM = 128, BN = 64, NT = 256, WM = 64, WN = 32;
+    if (GROUPS && p.ngroups > 1 && bz > 0) { p.X = g2.A2; p.Wt = g2.B2; p.ep = g2.ep2; }
     extern __shared__ __attribute__((aligned(1024))) char p3_smem[];
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), wm = w >> 1, wn = w & 1;
     const int cl = lane & 31, kl = lane >> 5;
@@ -722,7 +736,7 @@ __device__ __forceinline__ void p3_c3_body(const P3C3Params& p, const int bx, co
             return s;
         });
     }
-    if (p.splitk > 1 && !p3_splitk_reduce<2, 1, NT>(acc, p.ws, p.ws_count, t, ks, p.splitk, BM * BN, tid, reinterpret_cast<int*>(p3_smem))) return;
+    if (p.splitk > 1 && !p3_splitk_reduce<2, 1, NT>(acc, p.ws, p.ws_count, t + bz * p.mtiles * p.ntiles, ks, p.splitk, BM * BN, tid, reinterpret_cast<int*>(p3_smem))) return;
     p3_wave_epilogue<WM, WN, 2, 1>(p.ep, reinterpret_cast<float*>(p3_smem) + w * (WM * CP), acc, lane, n0 + wn * WN, p.Nout, [&](int rl) -> long {
         int n, y0, x0, py, px;
         p3_c3_decode_tile_row(p, tm, wm * WM + rl, n, y0, x0, py, px);
@@ -731,7 +745,7 @@ __device__ __forceinline__ void p3_c3_body(const P3C3Params& p, const int bx, co
     });
 }
 
-__global__ __launch_bounds__(256, 2) void p3_c3_kernel(P3C3Params p) { p3_c3_body(p, blockIdx.x, blockIdx.y); }
+__global__ __launch_bounds__(256, 2) void p3_c3_kernel(P3C3Params p, P3Group2 g2) { p3_c3_body<true>(p, g2, blockIdx.x, blockIdx.y, blockIdx.z); }
 
 // ---------------------------------------------------------------------------------------------
 // p3_tn_kernel: weight gradients.  dW[co][tap][ci] += row_scale[co] * sum_pix dY[pix][co] * X[src(pix, tap)][ci]: per tap a GEMM whose
@@ -1008,7 +1022,8 @@ __global__ __launch_bounds__(256) void p3_bwd_pair_nt_kernel(P3NtParams pn, P3Tn
         if (idx < n_tn) p3_tn_body<64, 64, 1, 1>(pt, idx % tn_sk, idx / tn_sk);
         return;
     }
-    p3_nt_body<BM, BN, 4, 1, NST>(pn, idx % nt_gx, (idx / nt_gx) % nt_sk, idx / (nt_gx * nt_sk));
+    P3Group2 none;   // (never read: GROUPS = false)
+    p3_nt_body<BM, BN, 4, 1, NST, false>(pn, none, idx % nt_gx, (idx / nt_gx) % nt_sk, idx / (nt_gx * nt_sk));
 }
 
 __global__ __launch_bounds__(256, 2) void p3_bwd_pair_c3_kernel(P3C3Params pc, P3TnParams pt, int n_tn, int n_tn8, int n_c38, int order, int tn_sk, int c3_gx) {
@@ -1017,7 +1032,8 @@ __global__ __launch_bounds__(256, 2) void p3_bwd_pair_c3_kernel(P3C3Params pc, P
         if (idx < n_tn) p3_tn_body<64, 64, 1, 1>(pt, idx % tn_sk, idx / tn_sk);
         return;
     }
-    p3_c3_body(pc, idx % c3_gx, idx / c3_gx);
+    P3Group2 none;   // (never read: GROUPS = false)
+    p3_c3_body<false>(pc, none, idx % c3_gx, idx / c3_gx, 0);
 }
 
 // ---- fp32 <-> P3 streaming conversions.  One thread = one 8-channel group.
@@ -1140,7 +1156,7 @@ struct NtGrid { long gx; int sk, ncls; size_t lds; };
 template <int BM, int BN, int NW, int NST>
 static NtGrid plan_nt(P3NtParams& p, int sk) {
     p.mtiles = cdiv(p.M, BM); p.ntiles = cdiv(p.N, BN);
-    NtGrid g; g.ncls = p.nclass > 1 ? p.nclass : 1;
+    NtGrid g; g.ncls = p.nclass > 1 ? p.nclass : (p.ngroups > 1 ? p.ngroups : 1);   // grid z: parity classes (data gradient) or groups (grouped forward)
     const long nt = (long)p.mtiles * p.ntiles;
     choose_xcd_array(p.mtiles, p.ntiles, (double)p.M * p.Cin * 6.0, (double)p.N * p.KH * p.KW * p.Cin * 6.0, p.xm, p.xn, g.gx);
     if (sk > p.nkt) sk = p.nkt;
@@ -1164,17 +1180,17 @@ static int nt_splitk(const P3NtParams& p, int bm, int bn, long slots) {
 }
 
 template <int BM, int BN, int NW, int PF, int NST>
-static int launch_nt_cfg(P3NtParams& p, int sk, hipStream_t st) {
+static int launch_nt_cfg(P3NtParams& p, const P3Group2& g2, int sk, hipStream_t st) {
     const NtGrid g = plan_nt<BM, BN, NW, NST>(p, sk);
     auto kern = p3_nt_kernel<BM, BN, NW, PF, NST>;
     static bool raised = false;
     if (!raised) { if (!raise_lds(reinterpret_cast<const void*>(kern), g.lds, "p3_nt")) return LDETR_ERR_LAUNCH; raised = true; }
-    hipLaunchKernelGGL(kern, dim3((unsigned)g.gx, g.sk, g.ncls), NW * 64, g.lds, st, p);
+    hipLaunchKernelGGL(kern, dim3((unsigned)g.gx, g.sk, g.ncls), NW * 64, g.lds, st, p, g2);
     note_engine_launch(true);
     return check_launch("p3_nt");
 }
 
-static int launch_nt(P3NtParams& p, bool forward, hipStream_t st) {
+static int launch_nt(P3NtParams& p, const P3Group2& g2, bool forward, hipStream_t st) {
     // Tile configurations: 1 = 128x128, 8 waves; 2 = 128x64, 4 waves; 3 = 64x64, 4 waves; 4 = 128x128, 4 waves.  One LDS stage (two barriers
     // per k-tile, half the LDS: more blocks per CU) and one k-tile of register prefetch are the defaults: the sweeps over the trunk shapes at
     // 16 x 256^2 (profiles/r04_p3_sweeps.txt: tile x prefetch depth x stage count) put 64x64 / one stage first on all but the large-grid
@@ -1189,10 +1205,10 @@ static int launch_nt(P3NtParams& p, bool forward, hipStream_t st) {
     const int pf = force_pf ? force_pf : 1, nst = force_nst ? force_nst : 1;
 #define P3_NT_CASE(BM_, BN_, NW_)                                                                                   \
     switch (pf * 2 + (nst == 1 ? 0 : 1)) {                                                                          \
-        case 2: return launch_nt_cfg<BM_, BN_, NW_, 1, 1>(p, sk, st);                                               \
-        case 3: return launch_nt_cfg<BM_, BN_, NW_, 1, 2>(p, sk, st);                                               \
-        case 4: return launch_nt_cfg<BM_, BN_, NW_, 2, 1>(p, sk, st);                                               \
-        default: return launch_nt_cfg<BM_, BN_, NW_, 2, 2>(p, sk, st);                                              \
+        case 2: return launch_nt_cfg<BM_, BN_, NW_, 1, 1>(p, g2, sk, st);                                               \
+        case 3: return launch_nt_cfg<BM_, BN_, NW_, 1, 2>(p, g2, sk, st);                                               \
+        case 4: return launch_nt_cfg<BM_, BN_, NW_, 2, 1>(p, g2, sk, st);                                               \
+        default: return launch_nt_cfg<BM_, BN_, NW_, 2, 2>(p, g2, sk, st);                                              \
     }
     switch (cfg) {
         case 1: P3_NT_CASE(128, 128, 8)
@@ -1230,17 +1246,18 @@ static long plan_c3(P3C3Params& p) {
     if (force_sk > 0) sk = force_sk;
     if (sk > p.ncc) sk = p.ncc;
     p.splitk = sk; p.ws = nullptr; p.ws_count = nullptr;
-    if (sk > 1 && !splitk_ws_alloc(nt, (size_t)nt * sk * 128 * 64 * sizeof(float), &p.ws, &p.ws_count)) p.splitk = sk = 1;
+    const int ng = p.ngroups > 1 ? p.ngroups : 1;
+    if (sk > 1 && !splitk_ws_alloc(nt * ng, (size_t)nt * ng * sk * 128 * 64 * sizeof(float), &p.ws, &p.ws_count)) p.splitk = sk = 1;
     long grid_x;
     choose_xcd_array(p.mtiles, p.ntiles, (double)p.N_img * p.H * p.W * p.Cin * 6.0, (double)p.Nout * 9 * p.Cin * 6.0, p.xm, p.xn, grid_x);
     return grid_x;
 }
 
-static int launch_c3(P3C3Params& p, hipStream_t st) {
+static int launch_c3(P3C3Params& p, const P3Group2& g2, hipStream_t st) {
     const long grid_x = plan_c3(p);
     static bool raised = false;
     if (!raised) { if (!raise_lds(reinterpret_cast<const void*>(&p3_c3_kernel), C3_LDS, "p3_c3")) return LDETR_ERR_LAUNCH; raised = true; }
-    hipLaunchKernelGGL(p3_c3_kernel, dim3((unsigned)grid_x, p.splitk, 1), 256, C3_LDS, st, p);
+    hipLaunchKernelGGL(p3_c3_kernel, dim3((unsigned)grid_x, p.splitk, p.ngroups > 1 ? p.ngroups : 1), 256, C3_LDS, st, p, g2);
     note_engine_launch(true);
     return check_launch("p3_c3");
 }
@@ -1397,10 +1414,13 @@ extern "C" int ldetr_p3_weight_prep(const int64_t* table_dev, int nconv, int tot
     return check_launch("p3_weight_prep");
 }
 
-extern "C" int ldetr_p3_conv2d_fwd(const void* x, int N, int H, int W, int Cin, const void* w, int Cout, int KH, int KW, int stride, int pad,
-                                   const ldetr_p3_epilogue* ep, void* out_p3, float* out_f32, void* stream) {
+// x2 != NULL: the grouped form (ldetr_p3_conv2d_fwd_dual) -- the same geometry on a second operand / epilogue / output set in the same launch
+static int p3_conv2d_fwd_impl(const void* x, int N, int H, int W, int Cin, const void* w, int Cout, int KH, int KW, int stride, int pad,
+                              const ldetr_p3_epilogue* ep, void* out_p3, float* out_f32,
+                              const void* x2, const void* w2, const ldetr_p3_epilogue* ep2, void* out2_p3, float* out2_f32, void* stream) {
     const int OH = (H + 2 * pad - KH) / stride + 1, OW = (W + 2 * pad - KW) / stride + 1;
     LDETR_CHECK(x && w && (out_p3 || out_f32), "p3_conv2d_fwd: null operand");
+    LDETR_CHECK(!x2 || (w2 && (out2_p3 || out2_f32)), "p3_conv2d_fwd_dual: null operand in the second set");
     LDETR_CHECK(Cin % 32 == 0 && Cout % 8 == 0 && KH * KW <= 32 && pad < KH && pad < KW && (stride == 1 || stride == 2),
                 "p3_conv2d_fwd: unsupported geometry (Cin=%d Cout=%d k=%dx%d stride=%d pad=%d)", Cin, Cout, KH, KW, stride, pad);
     const long xbytes = (long)N * H * W * Cin * 6, wbytes = (long)Cout * KH * KW * Cin * 6, pad_off = ((long)pad * W + pad) * Cin * 6;
@@ -1411,7 +1431,12 @@ extern "C" int ldetr_p3_conv2d_fwd(const void* x, int N, int H, int W, int Cin, 
             c.X = (const char*)x; c.x_bytes = (unsigned)xbytes; c.Wt = (const char*)w; c.w_bytes = (unsigned)wbytes;
             c.Cin = Cin; c.Nout = Cout; c.flip = 0; c.ncc = Cin / 32;
             fill_epi(c.ep, ep); c.ep.out_p3 = (char*)out_p3; c.ep.out_f32 = out_f32;
-            return launch_c3(c, (hipStream_t)stream);
+            P3Group2 g2; memset(&g2, 0, sizeof(g2));
+            if (x2) {
+                c.ngroups = 2; g2.A2 = (const char*)x2; g2.B2 = (const char*)w2;
+                fill_epi(g2.ep2, ep2); g2.ep2.out_p3 = (char*)out2_p3; g2.ep2.out_f32 = out2_f32;
+            }
+            return launch_c3(c, g2, (hipStream_t)stream);
         }
     }
     P3NtParams p; memset(&p, 0, sizeof(p));
@@ -1420,8 +1445,28 @@ extern "C" int ldetr_p3_conv2d_fwd(const void* x, int N, int H, int W, int Cin, 
     p.out_H = OH; p.out_W = OW; p.out_step = 1; p.tap_mode = 0; p.kh0 = 0; p.kw0 = 0; p.tstep = 1; p.nty = KH; p.ntx = KW;
     p.nkt = KH * KW * Cin / 32;
     fill_epi(p.ep, ep); p.ep.out_p3 = (char*)out_p3; p.ep.out_f32 = out_f32;
+    P3Group2 g2; memset(&g2, 0, sizeof(g2));
+    if (x2) {
+        p.ngroups = 2; g2.A2 = (const char*)x2 - pad_off; g2.B2 = (const char*)w2;
+        fill_epi(g2.ep2, ep2); g2.ep2.out_p3 = (char*)out2_p3; g2.ep2.out_f32 = out2_f32;
+    }
     if (p.M == 0) return LDETR_OK;
-    return launch_nt(p, true, (hipStream_t)stream);
+    return launch_nt(p, g2, true, (hipStream_t)stream);
+}
+
+extern "C" int ldetr_p3_conv2d_fwd(const void* x, int N, int H, int W, int Cin, const void* w, int Cout, int KH, int KW, int stride, int pad,
+                                   const ldetr_p3_epilogue* ep, void* out_p3, float* out_f32, void* stream) {
+    return p3_conv2d_fwd_impl(x, N, H, W, Cin, w, Cout, KH, KW, stride, pad, ep, out_p3, out_f32, nullptr, nullptr, nullptr, nullptr, nullptr, stream);
+}
+
+// The same convolution geometry on TWO (activations, weights, epilogue, output) sets as ONE launch: G's and D's ResNet trunks see the same
+// backgrounds through the same architecture with different weights, and two short launches in one grid overlap each other's fill and store
+// burst (the second set's blocks are dispatched behind the first's; see ldetr_p3_conv2d_bwd_pair).
+extern "C" int ldetr_p3_conv2d_fwd_dual(const void* x1, const void* x2, int N, int H, int W, int Cin, const void* w1, const void* w2, int Cout, int KH, int KW,
+                                        int stride, int pad, const ldetr_p3_epilogue* ep1, const ldetr_p3_epilogue* ep2, void* out1_p3, float* out1_f32,
+                                        void* out2_p3, float* out2_f32, void* stream) {
+    LDETR_CHECK(x2 != nullptr, "p3_conv2d_fwd_dual: null operand in the second set");
+    return p3_conv2d_fwd_impl(x1, N, H, W, Cin, w1, Cout, KH, KW, stride, pad, ep1, out1_p3, out1_f32, x2, w2, ep2, out2_p3, out2_f32, stream);
 }
 
 // dx[n][iy][ix][ci] = sum dy[n][(iy + pad - kh) / stride][(ix + pad - kw) / stride][co] * wb[ci][kh][kw][co] over the taps that divide:
@@ -1431,9 +1476,10 @@ extern "C" int ldetr_p3_conv2d_bwd_data(const void* dy, int N, int OH, int OW, i
     bool use_c3; P3C3Params c; P3NtParams p;
     const int rc = setup_bwd_data(dy, N, OH, OW, Cout, wb, Cin, KH, KW, stride, pad, IH, IW, ep, out_p3, out_f32, use_c3, c, p);
     if (rc != LDETR_OK) return rc;
-    if (use_c3) return launch_c3(c, (hipStream_t)stream);
+    P3Group2 none; memset(&none, 0, sizeof(none));
+    if (use_c3) return launch_c3(c, none, (hipStream_t)stream);
     if (p.M == 0) return LDETR_OK;
-    return launch_nt(p, false, (hipStream_t)stream);
+    return launch_nt(p, none, false, (hipStream_t)stream);
 }
 
 extern "C" int ldetr_p3_conv2d_bwd_weight(const void* x, int N, int H, int W, int Cin, const void* dy, int Cout, int KH, int KW, int stride, int pad,
@@ -1485,7 +1531,8 @@ extern "C" int ldetr_p3_conv2d_bwd_pair(const void* dy, int N, int OH, int OW, i
     }
     rc = launch_tn(pt, st);
     if (rc != LDETR_OK) return rc;
-    rc = use_c3 ? launch_c3(c, st) : (pn.M == 0 ? LDETR_OK : launch_nt(pn, false, st));
+    P3Group2 none; memset(&none, 0, sizeof(none));
+    rc = use_c3 ? launch_c3(c, none, st) : (pn.M == 0 ? LDETR_OK : launch_nt(pn, none, false, st));
     if (launches) *launches = 2;
     return rc;
 }

@@ -206,10 +206,14 @@ class ResNet50Body(nn.Module):
         N, H, W, C = x.shape
         return os.environ.get('LDETR_TRUNK_P3', '1') != '0' and N * H * W * 256 * 6 < 0x7fffffff and N * H * W < (1 << 24)
 
+    injected = None   # {(data_ptr, shape) of an input batch: its trunk output}, parked by dual_trunk_forward; consumed by the next forward on that batch
+
     def forward(self, x_nchw):
-        s, b = self.bn1.folded()
-        x = hconv.conv2d_nhwc(x_nchw, self.conv1.weight, s, b, None, 2, 3, relu=True, x_is_nchw=True)
-        x = hconv.maxpool3x3s2_nhwc(x)
+        if self.injected:
+            hit = self.injected.pop((x_nchw.data_ptr(), tuple(x_nchw.shape)), None)
+            if hit is not None:
+                return hit
+        x = self._entrance(x_nchw)
         if self.p3_enabled(x):
             return self._forward_p3(x)
         x = self.layer1(x); x = self.layer2(x)
@@ -221,10 +225,30 @@ class ResNet50Body(nn.Module):
             x = st.cut(x, 2)
         return x  # [N, H/32, W/32, 2048]
 
-    def _forward_p3(self, x):
+    def _entrance(self, x_nchw):
+        """Stem (7x7 / 2 conv + FrozenBN + ReLU on the fp32-operand engine) and max-pool -> fp32 [N, H/4, W/4, 64]."""
+        s, b = self.bn1.folded()
+        x = hconv.conv2d_nhwc(x_nchw, self.conv1.weight, s, b, None, 2, 3, relu=True, x_is_nchw=True)
+        return hconv.maxpool3x3s2_nhwc(x)
+
+    def _forward_p3(self, x, replay=None):
+        """replay: the plane-format input followed by the 52 convolutions' precomputed outputs in call order (dual_trunk_forward); the pass then only
+        builds the autograd graph."""
         planes = self.p3_planes()
         planes.ensure()
-        x = hp3.split(x)
+        x = hp3.split(x, pre=(replay.pop(0) if replay is not None else None))
+        if replay is not None:
+            prev, hp3._REPLAY[0] = hp3._REPLAY[0], replay
+            try:
+                y = self._blocks_p3(x, planes)
+            finally:
+                hp3._REPLAY[0] = prev
+            if replay:
+                raise RuntimeError('p3 replay: precomputed activations left over')
+            return y
+        return self._blocks_p3(x, planes)
+
+    def _blocks_p3(self, x, planes):
         for b in self.layer1:
             x = b.forward_p3(x, planes)
         for b in self.layer2:
@@ -240,6 +264,42 @@ class ResNet50Body(nn.Module):
         if st is not None:
             x = st.cut(x, 2)
         return x  # fp32 [N, H/32, W/32, 2048]
+
+
+def dual_trunk_forward(body_a, body_b, x_a, x_b):
+    """body_a(x_a), body_b(x_b) for two ResNet50Body modules on same-shaped image batches, every plane-format convolution of the two trunks as ONE
+    grouped launch (ldetr_p3_conv2d_fwd_dual).  G's and D's trunks convolve the same backgrounds through the same architecture with different
+    weights (networks_detr.py:79-82 and :230-233 build one backbone each); each conv alone is a short launch whose blocks run in lock-step, and two
+    of them in one grid overlap each other's fill and store burst.  Values are those of the two separate forwards bit for bit (same
+    kernels, same tiles); each module's autograd graph is built by its own ordinary forward, replayed around the precomputed activations, so the
+    two backward passes stay independent (they run in different phases)."""
+    ea, eb = body_a._entrance(x_a), body_b._entrance(x_b)
+    if not (body_a.p3_enabled(ea) and tuple(ea.shape) == tuple(eb.shape)):
+        return body_a(x_a), body_b(x_b)
+    planes_a, planes_b = body_a.p3_planes(), body_b.p3_planes()
+    planes_a.ensure(); planes_b.ensure()
+    outs_a, outs_b = [], []
+    with torch.no_grad():
+        ca, cb = hp3.split_raw(ea.detach()), hp3.split_raw(eb.detach())
+        outs_a.append(ca); outs_b.append(cb)
+        blocks_a = [b for li in range(1, 5) for b in getattr(body_a, f'layer{li}')]
+        blocks_b = [b for li in range(1, 5) for b in getattr(body_b, f'layer{li}')]
+
+        def dual(xa, xb, conv_a, conv_b, ia, ib, bn_a, bn_b, stride, pad, relu, res_a=None, res_b=None, out_f32=False):
+            (sa, ha), (sb, hb) = bn_a.folded(), bn_b.folded()
+            ya, yb = hp3.conv_fwd_dual_raw(xa, xb, planes_a.ptrs(ia)[0], planes_b.ptrs(ib)[0], conv_a.weight.shape, hp3._epi(sa, ha, residual_p3=res_a, relu=relu),
+                                           hp3._epi(sb, hb, residual_p3=res_b, relu=relu), stride, pad, out_f32)
+            outs_a.append(ya); outs_b.append(yb)
+            return ya, yb
+        for i, (ba, bb) in enumerate(zip(blocks_a, blocks_b)):
+            (a1, a2, a3, ad), (b1, b2, b3, bd) = ba.p3_index, bb.p3_index
+            o1a, o1b = dual(ca, cb, ba.conv1, bb.conv1, a1, b1, ba.bn1, bb.bn1, 1, 0, True)
+            o2a, o2b = dual(o1a, o1b, ba.conv2, bb.conv2, a2, b2, ba.bn2, bb.bn2, ba.conv2.stride, 1, True)
+            ida, idb = ca, cb
+            if ba.downsample is not None:
+                ida, idb = dual(ca, cb, ba.downsample[0], bb.downsample[0], ad, bd, ba.downsample[1], bb.downsample[1], ba.downsample[0].stride, 0, False)
+            ca, cb = dual(o2a, o2b, ba.conv3, bb.conv3, a3, b3, ba.bn3, bb.bn3, 1, 0, True, ida, idb, out_f32=(i == len(blocks_a) - 1))
+    return body_a._forward_p3(ea, replay=outs_a), body_b._forward_p3(eb, replay=outs_b)
 
 
 class BackboneBase(nn.Module):

@@ -102,19 +102,32 @@ class StyleGAN2Loss(Loss):
         stages: a detr_backbone.BackwardStages that records the trunk's backward cuts (Dmain's staged backward continues from them)."""
         if self.share_D_trunk != 'iteration' or not hasattr(self.D, 'trunk'):
             return
-        trunk_params = list(self.D.backbone.parameters())
+        body = self.D.backbone[0].body
+        # G's trunk for the Gmain phase rides along: same backgrounds, same architecture, different weights -> every convolution of the two trunks
+        # as one grouped launch (detr_backbone.dual_trunk_forward); G's output is parked on its body and consumed by Gmain's generator forward.
+        # Not with a staged backward (its cuts are recorded inside the ordinary forward) and not for ragged backgrounds.
+        g_body = self.G.backbone[0].body if hasattr(self.G, 'backbone') else None
+        dual = (stages is None and g_body is not None and isinstance(background, torch.Tensor) and os.environ.get('LDETR_DUAL_TRUNK', '1') != '0'
+                and type(g_body) is type(body) and hasattr(body, '_entrance'))
+        trunk_params = list(self.D.backbone.parameters()) + (list(self.G.backbone.parameters()) if dual else [])
         was = [p.requires_grad for p in trunk_params]
         for p in trunk_params:
-            p.requires_grad_(True)     # the autograd graph is built now, used by Dmain's backward (training_loop.py:282 sets it there)
-        body = self.D.backbone[0].body
+            p.requires_grad_(True)     # the autograd graphs are built now, used by the phases' backward passes (training_loop.py:282 sets it there)
         try:
             if stages is not None:
                 body.stages = stages
             with torch.enable_grad():
+                if dual:
+                    from .detr_backbone import dual_trunk_forward
+                    key = (background.data_ptr(), tuple(background.shape))
+                    out_g, out_d = dual_trunk_forward(g_body, body, background, background)
+                    g_body.injected = dict(g_body.injected or {}); g_body.injected[key] = out_g
+                    body.injected = {key: out_d}
                 self._trunk_cache[self._bg_key(background)] = self.D.trunk(background)
         finally:
             if stages is not None:
                 body.stages = None
+            body.injected = None
             for p, w in zip(trunk_params, was):
                 p.requires_grad_(w)
 
@@ -225,6 +238,9 @@ class StyleGAN2Loss(Loss):
             phase = {'Greg': 'none', 'Gboth': 'Gmain'}.get(phase, phase)
         if self.r1_gamma == 0:
             phase = {'Dreg': 'none', 'Dboth': 'Dmain'}.get(phase, phase)
+        g_body = self.G.backbone[0].body if hasattr(self.G, 'backbone') else None
+        if phase != 'Gmain' and g_body is not None and getattr(g_body, 'injected', None):
+            g_body.injected = None     # a parked G-trunk evaluation belongs to this iteration's Gmain only
         if phase == 'Gmain':
             self.g_main_loss(bbox_real, bbox_class, bbox_text, bbox_patch, padding_mask, background, gen_z, gen_c).mul(gain).backward()
         if phase == 'Dmain':

@@ -367,3 +367,31 @@ def test_resnet_trunk_plane_path_equals_fp32_engine_path(dev):
     errs = sorted(err(g1[n], g0[n]) for n in g1)
     med, p90 = errs[len(errs) // 2], errs[int(len(errs) * 0.9)]
     assert med <= 1e-4 and p90 <= 5e-3, f'trunk gradients: median {med:.2e}, p90 {p90:.2e}, worst {errs[-1]:.2e}'
+
+
+def test_dual_trunk_forward_equals_two_forwards(dev):
+    """detr_backbone.dual_trunk_forward (every plane-format conv of G's and D's trunk as one grouped launch, each module's autograd graph replayed around the
+    precomputed activations) against the two ordinary forwards: the same kernels on the same tiles -> identical outputs, and the same gradients up to the
+    order of the weight gradients' atomics."""
+    from layoutdetr_amd.training.detr_backbone import ResNet50Body, dual_trunk_forward
+    torch.manual_seed(8)
+    ba, bb = ResNet50Body().to(dev).train(), ResNet50Body().to(dev).train()
+    for p in list(ba.parameters()) + list(bb.parameters()):
+        p.requires_grad_(True)
+    img = torch.randn(2, 3, 64, 64, device=dev)
+    ga = torch.randn(2, 2, 2, 2048, device=dev); gb = torch.randn(2, 2, 2, 2048, device=dev)
+    ya, yb = ba(img), bb(img)
+    (ya * ga).sum().backward(); (yb * gb).sum().backward()
+    ref = {id(p): p.grad.clone() for p in list(ba.parameters()) + list(bb.parameters()) if p.grad is not None}
+    for p in list(ba.parameters()) + list(bb.parameters()):
+        p.grad = None
+    da, db = dual_trunk_forward(ba, bb, img, img)
+    assert torch.equal(da, ya) and torch.equal(db, yb), 'grouped forward differs from the two separate forwards'
+    (da * ga).sum().backward()          # the two backward passes are independent (they run in different phases of the step)
+    (db * gb).sum().backward()
+    n = 0
+    for p in list(ba.parameters()) + list(bb.parameters()):
+        if id(p) in ref:
+            e = err(p.grad, ref[id(p)]); n += 1
+            assert e <= 2e-5, f'gradient of a {tuple(p.shape)} parameter: {e:.2e}'
+    assert n > 100
