@@ -362,3 +362,64 @@ def test_stats_allreduce_flat_broadcast_and_consistency_check_gloo_world2():
         p.join(timeout=60)
         assert p.exitcode == 0
     assert all(all(r[1:]) for r in res), res
+
+
+def test_p3_entry_points_validate_before_launching():
+    """The plane-format convolution entry points (csrc/p3_engine.hip) check geometry and pointers on the host: testable without a GPU."""
+    import ctypes
+    from layoutdetr_amd import _lib
+    lib = _lib.load()
+    P = ctypes.c_void_p
+    rc = lib.ldetr_p3_conv2d_fwd(None, 1, 8, 8, 32, None, 64, 1, 1, 1, 0, None, None, None, None)
+    assert rc != 0 and b'null operand' in lib.ldetr_last_error()
+    rc = lib.ldetr_p3_conv2d_fwd(P(64), 1, 8, 8, 24, P(64), 64, 1, 1, 1, 0, None, P(64), None, None)          # Cin not a multiple of 32
+    assert rc != 0 and b'unsupported geometry' in lib.ldetr_last_error()
+    rc = lib.ldetr_p3_conv2d_fwd(P(64), 1, 8, 8, 32, P(64), 64, 3, 3, 3, 1, None, P(64), None, None)          # stride 3
+    assert rc != 0 and b'unsupported geometry' in lib.ldetr_last_error()
+    rc = lib.ldetr_p3_conv2d_fwd(P(64), 4096, 512, 512, 256, P(64), 64, 1, 1, 1, 0, None, P(64), None, None)  # beyond 31-bit buffer offsets
+    assert rc != 0 and b'too large' in lib.ldetr_last_error()
+    rc = lib.ldetr_p3_conv2d_fwd_dual(P(64), None, 1, 8, 8, 32, P(64), P(64), 64, 1, 1, 1, 0, None, None, P(64), None, P(64), None, None)
+    assert rc != 0 and b'second set' in lib.ldetr_last_error()
+    rc = lib.ldetr_p3_conv2d_bwd_weight(P(64), 1, 8, 8, 32, P(64), 48, 1, 1, 1, 0, None, P(64), None)         # Cout not a multiple of 32
+    assert rc != 0 and b'unsupported geometry' in lib.ldetr_last_error()
+    rc = lib.ldetr_p3_conv2d_bwd_pair(P(64), 1, 8, 8, 64, P(64), P(64), 32, 1, 1, 1, 0, 8, 8, None, None, None, None, P(64), None, None)
+    assert rc != 0 and b'null operand' in lib.ldetr_last_error()                                              # neither dx_p3 nor dx_f32
+    rc = lib.ldetr_p3_split_f32(P(64), 12, P(64), 4, 12, None)                                               # C not a multiple of 8
+    assert rc != 0 and b'multiple of 8' in lib.ldetr_last_error()
+    assert lib.ldetr_p3_split_f32(P(64), 16, P(64), 0, 16, None) == 0                                         # empty input
+
+
+def test_backward_stage_count_and_two_stage_segments(monkeypatch):
+    """training_loop.backward_stage_count (trunk | rest at <= 4 samples per GPU, three stages above, LDETR_BACKWARD_STAGES overrides) and
+    FlatModule.stage_segments(2): the two-stage segments tile the flat buffer and merge the three-stage trunk segments."""
+    from layoutdetr_amd.training import training_loop as tl
+    monkeypatch.delenv('LDETR_BACKWARD_STAGES', raising=False)
+    assert [tl.backward_stage_count(b) for b in (1, 2, 4, 5, 16)] == [2, 2, 2, 3, 3]
+    monkeypatch.setenv('LDETR_BACKWARD_STAGES', '3')
+    assert tl.backward_stage_count(2) == 3
+    monkeypatch.setenv('LDETR_BACKWARD_STAGES', '2')
+    assert tl.backward_stage_count(16) == 2
+    monkeypatch.setenv('LDETR_BACKWARD_STAGES', 'junk')
+    assert tl.backward_stage_count(16) == 3
+
+    class Body(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.conv1 = torch.nn.Linear(3, 4)
+            for li in range(1, 5):
+                setattr(self, f'layer{li}', torch.nn.Linear(4, 4))
+
+    class Net(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.pos_token = torch.nn.Parameter(torch.zeros(5))
+            self.backbone = torch.nn.Sequential(torch.nn.Sequential())
+            self.backbone[0].body = Body()
+            self.head = torch.nn.Linear(4, 2)
+    fm = tl.FlatModule(Net())
+    s3, s2 = fm.stage_segments(3), fm.stage_segments(2)
+    assert len(s3) == 3 and len(s2) == 2 and s2[0] == s3[0]
+    (lo3, hi3), = s3[2]; (lo2, hi2), = s3[1]; (lo, hi), = s2[1]
+    assert (lo, hi) == (lo3, hi2) and hi3 == lo2, 'the two-stage trunk segment is layer1-2 followed by layer3-4'
+    ranges = sorted(r for st in s2 for r in st)
+    assert ranges[0][0] == 0 and ranges[-1][1] == fm.total and all(a[1] == b[0] for a, b in zip(ranges[:-1], ranges[1:]))
