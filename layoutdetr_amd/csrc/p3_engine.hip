@@ -995,30 +995,20 @@ __global__ __launch_bounds__(256) void p3_tn_kernel(P3TnParams p) { p3_tn_body<B
 // independent: on two streams they overlap to 0.65-0.85 of their serial time (tools/p3_dev.py pair), but parallel branches of a captured
 // hipGraph do not (0.92-1.0; `pair graph`), and the step is a graph.  So the pair is one grid holding both kernels' blocks; both read dY
 // (one L2 fill).
-// Which body a block of the paired grid runs, and its index in that body's own grid.  Default (order 0): the weight gradient's blocks first,
-// padded to a multiple of 8 so that both bodies keep their block -> XCD alignment (block b runs on XCD b % 8); the data gradient's blocks move
-// in as those retire.  Order 2 is the mirror image; order 1 interleaves the two in chunks of 8 in proportion to their counts; measured slower
-// (profiles/r04_p3_sweeps.txt: 0.98 against 0.85 of the two separate launches): CUs that hold both kinds at once lose more than the overlap gains.
-__device__ __forceinline__ bool p3_pair_split(int b, int n_tn8, int n_other8, int order, int& idx) {
-    if (order == 0) {          // weight gradient first
-        if (b < n_tn8 * 8) { idx = b; return true; }
-        idx = b - n_tn8 * 8; return false;
-    }
-    if (order == 2) {          // data gradient first
-        if (b < n_other8 * 8) { idx = b; return false; }
-        idx = b - n_other8 * 8; return true;
-    }
-    const int c = b >> 3, tot = n_tn8 + n_other8;
-    const int a = (int)(((long)c * n_tn8) / tot), a1 = (int)(((long)(c + 1) * n_tn8) / tot);
-    if (a1 > a) { idx = a * 8 + (b & 7); return true; }
-    idx = (c - a) * 8 + (b & 7);
+// Which body a block of the paired grid runs, and its index in that body's own grid: the weight gradient's blocks first, padded to a multiple of
+// 8 so that both bodies keep their block -> XCD alignment (block b runs on XCD b % 8); the data gradient's blocks move in as those retire.  Measured
+// alternatives (profiles/r04_p3_sweeps.txt): data gradient first 438.6 images/s against 443.5; the two kinds interleaved in chunks of 8 in
+// proportion to their counts 437.7 (0.98 of the separate launches against 0.85): CUs that hold both kinds at once lose more than the overlap gains.
+__device__ __forceinline__ bool p3_pair_split(int b, int n_tn8, int& idx) {
+    if (b < n_tn8 * 8) { idx = b; return true; }
+    idx = b - n_tn8 * 8;
     return false;
 }
 
 template <int BM, int BN, int NST>
-__global__ __launch_bounds__(256) void p3_bwd_pair_nt_kernel(P3NtParams pn, P3TnParams pt, int n_tn, int n_tn8, int n_nt8, int order, int tn_sk, int nt_gx, int nt_sk) {
+__global__ __launch_bounds__(256) void p3_bwd_pair_nt_kernel(P3NtParams pn, P3TnParams pt, int n_tn, int n_tn8, int tn_sk, int nt_gx, int nt_sk) {
     int idx;
-    if (p3_pair_split(blockIdx.x, n_tn8, n_nt8, order, idx)) {
+    if (p3_pair_split(blockIdx.x, n_tn8, idx)) {
         if (idx < n_tn) p3_tn_body<64, 64, 1, 1>(pt, idx % tn_sk, idx / tn_sk);
         return;
     }
@@ -1026,9 +1016,9 @@ __global__ __launch_bounds__(256) void p3_bwd_pair_nt_kernel(P3NtParams pn, P3Tn
     p3_nt_body<BM, BN, 4, 1, NST, false>(pn, none, idx % nt_gx, (idx / nt_gx) % nt_sk, idx / (nt_gx * nt_sk));
 }
 
-__global__ __launch_bounds__(256, 2) void p3_bwd_pair_c3_kernel(P3C3Params pc, P3TnParams pt, int n_tn, int n_tn8, int n_c38, int order, int tn_sk, int c3_gx) {
+__global__ __launch_bounds__(256, 2) void p3_bwd_pair_c3_kernel(P3C3Params pc, P3TnParams pt, int n_tn, int n_tn8, int tn_sk, int c3_gx) {
     int idx;
-    if (p3_pair_split(blockIdx.x, n_tn8, n_c38, order, idx)) {
+    if (p3_pair_split(blockIdx.x, n_tn8, idx)) {
         if (idx < n_tn) p3_tn_body<64, 64, 1, 1>(pt, idx % tn_sk, idx / tn_sk);
         return;
     }
@@ -1508,7 +1498,6 @@ extern "C" int ldetr_p3_conv2d_bwd_pair(const void* dy, int N, int OH, int OW, i
     static const int pair_on = env_int("LDETR_P3_PAIR", 3);   // bit 0: gather kernel + weight gradient, bit 1: patch kernel + weight gradient
     const bool forced = env_int("LDETR_P3_TILE", 0) || env_int("LDETR_P3_WTILE", 0) || env_int("LDETR_P3_PF", 0) || env_int("LDETR_P3_WPF", 0) || env_int("LDETR_P3_NST", 0);
     if (!forced && ((use_c3 && (pair_on & 2)) || (!use_c3 && (pair_on & 1)))) {
-        static const int order = env_int("LDETR_P3_PAIR_ORDER", 0);   // 0: the weight gradient's blocks first (0.85 of the two launches over the trunk shapes), 1: interleaved (0.98), 2: data gradient first
         plan_tn<64, 64>(pt, env_int("LDETR_P3_WSLOTS", 512));
         const long n_tn = (long)pt.splitk * pt.mtiles * pt.ntiles * pt.KH * pt.KW, n_tn_pad = (n_tn + 7) / 8 * 8;
         constexpr size_t lds_tn = (size_t)1 * (64 + 64) * 192;   // one LDS stage for the weight gradient's blocks: more blocks of either kind per CU
@@ -1517,13 +1506,12 @@ extern "C" int ldetr_p3_conv2d_bwd_pair(const void* dy, int N, int OH, int OW, i
             const size_t lds = C3_LDS > lds_tn ? (size_t)C3_LDS : lds_tn;
             static bool raised = false;
             if (!raised) { if (!raise_lds(reinterpret_cast<const void*>(&p3_bwd_pair_c3_kernel), lds, "p3_bwd_pair_c3")) return LDETR_ERR_LAUNCH; raised = true; }
-            hipLaunchKernelGGL(p3_bwd_pair_c3_kernel, dim3((unsigned)(n_tn_pad + gx * c.splitk)), 256, lds, st, c, pt, (int)n_tn, (int)(n_tn_pad / 8), (int)(gx * c.splitk / 8), order,
-                               pt.splitk, (int)gx);
+            hipLaunchKernelGGL(p3_bwd_pair_c3_kernel, dim3((unsigned)(n_tn_pad + gx * c.splitk)), 256, lds, st, c, pt, (int)n_tn, (int)(n_tn_pad / 8), pt.splitk, (int)gx);
         } else {
             const NtGrid g = plan_nt<64, 64, 4, 1>(pn, nt_splitk(pn, 64, 64, 512));
             const size_t lds = g.lds > lds_tn ? g.lds : lds_tn;
-            hipLaunchKernelGGL((p3_bwd_pair_nt_kernel<64, 64, 1>), dim3((unsigned)(n_tn_pad + g.gx * g.sk * g.ncls)), 256, lds, st, pn, pt, (int)n_tn, (int)(n_tn_pad / 8),
-                               (int)(g.gx * g.sk * g.ncls / 8), order, pt.splitk, (int)g.gx, g.sk);
+            hipLaunchKernelGGL((p3_bwd_pair_nt_kernel<64, 64, 1>), dim3((unsigned)(n_tn_pad + g.gx * g.sk * g.ncls)), 256, lds, st, pn, pt, (int)n_tn, (int)(n_tn_pad / 8), pt.splitk,
+                               (int)g.gx, g.sk);
         }
         note_engine_launch(true);
         if (launches) *launches = 1;

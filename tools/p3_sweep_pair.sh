@@ -1,7 +1,7 @@
 #!/bin/bash
 # Paired-backward sweep: gpurun -- 'bash tools/p3_sweep_pair.sh <tag>' -> gpurun_out/<tag>_pair_sweep.txt
 out=gpurun_out/${1:-r04}_pair_sweep.txt; : > $out
-for order in 0 1; do for slots in 512 1024; do
+for order in 0; do for slots in 512 1024; do   # (the block-order switch was removed after the sweep: weight gradient first)
   echo "== ORDER=$order WSLOTS=$slots" >> $out
   LDETR_P3_PAIR_ORDER=$order LDETR_P3_WSLOTS=$slots python tools/p3_dev.py pair 2>&1 | grep -v amdgpu.ids | cut -c1-25,85-200 >> $out
 done; done
