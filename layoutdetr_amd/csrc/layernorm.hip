@@ -46,17 +46,18 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(LnParams p) {
                 float4 rr = reinterpret_cast<const float4*>(p.r + row * p.D)[c4];
                 if (p.r_parts > 0) {
                     if (p.r_bias) { const float4 bb = reinterpret_cast<const float4*>(p.r_bias)[c4]; rr.x += bb.x; rr.y += bb.y; rr.z += bb.z; rr.w += bb.w; }
-                    int s = 1;
-                    for (; s + 8 <= p.r_parts; s += 8) {      // eight loads in flight, added in slice order (a load per iteration serialised 31 round trips: 12 us)
-                        float4 q[8];
+                    // sixteen loads in flight per round, the ragged tail as a predicated round (uniform predicate), added in slice order.  A load per
+                    // iteration serialised 31 round trips (12 us); rounds of eight with a scalar tail still serialised the 7 leftover slices of the
+                    // 8-head and 32-slice residuals: 7-10 round trips per launch instead of 1-2.
+                    constexpr int PW = NV == 1 ? 16 : 8;      // (wider rows keep their register budget: their launches are bandwidth-, not latency-bound)
+                    for (int s = 1; s < p.r_parts; s += PW) {
+                        float4 q[PW];
 #pragma unroll
-                        for (int j = 0; j < 8; j++) q[j] = reinterpret_cast<const float4*>(p.r + (s + j) * p.r_part_stride + row * p.D)[c4];
+                        for (int j = 0; j < PW; j++)
+                            q[j] = (s + j < p.r_parts) ? reinterpret_cast<const float4*>(p.r + (s + j) * p.r_part_stride + row * p.D)[c4] : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-                        for (int j = 0; j < 8; j++) { rr.x += q[j].x; rr.y += q[j].y; rr.z += q[j].z; rr.w += q[j].w; }
-                    }
-                    for (; s < p.r_parts; s++) {
-                        const float4 q = reinterpret_cast<const float4*>(p.r + s * p.r_part_stride + row * p.D)[c4];
-                        rr.x += q.x; rr.y += q.y; rr.z += q.z; rr.w += q.w;
+                        for (int j = 0; j < PW; j++)
+                            if (s + j < p.r_parts) { rr.x += q[j].x; rr.y += q[j].y; rr.z += q[j].z; rr.w += q[j].w; }
                     }
                 }
                 if (p.p_drop > 0.f) {
@@ -131,19 +132,15 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(LnParams p) {
                     const float4 d2 = reinterpret_cast<const float4*>(p.dy2 + row * p.D)[c4];
                     dy.x += d2.x; dy.y += d2.y; dy.z += d2.z; dy.w += d2.w;
                 }
-                {
-                    int s = 0;
-                    for (; s + 8 <= p.dy_nparts; s += 8) {
-                        float4 q[8];
+                constexpr int PW = NV == 1 ? 16 : 8;
+                for (int s = 0; s < p.dy_nparts; s += PW) {      // PW loads in flight, ragged tail predicated (see ln_fwd_kernel)
+                    float4 q[PW];
 #pragma unroll
-                        for (int j = 0; j < 8; j++) q[j] = reinterpret_cast<const float4*>(p.dy_parts + (s + j) * p.dy_part_stride + row * p.D)[c4];
+                    for (int j = 0; j < PW; j++)
+                        q[j] = (s + j < p.dy_nparts) ? reinterpret_cast<const float4*>(p.dy_parts + (s + j) * p.dy_part_stride + row * p.D)[c4] : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-                        for (int j = 0; j < 8; j++) { dy.x += q[j].x; dy.y += q[j].y; dy.z += q[j].z; dy.w += q[j].w; }
-                    }
-                    for (; s < p.dy_nparts; s++) {
-                        const float4 d2 = reinterpret_cast<const float4*>(p.dy_parts + s * p.dy_part_stride + row * p.D)[c4];
-                        dy.x += d2.x; dy.y += d2.y; dy.z += d2.z; dy.w += d2.w;
-                    }
+                    for (int j = 0; j < PW; j++)
+                        if (s + j < p.dy_nparts) { dy.x += q[j].x; dy.y += q[j].y; dy.z += q[j].z; dy.w += q[j].w; }
                 }
                 float4 gm = reinterpret_cast<const float4*>(p.gamma)[c4];
                 xh[i].x = (zz.x - mean) * rstd; xh[i].y = (zz.y - mean) * rstd;
