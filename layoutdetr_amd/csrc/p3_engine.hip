@@ -1160,6 +1160,16 @@ static NtGrid plan_nt(P3NtParams& p, int sk) {
     return g;
 }
 
+// Block-slot target of the split-K / pixel-slice policies by the launch's algorithmic work: below LDETR_P3_SMALL_GFLOP (default 1.5: the trunk at a
+// few samples per GPU) a launch is a latency chain and every extra reduction slice adds a partial-tile round trip to it -> 256 slots; above, 512
+// slots fill the chip.  2 samples per GPU 19.14 -> 18.77 ms, 4 per GPU 21.46 -> 21.02, 16 per GPU unchanged (profiles/r04_p3_sweeps.txt).
+static long slot_target(double flops, long dflt) {
+    static const double small = (getenv("LDETR_P3_SMALL_GFLOP") ? atof(getenv("LDETR_P3_SMALL_GFLOP")) : 1.5) * 1e9;
+    return (flops < small && dflt > 256) ? 256 : dflt;
+}
+static double nt_flops(const P3NtParams& p) { return 2.0 * p.M * p.N * p.nkt * 32.0 * (p.nclass > 1 ? p.nclass : 1); }
+static double tn_flops(const P3TnParams& p) { return 2.0 * p.npix * p.Cout * (double)p.Cin * p.KH * p.KW; }
+
 // split-K factor of a tile configuration: fill `slots` block slots, at least four k-tiles per slice
 static int nt_splitk(const P3NtParams& p, int bm, int bn, long slots) {
     const long nt = (long)cdiv(p.M, bm) * cdiv(p.N, bn);
@@ -1191,7 +1201,7 @@ static int launch_nt(P3NtParams& p, const P3Group2& g2, bool forward, hipStream_
     if (forward && p.nclass <= 1 && ((p.M >= 65536 && p.N >= 128) || (p.M >= 16384 && p.N >= 256 && p.nkt <= 16))) cfg = 1;
     if (force_tile) cfg = force_tile;
     const int bm = cfg == 3 ? 64 : 128, bn = (cfg == 1 || cfg == 4) ? 128 : 64;
-    const int sk = nt_splitk(p, bm, bn, force_slots ? force_slots : ((cfg == 2 || cfg == 3) ? 512 : 256));
+    const int sk = nt_splitk(p, bm, bn, force_slots ? force_slots : slot_target(nt_flops(p), (cfg == 2 || cfg == 3) ? 512 : 256));
     const int pf = force_pf ? force_pf : 1, nst = force_nst ? force_nst : 1;
 #define P3_NT_CASE(BM_, BN_, NW_)                                                                                   \
     switch (pf * 2 + (nst == 1 ? 0 : 1)) {                                                                          \
@@ -1232,7 +1242,8 @@ static long plan_c3(P3C3Params& p) {
     const long nt = (long)p.mtiles * p.ntiles;
     int sk = 1;
     const int force_sk = env_int("LDETR_P3_SK", 0);
-    if (nt < 384) { sk = (int)(512 / nt); if (sk > p.ncc / 2) sk = p.ncc / 2; if (sk > 16) sk = 16; if (sk < 1) sk = 1; }
+    const long slots = slot_target(2.0 * p.N_img * p.H * p.W * (double)p.Nout * 9.0 * p.Cin, 512);
+    if (nt < slots * 3 / 4) { sk = (int)(slots / nt); if (sk > p.ncc / 2) sk = p.ncc / 2; if (sk > 16) sk = 16; if (sk < 1) sk = 1; }
     if (force_sk > 0) sk = force_sk;
     if (sk > p.ncc) sk = p.ncc;
     p.splitk = sk; p.ws = nullptr; p.ws_count = nullptr;
@@ -1300,10 +1311,10 @@ static int launch_tn(P3TnParams& p, hipStream_t st) {
     const int pf = force_pf ? force_pf : 1, nst = force_nst ? force_nst : 1;   // one LDS stage, one pixel tile in flight: 1193 us; two stages / two tiles: 1222-1243 us
 #define P3_TN_CASE(BM_, BN_, TB_)                                                                            \
     switch (pf * 2 + (nst == 1 ? 0 : 1)) {                                                                   \
-        case 2: return launch_tn_cfg<BM_, BN_, 1, 1>(p, force_tb ? force_tb : TB_, st);                      \
-        case 3: return launch_tn_cfg<BM_, BN_, 1, 2>(p, force_tb ? force_tb : TB_, st);                      \
-        case 4: return launch_tn_cfg<BM_, BN_, 2, 1>(p, force_tb ? force_tb : TB_, st);                      \
-        default: return launch_tn_cfg<BM_, BN_, 2, 2>(p, force_tb ? force_tb : TB_, st);                     \
+        case 2: return launch_tn_cfg<BM_, BN_, 1, 1>(p, force_tb ? force_tb : (int)slot_target(tn_flops(p), TB_), st);                      \
+        case 3: return launch_tn_cfg<BM_, BN_, 1, 2>(p, force_tb ? force_tb : (int)slot_target(tn_flops(p), TB_), st);                      \
+        case 4: return launch_tn_cfg<BM_, BN_, 2, 1>(p, force_tb ? force_tb : (int)slot_target(tn_flops(p), TB_), st);                      \
+        default: return launch_tn_cfg<BM_, BN_, 2, 2>(p, force_tb ? force_tb : (int)slot_target(tn_flops(p), TB_), st);                     \
     }
     switch (cfg) {
         case 1: P3_TN_CASE(128, 128, 256)
@@ -1498,7 +1509,7 @@ extern "C" int ldetr_p3_conv2d_bwd_pair(const void* dy, int N, int OH, int OW, i
     static const int pair_on = env_int("LDETR_P3_PAIR", 3);   // bit 0: gather kernel + weight gradient, bit 1: patch kernel + weight gradient
     const bool forced = env_int("LDETR_P3_TILE", 0) || env_int("LDETR_P3_WTILE", 0) || env_int("LDETR_P3_PF", 0) || env_int("LDETR_P3_WPF", 0) || env_int("LDETR_P3_NST", 0);
     if (!forced && ((use_c3 && (pair_on & 2)) || (!use_c3 && (pair_on & 1)))) {
-        plan_tn<64, 64>(pt, env_int("LDETR_P3_WSLOTS", 512));
+        plan_tn<64, 64>(pt, env_int("LDETR_P3_WSLOTS", (int)slot_target(tn_flops(pt), 512)));
         const long n_tn = (long)pt.splitk * pt.mtiles * pt.ntiles * pt.KH * pt.KW, n_tn_pad = (n_tn + 7) / 8 * 8;
         constexpr size_t lds_tn = (size_t)1 * (64 + 64) * 192;   // one LDS stage for the weight gradient's blocks: more blocks of either kind per CU
         if (use_c3) {
@@ -1508,7 +1519,7 @@ extern "C" int ldetr_p3_conv2d_bwd_pair(const void* dy, int N, int OH, int OW, i
             if (!raised) { if (!raise_lds(reinterpret_cast<const void*>(&p3_bwd_pair_c3_kernel), lds, "p3_bwd_pair_c3")) return LDETR_ERR_LAUNCH; raised = true; }
             hipLaunchKernelGGL(p3_bwd_pair_c3_kernel, dim3((unsigned)(n_tn_pad + gx * c.splitk)), 256, lds, st, c, pt, (int)n_tn, (int)(n_tn_pad / 8), pt.splitk, (int)gx);
         } else {
-            const NtGrid g = plan_nt<64, 64, 4, 1>(pn, nt_splitk(pn, 64, 64, 512));
+            const NtGrid g = plan_nt<64, 64, 4, 1>(pn, nt_splitk(pn, 64, 64, slot_target(nt_flops(pn), 512)));
             const size_t lds = g.lds > lds_tn ? g.lds : lds_tn;
             hipLaunchKernelGGL((p3_bwd_pair_nt_kernel<64, 64, 1>), dim3((unsigned)(n_tn_pad + g.gx * g.sk * g.ncls)), 256, lds, st, pn, pt, (int)n_tn, (int)(n_tn_pad / 8), pt.splitk,
                                (int)g.gx, g.sk);
