@@ -140,6 +140,26 @@ class StyleGAN2Loss(Loss):
         feats, pos = out
         return [NestedTensor(f.tensors.detach(), f.mask, getattr(f, 'uniform', False)) for f in feats], [p.detach() for p in pos]
 
+    def _dual_trunks(self, background):
+        """G's and D's trunk on `background` as grouped launches (detr_backbone.dual_trunk_forward), parked on the two bodies for the G and D forwards
+        that follow in this call.  Used where a phase evaluates both trunks itself (the reference's call pattern and phase-level sharing: Gmain's
+        G + D(fake), Dmain's G + first D pass); each module's graph is built by its own replayed forward, so a frozen module gets none."""
+        if os.environ.get('LDETR_DUAL_TRUNK', '1') == '0' or not isinstance(background, torch.Tensor) or not hasattr(self.G, 'backbone') or not hasattr(self.D, 'backbone'):
+            return
+        g_body, d_body = self.G.backbone[0].body, self.D.backbone[0].body
+        if type(g_body) is not type(d_body) or not hasattr(g_body, '_entrance') or g_body.stages is not None or d_body.stages is not None:
+            return
+        from .detr_backbone import dual_trunk_forward
+        key = (background.data_ptr(), tuple(background.shape))
+        out_g, out_d = dual_trunk_forward(g_body, d_body, background, background)
+        g_body.injected = {key: out_g}
+        d_body.injected = {key: out_d}
+
+    def _drop_parked_trunks(self):
+        for m in (self.G, self.D):
+            if hasattr(m, 'backbone') and getattr(m.backbone[0].body, 'injected', None):
+                m.backbone[0].body.injected = None
+
     def run_G(self, z, bbox_class, bbox_real, bbox_text, bbox_patch, padding_mask, background, c, reconst=False, update_emas=False):
         if not reconst:
             return self.G(z, bbox_class, bbox_real, bbox_text, bbox_patch, padding_mask, background, c)
@@ -157,6 +177,8 @@ class StyleGAN2Loss(Loss):
         valid = ~padding_mask
         static = bool(getattr(self.G, 'static_shapes', False))
         cached = self._cached_trunk(background, detach=True, pop=False)
+        if cached is None:
+            self._dual_trunks(background)      # G's trunk and the trunk of D(fake) in one pass
         bbox_fake, loss_z, cls_logits, loss_lm, loss_text_len = self.run_G(gen_z, bbox_class, bbox_real, bbox_text, bbox_patch, padding_mask, background, gen_c, reconst=True)
         gen_logits, gen_logits_uncond = self.run_D(bbox_fake, bbox_class, bbox_text, bbox_patch, padding_mask, background, gen_c,
                                                    trunk_out=cached)
@@ -246,6 +268,8 @@ class StyleGAN2Loss(Loss):
         if phase == 'Dmain':
             if self.share_D_trunk and hasattr(self.D, 'trunk'):   # True / 'phase' / 'iteration'
                 cached = self._cached_trunk(background, detach=False, pop=True)
+                if cached is None:
+                    self._dual_trunks(background)      # the generator's (no-grad) trunk beside the phase's one D-trunk evaluation
                 if self.pair_D_passes and hasattr(self.D, 'forward_pair'):
                     # both D passes of the phase as ONE batch of 2B layouts (Discriminator.forward_pair): half the transformer / head launches
                     bbox_fake = self.run_G(gen_z, bbox_class, bbox_real, bbox_text, bbox_patch, padding_mask, background, gen_c, update_emas=True)
@@ -262,5 +286,6 @@ class StyleGAN2Loss(Loss):
                     l_real = self.d_real_loss(bbox_real, bbox_class, bbox_text, bbox_patch, padding_mask, background, real_c, trunk_out=trunk)
                 (l_gen + l_real).mul(gain).backward()   # one backward: the trunk sees the summed gradient of both passes
             else:
+                self._dual_trunks(background)          # reference call pattern: the generator's trunk beside the trunk of D(fake); D(real) evaluates its own
                 self.d_gen_loss(bbox_real, bbox_class, bbox_text, bbox_patch, padding_mask, background, gen_z, gen_c).mul(gain).backward()
                 self.d_real_loss(bbox_real, bbox_class, bbox_text, bbox_patch, padding_mask, background, real_c).mul(gain).backward()
