@@ -352,7 +352,14 @@ int ldetr_box_giou_pairwise_f32(const float* boxes1, const float* boxes2, int B,
  * P3 storage of an fp32 tensor [rows][C], C % 8 == 0: the exact three-way bf16 split x = hi + mid + lo in 48-byte groups of
  * 8 channels, [rows][C/8][3][8 x bf16] (6 bytes per element; `void*` below).  The convolutions contract such operands on the bf16
  * matrix pipe with fp32 accumulation: fp32-equivalent results (the same six-product scheme as ldetr_set_split_bf16's tiles).
- * Finite values only: an Inf / NaN element stays non-finite but not in the same class (Inf = Inf + NaN + NaN). */
+ * Every fp32 value converts exactly (bit for bit through split -> merge), incl. +-0, +-Inf, NaN and values next to FLT_MAX: a leading part that
+ * would round up to Inf is truncated instead, and a non-finite element is stored as (x, 0, 0).  The six-product contraction itself is exact for
+ * finite operands only, so every kernel checks its accumulators after the k-loop and a wave that finds a non-finite value recomputes its tile with
+ * fp32 FMAs on the merged planes: outputs are NaN / +Inf / -Inf exactly where an fp32 convolution puts them (training_loop.py:308 maps the classes
+ * to different gradients).
+ * Determinism: forward and data gradient are bit-reproducible run to run (split-K partials are summed in slice order by the last-arriving block);
+ * the weight gradient (ldetr_p3_conv2d_bwd_weight, and the dw half of ldetr_p3_conv2d_bwd_pair) accumulates its pixel slices with fp32 atomics onto
+ * the caller's buffer, so its low-order bits depend on the arrival order of the slices. */
 int ldetr_p3_split_f32(const float* src, int64_t ld, void* dst, int64_t rows, int C, void* stream);
 int ldetr_p3_merge_f32(const void* src, float* dst, int64_t ld, int64_t rows, int C, void* stream);
 /* w [O][KH][KW][I] fp32 (times o_scale[o] when not NULL: FrozenBN's factor of the output gradient) -> P3 [I][KH*KW][O], taps in the
@@ -400,6 +407,11 @@ int ldetr_p3_conv2d_bwd_weight(const void* x, int N, int H, int W, int Cin, cons
 int ldetr_p3_conv2d_bwd_pair(const void* dy, int N, int OH, int OW, int Cout, const void* wb, const void* x, int Cin, int KH, int KW, int stride, int pad,
                              int IH, int IW, const ldetr_p3_epilogue* ep, void* dx_p3, float* dx_f32, const float* dy_scale, float* dw,
                              int* launches, void* stream);
+
+/* Introspection for the parity tests: what the launch policy chose for the calling thread's most recent plane-format launch.
+ * info10 = {kind (1 gather, 2 patch, 3 weight gradient, 4 paired gather + weight gradient, 5 paired patch + weight gradient), tile rows, tile columns,
+ * waves per block, split-K factor, XCD array rows, XCD array columns, grid z (parity classes / groups), weight-gradient pixel slices, blocks}. */
+int ldetr_p3_last_launch(int32_t* info10);
 
 #ifdef __cplusplus
 }

@@ -1131,14 +1131,27 @@ static void choose_xcd_array(int mtiles, int ntiles, double a_bytes, double b_by
 
 static int env_int(const char* name, int dflt) { const char* v = getenv(name); return v ? atoi(v) : dflt; }
 
-static bool raise_lds(const void* kern, size_t lds, const char* what) {
+// The dynamic-LDS opt-in is a per-device function attribute: `raised` is one flag per device ordinal (a process that launches on a second GPU
+// must opt in there too).
+struct RaisedPerDevice { bool on[64] = {}; };
+static bool raise_lds(const void* kern, size_t lds, const char* what, RaisedPerDevice& raised) {
     if (lds <= 64 * 1024) return true;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = -1;
+    if (dev >= 0 && raised.on[dev]) return true;
     if (hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
         set_error("%s: cannot raise the dynamic LDS limit to %zu bytes", what, lds);
         return false;
     }
+    if (dev >= 0) raised.on[dev] = true;
     return true;
 }
+
+// What the launch policy chose for this thread's most recent plane-format launch (ldetr_p3_last_launch): tests assert the template a bench
+// shape reaches, so that a policy change cannot silently leave a kernel without a parity case.
+//   kind: 1 gather (p3_nt), 2 patch (p3_c3), 3 weight gradient (p3_tn), 4 paired gather + weight gradient, 5 paired patch + weight gradient
+struct P3LastLaunch { int kind, bm, bn, nw, splitk, xm, xn, ncls, tn_splitk; long grid; };
+static thread_local P3LastLaunch t_last = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 
 // ---- gather kernel: tile grid, XCD array, split-K scratch of one configuration -> grid dimensions
 struct NtGrid { long gx; int sk, ncls; size_t lds; };
@@ -1183,9 +1196,10 @@ template <int BM, int BN, int NW, int PF, int NST>
 static int launch_nt_cfg(P3NtParams& p, const P3Group2& g2, int sk, hipStream_t st) {
     const NtGrid g = plan_nt<BM, BN, NW, NST>(p, sk);
     auto kern = p3_nt_kernel<BM, BN, NW, PF, NST>;
-    static bool raised = false;
-    if (!raised) { if (!raise_lds(reinterpret_cast<const void*>(kern), g.lds, "p3_nt")) return LDETR_ERR_LAUNCH; raised = true; }
+    static RaisedPerDevice raised;
+    if (!raise_lds(reinterpret_cast<const void*>(kern), g.lds, "p3_nt", raised)) return LDETR_ERR_LAUNCH;
     hipLaunchKernelGGL(kern, dim3((unsigned)g.gx, g.sk, g.ncls), NW * 64, g.lds, st, p, g2);
+    t_last = {1, BM, BN, NW, g.sk, p.xm, p.xn, g.ncls, 0, g.gx};
     note_engine_launch(true);
     return check_launch("p3_nt");
 }
@@ -1256,9 +1270,10 @@ static long plan_c3(P3C3Params& p) {
 
 static int launch_c3(P3C3Params& p, const P3Group2& g2, hipStream_t st) {
     const long grid_x = plan_c3(p);
-    static bool raised = false;
-    if (!raised) { if (!raise_lds(reinterpret_cast<const void*>(&p3_c3_kernel), C3_LDS, "p3_c3")) return LDETR_ERR_LAUNCH; raised = true; }
+    static RaisedPerDevice raised;
+    if (!raise_lds(reinterpret_cast<const void*>(&p3_c3_kernel), C3_LDS, "p3_c3", raised)) return LDETR_ERR_LAUNCH;
     hipLaunchKernelGGL(p3_c3_kernel, dim3((unsigned)grid_x, p.splitk, p.ngroups > 1 ? p.ngroups : 1), 256, C3_LDS, st, p, g2);
+    t_last = {2, 128, 64, 4, p.splitk, p.xm, p.xn, p.ngroups > 1 ? p.ngroups : 1, 0, grid_x};
     note_engine_launch(true);
     return check_launch("p3_c3");
 }
@@ -1298,9 +1313,10 @@ static int launch_tn_cfg(P3TnParams& p, int target_blocks, hipStream_t st) {
     constexpr size_t lds_loop = (size_t)NST * (BM + BN) * 192, lds_cold = (size_t)(BM / 64) * (BN / 64) * 4096 * 4;   // (the cold path's accumulator image)
     constexpr size_t lds = lds_loop > lds_cold ? lds_loop : lds_cold;
     auto kern = p3_tn_kernel<BM, BN, PF, NST>;
-    static bool raised = false;
-    if (!raised) { if (!raise_lds(reinterpret_cast<const void*>(kern), lds, "p3_tn")) return LDETR_ERR_LAUNCH; raised = true; }
+    static RaisedPerDevice raised;
+    if (!raise_lds(reinterpret_cast<const void*>(kern), lds, "p3_tn", raised)) return LDETR_ERR_LAUNCH;
     hipLaunchKernelGGL(kern, dim3(p.splitk, (unsigned)nt, 1), 256, lds, st, p);
+    t_last = {3, BM, BN, 4, 0, 0, 0, 1, p.splitk, nt};
     note_engine_launch(true);
     return check_launch("p3_tn");
 }
@@ -1382,6 +1398,14 @@ static int setup_bwd_weight(const void* x, int N, int H, int W, int Cin, const v
 }  // namespace ldetr
 
 using namespace ldetr;
+
+extern "C" int ldetr_p3_last_launch(int32_t* info10) {
+    LDETR_CHECK(info10 != nullptr, "p3_last_launch: null output");
+    const P3LastLaunch& l = t_last;
+    const int32_t v[10] = {l.kind, l.bm, l.bn, l.nw, l.splitk, l.xm, l.xn, l.ncls, l.tn_splitk, (int32_t)(l.grid > 0x7fffffffL ? 0x7fffffff : l.grid)};
+    for (int i = 0; i < 10; i++) info10[i] = v[i];
+    return LDETR_OK;
+}
 
 extern "C" int ldetr_p3_split_f32(const float* src, int64_t ld, void* dst, int64_t rows, int C, void* stream) {
     LDETR_CHECK(src && dst && rows >= 0 && C > 0 && C % 8 == 0 && ld % 4 == 0, "p3_split: C must be a multiple of 8 and rows 16-byte aligned (C=%d)", C);
@@ -1515,14 +1539,16 @@ extern "C" int ldetr_p3_conv2d_bwd_pair(const void* dy, int N, int OH, int OW, i
         if (use_c3) {
             const long gx = plan_c3(c);
             const size_t lds = C3_LDS > lds_tn ? (size_t)C3_LDS : lds_tn;
-            static bool raised = false;
-            if (!raised) { if (!raise_lds(reinterpret_cast<const void*>(&p3_bwd_pair_c3_kernel), lds, "p3_bwd_pair_c3")) return LDETR_ERR_LAUNCH; raised = true; }
+            static RaisedPerDevice raised;
+            if (!raise_lds(reinterpret_cast<const void*>(&p3_bwd_pair_c3_kernel), lds, "p3_bwd_pair_c3", raised)) return LDETR_ERR_LAUNCH;
             hipLaunchKernelGGL(p3_bwd_pair_c3_kernel, dim3((unsigned)(n_tn_pad + gx * c.splitk)), 256, lds, st, c, pt, (int)n_tn, (int)(n_tn_pad / 8), pt.splitk, (int)gx);
+            t_last = {5, 128, 64, 4, c.splitk, c.xm, c.xn, 1, pt.splitk, n_tn_pad + gx * c.splitk};
         } else {
             const NtGrid g = plan_nt<64, 64, 4, 1>(pn, nt_splitk(pn, 64, 64, slot_target(nt_flops(pn), 512)));
             const size_t lds = g.lds > lds_tn ? g.lds : lds_tn;
             hipLaunchKernelGGL((p3_bwd_pair_nt_kernel<64, 64, 1>), dim3((unsigned)(n_tn_pad + g.gx * g.sk * g.ncls)), 256, lds, st, pn, pt, (int)n_tn, (int)(n_tn_pad / 8), pt.splitk,
                                (int)g.gx, g.sk);
+            t_last = {4, 64, 64, 4, g.sk, pn.xm, pn.xn, g.ncls, pt.splitk, n_tn_pad + g.gx * g.sk * g.ncls};
         }
         note_engine_launch(true);
         if (launches) *launches = 1;

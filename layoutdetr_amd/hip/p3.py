@@ -76,6 +76,9 @@ class WeightPlanes(object):
         self.offsets = []
         self.managed = False   # True: the training loop refreshes after every optimiser step (mark_stale + ensure); else every forward refreshes
         self.stale = True
+        self.versions = None   # Tensor._version of every weight / folded scale at the last refresh: torch-level in-place writes (load_state_dict,
+        #                        copy_params_and_buffers, broadcast, a torch optimiser, copy_) are detected here; only the raw flat-buffer Adam kernel,
+        #                        which does not bump versions, needs the explicit refresh (training_loop.refresh_weight_planes)
 
     def _build(self, key):
         dev = self.convs[0][0].device
@@ -102,14 +105,21 @@ class WeightPlanes(object):
     def _key(self):
         return tuple((w.data_ptr(), bn.folded()[0].data_ptr() if bn is not None else 0) for w, bn in self.convs)
 
+    def _versions(self):
+        return tuple((w._version, bn.folded()[0]._version if bn is not None else 0) for w, bn in self.convs)
+
     def ensure(self):
         key = self._key()
         if key != self.key:
             self._build(key)
             self.stale = True
+        vers = self._versions()
+        if vers != self.versions:
+            self.stale = True
         if self.stale or not self.managed:
             core.check(core.lib().ldetr_p3_weight_prep(core.ptr(self.table), len(self.convs), self.blocks, core.stream()), 'p3_weight_prep')
             self.stale = False
+            self.versions = vers
 
     def ptrs(self, idx):
         off = self.offsets[idx]

@@ -160,6 +160,11 @@ import weakref
 _P3_PLANES = weakref.WeakKeyDictionary()   # ResNet50Body -> hip.p3.WeightPlanes
 
 
+def existing_p3_planes(body):
+    """The body's weight images if it ever took the plane-format path, else None (nothing is built here: 2 x 6 bytes per trunk weight)."""
+    return _P3_PLANES.get(body)
+
+
 class ResNet50Body(nn.Module):
     """conv1/bn1/maxpool/layer1..4 of torchvision resnet50 (what IntermediateLayerGetter keeps, detr_backbone.py:78-79)."""
 

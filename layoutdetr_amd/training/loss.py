@@ -263,6 +263,18 @@ class StyleGAN2Loss(Loss):
         g_body = self.G.backbone[0].body if hasattr(self.G, 'backbone') else None
         if phase != 'Gmain' and g_body is not None and getattr(g_body, 'injected', None):
             g_body.injected = None     # a parked G-trunk evaluation belongs to this iteration's Gmain only
+        # A trunk evaluation parked for this call (detr_backbone.ResNet50Body.injected, keyed by the batch's address) must not outlive it: after a miss
+        # or an exception a later batch at the same address would otherwise be served stale features.  (Iteration-level sharing parks G's trunks of
+        # ALL micro-batches before Gmain: those stay until the phase after Gmain begins, see above.)
+        try:
+            self._run_phase(phase, bbox_real, bbox_class, bbox_text, bbox_patch, padding_mask, background, real_c, gen_z, gen_c, gain)
+        except BaseException:
+            self._drop_parked_trunks()
+            raise
+        if self.share_D_trunk != 'iteration' or phase != 'Gmain':
+            self._drop_parked_trunks()
+
+    def _run_phase(self, phase, bbox_real, bbox_class, bbox_text, bbox_patch, padding_mask, background, real_c, gen_z, gen_c, gain):
         if phase == 'Gmain':
             self.g_main_loss(bbox_real, bbox_class, bbox_text, bbox_patch, padding_mask, background, gen_z, gen_c).mul(gain).backward()
         if phase == 'Dmain':

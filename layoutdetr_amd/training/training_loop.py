@@ -38,20 +38,35 @@ def _phys_view(flat_slice, like):
 
 def _trunk_bodies(module):
     from .detr_backbone import ResNet50Body
-    import os
-    if os.environ.get('LDETR_TRUNK_P3', '1') == '0':
-        return []
     return [m for m in module.modules() if isinstance(m, ResNet50Body)]
 
 
 def refresh_weight_planes(module):
-    """The trunk's plane-format weight images (hip/p3.py) follow the parameters: one launch per module after every optimiser step (or any other
-    in-place change of the weights) instead of one per forward."""
+    """The trunk's plane-format weight images (hip/p3.py) follow the parameters: one launch per module after every optimiser step instead of one
+    per forward.  Only planes that exist (a body that took the plane-format path at least once) are touched: they are always marked stale --
+    whatever LDETR_TRUNK_P3 says now -- and rewritten right away while the plane-format trunk is on (the launch then sits behind the optimiser
+    step, outside the captured phases), else lazily by the next forward that needs them."""
+    import os
+    from .detr_backbone import existing_p3_planes
+    on = os.environ.get('LDETR_TRUNK_P3', '1') != '0'
     for body in _trunk_bodies(module):
-        planes = body.p3_planes()
-        planes.managed = True
+        planes = existing_p3_planes(body)
+        if planes is None:
+            continue
         planes.stale = True
-        planes.ensure()
+        if on:
+            planes.managed = True
+            planes.ensure()
+
+
+def mark_weight_planes_stale(module):
+    """After any change of the parameters that did not go through DataParallelStep.apply (load / copy / broadcast): torch-level writes are
+    also caught by the planes' version check; this covers raw-pointer writes."""
+    from .detr_backbone import existing_p3_planes
+    for body in _trunk_bodies(module):
+        planes = existing_p3_planes(body)
+        if planes is not None:
+            planes.stale = True
 
 
 class FlatModule(object):
@@ -277,6 +292,7 @@ def broadcast_module(module, src=0):
             n = t.numel()
             t.copy_(flat[off:off + n].view(t.shape).to(dtype))
             off += n
+    mark_weight_planes_stale(module)
 
 
 def check_ddp_consistency(module, ignore_regex=None):
@@ -382,6 +398,8 @@ def copy_params_and_buffers(src_module, dst_module, require_all=False):
             assert (name in src) or (not require_all), name
             if name in src and tuple(src[name].shape) == tuple(tensor.shape):
                 tensor.copy_(src[name].detach().to(tensor.device))
+    if isinstance(dst_module, torch.nn.Module):
+        mark_weight_planes_stale(dst_module)
 
 
 def load_pretrained_detr(modules, path='pretrained/up-detr-pre-training-60ep-imagenet.pth', verbose=True):
@@ -399,6 +417,7 @@ def load_pretrained_detr(modules, path='pretrained/up-detr-pre-training-60ep-ima
     for m in modules:
         own = m.state_dict()
         m.load_state_dict({k: v for k, v in sd.items() if k in own and tuple(own[k].shape) == tuple(v.shape)}, strict=False)
+        mark_weight_planes_stale(m)
     return True
 
 

@@ -274,8 +274,10 @@ def _kernel_family(name, shape):
     return 'other'
 
 
-def _full_iteration_vs_oracle(dev, bg, B, seed, tag, text_on=False, flip_tolerant=False, lm_on=False):
-    """One Gmain + Dmain iteration through the flat-parameter step against the CPU oracle in fp32 and fp64 (see the callers)."""
+def _full_iteration_vs_oracle(dev, bg, B, seed, tag, text_on=False, flip_tolerant=False, lm_on=False, bench_path=False):
+    """One Gmain + Dmain iteration through the flat-parameter step against the CPU oracle in fp32 and fp64 (see the callers).
+    bench_path: the configuration bench.py times -- static-shape heads, all slots valid, D's trunk evaluated once per iteration (grouped with G's
+    Gmain trunk), paired trunk backward; the oracle keeps the reference's call pattern (two D passes in Dmain, each with its own trunk)."""
     from layoutdetr_amd.training import training_loop as tl
     from layoutdetr_amd.training.loss import StyleGAN2Loss
     from layoutdetr_amd.training.networks_detr import TextTokens
@@ -291,7 +293,7 @@ def _full_iteration_vs_oracle(dev, bg, B, seed, tag, text_on=False, flip_toleran
         D.text_encoder.load_state_dict(G.text_encoder.state_dict())     # one frozen encoder: the oracle takes its features as an input
     else:
         G, D = make_modules(bg, seed=seed)
-    bt, zg, zd = make_batch(B, bg, seed=seed + 1)
+    bt, zg, zd = make_batch(B, bg, seed=seed + 1, ragged=not bench_path)
     Gsd = {k: v.clone() for k, v in G.state_dict().items()}; Dsd = {k: v.clone() for k, v in D.state_dict().items()}
     toks = None
     if text_on:
@@ -332,7 +334,10 @@ def _full_iteration_vs_oracle(dev, bg, B, seed, tag, text_on=False, flip_toleran
     G.eval().requires_grad_(False).to(dev); D.eval().requires_grad_(False).to(dev)
     pG = tl.Phase('Gmain', G, lr=0.0); pD = tl.Phase('Dmain', D, lr=0.0)     # lr 0: Dmain sees the same G as the oracle's apply_adam=False
     reports = {}
-    loss = StyleGAN2Loss(dev, G, D, share_D_trunk=False, report_fn=lambda n, v: reports.setdefault(n, []).append(v.detach().clone()))
+    if bench_path:
+        G.static_shapes = D.static_shapes = True
+    loss = StyleGAN2Loss(dev, G, D, share_D_trunk='iteration' if bench_path else False,
+                         report_fn=lambda n, v: reports.setdefault(n, []).append(v.detach().clone()))
     dp = tl.DataParallelStep(world_size=1)
     grads, terms = {}, {}
     orig = dp.apply
@@ -419,6 +424,14 @@ def test_full_iteration_configs1_b2_256_vs_oracle_fp64_adjudicated(dev):
     of the oracle, with the oracle's own fp32 run as yardstick — the step is piecewise linear (ReLU, max-pool, min/max in the
     layout losses), so a pre-activation within rounding distance of 0 flips a mask in ANY fp32 evaluation, CPU or GPU."""
     _full_iteration_vs_oracle(dev, 256, 2, 21, 'configs1 B=2 256')
+
+
+def test_full_iteration_configs2_b16_256_vs_oracle(dev):
+    """BASELINE configs[2] -- the headline size, B=16 at 256x256 with all 9 slots valid -- for the FULL Gmain + Dmain iteration through the path
+    bench.py times (static-shape heads, D's trunk once per iteration and grouped with G's, the large-grid tile policies of the plane-format engine,
+    paired data + weight gradients): every loss term, bbox_fake and every gradient tensor against the oracle in fp32 and fp64 with the per-kernel-family
+    gates of the B=2 test.  16 samples hold 8x the activations of configs[1], so some unit flips in either fp32 evaluation: flip-tolerant tails."""
+    _full_iteration_vs_oracle(dev, 256, 16, 71, 'configs2 B=16 256 bench path', flip_tolerant=True, bench_path=True)
 
 
 def test_full_iteration_configs4_share_b2_512_text_encoder_on_vs_oracle_fp64_adjudicated(dev):

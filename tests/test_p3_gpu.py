@@ -77,6 +77,28 @@ def err(a, ref):
     return ((a - ref).abs().max() / ref.abs().max().clamp_min(1e-30)).item()
 
 
+def last_launch(L):
+    """-> dict of the launch policy's choice for the most recent plane-format launch (ldetr_p3_last_launch)."""
+    info = (ctypes.c_int32 * 10)()
+    _core().check(L.ldetr_p3_last_launch(info), 'last_launch')
+    keys = ('kind', 'bm', 'bn', 'nw', 'splitk', 'xm', 'xn', 'ncls', 'tn_splitk', 'grid')
+    return dict(zip(keys, list(info)))
+
+
+SWEEP_FORCED = any(os.environ.get(v) for v in ('LDETR_P3_TILE', 'LDETR_P3_WTILE', 'LDETR_P3_PF', 'LDETR_P3_WPF', 'LDETR_P3_NST', 'LDETR_P3_SK', 'LDETR_P3_SLOTS',
+                                               'LDETR_P3_WSLOTS', 'LDETR_P3_WSK', 'LDETR_P3_XN', 'LDETR_P3_SMALL_GFLOP')) or os.environ.get('LDETR_P3_PAIR') == '0'
+
+
+def expect_launch(L, what, **want):
+    """The template / policy branch a shape is meant to exercise (skipped under the development sweeps' forcing switches)."""
+    if SWEEP_FORCED:
+        return
+    got = last_launch(L)
+    for k, v in want.items():
+        ok = v(got[k]) if callable(v) else got[k] == v
+        assert ok, f'{what}: launch policy chose {got}, expected {k} = {v if not callable(v) else "<predicate>"}'
+
+
 def run_fwd(L, xp, N, H, W, Ci, wp, Co, KH, KW, s, pad, ep, yp, yf):
     core = _core()
     core.check(L.ldetr_p3_conv2d_fwd(core.ptr(xp), N, H, W, Ci, core.ptr(wp), Co, KH, KW, s, pad, ctypes.byref(ep) if ep is not None else None,
@@ -124,6 +146,46 @@ FWD_CASES = [
     (5, 12, 20, 96, 40, 3, 1, 1, True),      # nothing a power of two
 ]
 
+# The shapes bench.py's B=16 / 256x256 step launches (profiles/r04h_engine_shapes.txt) with the policy branch each one must reach: the 128x128 /
+# 8-wave tile on the large forward grids, the XCD array over >= 1024 tiles, the 256- vs 512-slot split-K targets, the patch kernel.
+BENCH_FWD_CASES = [
+    # N, H, W, Ci, Co, k, stride, pad, expected launch
+    (16, 64, 64, 64, 256, 1, 1, 0, dict(kind=1, bm=128, bn=128, nw=8, splitk=1)),       # layer1 expand: M = 65536 -> 128x128 tile, 1024 tiles over the XCD array
+    (16, 64, 64, 256, 64, 1, 1, 0, dict(kind=1, bm=64, bn=64, splitk=1, grid=lambda g: g >= 1024)),   # layer1 reduce: N = 64 keeps the 64x64 tile, 1024 tiles
+    (16, 64, 64, 64, 64, 3, 1, 1, dict(kind=2)),                                         # layer1 3x3: patch kernel
+    (16, 64, 64, 256, 512, 1, 2, 0, dict(kind=1, bm=128, bn=128, nw=8)),                 # layer2 downsample: strided 1x1, M = 16384, N = 512
+    (16, 32, 32, 512, 128, 1, 1, 0, dict(kind=1, bm=64, bn=64, splitk=lambda k: k >= 1)), # layer2 reduce
+    (16, 32, 32, 128, 128, 3, 1, 1, dict(kind=2)),                                       # layer2 3x3
+    (16, 32, 32, 128, 512, 1, 1, 0, dict(kind=1, bm=128, bn=128, nw=8)),                 # layer2 expand: M = 16384, N >= 256, K <= 512
+    (16, 16, 16, 1024, 256, 1, 1, 0, dict(kind=1, bm=64, bn=64, splitk=lambda k: k > 1)), # layer3 reduce: 256 tiles -> split-K
+    (16, 16, 16, 256, 1024, 1, 1, 0, dict(kind=1, bm=64, bn=64)),                        # layer3 expand
+    (16, 8, 8, 2048, 512, 1, 1, 0, dict(kind=1, bm=64, bn=64, splitk=lambda k: k > 1)),  # layer4 reduce: 128 tiles, K = 2048
+]
+
+
+@pytest.mark.parametrize('case', BENCH_FWD_CASES, ids=lambda c: 'N{}_{}x{}_{}to{}_k{}s{}'.format(*c[:7]))
+def test_p3_conv_forward_bench_shapes_vs_float64(dev, L, case):
+    """Forward convolutions at the exact geometry of the headline bench (B=16, 256x256 backgrounds) against float64 conv2d, with FrozenBN + residual
+    + ReLU in the epilogue, and the launch policy's branch asserted -- the shapes below M = 4096 of FWD_CASES never reach these templates."""
+    N, H, W, Ci, Co, k, s, pad, want = case
+    torch.manual_seed(11)
+    x = torch.randn(N, H, W, Ci, device=dev) * torch.exp(0.5 * torch.randn(N, H, W, Ci, device=dev))
+    w = torch.randn(Co, k, k, Ci, device=dev) / (k * Ci ** 0.5)
+    OH, OW = (H + 2 * pad - k) // s + 1, (W + 2 * pad - k) // s + 1
+    xp, wp = p3_split(L, x.reshape(-1, Ci)), p3_split(L, w.reshape(Co, -1))
+    yf = torch.empty(N, OH, OW, Co, device=dev)
+    yp = torch.empty(N * OH * OW * Co * 6, dtype=torch.uint8, device=dev)
+    sc = torch.rand(Co, device=dev) + 0.5; sh = torch.randn(Co, device=dev); res = torch.randn(N, OH, OW, Co, device=dev)
+    resp = p3_split(L, res.reshape(-1, Co))
+    run_fwd(L, xp, N, H, W, Ci, wp, Co, k, k, s, pad, epilogue(sc, sh, residual_p3=resp, relu=True), yp, yf)
+    expect_launch(L, 'forward', **want)
+    torch.cuda.synchronize()
+    tail = lambda v: torch.relu(v * sc.double().cpu() + sh.double().cpu() + res.double().cpu())
+    ref, ref32 = tail(conv_ref64(x, w, s, pad)), tail(conv_f32_host(x, w, s, pad).double())
+    e, e32 = err(yf, ref), err(ref32, ref)
+    assert e <= max(2e-6, 2 * e32), f'forward: {e:.2e} from float64 (host fp32 conv: {e32:.2e})'
+    assert torch.equal(p3_merge(L, yp, N * OH * OW, Co), yf.reshape(-1, Co)), 'the P3 output is not the split of the fp32 output'
+
 
 @pytest.mark.parametrize('case', FWD_CASES, ids=lambda c: 'N{}_{}x{}_{}to{}_k{}s{}'.format(*c[:7]))
 def test_p3_conv_forward_vs_float64(dev, L, case):
@@ -169,7 +231,18 @@ BWD_CASES = [
     (16, 8, 8, 512, 512, 3, 1, 1),
     (16, 16, 16, 1024, 256, 1, 1, 0),
     (2, 14, 10, 64, 64, 3, 2, 1),            # stride 2 on a ragged grid: parity classes of different sizes
+    # bench.py's B=16 / 256x256 geometry (profiles/r04h_engine_shapes.txt): the paired launches that dominate the step
+    (16, 64, 64, 64, 256, 1, 1, 0),          # M = 65536: weight-gradient pixel slices over the XCDs
+    (16, 64, 64, 256, 64, 1, 1, 0),
+    (16, 64, 64, 256, 512, 1, 2, 0),         # strided 1x1: four parity classes, three of them without taps
+    (16, 64, 64, 128, 128, 3, 2, 1),         # layer2's strided 3x3
+    (16, 32, 32, 512, 128, 1, 1, 0),
+    (16, 32, 32, 128, 128, 3, 1, 1),         # paired patch kernel
+    (16, 16, 16, 1024, 256, 1, 1, 0),
+    (16, 8, 8, 2048, 512, 1, 1, 0),
 ]
+BENCH_PAIR_KIND = {(16, 64, 64, 64, 256, 1, 1, 0): 4, (16, 64, 64, 256, 64, 1, 1, 0): 4, (16, 64, 64, 256, 512, 1, 2, 0): 4, (16, 64, 64, 128, 128, 3, 2, 1): 4,
+                   (16, 32, 32, 512, 128, 1, 1, 0): 4, (16, 32, 32, 128, 128, 3, 1, 1): 5, (16, 16, 16, 1024, 256, 1, 1, 0): 4, (16, 8, 8, 2048, 512, 1, 1, 0): 4}
 
 
 @pytest.mark.parametrize('case', BWD_CASES, ids=lambda c: 'N{}_{}x{}_{}to{}_k{}s{}'.format(*c[:7]))
@@ -218,6 +291,8 @@ def test_p3_conv_backward_vs_float64(dev, L, case):
     forced = any(os.environ.get(v) for v in ('LDETR_P3_TILE', 'LDETR_P3_WTILE', 'LDETR_P3_PF', 'LDETR_P3_WPF', 'LDETR_P3_NST'))
     want = 2 if (forced or os.environ.get('LDETR_P3_PAIR') == '0') else 1      # the development switches fall back to the two launches
     assert nl.value == want, f'expected {want} launch(es) for the pair, got {nl.value}'
+    if tuple(case) in BENCH_PAIR_KIND:
+        expect_launch(L, 'paired backward', kind=BENCH_PAIR_KIND[tuple(case)], ncls=(s * s if (s > 1 and BENCH_PAIR_KIND[tuple(case)] == 4) else 1))
     assert torch.equal(dxp2, dxp), 'paired launch: data gradient differs from the separate launch'
     e = err((dw2 - dw0), gw)
     assert e <= max(3e-6, 3 * e32), f'paired launch: weight gradient {e:.2e} from float64 (host fp32: {e32:.2e})'
