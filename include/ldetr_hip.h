@@ -250,6 +250,86 @@ int ldetr_layernorm_bwd_f32(const float* dy, const float* z, const float* mean, 
                             float* dx, float* dresidual, float* dgamma, float* dbeta, int64_t rows, int D,
                             float p_drop, uint64_t seed, const uint64_t* seed_ptr, void* stream);
 
+/* ---- Group launches of the short token stacks (round 5).
+ * D's conditional and unconditional reconstruction decoders (networks_detr.py:269, 275-276 via training/util.py:13-43), and D's layout decoder
+ * beside its unconditional encoder (networks_detr.py:242-243), are structurally identical, independent stacks that the reference runs one after the
+ * other; every launch of such a stack is a fraction of a wave of work per CU.  The entry points below take ONE or TWO argument blocks: the second
+ * problem's blocks follow the first's in the same grid (the ldetr_p3_conv2d_fwd_dual idea), so two stacks advance with one launch per sub-block.
+ * The argument blocks are plain structs of device pointers and sizes; the single-problem entry points above are these with n = 1. */
+typedef struct ldetr_ln_args {
+    const float* x; const float* r; const float* gamma; const float* beta;       /* forward: y = LN(x + dropout(r)); r may be NULL */
+    float* y; float* z; float* mean; float* rstd;                                 /* z = pre-norm sum (kept for the backward), row statistics */
+    const float* dy; float* dx; float* dr; float* dgamma; float* dbeta;            /* backward: dx = dz, dr = dz * dropout mask (optional); dgamma / dbeta += (atomics) */
+    int64_t rows; int D; float eps, p_drop; uint64_t seed; const uint64_t* seed_ptr;
+    const float* pos; int64_t pos_rows; float* ypos; const float* dy2;             /* second output y + pos[row % pos_rows] and its gradient */
+    int r_parts; int64_t r_part_stride; const float* r_bias;                      /* forward: r = r_bias + sum of r_parts slices r[s][rows][D] */
+    const float* dy_parts; int dy_nparts; int64_t dy_part_stride;                 /* backward: incoming gradient = dy (+ dy2) + sum of dy_nparts slices */
+} ldetr_ln_args;
+int ldetr_layernorm_fwd_group_f32(const ldetr_ln_args* a, int n, void* stream);
+int ldetr_layernorm_bwd_group_f32(const ldetr_ln_args* a, int n, void* stream);
+/* out = base (or 0 when NULL) + sum_s parts[s], in slice order; n elements (multiple of 4), 16-byte aligned buffers. */
+int ldetr_sum_parts_f32(const float* base, const float* parts, int n_parts, int64_t part_stride, float* out, int64_t n, void* stream);
+
+typedef struct ldetr_ffn_args {
+    const float* x; int64_t ldx;              /* [M][ldx] block input */
+    const float* w1; const float* b1;         /* [F][256], [F] */
+    const float* w2;                          /* [256][F] */
+    float* h;                                 /* [M][F] hidden after relu (+ dropout): written by the forward, read by the backward */
+    float* ypart;                             /* forward out: [F/64][M][256] */
+    int M, F;
+    float p_drop; uint64_t seed; const uint64_t* seed_ptr;
+    const float* dy;                          /* backward: [M][256] gradient of the block output */
+    float* dxpart;                            /* backward out: [F/64][M][256] */
+    float* dh;                                /* backward out (optional): [M][F] gradient of the hidden pre-activation */
+} ldetr_ffn_args;
+int ldetr_ffn_fwd_group_f32(const ldetr_ffn_args* a, int n, void* stream);
+int ldetr_ffn_bwd_group_f32(const ldetr_ffn_args* a, int n, void* stream);
+
+/* Self-attention sub-block (ldetr_mha_small_fwd_f32's arguments) and its BACKWARD as one launch: per (sample, head) block
+ *   dO_h = dr_b W_out[:, 32h : 32h+32]; attention backward on the saved projection (dropout mask regenerated from the seed); the head's packed
+ *   gradient dqkv [B*L][768] (operand of the weight gradient dW_in += dqkv^T x, written once); and the head's contribution to the input gradient
+ *   dqkv_h W_in,h -> dxpart[h][B*L][256] (reduce with ldetr_layernorm_bwd_group_f32's dy_parts or ldetr_sum_parts_f32).
+ * Replaces {out_proj data gradient, ldetr_attention_bwd_f32, in_proj data gradient} = three launches of the unfused path. */
+typedef struct ldetr_mha_small_args {
+    const float* x; int64_t ldx;
+    const float* w_in; const float* b_in; const float* w_out;
+    const unsigned char* kpm;
+    float* qkv; float* o; float* lse; float* ypart;       /* forward outputs; the backward reads qkv, o, lse */
+    int B, L;
+    float scale, p_drop; uint64_t seed; const uint64_t* seed_ptr;
+    const float* dr;                                       /* backward: [B*L][256] gradient of the sub-block output (before out_proj's bias) */
+    float* dqkv; float* dxpart;                            /* backward outputs */
+} ldetr_mha_small_args;
+int ldetr_mha_small_fwd_group_f32(const ldetr_mha_small_args* a, int n, void* stream);
+int ldetr_mha_small_bwd_group_f32(const ldetr_mha_small_args* a, int n, void* stream);
+
+/* Cross-attention sub-block backward (forward: ldetr_mha_cross_fwd_f32) as one launch per (sample, head): dO_h = dr_b W_out[:, head]; attention backward
+ * on the saved q and the projected memory K / V (dK / dV written to dk / dv with pitches lddk / lddv: the grouped projection's gradient buffer);
+ * dq [B*Lq][256]; dxpart[h][B*Lq][256] = dq_h W_q,h. */
+typedef struct ldetr_mha_cross_args {
+    const float* x; int64_t ldx;
+    const float* w_q; const float* b_q;
+    const float* k; int64_t ldk; const float* v; int64_t ldv;
+    const float* w_out;
+    const unsigned char* kpm;
+    float* q; float* o; float* lse; float* ypart;
+    int B, Lq, Lk;
+    float scale, p_drop; uint64_t seed; const uint64_t* seed_ptr;
+    const float* dr;
+    float* dq; float* dk; int64_t lddk; float* dv; int64_t lddv; float* dxpart;
+} ldetr_mha_cross_args;
+int ldetr_mha_cross_bwd_f32(const ldetr_mha_cross_args* a, void* stream);
+
+/* Up to 8 weight gradients dW[rows][cols] += A^T B over the tokens (A [M][lda] holds the `rows` output features in columns, B [M][ldb] the `cols`
+ * input features; both row-major over tokens), bias gradient db[rows] += column sums of A (optional), as ONE launch: the weight gradients of a
+ * transformer layer (feed-forward W1 / W2, attention in_proj / out_proj) are independent contractions with K = tokens. */
+typedef struct ldetr_wgrad_desc {
+    const float* A; int64_t lda; const float* B; int64_t ldb;
+    float* dW; int64_t ldw; float* db;
+    int M, rows, cols;
+} ldetr_wgrad_desc;
+int ldetr_wgrad_multi_f32(const ldetr_wgrad_desc* d, int n, void* stream);
+
 int ldetr_colsum_f32(const float* a, float* red, int B, int64_t P, int C, void* stream);
 int ldetr_act_bwd_reduce_f32(const float* dy, const float* y, float* dv, const float* bias, const float* demod,
                              float* dbias, float* ddemod, int B, int64_t P, int C, int act, float alpha, float gain,
@@ -407,6 +487,10 @@ int ldetr_p3_conv2d_bwd_weight(const void* x, int N, int H, int W, int Cin, cons
 int ldetr_p3_conv2d_bwd_pair(const void* dy, int N, int OH, int OW, int Cout, const void* wb, const void* x, int Cin, int KH, int KW, int stride, int pad,
                              int IH, int IW, const ldetr_p3_epilogue* ep, void* dx_p3, float* dx_f32, const float* dy_scale, float* dw,
                              int* launches, void* stream);
+
+/* sizeof of {ldetr_ln_args, ldetr_ffn_args, ldetr_mha_small_args, ldetr_mha_cross_args, ldetr_wgrad_desc, ldetr_p3_epilogue}: lets a host binding check
+ * its mirror of the argument blocks. */
+int ldetr_struct_sizes(int32_t* out6);
 
 /* Introspection for the parity tests: what the launch policy chose for the calling thread's most recent plane-format launch.
  * info10 = {kind (1 gather, 2 patch, 3 weight gradient, 4 paired gather + weight gradient, 5 paired patch + weight gradient), tile rows, tile columns,

@@ -37,6 +37,46 @@ class Epilogue(Structure):
                 ('seed_ptr', c_void_p), ('accumulate', c_int), ('a_rowsum', c_void_p)]
 
 
+class LnArgs(Structure):
+    """ldetr_ln_args (include/ldetr_hip.h): one LayerNorm problem of a group launch."""
+    _fields_ = [('x', c_void_p), ('r', c_void_p), ('gamma', c_void_p), ('beta', c_void_p),
+                ('y', c_void_p), ('z', c_void_p), ('mean', c_void_p), ('rstd', c_void_p),
+                ('dy', c_void_p), ('dx', c_void_p), ('dr', c_void_p), ('dgamma', c_void_p), ('dbeta', c_void_p),
+                ('rows', c_int64), ('D', c_int), ('eps', c_float), ('p_drop', c_float), ('seed', c_uint64), ('seed_ptr', c_void_p),
+                ('pos', c_void_p), ('pos_rows', c_int64), ('ypos', c_void_p), ('dy2', c_void_p),
+                ('r_parts', c_int), ('r_part_stride', c_int64), ('r_bias', c_void_p),
+                ('dy_parts', c_void_p), ('dy_nparts', c_int), ('dy_part_stride', c_int64)]
+
+
+class FfnArgs(Structure):
+    """ldetr_ffn_args."""
+    _fields_ = [('x', c_void_p), ('ldx', c_int64), ('w1', c_void_p), ('b1', c_void_p), ('w2', c_void_p), ('h', c_void_p), ('ypart', c_void_p),
+                ('M', c_int), ('F', c_int), ('p_drop', c_float), ('seed', c_uint64), ('seed_ptr', c_void_p),
+                ('dy', c_void_p), ('dxpart', c_void_p), ('dh', c_void_p)]
+
+
+class MhaSmallArgs(Structure):
+    """ldetr_mha_small_args."""
+    _fields_ = [('x', c_void_p), ('ldx', c_int64), ('w_in', c_void_p), ('b_in', c_void_p), ('w_out', c_void_p), ('kpm', c_void_p),
+                ('qkv', c_void_p), ('o', c_void_p), ('lse', c_void_p), ('ypart', c_void_p), ('B', c_int), ('L', c_int),
+                ('scale', c_float), ('p_drop', c_float), ('seed', c_uint64), ('seed_ptr', c_void_p),
+                ('dr', c_void_p), ('dqkv', c_void_p), ('dxpart', c_void_p)]
+
+
+class MhaCrossArgs(Structure):
+    """ldetr_mha_cross_args."""
+    _fields_ = [('x', c_void_p), ('ldx', c_int64), ('w_q', c_void_p), ('b_q', c_void_p), ('k', c_void_p), ('ldk', c_int64), ('v', c_void_p), ('ldv', c_int64),
+                ('w_out', c_void_p), ('kpm', c_void_p), ('q', c_void_p), ('o', c_void_p), ('lse', c_void_p), ('ypart', c_void_p),
+                ('B', c_int), ('Lq', c_int), ('Lk', c_int), ('scale', c_float), ('p_drop', c_float), ('seed', c_uint64), ('seed_ptr', c_void_p),
+                ('dr', c_void_p), ('dq', c_void_p), ('dk', c_void_p), ('lddk', c_int64), ('dv', c_void_p), ('lddv', c_int64), ('dxpart', c_void_p)]
+
+
+class WgradDesc(Structure):
+    """ldetr_wgrad_desc."""
+    _fields_ = [('A', c_void_p), ('lda', c_int64), ('B', c_void_p), ('ldb', c_int64), ('dW', c_void_p), ('ldw', c_int64), ('db', c_void_p),
+                ('M', c_int), ('rows', c_int), ('cols', c_int)]
+
+
 _P = c_void_p
 _I = c_int
 _L = c_int64
@@ -90,6 +130,15 @@ SIGNATURES = {
     'ldetr_debug_trace_tiles': [_P],
     'ldetr_set_split_bf16': [c_int],
     'ldetr_engine_launch_counts': [POINTER(c_int64), POINTER(c_int64)],
+    'ldetr_layernorm_fwd_group_f32': [_P, _I, _P],
+    'ldetr_layernorm_bwd_group_f32': [_P, _I, _P],
+    'ldetr_sum_parts_f32': [_P, _P, _I, _L, _P, _L, _P],
+    'ldetr_ffn_fwd_group_f32': [_P, _I, _P],
+    'ldetr_ffn_bwd_group_f32': [_P, _I, _P],
+    'ldetr_mha_small_fwd_group_f32': [_P, _I, _P],
+    'ldetr_mha_small_bwd_group_f32': [_P, _I, _P],
+    'ldetr_mha_cross_bwd_f32': [_P, _P],
+    'ldetr_wgrad_multi_f32': [_P, _I, _P],
     'ldetr_gemm_pair_f32': [_P, _P, _P],
     'ldetr_gemm_pair_is_single_launch': [_P, _P],
     'ldetr_demod_fwd_f32': [_P, _L, _L, _L, _L, _P, _P, _P, _I, _I, _I, _I, _I, _F, _P],
@@ -107,6 +156,7 @@ SIGNATURES = {
     'ldetr_p3_conv2d_fwd_dual': [_P, _P, _I, _I, _I, _I, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P],
     'ldetr_p3_conv2d_bwd_pair': [_P, _I, _I, _I, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P],
     'ldetr_p3_last_launch': [_P],
+    'ldetr_struct_sizes': [_P],
     'ldetr_resize_normalize_u8': [_P, _L, _I, _I, _I, _I, _P, _P, _I, _P, _P, _I, _P, _P, _P, _F, _F, _F, _F, _F, _F, _P],
 }
 
@@ -134,8 +184,13 @@ def load():
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported
         fn.restype = c_int
         fn.argtypes = argtypes
-    if lib.ldetr_abi_version() != 22:
+    if lib.ldetr_abi_version() != 23:
         raise RuntimeError('libldetr_hip.so ABI version mismatch; rebuild it')
+    sizes = (ctypes.c_int32 * 6)()
+    lib.ldetr_struct_sizes(sizes)
+    mirror = [ctypes.sizeof(t) for t in (LnArgs, FfnArgs, MhaSmallArgs, MhaCrossArgs, WgradDesc, P3Epilogue)]
+    if list(sizes) != mirror:
+        raise RuntimeError(f'libldetr_hip.so argument blocks {list(sizes)} do not match the ctypes mirror {mirror}; rebuild')
     _lib = lib
     return lib
 

@@ -29,7 +29,7 @@ FLAGS = ([] if os.environ.get('LDETR_TILE_TRACE') else ['-DLDETR_TILE_TRACE=0'])
          '-Wno-unused-result', '-Rpass-analysis=kernel-resource-usage']
 # kernels whose register budget is the design: any scratch (spill / stack object) is a build error, not a silent 10x slowdown
 # (an erf in the engine's epilogue once cost 320 bytes of scratch per lane and every 128x128 GEMM ran 14x slower)
-NO_SCRATCH = ('wgrad_c32_3x3_kernel', 'gemm_f32_kernel', 'gemm_small_kernel', 'attn_fwd_kernel', 'attn_fwd_wide_kernel', 'attn_bwd_kernel', 'ffn_fwd_kernel', 'ffn_bwd_kernel', 'conv3x3_c32_kernel', 'mha_small_fwd_kernel', 'mha_cross_fwd_kernel', 'p3_nt_kernel', 'p3_tn_kernel', 'p3_c3_kernel', 'p3_bwd_pair')
+NO_SCRATCH = ('wgrad_c32_3x3_kernel', 'gemm_f32_kernel', 'gemm_small_kernel', 'attn_fwd_kernel', 'attn_fwd_wide_kernel', 'attn_bwd_kernel', 'ffn_fwd_kernel', 'ffn_bwd_kernel', 'conv3x3_c32_kernel', 'mha_small_fwd_kernel', 'mha_cross_fwd_kernel', 'mha_small_bwd_kernel', 'mha_cross_bwd_kernel', 'wgrad_multi_kernel', 'ln_fwd_kernel', 'ln_bwd_kernel', 'p3_nt_kernel', 'p3_tn_kernel', 'p3_c3_kernel', 'p3_bwd_pair')
 
 
 def _hipcc():

@@ -22,18 +22,9 @@
 
 namespace ldetr {
 
-struct FfnParams {
-    const float* x; long ldx;                 // [M, 256]
-    const float* w1; const float* b1;         // [F, 256], [F]
-    const float* w2;                          // [256, F]
-    float* h;                                 // [M, F] hidden after relu (+ dropout): saved for / read by the backward
-    float* ypart;                             // [F / 64][M][256]
-    int M, F;
-    float p_drop; unsigned long long seed; const unsigned long long* seed_ptr;
-    const float* dy;                          // [M, 256] gradient of the block's output
-    float* dxpart;                            // [F / 64][M][256] per-slice contributions to the input gradient
-    float* dh;                                // [M, F] gradient of the hidden pre-activation (written when the weight gradients are wanted)
-};
+// One problem = the public argument block (include/ldetr_hip.h: ldetr_ffn_args).  A launch carries one or two: the second problem's blocks follow
+// the first's in a 1-D grid (two independent stacks' feed-forward blocks as ONE launch); block c of a problem = (row tile c % gx, hidden slice c / gx).
+typedef ldetr_ffn_args FfnParams;
 
 constexpr int FD = 256, FHS = 64, FHP = 68;   // model width, hidden slice, LDS pitch of the hidden tile
 
@@ -55,11 +46,14 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t rsrc(const float* p) {
 }
 #define FFN_MFMA16(A, B, ACC) _Pragma("unroll") for (int t_ = 0; t_ < 16; t_++) ACC = __builtin_amdgcn_mfma_f32_32x32x2f32(A[t_], B[t_], ACC, 0, 0, 0)
 
-__global__ __launch_bounds__(256) void ffn_fwd_kernel(FfnParams p) {
+__global__ __launch_bounds__(256) void ffn_fwd_kernel(FfnParams pa, FfnParams pb, int nb0) {
     __shared__ float red[2][32][33];
     __shared__ float Hs[32][FHP];
+    const bool second = (int)blockIdx.x >= nb0;
+    const FfnParams& p = second ? pb : pa;
+    const int bid = second ? (int)blockIdx.x - nb0 : (int)blockIdx.x, gx = (p.M + 31) >> 5;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, cl = lane & 31, kl = lane >> 5;
-    const int m0 = blockIdx.x * 32, s = blockIdx.y, j0 = s * FHS;
+    const int s = bid / gx, m0 = (bid - s * gx) * 32, j0 = s * FHS;
     const int OOB = (int)0x80000000;
     // ---- phase 1: wave (ct, kh) = 32 hidden units x half of the 256-long reduction
     const int ct = wave & 1, kh = wave >> 1;
@@ -91,7 +85,7 @@ __global__ __launch_bounds__(256) void ffn_fwd_kernel(FfnParams p) {
         if (kh == 0) {
             const float bias = p.b1[j0 + ct * 32 + cl];
             const float inv_keep = p.p_drop > 0.f ? 1.f / (1.f - p.p_drop) : 1.f;
-            const unsigned long long seed = p.seed + (p.seed_ptr ? *p.seed_ptr : 0ull);
+            const uint64_t seed = p.seed + (p.seed_ptr ? *p.seed_ptr : 0ull);
 #pragma unroll
             for (int r = 0; r < 16; r++) {
                 const int row = (r & 3) + 8 * (r >> 2) + 4 * kl;
@@ -131,12 +125,14 @@ __global__ __launch_bounds__(256) void ffn_fwd_kernel(FfnParams p) {
     }
 }
 
-template <bool WGRAD>
-__global__ __launch_bounds__(256) void ffn_bwd_kernel(FfnParams p) {
+__global__ __launch_bounds__(256) void ffn_bwd_kernel(FfnParams pa, FfnParams pb, int nb0) {
     __shared__ float red[2][32][33];
     __shared__ float dHs[32][FHP];
+    const bool second = (int)blockIdx.x >= nb0;
+    const FfnParams& p = second ? pb : pa;
+    const int bid = second ? (int)blockIdx.x - nb0 : (int)blockIdx.x, gx = (p.M + 31) >> 5;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, cl = lane & 31, kl = lane >> 5;
-    const int m0 = blockIdx.x * 32, s = blockIdx.y, j0 = s * FHS;
+    const int s = bid / gx, m0 = (bid - s * gx) * 32, j0 = s * FHS;
     const int OOB = (int)0x80000000;
     const __amdgpu_buffer_rsrc_t rsDY = rsrc(p.dy), rsW1 = rsrc(p.w1), rsW2 = rsrc(p.w2), rsX = rsrc(p.x);
     const float inv_keep = p.p_drop > 0.f ? 1.f / (1.f - p.p_drop) : 1.f;
@@ -181,7 +177,7 @@ __global__ __launch_bounds__(256) void ffn_bwd_kernel(FfnParams p) {
                 // relu'(pre) and the dropout mask in one test: the saved hidden value is positive exactly where both let the gradient through
                 const float dh = hv > 0.f ? (acc[r] + red[ct][row][cl]) * inv_keep : 0.f;
                 dHs[row][ct * 32 + cl] = dh;
-                if (WGRAD && m < p.M) p.dh[m * p.F + j0 + ct * 32 + cl] = dh;      // pre-activation gradient: operand of the weight-gradient launch
+                if (p.dh && m < p.M) p.dh[m * p.F + j0 + ct * 32 + cl] = dh;      // pre-activation gradient: operand of the weight-gradient launch
             }
         }
         __syncthreads();
@@ -225,30 +221,50 @@ static int ffn_check(const char* what, int64_t M, int D, int F, const void* x, i
     return LDETR_OK;
 }
 
+static int ffn_check_args(const char* what, const FfnParams& p, bool bwd) {
+    if (int rc = ffn_check(what, p.M, FD, p.F, p.x, p.ldx)) return rc;
+    if (!bwd) {
+        LDETR_CHECK(p.w1 && p.b1 && p.w2 && p.h && p.ypart, "%s: null pointer", what);
+        LDETR_CHECK(p.p_drop >= 0.f && p.p_drop < 1.f, "%s: p_drop out of range", what);
+    } else {
+        LDETR_CHECK(p.dy && p.h && p.w1 && p.w2 && p.dxpart, "%s: null pointer", what);
+        LDETR_CHECK((((uintptr_t)p.dy) & 15) == 0, "%s: dy must be 16-byte aligned", what);
+    }
+    return LDETR_OK;
+}
+
+static int ffn_launch(const ldetr_ffn_args* a, int n, bool bwd, void* stream) {
+    const char* what = bwd ? "ffn_bwd" : "ffn_fwd";
+    LDETR_CHECK(a && (n == 1 || n == 2), "%s: 1 or 2 problems", what);
+    FfnParams p[2]; p[0] = a[0]; p[1] = n == 2 ? a[1] : a[0];
+    int nb[2] = {0, 0};
+    for (int i = 0; i < n; i++) {
+        if (int rc = ffn_check_args(what, p[i], bwd)) return rc;
+        nb[i] = cdiv(p[i].M, 32) * (p[i].F / FHS);
+    }
+    if (nb[0] + nb[1] == 0) return LDETR_OK;
+    if (bwd) hipLaunchKernelGGL(ffn_bwd_kernel, dim3(nb[0] + nb[1]), dim3(256), 0, (hipStream_t)stream, p[0], p[1], nb[0]);
+    else hipLaunchKernelGGL(ffn_fwd_kernel, dim3(nb[0] + nb[1]), dim3(256), 0, (hipStream_t)stream, p[0], p[1], nb[0]);
+    return check_launch(what);
+}
+
+extern "C" int ldetr_ffn_fwd_group_f32(const ldetr_ffn_args* a, int n, void* stream) { return ffn_launch(a, n, false, stream); }
+extern "C" int ldetr_ffn_bwd_group_f32(const ldetr_ffn_args* a, int n, void* stream) { return ffn_launch(a, n, true, stream); }
+
 extern "C" int ldetr_ffn_fwd_f32(const float* x, int64_t ldx, const float* w1, const float* b1, const float* w2, float* h, float* ypart,
                                  int64_t M, int D, int F, float p_drop, uint64_t seed, const uint64_t* seed_ptr, void* stream) {
     if (int rc = ffn_check("ffn_fwd", M, D, F, x, ldx)) return rc;
-    LDETR_CHECK(w1 && b1 && w2 && h && ypart, "ffn_fwd: null pointer");
-    LDETR_CHECK(p_drop >= 0.f && p_drop < 1.f, "ffn_fwd: p_drop out of range");
-    if (M == 0) return LDETR_OK;
     FfnParams p; memset(&p, 0, sizeof(p));
     p.x = x; p.ldx = ldx; p.w1 = w1; p.b1 = b1; p.w2 = w2; p.h = h; p.ypart = ypart; p.M = (int)M; p.F = F;
-    p.p_drop = p_drop; p.seed = seed; p.seed_ptr = (const unsigned long long*)seed_ptr;
-    hipLaunchKernelGGL(ffn_fwd_kernel, dim3(cdiv(M, 32), F / FHS), dim3(256), 0, (hipStream_t)stream, p);
-    return check_launch("ffn_fwd");
+    p.p_drop = p_drop; p.seed = seed; p.seed_ptr = seed_ptr;
+    return ffn_launch(&p, 1, false, stream);
 }
 
 extern "C" int ldetr_ffn_bwd_f32(const float* dy, const float* x, int64_t ldx, const float* h, const float* w1, const float* w2,
                                  float* dxpart, float* dh, int64_t M, int D, int F, float p_drop, void* stream) {
     if (int rc = ffn_check("ffn_bwd", M, D, F, x, ldx)) return rc;
-    LDETR_CHECK(dy && h && w1 && w2 && dxpart, "ffn_bwd: null pointer");
-    LDETR_CHECK((((uintptr_t)dy) & 15) == 0, "ffn_bwd: dy must be 16-byte aligned");
-    if (M == 0) return LDETR_OK;
     FfnParams p; memset(&p, 0, sizeof(p));
     p.x = x; p.ldx = ldx; p.w1 = w1; p.w2 = w2; p.h = const_cast<float*>(h); p.M = (int)M; p.F = F; p.p_drop = p_drop;
     p.dy = dy; p.dxpart = dxpart; p.dh = dh;
-    const dim3 grid(cdiv(M, 32), F / FHS);
-    if (dh) hipLaunchKernelGGL(ffn_bwd_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, p);
-    else hipLaunchKernelGGL(ffn_bwd_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, p);
-    return check_launch("ffn_bwd");
+    return ffn_launch(&p, 1, true, stream);
 }

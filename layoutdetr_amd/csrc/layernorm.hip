@@ -9,31 +9,21 @@
 
 namespace ldetr {
 
-struct LnParams {
-    const float* x; const float* r; const float* gamma; const float* beta;
-    float* y; float* z; float* mean; float* rstd;
-    const float* dy; float* dx; float* dr; float* dgamma; float* dbeta;
-    long rows; int D; float eps, p_drop; unsigned long long seed; const unsigned long long* seed_ptr;
-    // second output ypos[row] = y[row] + pos[row % pos_rows] (the next attention's q/k input: detr_transformer.py:207,277 add the
-    // position embedding with a separate kernel per layer), and its gradient dy2 summed into dy on load
-    const float* pos; long pos_rows; float* ypos; const float* dy2;
-    // the residual branch as `r_parts` partial sums [r_parts][rows][D] (+ a column bias): the slices of the fused feed-forward block
-    // (ffn_fused.hip) are added here, in slice order, instead of by a reduction launch of their own
-    int r_parts; long r_part_stride; const float* r_bias;
-    // backward: the incoming gradient as dy + sum of `dy_nparts` partial sums [dy_nparts][rows][D] (the hidden slices' contributions to the
-    // feed-forward block's input gradient), added in slice order
-    const float* dy_parts; int dy_nparts; long dy_part_stride;
-};
+// One problem of a launch = the public argument block (include/ldetr_hip.h: ldetr_ln_args); a launch carries one or two of them (the second
+// problem's row blocks follow the first's in the grid: two independent stacks' LayerNorms as ONE launch).
+typedef ldetr_ln_args LnParams;
 
 // NV = float4 vectors per lane (D = 256*NV at most; lanes past D/4 idle)
 template <int NV>
-__global__ __launch_bounds__(256) void ln_fwd_kernel(LnParams p) {
+__global__ __launch_bounds__(256) void ln_fwd_kernel(LnParams pa, LnParams pb, int nb0) {
+    const bool second = (int)blockIdx.x >= nb0;
+    const LnParams& p = second ? pb : pa;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const long row = (long)blockIdx.x * 4 + wave;
+    const long row = (long)(second ? (int)blockIdx.x - nb0 : (int)blockIdx.x) * 4 + wave;
     if (row >= p.rows) return;
     const int D4 = p.D >> 2;
     const float inv_keep = p.p_drop > 0.f ? 1.f / (1.f - p.p_drop) : 1.f;
-    const unsigned long long seed = p.seed + (p.seed_ptr ? *p.seed_ptr : 0ull);
+    const uint64_t seed = p.seed + (p.seed_ptr ? *p.seed_ptr : 0ull);
     float4 v[NV];
     float s = 0.f;
 #pragma unroll
@@ -108,16 +98,19 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(LnParams p) {
 // dx = dz; dr = dz * dropmask (regenerated).  dgamma/dbeta: per-wave register partials over a
 // grid-stride row loop, LDS combine across the 4 waves, one atomicAdd per block per column.
 template <int NV>
-__global__ __launch_bounds__(256) void ln_bwd_kernel(LnParams p) {
+__global__ __launch_bounds__(256) void ln_bwd_kernel(LnParams pa, LnParams pb, int nb0) {
     __shared__ float red[2][4][256 * NV];
+    const bool second = (int)blockIdx.x >= nb0;
+    const LnParams& p = second ? pb : pa;
+    const int bx = second ? (int)blockIdx.x - nb0 : (int)blockIdx.x, gx = second ? (int)gridDim.x - nb0 : nb0;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int D4 = p.D >> 2;
     const float inv_keep = p.p_drop > 0.f ? 1.f / (1.f - p.p_drop) : 1.f;
-    const unsigned long long seed = p.seed + (p.seed_ptr ? *p.seed_ptr : 0ull);
+    const uint64_t seed = p.seed + (p.seed_ptr ? *p.seed_ptr : 0ull);
     float4 ag[NV], ab[NV];
 #pragma unroll
     for (int i = 0; i < NV; i++) { ag[i] = make_float4(0.f, 0.f, 0.f, 0.f); ab[i] = ag[i]; }
-    for (long row = (long)blockIdx.x * 4 + wave; row < p.rows; row += (long)gridDim.x * 4) {
+    for (long row = (long)bx * 4 + wave; row < p.rows; row += (long)gx * 4) {
         const float mean = p.mean[row], rstd = p.rstd[row];
         float4 xh[NV], g[NV];
         float s1 = 0.f, s2 = 0.f;
@@ -207,29 +200,45 @@ extern "C" int ldetr_layernorm_fwd_pos_f32(const float* x, const float* residual
     return ldetr_layernorm_fwd_parts_f32(x, residual, 0, 0, nullptr, gamma, beta, y, z, mean, rstd, rows, D, eps, p_drop, seed, seed_ptr, pos, pos_rows, ypos, stream);
 }
 
+static int ln_check_fwd(const LnParams& p) {
+    LDETR_CHECK(p.r_parts >= 0 && (p.r_parts == 0 || (p.r && p.r_part_stride >= p.rows * p.D)), "layernorm_fwd: bad partial-sum arguments");
+    LDETR_CHECK(p.x && p.gamma && p.beta && p.y, "layernorm_fwd: null pointer");
+    LDETR_CHECK((p.pos == nullptr) == (p.ypos == nullptr) && (!p.pos || p.pos_rows > 0), "layernorm_fwd: pos, pos_rows and ypos go together");
+    LDETR_CHECK(p.D % 4 == 0 && p.D >= 4 && p.D <= 1024, "layernorm_fwd: D must be a multiple of 4 in [4, 1024]");
+    LDETR_CHECK(p.rows >= 0 && p.rows < (1L << 31) - 8, "layernorm_fwd: bad row count");
+    return LDETR_OK;
+}
+
+// n = 1 or 2 problems (same D) as ONE launch
+extern "C" int ldetr_layernorm_fwd_group_f32(const ldetr_ln_args* a, int n, void* stream) {
+    LDETR_CHECK(a && (n == 1 || n == 2), "layernorm_fwd_group: 1 or 2 problems");
+    LnParams p[2]; p[0] = a[0]; p[1] = n == 2 ? a[1] : a[0];
+    for (int i = 0; i < n; i++) {
+        if (int rc = ln_check_fwd(p[i])) return rc;
+        if (p[i].r_parts == 0) p[i].r_bias = nullptr;
+    }
+    LDETR_CHECK(n == 1 || p[0].D == p[1].D, "layernorm_fwd_group: both problems must have the same D");
+    const int nb0 = (int)((p[0].rows + 3) / 4), nb1 = n == 2 ? (int)((p[1].rows + 3) / 4) : 0;
+    if (nb0 + nb1 == 0) return LDETR_OK;
+    hipStream_t st = (hipStream_t)stream;
+    const int nv = (p[0].D + 255) / 256, grid = nb0 + nb1;
+    if (nv == 1) hipLaunchKernelGGL(ln_fwd_kernel<1>, grid, 256, 0, st, p[0], p[1], nb0);
+    else if (nv == 2) hipLaunchKernelGGL(ln_fwd_kernel<2>, grid, 256, 0, st, p[0], p[1], nb0);
+    else if (nv == 3) hipLaunchKernelGGL(ln_fwd_kernel<3>, grid, 256, 0, st, p[0], p[1], nb0);
+    else hipLaunchKernelGGL(ln_fwd_kernel<4>, grid, 256, 0, st, p[0], p[1], nb0);
+    return check_launch("layernorm_fwd");
+}
+
 extern "C" int ldetr_layernorm_fwd_parts_f32(const float* x, const float* parts, int n_parts, int64_t part_stride, const float* part_bias,
                                              const float* gamma, const float* beta, float* y, float* z, float* mean, float* rstd,
                                              int64_t rows, int D, float eps, float p_drop, uint64_t seed, const uint64_t* seed_ptr,
                                              const float* pos, int64_t pos_rows, float* ypos, void* stream) {
-    const float* residual = parts;
-    LDETR_CHECK(n_parts >= 0 && (n_parts == 0 || (parts && part_stride >= rows * D)), "layernorm_fwd: bad partial-sum arguments");
-    LDETR_CHECK(x && gamma && beta && y, "layernorm_fwd: null pointer");
-    LDETR_CHECK((pos == nullptr) == (ypos == nullptr) && (!pos || pos_rows > 0), "layernorm_fwd: pos, pos_rows and ypos go together");
-    LDETR_CHECK(D % 4 == 0 && D >= 4 && D <= 1024, "layernorm_fwd: D must be a multiple of 4 in [4, 1024]");
-    if (rows == 0) return LDETR_OK;
     LnParams p; memset(&p, 0, sizeof(p));
-    p.x = x; p.r = residual; p.gamma = gamma; p.beta = beta; p.y = y; p.z = z; p.mean = mean; p.rstd = rstd;
-    p.rows = rows; p.D = D; p.eps = eps; p.p_drop = p_drop; p.seed = seed; p.seed_ptr = (const unsigned long long*)seed_ptr;
+    p.x = x; p.r = parts; p.gamma = gamma; p.beta = beta; p.y = y; p.z = z; p.mean = mean; p.rstd = rstd;
+    p.rows = rows; p.D = D; p.eps = eps; p.p_drop = p_drop; p.seed = seed; p.seed_ptr = seed_ptr;
     p.pos = pos; p.pos_rows = pos_rows; p.ypos = ypos;
     p.r_parts = n_parts; p.r_part_stride = part_stride; p.r_bias = n_parts > 0 ? part_bias : nullptr;
-    int grid = (int)((rows + 3) / 4);
-    hipStream_t st = (hipStream_t)stream;
-    int nv = (D + 255) / 256;
-    if (nv == 1) hipLaunchKernelGGL(ln_fwd_kernel<1>, grid, 256, 0, st, p);
-    else if (nv == 2) hipLaunchKernelGGL(ln_fwd_kernel<2>, grid, 256, 0, st, p);
-    else if (nv == 3) hipLaunchKernelGGL(ln_fwd_kernel<3>, grid, 256, 0, st, p);
-    else hipLaunchKernelGGL(ln_fwd_kernel<4>, grid, 256, 0, st, p);
-    return check_launch("layernorm_fwd");
+    return ldetr_layernorm_fwd_group_f32(&p, 1, stream);
 }
 
 // dgamma/dbeta are accumulated with atomics: the caller zeroes them (or passes running gradients).
@@ -245,27 +254,67 @@ extern "C" int ldetr_layernorm_bwd2_f32(const float* dy, const float* dy2, const
     return ldetr_layernorm_bwd_parts_f32(dy, dy2, nullptr, 0, 0, z, mean, rstd, gamma, dx, dresidual, dgamma, dbeta, rows, D, p_drop, seed, seed_ptr, stream);
 }
 
+static int ln_check_bwd(const LnParams& p) {
+    LDETR_CHECK(p.dy_nparts >= 0 && (p.dy_nparts == 0 || (p.dy_parts && p.dy_part_stride >= p.rows * p.D)), "layernorm_bwd: bad partial-sum arguments");
+    LDETR_CHECK(p.dy && p.z && p.mean && p.rstd && p.gamma, "layernorm_bwd: null pointer");
+    LDETR_CHECK(p.D % 4 == 0 && p.D >= 4 && p.D <= 1024, "layernorm_bwd: D must be a multiple of 4 in [4, 1024]");
+    LDETR_CHECK((p.dgamma == nullptr) == (p.dbeta == nullptr), "layernorm_bwd: dgamma and dbeta go together");
+    return LDETR_OK;
+}
+
+extern "C" int ldetr_layernorm_bwd_group_f32(const ldetr_ln_args* a, int n, void* stream) {
+    LDETR_CHECK(a && (n == 1 || n == 2), "layernorm_bwd_group: 1 or 2 problems");
+    LnParams p[2]; p[0] = a[0]; p[1] = n == 2 ? a[1] : a[0];
+    for (int i = 0; i < n; i++)
+        if (int rc = ln_check_bwd(p[i])) return rc;
+    LDETR_CHECK(n == 1 || p[0].D == p[1].D, "layernorm_bwd_group: both problems must have the same D");
+    auto blocks = [](long rows) { long g = (rows + 3) / 4; return (int)(g > 512 ? 512 : g); };
+    const int nb0 = blocks(p[0].rows), nb1 = n == 2 ? blocks(p[1].rows) : 0;
+    if (nb0 + nb1 == 0) return LDETR_OK;
+    hipStream_t st = (hipStream_t)stream;
+    const int nv = (p[0].D + 255) / 256, grid = nb0 + nb1;
+    if (nv == 1) hipLaunchKernelGGL(ln_bwd_kernel<1>, grid, 256, 0, st, p[0], p[1], nb0);
+    else if (nv == 2) hipLaunchKernelGGL(ln_bwd_kernel<2>, grid, 256, 0, st, p[0], p[1], nb0);
+    else if (nv == 3) hipLaunchKernelGGL(ln_bwd_kernel<3>, grid, 256, 0, st, p[0], p[1], nb0);
+    else hipLaunchKernelGGL(ln_bwd_kernel<4>, grid, 256, 0, st, p[0], p[1], nb0);
+    return check_launch("layernorm_bwd");
+}
+
 extern "C" int ldetr_layernorm_bwd_parts_f32(const float* dy, const float* dy2, const float* dy_parts, int n_parts, int64_t part_stride,
                                              const float* z, const float* mean, const float* rstd, const float* gamma,
                                              float* dx, float* dresidual, float* dgamma, float* dbeta, int64_t rows, int D,
                                              float p_drop, uint64_t seed, const uint64_t* seed_ptr, void* stream) {
-    LDETR_CHECK(n_parts >= 0 && (n_parts == 0 || (dy_parts && part_stride >= rows * D)), "layernorm_bwd: bad partial-sum arguments");
-    LDETR_CHECK(dy && z && mean && rstd && gamma, "layernorm_bwd: null pointer");
-    LDETR_CHECK(D % 4 == 0 && D >= 4 && D <= 1024, "layernorm_bwd: D must be a multiple of 4 in [4, 1024]");
-    LDETR_CHECK((dgamma == nullptr) == (dbeta == nullptr), "layernorm_bwd: dgamma and dbeta go together");
-    if (rows == 0) return LDETR_OK;
     LnParams p; memset(&p, 0, sizeof(p));
     p.dy = dy; p.z = const_cast<float*>(z); p.mean = const_cast<float*>(mean); p.rstd = const_cast<float*>(rstd);
     p.gamma = gamma; p.dx = dx; p.dr = dresidual; p.dgamma = dgamma; p.dbeta = dbeta; p.dy2 = dy2;
     p.dy_parts = dy_parts; p.dy_nparts = n_parts; p.dy_part_stride = part_stride;
-    p.rows = rows; p.D = D; p.p_drop = p_drop; p.seed = seed; p.seed_ptr = (const unsigned long long*)seed_ptr;
-    int grid = (int)((rows + 3) / 4);
-    if (grid > 512) grid = 512;
-    hipStream_t st = (hipStream_t)stream;
-    int nv = (D + 255) / 256;
-    if (nv == 1) hipLaunchKernelGGL(ln_bwd_kernel<1>, grid, 256, 0, st, p);
-    else if (nv == 2) hipLaunchKernelGGL(ln_bwd_kernel<2>, grid, 256, 0, st, p);
-    else if (nv == 3) hipLaunchKernelGGL(ln_bwd_kernel<3>, grid, 256, 0, st, p);
-    else hipLaunchKernelGGL(ln_bwd_kernel<4>, grid, 256, 0, st, p);
-    return check_launch("layernorm_bwd");
+    p.rows = rows; p.D = D; p.p_drop = p_drop; p.seed = seed; p.seed_ptr = seed_ptr;
+    return ldetr_layernorm_bwd_group_f32(&p, 1, stream);
+}
+
+// out[rows][D] = base[rows][D] (or 0) + sum_s parts[s][rows][D], in slice order: where a gradient that travelled between sub-blocks as partial sums
+// (the per-head input gradients of ldetr_mha_small_bwd_group_f32) leaves the token stacks as ONE tensor.
+__global__ __launch_bounds__(256) void sum_parts_kernel(const float4* __restrict__ base, const float4* __restrict__ parts, int n_parts, long part_stride4, float4* __restrict__ out, long n4) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        float4 v = base ? base[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int s = 0; s < n_parts; s += 8) {
+            float4 q[8];
+#pragma unroll
+            for (int j = 0; j < 8; j++) q[j] = (s + j < n_parts) ? parts[(long)(s + j) * part_stride4 + i] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int j = 0; j < 8; j++)
+                if (s + j < n_parts) { v.x += q[j].x; v.y += q[j].y; v.z += q[j].z; v.w += q[j].w; }
+        }
+        out[i] = v;
+    }
+}
+
+extern "C" int ldetr_sum_parts_f32(const float* base, const float* parts, int n_parts, int64_t part_stride, float* out, int64_t n, void* stream) {
+    LDETR_CHECK(out && n >= 0 && n % 4 == 0 && part_stride % 4 == 0 && n_parts >= 0 && (n_parts == 0 || parts), "sum_parts: bad arguments");
+    LDETR_CHECK(((((uintptr_t)base) | ((uintptr_t)parts) | ((uintptr_t)out)) & 15) == 0, "sum_parts: buffers must be 16-byte aligned");
+    if (n == 0) return LDETR_OK;
+    const long n4 = n / 4;
+    const int grid = (int)std::min<long>((n4 + 255) / 256, 1024);
+    hipLaunchKernelGGL(sum_parts_kernel, grid, 256, 0, (hipStream_t)stream, (const float4*)base, (const float4*)parts, n_parts, (long)(part_stride / 4), (float4*)out, n4);
+    return check_launch("sum_parts");
 }

@@ -14,4 +14,11 @@ void set_error(const char* fmt, ...) {
 }  // namespace ldetr
 
 extern "C" const char* ldetr_last_error(void) { return ldetr::g_err; }
-extern "C" int ldetr_abi_version(void) { return 22; }
+extern "C" int ldetr_abi_version(void) { return 23; }
+// sizeof of every argument block of the group launches, in header order: the host bindings (layoutdetr_amd/_lib.py) mirror them field by field
+extern "C" int ldetr_struct_sizes(int32_t* out6) {
+    if (!out6) return 1;
+    out6[0] = (int32_t)sizeof(ldetr_ln_args); out6[1] = (int32_t)sizeof(ldetr_ffn_args); out6[2] = (int32_t)sizeof(ldetr_mha_small_args);
+    out6[3] = (int32_t)sizeof(ldetr_mha_cross_args); out6[4] = (int32_t)sizeof(ldetr_wgrad_desc); out6[5] = (int32_t)sizeof(ldetr_p3_epilogue);
+    return 0;
+}

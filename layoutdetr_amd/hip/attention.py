@@ -7,7 +7,6 @@ head-averaged attention weights the reference discards (`[0]`) are never formed.
 Layout is batch-first: activations are [B*L, d] row-major (row = b*L + position).
 """
 import math
-import os
 
 import torch
 
@@ -222,187 +221,6 @@ def grouped_kv(mem_pos, mem, mhas):
     return [(outs[i], outs[n + i], dst(i)) for i in range(n)]
 
 
-SMALL_FUSED = os.environ.get('LDETR_MHA_SMALL', '1') != '0'
-
-
-def small_usable(x2, in_proj_weight, nhead, L):
-    """The one-launch self-attention forward (csrc/mha_small.hip): d_model 256, 8 heads, at most 16 tokens per sample."""
-    return (SMALL_FUSED and x2.is_cuda and x2.dtype == torch.float32 and in_proj_weight.shape[1] == 256 and nhead == 8 and 1 <= L <= 16
-            and x2.dim() == 2 and x2.stride(1) == 1 and x2.stride(0) % 4 == 0 and x2.data_ptr() % 16 == 0)
-
-
-class _SelfAttnPartsFn(torch.autograd.Function):
-    """Self-attention sub-block with q = k = v = x on <= 16 tokens per sample: ONE forward launch (packed projection, attention, the
-    output projection's per-head contributions).  -> (ypart [H, B*L, d], alias of x): the consumer -- the residual + LayerNorm launch
-    (hip.layernorm.add_layernorm / hip.ffn.add_ln_ffn_add_ln with a 3-D residual and `r_bias` = out_proj.bias) -- sums the H
-    contributions; its gradient arrives as one [B*L, d] matrix broadcast over H.  Backward = the unfused path's three launches on the
-    saved projection (out_proj dX + dW pair, ldetr_attention_bwd_f32, in_proj dX + dW pair); the residual-path gradient that arrives
-    through the alias is added in the last dX GEMM's epilogue."""
-
-    @staticmethod
-    def forward(ctx, x, w_in, b_in, w_out, b_out, kpm, B, H, L, p_drop):
-        core.require_gpu(x, w_in, b_in, w_out, b_out, kpm)
-        ctx.set_materialize_grads(False)
-        d = x.shape[1]
-        M = B * L
-        assert x.shape[0] == M
-        Wi, Bi, Wo = core.f32c(w_in.detach()), core.f32c(b_in.detach()), core.f32c(w_out.detach())
-        new = lambda *shape: torch.empty(shape, device=x.device, dtype=torch.float32)
-        qkv, o, lse, ypart = new(M, 3 * d), new(M, d), new(B * H * L), new(H, M, d)
-        seed = core.next_seed() if p_drop > 0 else 0
-        scale = 1.0 / math.sqrt(d // H)
-        core.check(core.lib().ldetr_mha_small_fwd_f32(
-            core.ptr(x), x.stride(0), core.ptr(Wi), core.ptr(Bi), core.ptr(Wo), core.ptr(kpm), core.ptr(qkv), core.ptr(o), core.ptr(lse),
-            core.ptr(ypart), B, L, d, H, scale, p_drop, seed, core.seed_ptr() if p_drop > 0 else None, core.stream()), 'mha_small_fwd')
-        ctx.save_for_backward(x, Wi, Wo, kpm, qkv, o, lse)
-        ctx.cfg = (B, H, L, d, scale, p_drop, seed)
-        ctx.params = (w_in, b_in, w_out, b_out)
-        return ypart, x
-
-    @staticmethod
-    def backward(ctx, dypart, dx_pass=None):
-        x, Wi, Wo, kpm, qkv, o, lse = ctx.saved_tensors
-        B, H, L, d, scale, p_drop, seed = ctx.cfg
-        w_in, b_in, w_out, b_out = ctx.params
-        if dypart is None:
-            return (dx_pass,) + (None,) * 9
-        M = B * L
-        dev = x.device
-        # every head's contribution receives the same gradient (the consumer returns it broadcast: stride 0 over H)
-        dr = core.f32c(dypart[0] if dypart.stride(0) == 0 else dypart.sum(0))
-        need_x = ctx.needs_input_grad[0]
-        need_w = any(ctx.needs_input_grad[1:5]) and not core.WEIGHT_GRADIENTS_DISABLED[0]
-        ret = [None] * 4
-        if need_w:
-            flat = [core.flat_grad(t) for t in (w_in, b_in, w_out, b_out)]
-            if all(f is not None and f.is_contiguous() for f in flat):
-                tgt = flat
-            else:
-                tgt = [torch.zeros_like(t, memory_format=torch.contiguous_format) for t in (w_in, b_in, w_out, b_out)]
-                ret = tgt
-        # out_proj: d_o = dr W_out, dW_out += dr^T o, db_out = column sums of dr
-        d_o = torch.empty((M, d), device=dev, dtype=torch.float32)
-        if need_w:
-            core.gemm_pair(dict(A=dr, B=Wo, ta=0, tb=1, M=M, N=d, K=d, out=d_o, ep=core.epilogue()),
-                           dict(A=dr, B=o, ta=1, tb=1, M=d, N=d, K=M, out=tgt[2], ep=core.epilogue(accumulate=True, a_rowsum=tgt[3])))
-        else:
-            core.gemm(dr, Wo, 0, 1, M, d, d, out=d_o)
-        # attention backward on the saved projection
-        dqkv = torch.empty_like(qkv)
-        q, k, v = qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:]
-        dq, dk, dv = dqkv[:, :d], dqkv[:, d:2 * d], dqkv[:, 2 * d:]
-        core.check(core.lib().ldetr_attention_bwd_f32(
-            core.ptr(q), 3 * d, core.ptr(k), 3 * d, core.ptr(v), 3 * d, core.ptr(kpm), core.ptr(o), d, core.ptr(lse), core.ptr(d_o), d,
-            core.ptr(dq), 3 * d, core.ptr(dk), 3 * d, core.ptr(dv), 3 * d, B, H, L, L, d // H, scale, p_drop, seed,
-            core.seed_ptr() if p_drop > 0 else None, 0, core.stream()), 'attention_bwd')
-        # in_proj: dx = dqkv W_in (+ the residual-path gradient), dW_in += dqkv^T x, db_in = column sums of dqkv
-        dx = None
-        res = core.f32c(dx_pass.reshape(M, d)) if dx_pass is not None else None
-        if need_x and need_w:
-            dx = torch.empty((M, d), device=dev, dtype=torch.float32)
-            core.gemm_pair(dict(A=dqkv, B=Wi, ta=0, tb=1, M=M, N=d, K=3 * d, out=dx, ep=core.epilogue(residual=res)),
-                           dict(A=dqkv, B=x, ta=1, tb=1, M=3 * d, N=d, K=M, out=tgt[0], ep=core.epilogue(accumulate=True, a_rowsum=tgt[1])))
-        else:
-            if need_x:
-                dx = core.gemm(dqkv, Wi, 0, 1, M, d, 3 * d, ep=core.epilogue(residual=res))
-            if need_w:
-                core.gemm(dqkv, x, 1, 1, 3 * d, d, M, out=tgt[0], ep=core.epilogue(accumulate=True, a_rowsum=tgt[1]))
-        if not need_x:
-            dx = dx_pass
-        return (dx, ret[0], ret[1], ret[2], ret[3], None, None, None, None, None)
-
-
-class _CrossAttnPartsFn(torch.autograd.Function):
-    """Cross-attention sub-block onto memory K / V that hip.attention.grouped_kv projected (<= 16 queries per sample, <= 64 memory tokens):
-    query projection + attention + per-head output projection as ONE forward launch (csrc/mha_small.hip: mha_cross_fwd_kernel).
-    -> (ypart [H, B*Lq, d], alias of x) like _SelfAttnPartsFn; backward = out_proj pair, ldetr_attention_bwd_f32 (dK / dV written into the
-    grouped projection's gradient buffer, `kv_grad_dst`), query-projection pair."""
-
-    @staticmethod
-    def forward(ctx, x, K, V, w_in, b_in, w_out, b_out, kpm, B, H, Lq, Lk, p_drop, kv_grad_dst):
-        core.require_gpu(x, K, V, w_in, b_in, w_out, b_out, kpm)
-        ctx.set_materialize_grads(False)
-        d = x.shape[1]
-        M = B * Lq
-        assert x.shape[0] == M and K.stride(1) == 1 and V.stride(1) == 1
-        Wq, Bq, Wo = core.f32c(w_in.detach()[:d]), core.f32c(b_in.detach()[:d]), core.f32c(w_out.detach())
-        new = lambda *shape: torch.empty(shape, device=x.device, dtype=torch.float32)
-        q, o, lse, ypart = new(M, d), new(M, d), new(B * H * Lq), new(H, M, d)
-        seed = core.next_seed() if p_drop > 0 else 0
-        scale = 1.0 / math.sqrt(d // H)
-        core.check(core.lib().ldetr_mha_cross_fwd_f32(
-            core.ptr(x), x.stride(0), core.ptr(Wq), core.ptr(Bq), core.ptr(K), K.stride(0), core.ptr(V), V.stride(0), core.ptr(Wo), core.ptr(kpm),
-            core.ptr(q), core.ptr(o), core.ptr(lse), core.ptr(ypart), B, Lq, Lk, d, H, scale, p_drop, seed,
-            core.seed_ptr() if p_drop > 0 else None, core.stream()), 'mha_cross_fwd')
-        ctx.save_for_backward(x, K, V, Wq, Wo, kpm, q, o, lse)
-        ctx.cfg = (B, H, Lq, Lk, d, scale, p_drop, seed)
-        ctx.params = (w_in, b_in, w_out, b_out)
-        ctx.kv_grad_dst = kv_grad_dst
-        return ypart, x
-
-    @staticmethod
-    def backward(ctx, dypart, dx_pass=None):
-        x, K, V, Wq, Wo, kpm, q, o, lse = ctx.saved_tensors
-        B, H, Lq, Lk, d, scale, p_drop, seed = ctx.cfg
-        w_in, b_in, w_out, b_out = ctx.params
-        nin = 14
-        if dypart is None:
-            return (dx_pass,) + (None,) * (nin - 1)
-        M = B * Lq
-        dev = x.device
-        dr = core.f32c(dypart[0] if dypart.stride(0) == 0 else dypart.sum(0))
-        need_x = ctx.needs_input_grad[0]
-        need_w = any(ctx.needs_input_grad[3:7]) and not core.WEIGHT_GRADIENTS_DISABLED[0]
-        ret = [None] * 4
-        if need_w:
-            flat = [core.flat_grad(t) for t in (w_in, b_in, w_out, b_out)]
-            if all(f is not None and f.is_contiguous() for f in flat):
-                tgt = flat
-            else:
-                tgt = [torch.zeros_like(t, memory_format=torch.contiguous_format) for t in (w_in, b_in, w_out, b_out)]
-                ret = tgt
-        d_o = torch.empty((M, d), device=dev, dtype=torch.float32)
-        if need_w:
-            core.gemm_pair(dict(A=dr, B=Wo, ta=0, tb=1, M=M, N=d, K=d, out=d_o, ep=core.epilogue()),
-                           dict(A=dr, B=o, ta=1, tb=1, M=d, N=d, K=M, out=tgt[2], ep=core.epilogue(accumulate=True, a_rowsum=tgt[3])))
-        else:
-            core.gemm(dr, Wo, 0, 1, M, d, d, out=d_o)
-        dq = torch.empty((M, d), device=dev, dtype=torch.float32)
-        if ctx.kv_grad_dst is not None:
-            dk, dv = ctx.kv_grad_dst()
-        else:
-            dk = torch.empty((B * Lk, d), device=dev, dtype=torch.float32); dv = torch.empty((B * Lk, d), device=dev, dtype=torch.float32)
-        core.check(core.lib().ldetr_attention_bwd_f32(
-            core.ptr(q), d, core.ptr(K), K.stride(0), core.ptr(V), V.stride(0), core.ptr(kpm), core.ptr(o), d, core.ptr(lse), core.ptr(d_o), d,
-            core.ptr(dq), d, core.ptr(dk), dk.stride(0), core.ptr(dv), dv.stride(0), B, H, Lq, Lk, d // H, scale, p_drop, seed,
-            core.seed_ptr() if p_drop > 0 else None, 0, core.stream()), 'attention_bwd')
-        dx = None
-        res = core.f32c(dx_pass.reshape(M, d)) if dx_pass is not None else None
-        if need_x and need_w:
-            dx = torch.empty((M, d), device=dev, dtype=torch.float32)
-            core.gemm_pair(dict(A=dq, B=Wq, ta=0, tb=1, M=M, N=d, K=d, out=dx, ep=core.epilogue(residual=res)),
-                           dict(A=dq, B=x, ta=1, tb=1, M=d, N=d, K=M, out=tgt[0][:d], ep=core.epilogue(accumulate=True, a_rowsum=tgt[1][:d])))
-        else:
-            if need_x:
-                dx = core.gemm(dq, Wq, 0, 1, M, d, d, ep=core.epilogue(residual=res))
-            if need_w:
-                core.gemm(dq, x, 1, 1, d, d, M, out=tgt[0][:d], ep=core.epilogue(accumulate=True, a_rowsum=tgt[1][:d]))
-        if not need_x:
-            dx = dx_pass
-        return (dx, dk, dv, ret[0], ret[1], ret[2], ret[3], None, None, None, None, None, None, None)
-
-
-def cross_usable(x2, K, V, in_proj_weight, nhead, Lq, Lk):
-    return (SMALL_FUSED and small_usable(x2, in_proj_weight, nhead, Lq) and 1 <= Lk <= 64 and K.stride(1) == 1 and V.stride(1) == 1
-            and K.stride(0) % 4 == 0 and V.stride(0) % 4 == 0 and K.data_ptr() % 16 == 0 and V.data_ptr() % 16 == 0)
-
-
-def self_attention_parts(x2, m_in_w, m_in_b, m_out_w, m_out_b, nhead, B, L, key_padding_mask=None, p_drop=0.0):
-    """-> (ypart [H, B*L, d], out_proj.bias (no gradient through this copy: it is formed in the node), alias of x2 for the residual branch)."""
-    ypart, alias = _SelfAttnPartsFn.apply(x2, m_in_w, m_in_b, m_out_w, m_out_b, _kpm_u8(key_padding_mask), B, nhead, L, p_drop)
-    return ypart, m_out_b.detach(), alias
-
-
 def mha_forward(query, key, value, in_proj_weight, in_proj_bias, out_w, out_b, nhead, B, Lq, Lk,
                 key_padding_mask=None, p_drop=0.0, same_qk=False, same_qkv=False, qk_pos=None, passthru=False, qk_in=None, kv_alias=False):
     """query: [B*Lq, d]; key/value: [B*Lk, d].  Returns [B*Lq, d] (before the caller's residual/dropout/LN).
@@ -455,13 +273,9 @@ def mha_forward(query, key, value, in_proj_weight, in_proj_bias, out_w, out_b, n
 
 def mha_cross_kv(query, K, V, grad_dst, in_proj_weight, in_proj_bias, out_w, out_b, nhead, B, Lq, Lk, key_padding_mask=None, p_drop=0.0):
     """Cross-attention block whose key / value projections were made by grouped_kv(): q projection (rows 0:d of the packed weight),
-    fused attention on the layer's [M, d] blocks of the grouped buffer, output projection.  -> (block output, out_proj bias still to be
-    added (the one-launch form returns per-head contributions [H, B*Lq, d]) or None, alias of `query` for the residual branch)."""
+    fused attention on the layer's [M, d] blocks of the grouped buffer, output projection.  -> (block output, alias of `query` for the residual
+    branch).  (The <= 16-query stacks at d_model 256 run inside hip.stacks instead: one launch per direction for the whole sub-block.)"""
     d = query.shape[1]
-    if cross_usable(query, K, V, in_proj_weight, nhead, Lq, Lk):
-        ypart, alias = _CrossAttnPartsFn.apply(query, K, V, in_proj_weight, in_proj_bias, out_w, out_b, _kpm_u8(key_padding_mask), B, nhead, Lq, Lk,
-                                               p_drop, grad_dst)
-        return ypart, out_b.detach(), alias
     q, alias = linear(query, in_proj_weight, in_proj_bias, rows=(0, d), passthru=True)
     o = attention(q, K, V, key_padding_mask, B, nhead, Lq, Lk, p_drop, kv_grad_dst=grad_dst)
-    return linear(o, out_w, out_b), None, alias
+    return linear(o, out_w, out_b), alias

@@ -15,8 +15,9 @@ import torch
 from torch import Tensor, nn
 
 from ..hip import core
-from ..hip.attention import grouped_kv, mha_cross_kv, mha_forward, self_attention_parts, small_usable
+from ..hip.attention import grouped_kv, mha_cross_kv, mha_forward
 from ..hip import ffn as hffn
+from ..hip import stacks as hstacks
 from ..hip.layernorm import add_layernorm
 from ..hip.linear import linear
 
@@ -79,17 +80,6 @@ def _add_ln(norm: nn.LayerNorm, x2, r2, drop: nn.Dropout, training, pos=None, r_
     return add_layernorm(x2, r2, norm.weight, norm.bias, norm.eps, drop.p if training else 0.0, pos=pos, r_bias=r_bias)
 
 
-def _self_attn(m: nn.MultiheadAttention, x2, B, L, kpm, training):
-    """Self-attention sub-block with q = k = v = x2 -> (block output, out_proj bias still to be added or None, alias of x2 for the residual
-    branch).  Up to 16 tokens per sample: ONE launch (csrc/mha_small.hip) whose output is the per-head contributions [H, B*L, d]; the
-    residual + LayerNorm launch that follows sums them (r_bias).  Otherwise projection, attention, projection."""
-    if small_usable(x2, m.in_proj_weight, m.num_heads, L):
-        return self_attention_parts(x2, m.in_proj_weight, m.in_proj_bias, m.out_proj.weight, m.out_proj.bias, m.num_heads, B, L,
-                                    key_padding_mask=kpm, p_drop=m.dropout if training else 0.0)
-    a, x2 = _mha(m, x2, x2, x2, B, L, L, kpm, training, same_qkv=True)
-    return a, None, x2
-
-
 def _add_ln_ffn_add_ln(layer, norm_a: nn.LayerNorm, x2, r2, drop_a: nn.Dropout, norm_b: nn.LayerNorm, drop_b: nn.Dropout, pos=None, r_bias=None):
     """The tail of a layer: x1 = norm_a(x + dropout(r)); norm_b(x1 + dropout(linear2(dropout(relu(linear1(x1)))))) (detr_transformer.py:210-214
     / 280-285).  On the token counts of the decoder-side stacks ONE autograd node of 3 launches forward / 4 backward (hip/ffn.py: fused
@@ -120,9 +110,9 @@ class TransformerEncoderLayer(nn.Module):
 
     def forward2d(self, x2, B, L, kpm, pos2, xpos2=None, emit_pos=False):
         """xpos2: x2 + pos2 when the producer already formed it (the previous layer's norm2 emits it: emit_pos) -> (y2[, y2 + pos2])."""
-        if pos2 is None:
-            a, rb, x2 = _self_attn(self.self_attn, x2, B, L, kpm, self.training)
-            return _add_ln_ffn_add_ln(self, self.norm1, x2, a, self.dropout1, self.norm2, self.dropout2, r_bias=rb)
+        if pos2 is None:      # (the <= 16-token stacks at d_model 256 never get here: TransformerEncoder.forward2d hands them to hip.stacks as a whole)
+            a, x2 = _mha(self.self_attn, x2, x2, x2, B, L, L, kpm, self.training, same_qkv=True)
+            return _add_ln_ffn_add_ln(self, self.norm1, x2, a, self.dropout1, self.norm2, self.dropout2)
         a, x2 = _mha(self.self_attn, x2, x2, x2, B, L, L, kpm, self.training, same_qk=True, qk_pos=pos2, qk_in=xpos2)
         return _add_ln_ffn_add_ln(self, self.norm1, x2, a, self.dropout1, self.norm2, self.dropout2, pos=pos2 if emit_pos else None)
 
@@ -149,16 +139,15 @@ class TransformerDecoderLayer(nn.Module):
         """-> (t2, alias of mem2, alias of mem_pos2): the next layer reads the memory through the aliases (mha_forward kv_alias).
         kv = (K, V, grad_dst) from hip.attention.grouped_kv: the memory projections of this layer were made by the stack (one GEMM for
         all layers); mem2 / mem_pos2 are then not touched here."""
-        a, rb, t2 = _self_attn(self.self_attn, t2, B, Lq, tgt_kpm, self.training)
-        t2 = _add_ln(self.norm1, t2, a, self.dropout1, self.training, r_bias=rb)
+        a, t2 = _mha(self.self_attn, t2, t2, t2, B, Lq, Lq, tgt_kpm, self.training, same_qkv=True)
+        t2 = _add_ln(self.norm1, t2, a, self.dropout1, self.training)
         if kv is not None:
             m = self.multihead_attn
-            a, rb, t2 = mha_cross_kv(t2, kv[0], kv[1], kv[2], m.in_proj_weight, m.in_proj_bias, m.out_proj.weight, m.out_proj.bias, m.num_heads, B, Lq, S,
-                                     key_padding_mask=mem_kpm, p_drop=m.dropout if self.training else 0.0)
+            a, t2 = mha_cross_kv(t2, kv[0], kv[1], kv[2], m.in_proj_weight, m.in_proj_bias, m.out_proj.weight, m.out_proj.bias, m.num_heads, B, Lq, S,
+                                 key_padding_mask=mem_kpm, p_drop=m.dropout if self.training else 0.0)
         else:
-            rb = None
             a, t2, mem_pos2, mem2 = _mha(self.multihead_attn, t2, mem_pos2, mem2, B, Lq, S, mem_kpm, self.training, kv_alias=True)
-        return _add_ln_ffn_add_ln(self, self.norm2, t2, a, self.dropout2, self.norm3, self.dropout3, r_bias=rb), mem2, mem_pos2
+        return _add_ln_ffn_add_ln(self, self.norm2, t2, a, self.dropout2, self.norm3, self.dropout3), mem2, mem_pos2
 
 
 def _get_clones(module, N):
@@ -172,11 +161,23 @@ class TransformerEncoder(nn.Module):
         self.num_layers = num_layers
         self.norm = norm
 
+    def as_prog(self, x2, B, L, kpm):
+        """This stack on x2 [B*L, d] as a hip.stacks.Prog (to run alone or in lock-step with an independent partner stack), or None when the stack
+        node does not take it (position embeddings, a final norm, another width / more than 16 tokens per sample)."""
+        if self.norm is not None or not hstacks.ENABLED:
+            return None
+        prog = hstacks.Prog('enc', self.layers, x2, B, L, _mask_u8(kpm), self.training)
+        return prog if hstacks.usable(prog) else None
+
     def forward2d(self, x2, B, L, kpm, pos2, want_pos=False):
         """want_pos (with pos2): also return x_out + pos2 (the decoder's cross-attention key input, detr_transformer.py:277), formed by
         the last layer's LayerNorm launch.  Between layers the position-embedded copy comes from the previous layer's norm2 as well:
         one add launch per stack (the first layer's input) instead of one per layer."""
         kpm = _mask_u8(kpm)   # one conversion per stack, not one per attention launch
+        if pos2 is None and not want_pos:
+            prog = self.as_prog(x2, B, L, kpm)
+            if prog is not None:
+                return hstacks.run([prog])[0]
         xpos2 = None
         n = len(self.layers)
         for i, layer in enumerate(self.layers):
@@ -203,13 +204,22 @@ class TransformerDecoder(nn.Module):
         self.norm = norm
         self.return_intermediate = return_intermediate
 
-    def forward2d(self, t2, mem2, pos2, B, Lq, S, tgt_kpm, mem_kpm, mem_pos2=None):
+    def forward2d(self, t2, mem2, pos2, B, Lq, S, tgt_kpm, mem_kpm, mem_pos2=None, partner=None):
+        """partner: a hip.stacks.Prog of an INDEPENDENT stack to advance in lock-step with this one (D's unconditional encoder beside its layout
+        decoder) -> (output, partner's output); run on its own when this stack does not take the stack node."""
         tgt_kpm, mem_kpm = _mask_u8(tgt_kpm), _mask_u8(mem_kpm)
         if mem_pos2 is None:
             mem_pos2 = mem2 + pos2
         # the memory is the same for every layer (detr_transformer.py:277-280 projects it per layer): all layers' K / V projections as two
         # GEMMs with N = layers * d, their backward as four (hip.attention._GroupedKVFn); LDETR_GROUP_KV=0 restores the per-layer launches
         kvs = grouped_kv(mem_pos2, mem2, [l.multihead_attn for l in self.layers]) if (_GROUP_KV and len(self.layers) > 1) else None
+        if kvs is not None and hstacks.ENABLED:
+            prog = hstacks.Prog('dec', self.layers, t2, B, Lq, tgt_kpm, self.training, final_norm=self.norm, kvs=kvs, S=S, mem_kpm=mem_kpm)
+            if hstacks.usable(prog):
+                outs = hstacks.run([prog] + ([partner] if partner is not None else []))
+                return outs[0] if partner is None else (outs[0], outs[1])
+        if partner is not None:
+            return self.forward2d(t2, mem2, pos2, B, Lq, S, tgt_kpm, mem_kpm, mem_pos2=mem_pos2), hstacks.run([partner])[0]
         for i, layer in enumerate(self.layers):
             t2, mem2, mem_pos2 = layer.forward2d(t2, mem2, mem_pos2, B, Lq, S, tgt_kpm, mem_kpm, kv=None if kvs is None else kvs[i])
         if self.norm is not None:
@@ -251,7 +261,8 @@ class Transformer(nn.Module):
             if p.dim() > 1:
                 nn.init.xavier_uniform_(p)
 
-    def forward(self, src, mask, pos_embed, tgt, tgt_key_padding_mask, decoder_mask=None):
+    def forward(self, src, mask, pos_embed, tgt, tgt_key_padding_mask, decoder_mask=None, partner=None):
+        """partner (extension): a hip.stacks.Prog to run in lock-step with the decoder -> (hs, memory, partner's output)."""
         if decoder_mask is not None:
             raise NotImplementedError('decoder_mask (tgt_mask) is never passed on the LayoutDETR path')
         bs, c, h, w = src.shape
@@ -265,10 +276,12 @@ class Transformer(nn.Module):
             tgt_key_padding_mask = torch.cat([self.token_mask.expand(bs, -1), tgt_key_padding_mask], dim=1)
         Lq = tgt.shape[0]
         t2 = tgt.permute(1, 0, 2).reshape(bs * Lq, c)
-        hs2 = self.decoder.forward2d(t2, mem2, pos2, bs, Lq, S, tgt_key_padding_mask, mem_kpm, mem_pos2=mem_pos2)
+        hs2 = self.decoder.forward2d(t2, mem2, pos2, bs, Lq, S, tgt_key_padding_mask, mem_kpm, mem_pos2=mem_pos2, partner=partner)
+        if partner is not None:
+            hs2, other = hs2
         hs = hs2.reshape(bs, Lq, c)
         memory = mem2.reshape(bs, h, w, c).permute(0, 3, 1, 2)
-        return hs, memory
+        return (hs, memory) if partner is None else (hs, memory, other)
 
 
 class TransformerWithToken(Transformer):

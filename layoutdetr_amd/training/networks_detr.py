@@ -35,7 +35,7 @@ from .detr_backbone import Backbone, Joiner
 from .detr_position_encoding import PositionEmbeddingSine
 from .detr_transformer import Transformer, TransformerEncoder, TransformerEncoderLayer, TransformerWithToken, mask_scope
 from .networks_stylegan2 import Decoder
-from .util import TransformerWithToken_layoutganpp, encode_seq_first
+from .util import TransformerWithToken_layoutganpp, encode_seq_first, encode_seq_first_pair
 
 
 def merge_lists(lists):
@@ -391,12 +391,19 @@ class Discriminator(nn.Module):
         b = self.fc_bbox(bbox)
         x = torch.cat([b, l, text_feat, text_len_feat], dim=-1)
         x = self.enc_fc_in(x, final_relu=True).permute(1, 0, 2)
-        x = self.enc_transformer(src=src, mask=mask, pos_embed=pos, tgt=x, tgt_key_padding_mask=padding_mask)[0].transpose(0, 1)
-        x0 = x[0]
-        logit_disc = self.fc_out_disc(x0).squeeze(-1)
         x_uncond = torch.cat([self.fc_bbox_uncond(bbox), l_uncond], dim=-1)
         x_uncond = self.enc_fc_in_uncond(x_uncond, final_relu=True).permute(1, 0, 2)
-        x_uncond = self.enc_transformer_uncond(x_uncond, src_key_padding_mask=padding_mask)
+        # The unconditional encoder (networks_detr.py:243) does not depend on the conditional path: it advances in lock-step with the layout decoder
+        # of enc_transformer, one launch per sub-block step for both stacks (hip.stacks); the reference runs them one after the other.
+        partner = self.enc_transformer_uncond.as_prog(x_uncond, padding_mask)
+        if partner is not None:
+            x, _, y_uncond = self.enc_transformer(src=src, mask=mask, pos_embed=pos, tgt=x, tgt_key_padding_mask=padding_mask, partner=partner[0])
+            x_uncond = partner[1](y_uncond)
+        else:
+            x = self.enc_transformer(src=src, mask=mask, pos_embed=pos, tgt=x, tgt_key_padding_mask=padding_mask)[0]
+            x_uncond = self.enc_transformer_uncond(x_uncond, src_key_padding_mask=padding_mask)
+        x0 = x.transpose(0, 1)[0]
+        logit_disc = self.fc_out_disc(x0).squeeze(-1)
         x0_uncond = x_uncond[0]
         return x0, logit_disc, x0_uncond, self.fc_out_disc_uncond(x0_uncond).squeeze(-1)
 
@@ -406,7 +413,12 @@ class Discriminator(nn.Module):
         x = x0.unsqueeze(0).expand(N, -1, -1)
         t = self.pos_token[:N].expand(-1, B, -1)
         x = self.dec_fc_in(torch.cat([x, t], dim=-1), relu=True)
-        x = encode_seq_first(self.dec_transformer, x, padding_mask)
+        x_uncond = x0_uncond.unsqueeze(0).expand(N, -1, -1)
+        t_uncond = self.pos_token_uncond[:N].expand(-1, B, -1)
+        x_uncond = self.dec_fc_in_uncond(torch.cat([x_uncond, t_uncond], dim=-1), relu=True)
+        # the conditional and the unconditional reconstruction decoder (networks_detr.py:269, 275-276) are independent stacks of the same geometry:
+        # one launch per sub-block step for both
+        x, x_uncond = encode_seq_first_pair(self.dec_transformer, x, self.dec_transformer_uncond, x_uncond, padding_mask)
         static = self.static_shapes
         x = x.permute(1, 0, 2) if static else x.permute(1, 0, 2)[valid]
         bbox_pred = self.bbox_embed(x).sigmoid()
@@ -420,10 +432,6 @@ class Discriminator(nn.Module):
         loss_lm = loss_lm if loss_lm is not None else _zero_like_loss(loss_text_len)
         bg_rec = self.bg_decoder(x0)
 
-        x_uncond = x0_uncond.unsqueeze(0).expand(N, -1, -1)
-        t_uncond = self.pos_token_uncond[:N].expand(-1, B, -1)
-        x_uncond = self.dec_fc_in_uncond(torch.cat([x_uncond, t_uncond], dim=-1), relu=True)
-        x_uncond = encode_seq_first(self.dec_transformer_uncond, x_uncond, padding_mask)
         x_uncond = x_uncond.permute(1, 0, 2) if static else x_uncond.permute(1, 0, 2)[valid]
         bbox_pred_uncond = self.bbox_embed_uncond(x_uncond).sigmoid()
         logit_cls_uncond = self.fc_out_cls_uncond(x_uncond)

@@ -547,74 +547,162 @@ def test_split_bf16_non_finite_operands_match_f32_pipe_and_reference_sanitiser(d
         assert_close(pg.cpu()[big], pr.detach()[big], 1e-5, 'adam after sanitising a split-pipe gradient')
 
 
-# ------------------------------------------------------------------------------------------ fused attention sub-blocks
-@pytest.mark.parametrize('B,Lq,Lk,p_mask', [(16, 9, 0, True), (5, 10, 0, True), (3, 16, 0, False), (1, 1, 0, False),
-                                            (16, 10, 64, True), (4, 9, 4, True), (3, 16, 37, True), (2, 1, 64, False)])
-def test_fused_attention_subblocks_vs_fp64_reference(dev, B, Lq, Lk, p_mask):
-    """y = LayerNorm(x + MultiheadAttention(256, 8)(...)) through the one-launch forward kernels of csrc/mha_small.hip (Lk = 0: self-attention
-    q = k = v = x, mha_small_fwd_kernel; Lk > 0: cross-attention onto already projected memory K / V, mha_cross_fwd_kernel), their per-head
-    contributions summed by the partial-sum LayerNorm launch, backward through ldetr_attention_bwd_f32 + the paired projection gradients --
-    against an fp64 torch evaluation (no relu on this path: every value and gradient is held entry by entry), ragged key-padding masks."""
-    from layoutdetr_amd.hip import attention as A
-    from layoutdetr_amd.hip.layernorm import add_layernorm
-    torch.manual_seed(300 + 7 * B + Lq + Lk)
+# ------------------------------------------------------------------------------------------ the short token stacks as one node (hip/stacks.py)
+def _randomise(mod, seed):
+    g = torch.Generator().manual_seed(seed)
+    for n, p_ in mod.named_parameters():
+        if n.endswith('bias'):
+            p_.data = torch.randn(p_.shape, generator=g) * 0.2
+        elif 'norm' in n and n.endswith('weight'):
+            p_.data = torch.rand(p_.shape, generator=g) + 0.5
+
+
+@pytest.mark.parametrize('kind,B,L,S,masked', [('enc', 16, 9, 0, True), ('enc', 5, 10, 0, True), ('enc', 3, 16, 0, False), ('enc', 1, 1, 0, False),
+                                               ('dec', 16, 10, 64, True), ('dec', 4, 9, 4, True), ('dec', 3, 16, 37, True), ('dec', 2, 1, 64, False),
+                                               ('dec', 3, 9, 80, True)])
+def test_token_stack_node_vs_fp64_oracle(dev, kind, B, L, S, masked):
+    """A 2-layer encoder-type stack (nn.TransformerEncoderLayer semantics, training/util.py:13-43) and a 2-layer DETR decoder stack + final norm
+    (training/detr_transformer.py:265-286, 88) at d_model 256 / 8 heads / 2048 hidden through the stack node (hip/stacks.py: one-launch self- and
+    cross-attention sub-blocks forward AND backward, fused feed-forward block, partial-sum LayerNorms, one weight-gradient launch per layer) against
+    the fixture-pinned oracle (oracle/detr_ref.py) evaluated in float64: output, input gradient, the projected memory's gradients and EVERY parameter
+    gradient, entry by entry; ragged key-padding masks; S = 80 memory tokens takes the node's generic cross-attention path (> 64 keys)."""
+    from layoutdetr_amd.hip import stacks as hstacks
+    from layoutdetr_amd.training import detr_transformer as T
+    from oracle import detr_ref
+    torch.manual_seed(300 + 7 * B + L + S)
     d, H = 256, 8
-    mha = torch.nn.MultiheadAttention(d, H, dropout=0.0)
-    mha.in_proj_bias.data.normal_(0, 0.2); mha.out_proj.bias.data.normal_(0, 0.2)
-    ln = torch.nn.LayerNorm(d); ln.weight.data.uniform_(0.5, 1.5); ln.bias.data.normal_(0, 0.1)
-    x = torch.randn(B * Lq, d); gy = torch.randn(B * Lq, d)
-    S = Lk if Lk else Lq
-    kpm = torch.zeros(B, S, dtype=torch.bool)
-    if p_mask:
-        kpm[0, S - S // 3:] = True
+    if kind == 'enc':
+        mod = T.TransformerEncoder(T.TransformerEncoderLayer(d_model=d, nhead=H, dim_feedforward=2048), num_layers=2)
+    else:
+        mod = T.TransformerDecoder(T.TransformerDecoderLayer(d_model=d, nhead=H, dim_feedforward=2048), num_layers=2, norm=torch.nn.LayerNorm(d))
+    _randomise(mod, 17)
+    mod.eval()
+    x = torch.randn(B * L, d); gy = torch.randn(B * L, d)
+    kpm = torch.zeros(B, L, dtype=torch.bool)
+    mem_kpm = torch.zeros(B, max(S, 1), dtype=torch.bool)
+    if masked:
+        kpm[0, L - L // 3:] = True
         if B > 2:
             kpm[2, 1:] = True
-    cross = Lk > 0
-    Kp = torch.randn(B * Lk, 2 * d)[:, :d] if cross else None      # views with a row pitch, as hip.attention.grouped_kv hands them out
-    Vp = torch.randn(B * Lk, 3 * d)[:, d:2 * d] if cross else None
-    # ---- fp64 reference
-    Wi, bi, Wo, bo = [t.detach().double() for t in (mha.in_proj_weight, mha.in_proj_bias, mha.out_proj.weight, mha.out_proj.bias)]
-    Wi.requires_grad_(True); bi.requires_grad_(True); Wo.requires_grad_(True); bo.requires_grad_(True)
-    lnr = torch.nn.LayerNorm(d).double(); lnr.load_state_dict({k: v.double() for k, v in ln.state_dict().items()})
+        if S:
+            mem_kpm[1 % B, S - S // 3:] = True
+    mem = torch.randn(B * S, d) if S else None
+    pos = torch.randn(S, d) * 0.3 if S else None
+    # ---- float64 oracle (seq-first tensors)
+    sd = {k: v.detach().double().requires_grad_(True) for k, v in mod.state_dict().items()}
     xr = x.double().requires_grad_(True)
-    if cross:
-        Kr, Vr = Kp.double().clone().requires_grad_(True), Vp.double().clone().requires_grad_(True)
-        q = xr @ Wi[:d].t() + bi[:d]; k, v = Kr, Vr
+    sf = lambda t, n: t.reshape(B, n, d).permute(1, 0, 2)
+    if kind == 'enc':
+        yr = detr_ref.torch_encoder(sd, '', sf(xr, L), H, kpm)
     else:
-        qkv = xr @ Wi.t() + bi
-        q, k, v = qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:]
-    heads = lambda t, L: t.reshape(B, L, H, d // H).permute(0, 2, 1, 3)
-    sc = heads(q, Lq) @ heads(k, S).transpose(-1, -2) / math.sqrt(d // H)
-    sc = sc.masked_fill(kpm[:, None, None, :], float('-inf'))
-    o = (sc.softmax(-1) @ heads(v, S)).permute(0, 2, 1, 3).reshape(B * Lq, d)
-    yr = lnr(xr + o @ Wo.t() + bo)
+        memr = mem.double().requires_grad_(True)
+        y_ = sf(xr, L)
+        for i in range(2):
+            y_ = detr_ref.decoder_layer(sd, f'layers.{i}.', y_, sf(memr, S), H, kpm, mem_kpm, pos.double()[:, None, :].expand(S, B, d))
+        yr = detr_ref._ln(sd, 'norm.', y_)
+    yr = yr.permute(1, 0, 2).reshape(B * L, d)
     (yr * gy.double()).sum().backward()
     # ---- HIP
-    mha.to(dev); ln.to(dev)
+    mod.to(dev)
     xg = x.to(dev).requires_grad_(True)
-    if cross:
-        Kg, Vg = Kp.to(dev).requires_grad_(True), Vp.to(dev).requires_grad_(True)
-        Kv, Vv = Kg.as_strided(Kg.shape, Kg.stride()), Vg.as_strided(Vg.shape, Vg.stride())
-        assert A.cross_usable(xg, Kg, Vg, mha.in_proj_weight, H, Lq, Lk)
-        part, rb, alias = A.mha_cross_kv(xg, Kg, Vg, None, mha.in_proj_weight, mha.in_proj_bias, mha.out_proj.weight, mha.out_proj.bias, H, B, Lq, Lk,
-                                         key_padding_mask=kpm.to(dev), p_drop=0.0)
+    assert hstacks.ENABLED
+    n0 = hstacks.NODE_RUNS[0]
+    if kind == 'enc':
+        y = mod.forward2d(xg, B, L, kpm.to(dev), None)
     else:
-        assert A.small_usable(xg, mha.in_proj_weight, H, Lq)
-        part, rb, alias = A.self_attention_parts(xg, mha.in_proj_weight, mha.in_proj_bias, mha.out_proj.weight, mha.out_proj.bias, H, B, Lq,
-                                                 key_padding_mask=kpm.to(dev), p_drop=0.0)
-    assert part.shape == (H, B * Lq, d)
-    y = add_layernorm(alias, part, ln.weight, ln.bias, ln.eps, 0.0, r_bias=rb)
+        memg = mem.to(dev).requires_grad_(True)
+        pos2 = pos.to(dev).repeat(B, 1)
+        y = mod.forward2d(xg, memg, pos2, B, L, S, kpm.to(dev), mem_kpm.to(dev))
+    assert hstacks.NODE_RUNS[0] == n0 + 1, 'the stack did not take the stack node'
     (y * gy.to(dev)).sum().backward()
-    assert_close(y, yr, 1e-5, 'y')
-    assert_close(xg.grad, xr.grad, 2e-5, 'dx')
-    if cross:
-        assert_close(Kg.grad, Kr.grad, 2e-5, 'dK'); assert_close(Vg.grad, Vr.grad, 2e-5, 'dV')
-        assert_close(mha.in_proj_weight.grad[:d], Wi.grad[:d], 2e-5, 'dW_q'); assert_close(mha.in_proj_bias.grad[:d], bi.grad[:d], 2e-5, 'db_q')
-        assert float(mha.in_proj_weight.grad[d:].abs().max()) == 0.0        # (the K / V rows belong to the grouped projection's node)
-    else:
-        assert_close(mha.in_proj_weight.grad, Wi.grad, 2e-5, 'dW_in'); assert_close(mha.in_proj_bias.grad, bi.grad, 2e-5, 'db_in')
-    assert_close(mha.out_proj.weight.grad, Wo.grad, 2e-5, 'dW_out'); assert_close(mha.out_proj.bias.grad, bo.grad, 2e-5, 'db_out')
-    assert_close(ln.weight.grad, lnr.weight.grad, 2e-5, 'dgamma'); assert_close(ln.bias.grad, lnr.bias.grad, 2e-5, 'dbeta')
+    assert_close(y, yr, 2e-5, 'y')
+    assert_close(xg.grad, xr.grad, 5e-5, 'dx')
+    if kind == 'dec':
+        assert_close(memg.grad, memr.grad, 5e-5, 'd memory')
+    named = dict(mod.named_parameters())
+    for k, v in sd.items():
+        if v.grad is None:
+            continue
+        assert named[k].grad is not None, k
+        assert_close(named[k].grad, v.grad, 5e-5, 'd ' + k)
+
+
+def test_token_stacks_in_a_group_equal_the_stacks_alone_bit_for_bit(dev):
+    """Two independent stacks in lock-step (ONE launch per sub-block step for both: the second problem's blocks follow the first's in the grid) give
+    exactly the values and gradients of the two stacks run one after the other -- an encoder-type pair (D's reconstruction decoders) and a decoder
+    beside an encoder-type stack (D's layout decoder beside its unconditional encoder), dropout on (same seeds in both runs), gradients accumulated
+    into a FlatModule buffer on top of existing content."""
+    from layoutdetr_amd.hip import core
+    from layoutdetr_amd.hip import stacks as hstacks
+    from layoutdetr_amd.hip.attention import grouped_kv
+    from layoutdetr_amd.training import detr_transformer as T
+    from layoutdetr_amd.training.training_loop import FlatModule
+    torch.manual_seed(411)
+    d, H, B, L, S = 256, 8, 16, 9, 64
+    ea = T.TransformerEncoder(T.TransformerEncoderLayer(d_model=d, nhead=H, dim_feedforward=2048), num_layers=3)
+    eb = T.TransformerEncoder(T.TransformerEncoderLayer(d_model=d, nhead=H, dim_feedforward=2048), num_layers=3)
+    dc = T.TransformerDecoder(T.TransformerDecoderLayer(d_model=d, nhead=H, dim_feedforward=2048), num_layers=3, norm=torch.nn.LayerNorm(d))
+    mods = torch.nn.ModuleList([ea, eb, dc]).to(dev).train()
+    fm = FlatModule(mods)
+    xa0, xb0, xd0 = torch.randn(B * L, d, device=dev), torch.randn(B * L, d, device=dev), torch.randn(B * L, d, device=dev)
+    mem0 = torch.randn(B * S, d, device=dev); pos2 = (torch.randn(S, d, device=dev) * 0.3).repeat(B, 1)
+    kpm = torch.zeros(B, L, dtype=torch.uint8, device=dev); kpm[2, 4:] = 1; kpm[7, 1:] = 1
+    ga, gb, gd = torch.randn(B * L, d, device=dev), torch.randn(B * L, d, device=dev), torch.randn(B * L, d, device=dev)
+    res = {}
+    for grouped in (False, True):
+        fm.zero_grad(); fm.gflat.fill_(0.125)
+        xa, xb, xd, mem = (t.clone().requires_grad_(True) for t in (xa0, xb0, xd0, mem0))
+        core._seed_counter[0] = 5000
+        pa, pb = ea.as_prog(xa, B, L, kpm), eb.as_prog(xb, B, L, kpm)
+        kvs = grouped_kv(mem + pos2, mem, [l.multihead_attn for l in dc.layers])
+        pd = hstacks.Prog('dec', dc.layers, xd, B, L, kpm, True, final_norm=dc.norm, kvs=kvs, S=S, mem_kpm=None)
+        pe = eb.as_prog(xa * 0.5, B, L, kpm)           # (a second use of eb's weights: beside the decoder)
+        assert pa is not None and pb is not None and pe is not None and hstacks.usable(pd)
+        if grouped:
+            ya, yb = hstacks.run([pa, pb])
+            yd, ye = hstacks.run([pd, pe])
+        else:
+            # the same seed order as the grouped run: per layer step the first stack's draws, then the second's
+            ya, yb, yd, ye = _run_alone_with_group_seed_order(hstacks, core, [pa, pb], [pd, pe])
+        ((ya * ga).sum() + (yb * gb).sum() + (yd * gd).sum() + (ye * ga).sum()).backward()
+        res[grouped] = dict(ya=ya.detach().clone(), yb=yb.detach().clone(), yd=yd.detach().clone(), ye=ye.detach().clone(), dxa=xa.grad.clone(), dxb=xb.grad.clone(),
+                            dxd=xd.grad.clone(), dmem=mem.grad.clone(), g=fm.gflat.clone())
+    for k, v in res[False].items():
+        if k == 'g':      # weight gradients of eb arrive from two nodes: their order in the flat buffer's += is autograd's; values to rounding
+            assert_close(res[True][k], v, 1e-6, k)
+        else:
+            assert torch.equal(res[True][k], v), f'{k}: grouped launch differs from the single launches ({(res[True][k] - v).abs().max().item():.3e})'
+
+
+def _run_alone_with_group_seed_order(hstacks, core, *groups):
+    """Each stack of a group as its own node, with the dropout seeds the grouped run would have drawn.  hip.core.next_seed is a counter: a group draws
+    per layer step across its stacks (every stack's attention seed; a decoder's norm1 + cross-attention seeds; every stack's norm_a, hidden, norm_b
+    seeds), a lone stack layer by layer on its own -- so the lone runs are handed the group's draw indices."""
+    outs = []
+    for progs in groups:
+        base, real = core._seed_counter[0], core.next_seed
+        order = []                                   # stack identity of every draw of the grouped run, in draw order
+        for i in range(max(len(p.layers) for p in progs)):
+            act = [p for p in progs if i < len(p.layers)]
+            order += [id(p) for p in act]
+            for p in act:
+                if p.kind == 'dec':
+                    order += [id(p), id(p)]
+            for p in act:
+                order += [id(p)] * 3
+        for p in progs:
+            mine = iter([j for j, pid in enumerate(order) if pid == id(p)])
+
+            def fake(mine=mine):
+                core._seed_counter[0] = base + next(mine)
+                return real()
+            core.next_seed = fake
+            try:
+                outs.append(hstacks.run([p])[0])
+            finally:
+                core.next_seed = real
+        core._seed_counter[0] = base + len(order)
+    return outs
 
 
 # ------------------------------------------------------------------------------------------ fused feed-forward block

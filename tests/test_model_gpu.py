@@ -187,7 +187,7 @@ def test_fused_self_attention_stacks_equal_unfused_stacks(dev, flat, train):
     a 6-layer token encoder (9 x 16, ragged key-padding masks), outputs, input gradients and every parameter gradient.  train=True: both
     paths draw their dropout seeds in the same order and index the attention mask identically, so they must still agree (the backward of
     the fused block is ldetr_attention_bwd_f32 regenerating the fused forward's mask)."""
-    from layoutdetr_amd.hip import attention as A
+    from layoutdetr_amd.hip import stacks as A
     from layoutdetr_amd.hip import core
     from layoutdetr_amd.training import detr_transformer as T
     from layoutdetr_amd.training.training_loop import FlatModule
@@ -203,10 +203,10 @@ def test_fused_self_attention_stacks_equal_unfused_stacks(dev, flat, train):
     g_hs = torch.randn(B, N + 1, d, device=dev); g_enc = torch.randn(B * N, d, device=dev)
     fm = FlatModule(both) if flat else None
     res = {}
-    prev = A.SMALL_FUSED
+    prev = A.ENABLED
     try:
         for fused in (False, True):
-            A.SMALL_FUSED = fused
+            A.ENABLED = fused
             core._seed_counter[0] = 1000
             if flat:
                 fm.zero_grad(); fm.gflat.fill_(0.125)
@@ -221,7 +221,7 @@ def test_fused_self_attention_stacks_equal_unfused_stacks(dev, flat, train):
             res[fused] = dict(hs=hs.detach().clone(), y=y.detach().clone(), d_src=src.grad.clone(), d_tgt=tgt.grad.clone(), d_x=x.grad.clone(),
                               **{'g/' + k: p_.grad.detach().clone() for k, p_ in both.named_parameters() if p_.grad is not None})
     finally:
-        A.SMALL_FUSED = prev
+        A.ENABLED = prev
     assert set(res[True]) == set(res[False])
     assert any('self_attn.in_proj_weight' in k for k in res[True]) and any('self_attn.out_proj.bias' in k for k in res[True])
     worst = 0.0
