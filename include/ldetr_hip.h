@@ -250,6 +250,22 @@ int ldetr_layernorm_bwd_f32(const float* dy, const float* z, const float* mean, 
                             float* dx, float* dresidual, float* dgamma, float* dbeta, int64_t rows, int D,
                             float p_drop, uint64_t seed, const uint64_t* seed_ptr, void* stream);
 
+/* The tail of a loss phase (StyleGAN2Loss.accumulate_gradients, training/loss.py:84-116, 146-218: sum of ~10 weighted terms, .mean(), backward) as one
+ * launch per direction: total = sum_k w[k] * c_k * sum_i f_k(x[k][i]), c_k = 1 / n[k] (red[k] = 0: a per-sample term that is averaged) or 1 (red[k] = 1:
+ * per-sample contributions to a sum); fn[k]: 0 identity, 1 softplus(x), 2 softplus(-x) (F.softplus: threshold 20), 3 ratio x[0] / x[1] (n = 2: the
+ * (loss sum, count) pair of ldetr_softmax_xent_fwd_f32; its gradient is passed UNdivided, ldetr_softmax_xent_bwd_f32 divides by the count).
+ * x / w / n / fn / red are HOST arrays of K <= 16 entries (x[k]: device pointers); vals [K][ld] (weighted values, for the reported statistics),
+ * sums [K], total [1]; backward: g [1] -> grads [K][ld]. */
+int ldetr_loss_combine_fwd_f32(const float* const* x, const float* w, const int* n, const int* fn, const int* red, int K, int ld,
+                               float* vals, float* sums, float* total, void* stream);
+int ldetr_loss_combine_bwd_f32(const float* const* x, const float* w, const int* n, const int* fn, const int* red, int K, int ld,
+                               const float* g, float* grads, void* stream);
+/* F.mse_loss(a[valid], b[valid]) of the static-shape heads without the gather: a [rows][D], b [rows / bdiv][D] (one reference row per bdiv rows),
+ * valid [rows] (nonzero = counted) -> out2 = {sum |a - b|^2 / (max(count, 1) * D), count}; backward: da = 2 (a - b) g / (count * D) on valid rows. */
+int ldetr_masked_mse_fwd_f32(const float* a, const float* b, const uint8_t* valid, int64_t rows, int D, int bdiv, float* out2, void* stream);
+int ldetr_masked_mse_bwd_f32(const float* a, const float* b, const uint8_t* valid, int64_t rows, int D, int bdiv, const float* out2,
+                             const float* g, float* da, void* stream);
+
 /* ---- Group launches of the short token stacks (round 5).
  * D's conditional and unconditional reconstruction decoders (networks_detr.py:269, 275-276 via training/util.py:13-43), and D's layout decoder
  * beside its unconditional encoder (networks_detr.py:242-243), are structurally identical, independent stacks that the reference runs one after the

@@ -139,6 +139,10 @@ SIGNATURES = {
     'ldetr_mha_small_bwd_group_f32': [_P, _I, _P],
     'ldetr_mha_cross_bwd_f32': [_P, _P],
     'ldetr_wgrad_multi_f32': [_P, _I, _P],
+    'ldetr_loss_combine_fwd_f32': [_P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P],
+    'ldetr_loss_combine_bwd_f32': [_P, _P, _P, _P, _P, _I, _I, _P, _P, _P],
+    'ldetr_masked_mse_fwd_f32': [_P, _P, _P, _L, _I, _I, _P, _P],
+    'ldetr_masked_mse_bwd_f32': [_P, _P, _P, _L, _I, _I, _P, _P, _P, _P],
     'ldetr_gemm_pair_f32': [_P, _P, _P],
     'ldetr_gemm_pair_is_single_launch': [_P, _P],
     'ldetr_demod_fwd_f32': [_P, _L, _L, _L, _L, _P, _P, _P, _I, _I, _I, _I, _I, _F, _P],

@@ -11,6 +11,7 @@
 // compute_alignment keeps its quirk of comparing valid boxes against padded ones too (the mask is applied to rows only).
 //   losses [4][B]: per-sample shares, so that  mse = losses[0].sum(), gIoU = losses[1].sum(), overlap = losses[2] ([B]),
 //                  alignment = losses[3] ([B]).   grads [4][B][N][4] = d losses[t][b] / d bbox[b].
+#include <algorithm>
 #include "ldetr_common.hpp"
 #include "../../include/ldetr_hip.h"
 
@@ -180,6 +181,110 @@ __global__ __launch_bounds__(256) void layout_losses_bwd_kernel(LayoutLossParams
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------------------------
+// The tail of a loss phase as ONE launch per direction.  StyleGAN2Loss.accumulate_gradients (training/loss.py:84-116, 146-218) forms each phase's loss
+// as sum_k w_k * term_k over ~10 terms -- softplus(+-logits) [B], per-sample layout terms [B], scalar reconstruction / cross-entropy terms -- then
+// .mean().mul(gain).backward(): ~30 scalar-sized ATen launches forward and ~40 backward per phase.  Here: total = sum_k w_k * c_k * sum_i f_k(x_k[i])
+// (c_k = 1 / n_k for a per-sample term that the reference averages, 1 for a term given as per-sample contributions to a sum, f_k in {x, softplus(x),
+// softplus(-x)}; a `ratio` term is x[0] / x[1]: the cross-entropy kernel's (loss sum, count) pair), the weighted per-element values for the statistics
+// the reference reports (training_stats.report), and in the backward every term's gradient in one pass.
+struct LossCombineParams {
+    const float* x[16]; float w[16]; int n[16]; int fn[16]; int red[16];
+    int K, ld;
+    float* vals; float* sums; float* total;     // [K][ld] weighted values, [K] their sums, [1]
+    const float* g; float* grads;               // backward: d total, [K][ld]
+};
+
+__device__ __forceinline__ float softplus_f(float x) { return x > 20.f ? x : log1pf(expf(x)); }        // F.softplus(beta 1, threshold 20)
+__device__ __forceinline__ float sigmoid_f(float x) { return 1.f / (1.f + expf(-x)); }
+
+__global__ __launch_bounds__(256) void loss_combine_fwd_kernel(LossCombineParams p) {
+    __shared__ float red[4];
+    const int tid = threadIdx.x;
+    float total = 0.f;
+    for (int k = 0; k < p.K; k++) {
+        const float w = p.w[k];
+        if (p.fn[k] == 3) {
+            const float v = p.x[k][0] / p.x[k][1] * w;
+            if (tid == 0) { p.vals[(long)k * p.ld] = v; p.sums[k] = v; }
+            total += v;
+            continue;
+        }
+        float part = 0.f;
+        for (int i = tid; i < p.n[k]; i += 256) {
+            const float x = p.x[k][i];
+            const float v = (p.fn[k] == 1 ? softplus_f(x) : (p.fn[k] == 2 ? softplus_f(-x) : x)) * w;
+            p.vals[(long)k * p.ld + i] = v;
+            part += v;
+        }
+        part = wave_sum(part);
+        __syncthreads();
+        if ((tid & 63) == 0) red[tid >> 6] = part;
+        __syncthreads();
+        const float s = red[0] + red[1] + red[2] + red[3];
+        if (tid == 0) p.sums[k] = s;
+        total += s * (p.red[k] ? 1.f : 1.f / (float)p.n[k]);
+    }
+    if (tid == 0) p.total[0] = total;
+}
+
+__global__ __launch_bounds__(256) void loss_combine_bwd_kernel(LossCombineParams p) {
+    const float g = p.g[0];
+    for (int k = blockIdx.x; k < p.K; k += gridDim.x) {
+        const float w = p.w[k];
+        if (p.fn[k] == 3) {       // the cross-entropy backward divides by its count itself
+            if (threadIdx.x == 0) { p.grads[(long)k * p.ld] = g * w; p.grads[(long)k * p.ld + 1] = 0.f; }
+            continue;
+        }
+        const float c = g * w * (p.red[k] ? 1.f : 1.f / (float)p.n[k]);
+        for (int i = threadIdx.x; i < p.n[k]; i += 256) {
+            const float x = p.x[k][i];
+            float d = 1.f;
+            if (p.fn[k] == 1) d = x > 20.f ? 1.f : sigmoid_f(x);
+            else if (p.fn[k] == 2) d = -x > 20.f ? -1.f : -sigmoid_f(-x);
+            p.grads[(long)k * p.ld + i] = c * d;
+        }
+    }
+}
+
+// F.mse_loss(a[valid], b[valid]) without the gather (the static-shape heads: networks_detr.py:314 / loss.py:240, 245): a [rows][D], b [rows / bdiv][D]
+// (bdiv > 1: one reference row per group of bdiv rows, the per-sample z of loss_z), valid [rows] -> out[0] = sum over valid rows of |a - b|^2 /
+// (max(count, 1) * D), out[1] = count.  One block (rows are slots of a batch: a few hundred).
+struct MaskedMseParams { const float* a; const float* b; const unsigned char* valid; long rows; int D, bdiv; float* out; const float* g; float* da; };
+
+__global__ __launch_bounds__(256) void masked_mse_fwd_kernel(MaskedMseParams p) {
+    __shared__ float red[2][4];
+    const int tid = threadIdx.x;
+    float s = 0.f, c = 0.f;
+    const long n = p.rows * p.D;
+    for (long i = tid; i < n; i += 256) {
+        const long row = i / p.D; const int d = (int)(i - row * p.D);
+        if (p.valid[row]) {
+            const float e = p.a[i] - p.b[(row / p.bdiv) * p.D + d];
+            s += e * e;
+            c += d == 0 ? 1.f : 0.f;
+        }
+    }
+    s = wave_sum(s); c = wave_sum(c);
+    if ((tid & 63) == 0) { red[0][tid >> 6] = s; red[1][tid >> 6] = c; }
+    __syncthreads();
+    if (tid == 0) {
+        const float cnt = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+        p.out[0] = (red[0][0] + red[0][1] + red[0][2] + red[0][3]) / (fmaxf(cnt, 1.f) * (float)p.D);
+        p.out[1] = cnt;
+    }
+}
+
+__global__ __launch_bounds__(256) void masked_mse_bwd_kernel(MaskedMseParams p) {
+    const long n = p.rows * p.D;
+    const float c = 2.f * p.g[0] / (fmaxf(p.out[1], 1.f) * (float)p.D);
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const long row = i / p.D; const int d = (int)(i - row * p.D);
+        p.da[i] = p.valid[row] ? c * (p.a[i] - p.b[(row / p.bdiv) * p.D + d]) : 0.f;
+    }
+}
+
 }  // namespace ldetr
 
 using namespace ldetr;
@@ -202,4 +307,54 @@ extern "C" int ldetr_layout_losses_bwd_f32(const float* grads, const float* grad
     const long per = (long)B * N * 4;
     hipLaunchKernelGGL(layout_losses_bwd_kernel, dim3((unsigned)((per + 255) / 256 > 1024 ? 1024 : (per + 255) / 256)), 256, 0, (hipStream_t)stream, p);
     return check_launch("layout_losses_bwd");
+}
+
+static int loss_combine_fill(LossCombineParams& p, const float* const* x, const float* w, const int* n, const int* fn, const int* red, int K, int ld) {
+    LDETR_CHECK(x && w && n && fn && red && K >= 1 && K <= 16 && ld >= 2, "loss_combine: 1..16 terms");
+    memset(&p, 0, sizeof(p));
+    for (int k = 0; k < K; k++) {
+        LDETR_CHECK(x[k] && n[k] >= 1 && n[k] <= ld && fn[k] >= 0 && fn[k] <= 3 && (fn[k] != 3 || n[k] == 2), "loss_combine: bad term %d", k);
+        p.x[k] = x[k]; p.w[k] = w[k]; p.n[k] = n[k]; p.fn[k] = fn[k]; p.red[k] = red[k];
+    }
+    p.K = K; p.ld = ld;
+    return LDETR_OK;
+}
+
+extern "C" int ldetr_loss_combine_fwd_f32(const float* const* x, const float* w, const int* n, const int* fn, const int* red, int K, int ld,
+                                          float* vals, float* sums, float* total, void* stream) {
+    LossCombineParams p;
+    if (int rc = loss_combine_fill(p, x, w, n, fn, red, K, ld)) return rc;
+    LDETR_CHECK(vals && sums && total, "loss_combine_fwd: null output");
+    p.vals = vals; p.sums = sums; p.total = total;
+    hipLaunchKernelGGL(loss_combine_fwd_kernel, dim3(1), 256, 0, (hipStream_t)stream, p);
+    return check_launch("loss_combine_fwd");
+}
+
+extern "C" int ldetr_loss_combine_bwd_f32(const float* const* x, const float* w, const int* n, const int* fn, const int* red, int K, int ld,
+                                          const float* g, float* grads, void* stream) {
+    LossCombineParams p;
+    if (int rc = loss_combine_fill(p, x, w, n, fn, red, K, ld)) return rc;
+    LDETR_CHECK(g && grads, "loss_combine_bwd: null pointer");
+    p.g = g; p.grads = grads;
+    hipLaunchKernelGGL(loss_combine_bwd_kernel, dim3((unsigned)K), 256, 0, (hipStream_t)stream, p);
+    return check_launch("loss_combine_bwd");
+}
+
+extern "C" int ldetr_masked_mse_fwd_f32(const float* a, const float* b, const uint8_t* valid, int64_t rows, int D, int bdiv, float* out2, void* stream) {
+    LDETR_CHECK(a && b && valid && out2 && rows >= 0 && D >= 1 && bdiv >= 1, "masked_mse_fwd: bad arguments");
+    MaskedMseParams p; memset(&p, 0, sizeof(p));
+    p.a = a; p.b = b; p.valid = valid; p.rows = rows; p.D = D; p.bdiv = bdiv; p.out = out2;
+    hipLaunchKernelGGL(masked_mse_fwd_kernel, dim3(1), 256, 0, (hipStream_t)stream, p);
+    return check_launch("masked_mse_fwd");
+}
+
+extern "C" int ldetr_masked_mse_bwd_f32(const float* a, const float* b, const uint8_t* valid, int64_t rows, int D, int bdiv, const float* out2,
+                                        const float* g, float* da, void* stream) {
+    LDETR_CHECK(a && b && valid && out2 && g && da && rows >= 0 && D >= 1 && bdiv >= 1, "masked_mse_bwd: bad arguments");
+    if (rows == 0) return LDETR_OK;
+    MaskedMseParams p; memset(&p, 0, sizeof(p));
+    p.a = a; p.b = b; p.valid = valid; p.rows = rows; p.D = D; p.bdiv = bdiv; p.out = const_cast<float*>(out2); p.g = g; p.da = da;
+    const long n = rows * D;
+    hipLaunchKernelGGL(masked_mse_bwd_kernel, dim3((unsigned)std::min<long>((n + 255) / 256, 256)), 256, 0, (hipStream_t)stream, p);
+    return check_launch("masked_mse_bwd");
 }

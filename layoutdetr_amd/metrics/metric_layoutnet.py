@@ -98,6 +98,14 @@ def layout_losses_fused(bbox_fake, bbox_real, valid):
     return out[0].sum(), out[1].sum(), out[2], out[3]
 
 
+def layout_losses_per_sample(bbox_fake, bbox_real, valid):
+    """-> [4, B]: per-sample shares of (mse, gIoU) -- their sums are the two scalar terms -- and the per-sample overlap / alignment terms, as ONE
+    autograd tensor (hip.losses.combine takes it whole)."""
+    if bbox_real.requires_grad:
+        raise NotImplementedError('layout_losses_fused: the reference boxes are data (no gradient is produced for them)')
+    return _LayoutLossesFn.apply(bbox_fake, bbox_real, valid)
+
+
 def linear_sum_assignment_batched(cost, maximize=False):
     """Batched Hungarian on device: cost [batch, n, n] float64 -> (row_ind, col_ind) int32 [batch, n], bit-exact with
     scipy.optimize.linear_sum_assignment as used by compute_maximum_iou_for_layout (metric_layoutnet.py:100-113)."""

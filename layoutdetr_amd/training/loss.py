@@ -10,22 +10,26 @@ import torch.nn.functional as F
 
 from ..hip import core
 
-from ..metrics.metric_layoutnet import compute_alignment, compute_overlap, generalized_iou_loss, layout_losses_fused
+from ..hip import losses as hl
+from ..metrics.metric_layoutnet import compute_alignment, compute_overlap, generalized_iou_loss, layout_losses_fused, layout_losses_per_sample
 
 
 def _masked_mse(a, b, valid):
     """F.mse_loss(a[valid], b[valid]) without the gather: a, b [B,N,D], valid [B,N] bool."""
+    if a.is_cuda and a.dtype == torch.float32 and not b.requires_grad:
+        return hl.masked_mse(a, b, valid.to(torch.uint8))      # one launch per direction (csrc/layout_loss.hip) instead of ~9 + ~12
     vf = valid.to(a.dtype)
     return ((a - b).square().sum(-1) * vf).sum() / (vf.sum().clamp_min(1.0) * a.shape[-1])
 
 
-def _masked_ce(logits, target, valid):
+def _masked_ce(logits, target, valid, raw=False):
     """F.cross_entropy(logits[valid], target[valid]) without the gather: logits [B,N,L].  On the GPU the padded slots become ignored
     targets of the fused softmax-cross-entropy kernel (csrc/xent.hip: loss and row log-sum-exp in one pass, gradient in one pass):
-    the same mean over the same slots in 4 launches instead of ~13."""
+    the same mean over the same slots in 4 launches instead of ~13.  raw: the (loss sum, count) pair for hip.losses.combine's RATIO term."""
     if logits.is_cuda and logits.dtype == torch.float32:
         from .med import softmax_cross_entropy
-        return softmax_cross_entropy(logits.flatten(0, 1), target.flatten().masked_fill(~valid.flatten(), -100))
+        return softmax_cross_entropy(logits.flatten(0, 1), target.flatten().masked_fill(~valid.flatten(), -100), raw=raw)
+    assert not raw
     vf = valid.to(logits.dtype).flatten()
     ce = F.cross_entropy(logits.flatten(0, 1), target.flatten(), reduction='none')
     return (ce * vf).sum() / vf.sum().clamp_min(1.0)
@@ -84,6 +88,7 @@ class StyleGAN2Loss(Loss):
         # with a shared trunk, D(fake) and D(real) of Dmain also run as one batch of 2B (values identical; LDETR_PAIR_D=0 = two calls)
         self.pair_D_passes = bool(share_D_trunk) and os.environ.get('LDETR_PAIR_D', '1') != '0'
         self.fused_layout_losses = os.environ.get('LDETR_FUSED_LAYOUT_LOSSES', '1') != '0'   # csrc/layout_loss.hip (static-shape path)
+        self.fused_loss_tail = os.environ.get('LDETR_FUSED_LOSS_TAIL', '1') != '0'           # hip.losses.combine: a phase's tail as one launch per direction
         # share_D_trunk='iteration' goes one step further: D's weights do not change between the Gmain and the Dmain phase of one
         # iteration (Gmain updates G only, training_loop.py:281-313), so ONE trunk evaluation per iteration serves D(fake) in Gmain
         # (values only: D is frozen there) and both D passes of Dmain (with its autograd graph).  The iteration driver calls
@@ -172,7 +177,7 @@ class StyleGAN2Loss(Loss):
             return self.D(bbox, bbox_class, bbox_text, bbox_patch, padding_mask, background, c, **kw)
         return self.D(bbox, bbox_class, bbox_text, bbox_patch, padding_mask, background, c, reconst, **kw)
 
-    def g_main_loss(self, bbox_real, bbox_class, bbox_text, bbox_patch, padding_mask, background, gen_z, gen_c):
+    def g_main_loss(self, bbox_real, bbox_class, bbox_text, bbox_patch, padding_mask, background, gen_z, gen_c, gain=1.0):
         w = self.w
         valid = ~padding_mask
         static = bool(getattr(self.G, 'static_shapes', False))
@@ -182,51 +187,77 @@ class StyleGAN2Loss(Loss):
         bbox_fake, loss_z, cls_logits, loss_lm, loss_text_len = self.run_G(gen_z, bbox_class, bbox_real, bbox_text, bbox_patch, padding_mask, background, gen_c, reconst=True)
         gen_logits, gen_logits_uncond = self.run_D(bbox_fake, bbox_class, bbox_text, bbox_patch, padding_mask, background, gen_c,
                                                    trunk_out=cached)
+        T = hl.Term
+        w_ = lambda v, key: v * w[key]      # noqa: E731
+        fused_tail = self.fused_loss_tail and gen_logits.is_cuda
+        lay = None
         if static and self.fused_layout_losses and bbox_fake.is_cuda and bbox_fake.shape[1] <= 64:
             # one launch for the four layout terms and their gradients (csrc/layout_loss.hip) instead of ~280 elementwise ones
-            l_rec, l_giou, l_ovl, l_aln = layout_losses_fused(bbox_fake, bbox_real, valid)
+            if fused_tail:
+                lay = layout_losses_per_sample(bbox_fake, bbox_real, valid)
+            else:
+                l_rec, l_giou, l_ovl, l_aln = layout_losses_fused(bbox_fake, bbox_real, valid)
         elif static:
             l_rec, l_giou = _masked_mse(bbox_fake, bbox_real, valid), _masked_giou(bbox_fake, bbox_real, valid)
             l_ovl, l_aln = compute_overlap(bbox_fake, valid), compute_alignment(bbox_fake, valid)
         else:
             l_rec, l_giou = F.mse_loss(bbox_fake[valid], bbox_real[valid]), generalized_iou_loss(bbox_fake[valid], bbox_real[valid])
             l_ovl, l_aln = compute_overlap(bbox_fake, valid), compute_alignment(bbox_fake, valid)
-        terms = dict(
-            loss_Ggen=F.softplus(-gen_logits),
-            loss_Ggen_uncond=F.softplus(-gen_logits_uncond),
-            loss_Ggen_bbox_rec=l_rec * w['Ggen_bbox_rec'],
-            loss_Ggen_bbox_gIoU=l_giou * w['Ggen_bbox_gIoU'],
-            loss_Ggen_overlapping=l_ovl * w['Ggen_overlapping'],
-            loss_Ggen_alignment=l_aln * w['Ggen_alignment'],
-            loss_Ggen_z_rec=loss_z * w['Ggen_z_rec'],
-            loss_Ggen_bbox_cls=(_masked_ce(cls_logits, bbox_class, valid) if static else F.cross_entropy(cls_logits, bbox_class[valid])) * w['Ggen_bbox_cls'],
-            loss_Ggen_text_rec=loss_lm * w['Ggen_text_rec'],
-            loss_Ggen_text_len_rec=loss_text_len * w['Ggen_text_len_rec'],
-        )
         self.report('Loss/scores/fake', gen_logits)
         if self._reporting:
             self.report('Loss/signs/fake', gen_logits.sign())
+        if fused_tail:
+            # the whole tail -- softplus of the two scores, the weights, the sum over the terms, the batch mean and the gain -- and its backward as one
+            # launch per direction (hip.losses.combine) instead of ~30 + ~40 scalar-sized ATen launches
+            terms = [T('loss_Ggen', gen_logits, 1.0, hl.SOFTPLUS_NEG), T('loss_Ggen_uncond', gen_logits_uncond, 1.0, hl.SOFTPLUS_NEG)]
+            if lay is not None:
+                terms.append(T(['loss_Ggen_bbox_rec', 'loss_Ggen_bbox_gIoU', 'loss_Ggen_overlapping', 'loss_Ggen_alignment'], lay,
+                               [w['Ggen_bbox_rec'], w['Ggen_bbox_gIoU'], w['Ggen_overlapping'], w['Ggen_alignment']], hl.IDENT, [True, True, False, False]))
+            else:
+                terms += [T('loss_Ggen_bbox_rec', l_rec, w['Ggen_bbox_rec']), T('loss_Ggen_bbox_gIoU', l_giou, w['Ggen_bbox_gIoU']),
+                          T('loss_Ggen_overlapping', l_ovl, w['Ggen_overlapping']), T('loss_Ggen_alignment', l_aln, w['Ggen_alignment'])]
+            terms.append(T('loss_Ggen_z_rec', loss_z, w['Ggen_z_rec']))
+            if static:
+                terms.append(T('loss_Ggen_bbox_cls', _masked_ce(cls_logits, bbox_class, valid, raw=True), w['Ggen_bbox_cls'], hl.RATIO))
+            else:
+                terms.append(T('loss_Ggen_bbox_cls', F.cross_entropy(cls_logits, bbox_class[valid]), w['Ggen_bbox_cls']))
+            terms += [T('loss_Ggen_text_rec', loss_lm, w['Ggen_text_rec']), T('loss_Ggen_text_len_rec', loss_text_len, w['Ggen_text_len_rec'])]
+            total, rep = hl.combine(terms, gain)
+            for k, v in rep.items():
+                self.report('Loss/G/' + k, v)
+            self.last = dict(bbox_fake=bbox_fake.detach(), **{k: v.detach() for k, v in rep.items()})
+            return total
+        terms = dict(
+            loss_Ggen=F.softplus(-gen_logits),
+            loss_Ggen_uncond=F.softplus(-gen_logits_uncond),
+            loss_Ggen_bbox_rec=w_(l_rec, 'Ggen_bbox_rec'),
+            loss_Ggen_bbox_gIoU=w_(l_giou, 'Ggen_bbox_gIoU'),
+            loss_Ggen_overlapping=w_(l_ovl, 'Ggen_overlapping'),
+            loss_Ggen_alignment=w_(l_aln, 'Ggen_alignment'),
+            loss_Ggen_z_rec=w_(loss_z, 'Ggen_z_rec'),
+            loss_Ggen_bbox_cls=w_(_masked_ce(cls_logits, bbox_class, valid) if static else F.cross_entropy(cls_logits, bbox_class[valid]), 'Ggen_bbox_cls'),
+            loss_Ggen_text_rec=w_(loss_lm, 'Ggen_text_rec'),
+            loss_Ggen_text_len_rec=w_(loss_text_len, 'Ggen_text_len_rec'),
+        )
         for k, v in terms.items():
             self.report('Loss/G/' + k, v)
         total = sum(terms.values())
         self.last = dict(bbox_fake=bbox_fake.detach(), **{k: v.detach() for k, v in terms.items()})
-        return total.mean()
+        return total.mean().mul(gain)
 
-    def d_gen_loss(self, bbox_real, bbox_class, bbox_text, bbox_patch, padding_mask, background, gen_z, gen_c, trunk_out=None, gen_out=None):
+    def d_gen_terms(self, bbox_real, bbox_class, bbox_text, bbox_patch, padding_mask, background, gen_z, gen_c, trunk_out=None, gen_out=None):
+        """-> the terms of loss.py:146-160 (D on the generated layout) as hip.losses.Term objects."""
         if gen_out is None:
             bbox_fake = self.run_G(gen_z, bbox_class, bbox_real, bbox_text, bbox_patch, padding_mask, background, gen_c, update_emas=True)
             gen_out = self.run_D(bbox_fake, bbox_class, bbox_text, bbox_patch, padding_mask, background, gen_c, update_emas=True, trunk_out=trunk_out)
         gen_logits, gen_logits_uncond = gen_out
-        loss_Dgen = F.softplus(gen_logits)
-        loss_Dgen_uncond = F.softplus(gen_logits_uncond)
         self.report('Loss/scores/fake', gen_logits)
         if self._reporting:
             self.report('Loss/signs/fake', gen_logits.sign())
-        self.report('Loss/D/loss_Dgen', loss_Dgen)
-        self.report('Loss/D/loss_Dgen_uncond', loss_Dgen_uncond)
-        return (loss_Dgen + loss_Dgen_uncond).mean()
+        return [hl.Term('loss_Dgen', gen_logits, 1.0, hl.SOFTPLUS), hl.Term('loss_Dgen_uncond', gen_logits_uncond, 1.0, hl.SOFTPLUS)]
 
-    def d_real_loss(self, bbox_real, bbox_class, bbox_text, bbox_patch, padding_mask, background, real_c, trunk_out=None, real_out=None):
+    def d_real_terms(self, bbox_real, bbox_class, bbox_text, bbox_patch, padding_mask, background, real_c, trunk_out=None, real_out=None):
+        """-> the terms of loss.py:162-218 (D on the real layout with the reconstruction heads)."""
         w = self.w
         valid = ~padding_mask
         static = bool(getattr(self.D, 'static_shapes', False))
@@ -234,23 +265,42 @@ class StyleGAN2Loss(Loss):
         if real_out is None:
             real_out = self.run_D(bbox_real_tmp, bbox_class, bbox_text, bbox_patch, padding_mask, background, real_c, reconst=True, trunk_out=trunk_out)
         (real_logits, real_logits_uncond, bbox_rec, cls_logits, loss_lm, loss_text_len, bg_rec, bbox_rec_uncond, cls_logits_uncond) = real_out
-        terms = dict(
-            loss_Dreal=F.softplus(-real_logits),
-            loss_Dreal_uncond=F.softplus(-real_logits_uncond),
-            loss_Dreal_bbox_rec=(_masked_mse(bbox_rec, bbox_real_tmp, valid) if static else F.mse_loss(bbox_rec, bbox_real_tmp[valid])) * w['Dreal_bbox_rec'],
-            loss_Dreal_bbox_cls=(_masked_ce(cls_logits, bbox_class, valid) if static else F.cross_entropy(cls_logits, bbox_class[valid])) * w['Dreal_bbox_cls'],
-            loss_Dreal_text_rec=loss_lm * w['Dreal_text_rec'],
-            loss_Dreal_text_len_rec=loss_text_len * w['Dreal_text_len_rec'],
-            loss_Dreal_bg_rec=F.mse_loss(bg_rec, background) * w['Dreal_im_rec'],
-            loss_Dreal_bbox_rec_uncond=(_masked_mse(bbox_rec_uncond, bbox_real_tmp, valid) if static else F.mse_loss(bbox_rec_uncond, bbox_real_tmp[valid])) * w['Dreal_bbox_rec'],
-            loss_Dreal_bbox_cls_uncond=(_masked_ce(cls_logits_uncond, bbox_class, valid) if static else F.cross_entropy(cls_logits_uncond, bbox_class[valid])) * w['Dreal_bbox_cls'],
-        )
+        T = hl.Term
+        fused = self.fused_loss_tail and real_logits.is_cuda and static
+
+        def ce(logits):
+            if fused:
+                return dict(x=_masked_ce(logits, bbox_class, valid, raw=True), fn=hl.RATIO)
+            return dict(x=_masked_ce(logits, bbox_class, valid) if static else F.cross_entropy(logits, bbox_class[valid]))
+        mse = (lambda a: _masked_mse(a, bbox_real_tmp, valid)) if static else (lambda a: F.mse_loss(a, bbox_real_tmp[valid]))
         self.report('Loss/scores/real', real_logits)
         if self._reporting:
             self.report('Loss/signs/real', real_logits.sign())
-        for k, v in terms.items():
-            self.report('Loss/D/' + k, v)
-        return sum(terms.values()).mean()
+        return [T('loss_Dreal', real_logits, 1.0, hl.SOFTPLUS_NEG), T('loss_Dreal_uncond', real_logits_uncond, 1.0, hl.SOFTPLUS_NEG),
+                T('loss_Dreal_bbox_rec', mse(bbox_rec), w['Dreal_bbox_rec']), T('loss_Dreal_bbox_cls', weight=w['Dreal_bbox_cls'], **ce(cls_logits)),
+                T('loss_Dreal_text_rec', loss_lm, w['Dreal_text_rec']), T('loss_Dreal_text_len_rec', loss_text_len, w['Dreal_text_len_rec']),
+                T('loss_Dreal_bg_rec', F.mse_loss(bg_rec, background), w['Dreal_im_rec']),
+                T('loss_Dreal_bbox_rec_uncond', mse(bbox_rec_uncond), w['Dreal_bbox_rec']),
+                T('loss_Dreal_bbox_cls_uncond', weight=w['Dreal_bbox_cls'], **ce(cls_logits_uncond))]
+
+    def _finish(self, terms, prefix, gain=1.0):
+        """sum of the terms -> batch mean -> x gain (loss.py:213, 253 + the .mul(gain) of :116, 160, 218), every term reported like the reference does.
+        On the GPU one launch per direction for all of it (hip.losses.combine)."""
+        if self.fused_loss_tail and terms[0].x.is_cuda:
+            total, rep = hl.combine(terms, gain)
+        else:
+            f = {hl.IDENT: lambda x: x, hl.SOFTPLUS: F.softplus, hl.SOFTPLUS_NEG: lambda x: F.softplus(-x)}
+            rep = {t.name: f[t.fn](t.x) * t.weight for t in terms}
+            total = sum(rep.values()).mean().mul(gain)
+        for k, v in rep.items():
+            self.report(prefix + k, v)
+        return total
+
+    def d_gen_loss(self, *args, gain=1.0, **kwargs):
+        return self._finish(self.d_gen_terms(*args, **kwargs), 'Loss/D/', gain)
+
+    def d_real_loss(self, *args, gain=1.0, **kwargs):
+        return self._finish(self.d_real_terms(*args, **kwargs), 'Loss/D/', gain)
 
     def accumulate_gradients(self, phase, bbox_real, bbox_class, bbox_text, bbox_patch, padding_mask, background, real_c, gen_z, gen_c, gain, cur_nimg):
         assert phase in ['Gmain', 'Greg', 'Gboth', 'Dmain', 'Dreg', 'Dboth']
@@ -276,7 +326,7 @@ class StyleGAN2Loss(Loss):
 
     def _run_phase(self, phase, bbox_real, bbox_class, bbox_text, bbox_patch, padding_mask, background, real_c, gen_z, gen_c, gain):
         if phase == 'Gmain':
-            self.g_main_loss(bbox_real, bbox_class, bbox_text, bbox_patch, padding_mask, background, gen_z, gen_c).mul(gain).backward()
+            self.g_main_loss(bbox_real, bbox_class, bbox_text, bbox_patch, padding_mask, background, gen_z, gen_c, gain=gain).backward()
         if phase == 'Dmain':
             if self.share_D_trunk and hasattr(self.D, 'trunk'):   # True / 'phase' / 'iteration'
                 cached = self._cached_trunk(background, detach=False, pop=True)
@@ -287,17 +337,18 @@ class StyleGAN2Loss(Loss):
                     bbox_fake = self.run_G(gen_z, bbox_class, bbox_real, bbox_text, bbox_patch, padding_mask, background, gen_c, update_emas=True)
                     trunk = cached if cached is not None else self.D.trunk(background)
                     gen_out, real_out = self.D.forward_pair(bbox_fake, bbox_real.detach(), bbox_class, bbox_text, bbox_patch, padding_mask, background, real_c, trunk_out=trunk)
-                    l_gen = self.d_gen_loss(bbox_real, bbox_class, bbox_text, bbox_patch, padding_mask, background, gen_z, gen_c, gen_out=gen_out)
-                    l_real = self.d_real_loss(bbox_real, bbox_class, bbox_text, bbox_patch, padding_mask, background, real_c, real_out=real_out)
+                    t_gen = self.d_gen_terms(bbox_real, bbox_class, bbox_text, bbox_patch, padding_mask, background, gen_z, gen_c, gen_out=gen_out)
+                    t_real = self.d_real_terms(bbox_real, bbox_class, bbox_text, bbox_patch, padding_mask, background, real_c, real_out=real_out)
                 elif cached is not None:
-                    l_gen = self.d_gen_loss(bbox_real, bbox_class, bbox_text, bbox_patch, padding_mask, background, gen_z, gen_c, trunk_out=cached)
-                    l_real = self.d_real_loss(bbox_real, bbox_class, bbox_text, bbox_patch, padding_mask, background, real_c, trunk_out=cached)
+                    t_gen = self.d_gen_terms(bbox_real, bbox_class, bbox_text, bbox_patch, padding_mask, background, gen_z, gen_c, trunk_out=cached)
+                    t_real = self.d_real_terms(bbox_real, bbox_class, bbox_text, bbox_patch, padding_mask, background, real_c, trunk_out=cached)
                 else:
                     trunk = self.D.trunk(background)
-                    l_gen = self.d_gen_loss(bbox_real, bbox_class, bbox_text, bbox_patch, padding_mask, background, gen_z, gen_c, trunk_out=trunk)
-                    l_real = self.d_real_loss(bbox_real, bbox_class, bbox_text, bbox_patch, padding_mask, background, real_c, trunk_out=trunk)
-                (l_gen + l_real).mul(gain).backward()   # one backward: the trunk sees the summed gradient of both passes
+                    t_gen = self.d_gen_terms(bbox_real, bbox_class, bbox_text, bbox_patch, padding_mask, background, gen_z, gen_c, trunk_out=trunk)
+                    t_real = self.d_real_terms(bbox_real, bbox_class, bbox_text, bbox_patch, padding_mask, background, real_c, trunk_out=trunk)
+                # one backward: the trunk sees the summed gradient of both passes; mean(gen terms) + mean(real terms) = one combine over all of them
+                self._finish(t_gen + t_real, 'Loss/D/', gain).backward()
             else:
                 self._dual_trunks(background)          # reference call pattern: the generator's trunk beside the trunk of D(fake); D(real) evaluates its own
-                self.d_gen_loss(bbox_real, bbox_class, bbox_text, bbox_patch, padding_mask, background, gen_z, gen_c).mul(gain).backward()
-                self.d_real_loss(bbox_real, bbox_class, bbox_text, bbox_patch, padding_mask, background, real_c).mul(gain).backward()
+                self.d_gen_loss(bbox_real, bbox_class, bbox_text, bbox_patch, padding_mask, background, gen_z, gen_c, gain=gain).backward()
+                self.d_real_loss(bbox_real, bbox_class, bbox_text, bbox_patch, padding_mask, background, real_c, gain=gain).backward()

@@ -271,7 +271,8 @@ class _SoftmaxXentFn(torch.autograd.Function):
     node: it is written into a fresh buffer (logits may be another node's saved output)."""
 
     @staticmethod
-    def forward(ctx, logits, targets, ignore_index, label_smoothing):
+    def forward(ctx, logits, targets, ignore_index, label_smoothing, raw=False):
+        """raw: return the (loss sum, count) pair instead of their ratio (hip.losses.combine forms the ratio with the other terms of a phase)."""
         core.require_gpu(logits, targets)
         if logits.dtype != torch.float32 or logits.stride(1) != 1 or logits.stride(0) % 4 != 0 or logits.data_ptr() % 16 != 0:
             # rows must start 16-byte aligned: copy into a padded pitch (never taken for the 30524-entry vocabulary)
@@ -286,24 +287,24 @@ class _SoftmaxXentFn(torch.autograd.Function):
                                                          ctypes.c_void_p(acc.data_ptr()), ctypes.c_void_p(acc.data_ptr() + 4), rows, V,
                                                          ignore_index, label_smoothing, core.stream()), 'softmax_xent_fwd')
         ctx.save_for_backward(logits, targets, lse, acc)
-        ctx.cfg = (ignore_index, label_smoothing)
-        return acc[0] / acc[1]
+        ctx.cfg = (ignore_index, label_smoothing, raw)
+        return acc if raw else acc[0] / acc[1]
 
     @staticmethod
     def backward(ctx, g):
         logits, targets, lse, acc = ctx.saved_tensors
-        ignore_index, label_smoothing = ctx.cfg
+        ignore_index, label_smoothing, raw = ctx.cfg
         rows, V = logits.shape
-        g = g.to(torch.float32).contiguous()
+        g = g.to(torch.float32).contiguous()        # (raw: g[0] is the gradient of the loss sum / count ratio's numerator side, see hip.losses)
         dx = torch.empty((rows, logits.stride(0)), device=logits.device, dtype=torch.float32)[:, :V]   # same (padded) row pitch
         core.check(core.lib().ldetr_softmax_xent_bwd_f32(core.ptr(logits), logits.stride(0), core.ptr(targets), core.ptr(lse),
                                                          ctypes.c_void_p(acc.data_ptr() + 4), core.ptr(g), core.ptr(dx), dx.stride(0), rows, V,
                                                          ignore_index, label_smoothing, core.stream()), 'softmax_xent_bwd')
-        return dx, None, None, None
+        return dx, None, None, None, None
 
 
-def softmax_cross_entropy(logits, targets, ignore_index=-100, label_smoothing=0.0):
-    return _SoftmaxXentFn.apply(logits, targets, ignore_index, label_smoothing)
+def softmax_cross_entropy(logits, targets, ignore_index=-100, label_smoothing=0.0, raw=False):
+    return _SoftmaxXentFn.apply(logits, targets, ignore_index, label_smoothing, raw)
 
 
 def _layer_train(layer, x2, B, T, kpm, causal):

@@ -308,10 +308,14 @@ class Generator(nn.Module):
 
         valid = ~padding_mask
         if self.static_shapes:
-            vf = valid.to(torch.float32)
-            cnt = vf.sum().clamp_min(1.0)
             z_rec = self.fc_z_rec(x)
-            loss_z = ((z_rec - z0.unsqueeze(1)).square().sum(-1) * vf).sum() / (cnt * z_rec.shape[-1])
+            if z_rec.is_cuda and not z0.requires_grad:
+                from ..hip.losses import masked_mse
+                loss_z = masked_mse(z_rec, z0, valid.to(torch.uint8), bdiv=N)      # F.mse_loss(z_rec[valid], z0 per sample): one launch per direction
+            else:
+                vf = valid.to(torch.float32)
+                cnt = vf.sum().clamp_min(1.0)
+                loss_z = ((z_rec - z0.unsqueeze(1)).square().sum(-1) * vf).sum() / (cnt * z_rec.shape[-1])
             logit_cls = self.fc_out_cls(x)                                   # [B, N, L]: every slot, masked by the caller
             loss_text_len = _masked_ce_static(self.fc_text_len_rec(x), text_len, valid)
             loss_lm = _lm_loss(self, bbox_text, padding_mask, B, N, True)

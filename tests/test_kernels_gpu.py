@@ -547,6 +547,54 @@ def test_split_bf16_non_finite_operands_match_f32_pipe_and_reference_sanitiser(d
         assert_close(pg.cpu()[big], pr.detach()[big], 1e-5, 'adam after sanitising a split-pipe gradient')
 
 
+# ------------------------------------------------------------------------------------------ loss tails (hip/losses.py)
+@pytest.mark.parametrize('B', [1, 2, 16, 300])
+def test_loss_combine_and_masked_mse_vs_torch_autograd(dev, B):
+    """hip.losses.combine (softplus(+-x) per-sample terms, per-sample shares of scalar terms, scalars, the cross-entropy (sum, count) pair; batch mean,
+    gain) and hip.losses.masked_mse against the reference's op chain (training/loss.py:195-213: F.softplus, weights, sum, .mean().mul(gain)) in
+    float64 autograd: total, every reported term and every gradient."""
+    from layoutdetr_amd.hip import losses as hl
+    torch.manual_seed(700 + B)
+    mk = lambda *s: torch.randn(*s, dtype=torch.float64)
+    logit, logit2 = mk(B) * 3, mk(B) * 30                    # (|x| > 20: softplus' threshold branch)
+    lay, sc, ce = mk(4, B).abs(), mk(()), torch.tensor([7.5, 3.0], dtype=torch.float64)
+    leaves = [t.clone().requires_grad_(True) for t in (logit, logit2, lay, sc, ce)]
+    gain, W = 0.5, [1.0, 1.0, 100.0, 4.0, 7.0, 17.0, 5.0, 50.0]
+    a, b, l4, s0, c2 = leaves
+    ref = {'p': F.softplus(-a) * W[0], 'q': F.softplus(b) * W[1], 'r': l4[0].sum() * W[2], 'g': l4[1].sum() * W[3], 'o': l4[2] * W[4], 'al': l4[3] * W[5],
+           's': s0 * W[6], 'c': c2[0] / c2[1] * W[7]}
+    tot_ref = sum(ref.values()).mean() * gain
+    tot_ref.backward()
+    gl = [t.detach().float().to(dev).requires_grad_(True) for t in (logit, logit2, lay, sc, ce)]
+    T = hl.Term
+    total, rep = hl.combine([T('p', gl[0], W[0], hl.SOFTPLUS_NEG), T('q', gl[1], W[1], hl.SOFTPLUS), T(['r', 'g', 'o', 'al'], gl[2], W[2:6], hl.IDENT, [True, True, False, False]),
+                             T('s', gl[3], W[6]), T('c', gl[4], W[7], hl.RATIO)], gain)
+    total.backward()
+    assert_close(total, tot_ref, 2e-6, 'total')
+    for k, v in ref.items():
+        assert_close(rep[k], v.detach(), 2e-6, 'term ' + k)
+    for name, g, r in zip(('d logit', 'd logit2', 'd layout', 'd scalar'), gl[:4], leaves[:4]):
+        assert_close(g.grad, r.grad, 2e-6, name)
+    # the ratio's gradient leaves undivided (the cross-entropy backward divides by its count): d total / d (sum / count) * 1
+    assert_close(gl[4].grad[0], leaves[4].grad[0] * ce[1], 2e-6, 'd ce sum'); assert float(gl[4].grad[1]) == 0.0
+    # masked mse: per-slot reference rows and one reference row per sample
+    N, D = 9, 36
+    x = mk(B, N, D); y = mk(B, N, D); z = mk(B, D); valid = torch.rand(B, N) > 0.3
+    if B == 1:
+        valid[:] = False                     # no valid slot at all: 0 / max(0, 1), zero gradient
+    for bref, bdiv in ((y, 1), (z, N)):
+        xr = x.clone().requires_grad_(True)
+        full = bref if bdiv == 1 else bref.unsqueeze(1).expand(-1, N, -1)
+        if valid.any():
+            lr = F.mse_loss(xr[valid], full[valid]); lr.backward()
+        else:
+            lr = torch.zeros((), dtype=torch.float64); xr.grad = torch.zeros_like(x)
+        xg = x.float().to(dev).requires_grad_(True)
+        lg = hl.masked_mse(xg, bref.float().to(dev), valid.to(dev).to(torch.uint8), bdiv=bdiv)
+        (lg * 3.0).backward()
+        assert_close(lg, lr.detach(), 2e-6, 'masked mse'); assert_close(xg.grad, xr.grad * 3.0, 2e-6, 'd masked mse')
+
+
 # ------------------------------------------------------------------------------------------ the short token stacks as one node (hip/stacks.py)
 def _randomise(mod, seed):
     g = torch.Generator().manual_seed(seed)
