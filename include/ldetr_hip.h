@@ -250,6 +250,10 @@ int ldetr_layernorm_bwd_f32(const float* dy, const float* z, const float* mean, 
                             float* dx, float* dresidual, float* dgamma, float* dbeta, int64_t rows, int D,
                             float p_drop, uint64_t seed, const uint64_t* seed_ptr, void* stream);
 
+/* Second stage of ldetr_torgb_bwd_f32 (ToRGBLayer backward, training/networks_stylegan2.py:349-353): dws [B][3][C] ->
+ * dw[o][c] += sum_b dws[b][o][c] s[b][c] (accumulated) and ds[b][c] = sum_o dws[b][o][c] w[o][c]. */
+int ldetr_torgb_bwd_finish_f32(const float* dws, const float* s, const float* w, int B, int C, float* dw, float* ds, void* stream);
+
 /* The tail of a loss phase (StyleGAN2Loss.accumulate_gradients, training/loss.py:84-116, 146-218: sum of ~10 weighted terms, .mean(), backward) as one
  * launch per direction: total = sum_k w[k] * c_k * sum_i f_k(x[k][i]), c_k = 1 / n[k] (red[k] = 0: a per-sample term that is averaged) or 1 (red[k] = 1:
  * per-sample contributions to a sum); fn[k]: 0 identity, 1 softplus(x), 2 softplus(-x) (F.softplus: threshold 20), 3 ratio x[0] / x[1] (n = 2: the

@@ -143,6 +143,7 @@ SIGNATURES = {
     'ldetr_loss_combine_bwd_f32': [_P, _P, _P, _P, _P, _I, _I, _P, _P, _P],
     'ldetr_masked_mse_fwd_f32': [_P, _P, _P, _L, _I, _I, _P, _P],
     'ldetr_masked_mse_bwd_f32': [_P, _P, _P, _L, _I, _I, _P, _P, _P, _P],
+    'ldetr_torgb_bwd_finish_f32': [_P, _P, _P, _I, _I, _P, _P, _P],
     'ldetr_gemm_pair_f32': [_P, _P, _P],
     'ldetr_gemm_pair_is_single_launch': [_P, _P],
     'ldetr_demod_fwd_f32': [_P, _L, _L, _L, _L, _P, _P, _P, _I, _I, _I, _I, _I, _F, _P],

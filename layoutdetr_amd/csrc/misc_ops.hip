@@ -316,6 +316,26 @@ __global__ __launch_bounds__(256) void torgb_bwd_kernel(RgbParams p) {
     }
 }
 
+// Second stage of the toRGB backward: dws [B][3][C] = per-sample sums of dy x (x unmodulated) ->
+//   dw[o][c] += sum_b dws[b][o][c] * s[b][c]   (accumulated: dw is the flat .grad view or a zero-filled temporary)
+//   ds[b][c]  = sum_o dws[b][o][c] * w[o][c]
+// (the reference's autograd forms both with broadcast multiplies and reductions: 4 launches + 2 accumulations per layer)
+__global__ __launch_bounds__(256) void torgb_finish_kernel(const float* __restrict__ dws, const float* __restrict__ s, const float* __restrict__ w,
+                                                           float* __restrict__ dw, float* __restrict__ ds, int B, int C) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < 3 * C) {
+        const int c = i % C;
+        float a = 0.f;
+        for (int b = 0; b < B; b++) a += dws[(long)b * 3 * C + i] * s[(long)b * C + c];
+        dw[i] += a;
+    }
+    if (i < B * C) {
+        const int b = i / C, c = i - b * C;
+        const float* d = dws + (long)b * 3 * C + c;
+        ds[i] = d[0] * w[c] + d[C] * w[C + c] + d[2 * C] * w[2 * C + c];
+    }
+}
+
 }  // namespace ldetr
 
 using namespace ldetr;
@@ -482,4 +502,11 @@ extern "C" int ldetr_torgb_bwd_f32(const float* x, const float* dy, const float*
     dim3 grid((unsigned)((P + rows_pb - 1) / rows_pb), B, cdiv(C4, TQ));
     hipLaunchKernelGGL(torgb_bwd_kernel, grid, 256, 0, (hipStream_t)stream, p);
     return check_launch("torgb_bwd");
+}
+
+extern "C" int ldetr_torgb_bwd_finish_f32(const float* dws, const float* s, const float* w, int B, int C, float* dw, float* ds, void* stream) {
+    LDETR_CHECK(dws && s && w && dw && ds && B > 0 && C > 0, "torgb_bwd_finish: bad arguments");
+    const int n = (B > 3 ? B : 3) * C;
+    hipLaunchKernelGGL(torgb_finish_kernel, dim3((unsigned)((n + 255) / 256)), 256, 0, (hipStream_t)stream, dws, s, w, dw, ds, B, C);
+    return check_launch("torgb_bwd_finish");
 }

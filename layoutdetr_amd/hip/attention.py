@@ -101,14 +101,17 @@ class _AttnPackedFn(torch.autograd.Function):
 
 
 def _kpm_u8(key_padding_mask):
-    return None if key_padding_mask is None else key_padding_mask.to(torch.uint8).contiguous()
+    """bool / uint8 key-padding mask -> contiguous uint8 (a contiguous bool mask is reinterpreted in place: one byte per element holding 0 / 1)."""
+    m = key_padding_mask
+    if m is None:
+        return None
+    if m.dtype == torch.bool:
+        return (m if m.is_contiguous() else m.contiguous()).view(torch.uint8)
+    return m.to(torch.uint8).contiguous()
 
 
 def attention(q, k, v, key_padding_mask, B, H, Lq, Lk, p_drop=0.0, kv_grad_dst=None):
-    kpm = None
-    if key_padding_mask is not None:
-        kpm = key_padding_mask.to(torch.uint8).contiguous()
-    return _AttnFn.apply(q, k, v, kpm, B, H, Lq, Lk, p_drop, kv_grad_dst)
+    return _AttnFn.apply(q, k, v, _kpm_u8(key_padding_mask), B, H, Lq, Lk, p_drop, kv_grad_dst)
 
 
 class _GroupedKVFn(torch.autograd.Function):
@@ -154,7 +157,7 @@ class _GroupedKVFn(torch.autograd.Function):
         dK, dV = ctx.holder.dK, ctx.holder.dV          # two packed [M, n d] buffers (the weight-gradient GEMM's row sums need a packed operand)
         fresh = dK is None
         if fresh:
-            dK = torch.zeros((M, nd), device=mp.device, dtype=torch.float32); dV = torch.zeros((M, nd), device=mp.device, dtype=torch.float32)
+            dK = core.zeros((M, nd), mp.device); dV = core.zeros((M, nd), mp.device)
         for i, g in enumerate(grads):      # blocks the attention backward wrote in place arrive as views of dK / dV: nothing to do for them
             dst = (dK if i < n else dV)[:, (i % n) * d:(i % n + 1) * d]
             if g is None:
@@ -169,7 +172,7 @@ class _GroupedKVFn(torch.autograd.Function):
         out = [None] * (2 * n)
         if need_w:
             T = torch.empty((2, nd, d), device=mp.device, dtype=torch.float32)
-            tb = torch.zeros((2, nd), device=mp.device, dtype=torch.float32)
+            tb = core.zeros((2, nd), mp.device)
             core.gemm(dK, mp, 1, 1, nd, d, M, out=T[0], ep=core.epilogue(a_rowsum=tb[0]))
             core.gemm(dV, mm, 1, 1, nd, d, M, out=T[1], ep=core.epilogue(a_rowsum=tb[1]))
             gws, gbs = [core.flat_grad(w) for w in Ws], [core.flat_grad(b) for b in bs]
@@ -214,8 +217,8 @@ def grouped_kv(mem_pos, mem, mhas):
     def dst(i):
         def views():
             if holder.dK is None:      # zero-filled: a layer whose attention backward never runs contributes nothing
-                holder.dK = torch.zeros((M, n * d), device=mem.device, dtype=torch.float32)
-                holder.dV = torch.zeros((M, n * d), device=mem.device, dtype=torch.float32)
+                holder.dK = core.zeros((M, n * d), mem.device)
+                holder.dV = core.zeros((M, n * d), mem.device)
             return holder.dK[:, i * d:(i + 1) * d], holder.dV[:, i * d:(i + 1) * d]
         return views
     return [(outs[i], outs[n + i], dst(i)) for i in range(n)]

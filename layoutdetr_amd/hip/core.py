@@ -247,10 +247,10 @@ def colsum(a2d, B=1):
     """a2d: [B*P, C] -> [B, C] column sums per group of P rows."""
     require_gpu(a2d)
     R, C = a2d.shape
-    red = torch.zeros((B, C), device=a2d.device, dtype=torch.float32)
     if C % 4 != 0:
         # tiny ragged widths (e.g. 3 RGB channels): host reduction of a [R, C] view
         return a2d.reshape(B, R // B, C).sum(1)
+    red = torch.zeros((B, C), device=a2d.device, dtype=torch.float32)      # (may be returned as a parameter gradient: never arena memory)
     check(lib().ldetr_colsum_f32(ptr(a2d), ptr(red), B, R // B, C, stream()), 'colsum')
     return red
 
@@ -262,6 +262,73 @@ def flat_grad(p):
     if isinstance(p, torch.nn.Parameter) and getattr(p, '_ldetr_flat', False) and p.grad is not None and not torch.is_grad_enabled():
         return p.grad
     return None
+
+
+class _ZeroArena(object):
+    """Small zero-filled accumulation targets (bias / style / demodulation row sums, attention gradient buffers: ~70 `torch.zeros` per iteration,
+    one fill launch each) carved from ONE buffer that a single launch re-zeroes at the start of every loss phase (zero_arena_begin, called by
+    StyleGAN2Loss.accumulate_gradients).  Only for tensors that die inside the phase that took them and are never handed to autograd as a
+    PARAMETER gradient (AccumulateGrad may adopt such a tensor as .grad without copying); without an open phase, during a stream
+    capture that found the arena unallocated, or when the arena is full, `zeros` is plain torch.zeros."""
+
+    def __init__(self):
+        self.buf = {}          # device index -> (tensor, capacity in floats)
+        self.cursor = 0
+        self.high = {}         # device index -> floats handed out in the largest phase so far (what begin() re-zeroes, + slack)
+        self.open = None       # device index of the open phase
+
+    def begin(self, device):
+        dev = device.index if device.index is not None else torch.cuda.current_device()
+        self.open = None
+        if dev not in self.buf:
+            if torch.cuda.is_current_stream_capturing():
+                return                      # (allocated outside captures only: a capture's pool must not own a buffer that outlives its graph)
+            cap = 1 << 22                   # 16 MiB
+            self.buf[dev] = (torch.zeros(cap, device=torch.device('cuda', dev), dtype=torch.float32), cap)
+            self.high[dev] = 0
+        buf, cap = self.buf[dev]
+        n = min(cap, max(self.high[dev] * 2, 1 << 16))
+        buf[:n].zero_()
+        self.limit, self.cursor, self.open = n, 0, dev
+
+    def take(self, shape, device):
+        dev = device.index if device.index is not None else torch.cuda.current_device()
+        if self.open != dev:
+            return None
+        n = 1
+        for d in shape:
+            n *= int(d)
+        pad = (n + 3) // 4 * 4
+        if self.cursor + pad > self.limit:
+            self.high[dev] = max(self.high[dev], self.cursor + pad)      # the next phase zeroes more
+            return None
+        out = self.buf[dev][0][self.cursor:self.cursor + n].view(shape)
+        self.cursor += pad
+        self.high[dev] = max(self.high[dev], self.cursor)
+        return out
+
+    def end(self):
+        self.open = None
+
+
+ZERO_ARENA = _ZeroArena()
+_ZERO_ARENA_ON = os.environ.get('LDETR_ZERO_ARENA', '1') != '0'
+
+
+def zero_arena_begin(device):
+    if _ZERO_ARENA_ON:
+        ZERO_ARENA.begin(torch.device(device))
+
+
+def zero_arena_end():
+    ZERO_ARENA.end()
+
+
+def zeros(shape, device):
+    """fp32 zeros for an accumulation target that dies inside the current loss phase (see _ZeroArena)."""
+    device = torch.device(device)
+    t = ZERO_ARENA.take(tuple(shape), device) if device.type == 'cuda' else None
+    return t if t is not None else torch.zeros(shape, device=device, dtype=torch.float32)
 
 
 def pick_splitk(tiles, K, target=512, min_k=256):

@@ -31,8 +31,8 @@ def act_backward(dy2, y2, act, act_alpha, act_gain, want_dbias, bias=None, demod
     if want_dbias and dbias_out is not None:
         dbias = dbias_out
     else:
-        dbias = torch.zeros(C, device=dy2.device, dtype=torch.float32) if want_dbias else None
-    ddemod = torch.zeros((B, C), device=dy2.device, dtype=torch.float32) if want_ddemod else None
+        dbias = torch.zeros(C, device=dy2.device, dtype=torch.float32) if want_dbias else None      # (returned to autograd as a parameter gradient: never arena memory)
+    ddemod = core.zeros((B, C), dy2.device) if want_ddemod else None
     core.check(core.lib().ldetr_act_bwd_reduce_f32(
         core.ptr(dy2), core.ptr(y2), core.ptr(dv), core.ptr(bias), core.ptr(demod), core.ptr(dbias), core.ptr(ddemod),
         B, R // B, C, act, act_alpha, act_gain, core.stream()), 'act_bwd_reduce')

@@ -23,7 +23,7 @@ from ..torch_utils.ops import upfirdn2d as _up
 
 def _mul_reduce(a, x, scale, B, P, C, want_out=True):
     out = torch.empty_like(a) if want_out else None
-    red = torch.zeros((B, C), device=a.device, dtype=torch.float32)
+    red = core.zeros((B, C), a.device)
     core.check(core.lib().ldetr_mul_reduce_f32(core.ptr(a), core.ptr(x), core.ptr(scale), core.ptr(out), core.ptr(red),
                                                B, P, C, core.stream()), 'mul_reduce')
     return out, red
@@ -171,6 +171,7 @@ class _ToRGBFn(torch.autograd.Function):
                                                        core.ptr(s), s.stride(0), ctypes.byref(ep), core.stream()), 'torgb_fwd'), operands=(x, y, w))
         ctx.save_for_backward(x, w, s)
         ctx.wshape = weight.shape
+        ctx.params = (weight, bias)
         return y
 
     @staticmethod
@@ -182,13 +183,19 @@ class _ToRGBFn(torch.autograd.Function):
             raise NotImplementedError('toRGB backward kernel is specialised for 3 colour channels')
         dy = core.f32c(dy)
         dx = torch.empty_like(x)
-        dws = torch.zeros((B, O, C), device=x.device, dtype=torch.float32)
-        dbias = torch.zeros(O, device=x.device, dtype=torch.float32)
+        dws = core.zeros((B, O, C), x.device)
+        # weight / bias gradients go straight into the flat .grad views when there are any (atomics / += in the kernels): no temporaries, no
+        # AccumulateGrad launches; ds and dw come out of one finish launch instead of two broadcast multiplies + two reductions
+        wparam, bparam = ctx.params
+        gw, gb = core.flat_grad(wparam), core.flat_grad(bparam)
+        gw = gw.reshape(O, C) if (gw is not None and gw.is_contiguous()) else None
+        dbias = gb if gb is not None else torch.zeros(O, device=x.device, dtype=torch.float32)
+        dw = gw if gw is not None else torch.zeros((O, C), device=x.device, dtype=torch.float32)
+        ds = torch.empty((B, C), device=x.device, dtype=torch.float32)
         core.check(core.lib().ldetr_torgb_bwd_f32(core.ptr(x), core.ptr(dy), core.ptr(w), core.ptr(s), core.ptr(dx), core.ptr(dws),
                                                   core.ptr(dbias), B, H * W, C, core.stream()), 'torgb_bwd')
-        dw = (dws * s.unsqueeze(1)).sum(0).reshape(ctx.wshape)
-        ds = (dws * w.unsqueeze(0)).sum(1)
-        return dx, dw, ds, dbias
+        core.check(core.lib().ldetr_torgb_bwd_finish_f32(core.ptr(dws), core.ptr(s), core.ptr(w), B, C, core.ptr(dw), core.ptr(ds), core.stream()), 'torgb_bwd_finish')
+        return dx, (None if gw is not None else dw.reshape(ctx.wshape)), ds, (None if gb is not None else dbias)
 
 
 class _DemodFn(torch.autograd.Function):

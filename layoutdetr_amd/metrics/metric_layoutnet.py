@@ -69,7 +69,7 @@ class _LayoutLossesFn(torch.autograd.Function):
         B, N, _ = bbox.shape
         x = bbox.detach().to(torch.float32).contiguous()
         r = bbox_ref.detach().to(torch.float32).contiguous()
-        v = valid.to(torch.uint8).contiguous()
+        v = valid.contiguous().view(torch.uint8) if valid.dtype == torch.bool else valid.to(torch.uint8).contiguous()
         losses = torch.empty((4, B), device=x.device, dtype=torch.float32)
         grads = torch.empty((4, B, N, 4), device=x.device, dtype=torch.float32)
         core.check(core.lib().ldetr_layout_losses_f32(core.ptr(x), core.ptr(r), core.ptr(v), B, N, core.ptr(losses), core.ptr(grads),

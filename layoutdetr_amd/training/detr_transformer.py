@@ -39,34 +39,14 @@ def _mha(m: nn.MultiheadAttention, q2, k2, v2, B, Lq, Lk, kpm, training, same_qk
 
 _GROUP_KV = os.environ.get('LDETR_GROUP_KV', '1') != '0'
 
-_mask_scope = [None]     # dict while a Generator / Discriminator forward is running (mask_scope()), else None
-
-
-class mask_scope(object):
-    """Within one G / D forward the same key-padding mask reaches several transformer stacks (D runs four): inside this scope
-    `_mask_u8` converts each distinct mask tensor once.  The scope dies with the forward call, so nothing is carried across
-    iterations, hipGraph captures or in-place edits of the mask."""
-
-    def __enter__(self):
-        self.prev, _mask_scope[0] = _mask_scope[0], {}
-        return self
-
-    def __exit__(self, *exc):
-        _mask_scope[0] = self.prev
-
-
 def _mask_u8(kpm):
-    """bool key-padding mask -> the uint8 form the attention kernels read (no-op when already converted)."""
+    """bool key-padding mask -> the uint8 form the attention kernels read: a torch.bool tensor is one byte per element holding 0 / 1, so a
+    contiguous mask is reinterpreted in place (no launch); only a strided one is copied."""
     if kpm is None or kpm.dtype == torch.uint8:
         return kpm
-    memo = _mask_scope[0]
-    if memo is None:
-        return kpm.to(torch.uint8).contiguous()
-    key = (kpm.data_ptr(), tuple(kpm.shape), tuple(kpm.stride()))
-    hit = memo.get(key)
-    if hit is None:
-        hit = memo[key] = (kpm, kpm.to(torch.uint8).contiguous())     # the source is kept alive with its conversion: no address reuse inside the scope
-    return hit[1]
+    if kpm.dtype == torch.bool:
+        return (kpm if kpm.is_contiguous() else kpm.contiguous()).view(torch.uint8)
+    return kpm.to(torch.uint8).contiguous()
 
 
 def _ffn(layer, x2):

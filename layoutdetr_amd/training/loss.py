@@ -17,7 +17,7 @@ from ..metrics.metric_layoutnet import compute_alignment, compute_overlap, gener
 def _masked_mse(a, b, valid):
     """F.mse_loss(a[valid], b[valid]) without the gather: a, b [B,N,D], valid [B,N] bool."""
     if a.is_cuda and a.dtype == torch.float32 and not b.requires_grad:
-        return hl.masked_mse(a, b, valid.to(torch.uint8))      # one launch per direction (csrc/layout_loss.hip) instead of ~9 + ~12
+        return hl.masked_mse(a, b, valid.contiguous().view(torch.uint8))      # one launch per direction (csrc/layout_loss.hip) instead of ~9 + ~12
     vf = valid.to(a.dtype)
     return ((a - b).square().sum(-1) * vf).sum() / (vf.sum().clamp_min(1.0) * a.shape[-1])
 
@@ -316,11 +316,15 @@ class StyleGAN2Loss(Loss):
         # A trunk evaluation parked for this call (detr_backbone.ResNet50Body.injected, keyed by the batch's address) must not outlive it: after a miss
         # or an exception a later batch at the same address would otherwise be served stale features.  (Iteration-level sharing parks G's trunks of
         # ALL micro-batches before Gmain: those stay until the phase after Gmain begins, see above.)
+        if isinstance(background, torch.Tensor) and background.is_cuda:
+            core.zero_arena_begin(background.device)      # one fill for the phase's small accumulation targets (hip.core._ZeroArena)
         try:
             self._run_phase(phase, bbox_real, bbox_class, bbox_text, bbox_patch, padding_mask, background, real_c, gen_z, gen_c, gain)
         except BaseException:
             self._drop_parked_trunks()
             raise
+        finally:
+            core.zero_arena_end()
         if self.share_D_trunk != 'iteration' or phase != 'Gmain':
             self._drop_parked_trunks()
 

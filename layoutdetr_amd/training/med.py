@@ -282,7 +282,7 @@ class _SoftmaxXentFn(torch.autograd.Function):
         targets = targets.to(torch.int64).contiguous()
         rows, V = logits.shape
         lse = torch.empty(rows, device=logits.device, dtype=torch.float32)
-        acc = torch.zeros(2, device=logits.device, dtype=torch.float32)      # [loss_sum, count]
+        acc = core.zeros((2,), logits.device)      # [loss_sum, count]
         core.check(core.lib().ldetr_softmax_xent_fwd_f32(core.ptr(logits), logits.stride(0), core.ptr(targets), core.ptr(lse),
                                                          ctypes.c_void_p(acc.data_ptr()), ctypes.c_void_p(acc.data_ptr() + 4), rows, V,
                                                          ignore_index, label_smoothing, core.stream()), 'softmax_xent_fwd')

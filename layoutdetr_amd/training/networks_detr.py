@@ -33,7 +33,7 @@ from ..hip import core
 from ..hip.linear import linear
 from .detr_backbone import Backbone, Joiner
 from .detr_position_encoding import PositionEmbeddingSine
-from .detr_transformer import Transformer, TransformerEncoder, TransformerEncoderLayer, TransformerWithToken, mask_scope
+from .detr_transformer import Transformer, TransformerEncoder, TransformerEncoderLayer, TransformerWithToken
 from .networks_stylegan2 import Decoder
 from .util import TransformerWithToken_layoutganpp, encode_seq_first, encode_seq_first_pair
 
@@ -281,10 +281,6 @@ class Generator(nn.Module):
         self.fc_text_len_rec = Linear(hidden_dim, max_text_length)
 
     def forward(self, z, bbox_class, bbox_real, bbox_text, bbox_patch, padding_mask, background, c, reconst=False):
-        with mask_scope():
-            return self._forward(z, bbox_class, bbox_real, bbox_text, bbox_patch, padding_mask, background, c, reconst)
-
-    def _forward(self, z, bbox_class, bbox_real, bbox_text, bbox_patch, padding_mask, background, c, reconst=False):
         if isinstance(background, (list, torch.Tensor)):
             background = nested_tensor_from_tensor_list(background)
         bg_feat, pos = self.backbone(background)
@@ -311,7 +307,7 @@ class Generator(nn.Module):
             z_rec = self.fc_z_rec(x)
             if z_rec.is_cuda and not z0.requires_grad:
                 from ..hip.losses import masked_mse
-                loss_z = masked_mse(z_rec, z0, valid.to(torch.uint8), bdiv=N)      # F.mse_loss(z_rec[valid], z0 per sample): one launch per direction
+                loss_z = masked_mse(z_rec, z0, valid.contiguous().view(torch.uint8), bdiv=N)      # F.mse_loss(z_rec[valid], z0 per sample): one launch per direction
             else:
                 vf = valid.to(torch.float32)
                 cnt = vf.sum().clamp_min(1.0)
@@ -442,10 +438,6 @@ class Discriminator(nn.Module):
         return bbox_pred, logit_cls, loss_lm, loss_text_len, bg_rec, bbox_pred_uncond, logit_cls_uncond
 
     def forward(self, bbox, bbox_class, bbox_text, bbox_patch, padding_mask, background, c, reconst=False, trunk_out=None):
-        with mask_scope():
-            return self._forward(bbox, bbox_class, bbox_text, bbox_patch, padding_mask, background, c, reconst, trunk_out)
-
-    def _forward(self, bbox, bbox_class, bbox_text, bbox_patch, padding_mask, background, c, reconst=False, trunk_out=None):
         bg_feat, pos = self.trunk(background) if trunk_out is None else trunk_out
         bg_feat, mask = bg_feat[-1].decompose()
         assert mask is not None
@@ -461,11 +453,7 @@ class Discriminator(nn.Module):
             return logit_disc, logit_disc_uncond
         return (logit_disc, logit_disc_uncond) + self._reconstruct(x0, x0_uncond, bbox_text, text_len, padding_mask, B, N)
 
-    def forward_pair(self, *args, **kwargs):
-        with mask_scope():
-            return self._forward_pair(*args, **kwargs)
-
-    def _forward_pair(self, bbox_fake, bbox_real, bbox_class, bbox_text, bbox_patch, padding_mask, background, c, trunk_out=None):
+    def forward_pair(self, bbox_fake, bbox_real, bbox_class, bbox_text, bbox_patch, padding_mask, background, c, trunk_out=None):
         """D(bbox_fake) and D(bbox_real, reconst=True) of the SAME layouts' conditions in one pass — what phase Dmain evaluates with two
         calls (training/loss.py:149,165).  The samples of a batch are independent (FrozenBatchNorm, no batch statistics), so the two
         score paths run as ONE batch of 2B layouts: trunk, input_proj, label / text embeddings and the text encoder are evaluated
