@@ -316,11 +316,32 @@ __device__ __forceinline__ void p3_nt_koff(const P3NtParams& p, int tap, int cc,
 // from L2-resident operands whatever the access shape, plain buffer_load_dwordx4 + ds_write_b128 moves 105-220 GB/s per CU, and every
 // DMA-fed version of this kernel sat exactly on the first figure.  (Free functions: hipcc drops the host stub of a kernel template whose
 // lambda captures mutable locals next to buffer builtins.)
-template <int BM, int BN, int NW>
+template <int BM, int BN, int NW, bool ONE>
 __device__ __forceinline__ void p3_load_tile(const P3NtParams& p, const __amdgpu_buffer_rsrc_t rsA, const __amdgpu_buffer_rsrc_t rsB,
                                              const unsigned* offA, const unsigned* vmA, const unsigned* offB, int& tap, int& cc, int ktpt, bool live,
                                              ld128_t* ra, ld128_t* rb) {
     constexpr int RGA = BM / 16 / NW, RGB = BN / 16 / NW;
+    if constexpr (ONE) {
+        // 1x1 convolution = plain GEMM over contiguous P3 rows: no tap walk, no per-row validity masks (rows past M carry an out-of-range offset
+        // from the start); k-tile `cc` of either operand sits cc * 192 bytes into its row (one s_mul per k-tile).  A dead tile is an out-of-range
+        // VECTOR offset (the descriptor's range check does not cover the scalar offset): one v_cndmask per row group
+        const int so = cc * 192;
+        ++cc;      // (unconditionally: a dead tile's offset is irrelevant, and a `live`-dependent update would put the counter into a VGPR -- the loads' scalar
+        //           offset then needs a readfirstlane loop each)
+#pragma unroll
+        for (int i = 0; i < RGA; i++) {
+            const unsigned vo = live ? offA[i] : 0x80000000u;
+#pragma unroll
+            for (int j = 0; j < 3; j++) ra[i * 3 + j] = __builtin_amdgcn_raw_buffer_load_b128(rsA, vo, so + j * 64, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < RGB; i++) {
+            const unsigned vo = live ? offB[i] : 0x80000000u;
+#pragma unroll
+            for (int j = 0; j < 3; j++) rb[i * 3 + j] = __builtin_amdgcn_raw_buffer_load_b128(rsB, vo, so + j * 64, 0);
+        }
+        return;
+    }
     // live = false: a k-tile past the end of the slice.  Its loads are still issued (out-of-range offsets: zeros, no memory traffic) so that every
     // iteration of the k-loop issues the same number of loads and the compiler's vmcnt waits stay exact (a conditional load would make the
     // wait before each LDS store cover the whole prefetch queue).
@@ -359,7 +380,7 @@ __device__ __forceinline__ void p3_store_tile(char* sb, int w, int lane, const l
 // the iteration's one barrier and its registers take tile t+1+PF.  What bounds these launches is bytes in flight per CU over the load latency
 // (profiles/r04_pmc_sq.txt: matrix pipe 22-26 % busy on the 1x1 shapes with ONE tile in flight; 12 waves x 6 KiB / ~1.5 us = the ~50 GB/s per
 // CU every earlier variant sat on), so the depth is what the register file allows at the tile's occupancy.
-template <int BM, int BN, int NW, int PF, int NST, bool GROUPS>
+template <int BM, int BN, int NW, int PF, int NST, bool GROUPS, bool ONE = false>
 __device__ __forceinline__ void p3_nt_body(P3NtParams p, const P3Group2& g2, const int bx, const int by, const int bz) {   // (bx, by, bz): the block's place in the (tiles, k-slices, parity classes) grid
     constexpr int NT = NW * 64;   // NST = LDS stages: 2 = one barrier per k-tile; 1 = two barriers, half the LDS (more blocks per CU)
     constexpr int WGN = (NW == 8 && BN >= 128) ? 4 : 2, WGM = NW / WGN;
@@ -409,7 +430,7 @@ __device__ __forceinline__ void p3_nt_body(P3NtParams p, const P3Group2& g2, con
     for (int i = 0; i < RGA; i++) {
         unsigned vm, off;
         p3_nt_row(p, m0 + (w * RGA + i) * 16 + rr, off, vm);
-        offA[i] = off + pq * 16; vmA[i] = vm;
+        offA[i] = (ONE && vm == 0u) ? 0x80000000u : off + pq * 16; vmA[i] = vm;
     }
 #pragma unroll
     for (int i = 0; i < RGB; i++) {
@@ -418,7 +439,7 @@ __device__ __forceinline__ void p3_nt_body(P3NtParams p, const P3Group2& g2, con
     }
 
     // uniform walk over (tap, channel tile)
-    int tap = kt0 / ktpt, cc = kt0 - tap * ktpt;          // next k-tile to issue
+    int tap = ONE ? 0 : kt0 / ktpt, cc = kt0 - tap * ktpt;          // next k-tile to issue (ONE: cc counts k-tiles from the row start)
 
     // ---- fragment read offsets: piece e = 3*(2s + kl) + plane -> 64-byte slice e / 4, slot (e % 4) ^ swizzle(row)
     const int frr = cl & 15, frg = cl >> 4;               // row within its 16-row group, group within the 32-row block
@@ -443,7 +464,7 @@ __device__ __forceinline__ void p3_nt_body(P3NtParams p, const P3Group2& g2, con
     const int nloc = kt1 - kt0;
     ld128_t ra[PF][RGA * 3], rb[PF][RGB * 3];
 #pragma unroll
-    for (int d = 0; d < PF; d++) p3_load_tile<BM, BN, NW>(p, rsA, rsB, offA, vmA, offB, tap, cc, ktpt, d < nloc, ra[d], rb[d]);
+    for (int d = 0; d < PF; d++) p3_load_tile<BM, BN, NW, ONE>(p, rsA, rsB, offA, vmA, offB, tap, cc, ktpt, d < nloc, ra[d], rb[d]);
     if (nloc > 0) p3_store_tile<BM, BN, NW>(p3_smem, w, lane, ra[0], rb[0]);
     __syncthreads();
     for (int it0 = 0; it0 < nloc; it0 += PF) {
@@ -451,7 +472,9 @@ __device__ __forceinline__ void p3_nt_body(P3NtParams p, const P3Group2& g2, con
         for (int d = 0; d < PF; d++) {
             const int it = it0 + d;
             // tile `it` went from ra[d] to LDS before the last barrier: its registers take tile it + PF
-            p3_load_tile<BM, BN, NW>(p, rsA, rsB, offA, vmA, offB, tap, cc, ktpt, it + PF < nloc, ra[d], rb[d]);
+            p3_load_tile<BM, BN, NW, ONE>(p, rsA, rsB, offA, vmA, offB, tap, cc, ktpt, it + PF < nloc, ra[d], rb[d]);
+            __builtin_amdgcn_sched_barrier(0);      // pin the next tile's loads ahead of this tile's MFMAs: left alone, the scheduler sinks them behind the fragment reads (their registers are
+            //                                         then shared with the fragments) and every k-tile waits out its own load latency
             if (it < nloc) {
                 const char* sb = p3_smem + (it % NST) * ST_BYTES;
 #pragma unroll
@@ -524,8 +547,8 @@ __device__ __forceinline__ void p3_nt_body(P3NtParams p, const P3Group2& g2, con
     });
 }
 
-template <int BM, int BN, int NW, int PF, int NST>
-__global__ __launch_bounds__(NW * 64) void p3_nt_kernel(P3NtParams p, P3Group2 g2) { p3_nt_body<BM, BN, NW, PF, NST, true>(p, g2, blockIdx.x, blockIdx.y, blockIdx.z); }
+template <int BM, int BN, int NW, int PF, int NST, bool ONE = false>
+__global__ __launch_bounds__(NW * 64) void p3_nt_kernel(P3NtParams p, P3Group2 g2) { p3_nt_body<BM, BN, NW, PF, NST, true, ONE>(p, g2, blockIdx.x, blockIdx.y, blockIdx.z); }
 
 // ---------------------------------------------------------------------------------------------
 // p3_c3_kernel: 3x3 / stride 1 / pad 1 convolutions (forward, and the data gradient as the same conv with mirrored taps) on 2-D pixel
@@ -1005,7 +1028,7 @@ __device__ __forceinline__ bool p3_pair_split(int b, int n_tn8, int& idx) {
     return false;
 }
 
-template <int BM, int BN, int NST>
+template <int BM, int BN, int NST, bool ONE = false>
 __global__ __launch_bounds__(256) void p3_bwd_pair_nt_kernel(P3NtParams pn, P3TnParams pt, int n_tn, int n_tn8, int tn_sk, int nt_gx, int nt_sk) {
     int idx;
     if (p3_pair_split(blockIdx.x, n_tn8, idx)) {
@@ -1013,7 +1036,7 @@ __global__ __launch_bounds__(256) void p3_bwd_pair_nt_kernel(P3NtParams pn, P3Tn
         return;
     }
     P3Group2 none;   // (never read: GROUPS = false)
-    p3_nt_body<BM, BN, 4, 1, NST, false>(pn, none, idx % nt_gx, (idx / nt_gx) % nt_sk, idx / (nt_gx * nt_sk));
+    p3_nt_body<BM, BN, 4, 1, NST, false, ONE>(pn, none, idx % nt_gx, (idx / nt_gx) % nt_sk, idx / (nt_gx * nt_sk));
 }
 
 __global__ __launch_bounds__(256, 2) void p3_bwd_pair_c3_kernel(P3C3Params pc, P3TnParams pt, int n_tn, int n_tn8, int tn_sk, int c3_gx) {
@@ -1192,9 +1215,23 @@ static int nt_splitk(const P3NtParams& p, int bm, int bn, long slots) {
     return force_sk > 0 ? force_sk : sk;
 }
 
+// 1x1 convolution without parity classes (forward incl. the strided downsample convs, stride-1 data gradients): the gather kernel's plain-GEMM loop
+static bool nt_is_plain_gemm(const P3NtParams& p) { return p.KH * p.KW == 1 && p.pad == 0 && p.nclass <= 1 && (p.tap_mode == 0 || p.stride == 1); }
+
 template <int BM, int BN, int NW, int PF, int NST>
 static int launch_nt_cfg(P3NtParams& p, const P3Group2& g2, int sk, hipStream_t st) {
     const NtGrid g = plan_nt<BM, BN, NW, NST>(p, sk);
+    if constexpr (PF == 1 && NST == 1 && (BM == BN) && (NW == 4 ? BM == 64 : BM == 128)) {
+        if (nt_is_plain_gemm(p)) {
+            auto kern1 = p3_nt_kernel<BM, BN, NW, PF, NST, true>;
+            static RaisedPerDevice raised1;
+            if (!raise_lds(reinterpret_cast<const void*>(kern1), g.lds, "p3_nt", raised1)) return LDETR_ERR_LAUNCH;
+            hipLaunchKernelGGL(kern1, dim3((unsigned)g.gx, g.sk, g.ncls), NW * 64, g.lds, st, p, g2);
+            t_last = {1, BM, BN, NW, g.sk, p.xm, p.xn, g.ncls, 0, g.gx};
+            note_engine_launch(true);
+            return check_launch("p3_nt");
+        }
+    }
     auto kern = p3_nt_kernel<BM, BN, NW, PF, NST>;
     static RaisedPerDevice raised;
     if (!raise_lds(reinterpret_cast<const void*>(kern), g.lds, "p3_nt", raised)) return LDETR_ERR_LAUNCH;
@@ -1546,8 +1583,12 @@ extern "C" int ldetr_p3_conv2d_bwd_pair(const void* dy, int N, int OH, int OW, i
         } else {
             const NtGrid g = plan_nt<64, 64, 4, 1>(pn, nt_splitk(pn, 64, 64, slot_target(nt_flops(pn), 512)));
             const size_t lds = g.lds > lds_tn ? g.lds : lds_tn;
-            hipLaunchKernelGGL((p3_bwd_pair_nt_kernel<64, 64, 1>), dim3((unsigned)(n_tn_pad + g.gx * g.sk * g.ncls)), 256, lds, st, pn, pt, (int)n_tn, (int)(n_tn_pad / 8), pt.splitk,
-                               (int)g.gx, g.sk);
+            if (nt_is_plain_gemm(pn))
+                hipLaunchKernelGGL((p3_bwd_pair_nt_kernel<64, 64, 1, true>), dim3((unsigned)(n_tn_pad + g.gx * g.sk * g.ncls)), 256, lds, st, pn, pt, (int)n_tn, (int)(n_tn_pad / 8), pt.splitk,
+                                   (int)g.gx, g.sk);
+            else
+                hipLaunchKernelGGL((p3_bwd_pair_nt_kernel<64, 64, 1>), dim3((unsigned)(n_tn_pad + g.gx * g.sk * g.ncls)), 256, lds, st, pn, pt, (int)n_tn, (int)(n_tn_pad / 8), pt.splitk,
+                                   (int)g.gx, g.sk);
             t_last = {4, 64, 64, 4, g.sk, pn.xm, pn.xn, g.ncls, pt.splitk, n_tn_pad + g.gx * g.sk * g.ncls};
         }
         note_engine_launch(true);

@@ -1,15 +1,16 @@
 #!/bin/bash
-# Development aid: build a variant of the kernel library from an alternative gemm_conv.hip (the slow file) next to the production one:
-#   tools/build_variant.sh <name> <path/to/gemm_conv_variant.hip>  ->  layoutdetr_amd/lib/variants/libldetr_hip_<name>.so
-# Select it at run time with LDETR_LIB=<that path> (layoutdetr_amd/_lib.py).  The other objects are the production build's.
+# Development aid: build a variant of the kernel library with one source file compiled differently (other source / extra -D flags), next to the
+# production one:  tools/build_variant.sh <name> <source.hip in csrc/ or a path> [extra hipcc flags...]
+#   -> layoutdetr_amd/lib/variants/libldetr_hip_<name>.so ; select it at run time with LDETR_LIB=<that path> (layoutdetr_amd/_lib.py).
+# The other objects are the production build's (run `python -m layoutdetr_amd.build` first).
 set -e
-name=$1; src=$2
+name=$1; src=$2; shift 2
 root=$(cd "$(dirname "$0")/.." && pwd)
+[ -f "$src" ] || src=$root/layoutdetr_amd/csrc/$src
+base=$(basename $src)
 out=$root/layoutdetr_amd/lib/variants; mkdir -p $out /tmp/ldetr_var_$name
-cp $src $root/layoutdetr_amd/csrc/.variant_$name.hip
-hipcc -DLDETR_TILE_TRACE=0 -O3 -std=c++17 -fPIC --offload-arch=gfx950 -munsafe-fp-atomics -fno-gpu-rdc -Wno-unused-result \
-  -Rpass-analysis=kernel-resource-usage -x hip -c $root/layoutdetr_amd/csrc/.variant_$name.hip -o /tmp/ldetr_var_$name/gemm_conv.o 2> $out/$name.remarks.txt
-rm -f $root/layoutdetr_amd/csrc/.variant_$name.hip
-objs=$(ls $root/layoutdetr_amd/lib/obj/*.o | grep -v gemm_conv)
-hipcc -shared -fPIC --offload-arch=gfx950 -fno-gpu-rdc -o $out/libldetr_hip_$name.so $objs /tmp/ldetr_var_$name/gemm_conv.o
+hipcc -DLDETR_TILE_TRACE=0 -O3 -std=c++17 -fPIC --offload-arch=gfx950 -munsafe-fp-atomics -fno-gpu-rdc -Wno-unused-result "$@" \
+  -I$root/layoutdetr_amd/csrc -Rpass-analysis=kernel-resource-usage -x hip -c $src -o /tmp/ldetr_var_$name/$base.o 2> $out/$name.remarks.txt
+objs=$(ls $root/layoutdetr_amd/lib/obj/*.o | grep -v "/$base.o")
+hipcc -shared -fPIC --offload-arch=gfx950 -fno-gpu-rdc -o $out/libldetr_hip_$name.so $objs /tmp/ldetr_var_$name/$base.o
 echo built $out/libldetr_hip_$name.so
