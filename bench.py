@@ -65,12 +65,28 @@ def to_device_batch(bt, device, text_mode='features', text_tokens=40):
                 real_c=torch.zeros(b, 0, device=device), gen_c=torch.zeros(b, 0, device=device))
 
 
-def cpu_baseline(G_sd, D_sd, G_names, D_names, bg, budget_s=25.0):
-    """The oracle (a CPU port of the same step) on the host cores, bounded sample: the headline's batch 16 when one warm-up + one timed
-    iteration fit the budget, else batch 2 (and the unit says so)."""
+def _host_cpu():
+    """(logical cores visible to this process, CPU model string) of the box."""
+    nproc = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    model = 'unknown'
+    try:
+        with open('/proc/cpuinfo') as fh:
+            for line in fh:
+                if line.lower().startswith('model name'):
+                    model = line.split(':', 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    return nproc, model
+
+
+def cpu_baseline(G_sd, D_sd, G_names, D_names, bg, budget_s=34.0):
+    """The oracle (a CPU port of the same step) on the host cores, bounded sample: the headline's batch 16 -- one warm-up + up to three timed
+    iterations (>= 3) as far as they fit the budget -- else batch 2 (and the unit says so).  `cores` = the threads used (the cap
+    is measured, below), `host_cores` / `host_cpu` = what the box has."""
     from oracle import step_ref
-    ncores = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
-    ncores = min(ncores, 16)   # measured on the GPU box: 16 threads 1.1 s/iteration, 64 threads 3.3 s, 256 threads > 400 s (oversubscribed tiny ops)
+    nproc, cpu_model = _host_cpu()
+    ncores = min(nproc, 16)   # measured on the GPU box: 16 threads 1.1 s/iteration, 64 threads 3.3 s, 256 threads > 400 s (oversubscribed tiny ops)
     torch.set_num_threads(ncores)
     kw = dict(bg_size=bg, G_param_names=G_names, D_param_names=D_names)
     t_start = time.time()
@@ -93,8 +109,8 @@ def cpu_baseline(G_sd, D_sd, G_names, D_names, bg, budget_s=25.0):
         return (B * n / el, n), warm
 
     small, _ = leg(2, 3, t_start + 6.0)
-    big, warm16 = leg(16, 1, t_start + budget_s)
-    out = dict(cores=ncores, kind='port')
+    big, warm16 = leg(16, 3, t_start + budget_s)
+    out = dict(cores=ncores, host_cores=nproc, host_cpu=cpu_model, kind='port')
     if big is not None:
         out.update(value=round(big[0], 4), unit='images/s', batch=16,
                    sample=f'{big[1]} timed iteration(s) of the same Gmain+Dmain step at batch 16, {bg}x{bg} (oracle/step_ref.py, torch CPU fp32, dropout off) after 1 warm-up')
@@ -233,7 +249,7 @@ def run(args, rank, local_rank, world):
             tl.training_iteration(loss, [pG, pD], dp, batch, b_local, gen_z, ema=ema, batch_size=gb, ema_kimg=gb * 10 / 32, cur_nimg=cur_nimg[0])
             cur_nimg[0] += gb
 
-        step = eager_step
+        step, stage_info = eager_step, {}
         if not args.no_graph:
             # eager warm-up before capture (allocator, folded-BN / position-encoding caches) on a SIDE stream: autograd's AccumulateGrad
             # nodes remember the stream they were first used on, and one bound to the default stream breaks a later capture
@@ -247,6 +263,7 @@ def run(args, rank, local_rank, world):
                                           capture_stream=side, overlap=(dp.world > 1 and not args.no_overlap))
             graphed.cur_nimg = cur_nimg[0]
             step = graphed.run
+            stage_info = dict(backward_stages=graphed.n_stages, backward_stage_ms=[round(v, 2) for v in graphed.stage_ms] if graphed.stage_ms else None)
         for _ in range(args.warmup):
             step()
         dp.exposed.clear()
@@ -283,6 +300,7 @@ def run(args, rank, local_rank, world):
                 diag['allreduce_mb_per_step'] = round(4e-6 * (pG.fm.total + pD.fm.total), 1)
         out = dict(value=round(gb * args.steps / elapsed, 3), ms_per_step=round(elapsed / args.steps * 1e3, 3), global_batch=gb, per_gpu_batch=b_local)
         if diag is not None:
+            diag.update(stage_info)      # stages of the overlapped backward, chosen from the measured stage lengths (training_loop.backward_stage_count)
             out['diagnostics'] = diag
         if want_eager:
             out['eager_step'] = eager_step
@@ -339,6 +357,13 @@ def run(args, rank, local_rank, world):
                         os.environ['LDETR_TRUNK_P3'] = prev_p3
                     tl.refresh_weight_planes(G); tl.refresh_weight_planes(D)   # the weights moved while the plane-format trunk was off
                 extra['value_f32_mfma_only'] = r['value']
+                # the bound SCALE will hit at 8 GPUs (BASELINE configs[3] = the reference's recommended launch: global batch 16 -> 2 samples per GPU):
+                # a 2-sample step is a launch-latency chain, so 16 samples on one GPU / 2 samples on one GPU is all strong scaling can return
+                s2 = measure(2, share)
+                extra['strong_scaling_ceiling'] = dict(value=round(primary['ms_per_step'] / s2['ms_per_step'], 3), n_gpus=8, ms_per_step_16_per_gpu=primary['ms_per_step'],
+                                                       ms_per_step_share=s2['ms_per_step'], per_gpu_batch_share=2,
+                                                       note='ms_per_step(16 samples on one GPU) / ms_per_step(2 samples on one GPU), no gradient exchange: the speed-up of a global batch of 16 '
+                                                            'on 8 GPUs over N = 1 cannot exceed this (measured here on ONE GPU); weak scaling (16 per GPU) is the figure that scales with N')
     eager_step = primary.pop('eager_step')
     if primary.get('diagnostics') is not None:
         extra['diagnostics'] = primary.pop('diagnostics')
@@ -401,12 +426,13 @@ def run(args, rank, local_rank, world):
         by = {}
         t_pipe = [0.0, 0.0]          # engine time on the f32 MFMA pipe / on the bf16 pipe (exact operand split)
         n_pipe = [0, 0]
-        alg_bytes = 0.0
+        alg_bytes = alg_bytes_f32 = 0.0
         for tag, f, s_, e_, nb, pipes in core.PROF.records:   # the same records, split by C-ABI entry point
             key = 'dense_gemm' if tag == 'gemm' else tag.replace('ldetr_', '').replace('_f32', '')
             ms = s_.elapsed_time(e_)
             a = by.setdefault(key, [0.0, 0.0, 0, 0.0, 0.0]); a[0] += f; a[1] += ms; a[2] += 1; a[3] += nb
             alg_bytes += nb
+            alg_bytes_f32 += nb * (4.0 / 6.0 if tag.startswith('ldetr_p3') else 1.0)      # plane-format operands are 6 bytes per element: SURVEY 8d counts fp32 tensors
             tot = max(pipes[0] + pipes[1], 1)
             t_pipe[0] += ms * pipes[0] / tot; t_pipe[1] += ms * pipes[1] / tot      # (a call that issued launches on both pipes: split by launch count)
             n_pipe[0] += pipes[0]; n_pipe[1] += pipes[1]
@@ -420,7 +446,7 @@ def run(args, rank, local_rank, world):
         peak_eff = (t_pipe[0] * F32_MFMA_PEAK_TFLOPS + t_pipe[1] * SPLIT_PIPE_PEAK_TFLOPS) / tsum
         roofline = dict(bound='mfma', kernel='fp32-equivalent contraction engine, every launch: ldetr::p3_nt_kernel<*> / p3_c3_kernel / p3_tn_kernel<*> (the ResNet trunk on plane-format '
                                              'operands, bf16 pipe) + gemm_f32_kernel<*> (LDS-tiled GEMM / implicit conv) + gemm_small_kernel<*> / gemm_small_pair_kernel<*> '
-                                             '(+ conv3x3_c32 / wgrad_c32 / ffn kernels where they replace engine launches)',
+                                             '(+ conv3x3_c32 / wgrad_c32 where they replace engine launches) + the token-stack kernels (mha_small / mha_cross / ffn fwd + bwd, wgrad_multi: f32 MFMA)',
                         achieved=round(ach, 3), peak=F32_MFMA_PEAK_TFLOPS, unit='TFLOP/s', frac=round(ach / F32_MFMA_PEAK_TFLOPS, 4),
                         achieved_event_corrected=round(ach_corr, 3), frac_event_corrected=round(ach_corr / F32_MFMA_PEAK_TFLOPS, 4),
                         peak_effective=round(peak_eff, 1), frac_effective=round(ach / peak_eff, 4),
@@ -429,7 +455,7 @@ def run(args, rank, local_rank, world):
                                             f'{t_pipe[0] / tsum:.3f} on the f32 MFMA pipe ({F32_MFMA_PEAK_TFLOPS}; {n_pipe[0] // 2} launches)',
                         engine_ms_on_bf16_pipe=round(t_pipe[1] / 2, 3), engine_ms_on_f32_pipe=round(t_pipe[0] / 2, 3),
                         traffic=None, launches_per_step=launches // 2, algorithmic_gflop_per_step=round(fl / 2 / 1e9, 2),
-                        algorithmic_gb_per_step=round(alg_bytes / 2 / 1e9, 2),
+                        algorithmic_gb_per_step=round(alg_bytes / 2 / 1e9, 2), algorithmic_gb_per_step_fp32_tensors=round(alg_bytes_f32 / 2 / 1e9, 2),
                         engine_ms_per_step=round(sec / 2 * 1e3, 3), engine_ms_per_step_uncorrected=round(sec_raw / 2 * 1e3, 3),
                         event_pair_overhead_us=round(ev_over_ms * 1e3, 2), by_entry=by_entry,
                         matrix_pipe='fp32 values, fp32 accumulators and results throughout; the ResNet trunk keeps its activations and weights as the exact 3-way bf16 split '
@@ -453,6 +479,7 @@ def run(args, rank, local_rank, world):
                 roofline['traffic_unit'] = 'HBM bytes per engine launch (mean over the step)'
                 roofline['traffic_gb_per_step'] = round((pmc['engine_total']['fetch'] + pmc['engine_total']['write']) / 1e9, 2)
                 roofline['traffic_over_algorithmic'] = round(roofline['traffic_gb_per_step'] / max(roofline['algorithmic_gb_per_step'], 1e-9), 2)
+                roofline['traffic_over_fp32_algorithmic'] = round(roofline['traffic_gb_per_step'] / max(roofline['algorithmic_gb_per_step_fp32_tensors'], 1e-9), 2)
                 roofline['traffic_source'] = f"profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, two passes over tools/pmc_step.py; kernel sources {pmc['csrc_digest'][:12]} = this build)"
         try:    # the fractions north_star names, each as its own entry (HBM-bound kernels, modulated-conv layer at 256x256, DETR cross-attention)
             sys.path.insert(0, os.path.join(ROOT, 'tools'))
@@ -471,12 +498,14 @@ def run(args, rank, local_rank, world):
         out = dict(metric=METRIC, value=round(value, 3), unit='images/s', n_gpus=world, rccl_ranks=(dist.get_world_size() if world > 1 else 1), **({'shared_single_gpu_gloo': True} if share_gpu else {}),
                    steps=args.steps, warmup=args.warmup, ms_per_step=round(ms_per_step, 3), higher_is_better=True,
                    scaling=scaling, vs_baseline=None, dtype='f32', data='synthetic',
-                   config=dict(workload=f'BASELINE configs[{2 if world == 1 else 3}]: global batch {args.batch} ({b_local} per GPU), {bg}x{bg} backgrounds x 9 elements, full G+D adversarial '
+                   config=dict(reference_call_pattern_images_s=extra.get('value_reference_call_pattern'), phase_trunk_sharing_images_s=extra.get('value_phase_trunk_sharing'),
+                               headline_note="value = D's ResNet trunk evaluated once per iteration (value-identical: D's weights do not move between Gmain and Dmain); "
+                                             'quote it with phase_trunk_sharing_images_s (once per phase) and reference_call_pattern_images_s (once per D pass, as training/loss.py does)',
+                               workload=f'BASELINE configs[{2 if world == 1 else 3}]: global batch {args.batch} ({b_local} per GPU), {bg}x{bg} backgrounds x 9 elements, full G+D adversarial '
                                         'step (Gmain+Dmain fwd/bwd, grad exchange + nan_to_num, Adam, EMA), train mode (dropout 0.1); ' +
                                         ('hot-path-only: frozen-BERT text features are an input, LM-decoder loss excluded' if args.text_mode == 'features' else f'text path on: {args.text_mode}, {args.text_tokens} tokens per element'),
                                global_batch=args.batch, per_gpu_batch=b_local, background=bg, elements=9,
-                               parallelism=f'dp{world}', hip_graph=not args.no_graph, allreduce_overlapped_with_backward=(world > 1 and not args.no_graph and not args.no_overlap), text_mode=args.text_mode, text_tokens=(args.text_tokens if args.text_mode != 'features' else None), d_trunk_shared=False if args.no_share_trunk else args.share_trunk, params_G=n_params[0], params_D=n_params[1],
-                               reference_call_pattern_images_s=extra.get('value_reference_call_pattern'), phase_trunk_sharing_images_s=extra.get('value_phase_trunk_sharing')),
+                               parallelism=f'dp{world}', hip_graph=not args.no_graph, allreduce_overlapped_with_backward=(world > 1 and not args.no_graph and not args.no_overlap), text_mode=args.text_mode, text_tokens=(args.text_tokens if args.text_mode != 'features' else None), d_trunk_shared=False if args.no_share_trunk else args.share_trunk, params_G=n_params[0], params_D=n_params[1]),
                    roofline=roofline, cpu_baseline=cpu, **extra)
         print(json.dumps(out), flush=True)
     if world > 1:

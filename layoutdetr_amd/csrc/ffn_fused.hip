@@ -22,6 +22,8 @@
 
 namespace ldetr {
 
+void note_engine_launch(bool bf16_split_pipe);   // gemm_conv.hip (ldetr_engine_launch_counts): these kernels contract on the f32 MFMA pipe
+
 // One problem = the public argument block (include/ldetr_hip.h: ldetr_ffn_args).  A launch carries one or two: the second problem's blocks follow
 // the first's in a 1-D grid (two independent stacks' feed-forward blocks as ONE launch); block c of a problem = (row tile c % gx, hidden slice c / gx).
 typedef ldetr_ffn_args FfnParams;
@@ -245,6 +247,7 @@ static int ffn_launch(const ldetr_ffn_args* a, int n, bool bwd, void* stream) {
     if (nb[0] + nb[1] == 0) return LDETR_OK;
     if (bwd) hipLaunchKernelGGL(ffn_bwd_kernel, dim3(nb[0] + nb[1]), dim3(256), 0, (hipStream_t)stream, p[0], p[1], nb[0]);
     else hipLaunchKernelGGL(ffn_fwd_kernel, dim3(nb[0] + nb[1]), dim3(256), 0, (hipStream_t)stream, p[0], p[1], nb[0]);
+    note_engine_launch(false);
     return check_launch(what);
 }
 

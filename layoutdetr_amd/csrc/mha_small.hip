@@ -22,6 +22,8 @@
 
 namespace ldetr {
 
+void note_engine_launch(bool bf16_split_pipe);   // gemm_conv.hip (ldetr_engine_launch_counts): these kernels contract on the f32 MFMA pipe
+
 // One problem = the public argument block (include/ldetr_hip.h: ldetr_mha_small_args): x [B*L, 256], w_in [768, 256], b_in [768], w_out [256, 256],
 // kpm [B][L] (nonzero = masked key) or null, qkv [B*L, 768] (projection incl. bias, q unscaled), o [B*L, 256] (attention output before the output
 // projection), lse [B][8][L], ypart [8][B*L][256]; backward: dr [B*L, 256] in, dqkv [B*L, 768] and dxpart [8][B*L][256] out.
@@ -849,6 +851,7 @@ static int mha_small_launch(const ldetr_mha_small_args* a, int n, bool bwd, void
     if (nb[0] + nb[1] == 0) return LDETR_OK;
     if (bwd) hipLaunchKernelGGL(mha_small_bwd_kernel, dim3((unsigned)(nb[0] + nb[1])), dim3(256), 0, (hipStream_t)stream, p[0], p[1], nb[0]);
     else hipLaunchKernelGGL(mha_small_fwd_kernel, dim3((unsigned)(nb[0] + nb[1])), dim3(256), 0, (hipStream_t)stream, p[0], p[1], nb[0]);
+    note_engine_launch(false);
     return check_launch(what);
 }
 
@@ -877,6 +880,7 @@ extern "C" int ldetr_mha_cross_bwd_f32(const ldetr_mha_cross_args* a, void* stre
     LDETR_CHECK(p.p_drop >= 0.f && p.p_drop < 1.f, "mha_cross_bwd: p_drop out of range");
     if (p.B == 0) return LDETR_OK;
     hipLaunchKernelGGL(mha_cross_bwd_kernel, dim3((unsigned)(p.B * MS_H)), dim3(320), 0, (hipStream_t)stream, p);
+    note_engine_launch(false);
     return check_launch("mha_cross_bwd");
 }
 
@@ -895,6 +899,7 @@ extern "C" int ldetr_wgrad_multi_f32(const ldetr_wgrad_desc* d, int n, void* str
     m.n = n;
     if (total == 0) return LDETR_OK;
     hipLaunchKernelGGL(wgrad_multi_kernel, dim3((unsigned)total), dim3(256), 0, (hipStream_t)stream, m);
+    note_engine_launch(false);
     return check_launch("wgrad_multi");
 }
 
@@ -916,5 +921,6 @@ extern "C" int ldetr_mha_cross_fwd_f32(const float* x, int64_t ldx, const float*
     p.q = q; p.o = o; p.lse = lse; p.ypart = ypart; p.B = B; p.Lq = Lq; p.Lk = Lk; p.scale = scale; p.p_drop = p_drop;
     p.seed = seed; p.seed_ptr = seed_ptr;
     hipLaunchKernelGGL(mha_cross_fwd_kernel, dim3((unsigned)(B * MS_H)), dim3(256), 0, (hipStream_t)stream, p);
+    note_engine_launch(false);
     return check_launch("mha_cross_fwd");
 }

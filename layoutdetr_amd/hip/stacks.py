@@ -90,10 +90,32 @@ def _seed_ptr(p):
     return core.iter_seed().data_ptr() if p > 0 else None
 
 
-def _launch(fn, struct, args, what):
+def _launch(fn, struct, args, what, flops=0.0, nbytes=0.0):
+    """One group launch; flops > 0: a contraction launch, accounted with the engine's (bench.py roofline leg, hip.core.engine_call)."""
     n = len(args)
     arr = (struct * n)(*args)
-    core.check(fn(arr, n, core.stream()), what)
+    if flops > 0:
+        core.engine_call('ldetr_token_stack', flops, lambda: core.check(fn(arr, n, core.stream()), what), nbytes=nbytes)
+    else:
+        core.check(fn(arr, n, core.stream()), what)
+
+
+def _fl_self(pr, bwd=False):
+    """algorithmic FLOPs / bytes of the self-attention sub-block of one stack (projection, QK^T + PV, output projection; backward: their
+    data gradients incl. the recomputed scores)."""
+    M, D, att = pr.B * pr.L, D_MODEL, pr.B * N_HEAD * 2.0 * pr.L * pr.L * (D_MODEL // N_HEAD)
+    fl = 2.0 * M * D * 3 * D + 2.0 * M * D * D + (5 if bwd else 2) * att
+    return fl, 4.0 * (M * D * (6 if bwd else 5) + 4 * D * D + N_HEAD * M * D)
+
+
+def _fl_cross(pr, bwd=False):
+    M, D, att = pr.B * pr.L, D_MODEL, pr.B * N_HEAD * 2.0 * pr.L * pr.S * (D_MODEL // N_HEAD)
+    fl = 2.0 * M * D * D * 2 + (5 if bwd else 2) * att
+    return fl, 4.0 * (M * D * 4 + 2 * D * D + (4 if bwd else 2) * pr.B * pr.S * D + N_HEAD * M * D)
+
+
+def _fl_ffn(M, F):
+    return 4.0 * M * D_MODEL * F, 4.0 * (2 * D_MODEL * F + M * F + (F // 64 + 1) * M * D_MODEL)
 
 
 # ---------------------------------------------------------------------------------------------------------------- argument blocks
@@ -180,7 +202,8 @@ class _TokenStacksFn(torch.autograd.Function):
                 args.append(a)
                 s['sv'], s['r'], s['r_bias'] = sv, ypart, W[3]
                 s['saved'].append(sv)
-            _launch(lib.ldetr_mha_small_fwd_group_f32, _lib.MhaSmallArgs, args, 'mha_small_fwd')
+            fb = [_fl_self(s['prog']) for s in act]
+            _launch(lib.ldetr_mha_small_fwd_group_f32, _lib.MhaSmallArgs, args, 'mha_small_fwd', sum(f for f, _ in fb), sum(b for _, b in fb))
             # ---- decoders: norm1, then the cross-attention sub-block onto the projected memory
             for s in act:
                 pr = s['prog']
@@ -202,10 +225,11 @@ class _TokenStacksFn(torch.autograd.Function):
                 sv['cross_small'] = small
                 if small:
                     ypart = _new(dev, H, M, D)
-                    core.check(lib.ldetr_mha_cross_fwd_f32(
+                    fc = _fl_cross(pr)
+                    core.engine_call('ldetr_token_stack', fc[0], lambda: core.check(lib.ldetr_mha_cross_fwd_f32(
                         core.ptr(sv['t1']), D, core.ptr(Wq), core.ptr(Bq), core.ptr(K), K.stride(0), core.ptr(V), V.stride(0), core.ptr(W[8]), core.ptr(pr.mem_kpm),
                         core.ptr(sv['qc']), core.ptr(sv['oc']), core.ptr(sv['lse_c']), core.ptr(ypart), pr.B, pr.L, pr.S, D, H, scale, p_c, sv['seed_c'],
-                        _seed_ptr(p_c), core.stream()), 'mha_cross_fwd')
+                        _seed_ptr(p_c), core.stream()), 'mha_cross_fwd'), nbytes=fc[1])
                     s['r'], s['r_bias'], s['r_parts'] = ypart, W[9], H
                 else:
                     # more than 64 memory tokens (backgrounds above 256 x 256): projection, attention kernel, projection
@@ -242,7 +266,8 @@ class _TokenStacksFn(torch.autograd.Function):
                 s['keep'] = (s['r'], parts)      # (alive until their consumers have been queued: same stream, so queue order is enough)
                 s['cur'] = y
             _launch(lib.ldetr_layernorm_fwd_group_f32, _lib.LnArgs, ln_a, 'layernorm_fwd')
-            _launch(lib.ldetr_ffn_fwd_group_f32, _lib.FfnArgs, ffn, 'ffn_fwd')
+            fb = [_fl_ffn(s['M'], s['sv']['F']) for s in act]
+            _launch(lib.ldetr_ffn_fwd_group_f32, _lib.FfnArgs, ffn, 'ffn_fwd', sum(f for f, _ in fb), sum(b for _, b in fb))
             _launch(lib.ldetr_layernorm_fwd_group_f32, _lib.LnArgs, ln_b, 'layernorm_fwd')
         outs = []
         for s in st:
@@ -334,7 +359,8 @@ class _TokenStacksFn(torch.autograd.Function):
                                        target(base + 4 + o) if nw else None, target(base + 5 + o) if nw else None, sv['p_a'], sv['seed_a']))
                 s['t'] = dict(dz=dz, dr=dr, dxpart=dxpart, dh=dh, dsum=dsum, da=da, gin=g)
             _launch(lib.ldetr_layernorm_bwd_group_f32, _lib.LnArgs, a1, 'layernorm_bwd')
-            _launch(lib.ldetr_ffn_bwd_group_f32, _lib.FfnArgs, a2, 'ffn_bwd')
+            fb = [_fl_ffn(s['M'], s['saved'][i]['F']) for s, _ in act]
+            _launch(lib.ldetr_ffn_bwd_group_f32, _lib.FfnArgs, a2, 'ffn_bwd', sum(f for f, _ in fb), sum(b for _, b in fb))
             _launch(lib.ldetr_layernorm_bwd_group_f32, _lib.LnArgs, a3, 'layernorm_bwd')
             # ---- decoders: cross-attention backward, then norm1's
             for s, pr in act:
@@ -355,7 +381,8 @@ class _TokenStacksFn(torch.autograd.Function):
                     a.q, a.o, a.lse, a.B, a.Lq, a.Lk = sv['qc'].data_ptr(), sv['oc'].data_ptr(), sv['lse_c'].data_ptr(), pr.B, pr.L, pr.S
                     a.scale, a.p_drop, a.seed, a.seed_ptr = scale, sv['p_c'], sv['seed_c'], _seed_ptr(sv['p_c'])
                     a.dr, a.dq, a.dk, a.lddk, a.dv, a.lddv, a.dxpart = t['da'].data_ptr(), dq.data_ptr(), dk.data_ptr(), dk.stride(0), dv.data_ptr(), dv.stride(0), dxpart_c.data_ptr()
-                    core.check(lib.ldetr_mha_cross_bwd_f32(_lib.ctypes.byref(a), core.stream()), 'mha_cross_bwd')
+                    fc = _fl_cross(pr, bwd=True)
+                    core.engine_call('ldetr_token_stack', fc[0], lambda: core.check(lib.ldetr_mha_cross_bwd_f32(_lib.ctypes.byref(a), core.stream()), 'mha_cross_bwd'), nbytes=fc[1])
                     g1 = _Grad(t['dsum'], dxpart_c, H)
                 else:
                     d_o = core.gemm(t['da'], W[8], 0, 1, M, D, D)
@@ -389,7 +416,8 @@ class _TokenStacksFn(torch.autograd.Function):
                 a.dr, a.dxpart = t['da'].data_ptr(), t['dxpart_sa'].data_ptr()
                 a.dqkv = t['dqkv'].data_ptr() if t['dqkv'] is not None else None
                 args.append(a)
-            _launch(lib.ldetr_mha_small_bwd_group_f32, _lib.MhaSmallArgs, args, 'mha_small_bwd')
+            fb = [_fl_self(pr, bwd=True) for _, pr in act]
+            _launch(lib.ldetr_mha_small_bwd_group_f32, _lib.MhaSmallArgs, args, 'mha_small_bwd', sum(f for f, _ in fb), sum(b for _, b in fb))
             # ---- every weight gradient of the layer(s): contractions over the tokens, up to 8 per launch
             descs = []
             for s, pr in act:
@@ -416,7 +444,9 @@ class _TokenStacksFn(torch.autograd.Function):
             for j in range(0, len(descs), 8):
                 chunk = descs[j:j + 8]
                 arr = (_lib.WgradDesc * len(chunk))(*chunk)
-                core.check(lib.ldetr_wgrad_multi_f32(arr, len(chunk), core.stream()), 'wgrad_multi')
+                wf = sum(2.0 * d.M * d.rows * d.cols for d in chunk)
+                wb = sum(4.0 * (d.M * (d.rows + d.cols) + d.rows * d.cols) for d in chunk)
+                core.engine_call('ldetr_token_stack', wf, lambda: core.check(lib.ldetr_wgrad_multi_f32(arr, len(chunk), core.stream()), 'wgrad_multi'), nbytes=wb)
             for s, pr in act:
                 t = s['t']
                 s['g'] = _Grad(t['dsum'], t['dxpart_sa'], H)

@@ -479,15 +479,35 @@ def _trunk_body(module):
     return bb[0].body if bb is not None and hasattr(bb[0], 'body') else None
 
 
-def backward_stage_count(per_gpu_batch):
-    """Stages of a phase's backward when the gradient exchange is overlapped with it: trunk | rest (2) at <= 4 samples per GPU, where a third
-    boundary would make every stage graph only a few ms long and the host's issue latency between two replays shows in the exposed
-    communication time; layer1-2 | layer3-4 | rest (3) above.  LDETR_BACKWARD_STAGES = 2 | 3 overrides."""
+MIN_STAGE_MS = 1.5      # a backward stage shorter than this cannot hide the host's issue latency between two graph replays (collectives are host-issued)
+
+
+def backward_stage_count(per_gpu_batch, stage_ms=None):
+    """Stages of a phase's backward when the gradient exchange is overlapped with it: layer1-2 | layer3-4 | rest (3) or trunk | rest (2).
+    stage_ms: measured durations [rest, layer3-4, layer1-2] of one eager three-stage backward on THIS box (measure_backward_stages): three stages only
+    if each of them is long enough (MIN_STAGE_MS) to cover the host issuing the next replay and the collective -- otherwise the exposed communication
+    time is host jitter, not bandwidth.  Without a measurement: 2 at <= 4 samples per GPU, else 3.  LDETR_BACKWARD_STAGES = 2 | 3 overrides."""
     import os
     forced = os.environ.get('LDETR_BACKWARD_STAGES')
     if forced in ('2', '3'):
         return int(forced)
+    if stage_ms is not None and len(stage_ms) == 3:
+        return 3 if min(stage_ms) >= MIN_STAGE_MS else 2
     return 2 if per_gpu_batch <= 4 else 3
+
+
+def measure_backward_stages(loss, phase, dp, accumulate):
+    """One eager forward + three-stage backward of `phase` with HIP events at the stage boundaries -> [ms of stage 1 (incl. the forward), 2, 3], or
+    None when the phase has no stageable trunk.  No exchange is issued (timing only); gradients accumulate into the flat buffer as usual."""
+    segs = phase.fm.stage_segments(3)
+    body = _trunk_body(phase.module)
+    if segs is None or body is None or not hasattr(body, 'stages') or not torch.cuda.is_available():
+        return None
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+    ev[0].record()
+    staged_backward(loss, phase, dp, accumulate, between=lambda i: ev[i].record(), exchange=lambda ranges: None, n_stages=3)
+    torch.cuda.synchronize()
+    return [ev[i].elapsed_time(ev[i + 1]) for i in range(3)]
 
 
 def staged_backward(loss, phase, dp, run_stage1, between=None, exchange=None, stages=None, n_stages=3):
@@ -602,6 +622,27 @@ class GraphedIteration(object):
         if overlap is None:
             overlap = dp.world > 1
         pool = torch.cuda.graph_pool_handle() if (iter_share or overlap) else None
+        # how many stages the overlapped backward gets: from the measured length of the stages on this box, not from a batch-size rule
+        self.stage_ms, self.n_stages = None, backward_stage_count(b)
+        if overlap and b <= batch_gpu and phases and phases[0].fm.stage_segments() is not None:
+            ph = phases[0]
+            ph.module.requires_grad_(True); ph.module.text_encoder.requires_grad_(False)
+
+            def once(ph=ph):
+                core.reseed(dev)
+                gen_z = torch.randn(b, batch['bbox_class'].shape[1], z_dim, device=dev)
+                loss.accumulate_gradients(phase=ph.name, bbox_real=batch['bbox_real'], bbox_class=batch['bbox_class'], bbox_text=batch['bbox_text'],
+                                          bbox_patch=batch['bbox_patch'], padding_mask=batch['padding_mask'], background=batch['background'],
+                                          real_c=batch['real_c'], gen_z=gen_z, gen_c=batch['gen_c'], gain=1, cur_nimg=0)
+            cur = torch.cuda.current_stream()
+            st = self.capture_stream if self.capture_stream is not None else cur
+            st.wait_stream(cur)
+            with torch.cuda.stream(st):
+                ph.fm.zero_grad()
+                self.stage_ms = measure_backward_stages(loss, ph, dp, once)
+            cur.wait_stream(st)
+            ph.module.requires_grad_(False)
+            self.n_stages = backward_stage_count(b, self.stage_ms)
         d_stages = None
         if iter_share:
             # D's trunk forward gets its own graph, replayed before the phases; its activations stay alive in the shared pool until
@@ -609,7 +650,7 @@ class GraphedIteration(object):
             d_phase = next(p for p in phases if p.name == 'Dmain')
             if overlap and b <= batch_gpu and d_phase.fm.stage_segments() is not None and hasattr(_trunk_body(d_phase.module), 'stages'):
                 from .detr_backbone import BackwardStages
-                d_stages = BackwardStages(backward_stage_count(b))
+                d_stages = BackwardStages(self.n_stages)
             self.pre_graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.pre_graph, pool=pool, stream=self.capture_stream):
                 for s in range(0, b, batch_gpu):
@@ -646,7 +687,7 @@ class GraphedIteration(object):
             begin()
             try:
                 if staged:
-                    nst = backward_stage_count(b)
+                    nst = self.n_stages
                     segs = phase.fm.stage_segments(nst)
 
                     def between(i):

@@ -395,6 +395,8 @@ def test_backward_stage_count_and_two_stage_segments(monkeypatch):
     from layoutdetr_amd.training import training_loop as tl
     monkeypatch.delenv('LDETR_BACKWARD_STAGES', raising=False)
     assert [tl.backward_stage_count(b) for b in (1, 2, 4, 5, 16)] == [2, 2, 2, 3, 3]
+    # measured stage lengths [rest, layer3-4, layer1-2] decide when given: three stages only if each covers the host's issue latency
+    assert tl.backward_stage_count(16, [6.0, 3.1, 2.2]) == 3 and tl.backward_stage_count(16, [6.0, 3.1, 0.9]) == 2 and tl.backward_stage_count(2, [2.0, 1.6, 1.5]) == 3
     monkeypatch.setenv('LDETR_BACKWARD_STAGES', '3')
     assert tl.backward_stage_count(2) == 3
     monkeypatch.setenv('LDETR_BACKWARD_STAGES', '2')

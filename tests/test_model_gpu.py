@@ -919,6 +919,61 @@ if world > 1:
         assert agree >= 0.99, f'{k}: only {agree:.4f} of the parameters agree between 1 rank x 4 and 2 ranks x 2'
 
 
+def test_two_ranks_overlapped_exchange_equals_exchange_after_backward(dev):
+    """2 ranks x 2 samples, three iterations each: the staged backward with the segment-wise exchange launched behind every stage on the communication
+    stream (training_loop.staged_backward + DataParallelStep.exchange_async: what GraphedIteration(overlap=True) replays) hands Adam the SAME
+    gradients as one all-reduce after the whole backward (the reference's order, training_loop.py:303-312; bench.py --no-overlap): the exchanged
+    flat gradient of the last iteration and Adam's second moment (which has seen all three) are compared, at lr = 0 so that the three iterations see
+    the same weights in both runs (with a real step the two runs drift apart chaotically from the order of the weight-gradient atomics alone).
+    RCCL with >= 2 GPUs, gloo with both ranks on one device otherwise."""
+    import subprocess
+    import sys
+    import tempfile
+    code = r'''
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, os.environ["LDETR_ROOT"]); sys.path.insert(0, os.path.join(os.environ["LDETR_ROOT"], "tests"))
+import test_model_gpu as T
+from layoutdetr_amd.training import training_loop as tl
+from layoutdetr_amd.training.loss import StyleGAN2Loss
+from layoutdetr_amd.training.networks_detr import TextFeatures
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+two = torch.cuda.device_count() >= 2
+torch.cuda.set_device(rank if two else 0); dev = torch.device("cuda", rank if two else 0)
+dist.init_process_group("nccl", device_id=dev) if two else dist.init_process_group("gloo")
+G, D = T._make(dev, seed=5)
+bt, zg, zd = T._batch(4, 64, seed=6); bt["padding_mask"][:] = False
+n = 4 // world
+sl = slice(rank * n, (rank + 1) * n)
+G.eval().requires_grad_(False).to(dev); D.eval().requires_grad_(False).to(dev)
+pG = tl.Phase("Gmain", G, lr=0.0); pD = tl.Phase("Dmain", D, lr=0.0)
+dp = tl.DataParallelStep(world_size=world)
+batch = dict(bbox_real=bt["bbox_real"][sl].to(dev), bbox_class=bt["bbox_class"][sl].to(dev), bbox_text=TextFeatures(bt["text_feat"][sl].to(dev), bt["text_len"][sl].to(dev)),
+             bbox_patch=torch.zeros(n, 9, 1, 1, 1, device=dev), padding_mask=bt["padding_mask"][sl].to(dev), background=bt["background"][sl].to(dev),
+             real_c=torch.zeros(n, 0, device=dev), gen_c=torch.zeros(n, 0, device=dev))
+loss = StyleGAN2Loss(dev, G, D, share_D_trunk="iteration")
+for it in range(3):
+    tl.training_iteration(loss, [pG, pD], dp, batch, n, [zg[sl].to(dev), zd[sl].to(dev)], overlap=os.environ["LDETR_OVERLAP"] == "1")
+torch.cuda.synchronize()
+if rank == 0:
+    torch.save(dict(G=pG.fm.gflat.cpu(), D=pD.fm.gflat.cpu(), vG=pG.v.cpu(), vD=pD.v.cpu()), os.environ["LDETR_OUT"])
+dist.barrier(); dist.destroy_process_group()
+'''
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for overlap in ('1', '0'):
+        out = tempfile.mktemp(suffix='.pt')
+        env = dict(os.environ, LDETR_ROOT=root, LDETR_OUT=out, LDETR_OVERLAP=overlap, HSA_ENABLE_IPC_MODE_LEGACY='0')
+        subprocess.check_call([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=2', '--master-addr', '127.0.0.1',
+                               '--master-port', '29541', '--no-python', sys.executable, '-c', code], env=env)
+        outs.append(torch.load(out))
+    for k in ('G', 'D', 'vG', 'vD'):
+        # what differs between two separate runs is only the order in which the weight-gradient atomics landed
+        a, b = outs[0][k], outs[1][k]
+        assert a.abs().max() > 0
+        agree = torch.isclose(a, b, rtol=2e-3, atol=1e-5 * a.abs().max().item()).float().mean().item()
+        assert agree >= 0.999, f'{k}: only {agree:.4f} of the entries agree between the overlapped and the after-backward exchange'
+
+
 def test_decoder_mapping_latent_forms_and_truncation(dev):
     """The Decoder hands its mapping output to the synthesis network as ONE [B, w_dim] latent (no num_ws copies); the reference's
     [B, num_ws, w_dim] form, truncation towards w_avg and the per-layer cutoff (networks_stylegan2.py:951-964) give the same images."""
