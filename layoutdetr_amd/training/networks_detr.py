@@ -166,6 +166,41 @@ class _NoTextEncoder(nn.Module):
         raise NotImplementedError("text_mode='features': pass TextFeatures instead of strings (BERT text path is SURVEY §8f-1)")
 
 
+class _EmbeddingFn(torch.autograd.Function):
+    """nn.Embedding lookup (emb_label / enc_text_len, networks_detr.py:85, 94) with the gradient scattered straight into the table's flat .grad view
+    (fp32 atomics, csrc/xent.hip): aten's embedding_dense_backward zero-fills a table-sized temporary, scatters into it and AccumulateGrad adds it."""
+
+    @staticmethod
+    def forward(ctx, ids, weight):
+        core.require_gpu(ids, weight)
+        V, d = weight.shape
+        i64 = ids.to(torch.int64).contiguous()
+        out = torch.empty(tuple(ids.shape) + (d,), device=weight.device, dtype=torch.float32)
+        core.check(core.lib().ldetr_embedding_fwd_f32(core.ptr(weight.detach().contiguous()), None, core.ptr(i64), core.ptr(out), i64.numel(), d, V, 1, core.stream()), 'embedding_fwd')
+        ctx.save_for_backward(i64)
+        ctx.param = weight
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        i64, = ctx.saved_tensors
+        w = ctx.param
+        V, d = w.shape
+        acc = core.flat_grad(w)
+        tgt = acc if (acc is not None and acc.is_contiguous()) else torch.zeros((V, d), device=dy.device, dtype=torch.float32)
+        core.check(core.lib().ldetr_embedding_bwd_f32(core.ptr(core.f32c(dy)), core.ptr(i64), core.ptr(tgt), i64.numel(), d, V, -1, core.stream()), 'embedding_bwd')
+        return None, (None if tgt is acc else tgt)
+
+
+class Embedding(nn.Embedding):
+    """nn.Embedding parameters (same names / initialisation); GPU lookups and their gradient on the HIP gather / scatter kernels."""
+
+    def forward(self, ids):
+        if ids.is_cuda and self.weight.dtype == torch.float32 and self.weight.shape[1] % 4 == 0 and self.padding_idx is None:
+            return _EmbeddingFn.apply(ids, self.weight)
+        return super().forward(ids)
+
+
 class Linear(nn.Linear):
     """nn.Linear parameters, f32-MFMA forward/backward."""
 
@@ -267,10 +302,10 @@ class Generator(nn.Module):
         self.backbone = build_backbone()
         self.input_proj = Conv1x1(self.backbone.num_channels, hidden_dim, kernel_size=1)
         self.fc_z = Linear(z_dim * 9, bert_f_dim)
-        self.emb_label = nn.Embedding(num_bbox_labels, bert_f_dim)
+        self.emb_label = Embedding(num_bbox_labels, bert_f_dim)
         self.text_encoder = _build_text_encoder(text_mode, med_config, bert_num_encoder_layers, bert_num_heads)
         self.text_decoder = _build_text_decoder(text_mode, med_config, bert_num_decoder_layers, bert_num_heads, im_f_dim)
-        self.enc_text_len = nn.Embedding(max_text_length, bert_f_dim)
+        self.enc_text_len = Embedding(max_text_length, bert_f_dim)
         self.fc_in = MLP(input_dim=4 * bert_f_dim, hidden_dim=bert_f_dim, output_dim=hidden_dim, num_layers=3)
         self.transformer = Transformer(d_model=hidden_dim, dropout=0.1, nhead=8, dim_feedforward=2048, num_encoder_layers=6,
                                        num_decoder_layers=6, normalize_before=False, return_intermediate_dec=False)
@@ -345,10 +380,10 @@ class Discriminator(nn.Module):
         self.backbone = build_backbone()
         self.input_proj = Conv1x1(self.backbone.num_channels, hidden_dim, kernel_size=1)
         self.fc_bbox = Linear(4, bert_f_dim)
-        self.emb_label = nn.Embedding(num_bbox_labels, bert_f_dim)
+        self.emb_label = Embedding(num_bbox_labels, bert_f_dim)
         self.text_encoder = _build_text_encoder(text_mode, med_config, bert_num_encoder_layers, bert_num_heads)
         self.text_decoder = _build_text_decoder(text_mode, med_config, bert_num_decoder_layers, bert_num_heads, im_f_dim)
-        self.enc_text_len = nn.Embedding(max_text_length, bert_f_dim)
+        self.enc_text_len = Embedding(max_text_length, bert_f_dim)
         self.enc_fc_in = MLP(input_dim=4 * bert_f_dim, hidden_dim=bert_f_dim, output_dim=hidden_dim, num_layers=3)
         self.enc_transformer = TransformerWithToken(d_model=hidden_dim, dropout=0.1, nhead=8, dim_feedforward=2048,
                                                     num_encoder_layers=6, num_decoder_layers=6, normalize_before=False,
@@ -368,7 +403,7 @@ class Discriminator(nn.Module):
 
         # unconditional discriminator
         self.fc_bbox_uncond = Linear(4, bert_f_dim)
-        self.emb_label_uncond = nn.Embedding(num_bbox_labels, bert_f_dim)
+        self.emb_label_uncond = Embedding(num_bbox_labels, bert_f_dim)
         self.enc_fc_in_uncond = MLP(input_dim=2 * bert_f_dim, hidden_dim=bert_f_dim, output_dim=hidden_dim, num_layers=3)
         self.enc_transformer_uncond = TransformerWithToken_layoutganpp(d_model=hidden_dim, dim_feedforward=2048, nhead=8, num_layers=6)
         self.fc_out_disc_uncond = Linear(hidden_dim, 1)

@@ -36,9 +36,15 @@ class FullyConnectedLayer(torch.nn.Module):
 
     def forward(self, x):
         b = self.bias
+        spec = bias_act.activation_funcs[self.activation]
+        if self.activation == 'lrelu' and b is not None and self.bias_gain != 1 and self.bias_gain > 0:
+            # act(x (w g_w)^T + b g_b) gain = lrelu(g_b (x (w g_w / g_b)^T + b)) gain = (g_b gain) lrelu(x (w g_w / g_b)^T + b)  (lrelu is positively
+            # homogeneous): the bias gain of the mapping network's layers (lr_multiplier 0.01, networks_stylegan2.py:108-111) moves into the GEMM's scalars
+            # instead of a `b * bias_gain` launch forward and its gradient launch backward per layer
+            return linear(x, self.weight, b, act=core.ACT_LRELU, act_alpha=float(spec.def_alpha), act_gain=float(spec.def_gain * self.bias_gain),
+                          wscale=float(self.weight_gain / self.bias_gain))
         if b is not None and self.bias_gain != 1:
             b = b * self.bias_gain
-        spec = bias_act.activation_funcs[self.activation]
         if self.activation == 'linear':
             return linear(x, self.weight, b, wscale=float(self.weight_gain))
         if self.activation in ('relu', 'lrelu'):
