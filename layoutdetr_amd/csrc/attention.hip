@@ -660,10 +660,8 @@ extern "C" int ldetr_attention_fwd_f32(const float* q, int64_t ldq, const float*
         return check_launch("attention_fwd_long");
     }
     // wide heads (the BERT text models): LDS-staged K / V shared by four query tiles per block
-    static const int wide_on = getenv("LDETR_ATTN_WIDE") ? atoi(getenv("LDETR_ATTN_WIDE")) : 3;
-    const bool wide_on_32 = (wide_on & 2) != 0;
     // (32-wide heads too when a block's four query tiles are mostly real: the DETR encoder's 64 x 64 self-attention; bit 1 of the switch)
-    if ((wide_on & 1) && (head_dim >= 64 || ((wide_on_32) && Lq >= 48)) && (ldk % 4) == 0 && (ldv % 4) == 0 && ((((uintptr_t)k) | ((uintptr_t)v)) & 15) == 0) {
+    if ((head_dim >= 64 || Lq >= 48) && (ldk % 4) == 0 && (ldv % 4) == 0 && ((((uintptr_t)k) | ((uintptr_t)v)) & 15) == 0) {
         const int nch = (Lk + 63) / 64, wgrid = B * H * ((Lq + 63) / 64);
 #define LDETR_ATTN_WIDE(NCH, DHC)                                                                                         \
     do {                                                                                                                   \
@@ -722,8 +720,7 @@ extern "C" int ldetr_attention_bwd_f32(const float* q, int64_t ldq, const float*
     const int grid = B * H * (nqt + nkt);
     hipStream_t st = (hipStream_t)stream;
     // 32-wide heads, 17..64 keys, <= 64 queries: one LDS-staged block per (batch, head) (attn_bwd_lds_kernel)
-    static const int lds_on = getenv("LDETR_ATTN_BWD_LDS") ? atoi(getenv("LDETR_ATTN_BWD_LDS")) : 1;
-    if (lds_on && head_dim == 32 && Lq <= 64 && Lk <= 64 && nkt >= 2 && (ldq % 4) == 0 && (ldk % 4) == 0 && (ldv % 4) == 0 && (lddo % 4) == 0 && (ldo % 4) == 0 &&
+    if (head_dim == 32 && Lq <= 64 && Lk <= 64 && nkt >= 2 && (ldq % 4) == 0 && (ldk % 4) == 0 && (ldv % 4) == 0 && (lddo % 4) == 0 && (ldo % 4) == 0 &&
         ((((uintptr_t)q) | ((uintptr_t)k) | ((uintptr_t)v) | ((uintptr_t)dout) | ((uintptr_t)out)) & 15) == 0) {   // (dq / dk / dv: checked above for every path)
         hipLaunchKernelGGL(attn_bwd_lds_kernel, B * H, 512, 0, st, p);
         return check_launch("attention_bwd_lds");

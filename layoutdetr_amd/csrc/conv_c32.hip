@@ -237,9 +237,8 @@ __global__ __launch_bounds__(256) void conv3x3_c32_split_kernel(ConvC32Params p)
 int try_launch_conv_c32(const float* x, const ldetr_tensor4* xt, const float* w, int Cout, int KH, int KW, int stride, int pad,
                         float* y, long ldy, int OH, int OW, const float* k_scale, long k_scale_ld, const ldetr_epilogue* ep,
                         int transposed, hipStream_t st) {
-    static const int on = getenv("LDETR_CONV_C32") ? atoi(getenv("LDETR_CONV_C32")) : 1;
     const int N = xt->N, H = xt->H, W = xt->W;
-    if (!on || KH != 3 || KW != 3 || stride != 1 || pad != 1 || xt->C != 32 || Cout != 32 || OH != H || OW != W || ldy != 32 || (W & 31)) return 0;
+    if (KH != 3 || KW != 3 || stride != 1 || pad != 1 || xt->C != 32 || Cout != 32 || OH != H || OW != W || ldy != 32 || (W & 31)) return 0;
     if (xt->sc != 1 || xt->sw != 32 || xt->sh != (long)W * 32 || xt->sn != (long)H * W * 32) return 0;
     if ((long)H * W * 128 >= 0x7fffffffL || (long)N * H * W < (1L << 18)) return 0;       // 32-bit offsets inside a sample; small grids stay on the engine
     if ((((uintptr_t)x | (uintptr_t)y | (uintptr_t)w) & 15) != 0) return 0;
@@ -261,8 +260,7 @@ int try_launch_conv_c32(const float* x, const ldetr_tensor4* xt, const float* w,
     p.waves_per_sample = wps;
     p.tiles_per_wave = (tiles + wps - 1) / wps;
     // bf16 pipe with the exact operand split unless the engine's switch puts everything on the f32 MFMAs (LDETR_CONV_C32_SPLIT=0: f32 here only)
-    static const int split_on = getenv("LDETR_CONV_C32_SPLIT") ? atoi(getenv("LDETR_CONV_C32_SPLIT")) : 1;
-    if (split_on && engine_split_enabled()) hipLaunchKernelGGL(conv3x3_c32_split_kernel, dim3((unsigned)((long)N * wps / 4)), dim3(256), 0, st, p);
+    if (engine_split_enabled()) hipLaunchKernelGGL(conv3x3_c32_split_kernel, dim3((unsigned)((long)N * wps / 4)), dim3(256), 0, st, p);
     else hipLaunchKernelGGL(conv3x3_c32_kernel, dim3((unsigned)((long)N * wps / 4)), dim3(256), 0, st, p);
     return check_launch("conv3x3_c32") == 0 ? 1 : -1;
 }

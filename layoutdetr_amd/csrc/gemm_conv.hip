@@ -1387,9 +1387,8 @@ static Workspace& workspace_for_current_device() {
 // Split-K plan of a small-tile problem: few tiles + a long reduction (the decoders' 2048-wide FFN on 144 rows) would have 40 blocks
 // walk K one after the other; split K over up to 8 blocks per tile (>= 256 of K each) and reduce through the workspace in-kernel.
 static int plan_small_split(GemmParams& p, long blocks) {
-    static const int small_split = getenv("LDETR_SMALL_SPLIT") ? atoi(getenv("LDETR_SMALL_SPLIT")) : 1;
     int sk = 1;
-    if (small_split && blocks <= 128 && p.K >= 1024) {
+    if (blocks <= 128 && p.K >= 1024) {
         sk = p.K / 256; if (sk > 8) sk = 8;
         while (sk > 1 && blocks * sk > 640) sk--;
         if (sk > 1) {
@@ -1409,7 +1408,7 @@ static int plan_small_split(GemmParams& p, long blocks) {
 }
 
 static bool small_fast_ok(const GemmParams& p, int ta, int tb) {
-    static const int on = getenv("LDETR_SMALL_FAST") ? atoi(getenv("LDETR_SMALL_FAST")) : 1;
+    static const int on = (int)knob("SMALL_FAST", 1);
     const long a_bytes = (ta ? (long)p.K * p.A.ld : (long)p.M * p.A.ld) * 4, b_bytes = (tb ? (long)p.K * p.B.ld : (long)p.N * p.B.ld) * 4;
     return on && (p.K % 32) == 0 && a_bytes < 0x7fffffffL && b_bytes < 0x7fffffffL && (ta || (p.A.ld % 4) == 0) && (tb || (p.B.ld % 4) == 0) &&
            ((((uintptr_t)p.A.p) | ((uintptr_t)p.B.p)) & 15) == 0;
@@ -1483,7 +1482,7 @@ static void init_operand(Operand& o) { memset(&o, 0, sizeof(o)); o.KW = 1; o.KH 
 #endif
 
 // Dense GEMMs with fewer 64x64 tiles than this (and at most this much work) take the register-streaming 32x32 kernel.
-static const long SMALL_GEMM_TILES = getenv("LDETR_SMALL_TILES") ? atol(getenv("LDETR_SMALL_TILES")) : 256;   // 64x64-tile count below which the small-tile kernels run
+static const long SMALL_GEMM_TILES = 256;   // 64x64-tile count below which the small-tile kernels run
 constexpr long SMALL_GEMM_MNK = 1l << 30;
 #ifndef WGRAD_MIN_K
 #define WGRAD_MIN_K 512
@@ -1542,15 +1541,14 @@ static std::atomic<int> g_split_bf16_override{-1};   // ldetr_set_split_bf16: -1
 // qualify, otherwise the generic instantiation runs.  BKT is 32 for every tile shape.
 template <int AMODE, int BMODE>
 static bool fast_operands_ok(const GemmParams& p, int Mmax) {
-    static const int fast_loads = getenv("LDETR_FAST_LOADS") ? atoi(getenv("LDETR_FAST_LOADS")) : 63;   // 1 conv, 2 dense B, 4 transposed conv, 8 dense A, 16 row-contiguous dense, 32 pixel-major (weight gradient input)
+    static const int fast_loads = (int)knob("FAST_LOADS", 63);   // 1 conv, 2 dense B, 4 transposed conv, 8 dense A, 16 row-contiguous dense, 32 pixel-major (weight gradient input)
     constexpr int BKT = 32;
     constexpr bool a_cap = (AMODE == OP_KC_CONV || AMODE == OP_KC_CONVT || AMODE == OP_KC_DENSE || AMODE == OP_RC_DENSE || AMODE == OP_RC_PIX);
     constexpr bool b_cap = (BMODE == OP_KC_DENSE || BMODE == OP_RC_WT || BMODE == OP_RC_DENSE || BMODE == OP_RC_PIX || BMODE == OP_KC_WTAP);
     if (!a_cap && !b_cap) return false;
     const long lim = 0x7fffffffL;
     auto taps_ok = [&](int C, int KH, int KW) {   // a k-tile never straddles a tap (C == k-tile measured slower: 483 vs 420 us on the 32-channel 256^2 layer)
-        static const int c32 = getenv("LDETR_NARROW_FAST") ? atoi(getenv("LDETR_NARROW_FAST")) : 1;
-        return C > 0 && (C % BKT) == 0 && C >= ((p.narrow && c32) ? BKT : 2 * BKT) && (long)KH * KW <= 32 && p.samp_pix == 0;
+        return C > 0 && (C % BKT) == 0 && C >= (p.narrow ? BKT : 2 * BKT) && (long)KH * KW <= 32 && p.samp_pix == 0;
     };
     if (AMODE == OP_KC_CONV) {
         const long padoff = (long)p.A.pad * p.A.sh + (long)p.A.pad * p.A.sw;
@@ -1643,9 +1641,7 @@ static int launch_gemm(GemmParams& p, int Mmax, long out_rows, int zbase, bool a
         // mid-size problems (ResNet layer2-4 at batch 16): the 8-wave 128x64 tile with the reduction split until its grid fills the
         // chip beats the 4-wave 64x64 tile, as long as every slice keeps >= 512 of K
         const int sk = (int)((512 + t12864 - 1) / t12864);
-        static const int split_min_k = getenv("LDETR_SPLIT_MIN_K") ? atoi(getenv("LDETR_SPLIT_MIN_K")) : 512;
-        static const int split_max = getenv("LDETR_SPLIT_MAX") ? atoi(getenv("LDETR_SPLIT_MAX")) : 8;
-        if (sk >= 2 && sk <= split_max && p.K / sk >= split_min_k) { use12864 = true; p.splitk = sk; }
+        if (sk >= 2 && sk <= 8 && p.K / sk >= 512) { use12864 = true; p.splitk = sk; }
     }
     if (!use128 && !use12864 && auto_split && p.splitk <= 1 && t64 < 768 && !(p.ep.accumulate && !epilogue_is_linear(p.ep))) {
         // PMC: with <= 2 resident blocks per CU the single-accumulator waves leave the MFMA pipe ~55% idle; more, shorter blocks fill it
@@ -1654,11 +1650,10 @@ static int launch_gemm(GemmParams& p, int Mmax, long out_rows, int zbase, bool a
         int sk = want < maxs ? want : maxs;
         if (sk >= 2) p.splitk = sk;
     }
-    {   // development override for policy sweeps (tools/sweep_policy.py): LDETR_FORCE_TILE 1 = 64x64, 2 = 128x64, 3 = 128x128; LDETR_FORCE_SK n
-        static const int ft = getenv("LDETR_FORCE_TILE") ? atoi(getenv("LDETR_FORCE_TILE")) : 0;
-        static const int fs = getenv("LDETR_FORCE_SK") ? atoi(getenv("LDETR_FORCE_SK")) : 0;
-        static const int fall = getenv("LDETR_FORCE_TILE_ALL") ? atoi(getenv("LDETR_FORCE_TILE_ALL")) : 0;   // also weight gradients / per-tap launches
-        if (ft && ((auto_split && zbase == 1) || fall)) {
+    {   // development override for policy sweeps (tools/sweep_policy.py): LDETR_DEBUG="FORCE_TILE=t,FORCE_SK=n", t: 1 = 64x64, 2 = 128x64, 3 = 128x128
+        static const int ft = (int)knob("FORCE_TILE", 0);
+        static const int fs = (int)knob("FORCE_SK", 0);
+        if (ft) {
             use128 = ft == 3 && Mmax >= 128 && p.N >= 128; use12864 = ft == 2 && Mmax >= 128;
             if (fs) { int s2 = fs; while (s2 > 1 && p.K / s2 < 64) s2--; p.splitk = (p.ep.accumulate && !epilogue_is_linear(p.ep)) ? 1 : s2; }
         }
@@ -1666,10 +1661,9 @@ static int launch_gemm(GemmParams& p, int Mmax, long out_rows, int zbase, bool a
     // Narrow outputs (N <= 32: the 32-channel 256^2 StyleGAN2 layers): a 64-wide tile leaves half of every MFMA's columns empty.
     // 256 x 32 tile, four waves stacked along M (each 64 x 32: two accumulator chains, 1.5 LDS operand reads per MFMA).
     constexpr bool narrow_cap = (AMODE == OP_KC_CONV || AMODE == OP_KC_CONVT) && (BMODE == OP_KC_DENSE || BMODE == OP_RC_WT || BMODE == OP_KC_WTAP);
-    static const int narrow_on = getenv("LDETR_NARROW_TILE") ? atoi(getenv("LDETR_NARROW_TILE")) : 1;
     bool use_narrow = false;
     if constexpr (narrow_cap) {
-        if (narrow_on && p.N <= 32 && p.N % 4 == 0 && p.splitk <= 1 && (long)cdiv(Mmax, 256) * zbase >= 512) {
+        if (p.N <= 32 && p.N % 4 == 0 && p.splitk <= 1 && (long)cdiv(Mmax, 256) * zbase >= 512) {
             use_narrow = true; use128 = use12864 = false; p.narrow = 1;
         }
     }
@@ -1709,13 +1703,11 @@ static int launch_gemm(GemmParams& p, int Mmax, long out_rows, int zbase, bool a
     // bf16 split path (see gemm_f32_kernel): the 128-row tiles and the narrow tile, scalar-addressed operands only; four waves per
     // block so that every wave owns >= two 32x32 accumulators (LDS operand bytes per MFMA halve with each doubling of the wave tile)
     constexpr bool split_cap = (AMODE == OP_KC_CONV || AMODE == OP_KC_CONVT || AMODE == OP_KC_DENSE || AMODE == OP_RC_DENSE || AMODE == OP_RC_PIX || BMODE == OP_KC_DENSE || BMODE == OP_RC_WT || BMODE == OP_RC_DENSE || BMODE == OP_RC_PIX || BMODE == OP_KC_WTAP);
-    static const int split_tiles_env = getenv("LDETR_SPLIT_BF16") ? atoi(getenv("LDETR_SPLIT_BF16")) : 15;   // bit 0: 128x128, bit 1: 128x64, bit 2: 256x32, bit 3: 64x64
-    static const int split_kinds = getenv("LDETR_SPLIT_BF16_KINDS") ? atoi(getenv("LDETR_SPLIT_BF16_KINDS")) : 7;   // bit 0: both operands k-contiguous, bit 1: one, bit 2: none (weight gradients)
-    static const int split_min_kk = getenv("LDETR_SPLIT_BF16_MIN_K") ? atoi(getenv("LDETR_SPLIT_BF16_MIN_K")) : 128;
-    constexpr int split_kind = ((AMODE <= OP_KC_WTAP) && (BMODE <= OP_KC_WTAP)) ? 1 : (((AMODE <= OP_KC_WTAP) || (BMODE <= OP_KC_WTAP)) ? 2 : 4);
+    static const int split_tiles_env = (int)knob("SPLIT_BF16", 15);   // bit 0: 128x128, bit 1: 128x64, bit 2: 256x32, bit 3: 64x64
+    constexpr int split_min_kk = 128;
     const int split_ovr = g_split_bf16_override.load(std::memory_order_relaxed);
     const int split_tiles = split_ovr >= 0 ? split_ovr : split_tiles_env;
-    const int split_on = (split_kinds & split_kind) ? split_tiles : 0;
+    const int split_on = split_tiles;
     bool sp = false;
     if constexpr (split_cap) sp = split_on && (p.K / (split ? p.splitk : 1)) >= split_min_kk && fast_operands_ok<AMODE, BMODE>(p, Mmax);
     if constexpr (narrow_cap) {
@@ -1753,7 +1745,7 @@ static int launch_gemm(GemmParams& p, int Mmax, long out_rows, int zbase, bool a
 // then split K until that tile's grid fills the chip.  Mirrors the tile thresholds of launch_gemm.
 // (conv_c32.hip follows the same switch: value_f32_mfma_only of the bench line and the f32-pipe halves of the parity tests cover it too)
 bool engine_split_enabled() {
-    static const int split_tiles_env = getenv("LDETR_SPLIT_BF16") ? atoi(getenv("LDETR_SPLIT_BF16")) : 15;
+    static const int split_tiles_env = (int)knob("SPLIT_BF16", 15);
     const int ovr = g_split_bf16_override.load(std::memory_order_relaxed);
     return (ovr >= 0 ? ovr : split_tiles_env) != 0;
 }
@@ -1761,8 +1753,7 @@ bool engine_split_enabled() {
 static int wgrad_auto_split(int M, int N, int K, int zbase) {
     // few pixels (small per-GPU batches): shorter slices keep the chip busy; the floor of a weight-gradient launch is its serial k-loop
     // (measured: 128-pixel slices help at 2 samples per GPU, 25.3 -> 24.8 ms per step, and cost 4 % at 16 per GPU: keyed on the launch's work)
-    static const int small_min_k = getenv("LDETR_WGRAD_SMALL_MIN_K") ? atoi(getenv("LDETR_WGRAD_SMALL_MIN_K")) : 128;
-    const int WMINK = ((double)M * N * K * zbase < 6e8) ? small_min_k : WGRAD_MIN_K;
+    const int WMINK = ((double)M * N * K * zbase < 6e8) ? 128 : WGRAD_MIN_K;
     auto pick = [&](long tiles, long target, int min_k) {
         long s = (target + tiles - 1) / tiles, maxs = K / min_k;
         if (s > maxs) s = maxs;
@@ -1863,17 +1854,16 @@ extern "C" int ldetr_gemm_f32(const float* A, int64_t lda, int ta, const float* 
     LDETR_CHECK(!(p.splitk > 1 && p.ep.accumulate && !epilogue_is_linear(p.ep)), "gemm: split-K + accumulate needs a linear epilogue");
     hipStream_t st = (hipStream_t)stream;
     const bool auto_split = (splitk == 0);   // splitk: 0 = let the launch policy decide, 1 = never split, >1 = explicit
-    static const int small_maxk = getenv("LDETR_SMALL_MAXK") ? atoi(getenv("LDETR_SMALL_MAXK")) : (1 << 30);
     if (p.ep.a_rowsum) {
         LDETR_CHECK(ta == 1 && lda == M, "gemm: a_rowsum needs ta == 1 and a packed A (lda == M)");
-        const bool small = auto_split && (long)cdiv(M, 64) * cdiv(N, 64) < SMALL_GEMM_TILES && (long)M * N * K <= SMALL_GEMM_MNK && tb && K <= small_maxk;
+        const bool small = auto_split && (long)cdiv(M, 64) * cdiv(N, 64) < SMALL_GEMM_TILES && (long)M * N * K <= SMALL_GEMM_MNK && tb;
         if (!small) {   // not the kernel that folds the row sums in: one column-sum pass over A = [K, M]
             int rc = ldetr_colsum_f32(A, p.ep.a_rowsum, 1, K, M, stream);
             if (rc) return rc;
             p.ep.a_rowsum = nullptr;
         }
     }
-    if (auto_split && (long)cdiv(M, 64) * cdiv(N, 64) < SMALL_GEMM_TILES && (long)M * N * K <= SMALL_GEMM_MNK && K <= small_maxk) {
+    if (auto_split && (long)cdiv(M, 64) * cdiv(N, 64) < SMALL_GEMM_TILES && (long)M * N * K <= SMALL_GEMM_MNK) {
         if (!ta && !tb) return launch_small<0, 0>(p, st);
         if (!ta && tb) return launch_small<0, 1>(p, st);
         if (ta && tb) return launch_small<1, 1>(p, st);
@@ -1890,9 +1880,8 @@ extern "C" int ldetr_gemm_f32(const float* A, int64_t lda, int ta, const float* 
 // plain small-tile problems (the usual case on the transformers' token counts) they run as ONE launch of gemm_small_pair_kernel;
 // anything else falls back to two ldetr_gemm_f32 calls in order.  Same semantics either way.
 static bool small_class(const ldetr_gemm_desc& g) {
-    static const int small_maxk = getenv("LDETR_SMALL_MAXK") ? atoi(getenv("LDETR_SMALL_MAXK")) : (1 << 30);
     if (g.splitk != 0 || g.M <= 0 || g.N <= 0 || g.K <= 0) return false;
-    return (long)cdiv(g.M, 64) * cdiv(g.N, 64) < SMALL_GEMM_TILES && (long)g.M * g.N * g.K <= SMALL_GEMM_MNK && g.K <= small_maxk;
+    return (long)cdiv(g.M, 64) * cdiv(g.N, 64) < SMALL_GEMM_TILES && (long)g.M * g.N * g.K <= SMALL_GEMM_MNK;
 }
 
 static void fill_dense(GemmParams& p, const ldetr_gemm_desc& g) {
@@ -1907,7 +1896,7 @@ static void fill_dense(GemmParams& p, const ldetr_gemm_desc& g) {
 }
 
 static bool pair_single_launch(const ldetr_gemm_desc* g0, const ldetr_gemm_desc* g1) {
-    static const int pair_on = getenv("LDETR_GEMM_PAIR") ? atoi(getenv("LDETR_GEMM_PAIR")) : 1;
+    static const int pair_on = (int)knob("GEMM_PAIR", 1);
     // the instantiated pairings: NN + TN (a linear layer's data + weight gradient) and TN + TN (the two weight gradients of the
     // feed-forward block, hip/ffn.py); a row-sum output needs a transposed, packed A
     const bool nn_tn = g0->ta == 0 && g0->tb == 1 && g1->ta == 1 && g1->tb == 1, tn_tn = g0->ta == 1 && g0->tb == 1 && g1->ta == 1 && g1->tb == 1;
@@ -2000,8 +1989,7 @@ extern "C" int ldetr_conv2d_fwd_f32(const float* x, const ldetr_tensor4* xt, con
         p.A.ld = xt->C;  // pure GEMM view of a packed NHWC tensor
         // few output tiles (the trunk's 1x1 convolutions at 2-4 samples per GPU: 32..128 tiles of 64x64 on 256 CUs): the latency-bound
         // small-tile kernel, like every other dense contraction of that class (ldetr_gemm_f32); same epilogue
-        static const int conv_small = getenv("LDETR_CONV1X1_SMALL") ? atoi(getenv("LDETR_CONV1X1_SMALL")) : 1;
-        if (conv_small && !p.ep.samp_scale && (long)cdiv(p.M, 64) * cdiv(p.N, 64) < SMALL_GEMM_TILES && (long)p.M * p.N * p.K <= SMALL_GEMM_MNK)
+        if (!p.ep.samp_scale && (long)cdiv(p.M, 64) * cdiv(p.N, 64) < SMALL_GEMM_TILES && (long)p.M * p.N * p.K <= SMALL_GEMM_MNK)
             return launch_small<0, 0>(p, st);
         return launch_gemm<OP_KC_DENSE, OP_KC_DENSE>(p, p.M, p.M, 1, true, false, st);
     }
@@ -2037,8 +2025,7 @@ extern "C" int ldetr_conv2d_bwd_data_f32(const float* dy, const ldetr_tensor4* d
     fill_epilogue(p.ep, ep);
     {   // 1x1 / stride 1 on few output tiles (the trunk at 2-4 samples per GPU): dx[M, Cin] = (dy * scale)[M, Cout] . w[Cout, Cin] as a
         // dense small-tile contraction over Cout, like the forward (ldetr_conv2d_fwd_f32)
-        static const int conv_small = getenv("LDETR_CONV1X1_SMALL") ? atoi(getenv("LDETR_CONV1X1_SMALL")) : 1;
-        if (conv_small && KH == 1 && KW == 1 && stride == 1 && pad == 0 && dyt->sw == dyt->C && dyt->sh == (long)dyt->W * dyt->C &&
+        if (KH == 1 && KW == 1 && stride == 1 && pad == 0 && dyt->sw == dyt->C && dyt->sh == (long)dyt->W * dyt->C &&
             dyt->sn == (long)dyt->H * dyt->W * dyt->C && (!dy_scale || dy_scale_ld == 0) && dyt->C % 4 == 0 && !p.ep.samp_scale &&
             (long)cdiv(p.M, 64) * cdiv(p.N, 64) < SMALL_GEMM_TILES && (long)p.M * p.N * p.K <= SMALL_GEMM_MNK) {
             GemmParams g = p;
@@ -2108,8 +2095,7 @@ extern "C" int ldetr_conv2d_bwd_weight_f32(const float* x, const ldetr_tensor4* 
             p.B.p = x; p.B.ld = Cin; p.B.vec = al16(x);
             // few output tiles and a short reduction (the trunk's 1x1 weight gradients at 2-4 samples per GPU): the small-tile kernel
             // (dw is zero or holds the running gradient at this point: accumulate; its own in-kernel split-K when the reduction is long)
-            static const int conv_small = getenv("LDETR_CONV1X1_SMALL") ? atoi(getenv("LDETR_CONV1X1_SMALL")) : 1;
-            if (conv_small && (long)cdiv(p.M, 64) * cdiv(p.N, 64) < SMALL_GEMM_TILES && (long)p.M * p.N * p.K <= SMALL_GEMM_MNK && Kpix <= 8192) {
+            if ((long)cdiv(p.M, 64) * cdiv(p.N, 64) < SMALL_GEMM_TILES && (long)p.M * p.N * p.K <= SMALL_GEMM_MNK && Kpix <= 8192) {
                 p.zmode = 0; p.ntaps = 1; p.c_tap_stride = 0; p.splitk = 1; p.ep.accumulate = 1;
                 return launch_small<1, 1>(p, st);
             }

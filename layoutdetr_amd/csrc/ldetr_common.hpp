@@ -15,6 +15,12 @@ namespace ldetr {
 
 void set_error(const char* fmt, ...);
 
+// Development knobs (tile / split-K / prefetch forcing of the sweeps, A/B switches of single kernels): ONE environment variable,
+// LDETR_DEBUG="KEY=value,KEY=value", parsed once per process (ldetr_core.cpp); a key that is not set yields the default, which is the measured
+// best.  Keys are listed in DESIGN.md ("Diagnostic switches").
+long knob(const char* key, long dflt);
+double knob_f(const char* key, double dflt);
+
 // Slice of the caller-registered workspace (ldetr_set_workspace) for the launches enqueued next; nullptr if unavailable.
 // Defined in gemm_conv.hip next to the split-K ring it shares.
 float* scratch_alloc(size_t bytes);

@@ -1,6 +1,11 @@
 // Error reporting + ABI version for the layoutdetr_amd C ABI (include/ldetr_hip.h).
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <map>
+#include <mutex>
+#include <string>
 #include "../../include/ldetr_hip.h"
 
 namespace ldetr {
@@ -10,6 +15,36 @@ void set_error(const char* fmt, ...) {
     va_start(ap, fmt);
     vsnprintf(g_err, sizeof(g_err), fmt, ap);
     va_end(ap);
+}
+
+// LDETR_DEBUG="KEY=value,KEY=value": the development knobs of every kernel's launch policy behind one variable (ldetr_common.hpp)
+static const std::map<std::string, std::string>& knobs() {
+    static std::map<std::string, std::string> m;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        const char* e = getenv("LDETR_DEBUG");
+        if (!e) return;
+        std::string s(e);
+        size_t i = 0;
+        while (i < s.size()) {
+            size_t j = s.find(',', i); if (j == std::string::npos) j = s.size();
+            const std::string kv = s.substr(i, j - i);
+            const size_t eq = kv.find('=');
+            if (eq != std::string::npos && eq > 0) m[kv.substr(0, eq)] = kv.substr(eq + 1);
+            i = j + 1;
+        }
+    });
+    return m;
+}
+long knob(const char* key, long dflt) {
+    const auto& m = knobs();
+    const auto it = m.find(key);
+    return it == m.end() ? dflt : atol(it->second.c_str());
+}
+double knob_f(const char* key, double dflt) {
+    const auto& m = knobs();
+    const auto it = m.find(key);
+    return it == m.end() ? dflt : atof(it->second.c_str());
 }
 }  // namespace ldetr
 

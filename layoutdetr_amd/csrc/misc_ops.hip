@@ -149,7 +149,7 @@ static int launch_rr(RRParams& p, hipStream_t st) {
     const int TQ = C4 < 256 ? C4 : 256;
     const int RL = 256 / TQ;
     // a few blocks per CU in total, never straddling a sample; their partial sums go through the workspace to rr_finish_kernel
-    static const long target = getenv("LDETR_RR_BLOCKS") ? atol(getenv("LDETR_RR_BLOCKS")) : 2048;
+    static const long target = 2048;
     const long groups = (long)p.B * cdiv(C4, TQ);
     long chunks = target / groups; if (chunks < 1) chunks = 1;
     long rows_pb = (p.P + chunks - 1) / chunks;
@@ -162,9 +162,8 @@ static int launch_rr(RRParams& p, hipStream_t st) {
     // atomics queue up per output cache line: 32 per block and line at ~5 ns each, i.e. ~0.16 us per sharing block -- cheaper than
     // the ~4.5 us of a second launch up to ~30 sharers (measured: 48 us vs 10 us at 256 sharers); beyond that the partial sums go
     // through the workspace to rr_finish_kernel
-    static const long finish_min = getenv("LDETR_RR_FINISH_MIN") ? atol(getenv("LDETR_RR_FINISH_MIN")) : 32;
     const long sharers = p.red1 && p.red1_bs == 0 ? nblk : (long)grid.x;     // blocks adding into one output element
-    p.part = (p.red1 || p.red2) && sharers > finish_min ? scratch_alloc((size_t)nblk * p.C * sizeof(float) * (p.red2 ? 2 : 1)) : nullptr;
+    p.part = (p.red1 || p.red2) && sharers > 32 ? scratch_alloc((size_t)nblk * p.C * sizeof(float) * (p.red2 ? 2 : 1)) : nullptr;
     if (p.mode == RR_COLSUM) hipLaunchKernelGGL(rowreduce_kernel<RR_COLSUM>, grid, 256, 0, st, p);
     else if (p.mode == RR_ACTGRAD) hipLaunchKernelGGL(rowreduce_kernel<RR_ACTGRAD>, grid, 256, 0, st, p);
     else hipLaunchKernelGGL(rowreduce_kernel<RR_MULRED>, grid, 256, 0, st, p);

@@ -1141,18 +1141,16 @@ __global__ __launch_bounds__(256) void p3_weight_prep_kernel(const long long* __
 
 // XCD array (xm x xn = 8) over an mtiles x ntiles grid minimising the bytes every L2 has to pull through the fabric: a_bytes * xn + b_bytes * xm.
 static void choose_xcd_array(int mtiles, int ntiles, double a_bytes, double b_bytes, int& xm, int& xn, long& grid_x) {
-    static const int force = getenv("LDETR_P3_XN") ? atoi(getenv("LDETR_P3_XN")) : 0;
     double best = -1.0; xm = 8; xn = 1;
     for (int n = 1; n <= 8; n *= 2) {
         const int m = 8 / n;
         if ((n > ntiles && n > 1) || (m > mtiles && m > 1)) continue;
         const double cost = a_bytes * n + b_bytes * m;
-        if (best < 0 || cost < best || (force == n)) { best = force == n ? 0.0 : cost; xm = m; xn = n; }
+        if (best < 0 || cost < best) { best = cost; xm = m; xn = n; }
     }
     grid_x = 8L * cdiv(mtiles, xm) * cdiv(ntiles, xn);
 }
 
-static int env_int(const char* name, int dflt) { const char* v = getenv(name); return v ? atoi(v) : dflt; }
 
 // The dynamic-LDS opt-in is a per-device function attribute: `raised` is one flag per device ordinal (a process that launches on a second GPU
 // must opt in there too).
@@ -1196,11 +1194,11 @@ static NtGrid plan_nt(P3NtParams& p, int sk) {
     return g;
 }
 
-// Block-slot target of the split-K / pixel-slice policies by the launch's algorithmic work: below LDETR_P3_SMALL_GFLOP (default 1.5: the trunk at a
+// Block-slot target of the split-K / pixel-slice policies by the launch's algorithmic work: below 1.5 GFLOP (the trunk at a
 // few samples per GPU) a launch is a latency chain and every extra reduction slice adds a partial-tile round trip to it -> 256 slots; above, 512
 // slots fill the chip.  2 samples per GPU 19.14 -> 18.77 ms, 4 per GPU 21.46 -> 21.02, 16 per GPU unchanged (profiles/r04_p3_sweeps.txt).
 static long slot_target(double flops, long dflt) {
-    static const double small = (getenv("LDETR_P3_SMALL_GFLOP") ? atof(getenv("LDETR_P3_SMALL_GFLOP")) : 1.5) * 1e9;
+    static const double small = 1.5 * 1e9;
     return (flops < small && dflt > 256) ? 256 : dflt;
 }
 static double nt_flops(const P3NtParams& p) { return 2.0 * p.M * p.N * p.nkt * 32.0 * (p.nclass > 1 ? p.nclass : 1); }
@@ -1211,8 +1209,7 @@ static int nt_splitk(const P3NtParams& p, int bm, int bn, long slots) {
     const long nt = (long)cdiv(p.M, bm) * cdiv(p.N, bn);
     int sk = 1;
     if (nt < slots * 3 / 4) { sk = (int)(slots / nt); if (sk > p.nkt / 4) sk = p.nkt / 4; if (sk > 16) sk = 16; if (sk < 1) sk = 1; }
-    const int force_sk = env_int("LDETR_P3_SK", 0);
-    return force_sk > 0 ? force_sk : sk;
+    return sk;
 }
 
 // 1x1 convolution without parity classes (forward incl. the strided downsample convs, stride-1 data gradients): the gather kernel's plain-GEMM loop
@@ -1247,27 +1244,19 @@ static int launch_nt(P3NtParams& p, const P3Group2& g2, bool forward, hipStream_
     // 16 x 256^2 (profiles/r04_p3_sweeps.txt: tile x prefetch depth x stage count) put 64x64 / one stage first on all but the large-grid
     // forward shapes, where the 128x128 tile's halved operand traffic wins; deeper prefetch never paid (the loads are not what these short
     // launches wait for: blocks run in lock-step through fill, loop and a chip-wide epilogue burst).
-    static const int force_tile = env_int("LDETR_P3_TILE", 0), force_pf = env_int("LDETR_P3_PF", 0), force_nst = env_int("LDETR_P3_NST", 0), force_slots = env_int("LDETR_P3_SLOTS", 0);
+    // (two LDS stages / two k-tiles of prefetch were instantiated through round 5: profiles/r04_p3_sweeps.txt, profiles/r05_p3_pf.txt.)
+    static const int force_tile = (int)knob("P3_TILE", 0);
     int cfg = 3;
     if (forward && p.nclass <= 1 && ((p.M >= 65536 && p.N >= 128) || (p.M >= 16384 && p.N >= 256 && p.nkt <= 16))) cfg = 1;
     if (force_tile) cfg = force_tile;
     const int bm = cfg == 3 ? 64 : 128, bn = (cfg == 1 || cfg == 4) ? 128 : 64;
-    const int sk = nt_splitk(p, bm, bn, force_slots ? force_slots : slot_target(nt_flops(p), (cfg == 2 || cfg == 3) ? 512 : 256));
-    const int pf = force_pf ? force_pf : 1, nst = force_nst ? force_nst : 1;
-#define P3_NT_CASE(BM_, BN_, NW_)                                                                                   \
-    switch (pf * 2 + (nst == 1 ? 0 : 1)) {                                                                          \
-        case 2: return launch_nt_cfg<BM_, BN_, NW_, 1, 1>(p, g2, sk, st);                                               \
-        case 3: return launch_nt_cfg<BM_, BN_, NW_, 1, 2>(p, g2, sk, st);                                               \
-        case 4: return launch_nt_cfg<BM_, BN_, NW_, 2, 1>(p, g2, sk, st);                                               \
-        default: return launch_nt_cfg<BM_, BN_, NW_, 2, 2>(p, g2, sk, st);                                              \
-    }
+    const int sk = nt_splitk(p, bm, bn, slot_target(nt_flops(p), (cfg == 2 || cfg == 3) ? 512 : 256));
     switch (cfg) {
-        case 1: P3_NT_CASE(128, 128, 8)
-        case 2: P3_NT_CASE(128, 64, 4)
-        case 3: P3_NT_CASE(64, 64, 4)
-        default: P3_NT_CASE(128, 128, 4)
+        case 1: return launch_nt_cfg<128, 128, 8, 1, 1>(p, g2, sk, st);
+        case 2: return launch_nt_cfg<128, 64, 4, 1, 1>(p, g2, sk, st);
+        case 3: return launch_nt_cfg<64, 64, 4, 1, 1>(p, g2, sk, st);
+        default: return launch_nt_cfg<128, 128, 4, 1, 1>(p, g2, sk, st);
     }
-#undef P3_NT_CASE
 }
 
 // 3x3 / stride 1 / pad 1 on pixel patches: returns false when the geometry does not fit (the caller then takes the gather kernel).
@@ -1292,10 +1281,8 @@ static long plan_c3(P3C3Params& p) {
     p.ntiles = cdiv(p.Nout, 64);
     const long nt = (long)p.mtiles * p.ntiles;
     int sk = 1;
-    const int force_sk = env_int("LDETR_P3_SK", 0);
     const long slots = slot_target(2.0 * p.N_img * p.H * p.W * (double)p.Nout * 9.0 * p.Cin, 512);
     if (nt < slots * 3 / 4) { sk = (int)(slots / nt); if (sk > p.ncc / 2) sk = p.ncc / 2; if (sk > 16) sk = 16; if (sk < 1) sk = 1; }
-    if (force_sk > 0) sk = force_sk;
     if (sk > p.ncc) sk = p.ncc;
     p.splitk = sk; p.ws = nullptr; p.ws_count = nullptr;
     const int ng = p.ngroups > 1 ? p.ngroups : 1;
@@ -1313,11 +1300,6 @@ static int launch_c3(P3C3Params& p, const P3Group2& g2, hipStream_t st) {
     t_last = {2, 128, 64, 4, p.splitk, p.xm, p.xn, p.ngroups > 1 ? p.ngroups : 1, 0, grid_x};
     note_engine_launch(true);
     return check_launch("p3_c3");
-}
-
-static bool c3_enabled() {
-    static const int on = env_int("LDETR_P3_PATCH", 1);
-    return on != 0;
 }
 
 static void fill_epi(P3Epi& e, const ldetr_p3_epilogue* s) {
@@ -1338,8 +1320,6 @@ static void plan_tn(P3TnParams& p, int target_blocks) {
     if (sk > nkt / 4) sk = nkt / 4;
     if (sk >= 8) sk = (sk + 4) / 8 * 8;   // a multiple of the XCD count: slice s -> XCD s % 8
     if (sk < 1) sk = 1;
-    const int force_sk = env_int("LDETR_P3_WSK", 0);
-    if (force_sk > 0) sk = std::min(force_sk, nkt);
     p.splitk = sk;
 }
 
@@ -1359,22 +1339,14 @@ static int launch_tn_cfg(P3TnParams& p, int target_blocks, hipStream_t st) {
 }
 
 static int launch_tn(P3TnParams& p, hipStream_t st) {
-    static const int force_tile = env_int("LDETR_P3_WTILE", 0), force_pf = env_int("LDETR_P3_WPF", 0), force_nst = env_int("LDETR_P3_WNST", 0), force_tb = env_int("LDETR_P3_WSLOTS", 0);
-    const int cfg = force_tile ? force_tile : 3;   // 64 x 64: the most resident waves per CU (sweep: 1179 us over the trunk shapes against 1580-1940 for the wider tiles)
-    const int pf = force_pf ? force_pf : 1, nst = force_nst ? force_nst : 1;   // one LDS stage, one pixel tile in flight: 1193 us; two stages / two tiles: 1222-1243 us
-#define P3_TN_CASE(BM_, BN_, TB_)                                                                            \
-    switch (pf * 2 + (nst == 1 ? 0 : 1)) {                                                                   \
-        case 2: return launch_tn_cfg<BM_, BN_, 1, 1>(p, force_tb ? force_tb : (int)slot_target(tn_flops(p), TB_), st);                      \
-        case 3: return launch_tn_cfg<BM_, BN_, 1, 2>(p, force_tb ? force_tb : (int)slot_target(tn_flops(p), TB_), st);                      \
-        case 4: return launch_tn_cfg<BM_, BN_, 2, 1>(p, force_tb ? force_tb : (int)slot_target(tn_flops(p), TB_), st);                      \
-        default: return launch_tn_cfg<BM_, BN_, 2, 2>(p, force_tb ? force_tb : (int)slot_target(tn_flops(p), TB_), st);                     \
+    // 64 x 64, one LDS stage, one pixel tile in flight: the most resident waves per CU (sweep over the trunk shapes: 1179 us against 1580-1940 for
+    // the wider tiles; two stages / two tiles in flight 1222-1243 us against 1193: profiles/r04_p3_sweeps.txt)
+    static const int force_tile = (int)knob("P3_WTILE", 0);
+    switch (force_tile) {
+        case 1: return launch_tn_cfg<128, 128, 1, 1>(p, (int)slot_target(tn_flops(p), 256), st);
+        case 2: return launch_tn_cfg<128, 64, 1, 1>(p, (int)slot_target(tn_flops(p), 256), st);
+        default: return launch_tn_cfg<64, 64, 1, 1>(p, (int)slot_target(tn_flops(p), 512), st);
     }
-    switch (cfg) {
-        case 1: P3_TN_CASE(128, 128, 256)
-        case 2: P3_TN_CASE(128, 64, 256)
-        default: P3_TN_CASE(64, 64, 512)
-    }
-#undef P3_TN_CASE
 }
 
 // ---- operand set-up shared by the single and the paired entry points
@@ -1385,7 +1357,7 @@ static int setup_bwd_data(const void* dy, int N, int OH, int OW, int Cout, const
                 "p3_conv2d_bwd_data: unsupported geometry (Cin=%d Cout=%d k=%dx%d stride=%d pad=%d)", Cin, Cout, KH, KW, stride, pad);
     const long dybytes = (long)N * OH * OW * Cout * 6, wbytes = (long)Cin * KH * KW * Cout * 6;
     use_c3 = false;
-    if (KH == 3 && KW == 3 && stride == 1 && pad == 1 && OH == IH && OW == IW && dybytes < 0x7fffffffL && wbytes < 0x7fffffffL && c3_enabled()) {
+    if (KH == 3 && KW == 3 && stride == 1 && pad == 1 && OH == IH && OW == IW && dybytes < 0x7fffffffL && wbytes < 0x7fffffffL) {
         memset(&c, 0, sizeof(c));
         if (c3_geometry(N, IH, IW, c)) {   // dx = conv(dy, wb) with mirrored taps: source pixel = dst + 1 - k
             c.X = (const char*)dy; c.x_bytes = (unsigned)dybytes; c.Wt = (const char*)wb; c.w_bytes = (unsigned)wbytes;
@@ -1487,7 +1459,7 @@ static int p3_conv2d_fwd_impl(const void* x, int N, int H, int W, int Cin, const
                 "p3_conv2d_fwd: unsupported geometry (Cin=%d Cout=%d k=%dx%d stride=%d pad=%d)", Cin, Cout, KH, KW, stride, pad);
     const long xbytes = (long)N * H * W * Cin * 6, wbytes = (long)Cout * KH * KW * Cin * 6, pad_off = ((long)pad * W + pad) * Cin * 6;
     LDETR_CHECK(xbytes + pad_off < 0x7fffffffL && wbytes < 0x7fffffffL && (long)N * OH * OW * Cout * 6 < (1L << 40), "p3_conv2d_fwd: tensor too large for 31-bit buffer offsets");
-    if (KH == 3 && KW == 3 && stride == 1 && pad == 1 && c3_enabled()) {
+    if (KH == 3 && KW == 3 && stride == 1 && pad == 1) {
         P3C3Params c; memset(&c, 0, sizeof(c));
         if (c3_geometry(N, H, W, c)) {
             c.X = (const char*)x; c.x_bytes = (unsigned)xbytes; c.Wt = (const char*)w; c.w_bytes = (unsigned)wbytes;
@@ -1567,10 +1539,10 @@ extern "C" int ldetr_p3_conv2d_bwd_pair(const void* dy, int N, int OH, int OW, i
     LDETR_CHECK(pt.OH == OH && pt.OW == OW, "p3_conv2d_bwd_pair: dy is %dx%d but the geometry gives %dx%d", OH, OW, pt.OH, pt.OW);
     if (launches) *launches = 0;
     if (pt.npix == 0) return LDETR_OK;
-    static const int pair_on = env_int("LDETR_P3_PAIR", 3);   // bit 0: gather kernel + weight gradient, bit 1: patch kernel + weight gradient
-    const bool forced = env_int("LDETR_P3_TILE", 0) || env_int("LDETR_P3_WTILE", 0) || env_int("LDETR_P3_PF", 0) || env_int("LDETR_P3_WPF", 0) || env_int("LDETR_P3_NST", 0);
+    static const int pair_on = (int)knob("P3_PAIR", 3);   // bit 0: gather kernel + weight gradient, bit 1: patch kernel + weight gradient
+    static const bool forced = knob("P3_TILE", 0) || knob("P3_WTILE", 0);
     if (!forced && ((use_c3 && (pair_on & 2)) || (!use_c3 && (pair_on & 1)))) {
-        plan_tn<64, 64>(pt, env_int("LDETR_P3_WSLOTS", (int)slot_target(tn_flops(pt), 512)));
+        plan_tn<64, 64>(pt, (int)slot_target(tn_flops(pt), 512));
         const long n_tn = (long)pt.splitk * pt.mtiles * pt.ntiles * pt.KH * pt.KW, n_tn_pad = (n_tn + 7) / 8 * 8;
         constexpr size_t lds_tn = (size_t)1 * (64 + 64) * 192;   // one LDS stage for the weight gradient's blocks: more blocks of either kind per CU
         if (use_c3) {

@@ -105,8 +105,7 @@ __global__ __launch_bounds__(256) void stem_conv7x7_kernel(StemParams p) {
 // Called by ldetr_conv2d_fwd_f32: returns -1 if the problem is not the stem's, else the launch status.
 int try_launch_stem_conv(const float* x, const ldetr_tensor4* xt, const float* w, int Cout, int KH, int KW, int stride, int pad,
                          float* y, long ldy, int OH, int OW, const float* in_scale, const ldetr_epilogue* ep, hipStream_t st) {
-    static const int on = getenv("LDETR_STEM_KERNEL") ? atoi(getenv("LDETR_STEM_KERNEL")) : 1;
-    if (!on || xt->C != 3 || Cout != 64 || KH != 7 || KW != 7 || stride != 2 || pad != 3 || in_scale || ldy < 64) return -1;
+    if (xt->C != 3 || Cout != 64 || KH != 7 || KW != 7 || stride != 2 || pad != 3 || in_scale || ldy < 64) return -1;
     if (ep && (ep->samp_scale || ep->residual || ep->mask_mode || ep->p_drop > 0.f || ep->accumulate || ep->a_rowsum || ep->alpha != 1.f ||
                ep->out_scale != 1.f || (ep->act != 0 && ep->act != 1)))
         return -1;

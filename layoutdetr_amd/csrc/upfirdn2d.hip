@@ -253,8 +253,7 @@ extern "C" int ldetr_upfirdn2d_f32(const float* x, const float* f, float* y,
     long total = nhwc4 ? (long)N * outH * outW * (C / 4) : (long)N * C * outH * outW;
     int grid = (int)((total + 255) / 256);
     if (grid > 256 * 32) grid = 256 * 32;
-    static const int fir_mode = getenv("LDETR_FIR_TILED") ? atoi(getenv("LDETR_FIR_TILED")) : 1;   // 0: generic kernel everywhere (development switch)
-    if (nhwc4 && fir_mode && upx == 1 && upy == 1 && downx == 1 && downy == 1 && fw == 4 && fh == 4 && (long)outH * outW >= 64) {
+    if (nhwc4 && upx == 1 && upy == 1 && downx == 1 && downy == 1 && fw == 4 && fh == 4 && (long)outH * outW >= 64) {
         // register-tiled sliding-window form: 4 columns x TR rows per thread; TR = 8 (a strip re-reads 3 rows of its neighbour), 4 when
         // 8-row strips would leave the chip under two waves per SIMD -- at 16 x 128 channels x 64 x 64 the first version's 16-row strips
         // were 128 blocks on 256 CUs (2.97 TB/s; 4.03 with 4-row strips); 2 x 4 where threads are scarce

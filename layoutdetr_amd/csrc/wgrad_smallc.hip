@@ -129,9 +129,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_c32_3x3_kernel(WgradSmallParams 
 // -> 1 if the launch was taken, 0 if the shape does not fit (the caller falls back to the per-tap implicit GEMM), < 0 on error
 int try_launch_wgrad_smallc(const float* x, const ldetr_tensor4* xt, const float* dy, const ldetr_tensor4* dyt, float* dw, int KH, int KW, int stride, int pad,
                             const float* x_scale, int64_t x_scale_ld, const float* dy_scale, int64_t dy_scale_ld, hipStream_t st) {
-    static const int on = getenv("LDETR_WGRAD_SMALLC") ? atoi(getenv("LDETR_WGRAD_SMALLC")) : 1;
     const int N = xt->N, H = xt->H, W = xt->W;
-    if (!on || KH != 3 || KW != 3 || stride != 1 || pad != 1 || xt->C != 32 || dyt->C != 32 || dyt->H != H || dyt->W != W || (W & 1)) return 0;
+    if (KH != 3 || KW != 3 || stride != 1 || pad != 1 || xt->C != 32 || dyt->C != 32 || dyt->H != H || dyt->W != W || (W & 1)) return 0;
     if (xt->sc != 1 || xt->sw != 32 || xt->sh != (long)W * 32 || xt->sn != (long)H * W * 32) return 0;
     if (dyt->sc != 1 || dyt->sw != 32 || dyt->sh != (long)W * 32 || dyt->sn != (long)H * W * 32) return 0;
     // The kernel's border handling needs a first AND a distinct last column pair (W >= 4); its vector offsets reach (W + 1) pixels past either
@@ -139,7 +138,7 @@ int try_launch_wgrad_smallc(const float* x, const ldetr_tensor4* xt, const float
     // blocks' partial sums: the result is summation-order dependent from run to run, like the engine's atomic split-K path.)
     if (W < 4 || ((long)H * W + 2L * (W + 1)) * 128 >= 0x7fffffffL || (long)N * H * W < (1L << 18)) return 0;
     // strips of whole rows, never crossing a sample; about 4 waves per SIMD-pair of the chip
-    static const int target = getenv("LDETR_WGRAD_SMALLC_WAVES") ? atoi(getenv("LDETR_WGRAD_SMALLC_WAVES")) : 2048;   // strips: 2 waves per SIMD
+    static const int target = 2048;   // strips: 2 waves per SIMD
     int rpw = (int)(((long)N * H + target - 1) / target);
     if (rpw < 1) rpw = 1;
     while (rpw > 1 && H % rpw != 0) rpw--;

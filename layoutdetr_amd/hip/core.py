@@ -36,6 +36,16 @@ class _EngineProfile(object):
 PROF = _EngineProfile()
 
 
+def knob(key, default):
+    """Development knob `key` of LDETR_DEBUG="KEY=value,KEY=value" (the one variable the kernel library reads as well: csrc/ldetr_core.cpp), as an int;
+    unset -> default (the measured best).  Keys: DESIGN.md, "Diagnostic switches"."""
+    for kv in os.environ.get('LDETR_DEBUG', '').split(','):
+        k, _, v = kv.partition('=')
+        if k.strip() == key and v.strip():
+            return int(v)
+    return default
+
+
 def engine_call(tag, flops, thunk, operands=(), nbytes=None):
     """operands: the tensors the launch must read or write at least once (its algorithmic HBM bytes = 4 x their element counts; or `nbytes`)."""
     if not PROF.enabled:
@@ -84,8 +94,6 @@ def lib():
     l = _lib.load()
     if torch.cuda.is_available():
         dev = torch.cuda.current_device()
-        if dev not in _workspace and os.environ.get('LDETR_NO_WORKSPACE'):
-            _workspace[dev] = None   # development switch: exercise the fp32-atomic split-K path
         if dev not in _workspace:
             # split-K scratch (arrival counters + partial tiles), registered once per device and kept alive here
             ws = torch.zeros(WORKSPACE_BYTES // 4, dtype=torch.float32, device=torch.device('cuda', dev))
@@ -312,7 +320,7 @@ class _ZeroArena(object):
 
 
 ZERO_ARENA = _ZeroArena()
-_ZERO_ARENA_ON = os.environ.get('LDETR_ZERO_ARENA', '1') != '0'
+_ZERO_ARENA_ON = True      # (module switch of the A/B: 0.25 ms per iteration of fill launches at B=16)
 
 
 def zero_arena_begin(device):

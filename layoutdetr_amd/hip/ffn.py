@@ -11,17 +11,16 @@ sub-block with its own residual + LayerNorm) as ONE autograd node with 3 launche
               ldetr_layernorm_bwd_parts_f32 (norm_a: incoming gradient = dz + the 32 partial sums, in slice order -> dx, d r)
 
 No atomics on the activation path: forward and input gradients are bit-reproducible run to run.  Used for token counts up to
-LDETR_FFN_FUSED_MAX_ROWS (default 512: the decoder-side stacks, 144..320 tokens, where the two linear layers are latency-bound
+MAX_ROWS (512: the decoder-side stacks, 144..320 tokens, where the two linear layers are latency-bound
 launches); the image-token encoder (1024+ rows) keeps the large-tile GEMMs.
 """
-import os
 
 import torch
 
 from . import core
 
-FUSED = os.environ.get('LDETR_FFN_FUSED', '1') != '0'
-MAX_ROWS = int(os.environ.get('LDETR_FFN_FUSED_MAX_ROWS', '512'))
+FUSED = True      # module switches (tests / A-B runs set them)
+MAX_ROWS = 512
 
 
 def usable(x2, linear1, linear2):

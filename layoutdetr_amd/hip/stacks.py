@@ -16,7 +16,6 @@ Per layer: forward 4 launches (decoder: 6), backward 5 (decoder: 7) -- for one s
 input gradients are bit-reproducible and identical whether a stack runs alone or in a group.
 """
 import math
-import os
 
 import torch
 
@@ -24,7 +23,7 @@ from .. import _lib
 from . import core
 
 D_MODEL, N_HEAD, MAX_TOKENS, MAX_ROWS, MAX_CROSS_KEYS = 256, 8, 16, 512, 64
-ENABLED = os.environ.get('LDETR_TOKEN_STACKS', '1') != '0'    # 0: every sub-block as its own autograd node on the generic kernels (A/B and equivalence tests)
+ENABLED = core.knob('TOKEN_STACKS', 1) != 0    # 0: every sub-block as its own autograd node on the generic kernels (A/B and equivalence tests)
 
 NODE_RUNS = [0]   # how many stack nodes ran (tests assert that a stack took this path)
 

@@ -8,7 +8,6 @@ every projection / FFN is one f32-MFMA GEMM with fused bias/relu/dropout, attent
 kernel per call, and each `x = norm(x + dropout(sub(x)))` is one kernel.
 """
 import copy
-import os
 from typing import Optional
 
 import torch
@@ -37,7 +36,7 @@ def _mha(m: nn.MultiheadAttention, q2, k2, v2, B, Lq, Lk, kpm, training, same_qk
                        qk_in=qk_in, kv_alias=kv_alias)
 
 
-_GROUP_KV = os.environ.get('LDETR_GROUP_KV', '1') != '0'
+_GROUP_KV = True
 
 def _mask_u8(kpm):
     """bool key-padding mask -> the uint8 form the attention kernels read: a torch.bool tensor is one byte per element holding 0 / 1, so a
@@ -191,7 +190,7 @@ class TransformerDecoder(nn.Module):
         if mem_pos2 is None:
             mem_pos2 = mem2 + pos2
         # the memory is the same for every layer (detr_transformer.py:277-280 projects it per layer): all layers' K / V projections as two
-        # GEMMs with N = layers * d, their backward as four (hip.attention._GroupedKVFn); LDETR_GROUP_KV=0 restores the per-layer launches
+        # GEMMs with N = layers * d, their backward as four (hip.attention._GroupedKVFn); _GROUP_KV = False restores the per-layer launches
         kvs = grouped_kv(mem_pos2, mem2, [l.multihead_attn for l in self.layers]) if (_GROUP_KV and len(self.layers) > 1) else None
         if kvs is not None and hstacks.ENABLED:
             prog = hstacks.Prog('dec', self.layers, t2, B, Lq, tgt_kpm, self.training, final_norm=self.norm, kvs=kvs, S=S, mem_kpm=mem_kpm)

@@ -3,7 +3,6 @@ Same class name, constructor arguments, phase names and loss composition; the de
 pl_weight=0` configuration (train.py:135-136) makes Greg/Dreg no-ops exactly as loss.py:77-80 does.
 R1 / path-length regularisation need double-backward through the fused kernels and are not implemented
 (SURVEY §7 'second-order autograd'); requesting them raises."""
-import os
 
 import torch
 import torch.nn.functional as F
@@ -85,10 +84,10 @@ class StyleGAN2Loss(Loss):
         # gradient (the reference recomputes it, training/loss.py:176-210: two run_D calls, two backward calls).  Same losses and
         # gradients up to fp32 summation order; share_D_trunk=False restores the reference's call pattern.
         self.share_D_trunk = share_D_trunk
-        # with a shared trunk, D(fake) and D(real) of Dmain also run as one batch of 2B (values identical; LDETR_PAIR_D=0 = two calls)
-        self.pair_D_passes = bool(share_D_trunk) and os.environ.get('LDETR_PAIR_D', '1') != '0'
-        self.fused_layout_losses = os.environ.get('LDETR_FUSED_LAYOUT_LOSSES', '1') != '0'   # csrc/layout_loss.hip (static-shape path)
-        self.fused_loss_tail = os.environ.get('LDETR_FUSED_LOSS_TAIL', '1') != '0'           # hip.losses.combine: a phase's tail as one launch per direction
+        # with a shared trunk, D(fake) and D(real) of Dmain also run as one batch of 2B (values identical; LDETR_DEBUG="PAIR_D=0" = two calls)
+        self.pair_D_passes = bool(share_D_trunk) and core.knob('PAIR_D', 1) != 0
+        self.fused_layout_losses = True   # csrc/layout_loss.hip (static-shape path)
+        self.fused_loss_tail = core.knob('FUSED_LOSS_TAIL', 1) != 0           # hip.losses.combine: a phase's tail as one launch per direction
         # share_D_trunk='iteration' goes one step further: D's weights do not change between the Gmain and the Dmain phase of one
         # iteration (Gmain updates G only, training_loop.py:281-313), so ONE trunk evaluation per iteration serves D(fake) in Gmain
         # (values only: D is frozen there) and both D passes of Dmain (with its autograd graph).  The iteration driver calls
@@ -112,7 +111,7 @@ class StyleGAN2Loss(Loss):
         # as one grouped launch (detr_backbone.dual_trunk_forward); G's output is parked on its body and consumed by Gmain's generator forward.
         # Not with a staged backward (its cuts are recorded inside the ordinary forward) and not for ragged backgrounds.
         g_body = self.G.backbone[0].body if hasattr(self.G, 'backbone') else None
-        dual = (stages is None and g_body is not None and isinstance(background, torch.Tensor) and os.environ.get('LDETR_DUAL_TRUNK', '1') != '0'
+        dual = (stages is None and g_body is not None and isinstance(background, torch.Tensor) and core.knob('DUAL_TRUNK', 1) != 0
                 and type(g_body) is type(body) and hasattr(body, '_entrance'))
         trunk_params = list(self.D.backbone.parameters()) + (list(self.G.backbone.parameters()) if dual else [])
         was = [p.requires_grad for p in trunk_params]
@@ -149,7 +148,7 @@ class StyleGAN2Loss(Loss):
         """G's and D's trunk on `background` as grouped launches (detr_backbone.dual_trunk_forward), parked on the two bodies for the G and D forwards
         that follow in this call.  Used where a phase evaluates both trunks itself (the reference's call pattern and phase-level sharing: Gmain's
         G + D(fake), Dmain's G + first D pass); each module's graph is built by its own replayed forward, so a frozen module gets none."""
-        if os.environ.get('LDETR_DUAL_TRUNK', '1') == '0' or not isinstance(background, torch.Tensor) or not hasattr(self.G, 'backbone') or not hasattr(self.D, 'backbone'):
+        if core.knob('DUAL_TRUNK', 1) == 0 or not isinstance(background, torch.Tensor) or not hasattr(self.G, 'backbone') or not hasattr(self.D, 'backbone'):
             return
         g_body, d_body = self.G.backbone[0].body, self.D.backbone[0].body
         if type(g_body) is not type(d_body) or not hasattr(g_body, '_entrance') or g_body.stages is not None or d_body.stages is not None:

@@ -174,6 +174,18 @@ class DataParallelStep(object):
             for s in range(0, n, self.bucket):
                 dist.all_reduce(gflat[s:min(n, s + self.bucket)])
 
+    def agree_min(self, values):
+        """Element-wise MIN of a short list of host floats over the ranks (CPU tensor under gloo, device tensor under RCCL).  Every decision that
+        shapes the sequence of collectives -- the stage count of the overlapped backward above all -- must come out the same on every rank: a rank
+        measuring 1.49 ms where its neighbour measures 1.51 would cut its gradient buffer into different segments."""
+        if self.world <= 1 or values is None:
+            return values
+        import torch.distributed as dist
+        dev = 'cuda' if dist.get_backend() == 'nccl' else 'cpu'
+        t = torch.tensor([float(v) for v in values], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        return [float(v) for v in t.cpu()]
+
     def exchange_async(self, gflat, lo, hi):
         """SUM all-reduce of gflat[lo:hi] on the communication stream, ordered after everything queued so far on the current
         stream; the current stream keeps going (the next backward stage).  `finish()` joins."""
@@ -641,6 +653,7 @@ class GraphedIteration(object):
                 ph.fm.zero_grad()
                 self.stage_ms = measure_backward_stages(loss, ph, dp, once)
             cur.wait_stream(st)
+            self.stage_ms = dp.agree_min(self.stage_ms)      # one decision for all ranks (every rank takes this branch: same phases, same batch)
             ph.module.requires_grad_(False)
             self.n_stages = backward_stage_count(b, self.stage_ms)
         d_stages = None

@@ -160,7 +160,12 @@ def _dp_worker(rank, world, port, q):
     same = torch.equal(torch.nan_to_num(fm.gflat, nan=7.0), torch.nan_to_num(expect_sum, nan=7.0))
     post = losses_ref.dp_postprocess(fm.gflat, world)
     ok_post = (post[3] == 0) and (post[5] == 1e5) and (post[7] == -1e5) and torch.isfinite(post).all().item()
-    q.put((rank, bool(same), bool(ok_post), fm.gflat.nan_to_num(7.0).sum().item()))
+    # the stage count of the overlapped backward is derived from measured stage lengths: the ranks must derive it from the SAME numbers
+    # (rank 0 measures a 1.6 ms shortest stage -> 3 stages, rank 1 1.4 ms -> 2: different segment cuts = mismatched collectives)
+    from layoutdetr_amd.training.training_loop import backward_stage_count
+    agreed = dp.agree_min([5.0, 1.6 if rank == 0 else 1.4, 2.0 + rank])
+    ok_agree = agreed == [5.0, 1.4, 2.0] and backward_stage_count(16, agreed) == 2 and dp.agree_min(None) is None
+    q.put((rank, bool(same), bool(ok_post) and ok_agree, fm.gflat.nan_to_num(7.0).sum().item()))
     dist.destroy_process_group()
 
 

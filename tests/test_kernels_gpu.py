@@ -1263,7 +1263,7 @@ def test_gemm_pair_data_and_weight_gradient(dev, tokens, N, K):
 
 def test_fast_and_generic_instantiations_agree(dev, tmp_path):
     """The scalar-addressed (FAST) kernels and the paired launch only change how addresses are formed and how work is batched:
-    a subprocess with them switched off (LDETR_FAST_LOADS=0, LDETR_SMALL_FAST=0, LDETR_GEMM_PAIR=0) must produce the same
+    a subprocess with them switched off (LDETR_DEBUG="FAST_LOADS=0,SMALL_FAST=0,GEMM_PAIR=0,SPLIT_BF16=0") must produce the same
     conv / linear forward, data gradient and weight gradient as this process, to the last bit for the tiled conv kernels
     (same reduction order) and to 1e-6 where split-K decisions may differ."""
     import subprocess, sys
@@ -1286,10 +1286,10 @@ np.savez(sys.argv[1], **out)
 '''
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     res = {}
-    for tag, env in (('fast', {}), ('generic', {'LDETR_FAST_LOADS': '0', 'LDETR_SMALL_FAST': '0', 'LDETR_GEMM_PAIR': '0'})):
+    # SPLIT_BF16=0 on both sides: the bf16 split path exists for FAST operands only -> compare the f32 MFMA pipe with itself
+    for tag, env in (('fast', {'LDETR_DEBUG': 'SPLIT_BF16=0'}), ('generic', {'LDETR_DEBUG': 'FAST_LOADS=0,SMALL_FAST=0,GEMM_PAIR=0,SPLIT_BF16=0'})):
         path = str(tmp_path / f'{tag}.npz')
         e = dict(os.environ); e.update(env); e['PYTHONPATH'] = root + os.pathsep + e.get('PYTHONPATH', '')
-        e['LDETR_SPLIT_BF16'] = '0'      # the bf16 split path exists for FAST operands only: compare the f32 MFMA pipe with itself
         subprocess.run([sys.executable, '-c', script, path], check=True, env=e, cwd=root, timeout=300, stdin=subprocess.DEVNULL)
         res[tag] = np.load(path)
     for key in res['fast'].files:

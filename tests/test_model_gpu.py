@@ -700,7 +700,7 @@ def test_text_mode_encoder_lm_full_iteration(dev):
 @pytest.mark.gpu
 @pytest.mark.parametrize('workspace', [True, False])
 def test_graph_replay_with_lm_decoder_survives_allocator_churn(dev, workspace):
-    """Guards the two hipGraph-replay faults found at the B=16 hot-path size (tools/dbg_phase.py is the full-size repro; this
+    """Guards the two hipGraph-replay faults found at the B=16 hot-path size (this
     smaller case did not trip the old code every time): (1) memset nodes (the zero-fill of the atomic split-K path) and (2) aten's
     sort-based embedding backward (> 3072 tokens) replayed with garbage.  Both are own kernels now.  Replays must stay finite and
     reproducible when eager code frees, unmaps and overwrites allocator blocks in between, with the split-K fix-up scratch

@@ -85,8 +85,7 @@ def last_launch(L):
     return dict(zip(keys, list(info)))
 
 
-SWEEP_FORCED = any(os.environ.get(v) for v in ('LDETR_P3_TILE', 'LDETR_P3_WTILE', 'LDETR_P3_PF', 'LDETR_P3_WPF', 'LDETR_P3_NST', 'LDETR_P3_SK', 'LDETR_P3_SLOTS',
-                                               'LDETR_P3_WSLOTS', 'LDETR_P3_WSK', 'LDETR_P3_XN', 'LDETR_P3_SMALL_GFLOP')) or os.environ.get('LDETR_P3_PAIR') == '0'
+SWEEP_FORCED = 'P3_' in os.environ.get('LDETR_DEBUG', '')      # a development sweep is forcing tiles / prefetch / split-K / pairing (LDETR_DEBUG="P3_TILE=..")
 
 
 def expect_launch(L, what, **want):
@@ -288,8 +287,9 @@ def test_p3_conv_backward_vs_float64(dev, L, case):
     core.check(L.ldetr_p3_conv2d_bwd_pair(core.ptr(dyp), N, OH, OW, Co, core.ptr(wb), core.ptr(xp), Ci, k, k, s, pad, H, W, ctypes.byref(ep), core.ptr(dxp2), None,
                                           core.ptr(sc), core.ptr(dw2), ctypes.byref(nl), core.stream()), 'bwd_pair')
     torch.cuda.synchronize()
-    forced = any(os.environ.get(v) for v in ('LDETR_P3_TILE', 'LDETR_P3_WTILE', 'LDETR_P3_PF', 'LDETR_P3_WPF', 'LDETR_P3_NST'))
-    want = 2 if (forced or os.environ.get('LDETR_P3_PAIR') == '0') else 1      # the development switches fall back to the two launches
+    dbg = os.environ.get('LDETR_DEBUG', '')
+    forced = any(k in dbg for k in ('P3_TILE', 'P3_WTILE', 'P3_PF', 'P3_WPF', 'P3_NST', 'P3_PAIR=0'))
+    want = 2 if forced else 1      # the development switches fall back to the two launches
     assert nl.value == want, f'expected {want} launch(es) for the pair, got {nl.value}'
     if tuple(case) in BENCH_PAIR_KIND:
         expect_launch(L, 'paired backward', kind=BENCH_PAIR_KIND[tuple(case)], ncls=(s * s if (s > 1 and BENCH_PAIR_KIND[tuple(case)] == 4) else 1))

@@ -1,6 +1,6 @@
 """One ResNet 3x3 convolution (layer2 shape at 16 samples: 16 x 32 x 32 x 128 -> 128, forward) launched 20 times on the f32 MFMA pipe or on
 the bf16 split pipe: the process `rocprofv3 --pmc ...` wraps to read the issue / busy counters of the engine's k-loop.
-  LDETR_SPLIT_BF16=0|7 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_VMEM_RD --kernel-trace --output-format csv -d out -- python tools/pmc_conv.py [bwd_data|bwd_weight]"""
+  LDETR_DEBUG=SPLIT_BF16=0|7 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_VMEM_RD --kernel-trace --output-format csv -d out -- python tools/pmc_conv.py [bwd_data|bwd_weight]"""
 import ctypes
 import os
 import sys

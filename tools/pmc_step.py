@@ -33,7 +33,7 @@ def aggregate(dir_f, dir_w, iters):
                     e[key] += (2.0 * v if key == 'fetch' else v) / iters
                     if key == 'fetch':
                         e['launches'] += 1.0 / iters
-    eng = [k for k in out if k.startswith(('gemm_', 'p3_nt_', 'p3_c3_', 'p3_tn_', 'p3_bwd_pair_', 'conv3x3_c32', 'wgrad_c32', 'stem_conv'))]   # every kernel behind hip.core.engine_call
+    eng = [k for k in out if k.startswith(('gemm_', 'p3_nt_', 'p3_c3_', 'p3_tn_', 'p3_bwd_pair_', 'conv3x3_c32', 'wgrad_c32', 'stem_conv', 'mha_small_', 'mha_cross_', 'ffn_', 'wgrad_multi'))]   # every kernel behind hip.core.engine_call
     tot = dict(fetch=sum(out[k]['fetch'] for k in eng), write=sum(out[k]['write'] for k in eng), launches=sum(out[k]['launches'] for k in eng))
     from layoutdetr_amd import build as kbuild
     return dict(csrc_digest=kbuild.source_digest(), note='rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes over tools/pmc_step.py (2 eager iterations, B=16, 256x256); bytes per ITERATION; '

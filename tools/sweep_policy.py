@@ -1,12 +1,12 @@
 """Sweep of the tiled kernel's (tile, split-K) choices over the ResNet / StyleGAN conv shapes (development aid): runs
-tools/bench_engine.py under LDETR_FORCE_TILE / LDETR_FORCE_SK and prints, per shape and pass, the policy's time next to the best
+tools/bench_engine.py under LDETR_DEBUG="FORCE_TILE=..,FORCE_SK=.." and prints, per shape and pass, the policy's time next to the best
 forced configuration.  usage: python tools/sweep_policy.py [batch]"""
 import os, re, subprocess, sys
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 B = sys.argv[1] if len(sys.argv) > 1 else '16'
 pat = re.compile(r'^(.{28}) M=\s*(\d+) N=\s*(\d+) K=\s*(\d+)\s+fwd\s+([\d.]+)us.*?bwdD\s+([\d.]+)us.*?bwdW\(sk=\s*\d+\)\s+([\d.]+)us')
 def run(env):
-    e = dict(os.environ); e.update(env); e['LDETR_BENCH_CONV_ONLY'] = '1'; e['LDETR_FORCE_TILE_ALL'] = '1'
+    e = dict(os.environ); e.update(env); e['LDETR_BENCH_CONV_ONLY'] = '1'
     out = subprocess.run([sys.executable, os.path.join(root, 'tools', 'bench_engine.py'), B], env=e, capture_output=True, text=True, stdin=subprocess.DEVNULL).stdout
     res = {}
     for line in out.splitlines():
@@ -16,7 +16,7 @@ def run(env):
     return res
 base = run({})
 cfgs = [(t, s) for t in (1, 2, 3) for s in (1, 2, 4, 8, 16)]
-allr = {c: run({'LDETR_FORCE_TILE': str(c[0]), 'LDETR_FORCE_SK': str(c[1])}) for c in cfgs}
+allr = {c: run({'LDETR_DEBUG': 'FORCE_TILE=%d,FORCE_SK=%d' % c}) for c in cfgs}
 tn = {1: '64x64', 2: '128x64', 3: '128x128'}
 tot_base = [0, 0, 0]; tot_best = [0, 0, 0]
 for name in base:

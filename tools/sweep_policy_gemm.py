@@ -1,11 +1,11 @@
 """Sweep of the tiled kernel's (tile, split-K) choices over the transformer's dense GEMM shapes (development aid; the conv shapes are
-tools/sweep_policy.py): runs tools/bench_engine.py under LDETR_FORCE_TILE / LDETR_FORCE_SK.  usage: python tools/sweep_policy_gemm.py [batch]"""
+tools/sweep_policy.py): runs tools/bench_engine.py under LDETR_DEBUG="FORCE_TILE=..,FORCE_SK=..".  usage: python tools/sweep_policy_gemm.py [batch]"""
 import os, re, subprocess, sys
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 B = sys.argv[1] if len(sys.argv) > 1 else '16'
 pat = re.compile(r'^(.{28}) M=\s*(\d+) N=\s*(\d+) K=\s*(\d+)\s+fwd\+bias\+relu\s+([\d.]+)us.*?dX\s+([\d.]+)us.*?dW\s+([\d.]+)us')
 def run(env):
-    e = dict(os.environ); e.update(env); e['LDETR_BENCH_GEMM_ONLY'] = '1'; e['LDETR_FORCE_TILE_ALL'] = '1'
+    e = dict(os.environ); e.update(env); e['LDETR_BENCH_GEMM_ONLY'] = '1'
     out = subprocess.run([sys.executable, os.path.join(root, 'tools', 'bench_engine.py'), B], env=e, capture_output=True, text=True, stdin=subprocess.DEVNULL).stdout
     res = {}
     for line in out.splitlines():
@@ -15,7 +15,7 @@ def run(env):
     return res
 base = run({})
 cfgs = [(t, s) for t in (1, 2, 3) for s in (1, 2, 4, 8)]
-allr = {c: run({'LDETR_FORCE_TILE': str(c[0]), 'LDETR_FORCE_SK': str(c[1])}) for c in cfgs}
+allr = {c: run({'LDETR_DEBUG': 'FORCE_TILE=%d,FORCE_SK=%d' % c}) for c in cfgs}
 tn = {1: '64x64', 2: '128x64', 3: '128x128'}
 for name in base:
     line = f'{name:22s}'
