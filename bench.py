@@ -327,7 +327,7 @@ def run(args, rank, local_rank, world):
                                                      note='same processes, 16 samples per GPU, no gradient exchange (= the N=1 bench workload on each GPU); compare with BENCH at N=1',
                                                      rank_ms_per_step=(l.get('diagnostics') or {}).get('rank_ms_per_step'))
                 # what strong scaling of the 16-sample step can reach before any communication: the step at 16 / N samples per GPU is bound by its
-                # launch-latency floor, not by its FLOPs (DESIGN 7)
+                # launch-latency floor, not by its FLOPs (DESIGN 8)
                 ls = measure(gbatch // world, share, local_only=True)
                 extra['strong_scaling_ceiling'] = dict(value=round(l['ms_per_step'] / ls['ms_per_step'], 3), n_gpus=world,
                                                        ms_per_step_16_per_gpu=l['ms_per_step'], ms_per_step_share=ls['ms_per_step'], per_gpu_batch_share=gbatch // world,

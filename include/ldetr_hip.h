@@ -52,7 +52,7 @@ int ldetr_debug_trace_tiles(int64_t* buffer);
 
 /* Which tiles of the contraction engine run on the bf16 matrix pipe with the exact three-way operand split (fp32 operands and
  * results, fp32-equivalent accuracy: csrc/gemm_conv.hip, gemm_f32_kernel<..., SPLIT>).  Bit 0: 128x128, bit 1: 128x64, bit 2:
- * 256x32, bit 3: 64x64; 0 = f32 MFMA everywhere; -1 = back to the default / LDETR_SPLIT_BF16.  Process-wide; returns the previous override.
+ * 256x32, bit 3: 64x64; 0 = f32 MFMA everywhere; -1 = back to the default / LDETR_DEBUG="SPLIT_BF16=..".  Process-wide; returns the previous override.
  * Used by the parity tests to run the same contraction on both pipes.  Non-finite values: the split of +-Inf is Inf + NaN + NaN, so a
  * tile whose accumulators come out non-finite is recomputed on the f32 pipe inside the same launch -- both settings return the same
  * Inf / NaN classes as an fp32 matmul (what training_loop.py:306-309's nan_to_num(0, 1e5, -1e5) then sees is therefore the same). */

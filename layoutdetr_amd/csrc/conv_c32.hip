@@ -23,7 +23,7 @@
 
 namespace ldetr {
 
-bool engine_split_enabled();      // gemm_conv.hip: ldetr_set_split_bf16 / LDETR_SPLIT_BF16 != 0
+bool engine_split_enabled();      // gemm_conv.hip: ldetr_set_split_bf16 / LDETR_DEBUG="SPLIT_BF16=0"
 
 struct ConvC32Params {
     const float* x; float* y; const float* w;                  // x, y: [N, H, W, 32] packed; w: [32 out][3][3][32 in] (OHWI)
@@ -259,7 +259,7 @@ int try_launch_conv_c32(const float* x, const ldetr_tensor4* xt, const float* w,
     if (wps > tiles) wps = (tiles + 3) & ~3;
     p.waves_per_sample = wps;
     p.tiles_per_wave = (tiles + wps - 1) / wps;
-    // bf16 pipe with the exact operand split unless the engine's switch puts everything on the f32 MFMAs (LDETR_CONV_C32_SPLIT=0: f32 here only)
+    // bf16 pipe with the exact operand split unless the engine's switch puts everything on the f32 MFMAs
     if (engine_split_enabled()) hipLaunchKernelGGL(conv3x3_c32_split_kernel, dim3((unsigned)((long)N * wps / 4)), dim3(256), 0, st, p);
     else hipLaunchKernelGGL(conv3x3_c32_kernel, dim3((unsigned)((long)N * wps / 4)), dim3(256), 0, st, p);
     return check_launch("conv3x3_c32") == 0 ? 1 : -1;

@@ -216,7 +216,7 @@ def test_training_loop_entry_runs_like_train_py_drives_it(dev, tmp_path, referen
 def test_bench_two_ranks_on_one_gpu_prints_the_scaling_schema(dev):
     """`python bench.py --gpus 2` with both ranks on cuda:0 over gloo (LDETR_BENCH_SHARE_GPU=1): the rank logic, the staged graphs, the
     overlapped exchange plumbing and -- what this test is for -- the ONE JSON line the driver's scaling sweep parses, with every diagnostic
-    field the first real multi-GPU run is read through (DESIGN 7).  No xGMI is involved; values are not asserted, the schema is."""
+    field the first real multi-GPU run is read through (DESIGN 8).  No xGMI is involved; values are not asserted, the schema is."""
     import json
     import subprocess
     import sys
