@@ -141,27 +141,31 @@ __global__ __launch_bounds__(256) void upfirdn2d_nhwc4_kernel(UpfirdnParams p) {
 
 // The StyleGAN2 up-layer FIR (upfirdn2d.py:191-198 with up = down = 1, 4x4 taps; forward pad [1,1,1,1] on the (2r+1)^2 transposed-conv
 // output, backward pad [2,2,2,2] on the (2r)^2 gradient), channels_last.  HBM-bound: 8 bytes per output element.
-// One thread = 4 channels x TC output columns x TR output rows: the 4-row x (TC+3)-column input window lives in registers and slides
-// down the strip, so each input float4 is requested (TC+3)(TR+3)/(TC*TR) ~ 2x per output instead of 16x (the generic kernel's
-// one-output-per-thread form saturates the vector L1 at 1.7 TB/s); lanes run along channels, then column blocks: every request is a
-// fully used 64..128-byte segment.
-template <int TC, int TR>
-__global__ __launch_bounds__(256) void fir4x4_nhwc4_kernel(UpfirdnParams p) {
-    __shared__ float fl[16];
-    if (threadIdx.x < 16) {
-        int ky = threadIdx.x >> 2, kx = threadIdx.x & 3;
-        // tap applied to the input sample at window offset (jy, jx): f[3-jy][3-jx], or f[jy][jx] when flipped (see the generic kernel)
-        int sy = p.flip ? ky : 3 - ky, sx = p.flip ? kx : 3 - kx;
-        fl[threadIdx.x] = p.f[sx * p.fs_w + sy * p.fs_h] * p.gain;
-    }
-    __syncthreads();
+// One thread = 4 channels x TC = 2 output columns x TR output rows, INPUT-stationary: the strip's TR + 3 input rows are walked once, each row
+// ((TC+3) float4, double-buffered in registers) is added into the up to four output rows it touches and is dead after that; the four live output
+// rows are the only state.  An input float4 is requested ~3x per output from the vector L1 instead of 16x (the generic kernel's one-output-per-
+// thread form saturates it at 1.7 TB/s); lanes run along channels, then column blocks: every request is a fully used 64..128-byte segment.
+// Per output the fma chain is (jy, jx)-ordered from 0 -- the order of the generic kernel and of the output-stationary window form of rounds 2-4
+// (177 VGPRs, 2 waves per SIMD), so results are bit-identical to both.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+__global__ __launch_bounds__(256) void fir4x4_nhwc4_kernel(UpfirdnParams p, int TR, int xcd_blocks) {
+    constexpr int TC = 2, NB = 2;
+    // taps as wave-uniform scalars: tap applied to the input sample at window offset (jy, jx) = f[3-jy][3-jx], or f[jy][jx] when flipped
     float ft[4][4];
 #pragma unroll
-    for (int i = 0; i < 16; i++) ft[i >> 2][i & 3] = fl[i];
+    for (int i = 0; i < 16; i++) {
+        const int ky = i >> 2, kx = i & 3;
+        const int sy = p.flip ? ky : 3 - ky, sx = p.flip ? kx : 3 - kx;
+        ft[ky][kx] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, p.f[sx * p.fs_w + sy * p.fs_h] * p.gain)));
+    }
     const int C4 = p.C >> 2;
     const int XB = (p.outW + TC - 1) / TC, YB = (p.outH + TR - 1) / TR;
     const long total = (long)p.N * YB * XB * C4;
-    long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    // blocks are dealt to the 8 XCDs round-robin: XCD k takes the k-th contiguous eighth of the strips, so the 3 halo rows two vertically
+    // adjacent strips share are fetched into ONE L2 (xcd_blocks = blocks per XCD, 0 = identity)
+    const long blk = xcd_blocks ? (long)(blockIdx.x & 7) * xcd_blocks + (blockIdx.x >> 3) : blockIdx.x;
+    long idx = blk * blockDim.x + threadIdx.x;
     if (idx >= total) return;
     const int c = (int)(idx % C4) << 2;
     long t = idx / C4;
@@ -175,42 +179,63 @@ __global__ __launch_bounds__(256) void fir4x4_nhwc4_kernel(UpfirdnParams p) {
     bool colok[TC + 3];
 #pragma unroll
     for (int j = 0; j < TC + 3; j++) colok[j] = (unsigned)(ix0 + j) < (unsigned)p.inW;
-    float4 win[4][TC + 3];
+    float4 row[NB][TC + 3];      // NB - 1 rows of loads in flight ahead of the row being consumed
     auto load_row = [&](int slot, int iy) {
         const bool rowok = (unsigned)iy < (unsigned)p.inH;
         const float* rp = xb + (long)iy * p.xs_h + (long)ix0 * p.xs_w;
 #pragma unroll
         for (int j = 0; j < TC + 3; j++)
-            win[slot][j] = (rowok && colok[j]) ? *reinterpret_cast<const float4*>(rp + j * p.xs_w) : make_float4(0.f, 0.f, 0.f, 0.f);
+            row[slot][j] = (rowok && colok[j]) ? *reinterpret_cast<const float4*>(rp + j * p.xs_w) : make_float4(0.f, 0.f, 0.f, 0.f);
     };
-#pragma unroll
-    for (int r = 0; r < 3; r++) load_row(r, iy0 + r);
     float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
     if (p.has_act && p.bias) bias4 = *reinterpret_cast<const float4*>(p.bias + c);
+    float4 acc[4][TC];
 #pragma unroll
-    for (int oy = 0; oy < TR; oy++) {
-        load_row((oy + 3) & 3, iy0 + oy + 3);
-        if (y0 + oy < p.outH) {
+    for (int i = 0; i < 4; i++)
 #pragma unroll
-            for (int ox = 0; ox < TC; ox++) {
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int ox = 0; ox < TC; ox++) acc[i][ox] = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int nrows = TR + 3;
 #pragma unroll
-                for (int jy = 0; jy < 4; jy++) {
+    for (int i = 0; i < NB - 1; i++) load_row(i, iy0 + i);
+    for (int r0 = 0; r0 < nrows; r0 += 4) {
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int r = r0 + k;
+            if (r >= nrows) break;
+            load_row((k + NB - 1) % NB, r + NB - 1 < nrows ? iy0 + r + NB - 1 : -1);
+            // input row r is tap row jy of output row oy = r - jy (accumulator slot (k - jy) & 3); for a fixed output row the rows arrive in the order
+            // jy = 0, 1, 2, 3.  Slots of rows above / below the strip collect sums that are never stored.
+#pragma unroll
+            for (int jy = 3; jy >= 0; jy--) {
+#pragma unroll
+                for (int ox = 0; ox < TC; ox++) {
+                    float4 v = acc[(k - jy) & 3][ox];
+                    f32x2 lo = {v.x, v.y}, hi = {v.z, v.w};      // packed fp32 FMAs (v_pk_fma_f32): the same two roundings per element pair
 #pragma unroll
                     for (int jx = 0; jx < 4; jx++) {
-                        const float4 xv = win[(oy + jy) & 3][ox + jx];
-                        const float fv = ft[jy][jx];
-                        v.x = fmaf(xv.x, fv, v.x); v.y = fmaf(xv.y, fv, v.y); v.z = fmaf(xv.z, fv, v.z); v.w = fmaf(xv.w, fv, v.w);
+                        const float4 xv = row[k % NB][ox + jx];
+                        const f32x2 fv = {ft[jy][jx], ft[jy][jx]};
+                        lo = __builtin_elementwise_fma(f32x2{xv.x, xv.y}, fv, lo); hi = __builtin_elementwise_fma(f32x2{xv.z, xv.w}, fv, hi);
                     }
+                    acc[(k - jy) & 3][ox] = make_float4(lo.x, lo.y, hi.x, hi.y);
                 }
-                if (p.has_act) {
-                    v.x += bias4.x; v.y += bias4.y; v.z += bias4.z; v.w += bias4.w;
-                    v.x = (v.x > 0.f ? v.x : v.x * p.act_alpha) * p.act_gain; v.y = (v.y > 0.f ? v.y : v.y * p.act_alpha) * p.act_gain;
-                    v.z = (v.z > 0.f ? v.z : v.z * p.act_alpha) * p.act_gain; v.w = (v.w > 0.f ? v.w : v.w * p.act_alpha) * p.act_gain;
-                }
-                if (x0 + ox < p.outW)
-                    *reinterpret_cast<float4*>(yb + (long)(y0 + oy) * p.ys_h + (long)(x0 + ox) * p.ys_w) = v;
             }
+            const int oy = r - 3;      // complete with this row (slot (k + 1) & 3)
+            if (oy >= 0 && y0 + oy < p.outH) {
+#pragma unroll
+                for (int ox = 0; ox < TC; ox++) {
+                    float4 v = acc[(k + 1) & 3][ox];
+                    if (p.has_act) {
+                        v.x += bias4.x; v.y += bias4.y; v.z += bias4.z; v.w += bias4.w;
+                        v.x = (v.x > 0.f ? v.x : v.x * p.act_alpha) * p.act_gain; v.y = (v.y > 0.f ? v.y : v.y * p.act_alpha) * p.act_gain;
+                        v.z = (v.z > 0.f ? v.z : v.z * p.act_alpha) * p.act_gain; v.w = (v.w > 0.f ? v.w : v.w * p.act_alpha) * p.act_gain;
+                    }
+                    if (x0 + ox < p.outW)
+                        *reinterpret_cast<float4*>(yb + (long)(y0 + oy) * p.ys_h + (long)(x0 + ox) * p.ys_w) = v;
+                }
+            }
+#pragma unroll
+            for (int ox = 0; ox < TC; ox++) acc[(k + 1) & 3][ox] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
     }
 }
@@ -254,18 +279,16 @@ extern "C" int ldetr_upfirdn2d_f32(const float* x, const float* f, float* y,
     int grid = (int)((total + 255) / 256);
     if (grid > 256 * 32) grid = 256 * 32;
     if (nhwc4 && upx == 1 && upy == 1 && downx == 1 && downy == 1 && fw == 4 && fh == 4 && (long)outH * outW >= 64) {
-        // register-tiled sliding-window form: 4 columns x TR rows per thread; TR = 8 (a strip re-reads 3 rows of its neighbour), 4 when
-        // 8-row strips would leave the chip under two waves per SIMD -- at 16 x 128 channels x 64 x 64 the first version's 16-row strips
-        // were 128 blocks on 256 CUs (2.97 TB/s; 4.03 with 4-row strips); 2 x 4 where threads are scarce
+        // input-stationary register form: 2 columns x TR rows per thread, TR = 8 (a strip re-reads 3 rows of its neighbour), 4 where threads are
+        // scarce; strips dealt to the XCDs in contiguous eighths.  Round-5 sweep (profiles/r05_fir_sweep.txt): columns per thread 2 / 4, strip
+        // height 4..64, 1 or 3 rows of loads in flight, 2..4 waves per SIMD, packed or scalar FMAs all land at 4.9-5.5 TB/s on 16 x 32 x 256^2;
+        // only the XCD mapping moved it (+3..8 %): what bounds this kernel is none of occupancy, halo traffic or VALU issue
         const bool big = (long)N * outH * outW * (C / 4) >= (1L << 20);
-        const long cols4 = (long)N * ((outW + 3) / 4) * (C / 4);
-        int TC = big ? 4 : 2, TR = big ? 8 : 4;
-        if (big && cols4 * ((outH + 7) / 8) < (1L << 17)) TR = 4;
-        long threads = (long)N * ((outH + TR - 1) / TR) * ((outW + TC - 1) / TC) * (C / 4);
-        int g = (int)((threads + 255) / 256);
-        if (big && TR == 8) hipLaunchKernelGGL((fir4x4_nhwc4_kernel<4, 8>), g, 256, 0, st, p);
-        else if (big) hipLaunchKernelGGL((fir4x4_nhwc4_kernel<4, 4>), g, 256, 0, st, p);
-        else hipLaunchKernelGGL((fir4x4_nhwc4_kernel<2, 4>), g, 256, 0, st, p);
+        const int TC = 2, TR = big ? 8 : 4;
+        const long threads = (long)N * ((outH + TR - 1) / TR) * ((outW + TC - 1) / TC) * (C / 4);
+        int g = (int)((threads + 255) / 256), xcd_blocks = 0;
+        if (g >= 64) { g = (g + 7) / 8 * 8; xcd_blocks = g / 8; }
+        hipLaunchKernelGGL(fir4x4_nhwc4_kernel, g, 256, 0, st, p, TR, xcd_blocks);
     } else if (nhwc4) hipLaunchKernelGGL(upfirdn2d_nhwc4_kernel, grid, 256, 0, st, p);
     else hipLaunchKernelGGL(upfirdn2d_planar_kernel, grid, 256, 0, st, p);
     return check_launch("upfirdn2d");

@@ -1414,3 +1414,36 @@ def test_split_bf16_conv_fwd_bwd_is_fp32_equivalent(dev):
         print(f'conv {name}: f32 pipe max {m0:.2e} rms {r0:.2e} | bf16 split max {m1:.2e} rms {r1:.2e}')
         assert name == 'dw' or not torch.equal(a, b), name + ': the split tiles were not exercised'
         assert r1 <= 1.25 * r0 + 1e-9 and m1 <= 2.0 * m0 + 1e-9 and m1 < 5e-6, name
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('B,P,C', [(16, 4096, 32), (2, 65536, 32), (16, 64, 512), (1, 3000, 64), (3, 50, 1280), (16, 16, 512)])
+def test_row_reductions_all_paths_vs_fp64(dev, B, P, C):
+    """ldetr_colsum_f32 / ldetr_act_bwd_reduce_f32 / ldetr_mul_reduce_f32 (training/networks_stylegan2.py:66-72, bias_act backward + bias / demodulation
+    gradients) over shapes that take the direct-atomic path (<= 32 sharing blocks) and the two-stage path (partial sums through the workspace + rr_finish_kernel)
+    with per-sample outputs and with an output shared by the batch, more than 1024 channels (channel chunks in grid.z) and ragged row counts; outputs
+    accumulate INTO their destination.  Run twice (the workspace ring moves on)."""
+    from layoutdetr_amd.hip import core
+    from layoutdetr_amd.hip.linear import act_backward
+    from layoutdetr_amd.hip.modconv import _mul_reduce
+    g = torch.Generator(device='cpu').manual_seed(B * 1000 + C)
+    dy = torch.randn(B * P, C, generator=g); y = torch.randn(B * P, C, generator=g)
+    bias = torch.randn(C, generator=g); demod = torch.rand(B, C, generator=g) + 0.5; scale = torch.randn(B, C, generator=g)
+    dyd, yd, bd, dd, sd = (t.to(dev) for t in (dy, y, bias, demod, scale))
+    alpha, gain = 0.2, 2 ** 0.5
+    for rep in range(2):
+        # column sums per sample
+        red = core.colsum(dyd, B)
+        ref = dy.double().reshape(B, P, C).sum(1)
+        assert rel_err(red, ref) < 2e-6, ('colsum', rep)
+        # lrelu backward + bias gradient (shared by the batch, accumulated into an existing buffer) + demodulation gradient (per sample)
+        dbias = torch.full((C,), 3.0, device=dev)
+        dv, _, ddemod = act_backward(dyd, yd, core.ACT_LRELU, alpha, gain, True, bias=bd, demod=dd, want_ddemod=True, B=B, dbias_out=dbias)
+        dvr = dy.double() * torch.where(y > 0, gain, gain * alpha)
+        pre = torch.where(y > 0, y.double() / gain, y.double() / (gain * alpha)) - bias.double()
+        ddr = (dvr * pre).reshape(B, P, C).sum(1) / demod.double()
+        assert rel_err(dv, dvr) < 1e-6 and rel_err(dbias - 3.0, dvr.sum(0)) < 5e-6 and rel_err(ddemod, ddr) < 5e-6, ('act_bwd_reduce', rep)
+        # modulation backward: out = a * scale[b], red[b] = sum_rows a * x
+        out, red2 = _mul_reduce(dyd, yd, sd, B, P, C)
+        assert rel_err(out.reshape(B, P, C), dy.double().reshape(B, P, C) * scale.double()[:, None]) < 1e-6, ('mul_reduce out', rep)
+        assert rel_err(red2, (dy.double() * y.double()).reshape(B, P, C).sum(1)) < 5e-6, ('mul_reduce red', rep)

@@ -1,6 +1,6 @@
 """Stand-alone rates of the HBM-bound kernels at the StyleGAN2 Decoder's 256x256 / 128x128 shapes (B=16): upfirdn2d (up-layer FIR),
 bias_act forward / backward.  Algorithmic bytes per SURVEY 8(d): FIR 8 B per output element, bias_act 8 (fwd) / 12 (bwd).
-hipGraph-replayed (no host gaps), HIP events around the replay.   python tools/bench_hbm_kernels.py"""
+hipGraph-replayed (no host gaps), HIP events around the replay.   python tools/bench_hbm_kernels.py [short]"""
 import os
 import sys
 
@@ -132,5 +132,5 @@ if __name__ == '__main__':
     for r in measure():
         print(f"{r['kernel']:32s} {r['shape']:18s} {r['bytes'] / 1e6:8.1f} MB {r['us']:8.1f} us {r['tbps']:6.2f} TB/s ({r['tbps'] / 8.0:.2f} of 8 TB/s)")
     import json
-    for r in measure_named()[-6:]:
+    for r in ([] if 'short' in sys.argv[1:] else measure_named()[-6:]):
         print(json.dumps(r))
