@@ -12,8 +12,8 @@ class _AddLnFn(torch.autograd.Function):
         ctx.set_materialize_grads(False)
         D = x.shape[-1]
         x2 = core.f32c(x.reshape(-1, D))
-        # a 3-D residual [S, rows, D] is a sum still to be formed: r = r_bias + sum_s r[s] (the per-head contributions of the fused
-        # self-attention block, hip.attention.self_attention_parts), added in slice order inside this launch
+        # a 3-D residual [S, rows, D] is a sum still to be formed: r = r_bias + sum_s r[s] (per-head / per-slice contributions of a fused
+        # sub-block), added in slice order inside this launch
         n_parts = r.shape[0] if (r is not None and r.dim() == 3 and x.dim() == 2) else 0
         r2 = (core.f32c(r) if n_parts else core.f32c(r.reshape(-1, D))) if r is not None else None
         rb = core.f32c(r_bias) if (n_parts and r_bias is not None) else None

@@ -182,11 +182,11 @@ def test_fused_ffn_stacks_equal_unfused_stacks(dev, flat):
 
 @pytest.mark.parametrize('flat,train', [(False, False), (True, False), (True, True)])
 def test_fused_self_attention_stacks_equal_unfused_stacks(dev, flat, train):
-    """The <= 16-token stacks with the one-launch self-attention forward (csrc/mha_small.hip: projection + attention + per-head output
-    projection, summed by the LayerNorm launch) against the three-launch path: TransformerWithToken's decoder (10 tokens x 16 samples) and
-    a 6-layer token encoder (9 x 16, ragged key-padding masks), outputs, input gradients and every parameter gradient.  train=True: both
-    paths draw their dropout seeds in the same order and index the attention mask identically, so they must still agree (the backward of
-    the fused block is ldetr_attention_bwd_f32 regenerating the fused forward's mask)."""
+    """The <= 16-token stacks as ONE autograd node per stack (hip/stacks.py: group launches of csrc/mha_small.hip / ffn_fused.hip / layernorm.hip,
+    gradients between sub-blocks as partial sums, attention backward and the layer's weight gradients as one launch each) against the
+    per-sub-block path on the generic kernels (stacks.ENABLED = False): TransformerWithToken's decoder (10 tokens x 16 samples) and a 6-layer
+    token encoder (9 x 16, ragged key-padding masks): outputs, input gradients and every parameter gradient.  train=True: both paths draw their
+    dropout seeds in the same order and index the attention mask identically, so they must still agree."""
     from layoutdetr_amd.hip import stacks as A
     from layoutdetr_amd.hip import core
     from layoutdetr_amd.training import detr_transformer as T
