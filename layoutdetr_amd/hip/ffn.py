@@ -148,3 +148,68 @@ def add_ln_ffn_add_ln(x, r, norm_a, p_a, linear1, linear2, norm_b, p_hidden=0.0,
     (-> (y, y + pos))."""
     return _LnFfnLnFn.apply(x, r, norm_a.weight, norm_a.bias, norm_a.eps, p_a, linear1.weight, linear1.bias, linear2.weight, linear2.bias,
                             norm_b.weight, norm_b.bias, norm_b.eps, p_hidden, p_b, pos, r_bias)
+
+
+class _FfnLargeFn(torch.autograd.Function):
+    """linear2(dropout(relu(linear1(x)))) above the fused launch's token limit (the 64-token encoders: 1024+ rows) as ONE autograd node around the
+    engine's GEMMs: forward = the two launches of two hip.linear nodes (same epilogues, same dropout element index); backward = 3 launches instead
+    of 5: the hidden gradient dH = (dY W2) * relu'(h) / keep comes out of the first GEMM's epilogue (mask from the saved hidden activation: a dropped
+    or rectified element is 0 there), so no activation-gradient pass reads and rewrites it; both weight gradients (+ bias gradients as row sums of
+    their transposed operands) are one paired launch; dX = dH W1 takes the residual-path gradient in its epilogue.  Returns (y, alias of x): the
+    residual branch reads x through the alias, so this node is x's only consumer (hip.linear._LinearFn.forward)."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2, p_hidden):
+        core.require_gpu(x, w1, b1, w2, b2)
+        ctx.set_materialize_grads(False)
+        D, F = w1.shape[1], w1.shape[0]
+        x2 = core.f32c(x.reshape(-1, D))
+        W1, B1, W2, B2 = core.f32c(w1.detach()), core.f32c(b1.detach()), core.f32c(w2.detach()), core.f32c(b2.detach())
+        M = x2.shape[0]
+        seed = core.next_seed() if p_hidden > 0 else 0
+        h = core.gemm(x2, W1, 0, 0, M, F, D, ep=core.epilogue(col_bias=B1, act=core.ACT_RELU, p_drop=p_hidden, seed=seed))
+        y = core.gemm(h, W2, 0, 0, M, D, F, ep=core.epilogue(col_bias=B2))
+        ctx.save_for_backward(x2, h, W1, W2)
+        ctx.cfg = (x.shape, D, F, M, p_hidden)
+        ctx.params = (w1, b1, w2, b2)
+        return y.reshape(x.shape), x
+
+    @staticmethod
+    def backward(ctx, dy, dx_pass=None):
+        x2, h, W1, W2 = ctx.saved_tensors
+        xshape, D, F, M, p_hidden = ctx.cfg
+        w1, b1, w2, b2 = ctx.params
+        if dy is None:
+            return (dx_pass,) + (None,) * 5
+        dy2 = core.f32c(dy.reshape(-1, D))
+        need_x = ctx.needs_input_grad[0]
+        need_w = any(ctx.needs_input_grad[1:5]) and not core.WEIGHT_GRADIENTS_DISABLED[0]
+        # dH = (dY W2) masked by the saved hidden activation, 1 / keep folded into alpha
+        dh = core.gemm(dy2, W2, 0, 1, M, F, D, ep=core.epilogue(alpha=1.0 / (1.0 - p_hidden) if p_hidden > 0 else 1.0, mask_src=h, mask_mode=1))
+        out_w = [None] * 4
+        if need_w:
+            flat = [core.flat_grad(t) for t in (w1, b1, w2, b2)]
+            if all(f is not None and f.is_contiguous() for f in flat):
+                tgt = flat
+            else:
+                tgt = [torch.zeros_like(t, memory_format=torch.contiguous_format) for t in (w1, b1, w2, b2)]
+                out_w = tgt
+            core.gemm_pair(dict(A=dy2, B=h, ta=1, tb=1, M=D, N=F, K=M, out=tgt[2], ep=core.epilogue(accumulate=True, a_rowsum=tgt[3])),
+                           dict(A=dh, B=x2, ta=1, tb=1, M=F, N=D, K=M, out=tgt[0], ep=core.epilogue(accumulate=True, a_rowsum=tgt[1])))
+        dx = None
+        if need_x:
+            res = core.f32c(dx_pass.reshape(-1, D)) if dx_pass is not None else None
+            dx = core.gemm(dh, W1, 0, 1, M, D, F, ep=core.epilogue(residual=res)).reshape(xshape)
+        elif dx_pass is not None:
+            dx = dx_pass
+        return dx, out_w[0], out_w[1], out_w[2], out_w[3], None
+
+
+def large_usable(x2, linear1, linear2):
+    return (FUSED and x2.is_cuda and x2.dtype == torch.float32 and linear1.bias is not None and linear2.bias is not None
+            and linear1.weight.shape[0] % 4 == 0 and linear1.weight.shape[1] % 4 == 0)
+
+
+def ffn_large(x, linear1, linear2, p_hidden=0.0):
+    """-> (linear2(dropout(relu(linear1(x)))), alias of x for the residual branch)."""
+    return _FfnLargeFn.apply(x, linear1.weight, linear1.bias, linear2.weight, linear2.bias, p_hidden)

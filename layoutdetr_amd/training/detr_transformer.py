@@ -51,6 +51,8 @@ def _mask_u8(kpm):
 def _ffn(layer, x2):
     """-> (FFN output, alias of x2 for the residual branch)."""
     p = layer.dropout.p if layer.training else 0.0
+    if hffn.large_usable(x2, layer.linear1, layer.linear2):
+        return hffn.ffn_large(x2, layer.linear1, layer.linear2, p)
     h, x2 = linear(x2, layer.linear1.weight, layer.linear1.bias, act=core.ACT_RELU, p_drop=p, passthru=True)
     return linear(h, layer.linear2.weight, layer.linear2.bias), x2
 

@@ -996,3 +996,45 @@ def test_decoder_mapping_latent_forms_and_truncation(dev):
         before = m.mapping.w_avg.clone()
         m(z, update_emas=True)
         check(m.mapping.w_avg, w.mean(0).lerp(before, m.mapping.w_avg_beta), 1e-6, 'w_avg tracking')
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('rows,train', [(1024, False), (2048, True), (640, True)])
+def test_large_ffn_node_equals_two_linear_nodes(dev, rows, train):
+    """hip.ffn.ffn_large (the feed-forward block of the 64-token encoders above the fused launch's token limit as one autograd node: hidden gradient
+    out of the first GEMM's epilogue, both weight gradients as one paired launch) against the two hip.linear nodes it replaces
+    (detr_transformer.py:210-214): output, input gradient incl. the residual branch through the alias, and all four parameter gradients, with the
+    hidden dropout on (same seed order, same element index -> same mask) and off."""
+    from layoutdetr_amd.hip import core, ffn as hffn
+    from layoutdetr_amd.hip.linear import linear
+    from layoutdetr_amd.training.training_loop import FlatModule
+
+    def rel_err(a, b):
+        return ((a.double() - b.double()).abs().max() / (b.double().abs().max() + 1e-12)).item()
+    torch.manual_seed(5)
+    lin1, lin2 = torch.nn.Linear(256, 2048).to(dev), torch.nn.Linear(2048, 256).to(dev)
+    mod = torch.nn.ModuleList([lin1, lin2])
+    fm = FlatModule(mod)
+    x0 = torch.randn(rows, 256, device=dev)
+    dy = torch.randn(rows, 256, device=dev)
+    p = 0.1 if train else 0.0
+
+    def run(fused):
+        fm.zero_grad()
+        x = x0.clone().requires_grad_(True)
+        core._seed_counter[0] = 1000        # the same dropout seed for both paths (the per-iteration device word is not re-drawn in between)
+        if fused:
+            f, xa = hffn.ffn_large(x, lin1, lin2, p)
+        else:
+            h, xa = linear(x, lin1.weight, lin1.bias, act=core.ACT_RELU, p_drop=p, passthru=True)
+            f = linear(h, lin2.weight, lin2.bias)
+        y = xa * 0.5 + f            # the residual branch reads x through the alias
+        y.backward(dy)
+        return y.detach().clone(), x.grad.clone(), fm.gflat.clone()
+
+    ya, dxa, ga = run(False)
+    yb, dxb, gb = run(True)
+    assert torch.equal(ya, yb), 'forward: the node launches the same two GEMMs'
+    assert rel_err(dxb, dxa) < 2e-6, rel_err(dxb, dxa)
+    assert rel_err(gb, ga) < 1e-5, rel_err(gb, ga)
+    assert float((ya == 0).float().mean()) < 0.01 and float(gb.abs().max()) > 0
