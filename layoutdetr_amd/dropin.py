@@ -117,6 +117,7 @@ _ALIASES = {
     'training.detr_transformer': 'layoutdetr_amd.training.detr_transformer',
     'training.detr_backbone': 'layoutdetr_amd.training.detr_backbone',
     'training.networks_stylegan2': 'layoutdetr_amd.training.networks_stylegan2',
+    'training.dataset_layoutganpp': 'layoutdetr_amd.training.dataset_layoutganpp',     # train.py:107 names the dataset class through this module
     'torch_utils.ops.bias_act': 'layoutdetr_amd.torch_utils.ops.bias_act',
     'torch_utils.ops.upfirdn2d': 'layoutdetr_amd.torch_utils.ops.upfirdn2d',
     'torch_utils.ops.conv2d_resample': 'layoutdetr_amd.torch_utils.ops.conv2d_resample',

@@ -801,7 +801,10 @@ def training_loop(run_dir='.', training_set_kwargs={}, validation_set_kwargs={},
         print('Loading training set...')
     training_set = construct_class_by_name(**training_set_kwargs)
     sampler = InfiniteSampler(dataset=training_set, rank=rank, num_replicas=num_gpus, seed=random_seed)
-    it = iter(torch.utils.data.DataLoader(dataset=training_set, sampler=sampler, batch_size=batch_size // num_gpus, **data_loader_kwargs))
+    dl_kwargs = dict(data_loader_kwargs)
+    if getattr(training_set, 'mode', None) == 'device' and hasattr(training_set, 'collate'):
+        dl_kwargs.setdefault('collate_fn', training_set.collate)     # uint8 pages + 0-stride patch placeholder (dataset_layoutganpp.LayoutDataset)
+    it = iter(torch.utils.data.DataLoader(dataset=training_set, sampler=sampler, batch_size=batch_size // num_gpus, **dl_kwargs))
     common = dict(num_bbox_labels=training_set.num_bbox_labels, img_channels=training_set.num_channels, img_height=training_set.height,
                   img_width=training_set.width, background_size=training_set.background_size_for_training, c_dim=training_set.label_dim)
     if rank == 0:
@@ -846,9 +849,11 @@ def training_loop(run_dir='.', training_set_kwargs={}, validation_set_kwargs={},
         if isinstance(texts, list):     # strings -> tokens ONCE per iteration (the reference re-tokenises inside each of the 5 G/D forwards)
             from .networks_detr import _coerce_text
             texts = _coerce_text(G, texts, device)
+        from .dataset_layoutganpp import batch_backgrounds_to_device, patch_placeholder_to_device
         batch = dict(bbox_real=samples['bboxes'].to(device).float(), bbox_class=samples['labels'].to(device).long(), bbox_text=texts,
-                     bbox_patch=samples['patches'].to(device), padding_mask=~samples['mask'].to(device).bool(),
-                     background=samples['background'].to(device).float(), real_c=real_c.to(device))
+                     bbox_patch=patch_placeholder_to_device(samples['patches'], device), padding_mask=~samples['mask'].to(device).bool(),
+                     background=batch_backgrounds_to_device(samples['background'], training_set.background_size_for_training, device),
+                     real_c=real_c.to(device))
         # :257-263: one set of latents AND one set of conditioning labels (labels of random dataset items) PER PHASE
         gen_z = [torch.randn(b, batch['bbox_class'].shape[1], G.z_dim, device=device) for _ in phases]
         if labelled:
