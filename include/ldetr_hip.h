@@ -30,6 +30,8 @@
  *                                 PIL resize + normalise of the page background: training/dataset_layoutganpp.py:330-338
  *   ldetr_lsap_f64                scipy.optimize.linear_sum_assignment as used at metrics/metric_layoutnet.py:111,125,240
  *   ldetr_box_giou_pairwise_f32   box_cxcywh_to_xyxy + box_iou + generalized_box_iou: detr_util/box_ops.py:19-71
+ *   ldetr_bmm_strided_f32         torch.bmm inside nn.MultiheadAttention when the regulariser phases differentiate it twice:
+ *                                 training/loss.py:119-142 (path length), 207-215 (R1); hip/composite.py
  */
 #ifndef LDETR_HIP_H
 #define LDETR_HIP_H
@@ -446,6 +448,14 @@ int ldetr_lsap_f64(const double* cost, int batch, int n, int maximize, int* row_
  * the reference's Inf / NaN; the reference's `assert x1 >= x0` is the caller's (layoutdetr_amd/detr_util/box_ops.py). */
 int ldetr_box_giou_pairwise_f32(const float* boxes1, const float* boxes2, int B, int N, int M, int cxcywh, float* iou, float* uni,
                                 float* giou, double* cost, double cost_sign, void* stream);
+
+/* Batched small matrix product on strided views: C[b1][b2][m][n] = alpha * sum_k A[b1][b2][m][k] * B[b1][b2][k][n]; sa / sb / sc hold the
+ * (b1, b2, row, column) ELEMENT strides of each operand, so transposed operands and head-split views of a [rows][heads * dh] activation need
+ * no copy.  fp32 FMAs in k order (deterministic).  For the regulariser phases only (second-order autograd through the attention products,
+ * training/loss.py:119-142, 207-215: every product's backward is this product on transposed views); the hot path's attention is
+ * ldetr_attention_* / ldetr_mha_*.  nb1, nb2 <= 65535. */
+int ldetr_bmm_strided_f32(const float* A, const int64_t* sa, const float* B, const int64_t* sb, float* C, const int64_t* sc,
+                          int nb1, int nb2, int M, int N, int K, float alpha, void* stream);
 
 /* ---- Plane-format ("P3") convolutions of the ResNet-50 trunk (csrc/p3_engine.hip; ATen conv2d + its autograd behind
  * torchvision's resnet50 at training/detr_backbone.py:98-114).

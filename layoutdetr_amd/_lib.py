@@ -10,6 +10,7 @@ from ctypes import (POINTER, Structure, c_char_p, c_double, c_float, c_int, c_in
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # LDETR_LIB: development aid (tools/build_variant.sh) -- an alternative build of the same library, e.g. to A/B a kernel change on one box
+ABI_VERSION = 24   # include/ldetr_hip.h; csrc/ldetr_core.cpp
 LIB_PATH = os.environ.get('LDETR_LIB') or os.path.join(_HERE, 'lib', 'libldetr_hip.so')
 
 
@@ -123,6 +124,7 @@ SIGNATURES = {
     'ldetr_ema_lerp_f32': [_P, _P, _L, _F, _P],
     'ldetr_lsap_f64': [_P, _I, _I, _I, _P, _P, _P],
     'ldetr_box_giou_pairwise_f32': [_P, _P, _I, _I, _I, _I, _P, _P, _P, _P, c_double, _P],
+    'ldetr_bmm_strided_f32': [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _P],
     'ldetr_softmax_xent_fwd_f32': [_P, _L, _P, _P, _P, _P, _L, _I, _L, _F, _P],
     'ldetr_softmax_xent_bwd_f32': [_P, _L, _P, _P, _P, _P, _P, _L, _L, _I, _L, _F, _P],
     'ldetr_embedding_fwd_f32': [_P, _P, _P, _P, _L, _I, _I, _I, _P],
@@ -189,7 +191,7 @@ def load():
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported
         fn.restype = c_int
         fn.argtypes = argtypes
-    if lib.ldetr_abi_version() != 23:
+    if lib.ldetr_abi_version() != ABI_VERSION:
         raise RuntimeError('libldetr_hip.so ABI version mismatch; rebuild it')
     sizes = (ctypes.c_int32 * 6)()
     lib.ldetr_struct_sizes(sizes)

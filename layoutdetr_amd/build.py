@@ -20,7 +20,7 @@ LIBNAME = 'libldetr_hip.so'
 ARCH = 'gfx950'
 
 SOURCES = ['ldetr_core.cpp', 'bias_act.hip', 'upfirdn2d.hip', 'gemm_conv.hip', 'attention.hip', 'layernorm.hip',
-           'misc_ops.hip', 'optim.hip', 'lsap.hip', 'xent.hip', 'resample.hip', 'layout_loss.hip', 'demod.hip', 'wgrad_smallc.hip', 'stem_conv.hip', 'box_ops.hip', 'ffn_fused.hip', 'conv_c32.hip', 'mha_small.hip', 'p3_engine.hip']
+           'misc_ops.hip', 'optim.hip', 'lsap.hip', 'xent.hip', 'resample.hip', 'layout_loss.hip', 'demod.hip', 'wgrad_smallc.hip', 'stem_conv.hip', 'box_ops.hip', 'ffn_fused.hip', 'conv_c32.hip', 'mha_small.hip', 'p3_engine.hip', 'bmm_strided.hip']
 HEADERS = ['ldetr_common.hpp', os.path.join('..', '..', 'include', 'ldetr_hip.h')]
 
 # the per-block tracer of the tiled kernel (tools/trace_tiles.py) is a development build: LDETR_TILE_TRACE=1 python -m layoutdetr_amd.build --force

@@ -49,7 +49,7 @@ double knob_f(const char* key, double dflt) {
 }  // namespace ldetr
 
 extern "C" const char* ldetr_last_error(void) { return ldetr::g_err; }
-extern "C" int ldetr_abi_version(void) { return 23; }
+extern "C" int ldetr_abi_version(void) { return 24; }
 // sizeof of every argument block of the group launches, in header order: the host bindings (layoutdetr_amd/_lib.py) mirror them field by field
 extern "C" int ldetr_struct_sizes(int32_t* out6) {
     if (!out6) return 1;

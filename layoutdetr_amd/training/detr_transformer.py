@@ -13,7 +13,7 @@ from typing import Optional
 import torch
 from torch import Tensor, nn
 
-from ..hip import core
+from ..hip import composite, core
 from ..hip.attention import grouped_kv, mha_cross_kv, mha_forward
 from ..hip import ffn as hffn
 from ..hip import stacks as hstacks
@@ -188,9 +188,12 @@ class TransformerDecoder(nn.Module):
     def forward2d(self, t2, mem2, pos2, B, Lq, S, tgt_kpm, mem_kpm, mem_pos2=None, partner=None):
         """partner: a hip.stacks.Prog of an INDEPENDENT stack to advance in lock-step with this one (D's unconditional encoder beside its layout
         decoder) -> (output, partner's output); run on its own when this stack does not take the stack node."""
-        tgt_kpm, mem_kpm = _mask_u8(tgt_kpm), _mask_u8(mem_kpm)
         if mem_pos2 is None:
             mem_pos2 = mem2 + pos2
+        if composite.active():      # regulariser phases (R1 / path length) differentiate this stack twice: hip/composite.py
+            out = composite.decoder_forward2d(self, t2, mem2, mem_pos2, B, Lq, S, tgt_kpm, mem_kpm)
+            return out if partner is None else (out, hstacks.run([partner])[0])
+        tgt_kpm, mem_kpm = _mask_u8(tgt_kpm), _mask_u8(mem_kpm)
         # the memory is the same for every layer (detr_transformer.py:277-280 projects it per layer): all layers' K / V projections as two
         # GEMMs with N = layers * d, their backward as four (hip.attention._GroupedKVFn); _GROUP_KV = False restores the per-layer launches
         kvs = grouped_kv(mem_pos2, mem2, [l.multihead_attn for l in self.layers]) if (_GROUP_KV and len(self.layers) > 1) else None

@@ -1,13 +1,14 @@
 """StyleGAN2Loss for the LayoutDETR G/D step (reference: training/loss.py:28-218) over the gfx950 modules.
 Same class name, constructor arguments, phase names and loss composition; the default `gamma=0,
 pl_weight=0` configuration (train.py:135-136) makes Greg/Dreg no-ops exactly as loss.py:77-80 does.
-R1 / path-length regularisation need double-backward through the fused kernels and are not implemented
-(SURVEY §7 'second-order autograd'); requesting them raises."""
+R1 (`--gamma`, loss.py:207-215) and path-length regularisation (loss.py:119-142) differentiate D's score / G's boxes with
+`create_graph=True`: those phases run the heads and the decoder stack between the differentiated input and output on the
+twice-differentiable nodes of hip/composite.py (SURVEY §7 'second-order autograd'); everything else keeps the fused kernels."""
 
 import torch
 import torch.nn.functional as F
 
-from ..hip import core
+from ..hip import composite, core
 
 from ..hip import losses as hl
 from ..metrics.metric_layoutnet import compute_alignment, compute_overlap, generalized_iou_loss, layout_losses_fused, layout_losses_per_sample
@@ -71,9 +72,13 @@ class StyleGAN2Loss(Loss):
         self.D = D
         self.augment_pipe = augment_pipe
         self.r1_gamma = r1_gamma
+        self.style_mixing_prob = style_mixing_prob
         self.pl_weight = pl_weight
-        if r1_gamma != 0 or pl_weight != 0:
-            raise NotImplementedError('R1 / path-length regularisation (double backward) is not implemented on the fused kernels')
+        self.pl_batch_shrink = pl_batch_shrink
+        self.pl_decay = pl_decay
+        self.pl_no_weight_grad = pl_no_weight_grad
+        self.pl_mean = torch.zeros([], device=device)
+        self.pl_noise_fn = None       # tests: callable(bbox_fake) -> the noise of loss.py:131 instead of torch.randn_like
         self.w = dict(Dreal_bbox_cls=Dreal_bbox_cls_weight, Dreal_bbox_rec=Dreal_bbox_rec_weight, Dreal_text_rec=Dreal_text_rec_weight,
                       Dreal_text_len_rec=Dreal_text_len_rec_weight, Dreal_im_rec=Dreal_im_rec_weight, Ggen_bbox_rec=Ggen_bbox_rec_weight,
                       Ggen_bbox_gIoU=Ggen_bbox_gIoU_weight, Ggen_overlapping=Ggen_overlapping_weight, Ggen_alignment=Ggen_alignment_weight,
@@ -310,7 +315,7 @@ class StyleGAN2Loss(Loss):
         if self.r1_gamma == 0:
             phase = {'Dreg': 'none', 'Dboth': 'Dmain'}.get(phase, phase)
         g_body = self.G.backbone[0].body if hasattr(self.G, 'backbone') else None
-        if phase != 'Gmain' and g_body is not None and getattr(g_body, 'injected', None):
+        if phase not in ('Gmain', 'Gboth') and g_body is not None and getattr(g_body, 'injected', None):
             g_body.injected = None     # a parked G-trunk evaluation belongs to this iteration's Gmain only
         # A trunk evaluation parked for this call (detr_backbone.ResNet50Body.injected, keyed by the batch's address) must not outlive it: after a miss
         # or an exception a later batch at the same address would otherwise be served stale features.  (Iteration-level sharing parks G's trunks of
@@ -324,10 +329,58 @@ class StyleGAN2Loss(Loss):
             raise
         finally:
             core.zero_arena_end()
-        if self.share_D_trunk != 'iteration' or phase != 'Gmain':
+        if self.share_D_trunk != 'iteration' or phase not in ('Gmain', 'Gboth'):
             self._drop_parked_trunks()
 
+    def g_pl_loss(self, bbox_real, bbox_class, bbox_text, bbox_patch, padding_mask, background, gen_z, gen_c, gain=1.0):
+        """Path-length regularisation (loss.py:119-142): the first `batch / pl_batch_shrink` samples, || d(bbox_fake . noise) / d z || against
+        its running mean.  G's heads and layout decoder run on hip/composite.py (differentiated twice)."""
+        bs = gen_z.shape[0] // self.pl_batch_shrink
+        z = gen_z[:bs].detach().requires_grad_(True)
+        with composite.higher_order():
+            bbox_fake = self.run_G(z, bbox_class[:bs], bbox_real[:bs], bbox_text[:bs], bbox_patch[:bs], padding_mask[:bs], background[:bs], gen_c[:bs])
+        noise = self.pl_noise_fn(bbox_fake) if self.pl_noise_fn is not None else torch.randn_like(bbox_fake)
+        pl_noise = noise / float(bbox_fake.shape[2])
+        pl_grads = torch.autograd.grad(outputs=[(bbox_fake * pl_noise).sum()], inputs=[z], create_graph=True, only_inputs=True)[0]
+        pl_lengths = pl_grads.square().sum([1, 2]).sqrt()
+        pl_mean = self.pl_mean.lerp(pl_lengths.mean(), self.pl_decay)
+        self.pl_mean.copy_(pl_mean.detach())
+        pl_penalty = (pl_lengths - pl_mean).square()
+        self.report('Loss/pl_penalty', pl_penalty)
+        loss_Gpl = pl_penalty * self.pl_weight
+        self.report('Loss/G/reg', loss_Gpl)
+        self.last = dict(pl_penalty=pl_penalty.detach(), pl_lengths=pl_lengths.detach(), pl_grads=pl_grads.detach())
+        return loss_Gpl.mean().mul(gain)
+
+    def d_r1_loss(self, bbox_real, bbox_class, bbox_text, bbox_patch, padding_mask, background, real_c, gain=1.0):
+        """R1 (loss.py:162-166, 207-217 in phase 'Dreg'): gamma / 2 * || d D(real) / d bbox_real ||^2 per sample.  The reference evaluates
+        D with reconst=True here and discards the seven reconstruction outputs; only the conditional score is formed.  D's `fc_bbox`,
+        `enc_fc_in`, layout decoder and `fc_out_disc` run on hip/composite.py (differentiated twice)."""
+        bbox_real_tmp = bbox_real.detach().requires_grad_(True)
+        with composite.higher_order():
+            real_logits, _ = self.run_D(bbox_real_tmp, bbox_class, bbox_text, bbox_patch, padding_mask, background, real_c)
+        self.report('Loss/scores/real', real_logits)
+        if self._reporting:
+            self.report('Loss/signs/real', real_logits.sign())
+        r1_grads = torch.autograd.grad(outputs=[real_logits.sum()], inputs=[bbox_real_tmp], create_graph=True, only_inputs=True)[0]
+        r1_penalty = r1_grads.square().sum([1, 2])
+        loss_Dr1 = r1_penalty * (self.r1_gamma / 2)
+        self.report('Loss/r1_penalty', r1_penalty)
+        self.report('Loss/D/reg', loss_Dr1)
+        self.last = dict(r1_penalty=r1_penalty.detach(), r1_grads=r1_grads.detach(), real_logits=real_logits.detach())
+        return loss_Dr1.mean().mul(gain)
+
     def _run_phase(self, phase, bbox_real, bbox_class, bbox_text, bbox_patch, padding_mask, background, real_c, gen_z, gen_c, gain):
+        # 'Gboth' / 'Dboth' (no lazy regularisation: reg_interval None) = the main phase, then the regulariser on a forward pass of its own.
+        # The reference shares Dreal's forward with R1 in 'Dboth' (loss.py:162-217): same expected gradient, independent dropout draws here.
+        if phase in ('Greg', 'Gboth'):
+            if phase == 'Gboth':
+                self._run_phase('Gmain', bbox_real, bbox_class, bbox_text, bbox_patch, padding_mask, background, real_c, gen_z, gen_c, gain)
+            self.g_pl_loss(bbox_real, bbox_class, bbox_text, bbox_patch, padding_mask, background, gen_z, gen_c, gain=gain).backward()
+        if phase in ('Dreg', 'Dboth'):
+            if phase == 'Dboth':
+                self._run_phase('Dmain', bbox_real, bbox_class, bbox_text, bbox_patch, padding_mask, background, real_c, gen_z, gen_c, gain)
+            self.d_r1_loss(bbox_real, bbox_class, bbox_text, bbox_patch, padding_mask, background, real_c, gain=gain).backward()
         if phase == 'Gmain':
             self.g_main_loss(bbox_real, bbox_class, bbox_text, bbox_patch, padding_mask, background, gen_z, gen_c, gain=gain).backward()
         if phase == 'Dmain':

@@ -28,6 +28,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from ..detr_util.misc import NestedTensor, nested_tensor_from_tensor_list
+from ..hip import composite
 from ..hip import conv as hconv
 from ..hip import core
 from ..hip.linear import linear
@@ -205,6 +206,8 @@ class Linear(nn.Linear):
     """nn.Linear parameters, f32-MFMA forward/backward."""
 
     def forward(self, x, relu=False):
+        if composite.active():      # regulariser phases (R1 / path length): a twice-differentiable node (hip/composite.py)
+            return composite.linear(x, self.weight, self.bias, relu=relu)
         return linear(x, self.weight, self.bias, act=core.ACT_RELU if relu else core.ACT_NONE)
 
 
@@ -430,7 +433,7 @@ class Discriminator(nn.Module):
         x_uncond = self.enc_fc_in_uncond(x_uncond, final_relu=True).permute(1, 0, 2)
         # The unconditional encoder (networks_detr.py:243) does not depend on the conditional path: it advances in lock-step with the layout decoder
         # of enc_transformer, one launch per sub-block step for both stacks (hip.stacks); the reference runs them one after the other.
-        partner = self.enc_transformer_uncond.as_prog(x_uncond, padding_mask)
+        partner = None if composite.active() else self.enc_transformer_uncond.as_prog(x_uncond, padding_mask)
         if partner is not None:
             x, _, y_uncond = self.enc_transformer(src=src, mask=mask, pos_embed=pos, tgt=x, tgt_key_padding_mask=padding_mask, partner=partner[0])
             x_uncond = partner[1](y_uncond)

@@ -128,11 +128,19 @@ class FlatModule(object):
 
 
 class Phase(object):
-    """One optimiser phase ('Gmain' or 'Dmain'): module + flat Adam state."""
+    """One optimiser phase: module + flat Adam state.  'Gmain' / 'Dmain' (or 'Gboth' / 'Dboth' without lazy regularisation) own the state;
+    a regulariser phase ('Greg' / 'Dreg', training_loop.py:190-197) is built with `share=<its main phase>`: same flat buffers, same Adam
+    moments -- the reference hands ONE optimiser object to both -- and runs every `interval` iterations with gain = interval."""
 
-    def __init__(self, name, module, lr, betas=(0.0, 0.99), eps=1e-8, reg_interval=None):
+    def __init__(self, name, module, lr=None, betas=(0.0, 0.99), eps=1e-8, reg_interval=None, share=None, interval=1):
         self.name = name
         self.module = module
+        self.interval = int(interval)
+        self.main = share if share is not None else self
+        if share is not None:
+            self.fm, self.m, self.v = share.fm, share.m, share.v
+            self.lr, self.betas, self.eps = share.lr, share.betas, share.eps
+            return
         self.fm = FlatModule(module)
         if reg_interval is not None:  # lazy-regularisation rescaling, training_loop.py:191-194
             mb_ratio = reg_interval / (reg_interval + 1)
@@ -142,6 +150,46 @@ class Phase(object):
         self.m = torch.zeros_like(self.fm.flat)
         self.v = torch.zeros_like(self.fm.flat)
         self.step = 0
+        # torch.optim.Adam skips parameters whose .grad is None and keeps a step count PER PARAMETER.  A regulariser phase reaches only part
+        # of the module (R1: what D's conditional score depends on), so after its first step two groups of parameters exist with different
+        # step counts: `reg_runs` = the flat ranges the regulariser touches (found once, from its first exchanged gradient), `reg_steps` =
+        # how many regulariser steps they have taken on top of `step`.
+        self.reg_runs = None
+        self.reg_steps = 0
+
+    def touched_runs(self):
+        """Flat ranges [(lo, hi)] of the parameters that received a gradient in the regulariser phase that just ran (any non-zero element:
+        with the flat gradient buffer 'no gradient' shows as an all-zero segment).  One host synchronisation, once per run of the loop."""
+        fm = self.fm
+        flags = torch.stack([fm.gflat[o:o + p.numel()].abs().amax() for p, o in zip(fm.params, fm.offsets)]).gt(0).tolist()
+        runs = []
+        for i, hit in enumerate(flags):
+            if not hit:
+                continue
+            lo = fm.offsets[i]
+            hi = fm.offsets[i + 1] if i + 1 < len(fm.offsets) else fm.total
+            if runs and runs[-1][1] == lo:
+                runs[-1] = (runs[-1][0], hi)
+            else:
+                runs.append((lo, hi))
+        return runs
+
+    def step_ranges(self, regulariser):
+        """[(lo, hi, adam step number)] for the optimiser step being taken now (counters already advanced)."""
+        main = self.main
+        if main.reg_runs is None:
+            return [(0, main.fm.total, main.step)]
+        if regulariser:
+            return [(lo, hi, main.step + main.reg_steps) for lo, hi in main.reg_runs]
+        out, pos = [], 0
+        for lo, hi in main.reg_runs:
+            if lo > pos:
+                out.append((pos, lo, main.step))
+            out.append((lo, hi, main.step + main.reg_steps))
+            pos = hi
+        if pos < main.fm.total:
+            out.append((pos, main.fm.total, main.step))
+        return out
 
 
 class DataParallelStep(object):
@@ -223,17 +271,25 @@ class DataParallelStep(object):
         if ev is not None:
             ev[1].record()
             self.exposed.append((phase.name, ev[0], ev[1]))
-        phase.step += 1
+        main = phase.main
+        regulariser = phase is not main
+        if regulariser:
+            if main.reg_runs is None:
+                main.reg_runs = main.touched_runs()     # after the exchange: the same ranges on every rank
+            main.reg_steps += 1
+        else:
+            main.step += 1
         scale = 1.0 / self.world
         if fm.flat.device.type != 'cuda':
             raise RuntimeError('DataParallelStep.apply: parameters must live in GPU memory (no CPU fallback)')
         if not self.fuse:
             core.check(core.lib().ldetr_grad_sanitize_f32(core.ptr(fm.gflat), fm.total, scale, 0.0, 1e5, -1e5, core.stream()), 'grad_sanitize')
-        core.check(core.lib().ldetr_adam_ema_step_f32(core.ptr(fm.flat), core.ptr(fm.gflat), core.ptr(phase.m), core.ptr(phase.v), fm.total,
-                                                      phase.step, phase.lr, phase.betas[0], phase.betas[1], phase.eps,
-                                                      1 if self.fuse else 0, scale, 0.0, 1e5, -1e5,
-                                                      core.ptr(ema[0]) if ema is not None else None, float(ema[1]) if ema is not None else 0.0,
-                                                      core.stream()), 'adam_step')
+        for lo, hi, step in phase.step_ranges(regulariser):
+            core.check(core.lib().ldetr_adam_ema_step_f32(core.ptr(fm.flat[lo:hi]), core.ptr(fm.gflat[lo:hi]), core.ptr(main.m[lo:hi]), core.ptr(main.v[lo:hi]), hi - lo,
+                                                          step, main.lr, main.betas[0], main.betas[1], main.eps,
+                                                          1 if self.fuse else 0, scale, 0.0, 1e5, -1e5,
+                                                          core.ptr(ema[0][lo:hi]) if ema is not None else None, float(ema[1]) if ema is not None else 0.0,
+                                                          core.stream()), 'adam_step')
         refresh_weight_planes(phase.module)
 
 
@@ -557,8 +613,9 @@ def staged_backward(loss, phase, dp, run_stage1, between=None, exchange=None, st
 
 
 def training_iteration(loss, phases, dp, batch, batch_gpu, gen_z_per_phase, ema=None, batch_size=None, ema_kimg=None, cur_nimg=0, overlap=None,
-                       gen_c_per_phase=None, ema_rampup=0.05):
-    """One iteration = all phases (Gmain, Dmain) over the rank-local batch, as training_loop.py:274-328.
+                       gen_c_per_phase=None, ema_rampup=0.05, batch_idx=0):
+    """One iteration = all phases (Gmain, Dmain and -- every `phase.interval`-th iteration, counted by `batch_idx` -- the regulariser phases
+    Greg / Dreg with gain = interval) over the rank-local batch, as training_loop.py:274-328.
 
     batch: dict with bbox_real [b,9,4], bbox_class [b,9], bbox_text (TextFeatures), bbox_patch, padding_mask [b,9] bool,
            background [b,3,R,R], real_c, gen_c.  gen_z_per_phase: list of [b,9,z_dim] tensors, one per phase; gen_c_per_phase: the same for the
@@ -580,7 +637,13 @@ def training_iteration(loss, phases, dp, batch, batch_gpu, gen_z_per_phase, ema=
         for s in range(0, b, batch_gpu):
             loss.precompute_D_trunk(batch['background'][s:s + batch_gpu], stages=d_stages)
     lerp_done = False
+    due = [batch_idx % getattr(p, 'interval', 1) == 0 for p in phases]
+    # the fused G_ema lerp rides on the LAST optimiser step that moves G in this iteration (a Greg phase moves it again after Gmain)
+    last_of_fm = {id(p.fm): pi for pi, p in enumerate(phases) if due[pi]}
     for pi, (phase, gen_z) in enumerate(zip(phases, gen_z_per_phase)):
+        if not due[pi]:
+            continue
+        regulariser = getattr(phase, 'main', phase) is not phase
         phase.fm.zero_grad()
         phase.module.requires_grad_(True)
         phase.module.text_encoder.requires_grad_(False)
@@ -592,12 +655,12 @@ def training_iteration(loss, phases, dp, batch, batch_gpu, gen_z_per_phase, ema=
                 loss.accumulate_gradients(phase=phase.name, bbox_real=batch['bbox_real'][sl], bbox_class=batch['bbox_class'][sl],
                                           bbox_text=batch['bbox_text'][sl], bbox_patch=batch['bbox_patch'][sl],
                                           padding_mask=batch['padding_mask'][sl], background=batch['background'][sl],
-                                          real_c=batch['real_c'][sl], gen_z=gen_z[sl], gen_c=gen_c[sl], gain=1, cur_nimg=cur_nimg)
-        staged = overlap and b <= batch_gpu
+                                          real_c=batch['real_c'][sl], gen_z=gen_z[sl], gen_c=gen_c[sl], gain=getattr(phase, 'interval', 1), cur_nimg=cur_nimg)
+        staged = overlap and b <= batch_gpu and not regulariser      # a regulariser phase is exchanged in one piece after its backward
         exchanged = staged_backward(loss, phase, dp, accumulate, stages=(d_stages if (iter_share and phase.name == 'Dmain') else None),
                                     n_stages=backward_stage_count(b)) if staged else (accumulate() or False)
         phase.module.requires_grad_(False)
-        fe = ema.fused(phase, batch_size, ema_kimg, cur_nimg, ema_rampup) if ema is not None else None
+        fe = ema.fused(phase, batch_size, ema_kimg, cur_nimg, ema_rampup) if (ema is not None and not regulariser and last_of_fm[id(phase.fm)] == pi) else None
         lerp_done = lerp_done or fe is not None
         dp.apply(phase, exchanged=bool(exchanged), ema=fe)
     if ema is not None:
@@ -830,12 +893,17 @@ def training_loop(run_dir='.', training_set_kwargs={}, validation_set_kwargs={},
         opt.pop('class_name', None)                   # torch.optim.Adam in the reference; the fused Adam kernel here
         phases.append(Phase(name + ('both' if reg is None else 'main'), module, lr=opt.get('lr', 1e-3), betas=tuple(opt.get('betas', (0.9, 0.999))),
                             eps=opt.get('eps', 1e-8), reg_interval=reg))
+        # :195-197: the lazy regulariser phase shares the main phase's optimiser.  Built only when its regulariser is on (pl_weight for G,
+        # r1_gamma for D): with the weight at 0 the reference's phase is a no-op that leaves every .grad None, so its Adam step changes nothing
+        if reg is not None and float(getattr(loss, 'pl_weight' if name == 'G' else 'r1_gamma', 0) or 0) != 0:
+            phases.append(Phase(name + 'reg', module, share=phases[-1], interval=reg))
     dp = DataParallelStep(world_size=num_gpus)
     ema = EmaTracker(phases[0], G_ema)
     if rank == 0:
         print('Not run on this path: augment pipe, ADA, image snapshots, metrics (outside the hot path)')
         print(f'Training for {total_kimg} kimg...')
     cur_nimg, cur_tick, tick_start_nimg, tick_start = resume_kimg * 1000, 0, resume_kimg * 1000, time.time()
+    batch_idx = 0
     if progress_fn is not None:
         progress_fn(0, total_kimg)
     last = {}
@@ -862,8 +930,9 @@ def training_loop(run_dir='.', training_set_kwargs={}, validation_set_kwargs={},
             gen_c = [torch.zeros_like(batch['real_c']) for _ in phases]
         batch['gen_c'] = gen_c[0]
         training_iteration(loss, phases, dp, batch, batch_gpu, gen_z, ema=ema, batch_size=batch_size, ema_kimg=ema_kimg, cur_nimg=cur_nimg,
-                           gen_c_per_phase=gen_c, ema_rampup=ema_rampup)
+                           gen_c_per_phase=gen_c, ema_rampup=ema_rampup, batch_idx=batch_idx)
         cur_nimg += batch_size
+        batch_idx += 1
         done = cur_nimg >= total_kimg * 1000
         if not done and cur_tick != 0 and cur_nimg < tick_start_nimg + kimg_per_tick * 1000:
             continue

@@ -480,8 +480,8 @@ class _Body(torch.nn.Module):
         self.feats = torch.nn.Parameter(feats)
 
     def forward(self, x):
-        assert x.shape[0] == self.feats.shape[0] and x.shape[2] // 32 == self.feats.shape[2] and x.shape[3] // 32 == self.feats.shape[3]
-        return {'0': self.feats}
+        assert x.shape[0] <= self.feats.shape[0] and x.shape[2] // 32 == self.feats.shape[2] and x.shape[3] // 32 == self.feats.shape[3]
+        return {'0': self.feats[:x.shape[0]]}      # (the path-length phase runs the first half of the batch, loss.py:121-128)
 
 
 def _ref_G_D(nd, bg, feats_g, feats_d):
@@ -618,6 +618,86 @@ def gen_composition():
     save('composition', d)
 
 
+def gen_reg():
+    """The regulariser terms of the reference's OWN StyleGAN2Loss.accumulate_gradients: path length ('Greg', loss.py:119-142, pl_weight = 2,
+    pl_batch_shrink = 2) and R1 (loss.py:162-166 + 207-217, r1_gamma = 10) -- second-order autograd through the reference's Generator /
+    Discriminator at the real layer sizes (same stand-ins and seeded weights / inputs as gen_composition), in fp32 (tag '') and fp64 ('64').
+    R1 cannot be captured from phase 'Dreg': the reference raises UnboundLocalError there (loss.py:218 sums `loss_Dreal_text_len_rec`, which
+    the zero-initialisation block :168-176 omits and only the `phase in ['Dmain', 'Dboth']` branch assigns) -- i.e. `--gamma > 0` with lazy
+    regularisation (D_reg_interval = 16, the training_loop default train.py leaves in place) does not run in the reference.  It is captured
+    from phase 'Dboth' (main terms + R1 on one forward pass, dropout off): reported values directly, parameter gradients as
+    grad('Dboth') - grad('Dmain') -- the R1 term's own gradient.
+    Stored: every reported value, the path-length noise draw (torch.randn_like at :131, captured), the running mean after the call, and the
+    digests of the parameter gradients."""
+    from oracle import seeded
+    nd = _import_ref_networks()
+    from torch_utils import training_stats
+    from training.loss import StyleGAN2Loss
+    import training.loss as loss_mod
+    B, bg, seed = 4, 64, 13
+    inp = seeded.comp_inputs(B, bg, seed)
+    G, D = _ref_G_D(nd, bg, inp['feats_g'], inp['feats_d'])
+    skip = ('backbone.0.body.', 'text_encoder.', 'text_decoder.')
+    G.load_state_dict(seeded.seeded_state_dict(G, 1, skip)); D.load_state_dict(seeded.seeded_state_dict(D, 2, skip))
+    d = {'B': np.asarray(B), 'bg': np.asarray(bg), 'seed': np.asarray(seed), 'r1_gamma': np.asarray(10.0), 'pl_weight': np.asarray(2.0)}
+    patch = torch.zeros(B, 9, 1, 1, 1)
+    c = torch.zeros(B, 0)
+    tok = G.tokenizer(sum(inp['texts'], []))
+    d['text_feat'] = G.text_encoder(tok.input_ids, tok.attention_mask).last_hidden_state[:, 0, :].view(B, 9, -1)
+    d['text_len'] = torch.tensor([len(t) for t in sum(inp['texts'], [])]).view(B, 9)
+    reports = {}
+    real_report = training_stats.report
+    training_stats.report = lambda name, value: reports.setdefault(name, []).append(torch.as_tensor(value).detach().clone()) or value
+    loss_mod.training_stats.report = training_stats.report
+    real_randn_like = torch.randn_like
+    for tag, dt in (('', torch.float32), ('64', torch.float64)):
+        G.to(dt); D.to(dt)
+        D.bg_decoder.float()
+        cast = lambda t: t.to(dt) if t.dtype.is_floating_point else t
+        loss = StyleGAN2Loss(torch.device('cpu'), G, D, r1_gamma=10.0, pl_weight=2.0, pl_batch_shrink=2)
+        loss.pl_mean = loss.pl_mean.to(dt)
+        G.requires_grad_(False); D.requires_grad_(False)
+        grads = {}
+        for phase, mod_ in (('Greg', G), ('Dboth', D), ('Dmain', D)):
+            reports.clear()
+            mod_.requires_grad_(True); mod_.text_encoder.requires_grad_(False)
+            for p in mod_.parameters():
+                p.grad = None
+            noise = {}
+
+            def randn_like(t, *a, **k):
+                torch.manual_seed(77)
+                r = real_randn_like(t.float(), *a, **k).to(t.dtype)      # the same draw in both precisions
+                noise['v'] = r.detach().clone()
+                return r
+            torch.randn_like = randn_like
+            try:
+                loss.accumulate_gradients(phase=phase, bbox_real=cast(inp['bbox_real']), bbox_class=inp['bbox_class'], bbox_text=inp['texts'], bbox_patch=cast(patch),
+                                          padding_mask=inp['padding_mask'], background=inp['background'], real_c=cast(c),
+                                          gen_z=cast(inp['z_g'] if phase == 'Greg' else inp['z_d']), gen_c=cast(c), gain=4 if phase == 'Greg' else 1, cur_nimg=0)
+            finally:
+                torch.randn_like = real_randn_like
+            mod_.requires_grad_(False)
+            grads[phase] = {name: p.grad.detach().clone() for name, p in mod_.named_parameters() if p.grad is not None}
+            if phase == 'Greg':
+                d['pl_noise'] = noise['v'].float()
+                d[f'Greg/pl_mean{tag}'] = loss.pl_mean.detach().clone()
+            if phase != 'Dmain':
+                for name, vals in reports.items():
+                    for i, v in enumerate(vals):
+                        d[f'{phase}/report{tag}/{name}' + (f'#{i}' if len(vals) > 1 else '')] = v
+        for name, g in grads['Greg'].items():
+            st, sub = seeded.grad_digest(g)
+            d[f'Greg/gstat{tag}/{name}'] = st; d[f'Greg/gsub{tag}/{name}'] = sub if tag else sub.astype(np.float32)
+        for name, g in grads['Dboth'].items():
+            st, sub = seeded.grad_digest(g - grads['Dmain'][name])
+            d[f'R1/gstat{tag}/{name}'] = st; d[f'R1/gsub{tag}/{name}'] = sub if tag else sub.astype(np.float32)
+        if not tag:
+            d['Greg/params_with_grad'] = np.asarray(sorted(grads['Greg']))
+    training_stats.report = real_report
+    save('reg', d)
+
+
 def gen_config0():
     """BASELINE.json configs[0]: ONE sample, 128x128 background (stride 32 -> 4x4 = 16 memory tokens), 3 text boxes valid of the 9 slots,
     the reference's own `Generator.forward` (networks_detr.py:133-187) on CPU, reconst off and on.  Same stand-ins as gen_composition
@@ -694,6 +774,8 @@ if __name__ == '__main__':
     torch.set_num_threads(8)
     if '--only-composition' in sys.argv:
         gen_composition(); gen_config0(); sys.exit(0)
+    if '--only-reg' in sys.argv:
+        gen_reg(); sys.exit(0)
     if '--only-config0' in sys.argv:
         gen_config0(); sys.exit(0)
     if '--only-box-ops' in sys.argv:
@@ -706,4 +788,4 @@ if __name__ == '__main__':
         gen_bert(); gen_bert_lm(); sys.exit(0)
     if '--skip-done' not in sys.argv:
         gen_ops(); gen_transformer()
-    gen_losses(); gen_decoder(); gen_frozen_bn(); gen_lsap(); gen_dp_step(); gen_metrics(); gen_bert(); gen_bert_lm(); gen_resample(); gen_composition(); gen_config0(); gen_box_ops()
+    gen_losses(); gen_decoder(); gen_frozen_bn(); gen_lsap(); gen_dp_step(); gen_metrics(); gen_bert(); gen_bert_lm(); gen_resample(); gen_composition(); gen_reg(); gen_config0(); gen_box_ops()

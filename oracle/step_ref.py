@@ -3,6 +3,8 @@
 CPU fp32 restatement of one G/D training iteration in hot-path-only mode:
   StyleGAN2Loss.accumulate_gradients, phases Gmain and Dmain with gamma=0, pl_weight=0
       training/loss.py:84-116 (Gmain), :146-157 (Dgen), :161-218 (Dreal); weights from train.py:263-275
+  and the two regulariser phases: Greg (path length, :119-142) and Dreg (R1, :162-166 + :207-217) -- pinned by tests/golden/reg.npz, the
+  reference's own accumulate_gradients('Greg' / 'Dreg') in fp32 and fp64 (oracle/gen_golden.py:gen_reg)
   gradient post-processing + Adam(betas=(0,0.99), eps=1e-8)      training/training_loop.py:303-313, train.py:204-205
 Built on the pinned pieces (networks_ref / detr_ref / stylegan2_ref / losses_ref), and PINNED as a whole: tests/golden/composition.npz
 holds every training_stats-reported term and the parameter gradients of the reference's own StyleGAN2Loss.accumulate_gradients
@@ -72,6 +74,40 @@ def d_real_loss(D, bt, w=WEIGHTS, bg_size=256, terms=None):
     if terms is not None:
         terms.update({k: v.detach() for k, v in t.items()})
     return sum(v for k, v in t.items() if k.startswith('Loss/D/')).mean()
+
+
+def d_r1_loss(D, bt, r1_gamma, terms=None):
+    """loss.py:162-166, 207-217 in phase 'Dreg': gamma / 2 * || d D(real).sum() / d bbox_real ||^2 per sample (create_graph: the penalty is
+    differentiated again by the caller's backward)."""
+    real = bt['bbox_real'].detach().requires_grad_(True)
+    logits = networks_ref.discriminator(D, real, bt['bbox_class'], bt['text_feat'], bt['text_len'], bt['padding_mask'], bt['background'],
+                                        feats=bt.get('feats_D'))[0]
+    r1_grads = torch.autograd.grad([logits.sum()], [real], create_graph=True, only_inputs=True)[0]
+    r1_penalty = r1_grads.square().sum([1, 2])
+    loss = r1_penalty * (r1_gamma / 2)
+    if terms is not None:
+        terms.update({'Loss/scores/real': logits.detach(), 'Loss/signs/real': logits.detach().sign(), 'Loss/r1_penalty': r1_penalty.detach(),
+                      'Loss/D/reg': loss.detach(), 'r1_grads': r1_grads.detach()})
+    return loss.mean()
+
+
+def g_pl_loss(G, bt, z, noise, pl_mean, pl_weight, pl_batch_shrink=2, pl_decay=0.01, terms=None):
+    """loss.py:119-142 (phase 'Greg').  `noise` = the torch.randn_like(bbox_fake) draw of :131; `pl_mean` = the running mean before this call.
+    -> (loss, new running mean)."""
+    bs = z.shape[0] // pl_batch_shrink
+    zt = z[:bs].detach().requires_grad_(True)
+    feats = bt.get('feats_G')
+    bbox_fake = networks_ref.generator(G, zt, bt['bbox_class'][:bs], bt['text_feat'][:bs], bt['text_len'][:bs], bt['padding_mask'][:bs], bt['background'][:bs],
+                                       feats=None if feats is None else feats[:bs])
+    pl_noise = noise / float(bbox_fake.shape[2])
+    pl_grads = torch.autograd.grad([(bbox_fake * pl_noise).sum()], [zt], create_graph=True, only_inputs=True)[0]
+    pl_lengths = pl_grads.square().sum([1, 2]).sqrt()
+    new_mean = pl_mean.lerp(pl_lengths.mean(), pl_decay)
+    pl_penalty = (pl_lengths - new_mean).square()
+    loss = pl_penalty * pl_weight
+    if terms is not None:
+        terms.update({'Loss/pl_penalty': pl_penalty.detach(), 'Loss/G/reg': loss.detach(), 'pl_grads': pl_grads.detach(), 'pl_mean': new_mean.detach()})
+    return loss.mean(), new_mean.detach()
 
 
 def _params(sd, param_names=None):

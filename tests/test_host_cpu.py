@@ -29,7 +29,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), f'{name} declared in include/ldetr_hip.h but not exported'
     assert declared - {'ldetr_last_error', 'ldetr_abi_version'} == set(_lib.SIGNATURES), 'ctypes table out of sync with the header'
-    assert lib.ldetr_abi_version() == 23
+    assert lib.ldetr_abi_version() == _lib.ABI_VERSION == 24
 
 
 def test_no_cpu_fallback():

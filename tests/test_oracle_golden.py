@@ -374,3 +374,58 @@ def test_composition_loss_phases_vs_reference():
             assert e <= max(3 * e_ref, 1e-5), f'{phase} {n}: {e:.3e} vs fp64 (reference fp32 run: {e_ref:.3e})'
             worst, ref_worst = max(worst, e), max(ref_worst, e_ref)
     print(f'composition gradients vs the fp64 reference run: oracle worst {worst:.2e}, reference fp32 run worst {ref_worst:.2e}')
+
+
+def _reg_setup():
+    from oracle import seeded
+    d = load('reg')
+    B, bg, seed = int(d['B']), int(d['bg']), int(d['seed'])
+    inp = seeded.comp_inputs(B, bg, seed)
+    Gm, Dm, Gsd, Dsd = comp_modules(bg)
+    return d, inp, Gm, Dm, Gsd, Dsd
+
+
+def test_regulariser_phases_vs_reference():
+    """Path length ('Greg') and R1 of the reference's own StyleGAN2Loss.accumulate_gradients (tests/golden/reg.npz: second-order autograd
+    through the reference's modules): every reported value, the running path-length mean, and every parameter gradient as close to
+    the reference's fp64 run as its own fp32 run is."""
+    from oracle import step_ref
+    d, inp, Gm, Dm, Gsd, Dsd = _reg_setup()
+    tf, tl = d['text_feat'], d['text_len']
+    bg = int(d['bg'])
+    fg, fd = inp['feats_g'].clone().requires_grad_(True), inp['feats_d'].clone().requires_grad_(True)
+    bt = dict(bbox_real=inp['bbox_real'], bbox_class=inp['bbox_class'], text_feat=tf, text_len=tl, padding_mask=inp['padding_mask'],
+              background=inp['background'], feats_G=fg, feats_D=fd)
+    G = step_ref._params(Gsd, {n for n, _ in Gm.named_parameters()}); D = step_ref._params(Dsd, {n for n, _ in Dm.named_parameters()})
+    # ---- path length
+    t = {}
+    loss, new_mean = step_ref.g_pl_loss(G, bt, inp['z_g'], d['pl_noise'], torch.zeros(()), float(d['pl_weight']), terms=t)
+    (loss * 4).backward()
+    close(t['Loss/pl_penalty'], d['Greg/report/Loss/pl_penalty'], 2e-5); close(t['Loss/G/reg'], d['Greg/report/Loss/G/reg'], 2e-5)
+    close(new_mean, d['Greg/pl_mean'], 2e-6)
+    gG = {k: v.grad for k, v in G.items() if v.requires_grad and v.grad is not None}
+    gG['backbone.0.body.feats'] = fg.grad
+    names = [k[len('Greg/gstat/'):] for k in d if k.startswith('Greg/gstat/')]
+    assert set(names) == {n for n in gG if not (n.startswith('backbone.0.body.') and n != 'backbone.0.body.feats')}
+    worst = ref_worst = 0.0
+    for n in names:
+        e, e_ref = digest_errors(gG[n], d, 'Greg', n)
+        assert e <= max(3 * e_ref, 1e-5), f'Greg {n}: {e:.3e} vs fp64 (reference fp32 run: {e_ref:.3e})'
+        worst, ref_worst = max(worst, e), max(ref_worst, e_ref)
+    # ---- R1
+    t = {}
+    step_ref.d_r1_loss(D, bt, float(d['r1_gamma']), terms=t).backward()
+    close(t['Loss/r1_penalty'], d['Dboth/report/Loss/r1_penalty'], 2e-5); close(t['Loss/D/reg'], d['Dboth/report/Loss/D/reg'], 2e-5)
+    close(t['Loss/scores/real'], d['Dboth/report/Loss/scores/real'], 2e-5)
+    gD = {k: v.grad for k, v in D.items() if v.requires_grad and v.grad is not None}
+    gD['backbone.0.body.feats'] = fd.grad
+    # the fixture holds grad('Dboth') - grad('Dmain') for EVERY parameter of D: R1's own gradient where R1 reaches (non-zero in fp64),
+    # rounding residue of the subtraction elsewhere.  The oracle must reach exactly the parameters whose fp64 difference is non-zero.
+    reach = {k[len('R1/gstat64/'):] for k in d if k.startswith('R1/gstat64/') and float(d[k][2]) > 0}
+    got = {n for n in gD if not (n.startswith('backbone.0.body.') and n != 'backbone.0.body.feats')}
+    assert got == reach, got ^ reach
+    for n in sorted(got):
+        e, e_ref = digest_errors(gD[n], d, 'R1', n)
+        assert e <= max(3 * e_ref, 1e-5), f'R1 {n}: {e:.3e} vs fp64 (reference fp32 difference: {e_ref:.3e})'
+        worst, ref_worst = max(worst, e), max(ref_worst, e_ref)
+    print(f'regulariser gradients vs the fp64 reference run: oracle worst {worst:.2e}, reference fp32 run worst {ref_worst:.2e}')

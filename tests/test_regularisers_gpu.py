@@ -1,0 +1,226 @@
+"""R1 (`--gamma`, training/loss.py:162-166 + 207-217) and path-length regularisation (loss.py:119-142) on the HIP modules: second-order autograd
+through hip/composite.py.
+
+tests/golden/reg.npz holds what the reference's OWN StyleGAN2Loss.accumulate_gradients produces for these terms at the real layer sizes, in
+fp32 and fp64 (oracle/gen_golden.py:gen_reg drives the imported reference; the oracle is pinned to the same fixture by
+tests/test_oracle_golden.py::test_regulariser_phases_vs_reference).  R1 was captured from phase 'Dboth' minus phase 'Dmain': phase 'Dreg'
+raises UnboundLocalError in the reference (gen_reg's docstring).  Tolerances: reported values 1e-4 of the fp64 run (north_star: 1e-3), every
+parameter gradient within 3e-4 of its tensor's largest fp64 entry."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from test_composition_gpu import KW, build, check, load, make_batch, make_modules, rel
+
+pytestmark = pytest.mark.gpu
+
+
+def _digest_err(g, d, phase, name):
+    from oracle import seeded
+    st, sb = seeded.grad_digest(g.detach().cpu())
+    s64 = np.asarray(d[f'{phase}/gsub64/{name}']); st64 = np.asarray(d[f'{phase}/gstat64/{name}'])
+    mx = float(st64[2]) + 1e-300
+    return max(float(np.abs(sb - s64).max()) / mx, abs(st[0] - float(st64[0])) / (float(st64[0]) + 1e-300))
+
+
+def test_bmm_strided_and_composite_nodes_vs_float64(dev):
+    """The twice-differentiable contraction nodes against torch in float64: values, first derivatives and second derivatives (gradient of a
+    function of the gradient), on head-split / transposed views -- no copies, strides as the attention products use them."""
+    from layoutdetr_amd.hip import composite
+    g = torch.Generator().manual_seed(5)
+    B, H, Lq, Lk, dh = 3, 8, 10, 64, 32
+    q2 = torch.randn(B * Lq, H * dh, generator=g); k2 = torch.randn(B * Lk, H * dh, generator=g); w = torch.randn(40, H * dh, generator=g) * 0.1
+
+    def run(dt, dev_):
+        q = q2.to(dev_, dt).requires_grad_(True); k = k2.to(dev_, dt).requires_grad_(True); ww = w.to(dev_, dt).requires_grad_(True)
+        qh = q.view(B, Lq, H, dh).permute(0, 2, 1, 3); kh = k.view(B, Lk, H, dh).permute(0, 2, 1, 3)
+        if dt == torch.float32:
+            s = composite.bmm4(qh, kh.transpose(2, 3), 0.25)
+            y = composite.linear(q, ww, None, relu=True)
+        else:
+            s = torch.matmul(qh, kh.transpose(2, 3)) * 0.25
+            y = torch.relu(q @ ww.t())
+        f = (torch.softmax(s, -1) ** 2).sum() + (y ** 3).sum()
+        gq, = torch.autograd.grad(f, q, create_graph=True)
+        pen = (gq ** 2).sum()
+        pen.backward()
+        return s.detach(), gq.detach(), q.grad, k.grad, ww.grad
+    got = run(torch.float32, dev)
+    want = run(torch.float64, 'cpu')
+    for a, b, nm in zip(got, want, ('bmm4 value', 'first derivative', 'second derivative d/dq', 'second derivative d/dk', 'second derivative d/dw')):
+        check(a, b, 2e-5, nm)
+    # ragged tile edges and K not a multiple of 16; a row vector and a column vector through mm
+    a = torch.randn(2, 3, 17, 21, generator=g); b = torch.randn(2, 3, 21, 5, generator=g)
+    check(composite.bmm4(a.to(dev), b.to(dev), 1.5), torch.matmul(a.double(), b.double()) * 1.5, 1e-5, 'bmm4 17x21x5')
+    x = torch.randn(1, 36, generator=g); m = torch.randn(36, 768, generator=g)
+    check(composite.mm(x.to(dev), m.to(dev)), x.double() @ m.double(), 1e-5, 'mm row vector')
+    check(composite.mm(m.t().to(dev), x.t().to(dev)), m.t().double() @ x.t().double(), 1e-5, 'mm column vector, transposed operands')
+
+
+def test_regulariser_phases_vs_reference_fixture(dev):
+    """accumulate_gradients('Greg') and ('Dreg') on the HIP modules against the reference's own path-length / R1 terms: every reported value,
+    the running mean, every parameter gradient; and the set of parameters R1 reaches (torch.optim.Adam skips the others)."""
+    from layoutdetr_amd.training.loss import StyleGAN2Loss
+    from layoutdetr_amd.training.networks_detr import TextFeatures
+    from oracle import seeded
+    d = load('reg')
+    B, bg, seed = int(d['B']), int(d['bg']), int(d['seed'])
+    inp = seeded.comp_inputs(B, bg, seed)
+    G, D = build(dev, bg, inp)
+    t = {k: v.to(dev) for k, v in inp.items() if isinstance(v, torch.Tensor)}
+    tf = TextFeatures(d['text_feat'].to(dev), d['text_len'].to(dev))
+    patch = torch.zeros(B, 9, 1, 1, 1, device=dev)
+    c = torch.zeros(B, 0, device=dev)
+    reports = {}
+    loss = StyleGAN2Loss(dev, G, D, r1_gamma=float(d['r1_gamma']), pl_weight=float(d['pl_weight']), pl_batch_shrink=2,
+                         report_fn=lambda n, v: reports.setdefault(n, []).append(v.detach().clone()))
+    loss.pl_noise_fn = lambda bbox_fake: d['pl_noise'].to(dev)
+    worst_term = worst = 0.0
+    for phase, key, mod, z, gain in (('Greg', 'Greg', G, t['z_g'], 4), ('Dreg', 'R1', D, t['z_d'], 1)):
+        reports.clear()
+        mod.requires_grad_(True); mod.text_encoder.requires_grad_(False)
+        for p in mod.parameters():
+            p.grad = None
+        loss.accumulate_gradients(phase=phase, bbox_real=t['bbox_real'], bbox_class=t['bbox_class'], bbox_text=tf, bbox_patch=patch,
+                                  padding_mask=t['padding_mask'], background=t['background'], real_c=c, gen_z=z, gen_c=c, gain=gain, cur_nimg=0)
+        mod.requires_grad_(False)
+        rep = 'Greg' if phase == 'Greg' else 'Dboth'
+        names = ('Loss/pl_penalty', 'Loss/G/reg') if phase == 'Greg' else ('Loss/r1_penalty', 'Loss/D/reg', 'Loss/scores/real')
+        for k in names:
+            assert len(reports[k]) == 1
+            e = rel(reports[k][0], d[f'{rep}/report64/{k}'])
+            assert e <= 1e-4, f'{phase} {k}: {e:.3e} vs the fp64 reference run'
+            worst_term = max(worst_term, e)
+        if phase == 'Greg':
+            check(loss.pl_mean, d['Greg/pl_mean64'], 1e-4, 'running path-length mean')
+        grads = {n: p.grad for n, p in mod.named_parameters() if p.grad is not None and float(p.grad.abs().max()) > 0}
+        if 'backbone.0.body.feats' in grads:
+            grads['backbone.0.body.feats'] = grads['backbone.0.body.feats'].permute(0, 3, 1, 2)
+        reach = {k[len(key) + 9:] for k in d if k.startswith(key + '/gstat64/') and float(d[k][2]) > 0}
+        assert set(grads) == reach, sorted(set(grads) ^ reach)
+        for n in sorted(reach):
+            e = _digest_err(grads[n], d, key, n)
+            assert e <= 3e-4, f'{phase} {n}: {e:.3e} vs the fp64 reference run'
+            worst = max(worst, e)
+    print(f'[regularisers vs the reference fixture] worst reported value {worst_term:.2e}, worst gradient {worst:.2e} (of the tensor maximum, vs fp64)')
+
+
+def test_r1_and_path_length_with_the_resnet_trunk_vs_oracle_b2(dev):
+    """BASELINE configs[1]'s size (B=2 per regulariser batch, 256x256) with the real ResNet-50 trunk: the regulariser's gradient reaches the trunk
+    through the decoder's memory (first-order kernels) while the heads / decoder are differentiated twice -- against the oracle's double
+    backward in fp64 with its fp32 run as the yardstick."""
+    from layoutdetr_amd.training.loss import StyleGAN2Loss
+    from layoutdetr_amd.training.networks_detr import TextFeatures
+    from oracle import step_ref
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    B, bg = 4, 256            # path length runs the first B / 2 = 2 samples; R1 all four
+    G, D = make_modules(bg, seed=31)
+    bt, zg, _ = make_batch(B, bg, seed=32, ragged=True)
+    Gsd = {k: v.clone() for k, v in G.state_dict().items()}; Dsd = {k: v.clone() for k, v in D.state_dict().items()}
+    gn, dn = {n for n, _ in G.named_parameters()}, {n for n, _ in D.named_parameters()}
+    noise = torch.randn(B // 2, 9, 4, generator=torch.Generator().manual_seed(3))
+    want = {}
+    for dt in (torch.float32, torch.float64):
+        cast = lambda sd: {k: (v.to(dt) if v.dtype.is_floating_point else v) for k, v in sd.items()}
+        btc = {k: (v.to(dt) if v.dtype.is_floating_point else v) for k, v in bt.items()}
+        Gp, Dp = step_ref._params(cast(Gsd), gn), step_ref._params(cast(Dsd), dn)
+        tg, td = {}, {}
+        lg, _ = step_ref.g_pl_loss(Gp, btc, zg.to(dt), noise.to(dt), torch.zeros((), dtype=dt), 2.0, terms=tg)
+        lg.backward()
+        step_ref.d_r1_loss(Dp, btc, 10.0, terms=td).backward()
+        want[dt] = (tg, td, {k: v.grad for k, v in Gp.items() if v.grad is not None}, {k: v.grad for k, v in Dp.items() if v.grad is not None})
+    G.eval().requires_grad_(False).to(dev); D.eval().requires_grad_(False).to(dev)
+    loss = StyleGAN2Loss(dev, G, D, r1_gamma=10.0, pl_weight=2.0)
+    loss.pl_noise_fn = lambda bbox_fake: noise.to(dev)
+    dbt = dict(bbox_real=bt['bbox_real'].to(dev), bbox_class=bt['bbox_class'].to(dev), bbox_text=TextFeatures(bt['text_feat'].to(dev), bt['text_len'].to(dev)),
+               bbox_patch=torch.zeros(B, 9, 1, 1, 1, device=dev), padding_mask=bt['padding_mask'].to(dev), background=bt['background'].to(dev),
+               real_c=torch.zeros(B, 0, device=dev), gen_c=torch.zeros(B, 0, device=dev))
+    worst = 0.0
+    for phase, mod, idx, keys in (('Greg', G, 2, ('Loss/pl_penalty',)), ('Dreg', D, 3, ('Loss/r1_penalty', 'Loss/scores/real'))):
+        mod.requires_grad_(True); mod.text_encoder.requires_grad_(False)
+        for p in mod.parameters():
+            p.grad = None
+        got = {}
+        loss.report = lambda n, v: got.__setitem__(n, v.detach().clone())
+        loss.accumulate_gradients(phase=phase, gen_z=zg.to(dev), gain=1, cur_nimg=0, **dbt)
+        mod.requires_grad_(False)
+        t32, t64 = want[torch.float32][idx - 2], want[torch.float64][idx - 2]
+        for k in keys:
+            e, e_cpu = rel(got[k], t64[k]), rel(t32[k], t64[k])
+            assert e <= max(1e-3, 3 * e_cpu), f'{phase} {k}: {e:.3e} vs fp64 (CPU fp32: {e_cpu:.3e})'
+        g32, g64 = want[torch.float32][idx], want[torch.float64][idx]
+        errs, cpu_errs = [], []
+        for n, p in mod.named_parameters():
+            if n not in g64 or float(g64[n].abs().max()) == 0:
+                assert p.grad is None or float(p.grad.abs().max()) == 0, f'{phase}: {n} is not reached by the regulariser but has a gradient'
+                continue
+            assert p.grad is not None, f'{phase}: no gradient for {n}'
+            mx = float(g64[n].abs().max())
+            errs.append(float((p.grad.detach().cpu().double() - g64[n]).abs().max()) / mx)
+            cpu_errs.append(float((g32[n].double() - g64[n]).abs().max()) / mx)
+        errs, cpu_errs = np.array(errs), np.array(cpu_errs)
+        # distribution gate (ReLU / max-pool units at rounding distance of 0 flip in ANY fp32 evaluation and move single tensors by percents):
+        # the HIP path must be as close to fp64 as the CPU fp32 run is
+        assert np.median(errs) <= max(3 * np.median(cpu_errs), 5e-4), f'{phase}: median gradient error {np.median(errs):.2e} (CPU fp32 {np.median(cpu_errs):.2e})'
+        assert (errs > max(0.1, 10 * cpu_errs.max())).mean() <= 0.02, f'{phase}: {(errs > 0.1).sum()} of {len(errs)} tensors off by > 10 %'
+        worst = max(worst, float(np.median(errs)))
+        print(f'  [{phase} B={B} {bg}x{bg}, ResNet trunk] gradients vs fp64: HIP median {np.median(errs):.2e} max {errs.max():.2e}; CPU fp32 median {np.median(cpu_errs):.2e} max {cpu_errs.max():.2e} ({len(errs)} tensors)')
+
+
+def test_lazy_regulariser_phases_share_the_optimiser_like_the_reference(dev, tmp_path):
+    """training_loop(**c) with r1_gamma > 0 and D_reg_interval = 2 (train.py --gamma, training_loop.py:186-197): a 'Dreg' phase exists, runs
+    every 2nd iteration with gain 2 on the main phase's Adam state, and -- as torch.optim.Adam does for parameters whose .grad is None --
+    leaves the parameters R1 does not reach (reconstruction heads, unconditional path, StyleGAN2 decoder) and their moments untouched."""
+    from layoutdetr_amd.training import training_loop as tl
+    from layoutdetr_amd.training.loss import StyleGAN2Loss
+    from test_boundary_gpu import SyntheticLayouts
+    bg = 64
+    torch.manual_seed(0)
+    from layoutdetr_amd.training.networks_detr import Discriminator, Generator, TextFeatures
+    G = Generator(z_dim=4, img_height=bg, img_width=bg, background_size=bg, **KW).train().requires_grad_(False).to(dev)
+    D = Discriminator(img_height=bg, img_width=bg, background_size=bg, **KW).train().requires_grad_(False).to(dev)
+    seen = []
+    loss = StyleGAN2Loss(dev, G, D, r1_gamma=10.0, report_fn=lambda n, v: seen.append(n))
+    pG = tl.Phase('Gmain', G, lr=1e-4, betas=(0.0, 0.99), reg_interval=4)
+    pD = tl.Phase('Dmain', D, lr=1e-4, betas=(0.0, 0.99), reg_interval=2)
+    pR = tl.Phase('Dreg', D, share=pD, interval=2)
+    assert pR.fm is pD.fm and pR.m is pD.m and pR.lr == pD.lr and pR.main is pD
+    dp = tl.DataParallelStep(world_size=1)
+    B = 2
+    bt, _, _ = make_batch(B, bg, seed=9, ragged=False)
+    batch = dict(bbox_real=bt['bbox_real'].to(dev), bbox_class=bt['bbox_class'].to(dev), bbox_text=TextFeatures(bt['text_feat'].to(dev), bt['text_len'].to(dev)),
+                 bbox_patch=torch.zeros(B, 9, 1, 1, 1, device=dev), padding_mask=bt['padding_mask'].to(dev), background=bt['background'].to(dev),
+                 real_c=torch.zeros(B, 0, device=dev), gen_c=torch.zeros(B, 0, device=dev))
+    phases = [pG, pD, pR]
+    names = pD.fm.names
+    snap = lambda: (pD.fm.flat.clone(), pD.v.clone())
+    for it in range(3):
+        seen.clear()
+        before = snap()
+        z = [torch.randn(B, 9, 4, device=dev) for _ in phases]
+        tl.training_iteration(loss, phases, dp, batch, B, z, batch_idx=it)
+        ran = 'Loss/r1_penalty' in seen
+        assert ran == (it % 2 == 0), (it, seen)
+    assert pD.step == 3 and pD.reg_steps == 2 and pD.reg_runs
+    touched = torch.zeros(pD.fm.total, dtype=torch.bool)
+    for lo, hi in pD.reg_runs:
+        touched[lo:hi] = True
+    by_name = {n: bool(touched[o]) for n, o in zip(names, pD.fm.offsets)}
+    assert by_name['fc_bbox.weight'] and by_name['enc_fc_in.layers.0.weight'] and by_name['enc_transformer.decoder.layers.0.linear1.weight'] and by_name['fc_out_disc.weight']
+    assert by_name['backbone.0.body.layer4.2.conv3.weight'] and by_name['input_proj.weight'], 'R1 reaches the trunk through the memory'
+    for n in ('fc_out_disc.bias', 'bbox_embed.weight', 'fc_bbox_uncond.weight', 'dec_transformer.layers.0.linear1.weight', 'enc_transformer_uncond.token'):
+        assert not by_name[n], f'{n} is not on the path bbox_real -> real_logits'
+    assert not any(by_name[n] for n in names if n.startswith('bg_decoder.'))
+    # one more regulariser step in isolation: untouched ranges (parameters AND second moments) stay bit-identical
+    p0, v0 = snap()
+    pD.fm.zero_grad(); D.requires_grad_(True); D.text_encoder.requires_grad_(False)
+    loss.accumulate_gradients(phase='Dreg', gen_z=torch.randn(B, 9, 4, device=dev), gain=2, cur_nimg=0, **batch)
+    D.requires_grad_(False)
+    dp.apply(pR)
+    p1, v1 = snap()
+    un = ~touched.to(dev)
+    assert torch.equal(p0[un], p1[un]) and torch.equal(v0[un], v1[un]) and not torch.equal(p0[~un], p1[~un])
+    assert pD.reg_steps == 3 and pD.step == 3
+    assert all(torch.isfinite(p).all() for p in D.parameters())
