@@ -110,7 +110,11 @@ def cpu_baseline(G_sd, D_sd, G_names, D_names, bg, budget_s=34.0):
 
     small, _ = leg(2, 3, t_start + 6.0)
     big, warm16 = leg(16, 3, t_start + budget_s)
-    out = dict(cores=ncores, host_cores=nproc, host_cpu=cpu_model, kind='port')
+    out = dict(cores=ncores, host_cores=nproc, host_cpu=cpu_model, kind='port',
+               cores_note=f'{ncores} threads is the fastest setting of this port on the GPU boxes (measured: 16 threads 1.1 s / iteration at batch 16, 64 threads 3.3 s, all '
+                          f'{nproc} logical cores > 400 s: ~2000 tiny ops per iteration oversubscribe the thread pool); all_cores = the same step at torch.set_num_threads(os.cpu_count()) '
+                          '(BASELINE.md 2), batch 2, in a child process with a 25 s limit')
+    out['all_cores'] = cpu_baseline_all_cores(bg, nproc)
     if big is not None:
         out.update(value=round(big[0], 4), unit='images/s', batch=16,
                    sample=f'{big[1]} timed iteration(s) of the same Gmain+Dmain step at batch 16, {bg}x{bg} (oracle/step_ref.py, torch CPU fp32, dropout off) after 1 warm-up')
@@ -123,8 +127,45 @@ def cpu_baseline(G_sd, D_sd, G_names, D_names, bg, budget_s=34.0):
     return out
 
 
+def cpu_baseline_all_cores(bg, nproc, limit_s=25.0):
+    """BASELINE.md 2 asks for torch.set_num_threads(os.cpu_count()).  On the GPU boxes (256 logical cores) that setting is far slower than 16 threads and
+    cannot be interrupted in-process, so it runs as a child (`bench.py --cpu-probe-threads N`) with a time limit: -> dict(threads, value | None, note)."""
+    import subprocess
+    try:
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), '--cpu-probe-threads', str(nproc), '--bg', str(bg)], capture_output=True, text=True, timeout=limit_s,
+                           env=dict(os.environ, HIP_VISIBLE_DEVICES='', CUDA_VISIBLE_DEVICES=''))
+        line = [l for l in r.stdout.splitlines() if l.startswith('{')]
+        if r.returncode == 0 and line:
+            return json.loads(line[-1])
+        return dict(threads=nproc, value=None, note=f'child failed (rc {r.returncode}): {r.stderr[-200:]}')
+    except subprocess.TimeoutExpired:
+        return dict(threads=nproc, value=None, unit='images/s at batch 2', note=f'one warm-up + one timed batch-2 iteration did not finish within {limit_s:.0f} s at {nproc} threads')
+
+
+def cpu_probe(threads, bg):
+    """Child of cpu_baseline_all_cores: the oracle step at batch 2 with `threads` threads, one warm-up + one timed iteration; prints one JSON line."""
+    from layoutdetr_amd.training.networks_detr import Discriminator, Generator
+    from oracle import step_ref
+    torch.set_num_threads(threads)
+    torch.manual_seed(0)
+    kw = dict(num_bbox_labels=8, img_channels=3, img_height=bg, img_width=bg, c_dim=0, background_size=bg, bert_f_dim=768, bert_num_heads=4, bert_num_encoder_layers=12,
+              bert_num_decoder_layers=2, im_f_dim=512)
+    G = Generator(z_dim=4, f_dim=256, num_heads=4, num_layers=8, text_mode='features', **kw)
+    D = Discriminator(f_dim=256, num_heads=4, num_layers=8, text_mode='features', **kw)
+    G_sd, D_sd = dict(G.state_dict()), dict(D.state_dict())
+    names = dict(G_param_names={n for n, _ in G.named_parameters()}, D_param_names={n for n, _ in D.named_parameters()})
+    bt = make_batch(2, bg, 'cpu', 123)
+    zg, zd = torch.randn(2, 9, 4), torch.randn(2, 9, 4)
+    step_ref.training_iteration(G_sd, D_sd, bt, zg, zd, bg_size=bg, **names)
+    t0 = time.time()
+    step_ref.training_iteration(G_sd, D_sd, bt, zg, zd, bg_size=bg, **names)
+    el = time.time() - t0
+    print(json.dumps(dict(threads=threads, value=round(2 / el, 4), unit='images/s at batch 2', sample='1 timed iteration of the same Gmain+Dmain step at batch 2 after 1 warm-up')), flush=True)
+
+
 def parse_args():
     ap = argparse.ArgumentParser()
+    ap.add_argument('--cpu-probe-threads', type=int, default=0, help=argparse.SUPPRESS)
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=10)
     ap.add_argument('--warmup', type=int, default=3)
@@ -162,11 +203,22 @@ def _spawned(local_rank, args, port):
 
 def main():
     args = parse_args()
+    if args.cpu_probe_threads:
+        return cpu_probe(args.cpu_probe_threads, args.bg)
     os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')   # dmabuf IPC only on this host driver (RCCL needs it)
     env_world = int(os.environ.get('WORLD_SIZE', '0') or 0)
     if env_world >= 1 and 'RANK' in os.environ:            # launched by torch.distributed.run: one process per GPU already exists
         if env_world != args.gpus:
             raise SystemExit(f'bench.py: --gpus {args.gpus} but WORLD_SIZE={env_world}')
+        # preflight: fail fast, with one parsable line, when this node shows fewer GPUs than local ranks -- never share a device silently
+        # (RCCL refuses two ranks on one device only after every rank has entered init_process_group: minutes of rendezvous timeout)
+        n_local = int(os.environ.get('LOCAL_WORLD_SIZE', env_world) or env_world)
+        have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+        if have < n_local and not os.environ.get('LDETR_BENCH_SHARE_GPU'):
+            if int(os.environ['RANK']) == 0:
+                print(json.dumps(dict(metric=METRIC, value=None, unit='images/s', n_gpus=args.gpus, steps=args.steps, warmup=args.warmup,
+                                      error=f'{n_local} local rank(s) launched but {have} GPU(s) visible on this node')), flush=True)
+            raise SystemExit(2)
         run(args, int(os.environ['RANK']), int(os.environ.get('LOCAL_RANK', '0')), env_world)
     elif args.gpus > 1:                                      # plain `python bench.py --gpus N`: spawn the ranks (train.py:27-47 does the same)
         import torch.multiprocessing as mp
@@ -412,13 +464,19 @@ def run(args, rank, local_rank, world):
         torch.cuda.synchronize()
         ev_over_ms = max((sum(x.elapsed_time(y) for x, y in pairs) - sa.elapsed_time(sb)) / ncal, 0.0)
         sec = max(sec_raw - ev_over_ms * 1e-3 * launches, 1e-9)
-        if os.environ.get('LDETR_ENGINE_SHAPES'):   # development aid: per-(entry point, flop count) table
-            agg = {}
-            for tag, f, s_, e_, _nb, _pp in core.PROF.records:
-                a = agg.setdefault((tag, f), [0, 0.0]); a[0] += 1; a[1] += s_.elapsed_time(e_)
+        # per (kernel symbol, entry point, shape) table of the step's contraction launches: calls, mean duration, algorithmic FLOPs and bytes per
+        # launch -- what a single kernel's roofline is recomputed from (LDETR_ENGINE_SHAPES=<file> writes it: profiles/r06_engine_shapes.txt)
+        shapes = {}
+        for tag, f, s_, e_, nb, pp, lab in core.PROF.records:
+            a = shapes.setdefault((lab, tag, f, nb), [0, 0.0, pp]); a[0] += 1; a[1] += s_.elapsed_time(e_)
+        if os.environ.get('LDETR_ENGINE_SHAPES'):
             with open(os.environ['LDETR_ENGINE_SHAPES'], 'w') as fh:
-                for (tag, f), (n, ms) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
-                    fh.write(f'{tag:42s} gflop={f / 1e9:9.3f} calls/step={n // 2:4d} ms/step={ms / 2:8.3f} TF={f * n / ms / 1e9 if ms else 0:7.2f}\n')
+                fh.write(f'# {METRIC}; {b_local} samples per GPU, {bg}x{bg}; one row per (kernel symbol, C-ABI entry, algorithmic FLOPs, algorithmic bytes) of ONE iteration; '
+                         'us = mean HIP-event time of a call (event pair included); pipe = matrix pipe of its launches\n')
+                fh.write(f'# {"kernel":58s} {"entry":34s} {"calls/step":>10s} {"us/call":>9s} {"GFLOP/call":>11s} {"MB/call":>9s} {"TFLOP/s":>8s} {"TB/s":>6s}  pipe\n')
+                for (lab, tag, f, nb), (n, ms, pp) in sorted(shapes.items(), key=lambda kv: -kv[1][1]):
+                    fh.write(f'{lab:60s} {tag.replace("ldetr_", ""):34s} {n / 2:10.1f} {ms / n * 1e3:9.1f} {f / 1e9:11.4f} {nb / 1e6:9.2f} {f * n / ms / 1e9 if ms else 0:8.1f} '
+                             f'{nb * n / ms / 1e9 if ms else 0:6.2f}  {"bf16x6" if pp[1] else "f32"}\n')
         # `achieved` / `frac` use the UNCORRECTED event time: it is the figure that agrees with rocprofv3's kernel durations of the same
         # command (round 3: 32.06 ms of events against 32.0 ms in profiles/r03g_kernel_stats.csv); the pair-corrected one is reported beside it
         ach = fl / sec_raw / 1e12 if sec_raw > 0 else 0.0
@@ -427,7 +485,7 @@ def run(args, rank, local_rank, world):
         t_pipe = [0.0, 0.0]          # engine time on the f32 MFMA pipe / on the bf16 pipe (exact operand split)
         n_pipe = [0, 0]
         alg_bytes = alg_bytes_f32 = 0.0
-        for tag, f, s_, e_, nb, pipes in core.PROF.records:   # the same records, split by C-ABI entry point
+        for tag, f, s_, e_, nb, pipes, _lab in core.PROF.records:   # the same records, split by C-ABI entry point
             key = 'dense_gemm' if tag == 'gemm' else tag.replace('ldetr_', '').replace('_f32', '')
             ms = s_.elapsed_time(e_)
             a = by.setdefault(key, [0.0, 0.0, 0, 0.0, 0.0]); a[0] += f; a[1] += ms; a[2] += 1; a[3] += nb
@@ -444,7 +502,7 @@ def run(args, rank, local_rank, world):
         # launch on the f32 MFMA pipe 157.3 -- time-weighted over the step's engine launches
         tsum = max(t_pipe[0] + t_pipe[1], 1e-9)
         peak_eff = (t_pipe[0] * F32_MFMA_PEAK_TFLOPS + t_pipe[1] * SPLIT_PIPE_PEAK_TFLOPS) / tsum
-        roofline = dict(bound='mfma', kernel='fp32-equivalent contraction engine, every launch: ldetr::p3_nt_kernel<*> / p3_c3_kernel / p3_tn_kernel<*> (the ResNet trunk on plane-format '
+        engine = dict(bound='mfma', kernel='fp32-equivalent contraction engine, every launch: ldetr::p3_nt_kernel<*> / p3_c3_kernel / p3_tn_kernel<*> (the ResNet trunk on plane-format '
                                              'operands, bf16 pipe) + gemm_f32_kernel<*> (LDS-tiled GEMM / implicit conv) + gemm_small_kernel<*> / gemm_small_pair_kernel<*> '
                                              '(+ conv3x3_c32 / wgrad_c32 where they replace engine launches) + the token-stack kernels (mha_small / mha_cross / ffn fwd + bwd, wgrad_multi: f32 MFMA)',
                         achieved=round(ach, 3), peak=F32_MFMA_PEAK_TFLOPS, unit='TFLOP/s', frac=round(ach / F32_MFMA_PEAK_TFLOPS, 4),
@@ -454,7 +512,7 @@ def run(args, rank, local_rank, world):
                                             f'exact 3-way operand split (fp32-equivalent ceiling {SPLIT_PIPE_PEAK_TFLOPS:.1f} = 2500 / 6 TFLOP/s; {n_pipe[1] // 2} kernel launches per step), '
                                             f'{t_pipe[0] / tsum:.3f} on the f32 MFMA pipe ({F32_MFMA_PEAK_TFLOPS}; {n_pipe[0] // 2} launches)',
                         engine_ms_on_bf16_pipe=round(t_pipe[1] / 2, 3), engine_ms_on_f32_pipe=round(t_pipe[0] / 2, 3),
-                        traffic=None, launches_per_step=launches // 2, algorithmic_gflop_per_step=round(fl / 2 / 1e9, 2),
+                        launches_per_step=launches // 2, algorithmic_gflop_per_step=round(fl / 2 / 1e9, 2),
                         algorithmic_gb_per_step=round(alg_bytes / 2 / 1e9, 2), algorithmic_gb_per_step_fp32_tensors=round(alg_bytes_f32 / 2 / 1e9, 2),
                         engine_ms_per_step=round(sec / 2 * 1e3, 3), engine_ms_per_step_uncorrected=round(sec_raw / 2 * 1e3, 3),
                         event_pair_overhead_us=round(ev_over_ms * 1e3, 2), by_entry=by_entry,
@@ -464,6 +522,30 @@ def run(args, rank, local_rank, world):
                                     'tests/test_kernels_gpu.py test_split_bf16_*), every other launch on v_mfma_f32_32x32x2_f32 / 16x16x4_f32; `peak` stays the f32 MFMA peak, `achieved` counts '
                                     'algorithmic fp32 FLOPs (a split launch can exceed it: 6/16 of the bf16 pipe time per fp32 FLOP); value_f32_mfma_only = same step with every split off '
                                     '(LDETR_TRUNK_P3=0, ldetr_set_split_bf16(0))')
+        # ---- the dominant kernel: ONE kernel symbol (the one with the largest summed time in the step), priced against the pipe it runs on
+        ksym = {}
+        for tag, f, s_, e_, nb, pp, lab in core.PROF.records:
+            if tag == 'ldetr_token_stack':
+                continue                                   # a group of kernels behind one label, not a symbol
+            a = ksym.setdefault(lab.split(' splitK')[0], dict(flops=0.0, ms=0.0, n=0, nbytes=0.0, split=0))
+            a['flops'] += f; a['ms'] += s_.elapsed_time(e_); a['n'] += 1; a['nbytes'] += nb; a['split'] += 1 if pp[1] else 0
+
+        def kernel_entry(sym):
+            a = ksym[sym]
+            on_bf16 = a['split'] * 2 > a['n']
+            peak = SPLIT_PIPE_PEAK_TFLOPS if on_bf16 else F32_MFMA_PEAK_TFLOPS
+            tf = a['flops'] / a['ms'] / 1e9 if a['ms'] > 0 else 0.0
+            return dict(kernel=sym, launches_per_step=a['n'] // 2, avg_us=round(a['ms'] / a['n'] * 1e3, 2), ms_per_step=round(a['ms'] / 2, 3),
+                        gflop_per_launch=round(a['flops'] / a['n'] / 1e9, 4), algorithmic_mb_per_launch=round(a['nbytes'] / a['n'] / 1e6, 3),
+                        achieved=round(tf, 2), peak=round(peak, 1), unit='TFLOP/s', frac=round(tf / peak, 4), frac_of_f32_mfma_peak=round(tf / F32_MFMA_PEAK_TFLOPS, 4),
+                        pipe='bf16 matrix pipe, exact 3-way operand split (6 products per fp32 product: 2500 / 6)' if on_bf16 else 'f32 MFMA',
+                        algorithmic_tbps=round(a['nbytes'] / a['ms'] / 1e9, 3) if a['ms'] > 0 else 0.0)
+        order = sorted(ksym, key=lambda k: -ksym[k]['ms'])
+        roofline = dict(bound='mfma', **kernel_entry(order[0]), traffic=None,
+                        definition='achieved = algorithmic FLOPs of this kernel\'s launches in the step (2 x pixels x Cout x KH x KW x Cin per convolution, data + weight gradient '
+                                   'for a paired launch) / their summed HIP-event time, measured live on the launch stream; peak = the matrix pipe the kernel issues on; per-shape rows: '
+                                   'profiles/r06_engine_shapes.txt; rocprofv3 durations of the same command: profiles/r06*_kernel_stats.csv',
+                        by_kernel=[kernel_entry(k) for k in order[:12]], engine=engine)
         # HBM traffic of the engine from the PMC counters (FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 passes over the same step, eager):
         # measured offline with tools/pmc_step.py (rocprofv3 cannot wrap this process from inside) and committed; per launch, like `achieved`
         pmc_path = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
@@ -472,15 +554,31 @@ def run(args, rank, local_rank, world):
             pmc = json.load(open(pmc_path))
             if pmc.get('csrc_digest') != kbuild.source_digest():
                 # counters of another build of the kernels are not this build's traffic: say so instead of quoting them
-                roofline['traffic_note'] = (f"profiles/pmc_traffic.json was measured on kernel sources {str(pmc.get('csrc_digest'))[:12]}, this build is "
+                roofline['traffic_note'] = engine['traffic_note'] = (f"profiles/pmc_traffic.json was measured on kernel sources {str(pmc.get('csrc_digest'))[:12]}, this build is "
                                             f"{kbuild.source_digest()[:12]}: re-run tools/pmc_step.py (two rocprofv3 --pmc passes) to refresh it")
             else:
-                roofline['traffic'] = round(pmc['engine_bytes_per_launch'])
-                roofline['traffic_unit'] = 'HBM bytes per engine launch (mean over the step)'
-                roofline['traffic_gb_per_step'] = round((pmc['engine_total']['fetch'] + pmc['engine_total']['write']) / 1e9, 2)
-                roofline['traffic_over_algorithmic'] = round(roofline['traffic_gb_per_step'] / max(roofline['algorithmic_gb_per_step'], 1e-9), 2)
-                roofline['traffic_over_fp32_algorithmic'] = round(roofline['traffic_gb_per_step'] / max(roofline['algorithmic_gb_per_step_fp32_tensors'], 1e-9), 2)
-                roofline['traffic_source'] = f"profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, two passes over tools/pmc_step.py; kernel sources {pmc['csrc_digest'][:12]} = this build)"
+                engine['traffic'] = round(pmc['engine_bytes_per_launch'])
+                engine['traffic_unit'] = 'HBM bytes per engine launch (mean over the step)'
+                engine['traffic_gb_per_step'] = round((pmc['engine_total']['fetch'] + pmc['engine_total']['write']) / 1e9, 2)
+                engine['traffic_over_algorithmic'] = round(engine['traffic_gb_per_step'] / max(engine['algorithmic_gb_per_step'], 1e-9), 2)
+                engine['traffic_over_fp32_algorithmic'] = round(engine['traffic_gb_per_step'] / max(engine['algorithmic_gb_per_step_fp32_tensors'], 1e-9), 2)
+                src = f"profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, two passes over tools/pmc_step.py; kernel sources {pmc['csrc_digest'][:12]} = this build)"
+                engine['traffic_source'] = src
+
+                def pmc_of(sym):       # 'p3_bwd_pair_nt_kernel<64,64,1w>' <-> rocprofv3's 'p3_bwd_pair_nt_kernel<64, 64, 1, true>': same name, same leading integers
+                    import re
+                    base, nums = sym.split('<')[0], re.findall(r'\d+', sym.split('<', 1)[1]) if '<' in sym else []
+                    hits = [v for k, v in pmc['by_kernel'].items() if k.split('<')[0] == base and re.findall(r'\d+', k.split('<', 1)[1] if '<' in k else '')[:len(nums)] == nums]
+                    if not hits:
+                        return None
+                    return sum(h['fetch'] + h['write'] for h in hits) / max(sum(h['launches'] for h in hits), 1)
+                for ent in [roofline] + roofline['by_kernel']:
+                    t = pmc_of(ent['kernel'])
+                    if t is not None:
+                        ent['traffic'] = round(t)
+                        ent['traffic_over_algorithmic'] = round(t / max(ent['algorithmic_mb_per_launch'] * 1e6, 1.0), 2)
+                roofline['traffic_unit'] = 'HBM bytes per launch of this kernel (FETCH_SIZE x 2 + WRITE_SIZE, mean over its launches in the step)'
+                roofline['traffic_source'] = src
         try:    # the fractions north_star names, each as its own entry (HBM-bound kernels, modulated-conv layer at 256x256, DETR cross-attention)
             sys.path.insert(0, os.path.join(ROOT, 'tools'))
             import bench_hbm_kernels

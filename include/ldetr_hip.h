@@ -527,6 +527,12 @@ int ldetr_struct_sizes(int32_t* out6);
  * waves per block, split-K factor, XCD array rows, XCD array columns, grid z (parity classes / groups), weight-gradient pixel slices, blocks}. */
 int ldetr_p3_last_launch(int32_t* info10);
 
+/* The same for the fp32-operand engine (ldetr_gemm_f32 / ldetr_gemm_pair_f32 / ldetr_conv2d_* / ldetr_conv_transpose2d_*): the calling thread's most
+ * recent contraction launch.  info10 = {kind (1 gemm_f32_kernel tile, 2 gemm_small_kernel, 3 gemm_small_pair_kernel, 4 conv3x3_c32(_split)_kernel,
+ * 5 wgrad_c32_3x3_kernel, 6 stem_conv7x7_kernel), tile rows, tile columns, k-tile, waves per block, FAST (block-uniform address parts in SGPRs),
+ * SPLIT (1 = bf16 pipe with the exact 3-way operand split), split-K factor, blocks, operand modes (AMODE * 16 + BMODE; kinds 2 / 3: ta * 2 + tb)}. */
+int ldetr_engine_last_launch(int32_t* info10);
+
 #ifdef __cplusplus
 }
 #endif

@@ -163,6 +163,7 @@ SIGNATURES = {
     'ldetr_p3_conv2d_fwd_dual': [_P, _P, _I, _I, _I, _I, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P],
     'ldetr_p3_conv2d_bwd_pair': [_P, _I, _I, _I, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P],
     'ldetr_p3_last_launch': [_P],
+    'ldetr_engine_last_launch': [_P],
     'ldetr_struct_sizes': [_P],
     'ldetr_resize_normalize_u8': [_P, _L, _I, _I, _I, _I, _P, _P, _I, _P, _P, _I, _P, _P, _P, _F, _F, _F, _F, _F, _F, _P],
 }

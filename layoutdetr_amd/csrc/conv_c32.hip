@@ -262,6 +262,7 @@ int try_launch_conv_c32(const float* x, const ldetr_tensor4* xt, const float* w,
     // bf16 pipe with the exact operand split unless the engine's switch puts everything on the f32 MFMAs
     if (engine_split_enabled()) hipLaunchKernelGGL(conv3x3_c32_split_kernel, dim3((unsigned)((long)N * wps / 4)), dim3(256), 0, st, p);
     else hipLaunchKernelGGL(conv3x3_c32_kernel, dim3((unsigned)((long)N * wps / 4)), dim3(256), 0, st, p);
+    note_engine_launch(4, 32, 32, 32, 4, 1, engine_split_enabled() ? 1 : 0, 1, (long)N * wps / 4, transposed ? 1 : 0);
     return check_launch("conv3x3_c32") == 0 ? 1 : -1;
 }
 

@@ -1431,6 +1431,7 @@ static int launch_small(GemmParams& p, hipStream_t st) {
         else hipLaunchKernelGGL((gemm_small_kernel<TA, TB, 4>), grid, 256, 0, st, p);
     }
     t_launches_f32++;
+    note_engine_launch(2, 32, 32, 0, w8 ? 8 : 4, fast ? 1 : 0, 0, sk, blocks * sk, TA * 2 + TB);
     return check_launch("gemm_small");
 }
 
@@ -1603,17 +1604,22 @@ static int launch_tile_impl(GemmParams& p, dim3 grid, hipStream_t st) {
                                  : (size_t)2 * BKT * ((BM + 2) + (BN + 2)) * sizeof(float);
     auto kern = gemm_f32_kernel<BM, BN, BKT, AMODE, BMODE, NWV, FAST, SPLIT>;
     if (lds > 64 * 1024) {
-        static bool raised = false;   // one-time opt-in to > 64 KiB of dynamic LDS for this instantiation
-        if (!raised) {
+        // one-time opt-in to > 64 KiB of dynamic LDS for this instantiation, PER DEVICE (a function attribute belongs to the device's code object: a
+        // process that drives a second GPU -- tests, a future multi-device host -- must raise it there as well)
+        static std::atomic<bool> raised[64];
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = -1;
+        if (dev < 0 || !raised[dev].load(std::memory_order_acquire)) {
             if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
                 set_error("gemm: cannot raise the dynamic LDS limit to %zu bytes", lds);
                 return LDETR_ERR_LAUNCH;
             }
-            raised = true;
+            if (dev >= 0) raised[dev].store(true, std::memory_order_release);
         }
     }
     hipLaunchKernelGGL(kern, grid, NWV * 64, lds, st, p);
     (SPLIT ? t_launches_split : t_launches_f32)++;
+    note_engine_launch(1, BM, BN, BKT, NWV, FAST ? 1 : 0, SPLIT ? 1 : 0, p.splitk > 1 ? p.splitk : 1, (long)grid.x * grid.y * grid.z, AMODE * 16 + BMODE);
     return check_launch("gemm_f32");
 }
 
@@ -1927,6 +1933,7 @@ extern "C" int ldetr_gemm_pair_f32(const ldetr_gemm_desc* g0, const ldetr_gemm_d
             } else if (w8) hipLaunchKernelGGL((gemm_small_pair_kernel<1, 1, 1, 1, 8>), grid, 512, 0, st, p0, p1, gx0, nt0, sk0, gx1, nt1, sk1);
             else hipLaunchKernelGGL((gemm_small_pair_kernel<1, 1, 1, 1, 4>), grid, 256, 0, st, p0, p1, gx0, nt0, sk0, gx1, nt1, sk1);
             t_launches_f32++;
+            note_engine_launch(3, 32, 32, 0, w8 ? 8 : 4, (small_fast_ok(p0, 1, 1) && small_fast_ok(p1, 1, 1)) ? 1 : 0, 0, sk0 * 256 + sk1, (long)grid.x, 3 * 4 + 3);
             return check_launch("gemm_small_pair");
         }
         if (!p0.ep.a_rowsum) {
@@ -1940,6 +1947,7 @@ extern "C" int ldetr_gemm_pair_f32(const ldetr_gemm_desc* g0, const ldetr_gemm_d
             } else if (w8) hipLaunchKernelGGL((gemm_small_pair_kernel<0, 1, 1, 1, 8>), grid, 512, 0, st, p0, p1, gx0, nt0, sk0, gx1, nt1, sk1);
             else hipLaunchKernelGGL((gemm_small_pair_kernel<0, 1, 1, 1, 4>), grid, 256, 0, st, p0, p1, gx0, nt0, sk0, gx1, nt1, sk1);
             t_launches_f32++;
+            note_engine_launch(3, 32, 32, 0, w8 ? 8 : 4, (small_fast_ok(p0, 0, 1) && small_fast_ok(p1, 1, 1)) ? 1 : 0, 0, sk0 * 256 + sk1, (long)grid.x, 1 * 4 + 3);
             return check_launch("gemm_small_pair");
         }
     }

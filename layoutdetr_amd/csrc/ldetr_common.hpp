@@ -21,6 +21,12 @@ void set_error(const char* fmt, ...);
 long knob(const char* key, long dflt);
 double knob_f(const char* key, double dflt);
 
+// What the launch policy of the fp32-operand engine chose for the calling thread's most recent contraction launch (ldetr_engine_last_launch; defined in
+// ldetr_core.cpp): kind 1 gemm_f32_kernel<BM, BN, BK, AMODE, BMODE, waves, FAST, SPLIT>, 2 gemm_small_kernel, 3 gemm_small_pair_kernel,
+// 4 conv3x3_c32(_split)_kernel, 5 wgrad_c32_3x3_kernel, 6 stem_conv7x7_kernel.  The parity tests assert the template a bench shape reaches and bench.py
+// labels its per-launch records with it.
+void note_engine_launch(int kind, int bm, int bn, int bk, int waves, int fast, int split, int splitk, long blocks, int modes);
+
 // Slice of the caller-registered workspace (ldetr_set_workspace) for the launches enqueued next; nullptr if unavailable.
 // Defined in gemm_conv.hip next to the split-K ring it shares.
 float* scratch_alloc(size_t bytes);

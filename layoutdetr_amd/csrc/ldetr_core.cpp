@@ -8,6 +8,8 @@
 #include <string>
 #include "../../include/ldetr_hip.h"
 
+namespace ldetr { void note_engine_launch(int kind, int bm, int bn, int bk, int waves, int fast, int split, int splitk, long blocks, int modes); }
+
 namespace ldetr {
 static thread_local char g_err[512] = "";
 void set_error(const char* fmt, ...) {
@@ -46,7 +48,20 @@ double knob_f(const char* key, double dflt) {
     const auto it = m.find(key);
     return it == m.end() ? dflt : atof(it->second.c_str());
 }
+struct EngineLastLaunch { int kind, bm, bn, bk, waves, fast, split, splitk; long blocks; int modes; };
+static thread_local EngineLastLaunch t_engine_last = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+void note_engine_launch(int kind, int bm, int bn, int bk, int waves, int fast, int split, int splitk, long blocks, int modes) {
+    t_engine_last = {kind, bm, bn, bk, waves, fast, split, splitk, blocks, modes};
+}
 }  // namespace ldetr
+
+extern "C" int ldetr_engine_last_launch(int32_t* info10) {
+    if (!info10) { ldetr::set_error("engine_last_launch: null output"); return 1; }
+    const ldetr::EngineLastLaunch& l = ldetr::t_engine_last;
+    const int32_t v[10] = {l.kind, l.bm, l.bn, l.bk, l.waves, l.fast, l.split, l.splitk, (int32_t)(l.blocks > 0x7fffffffL ? 0x7fffffff : l.blocks), l.modes};
+    for (int i = 0; i < 10; i++) info10[i] = v[i];
+    return 0;
+}
 
 extern "C" const char* ldetr_last_error(void) { return ldetr::g_err; }
 extern "C" int ldetr_abi_version(void) { return 24; }

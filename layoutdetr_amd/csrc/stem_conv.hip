@@ -115,6 +115,7 @@ int try_launch_stem_conv(const float* x, const ldetr_tensor4* xt, const float* w
     p.y = y; p.ldy = ldy; p.OH = OH; p.OW = OW;
     const long blocks = (long)xt->N * ((OH + ST_ROWS - 1) / ST_ROWS) * ((OW + ST_COLS - 1) / ST_COLS);
     if (blocks <= 0 || blocks > 0x7fffffffL) return -1;
+    note_engine_launch(6, 0, 64, 0, 4, 1, 0, 1, blocks < 512 ? blocks : 512, 0);
     hipLaunchKernelGGL(stem_conv7x7_kernel, (int)(blocks < 512 ? blocks : 512), 256, 0, st, p);   // two blocks per CU, each walks its tiles
     return check_launch("stem_conv7x7");
 }

@@ -147,6 +147,7 @@ int try_launch_wgrad_smallc(const float* x, const ldetr_tensor4* xt, const float
     p.N = N; p.H = H; p.W = W; p.rows_per_wave = rpw;
     const long units = ((long)N * H) / rpw;
     hipLaunchKernelGGL(wgrad_c32_3x3_kernel, (int)((units + 3) / 4), 256, 0, st, p);
+    note_engine_launch(5, 32, 32, 0, 4, 1, 0, 1, (units + 3) / 4, rpw);
     return check_launch("wgrad_smallc") == 0 ? 1 : -1;
 }
 

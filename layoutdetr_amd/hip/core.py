@@ -59,8 +59,37 @@ def engine_call(tag, flops, thunk, operands=(), nbytes=None):
     c1 = engine_launch_counts()
     if nbytes is None:
         nbytes = 4.0 * sum(t.numel() for t in operands if t is not None)
-    PROF.records.append((tag, float(flops), s, e, nbytes, (c1[0] - c0[0], c1[1] - c0[1])))
+    PROF.records.append((tag, float(flops), s, e, nbytes, (c1[0] - c0[0], c1[1] - c0[1]), launched_kernel(tag)))
     return r
+
+
+_P3_KINDS = {1: 'p3_nt_kernel', 2: 'p3_c3_kernel', 3: 'p3_tn_kernel', 4: 'p3_bwd_pair_nt_kernel', 5: 'p3_bwd_pair_c3_kernel'}
+_ENGINE_KINDS = {1: 'gemm_f32_kernel', 2: 'gemm_small_kernel', 3: 'gemm_small_pair_kernel', 4: 'conv3x3_c32_kernel', 5: 'wgrad_c32_3x3_kernel', 6: 'stem_conv7x7_kernel'}
+
+
+def launched_kernel(tag):
+    """Kernel symbol (with the template arguments the launch policy chose) behind the calling thread's most recent engine call of entry point
+    `tag`: ldetr_p3_last_launch / ldetr_engine_last_launch.  bench.py labels its per-launch records with it; the parity tests assert it."""
+    info = (ctypes.c_int32 * 10)()
+    if tag.startswith('ldetr_p3'):
+        check(lib().ldetr_p3_last_launch(info), 'p3_last_launch')
+        kind, bm, bn, nw, sk = info[0], info[1], info[2], info[3], info[4]
+        name = _P3_KINDS.get(kind, 'p3_?')
+        if kind in (2, 5):
+            return name
+        return f'{name}<{bm},{bn},{nw}w>' + (f' splitK={sk}' if sk > 1 else '')
+    if tag == 'ldetr_token_stack':
+        return 'token-stack kernels (mha_small / mha_cross / ffn / wgrad_multi)'
+    check(lib().ldetr_engine_last_launch(info), 'engine_last_launch')
+    kind, bm, bn, bk, nw, fast, split, sk = [info[i] for i in range(8)]
+    name = _ENGINE_KINDS.get(kind, 'engine_?')
+    if kind == 1:
+        return f'{name}<{bm},{bn},{bk},{nw}w' + (',FAST' if fast else '') + (',SPLIT' if split else '') + '>' + (f' splitK={sk}' if sk > 1 else '')
+    if kind in (2, 3):
+        return f'{name}<{nw}w' + (',FAST' if fast else '') + '>'
+    if kind == 4:
+        return 'conv3x3_c32_split_kernel' if split else name
+    return name
 
 
 def engine_launch_counts():

@@ -222,6 +222,15 @@ class DataParallelStep(object):
             for s in range(0, n, self.bucket):
                 dist.all_reduce(gflat[s:min(n, s + self.bucket)])
 
+    def collective_plan(self, fm, n_stages=None):
+        """The (lo, hi) element ranges of the flat gradient buffer in the order this rank will all-reduce them for one phase: stage by stage
+        (FlatModule.stage_segments; None / un-stageable: the whole buffer), each stage's ranges cut into buckets.  A pure function of the
+        module's parameter list, the stage count and the bucket size -- every rank must compute the same list (tests/test_host_cpu.py
+        checks it at world 2 / 4 / 8 with ranks that MEASURED different stage lengths); a mismatch is a hang in RCCL, not an error."""
+        segs = fm.stage_segments(n_stages) if n_stages else None
+        ranges = [r for stage in segs for r in stage] if segs is not None else [(0, fm.total)]
+        return [(s, min(hi, s + self.bucket)) for lo, hi in ranges for s in range(lo, hi, self.bucket)]
+
     def agree_min(self, values):
         """Element-wise MIN of a short list of host floats over the ranks (CPU tensor under gloo, device tensor under RCCL).  Every decision that
         shapes the sequence of collectives -- the stage count of the overlapped backward above all -- must come out the same on every rank: a rank

@@ -169,6 +169,106 @@ def _dp_worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
+class _TrunkLike(torch.nn.Module):
+    """Parameter names / order of the generator as FlatModule.stage_segments reads them: direct parameters, a ResNet-like `backbone.0.body` with
+    layer1..layer4, heads behind it."""
+
+    def __init__(self):
+        super().__init__()
+        self.token = torch.nn.Parameter(torch.zeros(5))
+        body = torch.nn.Module()
+        body.conv1 = torch.nn.Linear(3, 4)
+        for i, n in enumerate((6, 10, 14, 9)):
+            setattr(body, f'layer{i + 1}', torch.nn.Sequential(torch.nn.Linear(n, n + 1), torch.nn.Linear(n + 1, 3)))
+        bb = torch.nn.Module(); bb.body = body
+        self.backbone = torch.nn.Sequential(bb)
+        self.head = torch.nn.Linear(11, 7)
+        self.text_encoder = torch.nn.Linear(2, 2)      # frozen: outside the flat buffers
+
+
+def _sequence_worker(rank, world, port, q):
+    """Every rank 'measures' different stage lengths (some on either side of the 1.5 ms threshold), agrees on them, derives the stage count and
+    exchanges its flat gradient stage by stage; the sequence of all_reduce calls (offset, length) it ISSUED is returned."""
+    import torch.distributed as dist
+    from layoutdetr_amd.training import training_loop as tl
+    dist.init_process_group('gloo', init_method=f'tcp://127.0.0.1:{port}', rank=rank, world_size=world)
+    torch.manual_seed(0)
+    fm = tl.FlatModule(_TrunkLike())
+    dp = tl.DataParallelStep(world_size=world, bucket_bytes=4 * 40)        # 40-float buckets: several per stage
+    issued = []
+    real = dist.all_reduce
+
+    def recording(t, *a, **k):
+        issued.append((t.storage_offset(), t.numel()))
+        return real(t, *a, **k)
+    dist.all_reduce = recording
+    out = []
+    try:
+        for case, mine in enumerate(([5.0, 1.45 + 0.02 * rank, 3.0], [5.0, 1.6 + 0.1 * rank, 1.7], [4.0 - 0.3 * rank, 9.0, 2.0 + rank])):
+            agreed = dp.agree_min(mine)
+            issued.clear()                       # (the agreement itself is a collective too: same on every rank by construction)
+            n = tl.backward_stage_count(16, agreed)
+            fm.gflat.copy_(torch.arange(fm.total, dtype=torch.float32) * (rank + 1))
+            plan = dp.collective_plan(fm, n)
+            for stage in fm.stage_segments(n):       # what staged_backward does after each stage of the backward
+                for lo, hi in stage:
+                    dp.exchange_async(fm.gflat, lo, hi)
+            dp.finish()
+            ok_sum = torch.equal(fm.gflat, torch.arange(fm.total, dtype=torch.float32) * (world * (world + 1) / 2))
+            out.append((case, n, list(issued), [(lo, hi - lo) for lo, hi in plan], bool(ok_sum)))
+    finally:
+        dist.all_reduce = real
+    q.put((rank, out))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('world', [2, 4, 8])
+def test_collective_sequence_is_identical_on_every_rank(world):
+    """RCCL readiness without hardware: segment bounds, bucket order and stage count of the overlapped exchange on 2 / 4 / 8 ranks (gloo) whose
+    LOCAL stage measurements differ -- every rank must issue the same all_reduce sequence, equal to DataParallelStep.collective_plan, covering the
+    flat buffer exactly once, for the 2-stage and the 3-stage cut."""
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0)); port = sk.getsockname()[1]
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_sequence_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in ps:
+        p.start()
+    res = dict(q.get(timeout=180) for _ in range(world))
+    for p in ps:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    stage_counts = set()
+    for case in range(3):
+        ref = res[0][case]
+        stage_counts.add(ref[1])
+        for r in range(world):
+            c, n, issued, plan, ok_sum = res[r][case]
+            assert (c, n) == (case, ref[1]), f'rank {r} chose {n} stages, rank 0 {ref[1]}'
+            assert issued == ref[2], f'rank {r} issued a different collective sequence in case {case}'
+            assert issued == plan, 'the issued sequence is not the planned one'
+            assert ok_sum, 'SUM over the ranks is wrong'
+        covered = sorted(ref[2])
+        assert covered[0][0] == 0 and all(a[0] + a[1] == b[0] for a, b in zip(covered, covered[1:])), 'the segments do not tile the flat buffer'
+    assert stage_counts == {2, 3}, f'the cases must exercise both cuts, got {stage_counts}'
+
+
+def test_bench_preflight_refuses_more_local_ranks_than_gpus():
+    """`bench.py --gpus N` under torch.distributed.run on a node that shows fewer GPUs than local ranks: ONE parsable line on rank 0, exit code 2,
+    before any rendezvous (here: no GPU at all)."""
+    import json
+    import subprocess
+    env = dict(os.environ, RANK='0', LOCAL_RANK='0', WORLD_SIZE='2', LOCAL_WORLD_SIZE='2', MASTER_ADDR='127.0.0.1', MASTER_PORT='29999',
+               HIP_VISIBLE_DEVICES='', CUDA_VISIBLE_DEVICES='')
+    env.pop('LDETR_BENCH_SHARE_GPU', None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '1', '--warmup', '0'], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 2, (r.returncode, r.stderr[-500:])
+    line = [l for l in r.stdout.splitlines() if l.startswith('{')]
+    assert len(line) == 1
+    d = json.loads(line[0])
+    assert d['value'] is None and d['n_gpus'] == 2 and 'GPU(s) visible' in d['error']
+
+
 def test_dp_gradient_exchange_gloo_world2():
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
