@@ -47,22 +47,34 @@ def make_batch(b, bg, device, seed):
     return bt
 
 
-def to_device_batch(bt, device, text_mode='features', text_tokens=40):
+LAST_TEXT_EVAL = [None]     # token positions the last to_device_batch() kept per element text (None: text features in)
+
+
+def to_device_batch(bt, device, text_mode='features', text_tokens=256, text_valid=(8, 40), text_padded=False):
+    """text path on: synthetic tokenizer output as the reference's tokenizer produces it (networks_detr.py:71,145: padding='max_length', max_length 256) --
+    random word ids on the first 8..40 positions, [PAD] = 0 behind them.  Unless text_padded, the all-padding tail shared by the whole
+    batch is dropped on the host (what tokenizer.texts_to_tokens does for strings: T = the batch's longest text; same CLS features / LM loss / gradients,
+    tests/test_composition_gpu.py::test_trimmed_text_tokens_equal_the_reference_padding_to_256) -> batch (LAST_TEXT_EVAL[0] = the evaluated token positions)."""
     from layoutdetr_amd.training.networks_detr import TextFeatures, TextTokens
     b = bt['bbox_real'].shape[0]
+    t_eval = None
     if text_mode == 'features':
         text = TextFeatures(bt['text_feat'].to(device), bt['text_len'].to(device))
-    else:   # synthetic tokenizer output: random word ids, ragged lengths, [PAD] = 0 behind them
+    else:
         g = torch.Generator().manual_seed(7)
         ids = torch.randint(1000, 30000, (b, 9, text_tokens), generator=g)
-        lens = torch.randint(3, text_tokens + 1, (b, 9), generator=g)
+        lens = torch.randint(min(text_valid[0], text_tokens), min(text_valid[1], text_tokens) + 1, (b, 9), generator=g)
         am = (torch.arange(text_tokens)[None, None, :] < lens[..., None]).long()
-        text = TextTokens((ids * am).to(device), am.to(device), bt['text_len'].to(device))
-    return dict(bbox_real=bt['bbox_real'].to(device), bbox_class=bt['bbox_class'].to(device),
-                bbox_text=text,
-                bbox_patch=torch.zeros(b, 9, 1, 1, 1, device=device).expand(b, 9, 3, 256, 256),  # shape only (0-stride view)
-                padding_mask=bt['padding_mask'].to(device), background=bt['background'].to(device),
-                real_c=torch.zeros(b, 0, device=device), gen_c=torch.zeros(b, 0, device=device))
+        ids = ids * am
+        t_eval = text_tokens if text_padded else max(int(lens.max()), 2)
+        text = TextTokens(ids[..., :t_eval].contiguous().to(device), am[..., :t_eval].contiguous().to(device), bt['text_len'].to(device))
+    batch = dict(bbox_real=bt['bbox_real'].to(device), bbox_class=bt['bbox_class'].to(device),
+                 bbox_text=text,
+                 bbox_patch=torch.zeros(b, 9, 1, 1, 1, device=device).expand(b, 9, 3, 256, 256),  # shape only (0-stride view)
+                 padding_mask=bt['padding_mask'].to(device), background=bt['background'].to(device),
+                 real_c=torch.zeros(b, 0, device=device), gen_c=torch.zeros(b, 0, device=device))
+    LAST_TEXT_EVAL[0] = t_eval
+    return batch
 
 
 def _host_cpu():
@@ -179,7 +191,9 @@ def parse_args():
     ap.add_argument('--text-mode', default='features', choices=['features', 'encoder', 'encoder+lm'],
                     help="'features' (headline config: frozen-BERT CLS features are the input); 'encoder': token ids in, the frozen text encoder runs "
                          "inside every G/D forward; 'encoder+lm': plus the trainable LM text decoder and its loss (SURVEY 8f-1)")
-    ap.add_argument('--text-tokens', type=int, default=40, help='tokens per element text (reference: padding to max_text_length)')
+    ap.add_argument('--text-tokens', type=int, default=256, help='token positions per element text as the tokenizer pads them (reference: max_text_length = 256, networks_detr.py:71,145)')
+    ap.add_argument('--text-valid', default='8-40', help='range of real tokens per element text (SURVEY 8d: 8-40), the rest is [PAD]')
+    ap.add_argument('--text-padded', action='store_true', help='evaluate all --text-tokens positions as the reference does, instead of the batch-longest text (same values, parity-tested)')
     ap.add_argument('--no-share-trunk', action='store_true', help="evaluate D's ResNet trunk separately for the fake and the real pass of Dmain, as the reference does")
     ap.add_argument('--share-trunk', default='iteration', choices=['phase', 'iteration'],
                     help="how often D's ResNet trunk runs on the iteration's backgrounds: 'iteration' (default) once -- D's weights do not change between Gmain and Dmain "
@@ -280,6 +294,7 @@ def run(args, rank, local_rank, world):
     n_params = (pG.fm.total, pD.fm.total)
     torch.manual_seed(0 * world + rank)   # training_loop.py:101-102 seed rule
     side = torch.cuda.Stream()
+    text_eval = [None]
 
     def barrier():
         if world > 1:
@@ -293,7 +308,9 @@ def run(args, rank, local_rank, world):
         gb = b_local * world
         dp = dp_world if not local_only else tl.DataParallelStep(world_size=1)
         loss = StyleGAN2Loss(device, G, D, share_D_trunk=share)
-        batch = to_device_batch(make_batch(b_local, bg, device, 1000 + rank), device, args.text_mode, args.text_tokens)
+        lo_, _, hi_ = args.text_valid.partition('-')
+        batch = to_device_batch(make_batch(b_local, bg, device, 1000 + rank), device, args.text_mode, args.text_tokens, (int(lo_), int(hi_ or lo_)), args.text_padded)
+        text_eval[0] = LAST_TEXT_EVAL[0]
         cur_nimg = [0]
 
         def eager_step():
@@ -601,9 +618,9 @@ def run(args, rank, local_rank, world):
                                              'quote it with phase_trunk_sharing_images_s (once per phase) and reference_call_pattern_images_s (once per D pass, as training/loss.py does)',
                                workload=f'BASELINE configs[{2 if world == 1 else 3}]: global batch {args.batch} ({b_local} per GPU), {bg}x{bg} backgrounds x 9 elements, full G+D adversarial '
                                         'step (Gmain+Dmain fwd/bwd, grad exchange + nan_to_num, Adam, EMA), train mode (dropout 0.1); ' +
-                                        ('hot-path-only: frozen-BERT text features are an input, LM-decoder loss excluded' if args.text_mode == 'features' else f'text path on: {args.text_mode}, {args.text_tokens} tokens per element'),
+                                        ('hot-path-only: frozen-BERT text features are an input, LM-decoder loss excluded' if args.text_mode == 'features' else f'text path on: {args.text_mode}, element texts of {args.text_valid} tokens padded to {args.text_tokens} as the reference tokenizer does; ' + (f'all {args.text_tokens} positions evaluated' if args.text_padded else f'the batch-longest text ({text_eval[0]} positions) evaluated: same values, parity-tested')),
                                global_batch=args.batch, per_gpu_batch=b_local, background=bg, elements=9,
-                               parallelism=f'dp{world}', hip_graph=not args.no_graph, allreduce_overlapped_with_backward=(world > 1 and not args.no_graph and not args.no_overlap), text_mode=args.text_mode, text_tokens=(args.text_tokens if args.text_mode != 'features' else None), d_trunk_shared=False if args.no_share_trunk else args.share_trunk, params_G=n_params[0], params_D=n_params[1]),
+                               parallelism=f'dp{world}', hip_graph=not args.no_graph, allreduce_overlapped_with_backward=(world > 1 and not args.no_graph and not args.no_overlap), text_mode=args.text_mode, text_tokens=(args.text_tokens if args.text_mode != 'features' else None), text_tokens_evaluated=text_eval[0], d_trunk_shared=False if args.no_share_trunk else args.share_trunk, params_G=n_params[0], params_D=n_params[1]),
                    roofline=roofline, cpu_baseline=cpu, **extra)
         print(json.dumps(out), flush=True)
     if world > 1:

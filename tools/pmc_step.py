@@ -36,7 +36,7 @@ def aggregate(dir_f, dir_w, iters):
     eng = [k for k in out if k.startswith(('gemm_', 'p3_nt_', 'p3_c3_', 'p3_tn_', 'p3_bwd_pair_', 'conv3x3_c32', 'wgrad_c32', 'stem_conv', 'mha_small_', 'mha_cross_', 'ffn_', 'wgrad_multi'))]   # every kernel behind hip.core.engine_call
     tot = dict(fetch=sum(out[k]['fetch'] for k in eng), write=sum(out[k]['write'] for k in eng), launches=sum(out[k]['launches'] for k in eng))
     from layoutdetr_amd import build as kbuild
-    return dict(csrc_digest=kbuild.source_digest(), note='rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes over tools/pmc_step.py (2 eager iterations, B=16, 256x256); bytes per ITERATION; '
+    return dict(csrc_digest=kbuild.source_digest(), note='rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes over tools/pmc_step.py (2 eager iterations; default B=16, 256x256, text features in); bytes per ITERATION; '
                      'FETCH_SIZE doubled (gfx950 128-B requests tallied at 64 B), WRITE_SIZE as reported', engine_total=tot,
                 engine_bytes_per_launch=(tot['fetch'] + tot['write']) / max(tot['launches'], 1), by_kernel={k: out[k] for k in sorted(out, key=lambda k: -(out[k]['fetch'] + out[k]['write']))})
 
@@ -50,17 +50,22 @@ def main():
     from layoutdetr_amd.training import training_loop as tl
     from layoutdetr_amd.training.loss import StyleGAN2Loss
     from layoutdetr_amd.training.networks_detr import Discriminator, Generator
-    b = 16
+    import argparse
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--b', type=int, default=16); ap.add_argument('--bg', type=int, default=256); ap.add_argument('--text-mode', default='features')
+    a = ap.parse_args()
+    b, bg = a.b, a.bg
     dev = torch.device('cuda:0')
     torch.manual_seed(0)
-    kw = dict(num_bbox_labels=8, img_channels=3, img_height=256, img_width=256, c_dim=0, background_size=256, bert_f_dim=768, im_f_dim=512)
+    kw = dict(num_bbox_labels=8, img_channels=3, img_height=bg, img_width=bg, c_dim=0, background_size=bg, bert_f_dim=768, im_f_dim=512,
+              bert_num_heads=4, bert_num_encoder_layers=12, bert_num_decoder_layers=2, text_mode=a.text_mode)
     G = Generator(z_dim=4, **kw).train().requires_grad_(False).to(dev)
     D = Discriminator(**kw).train().requires_grad_(False).to(dev)
     G.static_shapes = D.static_shapes = True
     pG, pD = tl.Phase('Gmain', G, lr=1e-5), tl.Phase('Dmain', D, lr=1e-5)
     loss = StyleGAN2Loss(dev, G, D, share_D_trunk='iteration')     # the bench headline's setting
     dp = tl.DataParallelStep(1)
-    batch = bench.to_device_batch(bench.make_batch(b, 256, dev, 1), dev)
+    batch = bench.to_device_batch(bench.make_batch(b, bg, dev, 1), dev, a.text_mode)
     for _ in range(2):
         z = [torch.randn(b, 9, 4, device=dev) for _ in range(2)]
         tl.training_iteration(loss, [pG, pD], dp, batch, b, z)
