@@ -45,11 +45,18 @@ __device__ __forceinline__ void adam_elem(float& p, float g, float& m, float& v,
     p -= (a.lr / a.bc1) * (m / denom);
 }
 
+// Block -> address mapping (round 6, tools/probes/stream_probe.hip at D's 90 M parameters = 1.44 GB of p / g / m / v, far beyond the 256 MB Infinity Cache): a block owns
+// 16 KB-contiguous chunks of every array (4 rounds of its 256 lanes x 16 B) and strides over chunks -- 5.54 TB/s against 5.11 for the plain grid-stride loop, 4.65 for
+// XCD-contiguous eighths (each XCD streaming its own region: worse, not better), 4.9 .. 5.4 for 64 KB .. 1 MB chunks; a plain copy on the same box reaches 5.64 TB/s.
+constexpr long STREAM_CHUNK4 = 1024;     // float4 per chunk
+
 template <bool EMA>      // (as a run-time branch on a.pe the plain step lost 7 % of its rate: 5.19 vs 5.58 TB/s)
 __global__ __launch_bounds__(256) void adam_kernel(AdamParams a) {
     const long n4 = a.n >> 2;
     const long stride = (long)gridDim.x * blockDim.x;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+    for (long c = (long)blockIdx.x * STREAM_CHUNK4; c < n4; c += (long)gridDim.x * STREAM_CHUNK4) {
+      const long ce = c + STREAM_CHUNK4 < n4 ? c + STREAM_CHUNK4 : n4;
+      for (long i = c + threadIdx.x; i < ce; i += 256) {
         // g, m, v are touched once per step (2.5 GB for D: nothing of it survives in the 256 MB Infinity Cache anyway): non-temporal, so the
         // stream does not evict the parameters, which the next phase's first kernels read
         f32x4 pv = reinterpret_cast<f32x4*>(a.p)[i];
@@ -68,6 +75,7 @@ __global__ __launch_bounds__(256) void adam_kernel(AdamParams a) {
             __builtin_nontemporal_store(f32x4{p.x + a.ema_beta * (ev[0] - p.x), p.y + a.ema_beta * (ev[1] - p.y),
                                               p.z + a.ema_beta * (ev[2] - p.z), p.w + a.ema_beta * (ev[3] - p.w)}, reinterpret_cast<f32x4*>(a.pe) + i);
         }
+      }
     }
     for (long i = (n4 << 2) + (long)blockIdx.x * blockDim.x + threadIdx.x; i < a.n; i += stride) {
         adam_elem(a.p[i], a.g[i], a.m[i], a.v[i], a);
@@ -78,20 +86,23 @@ __global__ __launch_bounds__(256) void adam_kernel(AdamParams a) {
 __global__ __launch_bounds__(256) void ema_kernel(float* pe, const float* p, long n, float beta) {
     const long n4 = n >> 2;
     const long stride = (long)gridDim.x * blockDim.x;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+    for (long c = (long)blockIdx.x * STREAM_CHUNK4; c < n4; c += (long)gridDim.x * STREAM_CHUNK4) {     // block-owned 16 KB chunks, see adam_kernel
+      const long ce = c + STREAM_CHUNK4 < n4 ? c + STREAM_CHUNK4 : n4;
+      for (long i = c + threadIdx.x; i < ce; i += 256) {
         float4 a = reinterpret_cast<const float4*>(p)[i];
         const f32x4 ev = __builtin_nontemporal_load(reinterpret_cast<f32x4*>(pe) + i);     // p_ema is touched once per iteration: streaming
         float4 e = make_float4(ev[0], ev[1], ev[2], ev[3]);
         e.x = a.x + beta * (e.x - a.x); e.y = a.y + beta * (e.y - a.y);
         e.z = a.z + beta * (e.z - a.z); e.w = a.w + beta * (e.w - a.w);
         __builtin_nontemporal_store(f32x4{e.x, e.y, e.z, e.w}, reinterpret_cast<f32x4*>(pe) + i);
+      }
     }
     for (long i = (n4 << 2) + (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
         pe[i] = p[i] + beta * (pe[i] - p[i]);
 }
 
 static inline int stream_grid(long n) {
-    long g = (n / 4 + 255) / 256;
+    long g = (n / 4 + STREAM_CHUNK4 - 1) / STREAM_CHUNK4;      // one block per 16 KB chunk, at most 16 blocks per CU (adam / ema; the sanitise loop strides by the grid either way)
     if (g > 256 * 16) g = 256 * 16;
     if (g < 1) g = 1;
     return (int)g;

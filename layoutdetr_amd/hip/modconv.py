@@ -29,6 +29,18 @@ def _mul_reduce(a, x, scale, B, P, C, want_out=True):
     return out, red
 
 
+def _prescaled_for_wgrad(x, dv, s, d, B, H):
+    """Operands of a layer's weight gradient dW = sum_b s_b (x_b (*) (dv_b d_b)): -> (x, dv, style scale, demodulation scale) to hand to the weight-gradient
+    launch.  The launch can apply the per-sample scales itself (K slices aligned to samples, partial tiles merged by atomics): right for the large
+    layers.  On the 4x4 .. 16x16 layers at >= 8 samples that costs more than it saves -- 16 slices of 16 .. 256 pixels each write a full
+    [Cout, 9 Cin] partial (150 MB of atomics at 512 channels; measured at 16 samples: 8x8 162 -> 66 us, 4x4 58 -> 42 us, 16x16 266 -> 211 us,
+    tools/bench_sg2_wgrad.py) -- so the two small operands are scaled first (two element-wise launches over <= 8 MB) and the reduction is split
+    freely.  At 2 samples per GPU or from 32x32 on the in-launch scales win."""
+    if B >= 8 and H <= 16:
+        return x * s[:, None, None, :], dv * d[:, None, None, :], None, None
+    return x, dv, s, d
+
+
 class _ModConvFn(torch.autograd.Function):
     """y = lrelu(conv3x3(x * s) * d + bias) * gain      (up == 1)"""
 
@@ -78,9 +90,10 @@ class _ModConvFn(torch.autograd.Function):
                 dw_ohwi = torch.empty((O, KH, KW, I), device=dy.device, dtype=torch.float32)
             xt = core.tensor4_nhwc(x)
             sk = 0   # the library picks tile and split-K factor together
-            core.engine_call('ldetr_conv2d_bwd_weight_f32', 2.0 * B * OH * OW * O * KH * KW * I, lambda: core.check(core.lib().ldetr_conv2d_bwd_weight_f32(core.ptr(x), ctypes.byref(xt), core.ptr(dv), ctypes.byref(dvt),
-                                                              core.ptr(dw_ohwi), KH, KW, 1, pad, sk, core.ptr(s), s.stride(0),
-                                                              core.ptr(d), d.stride(0), acc, core.stream()), 'modconv_bwd_weight'), operands=(x, dv, dw_ohwi))
+            xw, dvw, sw, dw_ = _prescaled_for_wgrad(x, dv, s, d, B, H)
+            core.engine_call('ldetr_conv2d_bwd_weight_f32', 2.0 * B * OH * OW * O * KH * KW * I, lambda: core.check(core.lib().ldetr_conv2d_bwd_weight_f32(core.ptr(xw), ctypes.byref(xt), core.ptr(dvw), ctypes.byref(dvt),
+                                                              core.ptr(dw_ohwi), KH, KW, 1, pad, sk, core.ptr(sw), sw.stride(0) if sw is not None else 0,
+                                                              core.ptr(dw_), dw_.stride(0) if dw_ is not None else 0, acc, core.stream()), 'modconv_bwd_weight'), operands=(x, dv, dw_ohwi))
             dw = None if acc else _grad_to_oihw(dw_ohwi)
         return dx, dw, ds, ddemod, dbias, None, None, None
 
@@ -142,9 +155,10 @@ class _ModConvUpFn(torch.autograd.Function):
                 dw_ohwi = torch.empty((O, KH, KW, I), device=dy.device, dtype=torch.float32)
             xt = core.tensor4_nhwc(x)
             sk = 0   # the library picks tile and split-K factor together
-            core.engine_call('ldetr_conv_transpose2d_bwd_weight_f32', 2.0 * B * H * W * O * KH * KW * I, lambda: core.check(core.lib().ldetr_conv_transpose2d_bwd_weight_f32(core.ptr(x), ctypes.byref(xt), core.ptr(dud), ctypes.byref(dudt),
-                                                                        core.ptr(dw_ohwi), KH, KW, 2, 0, sk, core.ptr(s), s.stride(0),
-                                                                        core.ptr(d), d.stride(0), acc, core.stream()), 'modconv_up_bwd_weight'), operands=(x, dud, dw_ohwi))
+            xw, dudw, sw, dw_ = _prescaled_for_wgrad(x, dud, s, d, B, H)
+            core.engine_call('ldetr_conv_transpose2d_bwd_weight_f32', 2.0 * B * H * W * O * KH * KW * I, lambda: core.check(core.lib().ldetr_conv_transpose2d_bwd_weight_f32(core.ptr(xw), ctypes.byref(xt), core.ptr(dudw), ctypes.byref(dudt),
+                                                                        core.ptr(dw_ohwi), KH, KW, 2, 0, sk, core.ptr(sw), sw.stride(0) if sw is not None else 0,
+                                                                        core.ptr(dw_), dw_.stride(0) if dw_ is not None else 0, acc, core.stream()), 'modconv_up_bwd_weight'), operands=(x, dud, dw_ohwi))
             dw = None if acc else _grad_to_oihw(dw_ohwi)
         return dx, dw, ds, ddemod, dbias, None, None, None
 

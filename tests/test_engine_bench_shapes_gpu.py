@@ -64,10 +64,10 @@ SG2_LAYERS = [
 SG2_EXPECT = {
     (4, 512, 512, 1): {'conv2d_fwd': ['gemm_f32_kernel<64,64,32,4w,FAST,SPLIT> splitK=12'], 'conv2d_bwd_data': ['gemm_f32_kernel<64,64,32,4w,FAST,SPLIT> splitK=12'], 'conv2d_bwd_weight': ['gemm_f32_kernel<64,64,32,4w>']},
     (4, 512, 512, 2): {'conv_transpose2d_fwd': ['gemm_f32_kernel<64,64,32,4w,FAST,SPLIT>'], 'conv_transpose2d_bwd_data': ['gemm_f32_kernel<64,64,32,4w,FAST,SPLIT> splitK=12'], 'conv_transpose2d_bwd_weight': ['gemm_f32_kernel<64,64,32,4w>']},
-    (8, 512, 512, 1): {'conv2d_fwd': ['gemm_f32_kernel<128,64,32,4w,FAST,SPLIT> splitK=8'], 'conv2d_bwd_data': ['gemm_f32_kernel<128,64,32,4w,FAST,SPLIT> splitK=8'], 'conv2d_bwd_weight': ['gemm_f32_kernel<128,128,32,8w,FAST> splitK=16']},
-    (8, 512, 512, 2): {'conv_transpose2d_fwd': ['gemm_f32_kernel<64,64,32,4w,FAST,SPLIT>'], 'conv_transpose2d_bwd_data': ['gemm_f32_kernel<128,64,32,4w,FAST,SPLIT> splitK=8'], 'conv_transpose2d_bwd_weight': ['gemm_f32_kernel<128,128,32,8w,FAST> splitK=16']},
-    (16, 512, 512, 1): {'conv2d_fwd': ['gemm_f32_kernel<128,64,32,4w,FAST,SPLIT> splitK=2'], 'conv2d_bwd_data': ['gemm_f32_kernel<128,64,32,4w,FAST,SPLIT> splitK=2'], 'conv2d_bwd_weight': ['gemm_f32_kernel<128,128,32,4w,FAST,SPLIT> splitK=16']},
-    (16, 512, 256, 2): {'conv_transpose2d_fwd': ['gemm_f32_kernel<128,64,32,4w,FAST,SPLIT>'], 'conv_transpose2d_bwd_data': ['gemm_f32_kernel<128,64,32,4w,FAST,SPLIT> splitK=2'], 'conv_transpose2d_bwd_weight': ['gemm_f32_kernel<128,128,32,4w,FAST,SPLIT> splitK=16']},
+    (8, 512, 512, 1): {'conv2d_fwd': ['gemm_f32_kernel<128,64,32,4w,FAST,SPLIT> splitK=8'], 'conv2d_bwd_data': ['gemm_f32_kernel<128,64,32,4w,FAST,SPLIT> splitK=8'], 'conv2d_bwd_weight': ['gemm_f32_kernel<128,64,32,4w,FAST,SPLIT> splitK=2']},
+    (8, 512, 512, 2): {'conv_transpose2d_fwd': ['gemm_f32_kernel<64,64,32,4w,FAST,SPLIT>'], 'conv_transpose2d_bwd_data': ['gemm_f32_kernel<128,64,32,4w,FAST,SPLIT> splitK=8'], 'conv_transpose2d_bwd_weight': ['gemm_f32_kernel<128,64,32,4w,FAST,SPLIT> splitK=2']},
+    (16, 512, 512, 1): {'conv2d_fwd': ['gemm_f32_kernel<128,64,32,4w,FAST,SPLIT> splitK=2'], 'conv2d_bwd_data': ['gemm_f32_kernel<128,64,32,4w,FAST,SPLIT> splitK=2'], 'conv2d_bwd_weight': ['gemm_f32_kernel<128,128,32,4w,FAST,SPLIT> splitK=4']},
+    (16, 512, 256, 2): {'conv_transpose2d_fwd': ['gemm_f32_kernel<128,64,32,4w,FAST,SPLIT>'], 'conv_transpose2d_bwd_data': ['gemm_f32_kernel<128,64,32,4w,FAST,SPLIT> splitK=2'], 'conv_transpose2d_bwd_weight': ['gemm_f32_kernel<128,128,32,4w,FAST,SPLIT> splitK=8']},
     (32, 256, 256, 1): {'conv2d_fwd': ['gemm_f32_kernel<128,64,32,4w,FAST,SPLIT>'], 'conv2d_bwd_data': ['gemm_f32_kernel<128,64,32,4w,FAST,SPLIT>'], 'conv2d_bwd_weight': ['gemm_f32_kernel<128,128,32,4w,FAST,SPLIT> splitK=16']},
     (32, 256, 128, 2): {'conv_transpose2d_fwd': ['gemm_f32_kernel<128,128,32,4w,FAST,SPLIT>'], 'conv_transpose2d_bwd_data': ['gemm_f32_kernel<128,64,32,4w,FAST,SPLIT>'], 'conv_transpose2d_bwd_weight': ['gemm_f32_kernel<128,128,32,4w,FAST,SPLIT> splitK=32']},
     (64, 128, 128, 1): {'conv2d_fwd': ['gemm_f32_kernel<128,128,32,4w,FAST,SPLIT>'], 'conv2d_bwd_data': ['gemm_f32_kernel<128,128,32,4w,FAST,SPLIT>'], 'conv2d_bwd_weight': ['gemm_f32_kernel<128,128,32,4w,FAST,SPLIT> splitK=64']},
