@@ -36,13 +36,34 @@ class _EngineProfile(object):
 PROF = _EngineProfile()
 
 
+_LEGACY_ENV = ('LDETR_PAIR_D', 'LDETR_DUAL_TRUNK', 'LDETR_FUSED_LAYOUT_LOSSES', 'LDETR_FFN_FUSED', 'LDETR_FFN_FUSED_LARGE', 'LDETR_GROUP_KV', 'LDETR_NO_WORKSPACE',
+               'LDETR_TOKEN_STACKS', 'LDETR_SPLIT_BF16', 'LDETR_GEMM_PAIR', 'LDETR_P3_PAIR')
+_legacy_warned = [False]
+
+
+def _warn_legacy_env():
+    """The development switches of rounds 1-4 were individual LDETR_* variables; since round 5 they are keys of LDETR_DEBUG="KEY=value,...".  A script that
+    still sets an old name would silently run the default path: say so once."""
+    if _legacy_warned[0]:
+        return
+    _legacy_warned[0] = True
+    old = [k for k in _LEGACY_ENV if k in os.environ]
+    if old:
+        import warnings
+        warnings.warn(f'{", ".join(old)}: these switches are keys of LDETR_DEBUG now (e.g. LDETR_DEBUG="{old[0][6:]}=0") and are IGNORED as variables; see DESIGN.md, "Diagnostic switches"')
+
+
 def knob(key, default):
     """Development knob `key` of LDETR_DEBUG="KEY=value,KEY=value" (the one variable the kernel library reads as well: csrc/ldetr_core.cpp), as an int;
     unset -> default (the measured best).  Keys: DESIGN.md, "Diagnostic switches"."""
+    _warn_legacy_env()
     for kv in os.environ.get('LDETR_DEBUG', '').split(','):
         k, _, v = kv.partition('=')
         if k.strip() == key and v.strip():
-            return int(v)
+            try:
+                return int(v)
+            except ValueError:
+                return int(float(v))      # the C side parses with atol / atof: accept what it accepts
     return default
 
 
@@ -345,6 +366,11 @@ class _ZeroArena(object):
         return out
 
     def end(self):
+        # LDETR_DEBUG="ARENA_GUARD=1": poison what the phase handed out.  An arena view that outlives its phase -- adopted as a leaf .grad, kept on a
+        # graph that spans phases -- then shows up as NaN in the next consumer instead of as a silently re-zeroed gradient; the GPU
+        # suite is run once with the guard on (profiles/r06_arena_guard.txt).
+        if self.open is not None and self.cursor and knob('ARENA_GUARD', 0) and not torch.cuda.is_current_stream_capturing():
+            self.buf[self.open][0][:self.cursor].fill_(float('nan'))
         self.open = None
 
 

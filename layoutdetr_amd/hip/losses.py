@@ -78,6 +78,12 @@ class _CombineFn(torch.autograd.Function):
 def combine(terms, gain=1.0):
     """terms: list of Term -> (total * gain as a scalar with autograd, {name: weighted value(s) as the reference reports them}).
     total = mean over the batch of the sum of the terms (scalars broadcast)."""
+    if gain == 0:
+        raise ValueError('combine: gain must be non-zero (the reported values are recovered from the gain-weighted ones)')
+    if not all(t.x.is_cuda for t in terms):
+        raise RuntimeError('combine: every term must live in GPU memory (no CPU fallback); got ' + ', '.join(str(t.x.device) for t in terms))
+    if sum(len(t.rows()) for t in terms) > 16:
+        raise ValueError(f'combine: at most 16 rows per launch (csrc/layout_loss.hip), got {sum(len(t.rows()) for t in terms)}: split the phase tail')
     spec = [[(w * gain, fn, red) for _, w, fn, red in t.rows()] for t in terms]
     total, vals, sums = _CombineFn.apply(spec, *[t.x for t in terms])
     inv = 1.0 / gain if gain != 1.0 else 1.0

@@ -63,7 +63,9 @@ def usable(prog):
         sa = l.self_attn
         if sa.num_heads != N_HEAD or sa.in_proj_weight.shape[1] != D_MODEL or l.linear1.weight.shape[0] % 64 != 0 or l.linear1.bias is None or l.linear2.bias is None:
             return False
-        if prog.kind == 'dec' and l.multihead_attn.num_heads != N_HEAD:
+        if sa.in_proj_bias is None or sa.out_proj.bias is None:        # the group kernels read both unconditionally (nn.MultiheadAttention(bias=False) takes the generic path)
+            return False
+        if prog.kind == 'dec' and (l.multihead_attn.num_heads != N_HEAD or l.multihead_attn.in_proj_bias is None or l.multihead_attn.out_proj.bias is None):
             return False
     if prog.kind == 'dec' and (prog.kvs is None or len(prog.kvs) != len(prog.layers)):
         return False

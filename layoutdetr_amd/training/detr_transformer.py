@@ -202,13 +202,13 @@ class TransformerDecoder(nn.Module):
             if hstacks.usable(prog):
                 outs = hstacks.run([prog] + ([partner] if partner is not None else []))
                 return outs[0] if partner is None else (outs[0], outs[1])
-        if partner is not None:
-            return self.forward2d(t2, mem2, pos2, B, Lq, S, tgt_kpm, mem_kpm, mem_pos2=mem_pos2), hstacks.run([partner])[0]
+        # the stack node did not take this stack (> 16 queries, > 512 rows, another width): the per-layer launches on the K / V blocks already projected
+        # above; a partner runs on its own
         for i, layer in enumerate(self.layers):
             t2, mem2, mem_pos2 = layer.forward2d(t2, mem2, mem_pos2, B, Lq, S, tgt_kpm, mem_kpm, kv=None if kvs is None else kvs[i])
         if self.norm is not None:
             t2 = add_layernorm(t2, None, self.norm.weight, self.norm.bias, self.norm.eps)
-        return t2
+        return t2 if partner is None else (t2, hstacks.run([partner])[0])
 
 
 def _rows_from_nchw(x):
