@@ -20,7 +20,7 @@ import torch
 from . import core
 
 FUSED = True      # module switches (tests / A-B runs set them)
-MAX_ROWS = 512
+MAX_ROWS = core.knob('FFN_MAX_ROWS', 512)      # LDETR_DEBUG="FFN_MAX_ROWS=n": A/B of the fused block on the 64-token encoders (1024 / 2048 rows)
 
 
 def usable(x2, linear1, linear2):
