@@ -582,10 +582,27 @@ def run(args, rank, local_rank, world):
                 src = f"profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, two passes over tools/pmc_step.py; kernel sources {pmc['csrc_digest'][:12]} = this build)"
                 engine['traffic_source'] = src
 
-                def pmc_of(sym):       # 'p3_bwd_pair_nt_kernel<64,64,1w>' <-> rocprofv3's 'p3_bwd_pair_nt_kernel<64, 64, 1, true>': same name, same leading integers
+                def pmc_of(sym):
+                    """HBM bytes per launch of kernel symbol `sym` (bench label, e.g. 'p3_bwd_pair_nt_kernel<64,64,4w>' or 'gemm_f32_kernel<128,64,32,4w,FAST,SPLIT>') from
+                    rocprofv3's per-instantiation counters ('p3_bwd_pair_nt_kernel<64, 64, 1, true>', 'gemm_f32_kernel<128, 64, 32, 2, 6, 4, true, true>'): same kernel name, same
+                    tile (the leading two / three integers), same FAST / SPLIT flags where the label carries them; several operand-mode instantiations of one tile are summed."""
                     import re
-                    base, nums = sym.split('<')[0], re.findall(r'\d+', sym.split('<', 1)[1]) if '<' in sym else []
-                    hits = [v for k, v in pmc['by_kernel'].items() if k.split('<')[0] == base and re.findall(r'\d+', k.split('<', 1)[1] if '<' in k else '')[:len(nums)] == nums]
+                    base = sym.split('<')[0]
+                    args = sym.split('<', 1)[1].rstrip('>') if '<' in sym else ''
+                    nums = re.findall(r'\d+', args)[:3 if base == 'gemm_f32_kernel' else 2]
+                    flags = None
+                    if base == 'gemm_f32_kernel':
+                        flags = ['true' if 'FAST' in args else 'false', 'true' if 'SPLIT' in args else 'false']
+                    hits = []
+                    for k, v in pmc['by_kernel'].items():
+                        if k.split('<')[0] != base:
+                            continue
+                        kargs = [a.strip() for a in (k.split('<', 1)[1].rstrip('>').split(',') if '<' in k else [])]
+                        if [a for a in kargs if a.isdigit()][:len(nums)] != nums:
+                            continue
+                        if flags is not None and kargs[-2:] != flags:
+                            continue
+                        hits.append(v)
                     if not hits:
                         return None
                     return sum(h['fetch'] + h['write'] for h in hits) / max(sum(h['launches'] for h in hits), 1)
