@@ -636,6 +636,9 @@ def run(args, rank, local_rank, world):
                                workload=f'BASELINE configs[{2 if world == 1 else 3}]: global batch {args.batch} ({b_local} per GPU), {bg}x{bg} backgrounds x 9 elements, full G+D adversarial '
                                         'step (Gmain+Dmain fwd/bwd, grad exchange + nan_to_num, Adam, EMA), train mode (dropout 0.1); ' +
                                         ('hot-path-only: frozen-BERT text features are an input, LM-decoder loss excluded' if args.text_mode == 'features' else f'text path on: {args.text_mode}, element texts of {args.text_valid} tokens padded to {args.text_tokens} as the reference tokenizer does; ' + (f'all {args.text_tokens} positions evaluated' if args.text_padded else f'the batch-longest text ({text_eval[0]} positions) evaluated: same values, parity-tested')),
+                               parity_notes='values checked against oracle/ (pinned to the reference by tests/golden/*; the torchvision ResNet-50 body of the oracle is parity-UNPINNED: torchvision is '
+                                            'absent from the build container, SURVEY 8c); dropout (on in this timed step, as in the reference) is validated statistically only; D-trunk sharing is value-identical '
+                                            '(tests/test_model_gpu.py::test_iteration_level_D_trunk_sharing_matches_reference_call_pattern)',
                                global_batch=args.batch, per_gpu_batch=b_local, background=bg, elements=9,
                                parallelism=f'dp{world}', hip_graph=not args.no_graph, allreduce_overlapped_with_backward=(world > 1 and not args.no_graph and not args.no_overlap), text_mode=args.text_mode, text_tokens=(args.text_tokens if args.text_mode != 'features' else None), text_tokens_evaluated=text_eval[0], d_trunk_shared=False if args.no_share_trunk else args.share_trunk, params_G=n_params[0], params_D=n_params[1]),
                    roofline=roofline, cpu_baseline=cpu, **extra)

@@ -253,6 +253,40 @@ def test_collective_sequence_is_identical_on_every_rank(world):
     assert stage_counts == {2, 3}, f'the cases must exercise both cuts, got {stage_counts}'
 
 
+def test_regulariser_phase_shares_the_optimiser_state_and_partitions_the_flat_buffer():
+    """training_loop.Phase(share=main): the lazy regulariser phase of training_loop.py:190-197 uses the main phase's optimiser.  torch.optim.Adam skips
+    parameters whose .grad is None and counts steps per parameter, so after the first regulariser step the flat buffer has two groups of ranges with
+    different step counts: `touched_runs` finds the ranges (any non-zero gradient element), `step_ranges` partitions the buffer for either kind of step."""
+    from layoutdetr_amd.training import training_loop as tl
+    torch.manual_seed(0)
+    m = _TrunkLike()
+    main = tl.Phase('Dmain', m, lr=1e-3, betas=(0.0, 0.99), reg_interval=16)
+    reg = tl.Phase('Dreg', m, share=main, interval=16)
+    assert reg.fm is main.fm and reg.m is main.m and reg.v is main.v and reg.main is main and reg.interval == 16
+    assert abs(main.lr - 1e-3 * 16 / 17) < 1e-12 and reg.lr == main.lr and abs(main.betas[1] - 0.99 ** (16 / 17)) < 1e-12
+    fm = main.fm
+    assert main.step_ranges(False) == [(0, fm.total, 0)]
+    # a regulariser that reaches the token, layer2 and the head only
+    fm.zero_grad()
+    hit = [i for i, n in enumerate(fm.names) if n == 'token' or 'layer2' in n or n.startswith('head')]
+    for i in hit:
+        fm.gflat[fm.offsets[i]:fm.offsets[i] + fm.params[i].numel()] = 1.0
+    runs = main.touched_runs()
+    covered = torch.zeros(fm.total, dtype=torch.bool)
+    for lo, hi in runs:
+        assert 0 <= lo < hi <= fm.total
+        covered[lo:hi] = True
+    for i, (p, o) in enumerate(zip(fm.params, fm.offsets)):
+        assert bool(covered[o:o + p.numel()].all()) == (i in hit), fm.names[i]
+    assert runs == sorted(runs) and all(a[1] < b[0] for a, b in zip(runs, runs[1:])), 'adjacent parameters merge into one range'
+    main.reg_runs, main.step, main.reg_steps = runs, 5, 2
+    r = reg.step_ranges(True)
+    assert [(lo, hi) for lo, hi, _ in r] == runs and all(st == 7 for _, _, st in r)
+    mm = main.step_ranges(False)
+    assert mm[0][0] == 0 and mm[-1][1] == fm.total and all(a[1] == b[0] for a, b in zip(mm, mm[1:])), 'the main step covers the buffer exactly once'
+    assert {st for _, _, st in mm} == {5, 7} and [(lo, hi) for lo, hi, st in mm if st == 7] == runs
+
+
 def test_bench_preflight_refuses_more_local_ranks_than_gpus():
     """`bench.py --gpus N` under torch.distributed.run on a node that shows fewer GPUs than local ranks: ONE parsable line on rank 0, exit code 2,
     before any rendezvous (here: no GPU at all)."""
