@@ -267,3 +267,33 @@ def test_both_phases_equal_main_plus_regulariser(dev):
         errs = sorted(((rel(b[n], a[n]), n) for n in a), reverse=True)
         print(f'  [{names[2]}] vs {names[0]} + {names[1]}: worst {errs[0][0]:.2e} ({errs[0][1]}); run-to-run spread of the separate sequence {noise:.2e}')
         assert errs[0][0] <= max(2e-5, 3 * noise), f'{names[2]} differs from {names[0]} + {names[1]}: ' + ', '.join(f'{n} {e:.2e}' for e, n in errs[:6]) + f' (run-to-run spread {noise:.2e})'
+
+
+def test_training_loop_with_gamma_builds_and_runs_the_lazy_regulariser_phase(dev, tmp_path):
+    """`train.py --gamma=1` (train.py:227 -> loss_kwargs.r1_gamma) through training_loop(**c): the loop builds a 'Dreg' phase on D's optimiser (training_loop.py:190-197),
+    runs it every D_reg_interval-th iteration and reports Loss/r1_penalty / Loss/D/reg in the tick statistics; G and D stay finite and keep training."""
+    import importlib
+    from layoutdetr_amd import dropin
+    dropin.install()
+    try:
+        tl = importlib.import_module('training.training_loop')
+        from test_boundary_gpu import _write_vocab
+        net = dict(bert_f_dim=768, bert_num_heads=4, bert_num_encoder_layers=2, bert_num_decoder_layers=2, im_f_dim=512, text_mode='encoder', tokenizer_vocab=str(_write_vocab(tmp_path)))
+        out = tl.training_loop(
+            run_dir=str(tmp_path), training_set_kwargs=dict(class_name='test_boundary_gpu.SyntheticLayouts', n=8),
+            data_loader_kwargs=dict(num_workers=0), random_seed=0, num_gpus=1, rank=0, batch_size=2, batch_gpu=2,
+            G_kwargs=dict(class_name='training.networks_detr.Generator', z_dim=4, **net), D_kwargs=dict(class_name='training.networks_detr.Discriminator', **net),
+            G_opt_kwargs=dict(class_name='torch.optim.Adam', betas=[0, 0.99], eps=1e-8, lr=1e-5), D_opt_kwargs=dict(class_name='torch.optim.Adam', betas=[0, 0.99], eps=1e-8, lr=1e-5),
+            loss_kwargs=dict(class_name='training.loss.StyleGAN2Loss', r1_gamma=1.0, pl_weight=0.0), G_reg_interval=4, D_reg_interval=2,
+            ema_kimg=2 * 10 / 32, total_kimg=0.010, kimg_per_tick=0.004, network_snapshot_ticks=None)
+    finally:
+        dropin.uninstall()
+    assert out['stats']['cur_nimg'] == 10
+    seen = set()
+    for line in open(tmp_path / 'stats.jsonl'):
+        import json
+        seen |= set(json.loads(line))
+    assert 'Loss/r1_penalty' in seen and 'Loss/D/reg' in seen, sorted(seen)
+    assert 'Loss/pl_penalty' not in seen, 'pl_weight = 0: no Greg phase'
+    assert all(torch.isfinite(p).all() for p in out['D'].parameters()) and all(torch.isfinite(p).all() for p in out['G'].parameters())
+
