@@ -66,7 +66,7 @@ def main():
     for (name, where, shape), n in m.counts.items():
         agg[(name, where)] += n
     for (name, where), n in agg.most_common(140):
-        shapes = [f'{s}:{c}' for (nm, w, s), c in m.counts.items() if nm == name and w == where][:4]
+        shapes = [f"{s}:{c}" for (nm, w, s), c in m.counts.items() if nm == name and w == where][:12]
         print(f'{n:5d}  {name:42s} {where:60s} {" ".join(shapes)}')
 
 
